@@ -1,0 +1,133 @@
+"""Known-answer tests pinning the oracle's C restatement of the reference's CUDA index kernels.
+
+The CUDA sources cannot run here, so these cases are derived by hand from the documented kernel
+semantics (file:line in each test).  They are the pin for SURVEY section 8 rows a4/a5/a6/a16.
+"""
+import numpy as np
+import pytest
+
+from oracle import ops as O
+
+
+def _soa(pts):  # (n,3) -> (1,3,n)
+    return np.ascontiguousarray(np.asarray(pts, np.float32).T[None])
+
+
+def test_opt_n_threads():
+    # grouping_cuda_kernel.cu:29-33 : min(1024, 2^floor(log2 n))
+    assert [O.opt_n_threads(n) for n in (1, 2, 3, 19, 78, 312, 1250, 5000)] == [1, 2, 2, 16, 64, 256, 1024, 1024]
+
+
+def test_ball_query_first_in_index_order_and_strict_radius():
+    # grouping_cuda_kernel.cu:88-98: scan k ascending, keep d2 < r2 (strict), stop at nsample
+    sup = [[0, 0, 0], [0.05, 0, 0], [0.1, 0, 0], [0.02, 0, 0], [0.03, 0, 0]]
+    q = [[0, 0, 0]]
+    idx = O.ball_query(_soa(q), _soa(sup), 0.1, 3)
+    assert idx.tolist() == [[[0, 1, 3]]]          # k=2 is at d == r exactly -> excluded (strict <)
+    idx = O.ball_query(_soa(q), _soa(sup), 0.1, 4)
+    assert idx.tolist() == [[[0, 1, 3, 4]]]       # cnt == nsample: no padding
+
+
+def test_ball_query_padding_quirks():
+    # grouping_cuda_kernel.cu:100-104: pad cyclically with own prefix iff cnt < nsample-1;
+    # when cnt == nsample-1 the last slot keeps the zero init (grouping_cuda.cpp:80-82)
+    sup = [[1, 0, 0], [0, 0, 0], [0.01, 0, 0], [2, 0, 0], [0.02, 0, 0]]
+    q = [[0, 0, 0]]
+    assert O.ball_query(_soa(q), _soa(sup), 0.1, 8).tolist() == [[[1, 2, 4, 1, 2, 4, 1, 2]]]
+    assert O.ball_query(_soa(q), _soa(sup), 0.1, 4).tolist() == [[[1, 2, 4, 0]]]   # cnt == ns-1 -> slot stays 0
+    assert O.ball_query(_soa(q), _soa(sup), 0.1, 5).tolist() == [[[1, 2, 4, 1, 2]]]
+    # no neighbour at all (cnt == 0 < ns-1): loop copies zeros -> all zero
+    assert O.ball_query(_soa([[9, 9, 9]]), _soa(sup), 0.1, 4).tolist() == [[[0, 0, 0, 0]]]
+
+
+def test_ball_query_batch_independent():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((3, 3, 200)).astype(np.float32) * 0.2
+    q = x[:, :, :50].copy()
+    full = O.ball_query(q, x, 0.15, 16)
+    for b in range(3):
+        assert (full[b] == O.ball_query(q[b:b + 1], x[b:b + 1], 0.15, 16)[0]).all()
+    # every query is a support member -> its own index must be present
+    for b in range(3):
+        for j in range(50):
+            assert j in full[b, j]
+
+
+def test_fps_vgtk_basic_and_origin_skip():
+    # grouping_cuda_kernel.cu:374-399: start index 0; points with |p|^2 <= 1e-3 are never candidates
+    pts = [[1, 0, 0], [0.01, 0.01, 0], [-1, 0, 0], [0, 2, 0], [0, 0, 0], [0.5, 0, 0]]
+    idx = O.furthest_point_sampling(_soa(pts), 4)
+    assert idx.tolist() == [[0, 3, 2, 5]]  # d2(0,3)=5 > d2(0,2)=4; then 2 (4), then 5 (0.25)
+    # the near-origin points (1 and 4) can never be selected even when asked for all six
+    idx = O.furthest_point_sampling(_soa(pts), 6)
+    assert 1 not in idx[0, 1:].tolist() and 4 not in idx[0, 1:].tolist()
+
+
+def test_fps_vgtk_tie_rule_tree_equals_keyed():
+    # grouping_cuda_kernel.cu:340-346,394-395 + tree reduce :402-460.  Lattice data => massive ties.
+    rng = np.random.default_rng(3)
+    for n in (37, 64, 200, 1500, 2600):
+        pts = rng.integers(-3, 4, (2, n, 3)).astype(np.float32) * 0.25 + 0.125
+        x = np.ascontiguousarray(pts.transpose(0, 2, 1))
+        a = O.furthest_point_sampling(x, n // 2)
+        b = O.furthest_point_sampling(x, n // 2, keyed=True)
+        assert (a == b).all(), n
+
+
+def test_fps_vgtk_tie_prefers_bit_reversed_lane():
+    # 4 candidates all at the same distance from point 0; block size = 4 for n = 5 -> bs = 4.
+    # lanes: k mod 4; tree: (0 vs 2),(1 vs 3) then (0 vs 1) -> winner among ties has smallest bit-reversed lane.
+    pts = [[0.5, 0.5, 0.5], [1.5, 0.5, 0.5], [-0.5, 0.5, 0.5], [0.5, 1.5, 0.5], [0.5, -0.5, 0.5]]
+    idx = O.furthest_point_sampling(_soa(pts), 2)
+    # candidates k=1..4 tie (k=0 has d=0).  lanes: k=1->1, 2->2, 3->3, 4->0 (thread 0 holds k=0 and k=4: 4 wins in-thread since d2>best)
+    assert idx.tolist() == [[0, 4]]
+
+
+def test_gather_points():
+    pts = np.arange(2 * 3 * 5, dtype=np.float32).reshape(2, 3, 5)
+    idx = np.array([[4, 0, 0], [1, 1, 3]], np.int32)
+    out = O.gather_points_forward(pts, idx)
+    assert out.shape == (2, 3, 3)
+    for b in range(2):
+        for c in range(3):
+            assert out[b, c].tolist() == pts[b, c, idx[b]].tolist()
+
+
+def test_knn_sorted_self_first_and_segments():
+    # knnquery_cuda_kernel.cu:65-108: brute force inside the query's segment, ascending output
+    rng = np.random.default_rng(1)
+    p = rng.standard_normal((300, 3)).astype(np.float32)
+    o = np.array([120, 300], np.int32)
+    idx, d2 = O.knnquery(8, p, p, o, o)
+    assert (idx[:, 0] == np.arange(300)).all() and (d2[:, 0] == 0).all()
+    assert (np.diff(d2, axis=1) >= 0).all()
+    assert idx[:120].max() < 120 and idx[120:].min() >= 120
+    # against a float64 brute force (no exact ties in random data)
+    for i in (0, 119, 120, 299):
+        s, e = (0, 120) if i < 120 else (120, 300)
+        ref = np.argsort(((p[s:e].astype(np.float64) - p[i]) ** 2).sum(1))[:8] + s
+        assert idx[i].tolist() == ref.tolist()
+
+
+def test_knn_short_segment_and_ties():
+    # fewer points than nsample: unfilled slots keep (idx=start, d2=1e10) (knnquery_cuda_kernel.cu:88-91)
+    p = np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0], [5, 5, 5], [5, 5, 6]], np.float32)
+    o = np.array([3, 5], np.int32)
+    idx, d2 = O.knnquery(4, p, p, o, o)
+    assert idx[0].tolist() == [0, 1, 2, 0] and d2[0].tolist() == [0, 1, 4, np.float32(1e10)]
+    assert idx[3].tolist() == [3, 4, 3, 3] and d2[4, 2] == np.float32(1e10)
+    # exact tie on membership: strict '<' keeps the EARLIER index (:97)
+    p = np.array([[0, 0, 0], [1, 0, 0], [-1, 0, 0], [0, 1, 0]], np.float32)
+    o = np.array([4], np.int32)
+    idx, _ = O.knnquery(2, p, p[:1], o, np.array([1], np.int32))
+    assert idx.tolist() == [[0, 1]]
+
+
+def test_fps_pointops_segments():
+    # sampling_cuda_kernel.cu:22-39: first index = segment start, no origin skip
+    p = np.array([[0, 0, 0], [1, 0, 0], [0.2, 0, 0], [3, 0, 0], [10, 0, 0], [10, 1, 0], [10, 5, 0]], np.float32)
+    o = np.array([4, 7], np.int32)
+    no = np.array([2, 4], np.int32)
+    assert O.furthestsampling(p, o, no).tolist() == [0, 3, 4, 6]
+    no = np.array([3, 6], np.int32)
+    assert O.furthestsampling(p, o, no).tolist() == [0, 3, 1, 4, 6, 5]
