@@ -1,0 +1,41 @@
+"""ctypes loader of libetch_hip.so.  The product path has NO fallback: if the HIP library is
+missing or a symbol is absent this raises, loudly."""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libetch_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "etch_hip.h")
+_lib = None
+
+
+class EtchHipError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    """Every function declared in include/etch_hip.h."""
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(etch_\w+)\s*\(", txt)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EtchHipError(
+                f"{LIB_PATH} is missing: build it with `python -m etch_amd.build` (hipcc, gfx950). "
+                "etch_amd has no CPU fallback.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name in declared_symbols():
+            fn = getattr(_lib, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = ctypes.c_int
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        kind = {-1: "invalid argument", -2: "unsupported size"}.get(status, f"hipError {status}")
+        raise EtchHipError(f"{what} failed: {kind}")

@@ -1,0 +1,48 @@
+// Shared helpers for the gfx950 kernels of etch_amd.  MI355X only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ETCH_WAVE 64
+
+#define ETCH_RETURN_IF_LAUNCH_FAILED()            \
+    do {                                          \
+        hipError_t e__ = hipGetLastError();       \
+        if (e__ != hipSuccess) return (int)e__;   \
+    } while (0)
+
+// status codes returned by every C-ABI entry point (0 = ok, >0 = hipError_t, <0 = argument error)
+#define ETCH_OK 0
+#define ETCH_EINVAL (-1)
+#define ETCH_EUNSUPPORTED (-2)
+
+// "bit-defined fp32" squared distance: ((dx*dx)+(dy*dy))+(dz*dz), every op rounded, NO fma.
+// Same contract as oracle/discrete_ops.c:sqdist.  The TU is also built with -ffp-contract=off.
+__device__ __forceinline__ float etch_sqdist(float ax, float ay, float az, float bx, float by, float bz) {
+#pragma clang fp contract(off)
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    float s = xx + yy;
+    return s + zz;
+}
+
+__device__ __forceinline__ unsigned long long etch_wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        unsigned long long o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ float etch_wave_sum_f32(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float etch_wave_max_f32(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}

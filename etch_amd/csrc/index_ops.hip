@@ -1,0 +1,313 @@
+// Index kernels of the ETCH hot path for gfx950.
+// Replaces, behind the same semantics:
+//   ball_query_cuda_kernel               /root/reference/external/vgtk/vgtk/cuda/grouping_cuda_kernel.cu:68-113
+//   furthest_point_sampling_cuda_kernel  .../grouping_cuda_kernel.cu:352-466
+//   gather_points_forward_kernel         .../gathering_cuda_kernel.cu:43-68
+//   knnquery_cuda_kernel                 /root/reference/external/pointops/src/knnquery/knnquery_cuda_kernel.cu:65-108
+//   furthestsampling_cuda_kernel         /root/reference/external/pointops/src/sampling/sampling_cuda_kernel.cu:15-129
+// Results are bit-identical to oracle/discrete_ops.c (integer outputs equal, distances equal).
+// Built with -ffp-contract=off: distance arithmetic is "bit-defined fp32" (common.h).
+#include "common.h"
+#include <cmath>
+
+// ------------------------------------------------------------------------------------ ball query
+// One WAVE per query: the 64 lanes test 64 consecutive support points per step (coalesced SoA
+// loads), a ballot gives the in-ball set in index order, so "first nsample in index order" is
+// exact and the early exit is per query.  The row is staged in LDS so the reference's padding
+// rule (cyclic prefix when cnt < nsample-1, zero slot when cnt == nsample-1) is applied once and
+// the row is written with one coalesced store.
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) ball_query_kernel(int n, int m, float radius2, int nsample,
+                                                               const float* __restrict__ new_xyz,
+                                                               const float* __restrict__ xyz, int* __restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) int smem_i[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const float* X = xyz + (size_t)b * 3 * n;
+    const float* Q = new_xyz + (size_t)b * 3 * m;
+    int* row = smem_i + wave * nsample;
+    for (int j = blockIdx.x * WAVES + wave; j < m; j += gridDim.x * WAVES) {
+        const float qx = Q[j], qy = Q[m + j], qz = Q[2 * m + j];
+        int cnt = 0;
+        for (int k0 = 0; k0 < n && cnt < nsample; k0 += 64) {
+            const int k = k0 + lane;
+            bool in = false;
+            if (k < n) {
+                float d2 = etch_sqdist(qx, qy, qz, X[k], X[n + k], X[2 * n + k]);
+                in = d2 < radius2;
+            }
+            const unsigned long long mask = __ballot(in);
+            const int before = __popcll(mask & ((1ull << lane) - 1ull));
+            if (in && cnt + before < nsample) row[cnt + before] = k;
+            cnt += __popcll(mask);
+        }
+        if (cnt > nsample) cnt = nsample;
+        __builtin_amdgcn_wave_barrier();
+        int* out = idx + ((size_t)b * m + j) * nsample;
+        for (int t = lane; t < nsample; t += 64) {
+            int v;
+            if (t < cnt) v = row[t];
+            else if (cnt < nsample - 1 && cnt > 0) v = row[t % cnt];
+            else v = 0;
+            out[t] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------ FPS
+// One workgroup per scan / segment, distances and validity live in registers (PPT points per
+// thread), one 64-bit max-reduction per round:
+//   key = (bits(d2) << 32) | (0xFFFFFFFF - tie),  tie = (bitrev(k_local mod bs) << 16) | (k_local / bs)
+// which reproduces the reference's per-thread strict '>' scan + LDS tree reduce tie-breaking
+// exactly (proved against the literal emulation in tests/test_oracle_ops.py).
+// Addressing: coordinate c of local point k is src[c * cs + k * ps].
+template <int THREADS, int PPT, bool REGS>
+__global__ void __launch_bounds__(THREADS) fps_kernel(const float* __restrict__ xyz, long cs, long ps,
+                                                      long batch_stride, int n_fixed, int m_fixed,
+                                                      const int* __restrict__ offset, const int* __restrict__ new_offset,
+                                                      int bs, int bs_bits, int skip_origin, int* __restrict__ idx) {
+    __shared__ unsigned long long red[THREADS / 64];
+    __shared__ int winner;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seg = blockIdx.x;
+    int start_n, n, start_m, m;
+    const float* src;
+    if (offset == nullptr) {                 // vgtk flavour: dense (b,3,n) batches, local indices
+        start_n = 0; n = n_fixed; start_m = seg * m_fixed; m = m_fixed;
+        src = xyz + (size_t)seg * batch_stride;
+    } else {                                 // pointops flavour: packed (n,3) with cumulative offsets, global indices
+        start_n = seg == 0 ? 0 : offset[seg - 1];
+        n = offset[seg] - start_n;
+        start_m = seg == 0 ? 0 : new_offset[seg - 1];
+        m = new_offset[seg] - start_m;
+        src = xyz + (size_t)start_n * ps;
+    }
+    // REGS: coordinates cached in registers (small PPT); otherwise re-read (coalesced, L2-resident) every round.
+    float px[REGS ? PPT : 1], py[REGS ? PPT : 1], pz[REGS ? PPT : 1];
+    float temp[PPT];
+    unsigned valid = 0u;                     // bit i: point tid + i*THREADS is a candidate
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int k = tid + i * THREADS;
+        temp[i] = 1e10f;
+        if (REGS) px[i] = py[i] = pz[i] = 0.f;
+        if (k < n) {
+            const float x = src[k * ps], y = src[cs + k * ps], z = src[2 * cs + k * ps];
+            if (REGS) { px[i] = x; py[i] = y; pz[i] = z; }
+            bool ok = true;
+            if (skip_origin) {
+#pragma clang fp contract(off)
+                float mag = ((x * x) + (y * y)) + (z * z);
+                ok = !((double)mag <= 1e-3);
+            }
+            if (ok) valid |= 1u << i;
+        }
+    }
+    if (tid == 0 && m > 0) idx[start_m] = start_n;
+    int old = 0;  // local index of the last selected point
+    for (int j = 1; j < m; ++j) {
+        const float x1 = src[old * ps], y1 = src[cs + old * ps], z1 = src[2 * cs + old * ps];
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            if (valid & (1u << i)) {
+                const int k = tid + i * THREADS;
+                float x, y, z;
+                if (REGS) { x = px[i]; y = py[i]; z = pz[i]; }
+                else { x = src[k * ps]; y = src[cs + k * ps]; z = src[2 * cs + k * ps]; }
+                float d = etch_sqdist(x, y, z, x1, y1, z1);
+                float d2 = d < temp[i] ? d : temp[i];
+                temp[i] = d2;
+                const unsigned kl = (unsigned)k & (unsigned)(bs - 1);
+                const unsigned rev = bs_bits ? (__brev(kl) >> (32 - bs_bits)) : 0u;
+                const unsigned tie = 0xFFFFFFFFu - ((rev << 16) | ((unsigned)k / (unsigned)bs));
+                unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | tie;
+                best = key > best ? key : best;
+            }
+        }
+        best = etch_wave_max_u64(best);
+        if (lane == 0) red[wave] = best;
+        __syncthreads();
+        if (wave == 0) {
+            unsigned long long v = lane < THREADS / 64 ? red[lane] : 0ull;
+            v = etch_wave_max_u64(v);
+            if (lane == 0) {
+                int w = 0;  // no candidate at all -> local index 0 (reference: besti default)
+                if (v != 0ull) {
+                    const unsigned t = 0xFFFFFFFFu - (unsigned)(v & 0xFFFFFFFFull);
+                    const unsigned rev = t >> 16, hi = t & 0xFFFFu;
+                    const unsigned kl = bs_bits ? (__brev(rev) >> (32 - bs_bits)) : 0u;
+                    w = (int)(hi * (unsigned)bs + kl);
+                }
+                winner = w;
+                idx[start_m + j] = start_n + w;
+            }
+        }
+        __syncthreads();
+        old = winner;
+    }
+}
+
+// ------------------------------------------------------------------------------------ gather
+// out[b,c,j] = points[b,c,idx[b,j]]   (b,c,n) x (b,m) -> (b,c,m); one thread per (j), loop over c.
+__global__ void __launch_bounds__(256) gather_points_kernel(int c, int n, int m, const float* __restrict__ points,
+                                                            const int* __restrict__ idx, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x) {
+        const int a = idx[(size_t)b * m + j];
+        for (int ci = 0; ci < c; ++ci) out[((size_t)b * c + ci) * m + j] = points[((size_t)b * c + ci) * n + a];
+    }
+}
+
+// ------------------------------------------------------------------------------------ kNN
+// One thread per query, support points of the query's segment streamed through LDS tiles
+// (coalesced AoS loads -> SoA LDS, broadcast reads).  The k-slot max-heap of the reference is
+// emulated literally (same strict '<' insert, same reheap / heap_sort) in LDS columns
+// [slot][thread] so that even the order among exactly tied distances is identical.
+#define KNN_THREADS 256
+#define KNN_TILE 512
+__device__ __forceinline__ void knn_reheap(float* hd, int* hi, int k) {
+    int root = 0, child = 1;
+    while (child < k) {
+        if (child + 1 < k && hd[(child + 1) * KNN_THREADS] > hd[child * KNN_THREADS]) child++;
+        if (hd[root * KNN_THREADS] > hd[child * KNN_THREADS]) return;
+        float tf = hd[root * KNN_THREADS]; hd[root * KNN_THREADS] = hd[child * KNN_THREADS]; hd[child * KNN_THREADS] = tf;
+        int ti = hi[root * KNN_THREADS]; hi[root * KNN_THREADS] = hi[child * KNN_THREADS]; hi[child * KNN_THREADS] = ti;
+        root = child; child = root * 2 + 1;
+    }
+}
+
+__global__ void __launch_bounds__(KNN_THREADS) knn_kernel(int nsample, const float* __restrict__ xyz,
+                                                          const float* __restrict__ new_xyz, const int* __restrict__ offset,
+                                                          const int* __restrict__ new_offset, int* __restrict__ idx,
+                                                          float* __restrict__ dist2, int write_sqrt) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float* tx = smem_f;                      // [KNN_TILE]
+    float* ty = tx + KNN_TILE;
+    float* tz = ty + KNN_TILE;
+    float* hd = tz + KNN_TILE + threadIdx.x; // heap distances, column of this thread: hd[slot * KNN_THREADS]
+    int* hi = (int*)(tz + KNN_TILE + nsample * KNN_THREADS) + threadIdx.x;
+    const int seg = blockIdx.y;
+    const int start = seg == 0 ? 0 : offset[seg - 1], end = offset[seg];
+    const int qs = seg == 0 ? 0 : new_offset[seg - 1], qe = new_offset[seg];
+    const int q = qs + blockIdx.x * KNN_THREADS + threadIdx.x;
+    if (qs + blockIdx.x * KNN_THREADS >= qe) return;  // whole block idle (uniform)
+    const bool active = q < qe;
+    float qx = 0, qy = 0, qz = 0;
+    if (active) { qx = new_xyz[q * 3]; qy = new_xyz[q * 3 + 1]; qz = new_xyz[q * 3 + 2]; }
+    for (int i = 0; i < nsample; ++i) { hd[i * KNN_THREADS] = 1e10f; hi[i * KNN_THREADS] = start; }
+    float top = 1e10f;
+    for (int t0 = start; t0 < end; t0 += KNN_TILE) {
+        const int cnt = min(KNN_TILE, end - t0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt * 3; e += KNN_THREADS) {
+            const float v = xyz[(size_t)t0 * 3 + e];
+            const int pnt = e / 3, c = e - pnt * 3;
+            (c == 0 ? tx : (c == 1 ? ty : tz))[pnt] = v;
+        }
+        __syncthreads();
+        if (active) {
+            for (int i = 0; i < cnt; ++i) {
+                const float d2 = etch_sqdist(qx, qy, qz, tx[i], ty[i], tz[i]);
+                if (d2 < top) {
+                    hd[0] = d2; hi[0] = t0 + i;
+                    knn_reheap(hd, hi, nsample);
+                    top = hd[0];
+                }
+            }
+        }
+    }
+    if (active) {
+        for (int i = nsample - 1; i > 0; i--) {  // heap_sort
+            float tf = hd[0]; hd[0] = hd[i * KNN_THREADS]; hd[i * KNN_THREADS] = tf;
+            int ti = hi[0]; hi[0] = hi[i * KNN_THREADS]; hi[i * KNN_THREADS] = ti;
+            knn_reheap(hd, hi, i);
+        }
+        for (int i = 0; i < nsample; ++i) {
+            idx[(size_t)q * nsample + i] = hi[i * KNN_THREADS];
+            const float d = hd[i * KNN_THREADS];
+            dist2[(size_t)q * nsample + i] = write_sqrt ? sqrtf(d) : d;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ C ABI
+static inline int ilog2_floor_host(int v) { int b = 0; while ((1 << (b + 1)) <= v) ++b; return b; }
+
+// opt_n_threads(): min(1024, 2^floor(log2 n)) computed like the reference host code (double log ratio)
+static int opt_n_threads_host(int work_size) {
+    const int pow_2 = (int)(std::log((double)work_size) / std::log(2.0));
+    int v = 1 << pow_2;
+    if (v > 1024) v = 1024;
+    if (v < 1) v = 1;
+    return v;
+}
+
+static int launch_fps(int nseg, int n_max, const float* xyz, long cs, long ps, long bstride, int n_fixed, int m_fixed,
+                      const int* offset, const int* new_offset, int skip_origin, int* idx, hipStream_t st) {
+    const int bs = opt_n_threads_host(n_max);
+    const int bits = ilog2_floor_host(bs);
+#define FPS_CASE(T, P, R)                                                                                              \
+    if (n_max <= T * P) {                                                                                              \
+        hipLaunchKernelGGL((fps_kernel<T, P, R>), dim3(nseg), dim3(T), 0, st, xyz, cs, ps, bstride, n_fixed, m_fixed,  \
+                           offset, new_offset, bs, bits, skip_origin, idx);                                            \
+        ETCH_RETURN_IF_LAUNCH_FAILED();                                                                                \
+        return ETCH_OK;                                                                                                \
+    }
+    FPS_CASE(64, 1, true) FPS_CASE(64, 4, true) FPS_CASE(256, 2, true) FPS_CASE(256, 8, true)
+    FPS_CASE(1024, 4, true) FPS_CASE(1024, 8, true) FPS_CASE(1024, 16, false) FPS_CASE(1024, 32, false)
+#undef FPS_CASE
+    return ETCH_EUNSUPPORTED;  // more than 32768 points per segment
+}
+
+extern "C" {
+
+int etch_ball_query(int b, int n, int m, float radius, int nsample, const float* new_xyz, const float* xyz, int* idx,
+                    void* stream) {
+    if (b <= 0 || m <= 0) return ETCH_OK;
+    if (n <= 0 || nsample <= 0 || nsample > 4096) return ETCH_EINVAL;
+    constexpr int WAVES = 4;
+    const float r2 = radius * radius;
+    int gx = (m + WAVES - 1) / WAVES;
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL((ball_query_kernel<WAVES>), dim3(gx, b), dim3(WAVES * 64), WAVES * nsample * sizeof(int),
+                       (hipStream_t)stream, n, m, r2, nsample, new_xyz, xyz, idx);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_furthest_point_sampling(int b, int n, int m, const float* xyz, int* idx, void* stream) {
+    if (b <= 0 || m <= 0) return ETCH_OK;
+    if (n <= 0) return ETCH_EINVAL;
+    return launch_fps(b, n, xyz, (long)n, 1, (long)3 * n, n, m, nullptr, nullptr, 1, idx, (hipStream_t)stream);
+}
+
+int etch_furthestsampling(int b, int n_max, const float* xyz, const int* offset, const int* new_offset, int* idx,
+                          void* stream) {
+    if (b <= 0) return ETCH_OK;
+    if (n_max <= 0) return ETCH_EINVAL;
+    return launch_fps(b, n_max, xyz, 1, 3, 0, 0, 0, offset, new_offset, 0, idx, (hipStream_t)stream);
+}
+
+int etch_gather_points(int b, int c, int n, int m, const float* points, const int* idx, float* out, void* stream) {
+    if (b <= 0 || m <= 0 || c <= 0) return ETCH_OK;
+    int gx = (m + 255) / 256;
+    if (gx > 8192) gx = 8192;
+    hipLaunchKernelGGL(gather_points_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream, c, n, m, points, idx, out);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_knnquery(int b, int m_max, int nsample, const float* xyz, const float* new_xyz, const int* offset,
+                  const int* new_offset, int* idx, float* dist, int write_sqrt, void* stream) {
+    if (b <= 0 || m_max <= 0) return ETCH_OK;
+    if (nsample <= 0 || nsample > 28) return ETCH_EUNSUPPORTED;  // heap columns must fit 64 KiB of LDS
+    const size_t lds = (size_t)(3 * KNN_TILE + 2 * nsample * KNN_THREADS) * 4;
+    hipLaunchKernelGGL(knn_kernel, dim3((m_max + KNN_THREADS - 1) / KNN_THREADS, b), dim3(KNN_THREADS), lds,
+                       (hipStream_t)stream, nsample, xyz, new_xyz, offset, new_offset, idx, dist, write_sqrt);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+}  // extern "C"

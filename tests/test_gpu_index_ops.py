@@ -1,0 +1,131 @@
+"""GPU parity of the index kernels against the oracle: bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+
+def scan(seed, n, sigma=(0.14, 0.31, 0.085)):
+    return (np.random.default_rng(seed).standard_normal((n, 3)) * np.array(sigma)).astype(np.float32)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("n,m,sigma", [(5000, 2500, (0.14, 0.31, 0.085)), (5000, 2500, (0.20, 0.45, 0.12)), (1024, 512, (0.14, 0.31, 0.085)),
+                                       (160, 80, (0.14, 0.31, 0.085)), (37, 20, (0.5, 0.5, 0.5)), (9000, 300, (0.14, 0.31, 0.085)),
+                                       (20000, 200, (0.14, 0.31, 0.085))])
+def test_fps_vgtk(n, m, sigma):
+    from etch_amd import ops
+    x = np.stack([scan(1000 + b, n, sigma).T for b in range(3)])
+    got = ops.furthest_point_sampling(dev(x), m).cpu().numpy()
+    assert np.array_equal(got, O.furthest_point_sampling(x, m))
+
+
+def test_fps_vgtk_ties_and_origin_skip():
+    from etch_amd import ops
+    rng = np.random.default_rng(3)
+    for n in (37, 64, 200, 1500, 2600, 4100):
+        pts = rng.integers(-3, 4, (2, n, 3)).astype(np.float32) * 0.25 + 0.125
+        pts[:, 5] = 0.0      # origin point: never a candidate
+        pts[:, 7] = 0.01
+        x = np.ascontiguousarray(pts.transpose(0, 2, 1))
+        got = ops.furthest_point_sampling(dev(x), n // 2).cpu().numpy()
+        assert np.array_equal(got, O.furthest_point_sampling(x, n // 2)), n
+
+
+@pytest.mark.parametrize("n,m,r,ns", [(5000, 2500, 0.08, 64), (2500, 2500, 0.11313708498984763, 32), (2500, 1250, 0.16, 64),
+                                      (1250, 1250, 0.16, 32), (300, 100, 0.05, 16), (70, 70, 10.0, 8), (5000, 64, 0.4, 100)])
+def test_ball_query(n, m, r, ns):
+    from etch_amd import ops
+    for sigma in ((0.14, 0.31, 0.085), (0.20, 0.45, 0.12)):
+        x = np.stack([scan(2000 + b, n, sigma).T for b in range(2)])
+        q = np.ascontiguousarray(x[:, :, :m])
+        got = ops.ball_query(dev(q), dev(x), r, ns).cpu().numpy()
+        assert np.array_equal(got, O.ball_query(q, x, r, ns))
+
+
+def test_ball_query_known_answers():
+    from etch_amd import ops
+    sup = np.array([[1, 0, 0], [0, 0, 0], [0.01, 0, 0], [2, 0, 0], [0.02, 0, 0]], np.float32).T[None]
+    q = np.array([[0, 0, 0], [9, 9, 9]], np.float32).T[None]
+    f = lambda ns: ops.ball_query(dev(q), dev(sup), 0.1, ns).cpu().numpy().tolist()
+    assert f(8) == [[[1, 2, 4, 1, 2, 4, 1, 2], [0] * 8]]
+    assert f(4) == [[[1, 2, 4, 0], [0] * 4]]
+    assert f(3) == [[[1, 2, 4], [0] * 3]]
+
+
+def test_gather_points():
+    from etch_amd import ops
+    rng = np.random.default_rng(0)
+    pts = rng.standard_normal((3, 3, 5001)).astype(np.float32)
+    idx = rng.integers(0, 5001, (3, 160000)).astype(np.int32)
+    got = ops.gather_points_forward(dev(pts), dev(idx)).cpu().numpy()
+    assert np.array_equal(got, O.gather_points_forward(pts, idx))
+
+
+@pytest.mark.parametrize("k,segs,qsegs", [(8, [5000, 5000], None), (16, [1250, 1250, 1250], [312, 312, 312]), (16, [312, 300], None),
+                                          (16, [19, 19], None), (3, [1250, 1250], [5000, 5000]), (3, [19, 19], [78, 78]), (16, [78], [19]),
+                                          (16, [5, 40], None)])
+def test_knn(k, segs, qsegs):
+    from etch_amd import ops
+    p = np.concatenate([scan(3000 + i, n) for i, n in enumerate(segs)])
+    o = np.cumsum(segs).astype(np.int32)
+    if qsegs is None:
+        q, qo = p, o
+    else:
+        q = np.concatenate([scan(4000 + i, n) for i, n in enumerate(qsegs)])
+        qo = np.cumsum(qsegs).astype(np.int32)
+    idx, dist = ops.knnquery(k, dev(p), dev(q), dev(o), dev(qo))
+    ri, rd2 = O.knnquery(k, p, q, o, qo)
+    assert np.array_equal(idx.cpu().numpy(), ri)
+    assert np.array_equal(dist.cpu().numpy(), np.sqrt(rd2))
+
+
+def test_knn_exact_ties_follow_heap_order():
+    from etch_amd import ops
+    rng = np.random.default_rng(5)
+    p = (rng.integers(-2, 3, (400, 3)).astype(np.float32)) * 0.5   # lattice: many exactly tied distances + duplicates
+    o = np.array([150, 400], np.int32)
+    for k in (3, 8, 16):
+        idx, dist = ops.knnquery(k, dev(p), dev(p), dev(o), dev(o), sqrt=False)
+        ri, rd2 = O.knnquery(k, p, p, o, o)
+        assert np.array_equal(idx.cpu().numpy(), ri), k
+        assert np.array_equal(dist.cpu().numpy(), rd2), k
+
+
+@pytest.mark.parametrize("segs,stride", [([5000, 5000, 5000], 4), ([1250, 1250], 4), ([312, 312], 4), ([78, 78, 78], 4), ([19, 19], 4),
+                                         ([150, 90], 4), ([4999, 130, 2047], 3)])
+def test_fps_pointops(segs, stride):
+    from etch_amd import ops
+    p = np.concatenate([scan(5000 + i, n) for i, n in enumerate(segs)])
+    o = np.cumsum(segs).astype(np.int32)
+    no = np.cumsum([n // stride for n in segs]).astype(np.int32)
+    got = ops.furthestsampling(dev(p), dev(o), dev(no)).cpu().numpy()
+    assert np.array_equal(got, O.furthestsampling(p, o, no))
+
+
+def test_pybind_module_mirrors():
+    """Same call conventions as the reference's pybind modules (caller-allocated outputs for pointops)."""
+    from etch_amd import epn_gathering, epn_grouping, pointops_cuda
+    x = np.stack([scan(1, 600).T])
+    xt = dev(x)
+    i = epn_grouping.furthest_point_sampling(xt, 300)
+    q = epn_gathering.gather_points_forward(xt, i)
+    bq = epn_grouping.ball_query(q, xt, 0.1, 16)
+    assert np.array_equal(bq.cpu().numpy(), O.ball_query(q.cpu().numpy(), x, 0.1, 16))
+    p = dev(scan(2, 500))
+    o = torch.tensor([200, 500], dtype=torch.int32).cuda()
+    idx = torch.zeros(500, 8, dtype=torch.int32).cuda()
+    d2 = torch.zeros(500, 8).cuda()
+    pointops_cuda.knnquery_cuda(500, 8, p, p, o, o, idx, d2)
+    ri, rd = O.knnquery(8, p.cpu().numpy(), p.cpu().numpy(), o.cpu().numpy(), o.cpu().numpy())
+    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(d2.cpu().numpy(), rd)
+    no = torch.tensor([50, 125], dtype=torch.int32).cuda()
+    out = torch.zeros(125, dtype=torch.int32).cuda()
+    pointops_cuda.furthestsampling_cuda(2, 300, p, o, no, torch.empty(500).cuda(), out)
+    assert np.array_equal(out.cpu().numpy(), O.furthestsampling(p.cpu().numpy(), o.cpu().numpy(), no.cpu().numpy()))
