@@ -1,0 +1,159 @@
+// Generic fp32 NT GEMM with fused epilogue on the gfx950 matrix cores (v_mfma_f32_16x16x4_f32):
+//     Y[r, o] = epi( sum_k X[rowmap(r), k] * W[o, k] )        r < R, o < O, k < K
+// Serves every dense per-point layer of the hot path (SURVEY 8 rows a9 skip conv, a13 linears,
+// a15 linears / heads): torch.nn.Linear / Conv1d(k=1) / Conv2d(1x1) with eval-mode BatchNorm folded
+// into (scale, shift).  fp32 inputs, fp32 accumulate: the f32 MFMA is an exact fmaf chain.
+//
+// Tiling: 256 threads = 4 waves, block tile 64 rows x 64 outputs, K step 32 staged through LDS
+// with 16-byte loads; each wave owns a 32x32 sub-tile (2x2 MFMA tiles).  K is consumed in an
+// interleaved order (lane group g = lane>>4 takes k = 16t + 4g + s in MFMA step s) so that one
+// ds_read_b128 per operand feeds four MFMAs; A and B use the same order, so the sum is unchanged.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct GemmArgs {
+    int R, K, O;
+    const float* X; long ldx; const int* row_idx; int grp, p_in, p_out;
+    const float* W; long ldw;
+    const float* bias; const float* scale; const float* shift;
+    int act;            // 0 none, 1 relu, 2 leaky_relu(0.01)
+    const float* res; long ldr; int res_mode;   // 0 none, 1 add before act, 2 add after act
+    float* Y; long ldy;
+};
+
+#define G_BM 64
+#define G_BN 64
+#define G_BK 32
+#define G_LD 36   // padded LDS row (floats); 144 B keeps 16-B alignment
+
+template <bool VEC>
+__device__ __forceinline__ float4 ld4_guard(const float* row, int k, int K, bool row_ok) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (VEC) {
+        if (row_ok && k < K) v = *reinterpret_cast<const float4*>(row + k);   // K % 4 == 0, 16-B aligned rows
+    } else if (row_ok) {
+        if (k < K) v.x = row[k];
+        if (k + 1 < K) v.y = row[k + 1];
+        if (k + 2 < K) v.z = row[k + 2];
+        if (k + 3 < K) v.w = row[k + 3];
+    }
+    return v;
+}
+
+template <bool VECX, bool VECW>
+__global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float Xs[G_BM * G_LD];
+    __shared__ __attribute__((aligned(16))) float Ws[G_BN * G_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * G_BM, o0 = blockIdx.y * G_BN;
+    const int wm = wave >> 1, wn = wave & 1;
+    // staging coordinates: thread -> (row = tid/8 [+32], float4 column = tid%8)
+    const int srow = tid >> 3, sc4 = (tid & 7) * 4;
+    const float* xrow[2];
+    bool xok[2];
+    const float* wrow[2];
+    bool wok[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = r0 + srow + 32 * h;
+        xok[h] = r < a.R;
+        long src = 0;
+        if (xok[h]) {
+            src = r;
+            if (a.row_idx) {
+                const int q = r / a.grp;
+                src = ((long)(q / a.p_out) * a.p_in + a.row_idx[q]) * a.grp + (r - q * a.grp);
+            }
+        }
+        xrow[h] = a.X + src * a.ldx;
+        const int o = o0 + srow + 32 * h;
+        wok[h] = o < a.O;
+        wrow[h] = a.W + (long)(wok[h] ? o : 0) * a.ldw;
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int k0 = 0; k0 < a.K; k0 += G_BK) {
+        float4 xv[2], wv[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            xv[h] = ld4_guard<VECX>(xrow[h], k0 + sc4, a.K, xok[h]);
+            wv[h] = ld4_guard<VECW>(wrow[h], k0 + sc4, a.K, wok[h]);
+        }
+        __syncthreads();   // previous tile fully consumed
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<float4*>(&Xs[(srow + 32 * h) * G_LD + sc4]) = xv[h];
+            *reinterpret_cast<float4*>(&Ws[(srow + 32 * h) * G_LD + sc4]) = wv[h];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float4 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *reinterpret_cast<const float4*>(&Xs[(wm * 32 + i * 16 + fr) * G_LD + t * 16 + fg * 4]);
+                bf[i] = *reinterpret_cast<const float4*>(&Ws[(wn * 32 + i * 16 + fr) * G_LD + t * 16 + fg * 4]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    // epilogue: D[row = fg*4 + reg][col = fr]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int o = o0 + wn * 32 + j * 16 + fr;
+        if (o >= a.O) continue;
+        const float bs = a.bias ? a.bias[o] : 0.f;
+        const float sc = a.scale ? a.scale[o] : 1.f;
+        const float sh = a.shift ? a.shift[o] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + wm * 32 + i * 16 + fg * 4 + q;
+                if (r >= a.R) continue;
+                float v = acc[i][j][q] + bs;
+                if (a.scale) v = v * sc + sh;
+                if (a.res_mode == 1) v += a.res[(long)r * a.ldr + o];
+                if (a.act == 1) v = fmaxf(v, 0.f);
+                else if (a.act == 2) v = v > 0.f ? v : 0.01f * v;
+                if (a.res_mode == 2) v += a.res[(long)r * a.ldr + o];
+                a.Y[(long)r * a.ldy + o] = v;
+            }
+    }
+}
+
+extern "C" int etch_linear(int R, int K, int O, const float* X, long ldx, const int* row_idx, int grp, int p_in, int p_out,
+                           const float* W, long ldw, const float* bias, const float* scale, const float* shift, int act,
+                           const float* res, long ldr, int res_mode, float* Y, long ldy, void* stream) {
+    if (R <= 0 || O <= 0) return ETCH_OK;
+    if (K <= 0) return ETCH_EINVAL;
+    if ((scale == nullptr) != (shift == nullptr)) return ETCH_EINVAL;
+    if (res_mode != 0 && res == nullptr) return ETCH_EINVAL;
+    if (row_idx && (grp <= 0 || p_out <= 0)) return ETCH_EINVAL;
+    GemmArgs a{R, K, O, X, ldx, row_idx, grp, p_in, p_out, W, ldw, bias, scale, shift, act, res, ldr, res_mode, Y, ldy};
+    dim3 grid((R + G_BM - 1) / G_BM, (O + G_BN - 1) / G_BN);
+    if (grid.y > 65535) return ETCH_EUNSUPPORTED;
+    const bool vx = !(K & 3) && !(ldx & 3) && !((uintptr_t)X & 15);
+    const bool vw = !(K & 3) && !(ldw & 3) && !((uintptr_t)W & 15);
+    hipStream_t st = (hipStream_t)stream;
+    if (vx && vw) hipLaunchKernelGGL((gemm_nt_kernel<true, true>), grid, dim3(256), 0, st, a);
+    else if (vx) hipLaunchKernelGGL((gemm_nt_kernel<true, false>), grid, dim3(256), 0, st, a);
+    else if (vw) hipLaunchKernelGGL((gemm_nt_kernel<false, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<false, false>), grid, dim3(256), 0, st, a);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}

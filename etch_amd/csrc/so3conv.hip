@@ -1,0 +1,439 @@
+// Fused SO(3)-equivariant point convolutions of the EPN encoder for gfx950.
+//
+// Activations live channels-last in HBM:  F[b][p][a][c]  (a = 60 icosahedral anchors), so a
+// neighbour gather (q, a) is one contiguous row of c floats.
+//
+//   etch_inter_so3conv   replaces inter_so3conv_grouping_anchor + inter_so3conv_feat_grouping + BasicSO3Conv
+//                        (/root/reference/external/vgtk/vgtk/so3conv/functional.py:286-324, :61-67, modules.py:33-39):
+//                        the [b,p,60,24,nn] kernel-weight tensor (921 MB / scan at b0c0) is NEVER materialised;
+//                        weights are generated in registers as the B operand of the first MFMA contraction.
+//   etch_intra_so3conv   replaces intra_so3conv_grouping + BasicSO3Conv (functional.py:331-378, modules.py:150-153):
+//                        the 12x gathered tensor is never written; optional InstanceNorm+LeakyReLU applied on load.
+//   etch_instnorm_stats / etch_instnorm_act_add
+//                        InstanceNorm2d(affine=False, eps=1e-5) + leaky_relu(0.01) (+ residual branch)
+//                        (/root/reference/src/models/so3conv.py:36-44,96-99,178-182).
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define NA 60
+#define KS 24
+
+// ------------------------------------------------------------------------------------------------
+// inter conv, CIN in {16,32,64}: one workgroup (4 waves) per output point.
+//   step 1 (per anchor, per wave):  X1[c,k] = sum_n F[idx[n], a, c] * w[a,k,n]      MFMA M=c, N=k(24->32), K=n
+//       w[a,k,n] = relu(1 - |g_n - R_a kappa_k|^2 / sigma) generated per lane as the B fragment
+//   step 2 (16 anchors at a time):  Y[o,col] = sum_kappa W[o,kappa] * X1[col][kappa] + bias      MFMA M=o, N=col, K=CIN*24
+//       X1 goes through LDS ([col][kappa], row stride CIN*24+4), W is read pre-permuted in fragment order.
+// ------------------------------------------------------------------------------------------------
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256) inter_so3conv_kernel(
+    int p1, int p2, int nn, float inv_sigma, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+    const int* __restrict__ ball_idx, const float* __restrict__ feats, const float* __restrict__ rk,
+    const float* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ out) {
+    constexpr int MT1 = CIN / 16;          // c tiles in step 1
+    constexpr int MT2 = COUT / 16;         // o tiles in step 2
+    constexpr int KK = CIN * KS;           // contraction length of step 2
+    constexpr int S = KK + 4;              // LDS row stride (floats), 16-B aligned, S/4 odd
+    constexpr int PS = COUT + 4;           // partial-tile row stride
+    constexpr int MAXT = 4;                // up to 64 neighbours (nn <= 64)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X1s = smem;                     // [16][S]
+    float* part = smem + 16 * S;           // [4 waves][16 cols][PS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int b = blockIdx.y, p = blockIdx.x;
+    const int nchunk = (nn + 15) >> 4;
+
+    // per-lane neighbour data for n = 16t + 4fg + s
+    int nidx[MAXT][4];
+    float gx[MAXT][4], gy[MAXT][4], gz[MAXT][4];
+    {
+        const float cx = new_xyz[((size_t)b * 3 + 0) * p2 + p], cy = new_xyz[((size_t)b * 3 + 1) * p2 + p],
+                    cz = new_xyz[((size_t)b * 3 + 2) * p2 + p];
+        const int* row = ball_idx + ((size_t)b * p2 + p) * nn;
+        const float* X = xyz + (size_t)b * 3 * p1;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int n = 16 * t + 4 * fg + s;
+                int q = -1;
+                if (t < nchunk && n < nn) q = row[n];
+                nidx[t][s] = q;
+                const int qq = q < 0 ? 0 : q;
+                gx[t][s] = X[qq] - cx; gy[t][s] = X[p1 + qq] - cy; gz[t][s] = X[2 * p1 + qq] - cz;
+            }
+    }
+    const float* Fb = feats + (size_t)b * p1 * NA * CIN;
+    float* outp = out + ((size_t)b * p2 + p) * NA * COUT;
+
+    for (int ag = 0; ag < 4; ++ag) {
+        // ---------------- step 1: 4 anchors per wave
+        for (int j = 0; j < 4; ++j) {
+            const int col = wave * 4 + j;
+            const int a = ag * 16 + col;
+            if (a >= NA) break;                         // wave-uniform
+            const float* rka = rk + (size_t)a * KS * 3;
+            const float r0x = rka[fr * 3], r0y = rka[fr * 3 + 1], r0z = rka[fr * 3 + 2];
+            const bool k1ok = fr < 8;
+            const int k1 = k1ok ? 16 + fr : 0;
+            const float r1x = rka[k1 * 3], r1y = rka[k1 * 3 + 1], r1z = rka[k1 * 3 + 2];
+            f32x4 acc[MT1][2];
+#pragma unroll
+            for (int mi = 0; mi < MT1; ++mi) { acc[mi][0] = (f32x4){0, 0, 0, 0}; acc[mi][1] = (f32x4){0, 0, 0, 0}; }
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                if (t < nchunk) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int q = nidx[t][s];
+                        const bool ok = q >= 0;
+                        float dx = gx[t][s] - r0x, dy = gy[t][s] - r0y, dz = gz[t][s] - r0z;
+                        float d0 = dx * dx + dy * dy + dz * dz;
+                        float w0 = fmaxf(0.f, 1.0f - d0 * inv_sigma);
+                        dx = gx[t][s] - r1x; dy = gy[t][s] - r1y; dz = gz[t][s] - r1z;
+                        float d1 = dx * dx + dy * dy + dz * dz;
+                        float w1 = fmaxf(0.f, 1.0f - d1 * inv_sigma);
+                        if (!ok) { w0 = 0.f; w1 = 0.f; }
+                        if (!k1ok) w1 = 0.f;
+                        const float* frow = Fb + ((size_t)(ok ? q : 0) * NA + a) * CIN + fr;
+#pragma unroll
+                        for (int mi = 0; mi < MT1; ++mi) {
+                            const float av = frow[mi * 16];
+                            acc[mi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w0, acc[mi][0], 0, 0, 0);
+                            acc[mi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w1, acc[mi][1], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            // D[row = 4fg + q][col = fr]: row -> channel c, col -> kernel point k
+            float* xcol = X1s + col * S;
+#pragma unroll
+            for (int mi = 0; mi < MT1; ++mi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = mi * 16 + fg * 4 + q;
+                    xcol[c * KS + fr] = acc[mi][0][q];
+                    if (k1ok) xcol[c * KS + 16 + fr] = acc[mi][1][q];
+                }
+        }
+        __syncthreads();
+        // ---------------- step 2: K split over the 4 waves (chunk t of 16 kappas -> wave t & 3)
+        f32x4 y[MT2];
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt) y[mt] = (f32x4){0, 0, 0, 0};
+        for (int t = wave; t < KK / 16; t += 4) {
+            const float4 bv = *reinterpret_cast<const float4*>(&X1s[fr * S + t * 16 + fg * 4]);
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) {
+                const float4 av = *reinterpret_cast<const float4*>(&Wp[(((size_t)t * MT2 + mt) * 64 + lane) * 4]);
+                y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, y[mt], 0, 0, 0);
+                y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, y[mt], 0, 0, 0);
+                y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, y[mt], 0, 0, 0);
+                y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, y[mt], 0, 0, 0);
+            }
+        }
+        // y[mt][q] = Y[o = 16mt + 4fg + q][col = fr]
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt)
+            *reinterpret_cast<float4*>(&part[(wave * 16 + fr) * PS + mt * 16 + fg * 4]) = make_float4(y[mt][0], y[mt][1], y[mt][2], y[mt][3]);
+        __syncthreads();
+        for (int e = tid; e < 16 * COUT; e += 256) {
+            const int col = e / COUT, o = e - col * COUT;
+            const int a = ag * 16 + col;
+            if (a < NA) {
+                float v = part[(0 * 16 + col) * PS + o] + part[(1 * 16 + col) * PS + o];
+                v += part[(2 * 16 + col) * PS + o] + part[(3 * 16 + col) * PS + o];
+                outp[(size_t)a * COUT + o] = v + bias[o];
+            }
+        }
+        // next group's step-1 writes to X1s / partial writes are ordered behind the two barriers above
+    }
+}
+
+// inter conv for tiny CIN (the first layer: CIN = 1): VALU only, one workgroup per output point.
+// X1[a][c][k] in LDS, then Y[a][o] = sum_{c,k} W[o, c*24+k] X1[a][c][k] + bias.
+__global__ void __launch_bounds__(256) inter_so3conv_small_kernel(
+    int cin, int cout, int p1, int p2, int nn, float inv_sigma, const float* __restrict__ xyz,
+    const float* __restrict__ new_xyz, const int* __restrict__ ball_idx, const float* __restrict__ feats,
+    const float* __restrict__ rk, const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* g = smem;                       // [nn][3]
+    int* qi = (int*)(smem + 3 * nn);       // [nn]
+    float* X1 = smem + 4 * nn;             // [NA][cin*KS]
+    const int tid = threadIdx.x, b = blockIdx.y, p = blockIdx.x;
+    const float* X = xyz + (size_t)b * 3 * p1;
+    for (int n = tid; n < nn; n += 256) {
+        const int q = ball_idx[((size_t)b * p2 + p) * nn + n];
+        qi[n] = q;
+        g[n * 3 + 0] = X[q] - new_xyz[((size_t)b * 3 + 0) * p2 + p];
+        g[n * 3 + 1] = X[p1 + q] - new_xyz[((size_t)b * 3 + 1) * p2 + p];
+        g[n * 3 + 2] = X[2 * p1 + q] - new_xyz[((size_t)b * 3 + 2) * p2 + p];
+    }
+    __syncthreads();
+    const float* Fb = feats + (size_t)b * p1 * NA * cin;
+    const int kk = cin * KS;
+    for (int e = tid; e < NA * KS; e += 256) {
+        const int a = e / KS, k = e - a * KS;
+        const float rx = rk[(a * KS + k) * 3], ry = rk[(a * KS + k) * 3 + 1], rz = rk[(a * KS + k) * 3 + 2];
+        for (int c = 0; c < cin; ++c) X1[a * kk + c * KS + k] = 0.f;
+        for (int n = 0; n < nn; ++n) {
+            const float dx = g[n * 3] - rx, dy = g[n * 3 + 1] - ry, dz = g[n * 3 + 2] - rz;
+            const float w = fmaxf(0.f, 1.0f - (dx * dx + dy * dy + dz * dz) * inv_sigma);
+            if (w > 0.f) {
+                const float* fr = Fb + ((size_t)qi[n] * NA + a) * cin;
+                for (int c = 0; c < cin; ++c) X1[a * kk + c * KS + k] += fr[c] * w;
+            }
+        }
+    }
+    __syncthreads();
+    float* outp = out + ((size_t)b * p2 + p) * NA * cout;
+    for (int e = tid; e < NA * cout; e += 256) {
+        const int a = e / cout, o = e - a * cout;
+        float acc = 0.f;
+        const float* wr = W + (size_t)o * kk;
+        const float* xr = X1 + a * kk;
+        for (int i = 0; i < kk; ++i) acc += wr[i] * xr[i];
+        outp[e] = acc + bias[o];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// intra conv: Y[b,p,a,o] = sum_{tap<12} sum_c act(X[b,p,intra_idx[a,tap],c]) * W[o, c*12+tap] + bias[o]
+// One workgroup = PTS points; the point's [60][C] tile is staged in LDS (optionally normalised +
+// leaky-relu'ed on the way in), each wave owns 16 anchors (N tile) x all output tiles.
+// K order inside the kernel: kappa = tap*C + c; W is pre-permuted on the host into fragment order.
+// ------------------------------------------------------------------------------------------------
+template <int C, int COUT, int PTS>
+__global__ void __launch_bounds__(256) intra_so3conv_kernel(int npts_total, int pts_per_batch, const float* __restrict__ X,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const int* __restrict__ intra_idx, const float* __restrict__ Wp,
+                                                            const float* __restrict__ bias, float* __restrict__ Y) {
+    constexpr int MT = COUT / 16;
+    constexpr int LD = C + 4;
+    constexpr int NT = 12 * C / 16;        // K chunks
+    __shared__ __attribute__((aligned(16))) float Xs[PTS * NA * LD];
+    __shared__ int iidx[NA * 12];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int pt0 = blockIdx.x * PTS;
+    for (int e = tid; e < NA * 12; e += 256) iidx[e] = intra_idx[e];
+    for (int e = tid; e < PTS * NA * (C / 4); e += 256) {
+        const int c4 = e % (C / 4), row = e / (C / 4);          // row = pt*60 + a
+        const int pt = pt0 + row / NA;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pt < npts_total) {
+            v = *reinterpret_cast<const float4*>(X + ((size_t)pt0 * NA + row) * C + c4 * 4);
+            if (mean) {
+                const int bb = pt / pts_per_batch;
+                const float4 m = *reinterpret_cast<const float4*>(mean + (size_t)bb * C + c4 * 4);
+                const float4 r = *reinterpret_cast<const float4*>(rstd + (size_t)bb * C + c4 * 4);
+                v.x = (v.x - m.x) * r.x; v.y = (v.y - m.y) * r.y; v.z = (v.z - m.z) * r.z; v.w = (v.w - m.w) * r.w;
+                v.x = v.x > 0.f ? v.x : 0.01f * v.x; v.y = v.y > 0.f ? v.y : 0.01f * v.y;
+                v.z = v.z > 0.f ? v.z : 0.01f * v.z; v.w = v.w > 0.f ? v.w : 0.01f * v.w;
+            }
+        }
+        *reinterpret_cast<float4*>(&Xs[row * LD + c4 * 4]) = v;
+    }
+    __syncthreads();
+    const int a = wave * 16 + fr;
+    const int aa = a < NA ? a : 0;
+    f32x4 acc[PTS][MT];
+#pragma unroll
+    for (int pi = 0; pi < PTS; ++pi)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[pi][mt] = (f32x4){0, 0, 0, 0};
+    for (int t = 0; t < NT; ++t) {
+        const int tap = t / (C / 16), cb = (t - tap * (C / 16)) * 16;
+        const int src = iidx[aa * 12 + tap];
+        float4 bv[PTS];
+#pragma unroll
+        for (int pi = 0; pi < PTS; ++pi) bv[pi] = *reinterpret_cast<const float4*>(&Xs[(pi * NA + src) * LD + cb + fg * 4]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const float4 av = *reinterpret_cast<const float4*>(&Wp[(((size_t)t * MT + mt) * 64 + lane) * 4]);
+#pragma unroll
+            for (int pi = 0; pi < PTS; ++pi) {
+                acc[pi][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv[pi].x, acc[pi][mt], 0, 0, 0);
+                acc[pi][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv[pi].y, acc[pi][mt], 0, 0, 0);
+                acc[pi][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv[pi].z, acc[pi][mt], 0, 0, 0);
+                acc[pi][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv[pi].w, acc[pi][mt], 0, 0, 0);
+            }
+        }
+    }
+    if (a < NA) {
+#pragma unroll
+        for (int pi = 0; pi < PTS; ++pi) {
+            const int pt = pt0 + pi;
+            if (pt >= npts_total) continue;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int o = mt * 16 + fg * 4;
+                const float4 bs = *reinterpret_cast<const float4*>(bias + o);
+                *reinterpret_cast<float4*>(Y + ((size_t)pt * NA + a) * COUT + o) =
+                    make_float4(acc[pi][mt][0] + bs.x, acc[pi][mt][1] + bs.y, acc[pi][mt][2] + bs.z, acc[pi][mt][3] + bs.w);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// InstanceNorm statistics over (p, a) per (b, c): deterministic two-level reduction in fp64.
+//   x [b][rows][C]  ->  mean[b][C], rstd[b][C] = 1/sqrt(var_biased + eps)
+// ------------------------------------------------------------------------------------------------
+#define IN_CHUNKS 64
+__global__ void __launch_bounds__(256) instnorm_partial_kernel(int rows, int C, const float* __restrict__ x,
+                                                               double* __restrict__ partial) {
+    // grid (IN_CHUNKS, b); thread -> channel lane (tid % C4) and row slice
+    extern __shared__ __attribute__((aligned(16))) double sred[];   // [256/C][2][C] ... sized 2*256
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int tpr = C;                         // threads per row pass
+    const int rpp = 256 / tpr;                 // rows per pass (C <= 256, C divides 256)
+    const int c = tid % tpr, rsub = tid / tpr;
+    const int r_begin = (int)(((long)rows * chunk) / IN_CHUNKS), r_end = (int)(((long)rows * (chunk + 1)) / IN_CHUNKS);
+    double s = 0.0, ss = 0.0;
+    const float* xb = x + (size_t)b * rows * C;
+    for (int r = r_begin + rsub; r < r_end; r += rpp) {
+        const double v = (double)xb[(size_t)r * C + c];
+        s += v; ss += v * v;
+    }
+    sred[tid] = s; sred[256 + tid] = ss;
+    __syncthreads();
+    if (rsub == 0) {
+        for (int k = 1; k < rpp; ++k) { s += sred[k * tpr + c]; ss += sred[256 + k * tpr + c]; }
+        partial[(((size_t)b * IN_CHUNKS + chunk) * 2 + 0) * C + c] = s;
+        partial[(((size_t)b * IN_CHUNKS + chunk) * 2 + 1) * C + c] = ss;
+    }
+}
+
+__global__ void instnorm_final_kernel(int rows, int C, float eps, const double* __restrict__ partial,
+                                      float* __restrict__ mean, float* __restrict__ rstd) {
+    const int b = blockIdx.x, c = threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < IN_CHUNKS; ++k) {
+        s += partial[(((size_t)b * IN_CHUNKS + k) * 2 + 0) * C + c];
+        ss += partial[(((size_t)b * IN_CHUNKS + k) * 2 + 1) * C + c];
+    }
+    const double m = s / rows;
+    double var = ss / rows - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[(size_t)b * C + c] = (float)m;
+    rstd[(size_t)b * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// out = lrelu((x1 - m1) * r1) [+ lrelu((x2 - m2) * r2)]     (elementwise, channels-last, float4)
+__global__ void __launch_bounds__(256) instnorm_act_add_kernel(long n4, int rows, int C, const float* __restrict__ x1,
+                                                               const float* __restrict__ m1, const float* __restrict__ r1,
+                                                               const float* __restrict__ x2, const float* __restrict__ m2,
+                                                               const float* __restrict__ r2, float* __restrict__ out) {
+    const long per_batch4 = (long)rows * C / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / per_batch4);
+        const int c = (int)((i * 4) % C);
+        float4 v = reinterpret_cast<const float4*>(x1)[i];
+        const float4 m = *reinterpret_cast<const float4*>(m1 + (size_t)b * C + c);
+        const float4 r = *reinterpret_cast<const float4*>(r1 + (size_t)b * C + c);
+        float o[4] = {(v.x - m.x) * r.x, (v.y - m.y) * r.y, (v.z - m.z) * r.z, (v.w - m.w) * r.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = o[k] > 0.f ? o[k] : 0.01f * o[k];
+        if (x2) {
+            const float4 v2 = reinterpret_cast<const float4*>(x2)[i];
+            const float4 mm = *reinterpret_cast<const float4*>(m2 + (size_t)b * C + c);
+            const float4 rr = *reinterpret_cast<const float4*>(r2 + (size_t)b * C + c);
+            float o2[4] = {(v2.x - mm.x) * rr.x, (v2.y - mm.y) * rr.y, (v2.z - mm.z) * rr.z, (v2.w - mm.w) * rr.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] += o2[k] > 0.f ? o2[k] : 0.01f * o2[k];
+        }
+        reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+template <int CIN, int COUT>
+static int launch_inter(int b, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz, const int* idx,
+                        const float* feats, const float* rk, const float* Wp, const float* bias, float* out, hipStream_t st) {
+    const size_t lds = (size_t)(16 * (CIN * KS + 4) + 4 * 16 * (COUT + 4)) * sizeof(float);
+    auto kern = inter_so3conv_kernel<CIN, COUT>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(p2, b), dim3(256), lds, st, p1, p2, nn, 1.0f / sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+template <int C, int COUT>
+static int launch_intra(int npts, int ppb, const float* X, const float* mean, const float* rstd, const int* intra_idx,
+                        const float* Wp, const float* bias, float* Y, hipStream_t st) {
+    constexpr int PTS = 2;
+    hipLaunchKernelGGL((intra_so3conv_kernel<C, COUT, PTS>), dim3((npts + PTS - 1) / PTS), dim3(256), 0, st, npts, ppb, X, mean,
+                       rstd, intra_idx, Wp, bias, Y);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+extern "C" {
+
+// W layouts: `W` = reference layout [cout][cin*24] (index c*24+k); `Wp` = fragment order produced by
+// etch_permute_weight_frag (only the MFMA path, cin % 16 == 0, reads it).
+int etch_inter_so3conv(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
+                       const int* ball_idx, const float* feats, const float* rk, const float* W, const float* Wp,
+                       const float* bias, float* out, void* stream) {
+    if (b <= 0 || p2 <= 0) return ETCH_OK;
+    if (nn <= 0 || nn > 64 || sigma <= 0.f) return ETCH_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+#define INTER_CASE(CI, CO) \
+    if (cin == CI && cout == CO) return launch_inter<CI, CO>(b, p1, p2, nn, sigma, xyz, new_xyz, ball_idx, feats, rk, Wp, bias, out, st);
+    INTER_CASE(16, 16) INTER_CASE(16, 32) INTER_CASE(32, 32) INTER_CASE(32, 64) INTER_CASE(64, 64)
+#undef INTER_CASE
+    if (cin <= 8) {
+        const size_t lds = (size_t)(4 * nn + NA * cin * KS) * sizeof(float);
+        hipLaunchKernelGGL(inter_so3conv_small_kernel, dim3(p2, b), dim3(256), lds, st, cin, cout, p1, p2, nn, 1.0f / sigma, xyz,
+                           new_xyz, ball_idx, feats, rk, W, bias, out);
+        ETCH_RETURN_IF_LAUNCH_FAILED();
+        return ETCH_OK;
+    }
+    return ETCH_EUNSUPPORTED;
+}
+
+int etch_intra_so3conv(int b, int c, int cout, int p, const float* X, const float* mean, const float* rstd,
+                       const int* intra_idx, const float* Wp, const float* bias, float* Y, void* stream) {
+    if (b <= 0 || p <= 0) return ETCH_OK;
+    hipStream_t st = (hipStream_t)stream;
+#define INTRA_CASE(CI, CO) \
+    if (c == CI && cout == CO) return launch_intra<CI, CO>(b * p, p, X, mean, rstd, intra_idx, Wp, bias, Y, st);
+    INTRA_CASE(16, 16) INTRA_CASE(32, 32) INTRA_CASE(64, 64)
+#undef INTRA_CASE
+    return ETCH_EUNSUPPORTED;
+}
+
+// workspace: IN_CHUNKS * b * 2 * C doubles
+int etch_instnorm_stats(int b, int rows, int C, const float* x, double* workspace, float* mean, float* rstd, void* stream) {
+    if (b <= 0) return ETCH_OK;
+    if (C <= 0 || C > 256 || (256 % C) != 0) return ETCH_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(instnorm_partial_kernel, dim3(IN_CHUNKS, b), dim3(256), 2 * 256 * sizeof(double), st, rows, C, x, workspace);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    hipLaunchKernelGGL(instnorm_final_kernel, dim3(b), dim3(256), 0, st, rows, C, 1e-5f, workspace, mean, rstd);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_instnorm_stats_workspace_bytes(int b, int C) { return (int)((size_t)IN_CHUNKS * b * 2 * C * sizeof(double)); }
+
+int etch_instnorm_act_add(int b, int rows, int C, const float* x1, const float* m1, const float* r1, const float* x2,
+                          const float* m2, const float* r2, float* out, void* stream) {
+    if (b <= 0 || rows <= 0) return ETCH_OK;
+    if (C & 3) return ETCH_EUNSUPPORTED;
+    const long n4 = (long)b * rows * C / 4;
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(instnorm_act_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n4, rows, C, x1, m1, r1, x2,
+                       m2, r2, out);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+}  // extern "C"

@@ -102,3 +102,88 @@ def furthestsampling(xyz, offset, new_offset, offset_host=None, new_offset_host=
     _lib.check(_lib.lib().etch_furthestsampling(len(offset_host), _seg_max(offset_host), _ptr(xyz), _ptr(offset), _ptr(new_offset),
                                                 _ptr(idx), _stream()), "etch_furthestsampling")
     return idx
+
+
+# ------------------------------------------------------------------ dense layers
+_c_long = ctypes.c_long
+ACT = {None: 0, "none": 0, "relu": 1, "leaky_relu": 2}
+
+
+def _optptr(t):
+    return _vp(0) if t is None else _ptr(t)
+
+
+def linear(x, weight, bias=None, scale=None, shift=None, act=None, res=None, res_mode=0, row_idx=None, grp=1, p_in=0, p_out=1,
+           rows=None, out=None):
+    """Y = epi(X[rowmap] @ W^T) via etch_linear.  x [*, K] (last dim contiguous), weight [O, K]."""
+    _need(weight, torch.float32, "weight")
+    if x.dtype != torch.float32 or not x.is_cuda:
+        raise _lib.EtchHipError("x must be a float32 CUDA(HIP) tensor")
+    K = x.shape[-1]
+    assert x.stride(-1) == 1 and weight.shape[1] == K, (x.shape, weight.shape)
+    x2 = x if x.dim() == 2 else x.reshape(-1, K)
+    ldx = x2.stride(0) if x2.shape[0] > 1 else K
+    R = x2.shape[0] if rows is None else rows
+    O = weight.shape[0]
+    if out is None:
+        out = torch.empty((R, O), dtype=torch.float32, device=x.device)
+    ldr = res.stride(0) if res is not None and res.dim() == 2 and res.shape[0] > 1 else O
+    _lib.check(_lib.lib().etch_linear(int(R), int(K), int(O), _ptr(x2), _c_long(ldx), _optptr(row_idx), int(grp), int(p_in), int(p_out),
+                                      _ptr(weight), _c_long(weight.stride(0)), _optptr(bias), _optptr(scale), _optptr(shift),
+                                      ACT[act], _optptr(res), _c_long(ldr), int(res_mode), _ptr(out), _c_long(out.stride(0)), _stream()),
+               "etch_linear")
+    return out
+
+
+def permute_weight_frag(w2):
+    """[O, K] (O % 16 == 0, K % 16 == 0) -> MFMA fragment order Wp[t][mt][lane][s] = W2[16mt + lane%16][16t + 4(lane//16) + s]."""
+    O, K = w2.shape
+    assert O % 16 == 0 and K % 16 == 0
+    return w2.reshape(O // 16, 16, K // 16, 4, 4).permute(2, 0, 3, 1, 4).contiguous().reshape(-1)
+
+
+# ------------------------------------------------------------------ EPN encoder
+def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma):
+    """feats_cl (b,p1,60,cin) channels-last -> (b,p2,60,cout) pre-norm."""
+    b, p1, na, cin = feats_cl.shape
+    p2, nn = ball_idx.shape[1], ball_idx.shape[2]
+    cout = W.shape[0]
+    for t, n in ((xyz, "xyz"), (new_xyz, "new_xyz"), (feats_cl, "feats"), (rk, "rk"), (W, "W"), (bias, "bias")):
+        _need(t, torch.float32, n)
+    _need(ball_idx, torch.int32, "ball_idx")
+    out = torch.empty((b, p2, 60, cout), dtype=torch.float32, device=xyz.device)
+    _lib.check(_lib.lib().etch_inter_so3conv(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
+                                             _ptr(feats_cl), _ptr(rk), _ptr(W), _optptr(Wp), _ptr(bias), _ptr(out), _stream()),
+               "etch_inter_so3conv")
+    return out
+
+
+def intra_so3conv(x_cl, intra_idx32, Wp, bias, cout, mean=None, rstd=None):
+    b, p, na, c = x_cl.shape
+    _need(x_cl, torch.float32, "x"), _need(intra_idx32, torch.int32, "intra_idx"), _need(Wp, torch.float32, "Wp")
+    out = torch.empty((b, p, 60, cout), dtype=torch.float32, device=x_cl.device)
+    _lib.check(_lib.lib().etch_intra_so3conv(b, c, cout, p, _ptr(x_cl), _optptr(mean), _optptr(rstd), _ptr(intra_idx32), _ptr(Wp),
+                                             _ptr(bias), _ptr(out), _stream()), "etch_intra_so3conv")
+    return out
+
+
+def instnorm_stats(x_cl):
+    """x (b, ..., C) -> mean (b,C), rstd (b,C) over all middle dims."""
+    _need(x_cl, torch.float32, "x")
+    b, C = x_cl.shape[0], x_cl.shape[-1]
+    rows = x_cl.numel() // (b * C)
+    ws = torch.empty((_lib.lib().etch_instnorm_stats_workspace_bytes(b, C) // 8,), dtype=torch.float64, device=x_cl.device)
+    mean = torch.empty((b, C), dtype=torch.float32, device=x_cl.device)
+    rstd = torch.empty((b, C), dtype=torch.float32, device=x_cl.device)
+    _lib.check(_lib.lib().etch_instnorm_stats(b, rows, C, _ptr(x_cl), _ptr(ws), _ptr(mean), _ptr(rstd), _stream()), "etch_instnorm_stats")
+    return mean, rstd
+
+
+def instnorm_act_add(x1, m1, r1, x2=None, m2=None, r2=None):
+    _need(x1, torch.float32, "x1")
+    b, C = x1.shape[0], x1.shape[-1]
+    rows = x1.numel() // (b * C)
+    out = torch.empty_like(x1)
+    _lib.check(_lib.lib().etch_instnorm_act_add(b, rows, C, _ptr(x1), _ptr(m1), _ptr(r1), _optptr(x2), _optptr(m2), _optptr(r2),
+                                                _ptr(out), _stream()), "etch_instnorm_act_add")
+    return out

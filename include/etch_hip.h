@@ -49,6 +49,49 @@ int etch_knnquery(int b, int m_max, int nsample, const float* xyz, const float* 
 int etch_furthestsampling(int b, int n_max, const float* xyz, const int* offset, const int* new_offset, int* idx,
                           void* stream);
 
+
+/* ---- dense per-point layers ----------------------------------------------------------------------- */
+
+/* Y[r,o] = epi(sum_k X[rowmap(r),k] * W[o,k]) on the fp32 matrix cores.  Replaces the un-fused ATen calls
+ * torch.nn.Linear / Conv1d(k=1) / Conv2d(1x1) + eval BatchNorm + ReLU used all over the path
+ * (src/models/direction_backbones.py:33-35,53-57, src/models/pointtransformer_seg.py:15-22,44-49,66,104-122,144-145,
+ * src/models/so3conv.py:166,181).  epi: v = acc + bias[o]; if scale: v = v*scale[o] + shift[o];
+ * res_mode 1: v += res[r,o]; act (0 none, 1 relu, 2 leaky 0.01); res_mode 2: v += res[r,o].
+ * rowmap: identity when row_idx == NULL; else q = r / grp, src = ((q / p_out) * p_in + row_idx[q]) * grp + r % grp
+ * (grp = 1, p_in = 0 gives a plain global row gather).  X, W need not be padded: any K / ld is accepted. */
+int etch_linear(int R, int K, int O, const float* X, long ldx, const int* row_idx, int grp, int p_in, int p_out,
+                const float* W, long ldw, const float* bias, const float* scale, const float* shift, int act,
+                const float* res, long ldr, int res_mode, float* Y, long ldy, void* stream);
+
+/* ---- EPN encoder (channels-last activations F[b][p][60][c]) -------------------------------------------- */
+
+/* Fused inter-SO(3) convolution.  Replaces inter_so3conv_grouping_anchor + inter_so3conv_feat_grouping
+ * (external/vgtk/vgtk/so3conv/functional.py:286-324, 61-67) + BasicSO3Conv (modules.py:33-39): the
+ * [b,p2,60,24,nn] kernel-weight tensor is never materialised.
+ * xyz (b,3,p1), new_xyz (b,3,p2), ball_idx (b,p2,nn) i32, feats (b,p1,60,cin), rk (60,24,3) = anchors @ kernels^T,
+ * W (cout, cin*24) reference layout, Wp = etch fragment order of W (used when cin % 16 == 0), bias (cout)
+ * -> out (b,p2,60,cout), pre-normalisation. */
+int etch_inter_so3conv(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz,
+                       const float* new_xyz, const int* ball_idx, const float* feats, const float* rk, const float* W,
+                       const float* Wp, const float* bias, float* out, void* stream);
+
+/* Fused intra-SO(3) convolution.  Replaces intra_so3conv_grouping (functional.py:331-378) + BasicSO3Conv
+ * (modules.py:150-153).  X (b,p,60,c); if mean != NULL the input is first normalised per (b,c) and passed
+ * through leaky_relu(0.01) on load (InstanceNorm of the preceding inter block, src/models/so3conv.py:96-99).
+ * intra_idx (60,12) i32; Wp = fragment order of W2[o][tap*c + ch] = W[o][ch*12 + tap]; -> Y (b,p,60,cout). */
+int etch_intra_so3conv(int b, int c, int cout, int p, const float* X, const float* mean, const float* rstd,
+                       const int* intra_idx, const float* Wp, const float* bias, float* Y, void* stream);
+
+/* InstanceNorm2d(affine=False, eps=1e-5) statistics over (p,a) per (b,c) (src/models/so3conv.py:24,85,168).
+ * x (b,rows,C) -> mean (b,C), rstd (b,C).  workspace: etch_instnorm_stats_workspace_bytes(b, C) bytes. */
+int etch_instnorm_stats(int b, int rows, int C, const float* x, double* workspace, float* mean, float* rstd, void* stream);
+int etch_instnorm_stats_workspace_bytes(int b, int C);
+
+/* out = leaky_relu((x1-m1)*r1) [+ leaky_relu((x2-m2)*r2)]: norm + activation + skip add of
+ * SeparableSO3ConvBlock.forward (src/models/so3conv.py:178-182).  x2 may be NULL. */
+int etch_instnorm_act_add(int b, int rows, int C, const float* x1, const float* m1, const float* r1, const float* x2,
+                          const float* m2, const float* r2, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

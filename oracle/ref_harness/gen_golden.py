@@ -83,9 +83,9 @@ def gen_so3_block(seed=2):
     with R.quiet():
         from models import so3conv as M
         import vgtk.so3conv as sptk
-    params = dict(dim_in=4, dim_out=8, kernel_size=1, stride=2, radius=0.2, sigma=0.02, n_neighbor=16, lazy_sample=False,
+    params = dict(dim_in=16, dim_out=32, kernel_size=1, stride=2, radius=0.2, sigma=0.02, n_neighbor=16, lazy_sample=False,
                   dropout_rate=0, multiplier=2, activation="leaky_relu", pooling=None, kanchor=60)
-    for tag, p in (("s2", params), ("s1", dict(params, stride=1, lazy_sample=True, dim_in=8, n_neighbor=12, radius=0.25))):
+    for tag, p in (("s2", params), ("s1", dict(params, stride=1, lazy_sample=True, dim_in=32, dim_out=32, n_neighbor=24, radius=0.25))):
         with R.quiet():
             blk = M.SeparableSO3ConvBlock(dict(p)).eval()
         blk.load_state_dict(seeded_state_dict(blk, seed))
@@ -198,13 +198,12 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ms = json.load(open(MARKERSET))
     model = R.build_reference_model(tempfile.mkdtemp(), ms)
-    gen_constants(model, ms)
-    gen_so3_block()
-    gen_direction(model)
-    gen_propagation()
-    gen_pt()
-    gen_markers(ms)
-    gen_model(model)
+    only = sys.argv[1:]
+    steps = {"constants": lambda: gen_constants(model, ms), "so3block": gen_so3_block, "direction": lambda: gen_direction(model),
+             "propagation": gen_propagation, "pt": gen_pt, "markers": lambda: gen_markers(ms), "model": lambda: gen_model(model)}
+    for name, fn in steps.items():
+        if not only or name in only:
+            fn()
 
 
 if __name__ == "__main__":
