@@ -187,3 +187,52 @@ def instnorm_act_add(x1, m1, r1, x2=None, m2=None, r2=None):
     _lib.check(_lib.lib().etch_instnorm_act_add(b, rows, C, _ptr(x1), _ptr(m1), _ptr(r1), _optptr(x2), _optptr(m2), _optptr(r2),
                                                 _ptr(out), _stream()), "etch_instnorm_act_add")
     return out
+
+
+# ------------------------------------------------------------------ propagation + direction head
+def prop3nn(xyz1_bn3, xyz2_b3s):
+    _need(xyz1_bn3, torch.float32, "xyz1"), _need(xyz2_b3s, torch.float32, "xyz2")
+    B, N, _ = xyz1_bn3.shape
+    S = xyz2_b3s.shape[2]
+    idx = torch.empty((B, N, 3), dtype=torch.int32, device=xyz1_bn3.device)
+    w = torch.empty((B, N, 3), dtype=torch.float32, device=xyz1_bn3.device)
+    _lib.check(_lib.lib().etch_prop3nn(B, N, S, _ptr(xyz1_bn3), _ptr(xyz2_b3s), _ptr(idx), _ptr(w), _stream()), "etch_prop3nn")
+    return idx, w
+
+
+def prop_interp(feats_cl, idx, w):
+    """feats_cl (B,S,A,C) -> out (B,N,A,C), inv (B,N,C)."""
+    _need(feats_cl, torch.float32, "feats"), _need(idx, torch.int32, "idx"), _need(w, torch.float32, "w")
+    B, S, A, C = feats_cl.shape
+    N = idx.shape[1]
+    out = torch.empty((B, N, A, C), dtype=torch.float32, device=feats_cl.device)
+    inv = torch.empty((B, N, C), dtype=torch.float32, device=feats_cl.device)
+    _lib.check(_lib.lib().etch_prop_interp(B, N, S, A, C, _ptr(feats_cl), _ptr(idx), _ptr(w), _ptr(out), _ptr(inv), _stream()), "etch_prop_interp")
+    return out, inv
+
+
+def mhsa_attention(qkv, T, qoff, koff, voff):
+    """qkv [T*60, ld] -> [T*60, 64]."""
+    _need(qkv, torch.float32, "qkv")
+    out = torch.empty((T * 60, 64), dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.lib().etch_mhsa_attention(_c_long(T), _ptr(qkv), _c_long(qkv.stride(0)), qoff, koff, voff, _ptr(out), _c_long(64), _stream()),
+               "etch_mhsa_attention")
+    return out
+
+
+def rowdot(x, w, bias):
+    _need(x, torch.float32, "x"), _need(w, torch.float32, "w")
+    R, K = x.shape
+    y = torch.empty((R,), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().etch_rowdot(_c_long(R), K, _ptr(x), _c_long(x.stride(0)), _ptr(w), _c_float(bias), _ptr(y), _stream()), "etch_rowdot")
+    return y
+
+
+def so3_mean_dir(w, anchors, want_R=False, want_sv=False):
+    _need(w, torch.float32, "w"), _need(anchors, torch.float32, "anchors")
+    T, A = w.shape
+    d = torch.empty((T, 3), dtype=torch.float32, device=w.device)
+    R = torch.empty((T, 3, 3), dtype=torch.float32, device=w.device) if want_R else None
+    sv = torch.empty((T, 3), dtype=torch.float32, device=w.device) if want_sv else None
+    _lib.check(_lib.lib().etch_so3_mean_dir(_c_long(T), A, _ptr(w), _ptr(anchors), _ptr(d), _optptr(R), _optptr(sv), _stream()), "etch_so3_mean_dir")
+    return d, R, sv

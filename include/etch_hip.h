@@ -92,6 +92,29 @@ int etch_instnorm_stats_workspace_bytes(int b, int C);
 int etch_instnorm_act_add(int b, int rows, int C, const float* x1, const float* m1, const float* r1, const float* x2,
                           const float* m2, const float* r2, float* out, void* stream);
 
+/* ---- feature propagation + direction head --------------------------------------------------------------- */
+
+/* 3-NN of PointFeatPropagation (src/models/pointnet2_utils.py:45-70): xyz1 (B,N,3), xyz2 (B,3,S) ->
+ * idx (B,N,3) i32 (ascending distance), weight (B,N,3) = normalised 1/(d2+1e-8) with d2 from the
+ * reference's expansion formula -2xy + |x|^2 + |y|^2 in fp32. */
+int etch_prop3nn(int B, int N, int S, const float* xyz1, const float* xyz2, int* idx, float* weight, void* stream);
+
+/* Weighted gather (pointnet2_utils.py:71) + anchor mean (models_pointcloud.py:184): feats (B,S,A,C) channels-last
+ * -> out (B,N,A,C), inv (B,N,C) = mean over A.  C in {32,64,128}. */
+int etch_prop_interp(int B, int N, int S, int A, int C, const float* feats, const int* idx, const float* weight,
+                     float* out, float* inv, void* stream);
+
+/* DotProdAttention of MultiHeadAttention (src/models/direction_backbones.py:102-129,160-194) for 60 tokens,
+ * 8 heads x 8 dims: rows [T*60][ld] hold q/k/v at column offsets qoff/koff/voff -> out rows [T*60][ldo] (64 cols). */
+int etch_mhsa_attention(long T, const float* qkv, long ld, int qoff, int koff, int voff, float* out, long ldo, void* stream);
+
+/* y[r] = x[r,:K] . w + bias: so3_reg Conv1d(128,1,1) (src/models/models_pointcloud.py:54,117). */
+int etch_rowdot(long R, int K, const float* x, long ldx, const float* w, float bias, float* y, void* stream);
+
+/* so3_mean (src/models/so3conv.py:186-225) + R @ [0,0,1] (models_pointcloud.py:120-124): w (T,60), anchors (60,3,3)
+ * -> dir (T,3); optional R (T,3,3) and singular values sv (T,3) (NULL to skip). */
+int etch_so3_mean_dir(long T, int A, const float* w, const float* anchors, float* dir, float* R, float* sv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,100 @@
+"""GPU parity: 3-NN propagation, direction head (MHSA + MLP + so3_reg), so3_mean."""
+import numpy as np
+import pytest
+import torch
+
+from etch_amd.utils.weights import seeded_tensor
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def rel_err(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+
+
+def test_propagation_vs_reference_golden(golden):
+    from etch_amd.models.pointnet2_utils import PointFeatPropagation
+    g = golden("module_propagation.npz")
+    d = lambda k: torch.from_numpy(g[k]).cuda()
+    pts = torch.from_numpy(np.ascontiguousarray(np.repeat(g["points2"], 1, axis=1)))
+    # D = 40 is not C*60; embed it as C=32 (pad) x ... -> use the cl kernels directly instead
+    from etch_amd import ops
+    from oracle import stage1 as S
+    xyz1, xyz2 = torch.from_numpy(g["xyz1"]), torch.from_numpy(g["xyz2"])
+    _, ridx, rw = S.feat_propagation(xyz1, xyz2, torch.from_numpy(g["points2"]), return_aux=True)
+    idx, w = ops.prop3nn(xyz1.permute(0, 2, 1).contiguous().cuda(), xyz2.contiguous().cuda())
+    assert np.array_equal(idx.cpu().numpy(), ridx.numpy().astype(np.int32))
+    # coincident points: weights dominated by 1/(noise + 1e-8) -> compare the interpolation, not raw weights
+    B, D, Sn = g["points2"].shape
+    rng = np.random.default_rng(0)
+    feats = rng.standard_normal((B, Sn, 60, 32)).astype(np.float32)
+    out, inv = ops.prop_interp(torch.from_numpy(feats).cuda(), idx, w)
+    ref = S.feat_propagation(xyz1, xyz2, torch.from_numpy(feats.reshape(B, Sn, -1)).permute(0, 2, 1)).numpy().reshape(B, -1, 60, 32)
+    coincident = np.zeros(ref.shape[1], bool)
+    coincident[:Sn] = True
+    assert rel_err(out.cpu().numpy()[:, ~coincident], ref[:, ~coincident]) < RTOL
+    assert rel_err(out.cpu().numpy()[:, coincident], ref[:, coincident]) < 5e-4   # cancellation noise in d2
+    assert rel_err(inv.cpu().numpy()[:, ~coincident], ref.mean(2)[:, ~coincident]) < RTOL
+    # and the reference-layout wrapper on the golden itself (D = 40 -> not a multiple of 60: skip wrapper), golden check via weights
+    gout = torch.from_numpy(g["out"])
+    w_ref = torch.sum(torch.from_numpy(g["points2"]).permute(0, 2, 1)[torch.arange(B).view(B, 1, 1), ridx] * rw.unsqueeze(-1), 2)
+    assert rel_err(w_ref.numpy(), gout.numpy()) < 1e-6
+
+
+def _load_direction(model_like, seed, prefix_map):
+    sd = model_like.state_dict()
+    for k, v in sd.items():
+        sd[k] = seeded_tensor(prefix_map + k, v.shape, v.dtype, seed)
+    model_like.load_state_dict(sd)
+    return model_like
+
+
+def test_direction_head_vs_reference_golden(golden):
+    from etch_amd import ops
+    from etch_amd.models.direction_backbones import BatchMLP, StackedMHSA
+    g = golden("module_direction.npz")
+    c = golden("constants.npz")
+    seed = int(g["seed"])
+    enc = _load_direction(StackedMHSA(64, 128, 8, 2), seed, "direction_encoder.").cuda().eval()
+    mlp = _load_direction(BatchMLP(128, 128), seed, "direction_predictor.").cuda().eval()
+    wreg = seeded_tensor("so3_reg.weight", (1, 128, 1), torch.float32, seed).view(-1).cuda()
+    breg = float(seeded_tensor("so3_reg.bias", (1,), torch.float32, seed))
+    ef = torch.from_numpy(g["equiv_feat"]).cuda()                      # [1, 24, 64, 60]
+    tok = ef.permute(0, 1, 3, 2).reshape(-1, 60, 64).contiguous()
+    x = mlp(enc(tok))
+    anc_w = ops.rowdot(x.view(-1, 128), wreg, breg).view(-1, 60)
+    assert rel_err(anc_w.cpu().numpy(), g["anc_w"]) < RTOL
+    # so3_mean on well-conditioned weights
+    d, R, sv = ops.so3_mean_dir(torch.from_numpy(g["mean_w"]).cuda(), torch.from_numpy(c["anchors"]).cuda(), True, True)
+    assert np.abs(R.cpu().numpy() - g["mean_R"]).max() < 1e-5
+    assert np.abs(d.cpu().numpy() - g["mean_R"][:, :, 2]).max() < 1e-5
+
+
+def test_so3_mean_negative_det_and_rank_deficient():
+    """Kabsch-with-reflection branch (det(U V^T) = -1) and degenerate inputs vs a float64 numpy SVD."""
+    from etch_amd import ops
+    from etch_amd import constants as K
+    rng = np.random.default_rng(9)
+    A = K.get_anchors()
+    w = rng.standard_normal((4000, 60)).astype(np.float32)
+    d, R, sv = ops.so3_mean_dir(torch.from_numpy(w).cuda(), torch.from_numpy(A).cuda(), True, True)
+    R, sv = R.cpu().numpy().astype(np.float64), sv.cpu().numpy()
+    Ce = np.einsum("ta,aij->tij", w.astype(np.float64), A.astype(np.float64))
+    U, S, Vt = np.linalg.svd(Ce)
+    dd = np.linalg.det(U @ Vt)
+    D = np.zeros((len(w), 3, 3)); D[:, 0, 0] = 1; D[:, 1, 1] = 1; D[:, 2, 2] = dd
+    Rref = U @ D @ Vt
+    assert (dd < 0).mean() > 0.2                                     # the reflection branch is exercised
+    assert np.allclose(sv, S, rtol=1e-5, atol=1e-6)
+    assert np.abs(np.linalg.det(R) - 1).max() < 1e-5
+    # projection is unique when the two smallest singular values are separated (else any answer is as good)
+    ok = (S[:, 1] - S[:, 2] * np.sign(dd) * 1.0 > 0.05 * S[:, 0]) if False else ((S[:, 1] + np.where(dd < 0, -S[:, 2], S[:, 2])) > 0.05 * S[:, 0])
+    assert ok.mean() > 0.5
+    assert np.abs(R - Rref)[ok].max() < 1e-4
+    # rank-deficient input must still give a proper rotation, not NaN
+    wz = np.zeros((3, 60), np.float32); wz[1, 29] = 1.0; wz[2, 0] = 1.0; wz[2, 1] = -1.0
+    _, Rz, _ = ops.so3_mean_dir(torch.from_numpy(wz).cuda(), torch.from_numpy(A).cuda(), True, False)
+    Rz = Rz.cpu().numpy()
+    assert np.isfinite(Rz).all() and np.abs(np.linalg.det(Rz.astype(np.float64)) - 1).max() < 1e-5
+    assert np.abs(Rz[1] - np.eye(3)).max() < 1e-6
