@@ -1,0 +1,311 @@
+// Point-Transformer kernels of the confidence / magnitude heads for gfx950 (Appendix B).
+// Dense Linear(+BN+ReLU) layers go through etch_linear (gemm.hip); this file holds the neighbourhood parts:
+//   etch_pt_attention      PointTransformerLayer.forward after the q/k/v projections
+//                          (/root/reference/src/models/pointtransformer_seg.py:28-36, src/models/pointops.py:79-100)
+//   etch_pt_group          queryandgroup(use_xyz=True) rows for TransitionDown (:61, pointops.py:90-98)
+//   etch_rows_maxpool      MaxPool1d(nsample) (:63)
+//   etch_pt_interp_add     linear1(x1) + pointops.interpolation(...) of TransitionUp (:97, pointops.py:164-178)
+//   etch_seg_mean / etch_concat_bcast   TransitionUp head branch (:83-93)
+//   etch_grouped_dot       confi[2] = Conv1d(128*k, k, 1, groups=k) (:145)
+//   etch_softmax_dot       confidence = sum_k softmax(cls)_k * confi_k (:183-189)
+// Eval-mode BatchNorm is folded on the host into per-channel (scale, shift).
+#include "common.h"
+
+struct PtAttnParams {
+    const float* p;       // [n,3]
+    const float* xq; const float* xk; const float* xv; long ldq;   // rows of the fused q|k|v GEMM output
+    const int* idx;       // [n, ns]
+    const float* W0; const float* b0; const float* s_p; const float* t_p;     // linear_p[0] (3x3), BN(3) folded
+    const float* W3; const float* b3;                                         // linear_p[3] [c,3], [c]
+    const float* s_w0; const float* t_w0;                                     // linear_w[0] BN(c)
+    const float* W2T; const float* b2;                                        // linear_w[2] transposed [c][cs], [cs]
+    const float* s_w3; const float* t_w3;                                     // linear_w[3] BN(cs)
+    const float* W5; const float* b5;                                         // linear_w[5] [cs][cs], [cs]
+    const float* s_out; const float* t_out;                                   // optional BN(c)+ReLU on the output (block.bn2)
+    float* out; long ldo;
+    int n, c, ns;
+};
+
+__global__ void __launch_bounds__(128) pt_attention_kernel(PtAttnParams a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int c = a.c, ns = a.ns, cs = c >> 3;
+    float* s_pr = sm;                    // [ns][c]
+    float* s_w = s_pr + ns * c;          // [ns][c]
+    float* s_h = s_w + ns * c;           // [ns][cs]
+    float* s_l = s_h + ns * cs;          // [ns][cs]
+    float* s_p3 = s_l + ns * cs;         // [ns][4]
+    int* s_idx = (int*)(s_p3 + ns * 4);  // [ns]
+    const int i = blockIdx.x, tid = threadIdx.x;
+    if (tid < ns) {
+        const int j = a.idx[(size_t)i * ns + tid];
+        s_idx[tid] = j;
+        const float rx = a.p[(size_t)j * 3] - a.p[(size_t)i * 3], ry = a.p[(size_t)j * 3 + 1] - a.p[(size_t)i * 3 + 1],
+                    rz = a.p[(size_t)j * 3 + 2] - a.p[(size_t)i * 3 + 2];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            float h = a.W0[o * 3] * rx + a.W0[o * 3 + 1] * ry + a.W0[o * 3 + 2] * rz + a.b0[o];
+            h = h * a.s_p[o] + a.t_p[o];
+            s_p3[tid * 4 + o] = fmaxf(h, 0.f);
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < ns * c; e += 128) {
+        const int j = e / c, ch = e - j * c;
+        const float pr = a.W3[ch * 3] * s_p3[j * 4] + a.W3[ch * 3 + 1] * s_p3[j * 4 + 1] + a.W3[ch * 3 + 2] * s_p3[j * 4 + 2] + a.b3[ch];
+        s_pr[e] = pr;
+        float w = a.xk[(size_t)s_idx[j] * a.ldq + ch] - a.xq[(size_t)i * a.ldq + ch] + pr;
+        w = w * a.s_w0[ch] + a.t_w0[ch];
+        s_w[e] = fmaxf(w, 0.f);
+    }
+    __syncthreads();
+    for (int e = tid; e < ns * cs; e += 128) {
+        const int j = e / cs, t = e - j * cs;
+        float acc = 0.f;
+        const float* wr = s_w + j * c;
+        for (int ch = 0; ch < c; ++ch) acc = fmaf(a.W2T[(size_t)ch * cs + t], wr[ch], acc);
+        acc += a.b2[t];
+        acc = acc * a.s_w3[t] + a.t_w3[t];
+        s_h[e] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    for (int e = tid; e < ns * cs; e += 128) {
+        const int j = e / cs, t = e - j * cs;
+        float acc = 0.f;
+        for (int u = 0; u < cs; ++u) acc = fmaf(a.W5[t * cs + u], s_h[j * cs + u], acc);
+        s_l[e] = acc + a.b5[t];
+    }
+    __syncthreads();
+    for (int t = tid; t < cs; t += 128) {      // softmax over the ns neighbours, per shared channel t
+        float mx = -INFINITY;
+        for (int j = 0; j < ns; ++j) mx = fmaxf(mx, s_l[j * cs + t]);
+        float den = 0.f;
+        for (int j = 0; j < ns; ++j) { const float ev = __expf(s_l[j * cs + t] - mx); s_l[j * cs + t] = ev; den += ev; }
+        const float inv = 1.0f / den;
+        for (int j = 0; j < ns; ++j) s_l[j * cs + t] *= inv;
+    }
+    __syncthreads();
+    for (int ch = tid; ch < c; ch += 128) {
+        const int t = ch % cs;
+        float acc = 0.f;
+        for (int j = 0; j < ns; ++j) acc += (a.xv[(size_t)s_idx[j] * a.ldq + ch] + s_pr[j * c + ch]) * s_l[j * cs + t];
+        if (a.s_out) acc = fmaxf(acc * a.s_out[ch] + a.t_out[ch], 0.f);
+        a.out[(size_t)i * a.ldo + ch] = acc;
+    }
+}
+
+// rows[(i*ns + j)] = [ p[idx[i,j]] - new_p[i]  (3) | x[idx[i,j]] (c) ],   row length 3 + c
+__global__ void __launch_bounds__(256) pt_group_kernel(int m, int ns, int c, const float* __restrict__ p, const float* __restrict__ new_p,
+                                                       const float* __restrict__ x, long ldx, const int* __restrict__ idx,
+                                                       float* __restrict__ out) {
+    const int ld = 3 + c;
+    const size_t total = (size_t)m * ns * ld;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t row = e / ld;
+        const int col = (int)(e - row * ld);
+        const int i = (int)(row / ns);
+        const int j = idx[row];
+        out[e] = col < 3 ? p[(size_t)j * 3 + col] - new_p[(size_t)i * 3 + col] : x[(size_t)j * ldx + col - 3];
+    }
+}
+
+// out[i, ch] = max_j x[i*ns + j, ch]
+__global__ void __launch_bounds__(256) rows_maxpool_kernel(int m, int ns, int c, const float* __restrict__ x, float* __restrict__ out) {
+    const size_t total = (size_t)m * c;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t i = e / c;
+        const int ch = (int)(e - i * c);
+        float v = -INFINITY;
+        for (int j = 0; j < ns; ++j) v = fmaxf(v, x[(i * ns + j) * c + ch]);
+        out[e] = v;
+    }
+}
+
+// out[i,ch] = a[i,ch] + ((f[idx0]*w0) + f[idx1]*w1) + f[idx2]*w2,  w = (1/(d+1e-8)) / sum   (d = NON-squared distance)
+__global__ void __launch_bounds__(256) pt_interp_add_kernel(int n, int c, const float* __restrict__ a, const float* __restrict__ f,
+                                                            const int* __restrict__ idx, const float* __restrict__ dist,
+                                                            float* __restrict__ out) {
+    const size_t total = (size_t)n * c;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t i = e / c;
+        const int ch = (int)(e - i * c);
+        const float r0 = 1.0f / (dist[i * 3] + 1e-8f), r1 = 1.0f / (dist[i * 3 + 1] + 1e-8f), r2 = 1.0f / (dist[i * 3 + 2] + 1e-8f);
+        const float nrm = (r0 + r1) + r2;
+        float v = f[(size_t)idx[i * 3] * c + ch] * (r0 / nrm);
+        v += f[(size_t)idx[i * 3 + 1] * c + ch] * (r1 / nrm);
+        v += f[(size_t)idx[i * 3 + 2] * c + ch] * (r2 / nrm);
+        out[e] = a[e] + v;
+    }
+}
+
+// mean[b, ch] = sum_{rows of segment b} x[row, ch] / cnt      (one workgroup per segment, thread per channel)
+__global__ void __launch_bounds__(256) seg_mean_kernel(int c, const float* __restrict__ x, const int* __restrict__ offset,
+                                                       float* __restrict__ mean) {
+    const int b = blockIdx.x;
+    const int s = b == 0 ? 0 : offset[b - 1], e = offset[b];
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+        float acc = 0.f;
+        for (int r = s; r < e; ++r) acc += x[(size_t)r * c + ch];
+        mean[(size_t)b * c + ch] = acc / (float)(e - s);
+    }
+}
+
+// out[row] = [ x[row] (c) | g[seg(row)] (c) ]
+__global__ void __launch_bounds__(256) concat_bcast_kernel(int n, int c, int nseg, const float* __restrict__ x, const float* __restrict__ g,
+                                                           const int* __restrict__ offset, float* __restrict__ out) {
+    const size_t total = (size_t)n * 2 * c;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t row = e / (2 * c);
+        const int col = (int)(e - row * 2 * c);
+        if (col < c) out[e] = x[row * c + col];
+        else {
+            int b = 0;
+            while (b < nseg - 1 && (int)row >= offset[b]) ++b;
+            out[e] = g[(size_t)b * c + col - c];
+        }
+    }
+}
+
+// out[r, g] = sum_j h[r, g*J + j] * w[g, j] + b[g]       (16 lanes per (r,g), J % 64 == 0)
+__global__ void __launch_bounds__(256) grouped_dot_kernel(long R, int G, int J, const float* __restrict__ h, long ldh,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ out, long ldo) {
+    const int sub = threadIdx.x & 15;
+    const long total = R * G;
+    for (long e = (long)blockIdx.x * 16 + (threadIdx.x >> 4); e < total; e += (long)gridDim.x * 16) {
+        const long r = e / G;
+        const int g = (int)(e - r * G);
+        const float* hr = h + r * ldh + (long)g * J;
+        const float* wr = w + (long)g * J;
+        float s = 0.f;
+        for (int k = sub * 4; k < J; k += 64) {
+            const float4 x = *reinterpret_cast<const float4*>(hr + k), y = *reinterpret_cast<const float4*>(wr + k);
+            s = fmaf(x.x, y.x, s); s = fmaf(x.y, y.y, s); s = fmaf(x.z, y.z, s); s = fmaf(x.w, y.w, s);
+        }
+        s += __shfl_xor(s, 8, 16); s += __shfl_xor(s, 4, 16); s += __shfl_xor(s, 2, 16); s += __shfl_xor(s, 1, 16);
+        if (sub == 0) out[r * ldo + g] = s + bias[g];
+    }
+}
+
+// conf[r] = sum_g softmax(logits[r, :])_g * v[r, g]       (one wave per row)
+__global__ void __launch_bounds__(256) softmax_dot_kernel(long R, int G, const float* __restrict__ logits, const float* __restrict__ v,
+                                                          float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += (long)gridDim.x * 4) {
+        float mx = -INFINITY;
+        for (int g = lane; g < G; g += 64) mx = fmaxf(mx, logits[r * G + g]);
+        mx = etch_wave_max_f32(mx);
+        float den = 0.f, num = 0.f;
+        for (int g = lane; g < G; g += 64) {
+            const float ev = __expf(logits[r * G + g] - mx);
+            den += ev; num += ev * v[r * G + g];
+        }
+        den = etch_wave_sum_f32(den); num = etch_wave_sum_f32(num);
+        if (lane == 0) out[r] = num / den;
+    }
+}
+
+// out[i, :c] = x[idx[i], :c]
+__global__ void __launch_bounds__(256) gather_rows_kernel(int m, int c, const float* __restrict__ x, long ldx, const int* __restrict__ idx,
+                                                          float* __restrict__ out) {
+    const size_t total = (size_t)m * c;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t i = e / c;
+        out[e] = x[(size_t)idx[i] * ldx + (e - i * c)];
+    }
+}
+
+static inline unsigned grid_for(size_t total, int per_block) {
+    size_t b = (total + per_block - 1) / per_block;
+    if (b > 65535u * 16u) b = 65535u * 16u;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+extern "C" {
+
+// params: 16 device pointers in the order of PtAttnParams (W0,b0,s_p,t_p,W3,b3,s_w0,t_w0,W2T,b2,s_w3,t_w3,W5,b5,s_out,t_out)
+int etch_pt_attention(int n, int c, int ns, const float* p, const float* xq, const float* xk, const float* xv, long ldq,
+                      const int* idx, const float* const* params, float* out, long ldo, void* stream) {
+    if (n <= 0) return ETCH_OK;
+    if (c <= 0 || (c & 7) || ns <= 0 || ns > 128) return ETCH_EINVAL;
+    PtAttnParams a;
+    a.p = p; a.xq = xq; a.xk = xk; a.xv = xv; a.ldq = ldq; a.idx = idx;
+    a.W0 = params[0]; a.b0 = params[1]; a.s_p = params[2]; a.t_p = params[3]; a.W3 = params[4]; a.b3 = params[5];
+    a.s_w0 = params[6]; a.t_w0 = params[7]; a.W2T = params[8]; a.b2 = params[9]; a.s_w3 = params[10]; a.t_w3 = params[11];
+    a.W5 = params[12]; a.b5 = params[13]; a.s_out = params[14]; a.t_out = params[15];
+    a.out = out; a.ldo = ldo; a.n = n; a.c = c; a.ns = ns;
+    const int cs = c / 8;
+    const size_t lds = (size_t)(2 * ns * c + 2 * ns * cs + ns * 4 + ns) * sizeof(float);
+    if (lds > 160 * 1024) return ETCH_EUNSUPPORTED;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)pt_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(pt_attention_kernel, dim3(n), dim3(128), lds, (hipStream_t)stream, a);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_pt_group(int m, int ns, int c, const float* p, const float* new_p, const float* x, long ldx, const int* idx, float* out,
+                  void* stream) {
+    if (m <= 0) return ETCH_OK;
+    hipLaunchKernelGGL(pt_group_kernel, dim3(grid_for((size_t)m * ns * (3 + c), 256)), dim3(256), 0, (hipStream_t)stream, m, ns, c, p,
+                       new_p, x, ldx, idx, out);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_gather_rows(int m, int c, const float* x, long ldx, const int* idx, float* out, void* stream) {
+    if (m <= 0) return ETCH_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((size_t)m * c, 256)), dim3(256), 0, (hipStream_t)stream, m, c, x, ldx, idx, out);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_rows_maxpool(int m, int ns, int c, const float* x, float* out, void* stream) {
+    if (m <= 0) return ETCH_OK;
+    hipLaunchKernelGGL(rows_maxpool_kernel, dim3(grid_for((size_t)m * c, 256)), dim3(256), 0, (hipStream_t)stream, m, ns, c, x, out);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_pt_interp_add(int n, int c, const float* a, const float* f, const int* idx, const float* dist, float* out, void* stream) {
+    if (n <= 0) return ETCH_OK;
+    hipLaunchKernelGGL(pt_interp_add_kernel, dim3(grid_for((size_t)n * c, 256)), dim3(256), 0, (hipStream_t)stream, n, c, a, f, idx, dist, out);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_seg_mean(int nseg, int c, const float* x, const int* offset, float* mean, void* stream) {
+    if (nseg <= 0) return ETCH_OK;
+    hipLaunchKernelGGL(seg_mean_kernel, dim3(nseg), dim3(256), 0, (hipStream_t)stream, c, x, offset, mean);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_concat_bcast(int n, int c, int nseg, const float* x, const float* g, const int* offset, float* out, void* stream) {
+    if (n <= 0) return ETCH_OK;
+    hipLaunchKernelGGL(concat_bcast_kernel, dim3(grid_for((size_t)n * 2 * c, 256)), dim3(256), 0, (hipStream_t)stream, n, c, nseg, x, g,
+                       offset, out);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_grouped_dot(long R, int G, int J, const float* h, long ldh, const float* w, const float* bias, float* out, long ldo,
+                     void* stream) {
+    if (R <= 0) return ETCH_OK;
+    if ((J & 3) || (ldh & 3)) return ETCH_EINVAL;
+    hipLaunchKernelGGL(grouped_dot_kernel, dim3(grid_for((size_t)R * G, 16)), dim3(256), 0, (hipStream_t)stream, R, G, J, h, ldh, w, bias,
+                       out, ldo);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_softmax_dot(long R, int G, const float* logits, const float* v, float* out, void* stream) {
+    if (R <= 0) return ETCH_OK;
+    hipLaunchKernelGGL(softmax_dot_kernel, dim3(grid_for((size_t)R, 4)), dim3(256), 0, (hipStream_t)stream, R, G, logits, v, out);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+}  // extern "C"

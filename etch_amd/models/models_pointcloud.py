@@ -1,0 +1,104 @@
+"""MI355X counterpart of /root/reference/src/models/models_pointcloud.py: `GT_network_equiv` with the same
+constructor contract (`option.{output_folder, EPN_input_radius, EPN_layer_num, markerset, device}`), the same
+module tree / state-dict keys (reference checkpoints load unchanged) and the same forward signature and
+result dictionary.  Every op on the path is a HIP kernel of libetch_hip.so."""
+import os
+
+import torch
+import torch.nn.init as init
+from torch import nn
+
+from .. import ops
+from ..config.EPN_options import get_default_cfg
+from .direction_backbones import BatchMLP, StackedMHSA
+from .pointnet2_utils import propagate_cl
+from .pointtransformer_seg import get_pointtransformer_confidence, get_pointtransformer_magnitude
+from .so3net import build_model
+
+
+class GT_network_equiv(nn.Module):
+    def __init__(self, option=None):
+        super().__init__()
+        self.option = option
+        model_setting_file = os.path.join(option.output_folder, "EPN_model_setting_json")
+        EPN_cfg = get_default_cfg()
+        EPN_cfg.model.search_radius = option.EPN_input_radius
+        mlp_layers = [[32, 32], [64, 64], [128, 128], [256, 256]]
+        strides_layers = [2, 2, 2, 2]
+        self.standard_vector = torch.tensor([0, 0, 1], dtype=torch.float32, requires_grad=False)
+        EPN_layer_n = option.EPN_layer_num
+        EPN_feat_dim = mlp_layers[EPN_layer_n - 1][0]
+        os.makedirs(option.output_folder, exist_ok=True)
+        self.encoder = build_model(EPN_cfg, mlps=mlp_layers[:EPN_layer_n], strides=strides_layers[:EPN_layer_n], to_file=model_setting_file)
+        # direction
+        self.direction_encoder = StackedMHSA(embedding_dim=EPN_feat_dim, value_dim=128, num_heads=8, num_layers=2)
+        self.direction_predictor = BatchMLP(in_features=128, out_features=128)
+        self.so3_reg = nn.Conv1d(128, 1, 1)
+        # magnitude / confidence
+        self.magnitude_encoder = get_pointtransformer_magnitude(c=EPN_feat_dim + 3, k=1)
+        self.confidence_encoder = get_pointtransformer_confidence(c=EPN_feat_dim + 3, k=len(option.markerset))
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        """models_pointcloud.py:72-77."""
+        for p in self.parameters():
+            if p.dim() > 1:
+                init.xavier_uniform_(p)
+
+    def encode(self, f):
+        return self.encoder(f)
+
+    def preprocess_data(self, xyz, features):
+        """models_pointcloud.py:82-92."""
+        B, N, C = features.shape
+        p = xyz.reshape(-1, 3)
+        x = features.reshape(-1, C)
+        o = torch.tensor([N * (i + 1) for i in range(B)], dtype=torch.int32).to(p.device)
+        return p, x, o
+
+    def decode_confidence(self, inv_feat, xyz):
+        return self.confidence_encoder(self.preprocess_data(xyz, inv_feat))
+
+    def decode_magnitude(self, inv_feat, xyz):
+        return self.magnitude_encoder(self.preprocess_data(xyz, inv_feat))
+
+    def anchor_weights(self, tokens):
+        """tokens [T, 60, C] -> anc_w [T, 60]: direction_encoder -> direction_predictor -> so3_reg (models_pointcloud.py:115-117)."""
+        x = self.direction_predictor(self.direction_encoder(tokens))
+        T = x.shape[0]
+        return ops.rowdot(x.view(T * 60, -1), self.so3_reg.weight.detach().view(-1), float(self.so3_reg.bias.detach().cpu())).view(T, 60)
+
+    def decode_direction(self, equiv_feat, anchors, initial_vectors, tokens_cl=None):
+        """models_pointcloud.py:111-126.  equiv_feat [B, N, C, 60] (reference layout) or tokens_cl [B, N, 60, C]."""
+        if tokens_cl is None:
+            tokens_cl = equiv_feat.permute(0, 1, 3, 2).contiguous()
+        B, N, na, C = tokens_cl.shape
+        anc_w = self.anchor_weights(tokens_cl.view(B * N, na, C))
+        self.last_anc_w = anc_w.view(B, N, na)
+        iv = initial_vectors.reshape(-1, 3)[0].tolist()
+        assert iv == [0.0, 0.0, 1.0], "only direction_mode='standard_vector' is implemented (as in the reference, :198-208)"
+        d, _, _ = ops.so3_mean_dir(anc_w, anchors.contiguous())
+        return d.view(B, N, 3)
+
+    def forward(self, hitpts, pred_items=["direction", "magnitude"], direction_mode="standard_vector"):
+        """models_pointcloud.py:146-221."""
+        B, N, _ = hitpts.size()
+        hitpts = hitpts.contiguous()
+        r, sample_idx_lists = self.encode(hitpts)
+        so3_anchors = r.anchors
+        selected_indexs = torch.arange(0, N).repeat(B, 1).unsqueeze(-1).expand(-1, -1, 3).to(hitpts.device)
+        # 3-NN propagation of the [C*60] equivariant features to all N points + anchor mean (:181-184), channels-last
+        point_equiv_cl, point_inv_feat = propagate_cl(hitpts, r.xyz, r.feats_cl)
+        results = {}
+        if "confidence" in pred_items:
+            part_labels, confidences = self.decode_confidence(point_inv_feat, hitpts)
+            results["confidences"] = confidences
+            results["part_labels"] = part_labels
+        if "direction" in pred_items:
+            if direction_mode != "standard_vector":
+                raise AssertionError("Not implemented")   # same as the reference (:199,210)
+            standard_vector = self.standard_vector.repeat(B, N, 1)
+            results["direction"] = self.decode_direction(None, so3_anchors, standard_vector, tokens_cl=point_equiv_cl)
+        if "magnitude" in pred_items:
+            results["magnitude"] = self.decode_magnitude(point_inv_feat, hitpts)
+        return results, selected_indexs

@@ -1,0 +1,77 @@
+"""MI355X counterpart of /root/reference/src/models/pointops.py (the functions on the inference path).
+
+Same names and argument order.  Two host-side economies that do not change any result:
+  * offsets are read back to the host once per tensor (the reference does `.item()` per scan), and
+  * identical kNN queries are computed once per forward (the reference recomputes the same query twice per
+    PointTransformerLayer, pointtransformer_seg.py:28-29, and again in every block of a level)."""
+import torch
+
+from .. import ops
+
+_host_cache = {}
+_knn_cache = None  # dict while a Point-Transformer forward is active
+
+
+def host_offsets(o):
+    key = (o.data_ptr(), o._version, o.shape[0])
+    v = _host_cache.get(key)
+    if v is None:
+        if len(_host_cache) > 64:
+            _host_cache.clear()
+        v = [int(t) for t in o.tolist()]
+        _host_cache[key] = v
+    return v
+
+
+class knn_scope:
+    """Enables kNN de-duplication for the duration of one network forward."""
+
+    def __enter__(self):
+        global _knn_cache
+        self._prev = _knn_cache
+        _knn_cache = {}
+        return self
+
+    def __exit__(self, *a):
+        global _knn_cache
+        _knn_cache = self._prev
+
+
+def furthestsampling(xyz, offset, new_offset):
+    """pointops.py:10-28."""
+    return ops.furthestsampling(xyz, offset, new_offset, host_offsets(offset), host_offsets(new_offset))
+
+
+def knnquery(nsample, xyz, new_xyz, offset, new_offset):
+    """pointops.py:32-45: -> idx (m,nsample) int32, dist (m,nsample) = sqrt(d2)."""
+    if new_xyz is None:
+        new_xyz = xyz
+    key = (nsample, xyz.data_ptr(), new_xyz.data_ptr(), offset.data_ptr(), new_offset.data_ptr())
+    if _knn_cache is not None and key in _knn_cache:
+        return _knn_cache[key]
+    r = ops.knnquery(nsample, xyz, new_xyz, offset, new_offset, host_offsets(new_offset))
+    if _knn_cache is not None:
+        _knn_cache[key] = r + (xyz, new_xyz)   # keep the tensors alive so data_ptr keys stay unique
+        return r
+    return r
+
+
+def queryandgroup(nsample, xyz, new_xyz, feat, idx, offset, new_offset, use_xyz=True):
+    """pointops.py:79-100: -> (m, nsample, 3+c) or (m, nsample, c)."""
+    if new_xyz is None:
+        new_xyz = xyz
+    if idx is None:
+        idx = knnquery(nsample, xyz, new_xyz, offset, new_offset)[0]
+    m, c = new_xyz.shape[0], feat.shape[1]
+    g = ops.pt_group(xyz, new_xyz, feat, idx).view(m, nsample, 3 + c)
+    return g if use_xyz else g[:, :, 3:]
+
+
+def interpolation(xyz, new_xyz, feat, offset, new_offset, k=3, add_to=None):
+    """pointops.py:164-178 (weights from NON-squared distances).  `add_to` fuses the `linear1(x1) + ...` of TransitionUp."""
+    assert k == 3
+    r = knnquery(k, xyz, new_xyz, offset, new_offset)
+    idx, dist = r[0], r[1]
+    if add_to is None:
+        add_to = torch.zeros((new_xyz.shape[0], feat.shape[1]), dtype=torch.float32, device=feat.device)
+    return ops.pt_interp_add(add_to, feat, idx, dist)

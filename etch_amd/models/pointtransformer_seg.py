@@ -1,0 +1,270 @@
+"""MI355X counterpart of /root/reference/src/models/pointtransformer_seg.py: identical module tree and
+state-dict keys; Linear(+BN+ReLU) layers run as one fp32-MFMA GEMM with a fused epilogue, the kNN
+vector-attention core is one kernel per layer, FPS / kNN are the HIP index kernels."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..vgtk_so3conv import _Derived
+from . import pointops
+
+
+def fold_bn(bn):
+    """eval-mode BatchNorm1d -> (scale, shift): y = x*scale + shift."""
+    s = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+    return s.contiguous(), (bn.bias.detach() - bn.running_mean * s).contiguous()
+
+
+class PointTransformerLayer(nn.Module):
+    """pointtransformer_seg.py:8-37."""
+
+    def __init__(self, in_planes, out_planes, share_planes=8, nsample=16):
+        super().__init__()
+        self.mid_planes = mid_planes = out_planes // 1
+        self.out_planes, self.share_planes, self.nsample = out_planes, share_planes, nsample
+        assert share_planes == 8
+        self.linear_q = nn.Linear(in_planes, mid_planes)
+        self.linear_k = nn.Linear(in_planes, mid_planes)
+        self.linear_v = nn.Linear(in_planes, out_planes)
+        self.linear_p = nn.Sequential(nn.Linear(3, 3), nn.BatchNorm1d(3), nn.ReLU(inplace=True), nn.Linear(3, out_planes))
+        self.linear_w = nn.Sequential(nn.BatchNorm1d(mid_planes), nn.ReLU(inplace=True), nn.Linear(mid_planes, mid_planes // share_planes),
+                                      nn.BatchNorm1d(mid_planes // share_planes), nn.ReLU(inplace=True),
+                                      nn.Linear(out_planes // share_planes, out_planes // share_planes))
+        self.softmax = nn.Softmax(dim=1)
+        self._d = _Derived()
+
+    def _derived(self):
+        ps = [p for p in self.parameters()] + [b for b in self.buffers()]
+
+        def build():
+            d = lambda t: t.detach().contiguous()
+            wqkv = torch.cat([d(self.linear_q.weight), d(self.linear_k.weight), d(self.linear_v.weight)], 0).contiguous()
+            bqkv = torch.cat([d(self.linear_q.bias), d(self.linear_k.bias), d(self.linear_v.bias)], 0).contiguous()
+            sp, tp = fold_bn(self.linear_p[1])
+            s0, t0 = fold_bn(self.linear_w[0])
+            s3, t3 = fold_bn(self.linear_w[3])
+            params = [d(self.linear_p[0].weight), d(self.linear_p[0].bias), sp, tp, d(self.linear_p[3].weight), d(self.linear_p[3].bias),
+                      s0, t0, d(self.linear_w[2].weight).t().contiguous(), d(self.linear_w[2].bias), s3, t3,
+                      d(self.linear_w[5].weight), d(self.linear_w[5].bias)]
+            return wqkv, bqkv, params
+
+        return self._d.get(ps, build)
+
+    def forward(self, pxo, out_bn=None) -> torch.Tensor:
+        p, x, o = pxo
+        wqkv, bqkv, params = self._derived()
+        qkv = ops.linear(x, wqkv, bias=bqkv)
+        idx = pointops.knnquery(self.nsample, p, p, o, o)[0]
+        return ops.pt_attention(p, qkv, self.out_planes, idx, params + list(out_bn if out_bn is not None else (None, None)), self.nsample)
+
+
+class TransitionDown(nn.Module):
+    """pointtransformer_seg.py:40-68."""
+
+    def __init__(self, in_planes, out_planes, stride=1, nsample=16):
+        super().__init__()
+        self.stride, self.nsample = stride, nsample
+        if stride != 1:
+            self.linear = nn.Linear(3 + in_planes, out_planes, bias=False)
+            self.pool = nn.MaxPool1d(nsample)
+        else:
+            self.linear = nn.Linear(in_planes, out_planes, bias=False)
+        self.bn = nn.BatchNorm1d(out_planes)
+        self.relu = nn.ReLU(inplace=True)
+        self._d = _Derived()
+
+    def forward(self, pxo):
+        p, x, o = pxo
+        s, t = self._d.get([self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var], lambda: fold_bn(self.bn))
+        w = self.linear.weight.detach()
+        if self.stride != 1:
+            oh = pointops.host_offsets(o)
+            n_o, count = [oh[0] // self.stride], oh[0] // self.stride
+            for i in range(1, len(oh)):
+                count += (oh[i] - oh[i - 1]) // self.stride
+                n_o.append(count)
+            n_o_t = torch.tensor(n_o, dtype=torch.int32, device=p.device)
+            pointops._host_cache[(n_o_t.data_ptr(), n_o_t._version, n_o_t.shape[0])] = n_o
+            idx = pointops.furthestsampling(p, o, n_o_t)
+            n_p = ops.gather_rows(p, idx)
+            kidx = pointops.knnquery(self.nsample, p, n_p, o, n_o_t)[0]
+            g = ops.pt_group(p, n_p, x, kidx)                                  # (m*ns, 3+c)
+            y = ops.linear(g, w, scale=s, shift=t, act="relu")                 # Linear -> BN -> ReLU
+            x = ops.rows_maxpool(y, self.nsample)
+            p, o = n_p, n_o_t
+        else:
+            x = ops.linear(x, w, scale=s, shift=t, act="relu")
+        return [p, x, o]
+
+
+class TransitionUp(nn.Module):
+    """pointtransformer_seg.py:71-98."""
+
+    def __init__(self, in_planes, out_planes=None):
+        super().__init__()
+        if out_planes is None:
+            self.linear1 = nn.Sequential(nn.Linear(2 * in_planes, in_planes), nn.BatchNorm1d(in_planes), nn.ReLU(inplace=True))
+            self.linear2 = nn.Sequential(nn.Linear(in_planes, in_planes), nn.ReLU(inplace=True))
+        else:
+            self.linear1 = nn.Sequential(nn.Linear(out_planes, out_planes), nn.BatchNorm1d(out_planes), nn.ReLU(inplace=True))
+            self.linear2 = nn.Sequential(nn.Linear(in_planes, out_planes), nn.BatchNorm1d(out_planes), nn.ReLU(inplace=True))
+        self._d = _Derived()
+
+    def _bn(self):
+        bns = [m for m in (self.linear1[1], self.linear2[1] if len(self.linear2) > 2 else None) if m is not None]
+        ts = [t for m in bns for t in (m.weight, m.bias, m.running_mean, m.running_var)]
+        return self._d.get(ts, lambda: [fold_bn(m) for m in bns])
+
+    def forward(self, pxo1, pxo2=None):
+        folded = self._bn()
+        l1 = self.linear1[0]
+        if pxo2 is None:
+            _, x, o = pxo1
+            nseg = o.shape[0]
+            g = ops.seg_mean(x, o, nseg)
+            g = ops.linear(g, self.linear2[0].weight.detach(), bias=self.linear2[0].bias.detach(), act="relu")
+            xc = ops.concat_bcast(x, g, o, nseg)
+            s, t = folded[0]
+            return ops.linear(xc, l1.weight.detach(), bias=l1.bias.detach(), scale=s, shift=t, act="relu")
+        p1, x1, o1 = pxo1
+        p2, x2, o2 = pxo2
+        (s1, t1), (s2, t2) = folded
+        a = ops.linear(x1, l1.weight.detach(), bias=l1.bias.detach(), scale=s1, shift=t1, act="relu")
+        b = ops.linear(x2, self.linear2[0].weight.detach(), bias=self.linear2[0].bias.detach(), scale=s2, shift=t2, act="relu")
+        return pointops.interpolation(p2, p1, b, o2, o1, add_to=a)
+
+
+class PointTransformerBlock(nn.Module):
+    """pointtransformer_seg.py:101-122."""
+    expansion = 1
+
+    def __init__(self, in_planes, planes, share_planes=8, nsample=16):
+        super().__init__()
+        self.linear1 = nn.Linear(in_planes, planes, bias=False)
+        self.bn1 = nn.BatchNorm1d(planes)
+        self.transformer2 = PointTransformerLayer(planes, planes, share_planes, nsample)
+        self.bn2 = nn.BatchNorm1d(planes)
+        self.linear3 = nn.Linear(planes, planes * self.expansion, bias=False)
+        self.bn3 = nn.BatchNorm1d(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self._d = _Derived()
+
+    def forward(self, pxo):
+        p, x, o = pxo
+        bns = (self.bn1, self.bn2, self.bn3)
+        f = self._d.get([t for m in bns for t in (m.weight, m.bias, m.running_mean, m.running_var)], lambda: [fold_bn(m) for m in bns])
+        y = ops.linear(x, self.linear1.weight.detach(), scale=f[0][0], shift=f[0][1], act="relu")
+        y = self.transformer2([p, y, o], out_bn=f[1])                                     # bn2 + relu fused into the kernel tail
+        y = ops.linear(y, self.linear3.weight.detach(), scale=f[2][0], shift=f[2][1], res=x, res_mode=1, act="relu")
+        return [p, y, o]
+
+
+class _PointTransformerBase(nn.Module):
+    def _make_enc(self, block, planes, blocks, share_planes=8, stride=1, nsample=16):
+        layers = [TransitionDown(self.in_planes, planes * block.expansion, stride, nsample)]
+        self.in_planes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.in_planes, self.in_planes, share_planes, nsample=nsample))
+        return nn.Sequential(*layers)
+
+    def _make_dec(self, block, planes, blocks, share_planes=8, nsample=16, is_head=False):
+        layers = [TransitionUp(self.in_planes, None if is_head else planes * block.expansion)]
+        self.in_planes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.in_planes, self.in_planes, share_planes, nsample=nsample))
+        return nn.Sequential(*layers)
+
+    def _build(self, block, blocks, c, planes):
+        self.in_planes = c
+        share_planes = 8
+        stride, nsample = [1, 4, 4, 4, 4], [8, 16, 16, 16, 16]
+        for i in range(5):
+            setattr(self, f"enc{i + 1}", self._make_enc(block, planes[i], blocks[i], share_planes, stride=stride[i], nsample=nsample[i]))
+        self.dec5 = self._make_dec(block, planes[4], 2, share_planes, nsample=nsample[4], is_head=True)
+        for i in (3, 2, 1, 0):
+            setattr(self, f"dec{i + 1}", self._make_dec(block, planes[i], 2, share_planes, nsample=nsample[i]))
+
+    def _unet(self, pxo):
+        p0, x0, o0 = pxo
+        x0 = p0 if self.c == 3 else torch.cat((p0, x0), 1)
+        p1, x1, o1 = self.enc1([p0, x0, o0])
+        p2, x2, o2 = self.enc2([p1, x1, o1])
+        p3, x3, o3 = self.enc3([p2, x2, o2])
+        p4, x4, o4 = self.enc4([p3, x3, o3])
+        p5, x5, o5 = self.enc5([p4, x4, o4])
+        x5 = self.dec5[1:]([p5, self.dec5[0]([p5, x5, o5]), o5])[1]
+        x4 = self.dec4[1:]([p4, self.dec4[0]([p4, x4, o4], [p5, x5, o5]), o4])[1]
+        x3 = self.dec3[1:]([p3, self.dec3[0]([p3, x3, o3], [p4, x4, o4]), o3])[1]
+        x2 = self.dec2[1:]([p2, self.dec2[0]([p2, x2, o2], [p3, x3, o3]), o2])[1]
+        x1 = self.dec1[1:]([p1, self.dec1[0]([p1, x1, o1], [p2, x2, o2]), o1])[1]
+        return x1
+
+
+class PointTransformer_confidence(_PointTransformerBase):
+    """pointtransformer_seg.py:125-195."""
+    CONFI_CHUNK = 16384   # rows per pass of the 128 -> 128*k hidden layer (keeps the hidden tile in L2/MALL)
+
+    def __init__(self, block, blocks, c=6, k=13):
+        super().__init__()
+        self.c, self.k = c, k
+        planes = [128, 128, 256, 256, 512]
+        self._build(block, blocks, c, planes)
+        self.cls = nn.Sequential(nn.Conv1d(planes[0], planes[0], 1), nn.BatchNorm1d(planes[0]), nn.ReLU(), nn.Conv1d(planes[0], k, 1))
+        self.confi = nn.Sequential(nn.Conv1d(planes[0], planes[0] * k, 1), nn.ReLU(), nn.Conv1d(planes[0] * k, 1 * k, 1, groups=k))
+        self._d = _Derived()
+
+    def forward(self, pxo):
+        p0, x0, o0 = pxo
+        B = o0.shape[0]
+        N = p0.shape[0] // B
+        with pointops.knn_scope():
+            x1 = self._unet(pxo)                                                     # (B*N, 128)
+        s, t = self._d.get([self.cls[1].weight, self.cls[1].bias, self.cls[1].running_mean, self.cls[1].running_var], lambda: fold_bn(self.cls[1]))
+        h = ops.linear(x1, self.cls[0].weight.detach().view(self.cls[0].out_channels, -1), bias=self.cls[0].bias.detach(), scale=s, shift=t, act="relu")
+        logits = ops.linear(h, self.cls[3].weight.detach().view(self.k, -1), bias=self.cls[3].bias.detach())          # (B*N, k)
+        w0 = self.confi[0].weight.detach().view(self.confi[0].out_channels, -1)
+        b0 = self.confi[0].bias.detach()
+        w2 = self.confi[2].weight.detach().view(self.k, -1).contiguous()
+        b2 = self.confi[2].bias.detach()
+        J = w2.shape[1]
+        R = x1.shape[0]
+        conf_k = torch.empty((R, self.k), dtype=torch.float32, device=x1.device)
+        for r0 in range(0, R, self.CONFI_CHUNK):
+            r1 = min(R, r0 + self.CONFI_CHUNK)
+            hid = ops.linear(x1[r0:r1], w0, bias=b0, act="relu")                     # (chunk, 128*k)
+            ops.grouped_dot(hid, w2, b2, self.k, J, out=conf_k[r0:r1])
+        conf = ops.softmax_dot(logits, conf_k)
+        return logits.view(B, N, self.k), conf.view(B, N, 1)
+
+
+class PointTransformer_magnitude(_PointTransformerBase):
+    """pointtransformer_seg.py:199-260."""
+
+    def __init__(self, block, blocks, c=6, k=1):
+        super().__init__()
+        self.c = c
+        assert k == 1, "Please check output dim of PointTransformer_magnitude"
+        planes = [64, 128, 256, 256, 512]
+        self._build(block, blocks, c, planes)
+        self.final_layer = nn.Sequential(nn.Linear(planes[0], planes[0]), nn.BatchNorm1d(planes[0]), nn.ReLU(inplace=True), nn.Linear(planes[0], 1))
+        self._d = _Derived()
+
+    def forward(self, pxo):
+        p0, x0, o0 = pxo
+        B = o0.shape[0]
+        N = p0.shape[0] // B
+        with pointops.knn_scope():
+            x1 = self._unet(pxo)
+        fl = self.final_layer
+        s, t = self._d.get([fl[1].weight, fl[1].bias, fl[1].running_mean, fl[1].running_var], lambda: fold_bn(fl[1]))
+        h = ops.linear(x1, fl[0].weight.detach(), bias=fl[0].bias.detach(), scale=s, shift=t, act="relu")
+        y = ops.linear(h, fl[3].weight.detach(), bias=fl[3].bias.detach())           # (B*N, 1)
+        return y.view(B, N, 1)
+
+
+def get_pointtransformer_confidence(**kwargs):
+    return PointTransformer_confidence(PointTransformerBlock, [2, 3, 4, 6, 3], **kwargs)
+
+
+def get_pointtransformer_magnitude(**kwargs):
+    return PointTransformer_magnitude(PointTransformerBlock, [2, 3, 4, 6, 3], **kwargs)

@@ -236,3 +236,74 @@ def so3_mean_dir(w, anchors, want_R=False, want_sv=False):
     sv = torch.empty((T, 3), dtype=torch.float32, device=w.device) if want_sv else None
     _lib.check(_lib.lib().etch_so3_mean_dir(_c_long(T), A, _ptr(w), _ptr(anchors), _ptr(d), _optptr(R), _optptr(sv), _stream()), "etch_so3_mean_dir")
     return d, R, sv
+
+
+# ------------------------------------------------------------------ Point-Transformer pieces
+def pt_attention(p, qkv, c, idx, params, ns):
+    """qkv [n,3c] (q|k|v) ; params: list of 16 tensors-or-None -> out [n,c]."""
+    n = p.shape[0]
+    out = torch.empty((n, c), dtype=torch.float32, device=p.device)
+    arr = (ctypes.c_void_p * 16)(*[(0 if t is None else t.data_ptr()) for t in params])
+    base = qkv.data_ptr()
+    _lib.check(_lib.lib().etch_pt_attention(n, c, ns, _ptr(p), _vp(base), _vp(base + 4 * c), _vp(base + 8 * c), _c_long(qkv.stride(0)),
+                                            _ptr(idx), arr, _ptr(out), _c_long(c), _stream()), "etch_pt_attention")
+    return out
+
+
+def pt_group(p, new_p, x, idx):
+    m, ns = idx.shape
+    c = x.shape[1]
+    out = torch.empty((m * ns, 3 + c), dtype=torch.float32, device=p.device)
+    _lib.check(_lib.lib().etch_pt_group(m, ns, c, _ptr(p), _ptr(new_p), _ptr(x), _c_long(x.stride(0)), _ptr(idx), _ptr(out), _stream()), "etch_pt_group")
+    return out
+
+
+def gather_rows(x, idx):
+    m, c = idx.shape[0], x.shape[1]
+    out = torch.empty((m, c), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().etch_gather_rows(m, c, _ptr(x), _c_long(x.stride(0)), _ptr(idx), _ptr(out), _stream()), "etch_gather_rows")
+    return out
+
+
+def rows_maxpool(x, ns):
+    m, c = x.shape[0] // ns, x.shape[1]
+    out = torch.empty((m, c), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().etch_rows_maxpool(m, ns, c, _ptr(x), _ptr(out), _stream()), "etch_rows_maxpool")
+    return out
+
+
+def pt_interp_add(a, f, idx, dist):
+    n, c = a.shape
+    out = torch.empty_like(a)
+    _lib.check(_lib.lib().etch_pt_interp_add(n, c, _ptr(a), _ptr(f), _ptr(idx), _ptr(dist), _ptr(out), _stream()), "etch_pt_interp_add")
+    return out
+
+
+def seg_mean(x, offset, nseg):
+    c = x.shape[1]
+    out = torch.empty((nseg, c), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().etch_seg_mean(nseg, c, _ptr(x), _ptr(offset), _ptr(out), _stream()), "etch_seg_mean")
+    return out
+
+
+def concat_bcast(x, g, offset, nseg):
+    n, c = x.shape
+    out = torch.empty((n, 2 * c), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().etch_concat_bcast(n, c, nseg, _ptr(x), _ptr(g), _ptr(offset), _ptr(out), _stream()), "etch_concat_bcast")
+    return out
+
+
+def grouped_dot(h, w, bias, G, J, out=None):
+    R = h.shape[0]
+    if out is None:
+        out = torch.empty((R, G), dtype=torch.float32, device=h.device)
+    _lib.check(_lib.lib().etch_grouped_dot(_c_long(R), G, J, _ptr(h), _c_long(h.stride(0)), _ptr(w), _ptr(bias), _ptr(out), _c_long(out.stride(0)),
+                                           _stream()), "etch_grouped_dot")
+    return out
+
+
+def softmax_dot(logits, v):
+    R, G = logits.shape
+    out = torch.empty((R,), dtype=torch.float32, device=logits.device)
+    _lib.check(_lib.lib().etch_softmax_dot(_c_long(R), G, _ptr(logits), _ptr(v), _ptr(out), _stream()), "etch_softmax_dot")
+    return out

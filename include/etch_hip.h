@@ -115,6 +115,43 @@ int etch_rowdot(long R, int K, const float* x, long ldx, const float* w, float b
  * -> dir (T,3); optional R (T,3,3) and singular values sv (T,3) (NULL to skip). */
 int etch_so3_mean_dir(long T, int A, const float* w, const float* anchors, float* dir, float* R, float* sv, void* stream);
 
+/* ---- Point-Transformer heads (src/models/pointtransformer_seg.py) ------------------------------------------ */
+
+/* PointTransformerLayer.forward after the q/k/v Linear layers (pointtransformer_seg.py:28-36; grouping as
+ * src/models/pointops.py:79-100).  p (n,3); xq/xk/xv rows with leading dimension ldq; idx (n,ns) kNN indices;
+ * params = 14 device pointers: linear_p[0] W(3x3), b(3); BN(3) folded scale, shift; linear_p[3] W(c,3), b(c);
+ * linear_w[0] BN(c) scale, shift; linear_w[2] W TRANSPOSED (c, c/8), b(c/8); linear_w[3] BN(c/8) scale, shift;
+ * linear_w[5] W(c/8,c/8), b(c/8); then an optional output BN(c) scale, shift (+ReLU) = block.bn2 (:117), NULL to skip
+ * (16 pointers in total).  -> out (n,c) rows with leading dimension ldo. */
+int etch_pt_attention(int n, int c, int ns, const float* p, const float* xq, const float* xk, const float* xv, long ldq,
+                      const int* idx, const float* const* params, float* out, long ldo, void* stream);
+
+/* queryandgroup(use_xyz=True) rows for TransitionDown (pointtransformer_seg.py:61, pointops.py:90-98):
+ * out[(i*ns+j)] = [p[idx[i,j]] - new_p[i] | x[idx[i,j]]], row length 3+c. */
+int etch_pt_group(int m, int ns, int c, const float* p, const float* new_p, const float* x, long ldx, const int* idx,
+                  float* out, void* stream);
+
+/* Row gather n_p = p[idx] (pointtransformer_seg.py:60): out[i,:c] = x[idx[i],:c]. */
+int etch_gather_rows(int m, int c, const float* x, long ldx, const int* idx, float* out, void* stream);
+
+/* MaxPool1d(nsample) over consecutive row groups (pointtransformer_seg.py:63): x (m*ns, c) -> out (m, c). */
+int etch_rows_maxpool(int m, int ns, int c, const float* x, float* out, void* stream);
+
+/* TransitionUp tail (pointtransformer_seg.py:97, pointops.py:164-178): out = a + sum_k w_k f[idx_k],
+ * w = (1/(dist+1e-8))/sum with the NON-squared kNN distances.  a,out (n,c); f (m,c); idx,dist (n,3). */
+int etch_pt_interp_add(int n, int c, const float* a, const float* f, const int* idx, const float* dist, float* out, void* stream);
+
+/* TransitionUp head branch (pointtransformer_seg.py:83-93): per-segment mean, and [x | g[segment]] concat. */
+int etch_seg_mean(int nseg, int c, const float* x, const int* offset, float* mean, void* stream);
+int etch_concat_bcast(int n, int c, int nseg, const float* x, const float* g, const int* offset, float* out, void* stream);
+
+/* confi[2]: Conv1d(G*J, G, 1, groups=G) (pointtransformer_seg.py:145): out[r,g] = h[r, g*J:(g+1)*J] . w[g] + b[g]. */
+int etch_grouped_dot(long R, int G, int J, const float* h, long ldh, const float* w, const float* bias, float* out, long ldo,
+                     void* stream);
+
+/* confidence = sum_g softmax(logits)_g * v_g (pointtransformer_seg.py:183-189): (R,G),(R,G) -> (R). */
+int etch_softmax_dot(long R, int G, const float* logits, const float* v, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
