@@ -21,6 +21,22 @@ def declared_symbols():
     return sorted(set(re.findall(r"\bint\s+(etch_\w+)\s*\(", txt)))
 
 
+class _Proxy:
+    """Attribute access -> C function.  When a profiler callback is installed (bench.py) every call is
+    bracketed by HIP events on the current stream; otherwise the raw ctypes function is returned."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+        self.profiler = None      # callable(name, args, fn) -> status
+
+    def __getattr__(self, name):
+        fn = getattr(self._cdll, name)
+        if self.profiler is None:
+            return fn
+        prof = self.profiler
+        return lambda *a: prof(name, a, fn)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -28,10 +44,11 @@ def lib():
             raise EtchHipError(
                 f"{LIB_PATH} is missing: build it with `python -m etch_amd.build` (hipcc, gfx950). "
                 "etch_amd has no CPU fallback.")
-        _lib = ctypes.CDLL(LIB_PATH)
+        cdll = ctypes.CDLL(LIB_PATH)
         for name in declared_symbols():
-            fn = getattr(_lib, name)  # AttributeError if the library does not export a declared symbol
+            fn = getattr(cdll, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = ctypes.c_int
+        _lib = _Proxy(cdll)
     return _lib
 
 

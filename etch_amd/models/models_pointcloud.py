@@ -11,6 +11,7 @@ from torch import nn
 from .. import ops
 from ..config.EPN_options import get_default_cfg
 from .direction_backbones import BatchMLP, StackedMHSA
+from . import pointops
 from .pointnet2_utils import propagate_cl
 from .pointtransformer_seg import get_pointtransformer_confidence, get_pointtransformer_magnitude
 from .so3net import build_model
@@ -53,7 +54,8 @@ class GT_network_equiv(nn.Module):
         B, N, C = features.shape
         p = xyz.reshape(-1, 3)
         x = features.reshape(-1, C)
-        o = torch.tensor([N * (i + 1) for i in range(B)], dtype=torch.int32).to(p.device)
+        oh = [N * (i + 1) for i in range(B)]
+        o = pointops.set_host_offsets(torch.tensor(oh, dtype=torch.int32).to(p.device), oh)
         return p, x, o
 
     def decode_confidence(self, inv_feat, xyz):

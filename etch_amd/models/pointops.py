@@ -8,19 +8,22 @@ import torch
 
 from .. import ops
 
-_host_cache = {}
 _knn_cache = None  # dict while a Point-Transformer forward is active
 
 
 def host_offsets(o):
-    key = (o.data_ptr(), o._version, o.shape[0])
-    v = _host_cache.get(key)
-    if v is None:
-        if len(_host_cache) > 64:
-            _host_cache.clear()
+    """Host copy of an offset tensor, memoised ON the tensor object (never by address: freed offsets get re-used)."""
+    v = getattr(o, "_etch_host", None)
+    if v is None or getattr(o, "_etch_host_version", -1) != o._version:
         v = [int(t) for t in o.tolist()]
-        _host_cache[key] = v
+        set_host_offsets(o, v)
     return v
+
+
+def set_host_offsets(o, values):
+    o._etch_host = list(values)
+    o._etch_host_version = o._version
+    return o
 
 
 class knn_scope:

@@ -84,7 +84,7 @@ class TransitionDown(nn.Module):
                 count += (oh[i] - oh[i - 1]) // self.stride
                 n_o.append(count)
             n_o_t = torch.tensor(n_o, dtype=torch.int32, device=p.device)
-            pointops._host_cache[(n_o_t.data_ptr(), n_o_t._version, n_o_t.shape[0])] = n_o
+            pointops.set_host_offsets(n_o_t, n_o)
             idx = pointops.furthestsampling(p, o, n_o_t)
             n_p = ops.gather_rows(p, idx)
             kidx = pointops.knnquery(self.nsample, p, n_p, o, n_o_t)[0]

@@ -307,3 +307,45 @@ def softmax_dot(logits, v):
     out = torch.empty((R,), dtype=torch.float32, device=logits.device)
     _lib.check(_lib.lib().etch_softmax_dot(_c_long(R), G, _ptr(logits), _ptr(v), _ptr(out), _stream()), "etch_softmax_dot")
     return out
+
+
+# ------------------------------------------------------------------ stage 2
+def argmax_rows(logits):
+    """(..., G) float32 -> (...) int64, first maximum (torch.max semantics)."""
+    _need(logits, torch.float32, "logits")
+    G = logits.shape[-1]
+    R = logits.numel() // G
+    out = torch.empty(logits.shape[:-1], dtype=torch.int64, device=logits.device)
+    _lib.check(_lib.lib().etch_argmax_rows(_c_long(R), G, _ptr(logits), _ptr(out), _stream()), "etch_argmax_rows")
+    return out
+
+
+def get_markers(points, labels, conf, num_markers):
+    _need(points, torch.float32, "points"), _need(labels, torch.int64, "labels"), _need(conf, torch.float32, "conf")
+    B, K = labels.shape
+    markers = torch.empty((B, num_markers, 3), dtype=torch.float32, device=points.device)
+    valid_f = torch.empty((B, num_markers), dtype=torch.float32, device=points.device)
+    valid_b = torch.empty((B, num_markers), dtype=torch.bool, device=points.device)
+    _lib.check(_lib.lib().etch_get_markers(B, K, num_markers, _ptr(points), _ptr(labels), _ptr(conf), _ptr(markers), _ptr(valid_f),
+                                           _ptr(valid_b), _stream()), "etch_get_markers")
+    return markers, valid_f, valid_b
+
+
+def smpl_lm_fit(consts, markers, valid_f, it0, step0, damp0, it1, step1, damp1, want_trace=False):
+    B, M = valid_f.shape
+    arr = (ctypes.c_void_p * 7)(*[t.data_ptr() for t in consts])
+    x = torch.empty((B, 85), dtype=torch.float32, device=markers.device)
+    x0 = torch.empty((B, 85), dtype=torch.float32, device=markers.device)
+    tr = torch.zeros((B, it0 + it1 + 2), dtype=torch.float32, device=markers.device) if want_trace else None
+    _lib.check(_lib.lib().etch_smpl_lm_fit(B, M, arr, _ptr(markers), _ptr(valid_f), int(it0), _c_float(step0), _c_float(damp0), int(it1),
+                                           _c_float(step1), _c_float(damp1), _ptr(x), _ptr(x0), _optptr(tr), _stream()), "etch_smpl_lm_fit")
+    return x, x0, tr
+
+
+def smpl_lbs(consts, x, V, n_extra):
+    B = x.shape[0]
+    arr = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in consts])
+    verts = torch.empty((B, V, 3), dtype=torch.float32, device=x.device)
+    joints = torch.empty((B, 24 + n_extra, 3), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().etch_smpl_lbs(B, V, n_extra, arr, _ptr(x), _ptr(verts), _ptr(joints), _stream()), "etch_smpl_lbs")
+    return verts, joints

@@ -1,0 +1,78 @@
+"""Body-model containers for stage 2 (SMPL marker fit).
+
+`SyntheticSMPL(seed)` builds a seeded SMPL-SHAPED model (V = 6890, J = 24 with the public SMPL parent table,
+10 betas, 207 pose-basis rows, <= 4 non-zero skinning weights per vertex): the licensed SMPL .pkl files the
+reference loads (src/models/fit_SMPL.py:92-101) are not redistributable and absent here.  `load_smpl_pkl`
+reads a real chumpy-free SMPL pickle when the user has one.  Array names follow smplx.SMPL buffers
+(v_template, shapedirs, posedirs, J_regressor, lbs_weights, parents, faces) [upstream smplx, not in the tree].
+"""
+import pickle
+
+import numpy as np
+
+SMPL_PARENTS = np.array([-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21], np.int32)
+# 21 vertex-picked joints appended by smplx's VertexJointSelector for SMPL (nose, eyes, ears, feet, finger tips)
+SMPL_EXTRA_JOINT_VIDS = np.array([332, 6260, 2800, 4071, 583, 3216, 3226, 3387, 6617, 6624, 6787,
+                                  2746, 2319, 2445, 2556, 2673, 6191, 5782, 5905, 6016, 6133], np.int32)
+
+
+class BodyModel:
+    """Plain numpy container (fp32)."""
+
+    def __init__(self, v_template, shapedirs, posedirs, J_regressor, lbs_weights, parents, faces, extra_vids=SMPL_EXTRA_JOINT_VIDS):
+        self.v_template = np.ascontiguousarray(v_template, np.float32)          # (V,3)
+        self.shapedirs = np.ascontiguousarray(shapedirs, np.float32)            # (V,3,NB)
+        self.posedirs = np.ascontiguousarray(posedirs, np.float32)              # (9*(J-1), V*3)
+        self.J_regressor = np.ascontiguousarray(J_regressor, np.float32)        # (J,V)
+        self.lbs_weights = np.ascontiguousarray(lbs_weights, np.float32)        # (V,J)
+        self.parents = np.ascontiguousarray(parents, np.int32)
+        self.faces = np.ascontiguousarray(faces, np.int32)
+        self.extra_vids = np.ascontiguousarray(extra_vids, np.int32)
+        self.num_betas = self.shapedirs.shape[2]
+        self.NUM_BODY_JOINTS = len(self.parents) - 1
+
+    @property
+    def num_verts(self):
+        return self.v_template.shape[0]
+
+    @property
+    def num_joints(self):
+        return len(self.parents)
+
+
+def SyntheticSMPL(seed=7, V=6890, NB=10):
+    rng = np.random.default_rng(seed)
+    J = len(SMPL_PARENTS)
+    v_t = rng.standard_normal((V, 3)) * np.array([0.15, 0.45, 0.10])
+    # a crude skeleton: joint centres = random vertices; weights = softmax over the 4 nearest joints
+    cent = v_t[rng.choice(V, J, replace=False)]
+    d2 = ((v_t[:, None] - cent[None]) ** 2).sum(-1)
+    near = np.argsort(d2, 1)[:, :4]
+    w = np.exp(-np.take_along_axis(d2, near, 1) / 0.01)
+    w /= w.sum(1, keepdims=True)
+    W = np.zeros((V, J))
+    np.put_along_axis(W, near, w, 1)
+    Jreg = np.zeros((J, V))
+    for j in range(J):
+        Jreg[j, np.argsort(d2[:, j])[:50]] = 1.0 / 50
+    S = rng.standard_normal((V, 3, NB)) * 0.01
+    P = rng.standard_normal((9 * (J - 1), V * 3)) * 0.001
+    faces = np.stack([np.arange(V - 2), np.arange(1, V - 1), np.arange(2, V)], 1)[: 2 * V - 4 - (V - 2)]  # a strip, only for OBJ export
+    faces = np.concatenate([faces, faces[:, ::-1]])[:13776]
+    return BodyModel(v_t, S, P, Jreg, W, SMPL_PARENTS, faces)
+
+
+def load_smpl_pkl(path, num_betas=10):
+    """Chumpy-free SMPL pickle (e.g. SMPL_NEUTRAL_10pc_rmchumpy.pkl): keys v_template, shapedirs, posedirs (V,3,207),
+    J_regressor (sparse or dense), weights, kintree_table, f."""
+    with open(path, "rb") as f:
+        d = pickle.load(f, encoding="latin1")
+    Jr = d["J_regressor"]
+    Jr = np.asarray(Jr.todense()) if hasattr(Jr, "todense") else np.asarray(Jr)
+    posedirs = np.asarray(d["posedirs"])
+    Vn = posedirs.shape[0]
+    posedirs = posedirs.reshape(Vn * 3, -1).T                                  # smplx: (207, V*3)
+    parents = np.asarray(d["kintree_table"])[0].astype(np.int64).copy()
+    parents[0] = -1
+    return BodyModel(np.asarray(d["v_template"]), np.asarray(d["shapedirs"])[:, :, :num_betas], posedirs, Jr, np.asarray(d["weights"]),
+                     parents, np.asarray(d["f"]))

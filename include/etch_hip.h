@@ -152,6 +152,33 @@ int etch_grouped_dot(long R, int G, int J, const float* h, long ldh, const float
 /* confidence = sum_g softmax(logits)_g * v_g (pointtransformer_seg.py:183-189): (R,G),(R,G) -> (R). */
 int etch_softmax_dot(long R, int G, const float* logits, const float* v, float* out, void* stream);
 
+/* ---- stage 2: markers + SMPL Levenberg-Marquardt fit ------------------------------------------------------ */
+
+/* torch.max(part_labels, -1) of predict_smpl (src/inference_demo.py:52-53): logits (R,G) -> int64 labels (R). */
+int etch_argmax_rows(long R, int G, const float* logits, long long* out, void* stream);
+
+/* get_markers (src/models/fit_SMPL.py:17-62): pts (B,K,3), labels (B,K) i64, conf (B,K,1) -> markers (B,M,3),
+ * valid as float (B,M) and/or as bool bytes (B,M) (either may be NULL).  Per (scan,label): top-3 confidences,
+ * weights conf^20, weighted centre; empty label -> zeros + invalid. */
+int etch_get_markers(int B, int K, int M, const float* pts, const long long* labels, const float* conf, float* markers,
+                     float* valid_f, unsigned char* valid_b, void* stream);
+
+/* fit_smpl's two Levenberg-Marquardt stages (src/models/fit_SMPL.py:161-249; Theseus LM + smplx LBS upstream).
+ * consts = 7 device pointers {J0 (24,3) = J_regressor @ v_template, Jd (24,3,10) = J_regressor @ shapedirs,
+ * parents (24) i32, and for the M marker vertices: v_template rows (M,3), shapedirs rows (M,3,10),
+ * posedirs columns as (M,207,3), lbs_weights rows (M,24)}.  markers (B,M,3), valid (B,M) float mask.
+ * Stage 0: it0 iterations, step0, damp0 over pose|betas[:2]|orient|transl; stage 1: it1, step1, damp1 over all 85.
+ * -> x_out (B,85) = pose(69) | betas(10) | global_orient(3) | transl(3); optional x_stage0 (B,85) and
+ * err_trace (B, it0+it1+2) = 0.5|r|^2 before/after every iteration of both stages. */
+int etch_smpl_lm_fit(int B, int M, const void* const* consts, const float* markers, const float* valid, int it0, float step0,
+                     float damp0, int it1, float step1, float damp1, float* x_out, float* x_stage0, float* err_trace, void* stream);
+int etch_smpl_lm_workspace_bytes(void);
+
+/* Final smpl_model(...) (fit_SMPL.py:258-259, smplx.SMPL.forward upstream): x (B,85) -> verts (B,V,3), joints
+ * (B,24+n_extra,3).  consts = 8 device pointers {v_template (V,3), shapedirs (V,3,10), posedirs (207,V*3),
+ * lbs_weights (V,24), J0, Jd, parents, extra_vids (n_extra) i32}. */
+int etch_smpl_lbs(int B, int V, int n_extra, const void* const* consts, const float* x, float* verts, float* joints, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
