@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the ETCH hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One step = one pass of the full hot path over one batch of synthetic scans already resident in HBM:
+  stage 1  GT_network_equiv.forward (EPN encoder + confidence / direction / magnitude heads)
+  glue     argmax labels, inner points = points - direction * magnitude / 10
+  stage 2  get_markers + (30 + 50)-iteration LM SMPL fit + final full-mesh LBS
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 32 scans x 5000 points per GPU
+(weak scaling: every rank processes its own 32 scans; no collective on the data path; one RCCL all_gather of the
+per-scan result rows at the end of the job).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import collections
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_*_f32)
+HBM_PEAK_GBS = 8000.0
+
+
+def synth_scan(global_index, n):
+    """rng(1000 + b).standard_normal((N,3)) * (0.14, 0.31, 0.085), fp32."""
+    return (np.random.default_rng(1000 + global_index).standard_normal((n, 3)) * np.array([0.14, 0.31, 0.085])).astype(np.float32)
+
+
+def build(device, seed=1):
+    from etch_amd import constants as K
+    from etch_amd.models.models_pointcloud import GT_network_equiv
+    from etch_amd.utils.body_model import SyntheticSMPL
+    from etch_amd.utils.weights import load_seeded
+
+    args = types.SimpleNamespace(output_folder=os.path.join("/tmp", f"etch_bench_{os.getpid()}"), EPN_input_radius=0.4, EPN_layer_num=2,
+                                 device=device, markerset=K.default_markerset(), scale_magnitude=10, body_model=SyntheticSMPL(7))
+    model = load_seeded(GT_network_equiv(option=args), seed).to(device).eval()
+    return args, model
+
+
+# ------------------------------------------------------------------------------------------------ roofline
+def algorithmic_flops(name, a):
+    """Algorithmic FLOPs of one C-ABI call from its integer arguments (DESIGN.md 'work per launch')."""
+    v = [x.value if hasattr(x, "value") else x for x in a]
+    if name == "etch_linear":
+        R, K, O = v[0], v[1], v[2]
+        return 2.0 * R * K * O, f"gemm_nt_kernel"
+    if name == "etch_inter_so3conv":
+        b, cin, cout, p1, p2, nn = v[0:6]
+        return 2.0 * b * p2 * 60 * 24 * (cin * nn + cout * cin), f"inter_so3conv_kernel<{cin},{cout}>"
+    if name == "etch_intra_so3conv":
+        b, c, cout, p = v[0:4]
+        return 2.0 * b * p * 60 * 12 * c * cout, f"intra_so3conv_kernel<{c},{cout}>"
+    if name == "etch_mhsa_attention":
+        T = v[0]
+        return T * 8 * (2.0 * 60 * 60 * 8 * 2), "mhsa_attention_kernel"
+    return 0.0, name.replace("etch_", "") + "_kernel"
+
+
+def profile_pass(run_step):
+    """One instrumented step: every C-ABI call bracketed by HIP events on the stream it is launched on."""
+    from etch_amd import _lib
+
+    rec = []
+
+    def prof(name, args, fn):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        st = fn(*args)
+        e.record()
+        rec.append((name, args, s, e))
+        return st
+
+    lib = _lib.lib()
+    lib.profiler = prof
+    try:
+        run_step()
+        torch.cuda.synchronize()
+    finally:
+        lib.profiler = None
+    agg = collections.OrderedDict()
+    for name, args, s, e in rec:
+        fl, kern = algorithmic_flops(name, args)
+        d = agg.setdefault(kern, dict(calls=0, ms=0.0, flops=0.0))
+        d["calls"] += 1
+        d["ms"] += s.elapsed_time(e)
+        d["flops"] += fl
+    return agg
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(n_points, gpu_pts, gpu_results, gpu_fit_aux, args, seed=1):
+    """The oracle (CPU restatement = "port") timed on this box's host cores on ONE scan of the same workload:
+    full stage 1 and the full 30 + 50 iteration LM fit.  Also returns parity numbers for that scan."""
+    from etch_amd.models.models_pointcloud import GT_network_equiv
+    from etch_amd.utils.weights import seeded_state_dict
+    from oracle import stage1 as S1
+    from oracle import stage2 as S2
+
+    cores = torch.get_num_threads()
+    cargs = types.SimpleNamespace(**{**vars(args), "device": torch.device("cpu")})
+    sd = seeded_state_dict(GT_network_equiv(option=cargs), seed)
+    table = S1.build_layer_table()
+    x = gpu_pts[:1].cpu()
+    t0 = time.time()
+    out = S1.forward(sd, x, table, num_markers=len(args.markerset))
+    t1 = time.time() - t0
+    labels = out["part_labels"].argmax(-1)
+    inner = x - out["direction"] * out["magnitude"] / args.scale_magnitude
+    mv = np.array(list(args.markerset.values()))
+    t0 = time.time()
+    mk, valid = S2.get_markers(len(args.markerset), inner, labels, out["confidences"])
+    fit = S2.fit_smpl(args.body_model, mv, mk, valid)
+    t2 = time.time() - t0
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+    parity = {k: rel(gpu_results[k][:1].cpu(), out[k]) for k in ("part_labels", "confidences", "magnitude")}
+    parity["label_agreement"] = float((gpu_results["part_labels"][:1].cpu().argmax(-1) == labels).float().mean())
+    # fitter-only parity: the oracle LM on the GPU's own markers of scan 0
+    gm, gv = gpu_fit_aux["markers"][:1].cpu(), gpu_fit_aux["valid"][:1].cpu()
+    fit_g = S2.fit_smpl(args.body_model, mv, gm, gv)
+    v2v = (gpu_fit_aux["verts"][:1].cpu() - fit_g["verts"]).norm(dim=-1).mean()
+    parity["v2v_mm_gpu_vs_oracle_same_markers"] = float(v2v * 1e3)
+    return dict(value=1.0 / (t1 + t2), unit="scans/s", cores=cores, kind="port",
+                sample=f"1 scan x {n_points} pts: oracle stage 1 ({t1:.1f} s) + get_markers + full 30+50-iteration autograd LM fit ({t2:.1f} s), torch CPU fp32"), parity
+
+
+# ------------------------------------------------------------------------------------------------ main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="scans per GPU")
+    ap.add_argument("--points", type=int, default=5000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    from etch_amd import parallel as P
+    from etch_amd.inference_demo import predict_smpl_batch
+
+    rank, world, local = P.init()
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    args, model = build(device)
+    B, N = a.batch, a.points
+    s0, _ = P.shard_range(B * world, rank, world)
+    pts = torch.from_numpy(np.stack([synth_scan(s0 + i, N) for i in range(B)])).to(device)
+    last = {}
+
+    def step():
+        meshes, markers, valid, info, aux = predict_smpl_batch(args, model, pts, "neutral", return_trace=True)
+        last.update(markers=markers, valid=valid, verts=aux["verts"], x=aux["x"], err=aux["err_trace"][:, -1])
+
+    for _ in range(a.warmup):
+        step()
+    P.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    P.barrier()
+    dt = P.max_over_ranks(time.perf_counter() - t0, device)
+
+    # end-of-batch metric reduction: one all_gather of per-scan rows [final LM error, #valid markers, pose/shape norm]
+    rows = torch.stack([last["err"], last["valid"].float().sum(1), last["x"][:, :79].norm(dim=1)], 1)
+    allrows = P.gather_rows(rows)
+
+    if rank != 0:
+        return
+    value = world * B * a.steps / dt
+    out = {"metric": "scans/s (5k pts, eq-net + 50-iter SMPL fit)", "value": round(value, 3), "unit": "scans/s", "n_gpus": world,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"configs[2]: batch={B}/GPU synthetic {N}-pt Gaussian-blob scans, full pipeline (eq-net + 30+50-iter LM SMPL fit), "
+                                  "seeded random weights, seeded SMPL-shaped body model, 86-marker superset",
+                      "global_batch": B * world, "points": N, "parallelism": f"scan-sharded x{world}"},
+           "mean_final_lm_error": float(allrows[:, 0].mean()), "scans_reported": int(allrows.shape[0])}
+
+    # roofline of the dominant kernel: one instrumented pass of the same step (HIP events on the launch stream)
+    model_results = {}
+
+    def stage1_only():
+        r, _ = model(pts, ["confidence", "direction", "magnitude"], "standard_vector")
+        model_results.update(r)
+
+    with torch.no_grad():
+        agg = profile_pass(step)
+        stage1_only()
+    tot_ms = sum(d["ms"] for d in agg.values())
+    kern, d = max(agg.items(), key=lambda kv: kv[1]["ms"])
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(pmc):
+        traffic = json.load(open(pmc)).get(kern)
+    out["roofline"] = {"bound": "mfma", "kernel": kern, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                       "launches_per_step": d["calls"], "avg_launch_ms": round(d["ms"] / d["calls"], 4),
+                       "algorithmic_gflop_per_launch": round(d["flops"] / d["calls"] / 1e9, 3),
+                       "share_of_step": round(d["ms"] / tot_ms, 3)}
+    out["kernel_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]}
+    total_flops = sum(v["flops"] for v in agg.values())
+    out["whole_step_mfma_frac"] = round(total_flops / (dt / a.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+
+    if world == 1 and not a.no_cpu_baseline:
+        cb, parity = cpu_baseline(N, pts, model_results, last, args)
+        out["cpu_baseline"] = cb
+        out["parity_scan0"] = parity
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()

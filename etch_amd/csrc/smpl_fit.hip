@@ -484,7 +484,25 @@ __global__ void __launch_bounds__(256) argmax_rows_kernel(long R, int G, const f
     }
 }
 
+// inner = points - (direction * magnitude) / scale      (src/inference_demo.py:58-59)
+__global__ void __launch_bounds__(256) inner_points_kernel(long n, const float* __restrict__ pts, const float* __restrict__ dir,
+                                                           const float* __restrict__ mag, float scale, float* __restrict__ out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n * 3; i += (long)gridDim.x * 256) {
+#pragma clang fp contract(off)
+        out[i] = pts[i] - (dir[i] * mag[i / 3]) / scale;
+    }
+}
+
 extern "C" {
+
+int etch_inner_points(long n, const float* pts, const float* dir, const float* mag, float scale, float* out, void* stream) {
+    if (n <= 0) return ETCH_OK;
+    long blocks = (n * 3 + 255) / 256;
+    if (blocks > 65535 * 8) blocks = 65535 * 8;
+    hipLaunchKernelGGL(inner_points_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, pts, dir, mag, scale, out);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
 
 int etch_argmax_rows(long R, int G, const float* logits, long long* out, void* stream) {
     if (R <= 0) return ETCH_OK;

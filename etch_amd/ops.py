@@ -349,3 +349,12 @@ def smpl_lbs(consts, x, V, n_extra):
     joints = torch.empty((B, 24 + n_extra, 3), dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().etch_smpl_lbs(B, V, n_extra, arr, _ptr(x), _ptr(verts), _ptr(joints), _stream()), "etch_smpl_lbs")
     return verts, joints
+
+
+def inner_points(points, direction, magnitude, scale):
+    _need(points, torch.float32, "points"), _need(direction, torch.float32, "direction"), _need(magnitude, torch.float32, "magnitude")
+    out = torch.empty_like(points)
+    n = points.numel() // 3
+    _lib.check(_lib.lib().etch_inner_points(_c_long(n), _ptr(points), _ptr(direction), _ptr(magnitude), _c_float(scale), _ptr(out), _stream()),
+               "etch_inner_points")
+    return out

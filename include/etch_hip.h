@@ -157,6 +157,9 @@ int etch_softmax_dot(long R, int G, const float* logits, const float* v, float* 
 /* torch.max(part_labels, -1) of predict_smpl (src/inference_demo.py:52-53): logits (R,G) -> int64 labels (R). */
 int etch_argmax_rows(long R, int G, const float* logits, long long* out, void* stream);
 
+/* pred_inner_points = points - direction * magnitude / scale_magnitude (src/inference_demo.py:58-59): (n,3),(n,3),(n) -> (n,3). */
+int etch_inner_points(long n, const float* pts, const float* dir, const float* mag, float scale, float* out, void* stream);
+
 /* get_markers (src/models/fit_SMPL.py:17-62): pts (B,K,3), labels (B,K) i64, conf (B,K,1) -> markers (B,M,3),
  * valid as float (B,M) and/or as bool bytes (B,M) (either may be NULL).  Per (scan,label): top-3 confidences,
  * weights conf^20, weighted centre; empty label -> zeros + invalid. */
