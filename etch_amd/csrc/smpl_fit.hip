@@ -84,38 +84,94 @@ __device__ inline void fk_chain(const int* parents, const double* R, const doubl
 }
 
 // ---------------------------------------------------------------------------------------------- LM fit
+#define LM_WAVES (LM_THREADS / 64)
+struct LmWaveScratch {               // per-wave staging of one marker
+    float P[624];                    // posedirs columns of the marker: [207][3]
+    float Ay[NJ][4];                 // W_vj * y_vj (xyz) and W_vj
+    float U[NJ][4];                  // subtree sum of Ay minus w * tw_k
+    float T[12];                     // sum_j W_vj Rw_j
+    float S[32];                     // shapedirs rows of the marker [3][10]
+};
 struct LmShared {
     float Jm[3 * MAXM * LDJ];            // Jacobian rows (fp32)
-    double A[DOF * (DOF + 1) / 2];       // packed lower triangle of J^T J + lambda I, then its Cholesky factor
+    double A[(DOF + 1) * (DOF + 2) / 2]; // packed lower triangle of [J^T J + lambda I ; g^T] (row 85 = rhs), then L and y
     double x[DOF];
     double R[NJ * 9], Rw[NJ * 9], tw[NJ * 3], Jj[NJ * 3];
-    double vp[MAXM * 3];
-    double g[DOF], delta[DOF];
+    double g[DOF + 3], delta[DOF + 3];
     float dR[NJ][3][9];
-    float omega[NJ][3][3];
+    float omega[NJ][3][4];
     float twd[NB][NJ][3];
+    float pf[208];
     float resid[3 * MAXM];
     int parents[NJ];
+    unsigned sub[NJ];                    // bit j of sub[k]: joint j lies in the subtree of joint k
+    float Jd[NJ * 3 * NB];               // LDS copy of the joint shape basis
+    float J0[NJ * 3];
+    double rdiag[DOF + 3];               // 1 / L_ii
+    double rpiv;                         // 1 / A_kk of the column being eliminated
+    float target[3 * MAXM], mask[MAXM];  // LDS copies: no global load may sit between a prefetch and its use
     double err;
+    long long phase[8];                 // s_memtime cycles per phase (thread 0), optional diagnostics
+    LmWaveScratch ws[LM_WAVES];
 };
 
 __device__ inline double& Apk(double* A, int i, int j) { return A[i * (i + 1) / 2 + j]; }   // i >= j
 
+// wave-wide fp64 sum on the VALU (DPP row shifts + row broadcasts, no LDS traffic); result broadcast to all lanes
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ double dpp_add_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, BOUND);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, BOUND);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v = dpp_add_f64<0x111, 0xf, true>(v);     // row_shr:1
+    v = dpp_add_f64<0x112, 0xf, true>(v);     // row_shr:2
+    v = dpp_add_f64<0x114, 0xf, true>(v);     // row_shr:4
+    v = dpp_add_f64<0x118, 0xf, true>(v);     // row_shr:8   -> lane 15 of every row holds the row sum
+    v = dpp_add_f64<0x142, 0xa, false>(v);    // row_bcast:15 into rows 1 and 3
+    v = dpp_add_f64<0x143, 0xc, false>(v);    // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
 // residual + Jacobian at s.x.  nb = number of active betas (2 in stage 0, 10 in stage 1).
 __device__ void lm_linearize(LmShared& s, const SmplConsts& C, int M, int nb, const float* target, const float* mask) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < NJ) {
         double th[3];
         joint_theta(s.x, tid, th);
         rodrigues_d(th, s.R + tid * 9, s.dR[tid], true);
         for (int c = 0; c < 3; ++c) {
-            double v = C.J0[tid * 3 + c];
-            for (int l = 0; l < NB; ++l) v += (double)C.Jd[(tid * 3 + c) * NB + l] * s.x[NPOSE + l];
+            double v = s.J0[tid * 3 + c];
+            for (int l = 0; l < NB; ++l) v += (double)s.Jd[(tid * 3 + c) * NB + l] * s.x[NPOSE + l];
             s.Jj[tid * 3 + c] = v;
         }
     }
     __syncthreads();
-    if (tid == 0) fk_chain(s.parents, s.R, s.Jj, s.Rw, s.tw);
+    long long t0 = 0;
+    if (tid == 0) t0 = wall_clock64();
+    if (tid < 64) {                            // forward kinematics: 12 lanes per joint step (9 rotation entries + 3 translation)
+        if (lane < 9) s.Rw[lane] = s.R[lane];
+        else if (lane < 12) s.tw[lane - 9] = s.Jj[lane - 9];
+        __builtin_amdgcn_wave_barrier();
+        for (int j = 1; j < NJ; ++j) {
+            const int p = s.parents[j];
+            const double* Rp = s.Rw + p * 9;
+            if (lane < 9) {
+                const int a = lane / 3, b = lane - a * 3;
+                s.Rw[j * 9 + lane] = Rp[a * 3] * s.R[j * 9 + b] + Rp[a * 3 + 1] * s.R[j * 9 + 3 + b] + Rp[a * 3 + 2] * s.R[j * 9 + 6 + b];
+            } else if (lane < 12) {
+                const int a = lane - 9;
+                s.tw[j * 3 + a] = Rp[a * 3] * (s.Jj[j * 3] - s.Jj[p * 3]) + Rp[a * 3 + 1] * (s.Jj[j * 3 + 1] - s.Jj[p * 3 + 1]) +
+                                  Rp[a * 3 + 2] * (s.Jj[j * 3 + 2] - s.Jj[p * 3 + 2]) + s.tw[p * 3 + a];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (tid >= 64 && tid < 64 + 207) {         // pose feature vec(R_k - I), k = 1..23
+        const int e = tid - 64, k = 1 + e / 9, q = e - (k - 1) * 9;
+        s.pf[e] = (float)(s.R[k * 9 + q] - ((q % 4 == 0) ? 1.0 : 0.0));
+    }
     __syncthreads();
     if (tid < NJ * 3) {                       // omega_kc = Rw_parent(k) * axial(dR_kc R_k^T)
         const int k = tid / 3, c = tid - k * 3;
@@ -133,108 +189,144 @@ __device__ void lm_linearize(LmShared& s, const SmplConsts& C, int M, int nb, co
     } else if (tid >= 128 && tid < 128 + NB) {   // d tw_j / d beta_l chain
         const int l = tid - 128;
         float (*t)[3] = s.twd[l];
-        for (int a = 0; a < 3; ++a) t[0][a] = C.Jd[(0 * 3 + a) * NB + l];
+        for (int a = 0; a < 3; ++a) t[0][a] = s.Jd[(0 * 3 + a) * NB + l];
         for (int j = 1; j < NJ; ++j) {
             const int p = s.parents[j];
             const double* Rp = s.Rw + p * 9;
-            const double d[3] = {(double)C.Jd[(j * 3 + 0) * NB + l] - C.Jd[(p * 3 + 0) * NB + l], (double)C.Jd[(j * 3 + 1) * NB + l] - C.Jd[(p * 3 + 1) * NB + l],
-                                 (double)C.Jd[(j * 3 + 2) * NB + l] - C.Jd[(p * 3 + 2) * NB + l]};
+            const double d[3] = {(double)s.Jd[(j * 3 + 0) * NB + l] - s.Jd[(p * 3 + 0) * NB + l], (double)s.Jd[(j * 3 + 1) * NB + l] - s.Jd[(p * 3 + 1) * NB + l],
+                                 (double)s.Jd[(j * 3 + 2) * NB + l] - s.Jd[(p * 3 + 2) * NB + l]};
             for (int a = 0; a < 3; ++a) t[j][a] = (float)(Rp[a * 3] * d[0] + Rp[a * 3 + 1] * d[1] + Rp[a * 3 + 2] * d[2] + t[p][a]);
         }
     }
-    if (tid < M * 3) {                        // posed marker vertex v_p = v_t + S beta + P^T vec(R_1..23 - I)
-        const int v = tid / 3, c = tid - v * 3;
-        double acc = C.mk_vt[v * 3 + c];
-        for (int l = 0; l < NB; ++l) acc += (double)C.mk_S[(v * 3 + c) * NB + l] * s.x[NPOSE + l];
-        const float* P = C.mk_P + (size_t)v * 207 * 3 + c;
-        for (int e = 0; e < 207; ++e) {
-            const int k = 1 + e / 9, q = e - (k - 1) * 9;
-            acc += (double)P[e * 3] * (s.R[k * 9 + q] - ((q % 4 == 0) ? 1.0 : 0.0));
-        }
-        s.vp[tid] = acc;
+    __syncthreads();
+    for (int e = tid; e < NB * NJ * 3; e += LM_THREADS) {   // Q[l][j] = d tw_j/d beta_l - Rw_j Jd_j[:,l]  (in place)
+        const int l = e / (NJ * 3), r = e - l * NJ * 3, j = r / 3, a = r - j * 3;
+        const double* Rj = s.Rw + j * 9;
+        s.twd[l][j][a] -= (float)(Rj[a * 3] * s.Jd[(j * 3 + 0) * NB + l] + Rj[a * 3 + 1] * s.Jd[(j * 3 + 1) * NB + l] + Rj[a * 3 + 2] * s.Jd[(j * 3 + 2) * NB + l]);
     }
     __syncthreads();
-    if (tid < M * 4) {
-        const int v = tid >> 2, part = tid & 3;
-        const float* W = C.mk_W + v * NJ;
-        const double mk = (double)mask[v];
-        const double vp[3] = {s.vp[v * 3], s.vp[v * 3 + 1], s.vp[v * 3 + 2]};
-        double As[NJ][3], ws[NJ], T[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, xv[3] = {0, 0, 0};
-        for (int j = 0; j < NJ; ++j) {
-            const double w = W[j];
+    if (tid == 0) { const long long t1 = wall_clock64(); s.phase[0] += t1 - t0; t0 = t1; }
+    // ---- one wave per marker: forward, residual, and the marker's three Jacobian rows
+    LmWaveScratch& w = s.ws[wave];
+    float pre[11];                             // register prefetch of the next marker's P (10 / lane) and S|W (1 / lane)
+    auto fetch = [&](int v) {
+        const float* Pg = C.mk_P + (size_t)v * 621;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) { const int i = lane + 64 * q; pre[q] = i < 621 ? Pg[i] : 0.f; }
+        pre[10] = lane < 3 * NB ? C.mk_S[(size_t)v * 3 * NB + lane] : (lane >= 32 && lane < 32 + NJ ? C.mk_W[v * NJ + lane - 32] : 0.f);
+    };
+    if (wave < M) fetch(wave);
+    for (int v = wave; v < M; v += LM_WAVES) {
+#pragma unroll
+        for (int q = 0; q < 10; ++q) { const int i = lane + 64 * q; if (i < 621) w.P[i] = pre[q]; }
+        if (lane < 3 * NB) w.S[lane] = pre[10];
+        if (lane >= 32 && lane < 32 + NJ) w.Ay[lane - 32][3] = pre[10];
+        if (v + LM_WAVES < M) fetch(v + LM_WAVES);
+        __builtin_amdgcn_wave_barrier();
+        long long tm0 = 0;
+        if (tid == 0) tm0 = wall_clock64();
+        // posed vertex v_p = v_t + S beta + P^T pf
+        double acc[3] = {0.0, 0.0, 0.0};
+        for (int e = lane; e < 207; e += 64) {
+            const double f = (double)s.pf[e];
+            acc[0] += f * (double)w.P[e * 3]; acc[1] += f * (double)w.P[e * 3 + 1]; acc[2] += f * (double)w.P[e * 3 + 2];
+        }
+        if (lane < 3 * NB) {                     // + S beta, one (c,l) term per lane
+            const int c = lane / NB, l = lane - c * NB;
+            const double sb = (double)w.S[lane] * s.x[NPOSE + l];
+            acc[0] += c == 0 ? sb : 0.0; acc[1] += c == 1 ? sb : 0.0; acc[2] += c == 2 ? sb : 0.0;
+        }
+        double vp[3];
+        for (int c = 0; c < 3; ++c) vp[c] = wave_sum_f64(acc[c]) + (double)C.mk_vt[v * 3 + c];
+        // per-joint contribution y_j (lane j)
+        double xy[3] = {0.0, 0.0, 0.0};
+        if (lane < NJ) {
+            const int j = lane;
+            const double wj = (double)w.Ay[j][3];
             const double* Rj = s.Rw + j * 9;
             const double d[3] = {vp[0] - s.Jj[j * 3], vp[1] - s.Jj[j * 3 + 1], vp[2] - s.Jj[j * 3 + 2]};
             for (int a = 0; a < 3; ++a) {
                 const double y = Rj[a * 3] * d[0] + Rj[a * 3 + 1] * d[1] + Rj[a * 3 + 2] * d[2] + s.tw[j * 3 + a];
-                As[j][a] = w * y;
-                xv[a] += w * y;
+                xy[a] = wj * y;
+                w.Ay[j][a] = (float)xy[a];
             }
-            ws[j] = w;
-            for (int i = 0; i < 9; ++i) T[i] += w * Rj[i];
+        } else if (lane >= 32 && lane < 41) {    // T = sum_j W_vj Rw_j
+            const int i = lane - 32;
+            double t = 0.0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) t += (double)w.Ay[j][3] * s.Rw[j * 9 + i];
+            w.T[i] = (float)t;
         }
-        for (int j = NJ - 1; j >= 1; --j) {   // subtree sums (SMPL parents precede children)
-            const int p = s.parents[j];
-            As[p][0] += As[j][0]; As[p][1] += As[j][1]; As[p][2] += As[j][2]; ws[p] += ws[j];
+        double xv[3];
+        for (int a = 0; a < 3; ++a) xv[a] = wave_sum_f64(xy[a]);
+        __builtin_amdgcn_wave_barrier();
+        if (tid == 0) { const long long t1 = wall_clock64(); s.phase[5] += t1 - tm0; tm0 = t1; }
+        if (lane < NJ) {                         // subtree sums relative to the joint origin
+            const int k = lane;
+            const unsigned m = s.sub[k];
+            float u0 = 0.f, u1 = 0.f, u2 = 0.f, uw = 0.f;
+            for (int j = 0; j < NJ; ++j)
+                if ((m >> j) & 1u) { u0 += w.Ay[j][0]; u1 += w.Ay[j][1]; u2 += w.Ay[j][2]; uw += w.Ay[j][3]; }
+            w.U[k][0] = u0 - uw * (float)s.tw[k * 3]; w.U[k][1] = u1 - uw * (float)s.tw[k * 3 + 1]; w.U[k][2] = u2 - uw * (float)s.tw[k * 3 + 2];
         }
+        __builtin_amdgcn_wave_barrier();
+        if (tid == 0) { const long long t1 = wall_clock64(); s.phase[6] += t1 - tm0; tm0 = t1; }
+        const float mk = s.mask[v];
+        if (lane < 3) s.resid[v * 3 + lane] = (float)((double)mk * ((double)s.target[v * 3 + lane] - (xv[lane] + s.x[NPOSE + NB + 3 + lane])));
         float* Jr = s.Jm + (size_t)(v * 3) * LDJ;
-        if (part == 0) {
-            for (int a = 0; a < 3; ++a) s.resid[v * 3 + a] = (float)(mk * ((double)target[v * 3 + a] - (xv[a] + s.x[NPOSE + NB + 3 + a])));
-        }
-        // columns of -mask * d x_v / d param.  Column order == x layout.
-        for (int k = part; k < NJ; k += 4) {
-            const double u[3] = {As[k][0] - ws[k] * s.tw[k * 3], As[k][1] - ws[k] * s.tw[k * 3 + 1], As[k][2] - ws[k] * s.tw[k * 3 + 2]};
-            for (int c = 0; c < 3; ++c) {
+        for (int col = lane; col < LDJ; col += 64) {
+            float d[3] = {0.f, 0.f, 0.f};
+            if (col < NPOSE || (col >= NPOSE + NB && col < NPOSE + NB + 3)) {
+                const int k = col < NPOSE ? 1 + col / 3 : 0;
+                const int c = col < NPOSE ? col - 3 * (k - 1) : col - (NPOSE + NB);
                 const float* om = s.omega[k][c];
-                double d[3] = {om[1] * u[2] - om[2] * u[1], om[2] * u[0] - om[0] * u[2], om[0] * u[1] - om[1] * u[0]};
+                const float* u = w.U[k];
+                d[0] = om[1] * u[2] - om[2] * u[1]; d[1] = om[2] * u[0] - om[0] * u[2]; d[2] = om[0] * u[1] - om[1] * u[0];
                 if (k >= 1) {
-                    const float* P = C.mk_P + ((size_t)v * 207 + (k - 1) * 9) * 3;
+                    const float* P = w.P + (k - 1) * 27;
                     const float* dr = s.dR[k][c];
-                    double vpd[3] = {0, 0, 0};
-                    for (int e = 0; e < 9; ++e) { vpd[0] += (double)dr[e] * P[e * 3]; vpd[1] += (double)dr[e] * P[e * 3 + 1]; vpd[2] += (double)dr[e] * P[e * 3 + 2]; }
-                    for (int a = 0; a < 3; ++a) d[a] += T[a * 3] * vpd[0] + T[a * 3 + 1] * vpd[1] + T[a * 3 + 2] * vpd[2];
+                    float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) { q0 += dr[e] * P[e * 3]; q1 += dr[e] * P[e * 3 + 1]; q2 += dr[e] * P[e * 3 + 2]; }
+                    for (int a = 0; a < 3; ++a) d[a] += w.T[a * 3] * q0 + w.T[a * 3 + 1] * q1 + w.T[a * 3 + 2] * q2;
                 }
-                const int col = k == 0 ? NPOSE + NB + c : 3 * (k - 1) + c;
-                for (int a = 0; a < 3; ++a) Jr[a * LDJ + col] = (float)(-mk * d[a]);
-            }
-        }
-        for (int l = part; l < NB; l += 4) {
-            double d[3] = {0, 0, 0};
-            if (l < nb) {
-                const float* Sv = C.mk_S + (size_t)v * 3 * NB;
-                const double sv[3] = {Sv[0 * NB + l], Sv[1 * NB + l], Sv[2 * NB + l]};
-                for (int a = 0; a < 3; ++a) d[a] = T[a * 3] * sv[0] + T[a * 3 + 1] * sv[1] + T[a * 3 + 2] * sv[2];
-                for (int j = 0; j < NJ; ++j) {
-                    const double w = W[j];
-                    if (w == 0.0) continue;
-                    const double* Rj = s.Rw + j * 9;
-                    const double jd[3] = {C.Jd[(j * 3 + 0) * NB + l], C.Jd[(j * 3 + 1) * NB + l], C.Jd[(j * 3 + 2) * NB + l]};
-                    for (int a = 0; a < 3; ++a)
-                        d[a] += w * ((double)s.twd[l][j][a] - (Rj[a * 3] * jd[0] + Rj[a * 3 + 1] * jd[1] + Rj[a * 3 + 2] * jd[2]));
+            } else if (col < NPOSE + NB) {
+                const int l = col - NPOSE;
+                if (l < nb) {
+                    const float sv[3] = {w.S[l], w.S[NB + l], w.S[2 * NB + l]};
+                    for (int a = 0; a < 3; ++a) d[a] = w.T[a * 3] * sv[0] + w.T[a * 3 + 1] * sv[1] + w.T[a * 3 + 2] * sv[2];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const float wj = w.Ay[j][3];
+                        d[0] += wj * s.twd[l][j][0]; d[1] += wj * s.twd[l][j][1]; d[2] += wj * s.twd[l][j][2];
+                    }
                 }
+            } else if (col < DOF) {
+                const int c = col - (NPOSE + NB + 3);
+                d[0] = c == 0 ? 1.f : 0.f; d[1] = c == 1 ? 1.f : 0.f; d[2] = c == 2 ? 1.f : 0.f;
             }
-            for (int a = 0; a < 3; ++a) Jr[a * LDJ + NPOSE + l] = (float)(-mk * d[a]);
+            Jr[col] = -mk * d[0]; Jr[LDJ + col] = -mk * d[1]; Jr[2 * LDJ + col] = -mk * d[2];   // cols 85..87: zero padding
         }
-        if (part == 3) {
-            for (int a = 0; a < 3; ++a)
-                for (int c = 0; c < 3; ++c) Jr[a * LDJ + NPOSE + NB + 3 + c] = (float)(a == c ? -mk : 0.0);
-        }
-        if (part == 2) {   // zero the alignment padding columns 85..87
-            for (int a = 0; a < 3; ++a) { Jr[a * LDJ + 85] = 0.f; Jr[a * LDJ + 86] = 0.f; Jr[a * LDJ + 87] = 0.f; }
-        }
+        __builtin_amdgcn_wave_barrier();
+        if (tid == 0) { const long long t1 = wall_clock64(); s.phase[7] += t1 - tm0; }
     }
     __syncthreads();
-    if (tid == 0) {
-        float e = 0.f;                        // error metric 0.5 * |r|^2 in fp32, like the reference
-        for (int i = 0; i < M * 3; ++i) e += s.resid[i] * s.resid[i];
-        s.err = 0.5 * (double)e;
+    if (tid == 0) { const long long t1 = wall_clock64(); s.phase[1] += t1 - t0; }
+    if (tid < 64) {
+        float e = 0.f;                        // error metric 0.5 * |r|^2 accumulated in fp32, like the reference
+        for (int i = lane; i < M * 3; i += 64) e += s.resid[i] * s.resid[i];
+        e = etch_wave_sum_f32(e);
+        if (lane == 0) s.err = 0.5 * (double)e;
     }
     __syncthreads();
 }
 
 // delta = (J^T J + lambda I)^-1 J^T (-r)
 __device__ void lm_solve(LmShared& s, int M, double lambda) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int rows = M * 3;
+    long long t0 = 0;
+    if (tid == 0) t0 = wall_clock64();
     // 4x4 register blocks of the lower triangle: 22 block rows -> 253 blocks
     if (tid < 253) {
         int bi = 0;
@@ -259,54 +351,95 @@ __device__ void lm_solve(LmShared& s, int M, double lambda) {
         const int c = tid - 256;
         double acc = 0.0;
         for (int r = 0; r < rows; ++r) acc += (double)s.Jm[r * LDJ + c] * (double)s.resid[r];
-        s.g[c] = -acc;
-    }
+        Apk(s.A, DOF, c) = -acc;                            // rhs g = -J^T r stored as row 85 of the packed matrix
+    } else if (tid == 256 + DOF) Apk(s.A, DOF, DOF) = 1.0;
     __syncthreads();
-    // right-looking Cholesky on the packed lower triangle
+    if (tid == 0) { const long long t1 = wall_clock64(); s.phase[2] += t1 - t0; t0 = t1; }
+    // Right-looking Cholesky of the packed lower triangle with the rhs carried as an extra row (gives y = L^-1 g for
+    // free), ONE barrier per column: the trailing update uses the unscaled column, A_ij -= A_ik A_jk / A_kk; columns
+    // are scaled to L in one pass at the end.  The pair enumeration e -> (ii, jj) does not depend on the column.
+    unsigned pr[10];
+#pragma unroll
+    for (int m = 0; m < 10; ++m) {
+        const int e = tid + LM_THREADS * m;
+        int ii = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+        while ((ii + 1) * (ii + 2) / 2 <= e) ++ii;
+        while (ii * (ii + 1) / 2 > e) --ii;
+        pr[m] = ((unsigned)ii << 16) | (unsigned)(e - ii * (ii + 1) / 2);
+    }
+    if (tid == 0) s.rpiv = 1.0 / Apk(s.A, 0, 0);
+    __syncthreads();
     for (int k = 0; k < DOF; ++k) {
-        if (tid == 0) Apk(s.A, k, k) = sqrt(Apk(s.A, k, k));
-        __syncthreads();
-        const double dkk = Apk(s.A, k, k);
-        for (int i = k + 1 + tid; i < DOF; i += LM_THREADS) Apk(s.A, i, k) /= dkk;
-        __syncthreads();
-        const int n = DOF - k - 1;             // trailing size
-        for (int e = tid; e < n * (n + 1) / 2; e += LM_THREADS) {
-            int ii = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-            while ((ii + 1) * (ii + 2) / 2 <= e) ++ii;
-            while (ii * (ii + 1) / 2 > e) --ii;
-            const int jj = e - ii * (ii + 1) / 2;
-            const int i = k + 1 + ii, j = k + 1 + jj;
-            Apk(s.A, i, j) -= Apk(s.A, i, k) * Apk(s.A, j, k);
+        const double inv = s.rpiv;                          // 1 / A_kk, published by the thread that finished A_kk
+        const int n = DOF - k;                              // trailing rows k+1 .. 85 (incl. the rhs row)
+        const int npairs = n * (n + 1) / 2;
+        const int tk = (k + 1) * (k + 2) / 2;               // packed offset of row k+1
+#pragma unroll
+        for (int m = 0; m < 10; ++m) {
+            if (tid + LM_THREADS * m < npairs) {
+                const int ii = (int)(pr[m] >> 16), jj = (int)(pr[m] & 0xFFFFu);
+                const int ri = tk + ii * (ii + 1) / 2 + (k + 1) * ii, rj = tk + jj * (jj + 1) / 2 + (k + 1) * jj;   // row starts of i, j
+                const double a = s.A[ri + k + 1 + jj] - s.A[ri + k] * s.A[rj + k] * inv;
+                s.A[ri + k + 1 + jj] = a;
+                if (m == 0 && tid == 0) s.rpiv = 1.0 / a;   // pair (k+1, k+1): the next pivot
+            }
         }
         __syncthreads();
     }
-    // forward / backward substitution by one wave's lane 0 .. (sequential 85 steps, dot products in a single thread)
-    if (tid == 0) {
-        for (int i = 0; i < DOF; ++i) {
-            double v = s.g[i];
-            for (int j = 0; j < i; ++j) v -= Apk(s.A, i, j) * s.delta[j];
-            s.delta[i] = v / Apk(s.A, i, i);
-        }
-        for (int i = DOF - 1; i >= 0; --i) {
-            double v = s.delta[i];
-            for (int j = i + 1; j < DOF; ++j) v -= Apk(s.A, j, i) * s.delta[j];
-            s.delta[i] = v / Apk(s.A, i, i);
-        }
+    if (tid < DOF) s.rdiag[tid] = 1.0 / sqrt(Apk(s.A, tid, tid));
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 10; ++m) {                          // scale: L_ik = A_ik / sqrt(A_kk) (i > k), y_k = A_85,k / sqrt(A_kk)
+        const int e = tid + LM_THREADS * m;
+        const int i = (int)(pr[m] >> 16), k = (int)(pr[m] & 0xFFFFu);
+        if (e < (DOF + 1) * (DOF + 2) / 2 && i != k && k < DOF) s.A[e] *= s.rdiag[k];
     }
     __syncthreads();
+    if (tid == 0) { const long long t1 = wall_clock64(); s.phase[3] += t1 - t0; t0 = t1; }
+    // back substitution L^T delta = y by one wave (lane owns rows lane and lane + 64); pivots broadcast with v_readlane
+    if (tid < 64) {
+        double y0 = Apk(s.A, DOF, lane), y1 = lane + 64 < DOF ? Apk(s.A, DOF, lane + 64) : 0.0;
+        for (int i = DOF - 1; i >= 0; --i) {
+            const double src = i < 64 ? y0 : y1;
+            const int lo = __builtin_amdgcn_readlane(__double2loint(src), i & 63), hi = __builtin_amdgcn_readlane(__double2hiint(src), i & 63);
+            const double di = __hiloint2double(hi, lo) * s.rdiag[i];
+            if (lane == (i & 63)) { if (i < 64) y0 = di; else y1 = di; }
+            if (lane < i) y0 -= Apk(s.A, i, lane) * di;
+            if (lane + 64 < i) y1 -= Apk(s.A, i, lane + 64) * di;
+        }
+        s.delta[lane] = y0;
+        if (lane + 64 < DOF) s.delta[lane + 64] = y1;
+    }
+    __syncthreads();
+    if (tid == 0) { const long long t1 = wall_clock64(); s.phase[4] += t1 - t0; }
 }
 
 __global__ void __launch_bounds__(LM_THREADS) smpl_lm_fit_kernel(SmplConsts C, int M, const float* __restrict__ markers,
                                                                 const float* __restrict__ valid, int it0, float step0, float damp0,
                                                                 int it1, float step1, float damp1, float* __restrict__ x_out,
-                                                                float* __restrict__ x_stage0, float* __restrict__ err_trace) {
+                                                                float* __restrict__ x_stage0, float* __restrict__ err_trace, long long* __restrict__ phase_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lm_smem[];
     LmShared& s = *reinterpret_cast<LmShared*>(lm_smem);
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* target = markers + (size_t)b * M * 3;
     const float* mask = valid + (size_t)b * M;
     if (tid < DOF) s.x[tid] = 0.0;
+    if (tid < 8) s.phase[tid] = 0;
     if (tid < NJ) s.parents[tid] = C.parents[tid];
+    for (int i = tid; i < NJ * 3 * NB; i += LM_THREADS) s.Jd[i] = C.Jd[i];
+    if (tid < NJ * 3) s.J0[tid] = C.J0[tid];
+    if (tid < M * 3) s.target[tid] = target[tid];
+    if (tid < M) s.mask[tid] = mask[tid];
+    __syncthreads();
+    if (tid < NJ) {                            // subtree membership masks
+        unsigned m = 0u;
+        for (int j = 0; j < NJ; ++j) {
+            int a = j;
+            while (a > tid) a = s.parents[a];
+            if (a == tid) m |= 1u << j;
+        }
+        s.sub[tid] = m;
+    }
     __syncthreads();
     int trace_pos = 0;
     for (int stage = 0; stage < 2; ++stage) {
@@ -337,6 +470,7 @@ __global__ void __launch_bounds__(LM_THREADS) smpl_lm_fit_kernel(SmplConsts C, i
         __syncthreads();
     }
     if (tid < DOF) x_out[(size_t)b * DOF + tid] = (float)s.x[tid];
+    if (phase_out && tid < 8) phase_out[(size_t)b * 8 + tid] = s.phase[tid];
 }
 
 // ---------------------------------------------------------------------------------------------- full-mesh LBS
@@ -525,7 +659,7 @@ int etch_smpl_lm_workspace_bytes() { return (int)sizeof(LmShared); }
 
 // consts: 7 device pointers {J0, Jd, parents, mk_vt, mk_S, mk_P, mk_W}
 int etch_smpl_lm_fit(int B, int M, const void* const* consts, const float* markers, const float* valid, int it0, float step0,
-                     float damp0, int it1, float step1, float damp1, float* x_out, float* x_stage0, float* err_trace, void* stream) {
+                     float damp0, int it1, float step1, float damp1, float* x_out, float* x_stage0, float* err_trace, long long* phase_ticks, void* stream) {
     if (B <= 0) return ETCH_OK;
     if (M <= 0 || M > MAXM) return ETCH_EUNSUPPORTED;
     SmplConsts C{(const float*)consts[0], (const float*)consts[1], (const int*)consts[2], (const float*)consts[3], (const float*)consts[4],
@@ -534,7 +668,7 @@ int etch_smpl_lm_fit(int B, int M, const void* const* consts, const float* marke
     hipError_t e = hipFuncSetAttribute((const void*)smpl_lm_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(smpl_lm_fit_kernel, dim3(B), dim3(LM_THREADS), lds, (hipStream_t)stream, C, M, markers, valid, it0, step0, damp0, it1,
-                       step1, damp1, x_out, x_stage0, err_trace);
+                       step1, damp1, x_out, x_stage0, err_trace, phase_ticks);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }

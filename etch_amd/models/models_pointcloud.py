@@ -92,6 +92,11 @@ class GT_network_equiv(nn.Module):
         # 3-NN propagation of the [C*60] equivariant features to all N points + anchor mean (:181-184), channels-last
         point_equiv_cl, point_inv_feat = propagate_cl(hitpts, r.xyz, r.feats_cl)
         results = {}
+        with pointops.knn_scope():      # both Point-Transformer nets share FPS / kNN indices (same points, same offsets)
+            self._heads(results, pred_items, direction_mode, hitpts, point_inv_feat, point_equiv_cl, so3_anchors, B, N)
+        return results, selected_indexs
+
+    def _heads(self, results, pred_items, direction_mode, hitpts, point_inv_feat, point_equiv_cl, so3_anchors, B, N):
         if "confidence" in pred_items:
             part_labels, confidences = self.decode_confidence(point_inv_feat, hitpts)
             results["confidences"] = confidences
@@ -103,4 +108,3 @@ class GT_network_equiv(nn.Module):
             results["direction"] = self.decode_direction(None, so3_anchors, standard_vector, tokens_cl=point_equiv_cl)
         if "magnitude" in pred_items:
             results["magnitude"] = self.decode_magnitude(point_inv_feat, hitpts)
-        return results, selected_indexs

@@ -27,12 +27,14 @@ def set_host_offsets(o, values):
 
 
 class knn_scope:
-    """Enables kNN de-duplication for the duration of one network forward."""
+    """Enables FPS / kNN / sub-sampling de-duplication for the duration of one forward.  Scopes nest: the model opens
+    one around BOTH Point-Transformer nets, which see the same points and offsets and therefore the same indices."""
 
     def __enter__(self):
         global _knn_cache
         self._prev = _knn_cache
-        _knn_cache = {}
+        if _knn_cache is None:
+            _knn_cache = {}
         return self
 
     def __exit__(self, *a):
@@ -40,23 +42,34 @@ class knn_scope:
         _knn_cache = self._prev
 
 
+def _memo(key, keep, fn):
+    if _knn_cache is None:
+        return fn()
+    hit = _knn_cache.get(key)
+    if hit is None:
+        hit = (fn(), keep)          # `keep` pins the key tensors so their addresses stay unique inside the scope
+        _knn_cache[key] = hit
+    return hit[0]
+
+
 def furthestsampling(xyz, offset, new_offset):
     """pointops.py:10-28."""
-    return ops.furthestsampling(xyz, offset, new_offset, host_offsets(offset), host_offsets(new_offset))
+    oh, noh = host_offsets(offset), host_offsets(new_offset)
+    return _memo(("fps", xyz.data_ptr(), tuple(oh), tuple(noh)), (xyz,), lambda: ops.furthestsampling(xyz, offset, new_offset, oh, noh))
+
+
+def gather_rows(x, idx):
+    """n_p = p[idx.long(), :] (pointtransformer_seg.py:60), memoised so both nets share the sub-sampled point tensors."""
+    return _memo(("rows", x.data_ptr(), idx.data_ptr()), (x, idx), lambda: ops.gather_rows(x, idx))
 
 
 def knnquery(nsample, xyz, new_xyz, offset, new_offset):
     """pointops.py:32-45: -> idx (m,nsample) int32, dist (m,nsample) = sqrt(d2)."""
     if new_xyz is None:
         new_xyz = xyz
-    key = (nsample, xyz.data_ptr(), new_xyz.data_ptr(), offset.data_ptr(), new_offset.data_ptr())
-    if _knn_cache is not None and key in _knn_cache:
-        return _knn_cache[key]
-    r = ops.knnquery(nsample, xyz, new_xyz, offset, new_offset, host_offsets(new_offset))
-    if _knn_cache is not None:
-        _knn_cache[key] = r + (xyz, new_xyz)   # keep the tensors alive so data_ptr keys stay unique
-        return r
-    return r
+    oh, noh = host_offsets(offset), host_offsets(new_offset)
+    return _memo(("knn", nsample, xyz.data_ptr(), new_xyz.data_ptr(), tuple(oh), tuple(noh)), (xyz, new_xyz),
+                 lambda: ops.knnquery(nsample, xyz, new_xyz, offset, new_offset, noh))
 
 
 def queryandgroup(nsample, xyz, new_xyz, feat, idx, offset, new_offset, use_xyz=True):

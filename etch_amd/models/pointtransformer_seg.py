@@ -86,7 +86,7 @@ class TransitionDown(nn.Module):
             n_o_t = torch.tensor(n_o, dtype=torch.int32, device=p.device)
             pointops.set_host_offsets(n_o_t, n_o)
             idx = pointops.furthestsampling(p, o, n_o_t)
-            n_p = ops.gather_rows(p, idx)
+            n_p = pointops.gather_rows(p, idx)
             kidx = pointops.knnquery(self.nsample, p, n_p, o, n_o_t)[0]
             g = ops.pt_group(p, n_p, x, kidx)                                  # (m*ns, 3+c)
             y = ops.linear(g, w, scale=s, shift=t, act="relu")                 # Linear -> BN -> ReLU

@@ -331,14 +331,14 @@ def get_markers(points, labels, conf, num_markers):
     return markers, valid_f, valid_b
 
 
-def smpl_lm_fit(consts, markers, valid_f, it0, step0, damp0, it1, step1, damp1, want_trace=False):
+def smpl_lm_fit(consts, markers, valid_f, it0, step0, damp0, it1, step1, damp1, want_trace=False, phase_ticks=None):
     B, M = valid_f.shape
     arr = (ctypes.c_void_p * 7)(*[t.data_ptr() for t in consts])
     x = torch.empty((B, 85), dtype=torch.float32, device=markers.device)
     x0 = torch.empty((B, 85), dtype=torch.float32, device=markers.device)
     tr = torch.zeros((B, it0 + it1 + 2), dtype=torch.float32, device=markers.device) if want_trace else None
     _lib.check(_lib.lib().etch_smpl_lm_fit(B, M, arr, _ptr(markers), _ptr(valid_f), int(it0), _c_float(step0), _c_float(damp0), int(it1),
-                                           _c_float(step1), _c_float(damp1), _ptr(x), _ptr(x0), _optptr(tr), _stream()), "etch_smpl_lm_fit")
+                                           _c_float(step1), _c_float(damp1), _ptr(x), _ptr(x0), _optptr(tr), _optptr(phase_ticks), _stream()), "etch_smpl_lm_fit")
     return x, x0, tr
 
 

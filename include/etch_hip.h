@@ -172,9 +172,11 @@ int etch_get_markers(int B, int K, int M, const float* pts, const long long* lab
  * posedirs columns as (M,207,3), lbs_weights rows (M,24)}.  markers (B,M,3), valid (B,M) float mask.
  * Stage 0: it0 iterations, step0, damp0 over pose|betas[:2]|orient|transl; stage 1: it1, step1, damp1 over all 85.
  * -> x_out (B,85) = pose(69) | betas(10) | global_orient(3) | transl(3); optional x_stage0 (B,85) and
- * err_trace (B, it0+it1+2) = 0.5|r|^2 before/after every iteration of both stages. */
+ * err_trace (B, it0+it1+2) = 0.5|r|^2 before/after every iteration of both stages; optional phase_ticks (B,8) i64 =
+ * 100 MHz wall-clock ticks spent in {kinematics, marker rows, J^T J, Cholesky, solves} (diagnostics). */
 int etch_smpl_lm_fit(int B, int M, const void* const* consts, const float* markers, const float* valid, int it0, float step0,
-                     float damp0, int it1, float step1, float damp1, float* x_out, float* x_stage0, float* err_trace, void* stream);
+                     float damp0, int it1, float step1, float damp1, float* x_out, float* x_stage0, float* err_trace,
+                     long long* phase_ticks, void* stream);
 int etch_smpl_lm_workspace_bytes(void);
 
 /* Final smpl_model(...) (fit_SMPL.py:258-259, smplx.SMPL.forward upstream): x (B,85) -> verts (B,V,3), joints
