@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="scans per GPU")
     ap.add_argument("--points", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", action="store_true", help="2-deep stream pipeline (stage 2 of step i enqueued on a second stream next to stage 1 of step i+1); "
+                    "default: synchronous steps -- on this pool kernels of different streams were measured NOT to overlap")
     a = ap.parse_args()
 
     from etch_amd import parallel as P
@@ -162,16 +164,29 @@ def main():
         meshes, markers, valid, info, aux = predict_smpl_batch(args, model, pts, "neutral", return_trace=True)
         last.update(markers=markers, valid=valid, verts=aux["verts"], x=aux["x"], err=aux["err_trace"][:, -1])
 
+    from etch_amd.pipeline import HotPathPipeline
+    pipe = HotPathPipeline(args, model, "neutral", max_in_flight=2, want_trace=True)
+
+    def run_steps(k):
+        """k steps; with the pipeline, stage 2 of step i overlaps stage 1 of step i+1 (all k steps finish inside the call)."""
+        if not a.pipeline:
+            for _ in range(k):
+                step()
+            return
+        for meshes, markers, valid, info in pipe.run(pts for _ in range(k)):
+            pass
+
     for _ in range(a.warmup):
         step()
+    run_steps(min(2, a.warmup))
     P.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
+    run_steps(a.steps)
     torch.cuda.synchronize()
     P.barrier()
     dt = P.max_over_ranks(time.perf_counter() - t0, device)
+    step()      # one synchronous step: per-scan result rows for the end-of-job gather
 
     # end-of-batch metric reduction: one all_gather of per-scan rows [final LM error, #valid markers, pose/shape norm]
     rows = torch.stack([last["err"], last["valid"].float().sum(1), last["x"][:, :79].norm(dim=1)], 1)
@@ -185,6 +200,7 @@ def main():
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"configs[2]: batch={B}/GPU synthetic {N}-pt Gaussian-blob scans, full pipeline (eq-net + 30+50-iter LM SMPL fit), "
                                   "seeded random weights, seeded SMPL-shaped body model, 86-marker superset",
+                      "schedule": "synchronous steps" if not a.pipeline else "2-deep stream pipeline: stage 2 of step i overlaps stage 1 of step i+1",
                       "global_batch": B * world, "points": N, "parallelism": f"scan-sharded x{world}"},
            "mean_final_lm_error": float(allrows[:, 0].mean()), "scans_reported": int(allrows.shape[0])}
 

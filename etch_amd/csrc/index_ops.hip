@@ -232,6 +232,87 @@ __global__ void __launch_bounds__(KNN_THREADS) knn_kernel(int nsample, const flo
     }
 }
 
+
+// kNN, one WAVE per query (the path the model uses; knn_kernel above is the thread-per-query form kept for tiny inputs):
+// the 64 lanes test 64 consecutive support points per step (coalesced AoS loads); lanes whose distance beats the
+// current heap top are collected with a ballot and inserted by lane 0 IN INDEX ORDER, re-testing each candidate against
+// the top as it evolves -- i.e. exactly the reference's sequential scan (same strict '<', same reheap / heap_sort),
+// only the distance evaluations run 64-wide.  Heap lives in LDS (k floats + k ints per wave).
+#define KNNW_WAVES 4
+__global__ void __launch_bounds__(KNNW_WAVES * 64) knn_wave_kernel(int nsample, int nseg, const float* __restrict__ xyz,
+                                                                    const float* __restrict__ new_xyz, const int* __restrict__ offset,
+                                                                    const int* __restrict__ new_offset, int m_total, int* __restrict__ idx,
+                                                                    float* __restrict__ dist2, int write_sqrt) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* hd = smem_f + wave * 2 * nsample;          // heap distances [k]
+    int* hi = (int*)(hd + nsample);                   // heap indices   [k]
+    float* cand_d = smem_f + KNNW_WAVES * 2 * nsample + wave * 128;   // candidates of the current chunk
+    int* cand_i = (int*)(cand_d + 64);
+    for (int q = blockIdx.x * KNNW_WAVES + wave; q < m_total; q += gridDim.x * KNNW_WAVES) {
+        int seg = 0;
+        while (seg < nseg - 1 && q >= new_offset[seg]) ++seg;
+        const int start = seg == 0 ? 0 : offset[seg - 1], end = offset[seg];
+        const float qx = new_xyz[(size_t)q * 3], qy = new_xyz[(size_t)q * 3 + 1], qz = new_xyz[(size_t)q * 3 + 2];
+        for (int i = lane; i < nsample; i += 64) { hd[i] = 1e10f; hi[i] = start; }
+        __builtin_amdgcn_wave_barrier();
+        float top = 1e10f;
+        for (int k0 = start; k0 < end; k0 += 64) {
+            const int k = k0 + lane;
+            float d2 = 3e38f;
+            if (k < end) d2 = etch_sqdist(qx, qy, qz, xyz[(size_t)k * 3], xyz[(size_t)k * 3 + 1], xyz[(size_t)k * 3 + 2]);
+            const bool c = d2 < top;
+            const unsigned long long mask = __ballot(c);
+            if (mask == 0ull) continue;                            // wave-uniform
+            const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+            if (c) { cand_d[pos] = d2; cand_i[pos] = k; }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                const int nc = __popcll(mask);
+                float t = top;
+                for (int e = 0; e < nc; ++e) {
+                    const float d = cand_d[e];
+                    if (d < t) {                                   // re-test: the top shrinks as candidates go in
+                        hd[0] = d; hi[0] = cand_i[e];
+                        int root = 0, child = 1;                   // reheap (knnquery_cuda_kernel.cu:21-37)
+                        while (child < nsample) {
+                            if (child + 1 < nsample && hd[child + 1] > hd[child]) child++;
+                            if (hd[root] > hd[child]) break;
+                            const float tf = hd[root]; hd[root] = hd[child]; hd[child] = tf;
+                            const int ti = hi[root]; hi[root] = hi[child]; hi[child] = ti;
+                            root = child; child = root * 2 + 1;
+                        }
+                        t = hd[0];
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            top = hd[0];
+        }
+        if (lane == 0) {
+            for (int i = nsample - 1; i > 0; i--) {                // heap_sort (:39-48)
+                float tf = hd[0]; hd[0] = hd[i]; hd[i] = tf;
+                int ti = hi[0]; hi[0] = hi[i]; hi[i] = ti;
+                int root = 0, child = 1;
+                while (child < i) {
+                    if (child + 1 < i && hd[child + 1] > hd[child]) child++;
+                    if (hd[root] > hd[child]) break;
+                    const float tf2 = hd[root]; hd[root] = hd[child]; hd[child] = tf2;
+                    const int ti2 = hi[root]; hi[root] = hi[child]; hi[child] = ti2;
+                    root = child; child = root * 2 + 1;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < nsample; i += 64) {
+            idx[(size_t)q * nsample + i] = hi[i];
+            const float d = hd[i];
+            dist2[(size_t)q * nsample + i] = write_sqrt ? sqrtf(d) : d;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ------------------------------------------------------------------------------------ C ABI
 static inline int ilog2_floor_host(int v) { int b = 0; while ((1 << (b + 1)) <= v) ++b; return b; }
 
@@ -299,10 +380,20 @@ int etch_gather_points(int b, int c, int n, int m, const float* points, const in
     return ETCH_OK;
 }
 
-int etch_knnquery(int b, int m_max, int nsample, const float* xyz, const float* new_xyz, const int* offset,
+int etch_knnquery(int b, int m_max, int m_total, int nsample, const float* xyz, const float* new_xyz, const int* offset,
                   const int* new_offset, int* idx, float* dist, int write_sqrt, void* stream) {
     if (b <= 0 || m_max <= 0) return ETCH_OK;
     if (nsample <= 0 || nsample > 28) return ETCH_EUNSUPPORTED;  // heap columns must fit 64 KiB of LDS
+    if (m_total > 0) {            // wave-per-query kernel
+        if (nsample > 100) return ETCH_EUNSUPPORTED;
+        const size_t lds = (size_t)(KNNW_WAVES * 2 * nsample + KNNW_WAVES * 128) * 4;
+        long blocks = ((long)m_total + KNNW_WAVES - 1) / KNNW_WAVES;
+        if (blocks > 256 * 64) blocks = 256 * 64;
+        hipLaunchKernelGGL(knn_wave_kernel, dim3((unsigned)blocks), dim3(KNNW_WAVES * 64), lds, (hipStream_t)stream, nsample, b, xyz,
+                           new_xyz, offset, new_offset, m_total, idx, dist, write_sqrt);
+        ETCH_RETURN_IF_LAUNCH_FAILED();
+        return ETCH_OK;
+    }
     const size_t lds = (size_t)(3 * KNN_TILE + 2 * nsample * KNN_THREADS) * 4;
     hipLaunchKernelGGL(knn_kernel, dim3((m_max + KNN_THREADS - 1) / KNN_THREADS, b), dim3(KNN_THREADS), lds,
                        (hipStream_t)stream, nsample, xyz, new_xyz, offset, new_offset, idx, dist, write_sqrt);

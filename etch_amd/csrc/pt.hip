@@ -93,6 +93,78 @@ __global__ void __launch_bounds__(128) pt_attention_kernel(PtAttnParams a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// GEMM-based split of the vector-attention layer (used for every level): the c -> c/8 -> c/8 weight MLP runs on the
+// fp32 matrix cores (etch_linear) over all (point, neighbour) rows; the two kernels below are the streaming ends.
+//   prep:       w_in[(i,j), ch] = relu(bn0( x_k[idx[i,j], ch] - x_q[i, ch] + p_r[(i,j), ch] ))
+//   aggregate:  out[i, ch] = sum_j (x_v[idx[i,j], ch] + p_r[(i,j), ch]) * softmax_j(logits[(i,j), ch % cs])   (+ BN + ReLU)
+// p_r = linear_p(p[idx] - p[i]) is recomputed on the fly in both (3 -> 3 -> c, 12 FMAs per value).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pt_rel_hidden(const PtAttnParams& a, int i, int j, float h[3]) {
+    const float rx = a.p[(size_t)j * 3] - a.p[(size_t)i * 3], ry = a.p[(size_t)j * 3 + 1] - a.p[(size_t)i * 3 + 1],
+                rz = a.p[(size_t)j * 3 + 2] - a.p[(size_t)i * 3 + 2];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        float v = a.W0[o * 3] * rx + a.W0[o * 3 + 1] * ry + a.W0[o * 3 + 2] * rz + a.b0[o];
+        h[o] = fmaxf(v * a.s_p[o] + a.t_p[o], 0.f);
+    }
+}
+
+__global__ void __launch_bounds__(256) pt_attn_prep_kernel(PtAttnParams a, float* __restrict__ w_in) {
+    const int c = a.c, ns = a.ns;
+    const int c4 = c >> 2;
+    const size_t total = (size_t)a.n * ns * c4;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t row = e / c4;
+        const int ch = (int)(e - row * c4) * 4;
+        const int i = (int)(row / ns);
+        const int j = a.idx[row];
+        float h[3];
+        pt_rel_hidden(a, i, j, h);
+        const float4 k4 = *reinterpret_cast<const float4*>(a.xk + (size_t)j * a.ldq + ch);
+        const float4 q4 = *reinterpret_cast<const float4*>(a.xq + (size_t)i * a.ldq + ch);
+        const float kv[4] = {k4.x, k4.y, k4.z, k4.w}, qv[4] = {q4.x, q4.y, q4.z, q4.w};
+        float o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cc = ch + u;
+            const float pr = a.W3[cc * 3] * h[0] + a.W3[cc * 3 + 1] * h[1] + a.W3[cc * 3 + 2] * h[2] + a.b3[cc];
+            const float w = (kv[u] - qv[u] + pr) * a.s_w0[cc] + a.t_w0[cc];
+            o[u] = fmaxf(w, 0.f);
+        }
+        *reinterpret_cast<float4*>(w_in + row * c + ch) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// one wave per point; lane handles channels ch = lane, lane + 64, ...
+__global__ void __launch_bounds__(256) pt_attn_aggregate_kernel(PtAttnParams a, const float* __restrict__ logits) {
+    const int c = a.c, ns = a.ns, cs = c >> 3;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= a.n) return;
+    const int* nb = a.idx + (size_t)i * ns;
+    for (int ch = lane; ch < c; ch += 64) {
+        const int t = ch % cs;
+        float mx = -INFINITY;
+        for (int j = 0; j < ns; ++j) mx = fmaxf(mx, logits[((size_t)i * ns + j) * cs + t]);
+        float den = 0.f, acc = 0.f;
+        const float w30 = a.W3[ch * 3], w31 = a.W3[ch * 3 + 1], w32 = a.W3[ch * 3 + 2], b3 = a.b3[ch];
+        for (int j = 0; j < ns; ++j) {
+            const int q = nb[j];
+            float h[3];
+            pt_rel_hidden(a, i, q, h);
+            const float pr = w30 * h[0] + w31 * h[1] + w32 * h[2] + b3;
+            const float ev = __expf(logits[((size_t)i * ns + j) * cs + t] - mx);
+            den += ev;
+            acc += (a.xv[(size_t)q * a.ldq + ch] + pr) * ev;
+        }
+        float v = acc / den;
+        if (a.s_out) v = fmaxf(v * a.s_out[ch] + a.t_out[ch], 0.f);
+        a.out[(size_t)i * a.ldo + ch] = v;
+    }
+}
+
 // rows[(i*ns + j)] = [ p[idx[i,j]] - new_p[i]  (3) | x[idx[i,j]] (c) ],   row length 3 + c
 __global__ void __launch_bounds__(256) pt_group_kernel(int m, int ns, int c, const float* __restrict__ p, const float* __restrict__ new_p,
                                                        const float* __restrict__ x, long ldx, const int* __restrict__ idx,
@@ -242,6 +314,37 @@ int etch_pt_attention(int n, int c, int ns, const float* p, const float* xq, con
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(pt_attention_kernel, dim3(n), dim3(128), lds, (hipStream_t)stream, a);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+static void fill_pt_params(PtAttnParams& a, int n, int c, int ns, const float* p, const float* xq, const float* xk, const float* xv, long ldq,
+                           const int* idx, const float* const* params, float* out, long ldo) {
+    a.p = p; a.xq = xq; a.xk = xk; a.xv = xv; a.ldq = ldq; a.idx = idx;
+    a.W0 = params[0]; a.b0 = params[1]; a.s_p = params[2]; a.t_p = params[3]; a.W3 = params[4]; a.b3 = params[5];
+    a.s_w0 = params[6]; a.t_w0 = params[7]; a.W2T = params[8]; a.b2 = params[9]; a.s_w3 = params[10]; a.t_w3 = params[11];
+    a.W5 = params[12]; a.b5 = params[13]; a.s_out = params[14]; a.t_out = params[15];
+    a.out = out; a.ldo = ldo; a.n = n; a.c = c; a.ns = ns;
+}
+
+int etch_pt_attn_prep(int n, int c, int ns, const float* p, const float* xq, const float* xk, long ldq, const int* idx,
+                      const float* const* params, float* w_in, void* stream) {
+    if (n <= 0) return ETCH_OK;
+    if (c <= 0 || (c & 7) || (ldq & 3)) return ETCH_EINVAL;
+    PtAttnParams a;
+    fill_pt_params(a, n, c, ns, p, xq, xk, nullptr, ldq, idx, params, nullptr, 0);
+    hipLaunchKernelGGL(pt_attn_prep_kernel, dim3(grid_for((size_t)n * ns * (c / 4), 256)), dim3(256), 0, (hipStream_t)stream, a, w_in);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_pt_attn_aggregate(int n, int c, int ns, const float* p, const float* xv, long ldq, const int* idx, const float* logits,
+                           const float* const* params, float* out, long ldo, void* stream) {
+    if (n <= 0) return ETCH_OK;
+    if (c <= 0 || (c & 7)) return ETCH_EINVAL;
+    PtAttnParams a;
+    fill_pt_params(a, n, c, ns, p, nullptr, nullptr, xv, ldq, idx, params, out, ldo);
+    hipLaunchKernelGGL(pt_attn_aggregate_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, logits);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }

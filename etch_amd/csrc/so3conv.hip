@@ -173,16 +173,31 @@ __global__ void __launch_bounds__(256) inter_so3conv_small_kernel(
     __syncthreads();
     const float* Fb = feats + (size_t)b * p1 * NA * cin;
     const int kk = cin * KS;
-    for (int e = tid; e < NA * KS; e += 256) {
-        const int a = e / KS, k = e - a * KS;
-        const float rx = rk[(a * KS + k) * 3], ry = rk[(a * KS + k) * 3 + 1], rz = rk[(a * KS + k) * 3 + 2];
-        for (int c = 0; c < cin; ++c) X1[a * kk + c * KS + k] = 0.f;
-        for (int n = 0; n < nn; ++n) {
-            const float dx = g[n * 3] - rx, dy = g[n * 3 + 1] - ry, dz = g[n * 3 + 2] - rz;
-            const float w = fmaxf(0.f, 1.0f - (dx * dx + dy * dy + dz * dz) * inv_sigma);
-            if (w > 0.f) {
-                const float* fr = Fb + ((size_t)qi[n] * NA + a) * cin;
-                for (int c = 0; c < cin; ++c) X1[a * kk + c * KS + k] += fr[c] * w;
+    if (cin == 1) {
+        // first EPN layer: one accumulator per (anchor, kernel point); neighbour features staged per anchor row on the fly
+        for (int e = tid; e < NA * KS; e += 256) {
+            const int a = e / KS, k = e - a * KS;
+            const float rx = rk[(a * KS + k) * 3], ry = rk[(a * KS + k) * 3 + 1], rz = rk[(a * KS + k) * 3 + 2];
+            float acc = 0.f;
+            for (int n = 0; n < nn; ++n) {
+                const float dx = g[n * 3] - rx, dy = g[n * 3 + 1] - ry, dz = g[n * 3 + 2] - rz;
+                const float w = fmaxf(0.f, 1.0f - (dx * dx + dy * dy + dz * dz) * inv_sigma);
+                acc = fmaf(Fb[(size_t)qi[n] * NA + a], w, acc);
+            }
+            X1[a * KS + k] = acc;
+        }
+    } else {
+        for (int e = tid; e < NA * KS; e += 256) {
+            const int a = e / KS, k = e - a * KS;
+            const float rx = rk[(a * KS + k) * 3], ry = rk[(a * KS + k) * 3 + 1], rz = rk[(a * KS + k) * 3 + 2];
+            for (int c = 0; c < cin; ++c) X1[a * kk + c * KS + k] = 0.f;
+            for (int n = 0; n < nn; ++n) {
+                const float dx = g[n * 3] - rx, dy = g[n * 3 + 1] - ry, dz = g[n * 3 + 2] - rz;
+                const float w = fmaxf(0.f, 1.0f - (dx * dx + dy * dy + dz * dz) * inv_sigma);
+                if (w > 0.f) {
+                    const float* fr = Fb + ((size_t)qi[n] * NA + a) * cin;
+                    for (int c = 0; c < cin; ++c) X1[a * kk + c * KS + k] += fr[c] * w;
+                }
             }
         }
     }

@@ -90,23 +90,38 @@ def get_markers(args, inner_points, part_labels, confidences):
     return markers, valid_b
 
 
-def fit_smpl(args, inner_points, part_labels, confidences, gender, steps_stage0=30, steps_stage1=50, lr_stage0=5e-1, lr_stage1=2e-1,
-             return_trace=False):
-    """fit_SMPL.py:68-269.  Returns (list of meshes, pred_markers_position (B,M,3), valid_mask (B,M) bool,
-    [pose (B,23,3), shape (B,10), global_orient (B,3), translation (B,3), joints (B,45,3)] as numpy)."""
-    B = inner_points.shape[0]
+def fit_smpl_device(args, inner_points, part_labels, confidences, gender, steps_stage0=30, steps_stage1=50, lr_stage0=5e-1, lr_stage1=2e-1,
+                    want_trace=False):
+    """Device-side part of fit_smpl: every kernel is enqueued on the current HIP stream, nothing is copied to the host.
+    Returns a dict of device tensors (markers, valid, x, x_stage0, err_trace, verts, joints) + the face array."""
     M = len(args.markerset)
     vids = list(args.markerset.values())
     bm = _resolve_body_model(args, gender)
     db = _device_body(bm, vids, inner_points.device)
     markers, valid_f, valid_b = ops.get_markers(inner_points.contiguous(), part_labels.contiguous(), confidences.contiguous(), M)
     # stage 0: damping 0.01 (fit_SMPL.py:200); stage 1: Theseus default damping 1e-3 (:249)
-    x, x0, trace = ops.smpl_lm_fit(db.lm_consts, markers, valid_f, steps_stage0, lr_stage0, 0.01, steps_stage1, lr_stage1, 1e-3, return_trace)
+    x, x0, trace = ops.smpl_lm_fit(db.lm_consts, markers, valid_f, steps_stage0, lr_stage0, 0.01, steps_stage1, lr_stage1, 1e-3, want_trace)
     verts, joints = ops.smpl_lbs(db.lbs_consts, x, db.V, db.n_extra)
+    return dict(markers=markers, valid=valid_b, x=x, x_stage0=x0, err_trace=trace, verts=verts, joints=joints, faces=db.faces)
+
+
+def fit_smpl_finalize(dev):
+    """Host-side part: copy the fit to the host in the reference's return format (fit_SMPL.py:261-269)."""
+    x = dev["x"]
+    B = x.shape[0]
     xn = x.detach().cpu().numpy()
-    vn = verts.detach().cpu().numpy()
-    meshes = [Mesh(vn[b], db.faces, process=False, maintain_order=True) for b in range(B)]
-    info = [xn[:, :69].reshape(B, 23, 3), xn[:, 69:79].copy(), xn[:, 79:82].copy(), xn[:, 82:85].copy(), joints.detach().cpu().numpy()]
+    vn = dev["verts"].detach().cpu().numpy()
+    meshes = [Mesh(vn[b], dev["faces"], process=False, maintain_order=True) for b in range(B)]
+    info = [xn[:, :69].reshape(B, 23, 3), xn[:, 69:79].copy(), xn[:, 79:82].copy(), xn[:, 82:85].copy(), dev["joints"].detach().cpu().numpy()]
+    return meshes, dev["markers"], dev["valid"], info
+
+
+def fit_smpl(args, inner_points, part_labels, confidences, gender, steps_stage0=30, steps_stage1=50, lr_stage0=5e-1, lr_stage1=2e-1,
+             return_trace=False):
+    """fit_SMPL.py:68-269.  Returns (list of meshes, pred_markers_position (B,M,3), valid_mask (B,M) bool,
+    [pose (B,23,3), shape (B,10), global_orient (B,3), translation (B,3), joints (B,45,3)] as numpy)."""
+    dev = fit_smpl_device(args, inner_points, part_labels, confidences, gender, steps_stage0, steps_stage1, lr_stage0, lr_stage1, return_trace)
+    out = fit_smpl_finalize(dev)
     if return_trace:
-        return meshes, markers, valid_b, info, dict(x=x, x_stage0=x0, err_trace=trace, verts=verts, joints=joints)
-    return meshes, markers, valid_b, info
+        return out + (dev,)
+    return out

@@ -86,14 +86,44 @@ class GT_network_equiv(nn.Module):
         """models_pointcloud.py:146-221."""
         B, N, _ = hitpts.size()
         hitpts = hitpts.contiguous()
+        with pointops.knn_scope():
+            return self._forward(hitpts, pred_items, direction_mode, B, N)
+
+    overlap_index_ops = True   # run the coordinate-only FPS / kNN of the Point-Transformer nets on a side stream
+
+    def _prefetch_pt_indices(self, hitpts, B, N):
+        """All FPS / kNN queries of both Point-Transformer nets depend on the coordinates only: issue them on a side HIP
+        stream so they overlap the EPN encoder; the nets find them memoised (pointops.knn_scope)."""
+        from .pointtransformer_seg import prefetch_indices
+        main = torch.cuda.current_stream()
+        if not hasattr(self, "_side_stream"):
+            self._side_stream = torch.cuda.Stream()
+        side = self._side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            oh = [N * (i + 1) for i in range(B)]
+            o = pointops.set_host_offsets(torch.tensor(oh, dtype=torch.int32).to(hitpts.device), oh)
+            made = prefetch_indices(hitpts.view(-1, 3), o)
+            done = torch.cuda.Event()
+            done.record(side)
+        for t in made:
+            t.record_stream(main)
+        return done
+
+    def _forward(self, hitpts, pred_items, direction_mode, B, N):
+        idx_ready = None
+        if self.overlap_index_ops and hitpts.is_cuda and ("confidence" in pred_items or "magnitude" in pred_items):
+            idx_ready = self._prefetch_pt_indices(hitpts, B, N)
         r, sample_idx_lists = self.encode(hitpts)
         so3_anchors = r.anchors
         selected_indexs = torch.arange(0, N).repeat(B, 1).unsqueeze(-1).expand(-1, -1, 3).to(hitpts.device)
         # 3-NN propagation of the [C*60] equivariant features to all N points + anchor mean (:181-184), channels-last
         point_equiv_cl, point_inv_feat = propagate_cl(hitpts, r.xyz, r.feats_cl)
         results = {}
-        with pointops.knn_scope():      # both Point-Transformer nets share FPS / kNN indices (same points, same offsets)
-            self._heads(results, pred_items, direction_mode, hitpts, point_inv_feat, point_equiv_cl, so3_anchors, B, N)
+        if idx_ready is not None:
+            torch.cuda.current_stream().wait_event(idx_ready)
+        # both Point-Transformer nets share FPS / kNN indices (same points, same offsets) through the enclosing knn_scope
+        self._heads(results, pred_items, direction_mode, hitpts, point_inv_feat, point_equiv_cl, so3_anchors, B, N)
         return results, selected_indexs
 
     def _heads(self, results, pred_items, direction_mode, hitpts, point_inv_feat, point_equiv_cl, so3_anchors, B, N):

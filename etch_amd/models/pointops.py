@@ -52,6 +52,17 @@ def _memo(key, keep, fn):
     return hit[0]
 
 
+def make_offsets(values, device, like=None):
+    """Device int32 offset tensor carrying its host copy; memoised per (parent offsets, stride) inside a knn_scope so the
+    two nets (and the index prefetch) share ONE tensor object per level (memo keys are tensor addresses)."""
+    def build():
+        return set_host_offsets(torch.tensor(values, dtype=torch.int32, device=device), values)
+    if like is None:
+        return build()
+    parent, stride = like
+    return _memo(("offs", parent.data_ptr(), stride, tuple(values)), (parent,), build)
+
+
 def furthestsampling(xyz, offset, new_offset):
     """pointops.py:10-28."""
     oh, noh = host_offsets(offset), host_offsets(new_offset)

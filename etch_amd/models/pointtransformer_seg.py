@@ -46,16 +46,21 @@ class PointTransformerLayer(nn.Module):
             params = [d(self.linear_p[0].weight), d(self.linear_p[0].bias), sp, tp, d(self.linear_p[3].weight), d(self.linear_p[3].bias),
                       s0, t0, d(self.linear_w[2].weight).t().contiguous(), d(self.linear_w[2].bias), s3, t3,
                       d(self.linear_w[5].weight), d(self.linear_w[5].bias)]
-            return wqkv, bqkv, params
+            return wqkv, bqkv, params, (d(self.linear_w[2].weight), d(self.linear_w[2].bias), s3, t3, d(self.linear_w[5].weight), d(self.linear_w[5].bias))
 
         return self._d.get(ps, build)
 
     def forward(self, pxo, out_bn=None) -> torch.Tensor:
         p, x, o = pxo
-        wqkv, bqkv, params = self._derived()
+        wqkv, bqkv, params, mlp = self._derived()
         qkv = ops.linear(x, wqkv, bias=bqkv)
         idx = pointops.knnquery(self.nsample, p, p, o, o)[0]
-        return ops.pt_attention(p, qkv, self.out_planes, idx, params + list(out_bn if out_bn is not None else (None, None)), self.nsample)
+        allp = params + list(out_bn if out_bn is not None else (None, None))
+        if self.fused_kernel:
+            return ops.pt_attention(p, qkv, self.out_planes, idx, allp, self.nsample)
+        return ops.pt_attention_split(p, qkv, self.out_planes, idx, allp, self.nsample, *mlp)
+
+    fused_kernel = False   # True: the single-kernel VALU variant (etch_pt_attention); False: attention MLP on the matrix cores
 
 
 class TransitionDown(nn.Module):
@@ -83,8 +88,7 @@ class TransitionDown(nn.Module):
             for i in range(1, len(oh)):
                 count += (oh[i] - oh[i - 1]) // self.stride
                 n_o.append(count)
-            n_o_t = torch.tensor(n_o, dtype=torch.int32, device=p.device)
-            pointops.set_host_offsets(n_o_t, n_o)
+            n_o_t = pointops.make_offsets(n_o, p.device, like=(o, self.stride))
             idx = pointops.furthestsampling(p, o, n_o_t)
             n_p = pointops.gather_rows(p, idx)
             kidx = pointops.knnquery(self.nsample, p, n_p, o, n_o_t)[0]
@@ -268,3 +272,30 @@ def get_pointtransformer_confidence(**kwargs):
 
 def get_pointtransformer_magnitude(**kwargs):
     return PointTransformer_magnitude(PointTransformerBlock, [2, 3, 4, 6, 3], **kwargs)
+
+
+def prefetch_indices(p0, o0, strides=(1, 4, 4, 4, 4), nsamples=(8, 16, 16, 16, 16)):
+    """Issue every FPS / kNN query of the Point-Transformer U-Net for (p0, o0) -- they depend on the coordinates only --
+    so that they land in the active pointops.knn_scope cache.  The model runs this on a side stream while the EPN
+    encoder is busy; both nets then find their indices memoised.  Returns the tensors created (for record_stream)."""
+    made = []
+    levels = []
+    p, o = p0, o0
+    for li in range(5):
+        if strides[li] != 1:
+            oh = pointops.host_offsets(o)
+            n_o, count = [oh[0] // strides[li]], oh[0] // strides[li]
+            for i in range(1, len(oh)):
+                count += (oh[i] - oh[i - 1]) // strides[li]
+                n_o.append(count)
+            n_o_t = pointops.make_offsets(n_o, p.device, like=(o, strides[li]))
+            idx = pointops.furthestsampling(p, o, n_o_t)
+            n_p = pointops.gather_rows(p, idx)
+            made += [idx, n_p, n_o_t] + list(pointops.knnquery(nsamples[li], p, n_p, o, n_o_t))
+            p, o = n_p, n_o_t
+        made += list(pointops.knnquery(nsamples[li], p, p, o, o))
+        levels.append((p, o))
+    for li in range(3, -1, -1):                                  # TransitionUp interpolation: coarse -> fine 3-NN
+        (pf, of), (pc, oc) = levels[li], levels[li + 1]
+        made += list(pointops.knnquery(3, pc, pf, oc, of))
+    return made

@@ -71,7 +71,7 @@ def _seg_max(offset_host):
     return mx
 
 
-def knnquery(nsample, xyz, new_xyz, offset, new_offset, new_offset_host=None, sqrt=True):
+def knnquery(nsample, xyz, new_xyz, offset, new_offset, new_offset_host=None, sqrt=True, wave_kernel=True):
     """pointops.knnquery (pointops.py:32-45): -> idx (m,nsample) int32, dist (m,nsample) = sqrt(d2).
 
     `new_offset_host` (list of ints) avoids a device->host sync for the grid size; if omitted it is
@@ -85,7 +85,7 @@ def knnquery(nsample, xyz, new_xyz, offset, new_offset, new_offset_host=None, sq
     m = new_xyz.shape[0]
     idx = torch.empty((m, nsample), dtype=torch.int32, device=xyz.device)
     dist = torch.empty((m, nsample), dtype=torch.float32, device=xyz.device)
-    _lib.check(_lib.lib().etch_knnquery(len(new_offset_host), _seg_max(new_offset_host), int(nsample), _ptr(xyz), _ptr(new_xyz),
+    _lib.check(_lib.lib().etch_knnquery(len(new_offset_host), _seg_max(new_offset_host), int(m) if wave_kernel else 0, int(nsample), _ptr(xyz), _ptr(new_xyz),
                                         _ptr(offset), _ptr(new_offset), _ptr(idx), _ptr(dist), 1 if sqrt else 0, _stream()),
                "etch_knnquery")
     return idx, dist
@@ -247,6 +247,23 @@ def pt_attention(p, qkv, c, idx, params, ns):
     base = qkv.data_ptr()
     _lib.check(_lib.lib().etch_pt_attention(n, c, ns, _ptr(p), _vp(base), _vp(base + 4 * c), _vp(base + 8 * c), _c_long(qkv.stride(0)),
                                             _ptr(idx), arr, _ptr(out), _c_long(c), _stream()), "etch_pt_attention")
+    return out
+
+
+def pt_attention_split(p, qkv, c, idx, params, ns, w2, b2, s3, t3, w5, b5):
+    """Same result as pt_attention with the two Linear layers of linear_w on the matrix cores (etch_linear)."""
+    n = p.shape[0]
+    arr = (ctypes.c_void_p * 16)(*[(0 if t is None else t.data_ptr()) for t in params])
+    base = qkv.data_ptr()
+    ldq = _c_long(qkv.stride(0))
+    w_in = torch.empty((n * ns, c), dtype=torch.float32, device=p.device)
+    _lib.check(_lib.lib().etch_pt_attn_prep(n, c, ns, _ptr(p), _vp(base), _vp(base + 4 * c), ldq, _ptr(idx), arr, _ptr(w_in), _stream()),
+               "etch_pt_attn_prep")
+    hid = linear(w_in, w2, bias=b2, scale=s3, shift=t3, act="relu")
+    logits = linear(hid, w5, bias=b5)
+    out = torch.empty((n, c), dtype=torch.float32, device=p.device)
+    _lib.check(_lib.lib().etch_pt_attn_aggregate(n, c, ns, _ptr(p), _vp(base + 8 * c), ldq, _ptr(idx), _ptr(logits), arr, _ptr(out), _c_long(c),
+                                                 _stream()), "etch_pt_attn_aggregate")
     return out
 
 

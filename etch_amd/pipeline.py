@@ -1,0 +1,63 @@
+"""Throughput pipeline of the hot path: stage 1 (equivariant net) of batch i+1 overlaps stage 2 (marker fit, 32 persistent
+workgroups = 1/8 of the chip) of batch i on a second HIP stream.  Results are identical to the synchronous
+`inference_demo.predict_smpl_batch`; only the schedule differs.  Scans are independent, so no state is shared between
+in-flight batches besides the (read-only) weights and body-model tables."""
+import torch
+
+from . import ops
+from .models.fit_SMPL import fit_smpl_device, fit_smpl_finalize
+
+
+class Ticket:
+    def __init__(self, done, stage1, fit):
+        self.done, self.stage1, self.fit = done, stage1, fit
+
+
+class HotPathPipeline:
+    def __init__(self, args, model, gender="neutral", max_in_flight=2, **fit_kwargs):
+        self.args, self.model, self.gender, self.fit_kwargs = args, model, gender, fit_kwargs
+        self.s1 = torch.cuda.Stream()
+        self.s2 = torch.cuda.Stream()
+        self.max_in_flight = max_in_flight
+        self.in_flight = []
+
+    def submit(self, points):
+        """Enqueue one batch (B,N,3) resident on the device; returns a Ticket.  Never blocks on the GPU."""
+        caller = torch.cuda.current_stream()
+        self.s1.wait_stream(caller)
+        with torch.no_grad():
+            with torch.cuda.stream(self.s1):
+                results, _ = self.model(points, pred_items=["confidence", "direction", "magnitude"], direction_mode="standard_vector")
+                labels = ops.argmax_rows(results["part_labels"])
+                inner = ops.inner_points(points.contiguous(), results["direction"], results["magnitude"], float(self.args.scale_magnitude))
+                ready = torch.cuda.Event()
+                ready.record(self.s1)
+            conf = results["confidences"]
+            for t in (inner, labels, conf):
+                t.record_stream(self.s2)
+            with torch.cuda.stream(self.s2):
+                self.s2.wait_event(ready)
+                fit = fit_smpl_device(self.args, inner, labels, conf, self.gender, **self.fit_kwargs)
+                done = torch.cuda.Event()
+                done.record(self.s2)
+        t = Ticket(done, results, fit)
+        self.in_flight.append(t)
+        return t
+
+    def result(self, ticket):
+        """Wait for one batch and return the reference's fit_smpl tuple (meshes, markers, valid, smpl_info)."""
+        ticket.done.synchronize()
+        if ticket in self.in_flight:
+            self.in_flight.remove(ticket)
+        with torch.cuda.stream(self.s2):
+            return fit_smpl_finalize(ticket.fit)
+
+    def run(self, batches):
+        """Process an iterable of batches with at most `max_in_flight` enqueued; yields results in order."""
+        pending = []
+        for pts in batches:
+            pending.append(self.submit(pts))
+            if len(pending) >= self.max_in_flight:
+                yield self.result(pending.pop(0))
+        while pending:
+            yield self.result(pending.pop(0))

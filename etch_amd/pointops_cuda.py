@@ -11,7 +11,7 @@ from .ops import _ptr, _seg_max, _stream
 def knnquery_cuda(m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2):
     """Fills idx (m,nsample) int32 and dist2 (m,nsample) with SQUARED distances (knnquery_cuda.cpp:9-19)."""
     no = new_offset.tolist()
-    _lib.check(_lib.lib().etch_knnquery(len(no), _seg_max(no), int(nsample), _ptr(xyz), _ptr(new_xyz), _ptr(offset), _ptr(new_offset),
+    _lib.check(_lib.lib().etch_knnquery(len(no), _seg_max(no), int(m), int(nsample), _ptr(xyz), _ptr(new_xyz), _ptr(offset), _ptr(new_offset),
                                         _ptr(idx), _ptr(dist2), 0, _stream()), "etch_knnquery")
 
 

@@ -38,9 +38,11 @@ int etch_gather_points(int b, int c, int n, int m, const float* points, const in
 
 /* Replaces knnquery_cuda_launcher: knnquery/knnquery_cuda_kernel.h:10-16, kernel .cu:65-108.
  * xyz (n,3), new_xyz (m,3), offset/new_offset (b) cumulative i32 -> idx (m,nsample) i32, dist (m,nsample) f32.
- * `m_max` = largest number of queries in one segment (grid sizing; known to the host that built the
- * offsets).  write_sqrt != 0 stores sqrt(d2) (what pointops.py:43 returns), else d2.  nsample <= 28. */
-int etch_knnquery(int b, int m_max, int nsample, const float* xyz, const float* new_xyz, const int* offset,
+ * `m_max` = largest number of queries in one segment, `m_total` = total number of queries (grid sizing; known to the
+ * host that built the offsets).  m_total > 0 selects the wave-per-query kernel (64-wide distance evaluation, the
+ * reference's sequential heap updates preserved); m_total == 0 the thread-per-query kernel.  Results are identical.
+ * write_sqrt != 0 stores sqrt(d2) (what pointops.py:43 returns), else d2.  nsample <= 28. */
+int etch_knnquery(int b, int m_max, int m_total, int nsample, const float* xyz, const float* new_xyz, const int* offset,
                   const int* new_offset, int* idx, float* dist, int write_sqrt, void* stream);
 
 /* Replaces furthestsampling_cuda_launcher: sampling/sampling_cuda_kernel.h:10-16, kernel .cu:15-129.
@@ -125,6 +127,15 @@ int etch_so3_mean_dir(long T, int A, const float* w, const float* anchors, float
  * (16 pointers in total).  -> out (n,c) rows with leading dimension ldo. */
 int etch_pt_attention(int n, int c, int ns, const float* p, const float* xq, const float* xk, const float* xv, long ldq,
                       const int* idx, const float* const* params, float* out, long ldo, void* stream);
+
+/* The same layer split around the matrix cores (the schedule the model uses): prep builds the attention-MLP input
+ * w_in[(i,j),:] = relu(bn(x_k[idx] - x_q + p_r)) (pointtransformer_seg.py:31-33 up to the first Linear), the two Linear
+ * layers of linear_w run through etch_linear over all n*ns rows, aggregate applies softmax over the neighbours and the
+ * shared-plane weighted sum (:34-36) [+ block.bn2 + ReLU].  params: the same 16 pointers as etch_pt_attention. */
+int etch_pt_attn_prep(int n, int c, int ns, const float* p, const float* xq, const float* xk, long ldq, const int* idx,
+                      const float* const* params, float* w_in, void* stream);
+int etch_pt_attn_aggregate(int n, int c, int ns, const float* p, const float* xv, long ldq, const int* idx, const float* logits,
+                           const float* const* params, float* out, long ldo, void* stream);
 
 /* queryandgroup(use_xyz=True) rows for TransitionDown (pointtransformer_seg.py:61, pointops.py:90-98):
  * out[(i*ns+j)] = [p[idx[i,j]] - new_p[i] | x[idx[i,j]]], row length 3+c. */

@@ -80,10 +80,11 @@ def test_knn(k, segs, qsegs):
     else:
         q = np.concatenate([scan(4000 + i, n) for i, n in enumerate(qsegs)])
         qo = np.cumsum(qsegs).astype(np.int32)
-    idx, dist = ops.knnquery(k, dev(p), dev(q), dev(o), dev(qo))
     ri, rd2 = O.knnquery(k, p, q, o, qo)
-    assert np.array_equal(idx.cpu().numpy(), ri)
-    assert np.array_equal(dist.cpu().numpy(), np.sqrt(rd2))
+    for wave_kernel in (True, False):
+        idx, dist = ops.knnquery(k, dev(p), dev(q), dev(o), dev(qo), wave_kernel=wave_kernel)
+        assert np.array_equal(idx.cpu().numpy(), ri), wave_kernel
+        assert np.array_equal(dist.cpu().numpy(), np.sqrt(rd2)), wave_kernel
 
 
 def test_knn_exact_ties_follow_heap_order():
@@ -92,10 +93,11 @@ def test_knn_exact_ties_follow_heap_order():
     p = (rng.integers(-2, 3, (400, 3)).astype(np.float32)) * 0.5   # lattice: many exactly tied distances + duplicates
     o = np.array([150, 400], np.int32)
     for k in (3, 8, 16):
-        idx, dist = ops.knnquery(k, dev(p), dev(p), dev(o), dev(o), sqrt=False)
         ri, rd2 = O.knnquery(k, p, p, o, o)
-        assert np.array_equal(idx.cpu().numpy(), ri), k
-        assert np.array_equal(dist.cpu().numpy(), rd2), k
+        for wave_kernel in (True, False):
+            idx, dist = ops.knnquery(k, dev(p), dev(p), dev(o), dev(o), sqrt=False, wave_kernel=wave_kernel)
+            assert np.array_equal(idx.cpu().numpy(), ri), (k, wave_kernel)
+            assert np.array_equal(dist.cpu().numpy(), rd2), (k, wave_kernel)
 
 
 @pytest.mark.parametrize("segs,stride", [([5000, 5000, 5000], 4), ([1250, 1250], 4), ([312, 312], 4), ([78, 78, 78], 4), ([19, 19], 4),

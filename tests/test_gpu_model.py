@@ -96,3 +96,17 @@ def test_whole_model_vs_reference_golden(tmp_path, golden):
     d2, _, _ = ops.so3_mean_dir(aw.cuda(), torch.from_numpy(c["anchors"]).cuda())
     err2 = np.abs(d2.cpu().numpy() - g["direction"].reshape(-1, 3)).max(1)
     assert (err2 <= 1e-5 / np.minimum(gap, 1.0) + 1e-5).all()   # fp32 rounding of the reference own Ce / SVD over the conditioning
+
+
+def test_pt_layer_fused_and_split_variants_agree(golden):
+    """etch_pt_attention (one VALU kernel) and the matrix-core split (prep + etch_linear x2 + aggregate) are the same function."""
+    from etch_amd.models import pointtransformer_seg as P
+    g = golden("module_pt.npz")
+    seeds = json.loads(str(g["seeds"]))
+    d = lambda k: torch.from_numpy(g[k]).cuda()
+    layer = load_seeded(P.PointTransformerLayer(32, 32, 8, 8), seeds["layer"]).cuda().eval()
+    layer.fused_kernel = True
+    a = layer([d("p"), d("x"), d("o")]).cpu().numpy()
+    layer.fused_kernel = False
+    b = layer([d("p"), d("x"), d("o")]).cpu().numpy()
+    assert rel_err(a, g["layer_out"]) < RTOL and rel_err(b, g["layer_out"]) < RTOL
