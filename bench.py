@@ -55,7 +55,7 @@ def algorithmic_flops(name, a):
         return 2.0 * R * K * O, f"gemm_nt_kernel"
     if name == "etch_inter_so3conv":
         b, cin, cout, p1, p2, nn = v[0:6]
-        return 2.0 * b * p2 * 60 * 24 * (cin * nn + cout * cin), f"inter_so3conv_kernel<{cin},{cout}>"
+        return 2.0 * b * p2 * 60 * 24 * (cin * nn + cout * cin), f"inter_so3conv_kernel<{cin},{cout},{(nn + 15) // 16 if nn <= 32 else 4}>"
     if name == "etch_intra_so3conv":
         b, c, cout, p = v[0:4]
         return 2.0 * b * p * 60 * 12 * c * cout, f"intra_so3conv_kernel<{c},{cout}>"

@@ -25,17 +25,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //   step 2 (16 anchors at a time):  Y[o,col] = sum_kappa W[o,kappa] * X1[col][kappa] + bias      MFMA M=o, N=col, K=CIN*24
 //       X1 goes through LDS ([col][kappa], row stride CIN*24+4), W is read pre-permuted in fragment order.
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int COUT>
-__global__ void __launch_bounds__(256) inter_so3conv_kernel(
+template <int CIN, int COUT, int MAXT>     // MAXT = ceil(nn / 16) neighbour chunks held in registers (nn <= 16 * MAXT)
+__global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
     int p1, int p2, int nn, float inv_sigma, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
     const int* __restrict__ ball_idx, const float* __restrict__ feats, const float* __restrict__ rk,
     const float* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ out) {
     constexpr int MT1 = CIN / 16;          // c tiles in step 1
     constexpr int MT2 = COUT / 16;         // o tiles in step 2
     constexpr int KK = CIN * KS;           // contraction length of step 2
-    constexpr int S = KK + 4;              // LDS row stride (floats), 16-B aligned, S/4 odd
+    // For CIN = 64 the X1 tile goes through LDS in two channel halves (the second half waits in registers), which
+    // halves the LDS footprint and lets two workgroups share a CU (2 waves / SIMD hide the gather latency of step 1).
+    constexpr int HALVES = CIN >= 64 ? 2 : 1;
+    constexpr int MTH = MT1 / HALVES;      // c tiles per half
+    constexpr int KH = KK / HALVES;        // contraction length per half
+    constexpr int S = KH + 4;              // LDS row stride (floats), 16-B aligned, S/4 odd
     constexpr int PS = COUT + 4;           // partial-tile row stride
-    constexpr int MAXT = 4;                // up to 64 neighbours (nn <= 64)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X1s = smem;                     // [16][S]
     float* part = smem + 16 * S;           // [4 waves][16 cols][PS]
@@ -66,71 +70,97 @@ __global__ void __launch_bounds__(256) inter_so3conv_kernel(
     }
     const float* Fb = feats + (size_t)b * p1 * NA * CIN;
     float* outp = out + ((size_t)b * p2 + p) * NA * COUT;
+    const bool k1ok = fr < 8;
 
     for (int ag = 0; ag < 4; ++ag) {
+        f32x4 keep[4][HALVES > 1 ? MTH : 1][2];        // second channel half of the wave's 4 anchors (HALVES == 2 only)
         // ---------------- step 1: 4 anchors per wave
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = wave * 4 + j;
             const int a = ag * 16 + col;
-            if (a >= NA) break;                         // wave-uniform
-            const float* rka = rk + (size_t)a * KS * 3;
-            const float r0x = rka[fr * 3], r0y = rka[fr * 3 + 1], r0z = rka[fr * 3 + 2];
-            const bool k1ok = fr < 8;
-            const int k1 = k1ok ? 16 + fr : 0;
-            const float r1x = rka[k1 * 3], r1y = rka[k1 * 3 + 1], r1z = rka[k1 * 3 + 2];
             f32x4 acc[MT1][2];
 #pragma unroll
             for (int mi = 0; mi < MT1; ++mi) { acc[mi][0] = (f32x4){0, 0, 0, 0}; acc[mi][1] = (f32x4){0, 0, 0, 0}; }
+            if (a < NA) {                                   // wave-uniform
+                const float* rka = rk + (size_t)a * KS * 3;
+                const float r0x = rka[fr * 3], r0y = rka[fr * 3 + 1], r0z = rka[fr * 3 + 2];
+                const int k1 = k1ok ? 16 + fr : 0;
+                const float r1x = rka[k1 * 3], r1y = rka[k1 * 3 + 1], r1z = rka[k1 * 3 + 2];
 #pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                if (t < nchunk) {
+                for (int t = 0; t < MAXT; ++t) {
+                    if (t < nchunk) {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const int q = nidx[t][s];
-                        const bool ok = q >= 0;
-                        float dx = gx[t][s] - r0x, dy = gy[t][s] - r0y, dz = gz[t][s] - r0z;
-                        float d0 = dx * dx + dy * dy + dz * dz;
-                        float w0 = fmaxf(0.f, 1.0f - d0 * inv_sigma);
-                        dx = gx[t][s] - r1x; dy = gy[t][s] - r1y; dz = gz[t][s] - r1z;
-                        float d1 = dx * dx + dy * dy + dz * dz;
-                        float w1 = fmaxf(0.f, 1.0f - d1 * inv_sigma);
-                        if (!ok) { w0 = 0.f; w1 = 0.f; }
-                        if (!k1ok) w1 = 0.f;
-                        const float* frow = Fb + ((size_t)(ok ? q : 0) * NA + a) * CIN + fr;
+                        for (int s = 0; s < 4; ++s) {
+                            const int q = nidx[t][s];
+                            const bool ok = q >= 0;
+                            float dx = gx[t][s] - r0x, dy = gy[t][s] - r0y, dz = gz[t][s] - r0z;
+                            float d0 = dx * dx + dy * dy + dz * dz;
+                            float w0 = fmaxf(0.f, 1.0f - d0 * inv_sigma);
+                            dx = gx[t][s] - r1x; dy = gy[t][s] - r1y; dz = gz[t][s] - r1z;
+                            float d1 = dx * dx + dy * dy + dz * dz;
+                            float w1 = fmaxf(0.f, 1.0f - d1 * inv_sigma);
+                            if (!ok) { w0 = 0.f; w1 = 0.f; }
+                            if (!k1ok) w1 = 0.f;
+                            const float* frow = Fb + ((size_t)(ok ? q : 0) * NA + a) * CIN + fr;
 #pragma unroll
-                        for (int mi = 0; mi < MT1; ++mi) {
-                            const float av = frow[mi * 16];
-                            acc[mi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w0, acc[mi][0], 0, 0, 0);
-                            acc[mi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w1, acc[mi][1], 0, 0, 0);
+                            for (int mi = 0; mi < MT1; ++mi) {
+                                const float av = frow[mi * 16];
+                                acc[mi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w0, acc[mi][0], 0, 0, 0);
+                                acc[mi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w1, acc[mi][1], 0, 0, 0);
+                            }
                         }
                     }
                 }
             }
-            // D[row = 4fg + q][col = fr]: row -> channel c, col -> kernel point k
+            // D[row = 4fg + q][col = fr]: row -> channel c (within the half), col -> kernel point k
             float* xcol = X1s + col * S;
 #pragma unroll
-            for (int mi = 0; mi < MT1; ++mi)
+            for (int mi = 0; mi < MTH; ++mi)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int c = mi * 16 + fg * 4 + q;
                     xcol[c * KS + fr] = acc[mi][0][q];
                     if (k1ok) xcol[c * KS + 16 + fr] = acc[mi][1][q];
                 }
+            if (HALVES > 1) {
+#pragma unroll
+                for (int mi = 0; mi < MTH; ++mi) { keep[j][mi][0] = acc[MTH + mi][0]; keep[j][mi][1] = acc[MTH + mi][1]; }
+            }
         }
-        __syncthreads();
-        // ---------------- step 2: K split over the 4 waves (chunk t of 16 kappas -> wave t & 3)
         f32x4 y[MT2];
 #pragma unroll
         for (int mt = 0; mt < MT2; ++mt) y[mt] = (f32x4){0, 0, 0, 0};
-        for (int t = wave; t < KK / 16; t += 4) {
-            const float4 bv = *reinterpret_cast<const float4*>(&X1s[fr * S + t * 16 + fg * 4]);
 #pragma unroll
-            for (int mt = 0; mt < MT2; ++mt) {
-                const float4 av = *reinterpret_cast<const float4*>(&Wp[(((size_t)t * MT2 + mt) * 64 + lane) * 4]);
-                y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, y[mt], 0, 0, 0);
-                y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, y[mt], 0, 0, 0);
-                y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, y[mt], 0, 0, 0);
-                y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, y[mt], 0, 0, 0);
+        for (int h = 0; h < HALVES; ++h) {
+            if (h > 0) {
+                __syncthreads();                            // every wave finished reading the first half
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float* xcol = X1s + (wave * 4 + j) * S;
+#pragma unroll
+                    for (int mi = 0; mi < MTH; ++mi)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int c = mi * 16 + fg * 4 + q;
+                            xcol[c * KS + fr] = keep[j][mi][0][q];
+                            if (k1ok) xcol[c * KS + 16 + fr] = keep[j][mi][1][q];
+                        }
+                }
+            }
+            __syncthreads();
+            // ---------------- step 2: K split over the 4 waves (chunk t of 16 kappas -> wave t & 3)
+            for (int t = wave; t < KH / 16; t += 4) {
+                const float4 bv = *reinterpret_cast<const float4*>(&X1s[fr * S + t * 16 + fg * 4]);
+                const int tg = h * (KH / 16) + t;           // chunk index in the full K = c*24 + k order
+#pragma unroll
+                for (int mt = 0; mt < MT2; ++mt) {
+                    const float4 av = *reinterpret_cast<const float4*>(&Wp[(((size_t)tg * MT2 + mt) * 64 + lane) * 4]);
+                    y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, y[mt], 0, 0, 0);
+                    y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, y[mt], 0, 0, 0);
+                    y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, y[mt], 0, 0, 0);
+                    y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, y[mt], 0, 0, 0);
+                }
             }
         }
         // y[mt][q] = Y[o = 16mt + 4fg + q][col = fr]
@@ -147,7 +177,7 @@ __global__ void __launch_bounds__(256) inter_so3conv_kernel(
                 outp[(size_t)a * COUT + o] = v + bias[o];
             }
         }
-        // next group's step-1 writes to X1s / partial writes are ordered behind the two barriers above
+        // next group's X1s / partial writes are ordered behind the barriers above
     }
 }
 
@@ -365,11 +395,11 @@ __global__ void __launch_bounds__(256) instnorm_act_add_kernel(long n4, int rows
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
-template <int CIN, int COUT>
-static int launch_inter(int b, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz, const int* idx,
-                        const float* feats, const float* rk, const float* Wp, const float* bias, float* out, hipStream_t st) {
-    const size_t lds = (size_t)(16 * (CIN * KS + 4) + 4 * 16 * (COUT + 4)) * sizeof(float);
-    auto kern = inter_so3conv_kernel<CIN, COUT>;
+template <int CIN, int COUT, int MAXT>
+static int launch_inter_t(int b, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz, const int* idx,
+                          const float* feats, const float* rk, const float* Wp, const float* bias, float* out, hipStream_t st) {
+    const size_t lds = (size_t)(16 * (CIN * KS / (CIN >= 64 ? 2 : 1) + 4) + 4 * 16 * (COUT + 4)) * sizeof(float);
+    auto kern = inter_so3conv_kernel<CIN, COUT, MAXT>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -377,6 +407,14 @@ static int launch_inter(int b, int p1, int p2, int nn, float sigma, const float*
     hipLaunchKernelGGL(kern, dim3(p2, b), dim3(256), lds, st, p1, p2, nn, 1.0f / sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
+}
+
+template <int CIN, int COUT>
+static int launch_inter(int b, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz, const int* idx,
+                        const float* feats, const float* rk, const float* Wp, const float* bias, float* out, hipStream_t st) {
+    if (nn <= 16) return launch_inter_t<CIN, COUT, 1>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, st);
+    if (nn <= 32) return launch_inter_t<CIN, COUT, 2>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, st);
+    return launch_inter_t<CIN, COUT, 4>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, st);
 }
 
 template <int C, int COUT>
