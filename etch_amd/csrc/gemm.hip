@@ -9,6 +9,7 @@
 // interleaved order (lane group g = lane>>4 takes k = 16t + 4g + s in MFMA step s) so that one
 // ds_read_b128 per operand feeds four MFMAs; A and B use the same order, so the sum is unchanged.
 #include "common.h"
+#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -41,19 +42,21 @@ __device__ __forceinline__ float4 ld4_guard(const float* row, int k, int K, bool
     return v;
 }
 
-template <bool VECX, bool VECW>
+template <bool VECX, bool VECW, int BN>      // BN = output-tile width: 64, 128 or 192 (X is read once when BN >= O)
 __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs a) {
+    constexpr int NJ = BN / 32;                // 16-wide output tiles per wave (wave tile = 32 rows x BN/2 outputs)
+    constexpr int WL = BN / 32;                // W float4 staging loads per thread
     __shared__ __attribute__((aligned(16))) float Xs[G_BM * G_LD];
-    __shared__ __attribute__((aligned(16))) float Ws[G_BN * G_LD];
+    __shared__ __attribute__((aligned(16))) float Ws[BN * G_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r0 = blockIdx.x * G_BM, o0 = blockIdx.y * G_BN;
+    const int r0 = blockIdx.x * G_BM, o0 = blockIdx.y * BN;
     const int wm = wave >> 1, wn = wave & 1;
-    // staging coordinates: thread -> (row = tid/8 [+32], float4 column = tid%8)
+    // staging coordinates: thread -> (row = tid/8 [+32h], float4 column = tid%8)
     const int srow = tid >> 3, sc4 = (tid & 7) * 4;
     const float* xrow[2];
     bool xok[2];
-    const float* wrow[2];
-    bool wok[2];
+    const float* wrow[WL];
+    bool wok[WL];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int r = r0 + srow + 32 * h;
@@ -67,43 +70,43 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs a) {
             }
         }
         xrow[h] = a.X + src * a.ldx;
+    }
+#pragma unroll
+    for (int h = 0; h < WL; ++h) {
         const int o = o0 + srow + 32 * h;
         wok[h] = o < a.O;
         wrow[h] = a.W + (long)(wok[h] ? o : 0) * a.ldw;
     }
-    f32x4 acc[2][2];
+    f32x4 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fg = lane >> 4;
     for (int k0 = 0; k0 < a.K; k0 += G_BK) {
-        float4 xv[2], wv[2];
+        float4 xv[2], wv[WL];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            xv[h] = ld4_guard<VECX>(xrow[h], k0 + sc4, a.K, xok[h]);
-            wv[h] = ld4_guard<VECW>(wrow[h], k0 + sc4, a.K, wok[h]);
-        }
+        for (int h = 0; h < 2; ++h) xv[h] = ld4_guard<VECX>(xrow[h], k0 + sc4, a.K, xok[h]);
+#pragma unroll
+        for (int h = 0; h < WL; ++h) wv[h] = ld4_guard<VECW>(wrow[h], k0 + sc4, a.K, wok[h]);
         __syncthreads();   // previous tile fully consumed
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            *reinterpret_cast<float4*>(&Xs[(srow + 32 * h) * G_LD + sc4]) = xv[h];
-            *reinterpret_cast<float4*>(&Ws[(srow + 32 * h) * G_LD + sc4]) = wv[h];
-        }
+        for (int h = 0; h < 2; ++h) *reinterpret_cast<float4*>(&Xs[(srow + 32 * h) * G_LD + sc4]) = xv[h];
+#pragma unroll
+        for (int h = 0; h < WL; ++h) *reinterpret_cast<float4*>(&Ws[(srow + 32 * h) * G_LD + sc4]) = wv[h];
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            float4 af[2], bf[2];
+            float4 af[2], bf[NJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = *reinterpret_cast<const float4*>(&Xs[(wm * 32 + i * 16 + fr) * G_LD + t * 16 + fg * 4]);
-                bf[i] = *reinterpret_cast<const float4*>(&Ws[(wn * 32 + i * 16 + fr) * G_LD + t * 16 + fg * 4]);
-            }
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const float4*>(&Xs[(wm * 32 + i * 16 + fr) * G_LD + t * 16 + fg * 4]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const float4*>(&Ws[(wn * (BN / 2) + j * 16 + fr) * G_LD + t * 16 + fg * 4]);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
@@ -113,8 +116,8 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs a) {
     }
     // epilogue: D[row = fg*4 + reg][col = fr]
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int o = o0 + wn * 32 + j * 16 + fr;
+    for (int j = 0; j < NJ; ++j) {
+        const int o = o0 + wn * (BN / 2) + j * 16 + fr;
         if (o >= a.O) continue;
         const float bs = a.bias ? a.bias[o] : 0.f;
         const float sc = a.scale ? a.scale[o] : 1.f;
@@ -136,6 +139,120 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs a) {
     }
 }
 
+template <int BN>
+static void launch_tiled(const GemmArgs& a, bool vx, bool vw, hipStream_t st) {
+    dim3 grid((a.R + G_BM - 1) / G_BM, (a.O + BN - 1) / BN);
+    if (vx && vw) hipLaunchKernelGGL((gemm_nt_kernel<true, true, BN>), grid, dim3(256), 0, st, a);
+    else if (vx) hipLaunchKernelGGL((gemm_nt_kernel<true, false, BN>), grid, dim3(256), 0, st, a);
+    else if (vw) hipLaunchKernelGGL((gemm_nt_kernel<false, true, BN>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<false, false, BN>), grid, dim3(256), 0, st, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Skinny-K variant for the per-token layers (K in {64,128}, O*K*4 <= 64 KiB): the whole weight matrix sits in LDS in
+// MFMA fragment order for the lifetime of a persistent workgroup; every wave streams its own 16-row tiles straight
+// from HBM into A fragments (each input byte is read exactly once, no LDS round trip, no inter-wave barrier in the
+// loop) and owns all O/16 accumulators, so X is read once and Y written once: HBM-roofline for K = 64.
+// ------------------------------------------------------------------------------------------------
+template <int K, int NT>
+__global__ void __launch_bounds__(256, 2) gemm_wres_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float Wl[];      // [K/16][NT][64 lanes][4]
+    constexpr int KT = K / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int e = tid; e < KT * NT * 64; e += 256) {
+        const int l = e & 63, nt = (e >> 6) % NT, t = (e >> 6) / NT;
+        const int o = nt * 16 + (l & 15);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (o < a.O) v = *reinterpret_cast<const float4*>(a.W + (long)o * a.ldw + t * 16 + (l >> 4) * 4);
+        *reinterpret_cast<float4*>(&Wl[e * 4]) = v;
+    }
+    __syncthreads();
+    const int ntiles = (a.R + 15) >> 4;
+    float4 an[KT];
+    auto load_tile = [&](int tile) {
+        const int r = tile * 16 + fr;
+        const bool ok = r < a.R;
+        long src = 0;
+        if (ok) {
+            src = r;
+            if (a.row_idx) {
+                const int q = r / a.grp;
+                src = ((long)(q / a.p_out) * a.p_in + a.row_idx[q]) * a.grp + (r - q * a.grp);
+            }
+        }
+        const float* xr = a.X + src * a.ldx + fg * 4;
+#pragma unroll
+        for (int t = 0; t < KT; ++t) an[t] = ok ? *reinterpret_cast<const float4*>(xr + t * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    int tile = blockIdx.x * 4 + wave;
+    if (tile < ntiles) load_tile(tile);
+    for (; tile < ntiles; tile += gridDim.x * 4) {
+        float4 ac[KT];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) ac[t] = an[t];
+        const int nxt = tile + gridDim.x * 4;
+        if (nxt < ntiles) load_tile(nxt);                   // prefetch the next tile's fragments
+        const int r0 = tile * 16;
+        constexpr int NG = NT < 4 ? NT : 4;                 // output tiles per pass: bounds the live B fragments / accumulators
+#pragma unroll 1
+        for (int ng = 0; ng < NT; ng += NG) {
+            f32x4 acc[NG];
+#pragma unroll
+            for (int j = 0; j < NG; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    const int nt = ng + j < NT ? ng + j : NT - 1;
+                    const float4 b = *reinterpret_cast<const float4*>(&Wl[((t * NT + nt) * 64 + lane) * 4]);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t].x, b.x, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t].y, b.y, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t].z, b.z, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t].w, b.w, acc[j], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                const int o = (ng + j) * 16 + fr;
+                if (ng + j >= NT || o >= a.O) continue;
+                const float bs = a.bias ? a.bias[o] : 0.f;
+                const float sc = a.scale ? a.scale[o] : 1.f;
+                const float sh = a.shift ? a.shift[o] : 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = r0 + fg * 4 + q;
+                    if (r >= a.R) continue;
+                    float v = acc[j][q] + bs;
+                    if (a.scale) v = v * sc + sh;
+                    if (a.res_mode == 1) v += a.res[(long)r * a.ldr + o];
+                    if (a.act == 1) v = fmaxf(v, 0.f);
+                    else if (a.act == 2) v = v > 0.f ? v : 0.01f * v;
+                    if (a.res_mode == 2) v += a.res[(long)r * a.ldr + o];
+                    a.Y[(long)r * a.ldy + o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int K, int NT>
+static int launch_wres(const GemmArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)(K / 16) * NT * 64 * 4 * sizeof(float);
+    auto kern = gemm_wres_kernel<K, NT>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int ntiles = (a.R + 15) / 16;
+    int per_cu = lds <= 40 * 1024 ? 4 : (lds <= 53 * 1024 ? 3 : (lds <= 80 * 1024 ? 2 : 1));
+    int blocks = 256 * per_cu;
+    if (blocks > (ntiles + 3) / 4) blocks = (ntiles + 3) / 4;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, a);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
 extern "C" int etch_linear(int R, int K, int O, const float* X, long ldx, const int* row_idx, int grp, int p_in, int p_out,
                            const float* W, long ldw, const float* bias, const float* scale, const float* shift, int act,
                            const float* res, long ldr, int res_mode, float* Y, long ldy, void* stream) {
@@ -145,15 +262,17 @@ extern "C" int etch_linear(int R, int K, int O, const float* X, long ldx, const 
     if (res_mode != 0 && res == nullptr) return ETCH_EINVAL;
     if (row_idx && (grp <= 0 || p_out <= 0)) return ETCH_EINVAL;
     GemmArgs a{R, K, O, X, ldx, row_idx, grp, p_in, p_out, W, ldw, bias, scale, shift, act, res, ldr, res_mode, Y, ldy};
-    dim3 grid((R + G_BM - 1) / G_BM, (O + G_BN - 1) / G_BN);
-    if (grid.y > 65535) return ETCH_EUNSUPPORTED;
     const bool vx = !(K & 3) && !(ldx & 3) && !((uintptr_t)X & 15);
     const bool vw = !(K & 3) && !(ldw & 3) && !((uintptr_t)W & 15);
     hipStream_t st = (hipStream_t)stream;
-    if (vx && vw) hipLaunchKernelGGL((gemm_nt_kernel<true, true>), grid, dim3(256), 0, st, a);
-    else if (vx) hipLaunchKernelGGL((gemm_nt_kernel<true, false>), grid, dim3(256), 0, st, a);
-    else if (vw) hipLaunchKernelGGL((gemm_nt_kernel<false, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_nt_kernel<false, false>), grid, dim3(256), 0, st, a);
+    static const bool no_wres = getenv("ETCH_GEMM_NO_WRES") != nullptr;   // diagnostics: force the tiled kernel
+    if (!no_wres && vx && vw && R >= 8192 && O <= 16) {   // weight-resident streaming kernel: narrow outputs only (measured)
+        if (K == 64) return launch_wres<64, 1>(a, st);
+        if (K == 128) return launch_wres<128, 1>(a, st);
+    }
+    // output-tile width 64: measured faster than 128 / 192 on every shape of the path (the X re-reads of the
+    // narrower tile hit L2 / Infinity Cache; the wider tiles lose occupancy) -- see profiles/r01_gemm_shapes.txt
+    launch_tiled<64>(a, vx, vw, st);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }
