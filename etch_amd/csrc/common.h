@@ -35,6 +35,26 @@ __device__ __forceinline__ unsigned long long etch_wave_max_u64(unsigned long lo
     return v;
 }
 
+// 64-bit wave max on the VALU (DPP row shifts + row broadcasts, no LDS traffic); result valid in every lane
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ unsigned long long etch_dpp_max_u64(unsigned long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v & 0xFFFFFFFFull), CTRL, ROW_MASK, 0xf, BOUND);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, ROW_MASK, 0xf, BOUND);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned long long etch_wave_max_u64_dpp(unsigned long long v) {
+    v = etch_dpp_max_u64<0x111, 0xf, true>(v);     // row_shr:1  (out-of-row lanes read 0, the identity of max)
+    v = etch_dpp_max_u64<0x112, 0xf, true>(v);     // row_shr:2
+    v = etch_dpp_max_u64<0x114, 0xf, true>(v);     // row_shr:4
+    v = etch_dpp_max_u64<0x118, 0xf, true>(v);     // row_shr:8  -> lane 15 of each row holds the row max
+    v = etch_dpp_max_u64<0x142, 0xa, false>(v);    // row_bcast:15 into rows 1 and 3
+    v = etch_dpp_max_u64<0x143, 0xc, false>(v);    // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave max
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xFFFFFFFFull), 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 __device__ __forceinline__ float etch_wave_sum_f32(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);

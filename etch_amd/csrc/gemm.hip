@@ -103,15 +103,13 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs a) {
             for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const float4*>(&Xs[(wm * 32 + i * 16 + fr) * G_LD + t * 16 + fg * 4]);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const float4*>(&Ws[(wn * (BN / 2) + j * 16 + fr) * G_LD + t * 16 + fg * 4]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                }
+            // k-slice outermost: consecutive MFMAs hit different accumulators (a 16x16x4 f32 MFMA has a 40-cycle
+            // dependent latency vs a 32-cycle issue interval), so no accumulator is touched twice in a row
+#define G_STEP(C)                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j)         \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].C, bf[j].C, acc[i][j], 0, 0, 0);
+            G_STEP(x) G_STEP(y) G_STEP(z) G_STEP(w)
+#undef G_STEP
         }
     }
     // epilogue: D[row = fg*4 + reg][col = fr]

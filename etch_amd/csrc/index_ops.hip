@@ -126,12 +126,12 @@ __global__ void __launch_bounds__(THREADS) fps_kernel(const float* __restrict__ 
                 best = key > best ? key : best;
             }
         }
-        best = etch_wave_max_u64(best);
+        best = etch_wave_max_u64_dpp(best);
         if (lane == 0) red[wave] = best;
         __syncthreads();
         if (wave == 0) {
             unsigned long long v = lane < THREADS / 64 ? red[lane] : 0ull;
-            v = etch_wave_max_u64(v);
+            v = etch_wave_max_u64_dpp(v);
             if (lane == 0) {
                 int w = 0;  // no candidate at all -> local index 0 (reference: besti default)
                 if (v != 0ull) {

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
 
     // per-lane neighbour data for n = 16t + 4fg + s
     int nidx[MAXT][4];
-    float gx[MAXT][4], gy[MAXT][4], gz[MAXT][4];
+    float gx[MAXT][4], gy[MAXT][4], gz[MAXT][4], ga[MAXT][4];
     {
         const float cx = new_xyz[((size_t)b * 3 + 0) * p2 + p], cy = new_xyz[((size_t)b * 3 + 1) * p2 + p],
                     cz = new_xyz[((size_t)b * 3 + 2) * p2 + p];
@@ -65,7 +65,10 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
                 if (t < nchunk && n < nn) q = row[n];
                 nidx[t][s] = q;
                 const int qq = q < 0 ? 0 : q;
-                gx[t][s] = X[qq] - cx; gy[t][s] = X[p1 + qq] - cy; gz[t][s] = X[2 * p1 + qq] - cz;
+                const float x = X[qq] - cx, y = X[p1 + qq] - cy, z = X[2 * p1 + qq] - cz;
+                // w = relu(1 - |g - r|^2 / sigma) = relu(ga + rb + G . r):  5 VALU ops per weight instead of 8
+                ga[t][s] = q < 0 ? -1e30f : 1.0f - (x * x + y * y + z * z) * inv_sigma;     // padded neighbour -> weight 0
+                gx[t][s] = 2.0f * inv_sigma * x; gy[t][s] = 2.0f * inv_sigma * y; gz[t][s] = 2.0f * inv_sigma * z;
             }
     }
     const float* Fb = feats + (size_t)b * p1 * NA * CIN;
@@ -87,22 +90,17 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
                 const float r0x = rka[fr * 3], r0y = rka[fr * 3 + 1], r0z = rka[fr * 3 + 2];
                 const int k1 = k1ok ? 16 + fr : 0;
                 const float r1x = rka[k1 * 3], r1y = rka[k1 * 3 + 1], r1z = rka[k1 * 3 + 2];
+                const float rb0 = -(r0x * r0x + r0y * r0y + r0z * r0z) * inv_sigma;
+                const float rb1 = k1ok ? -(r1x * r1x + r1y * r1y + r1z * r1z) * inv_sigma : -1e30f;   // k >= 24: weight 0
 #pragma unroll
                 for (int t = 0; t < MAXT; ++t) {
                     if (t < nchunk) {
 #pragma unroll
                         for (int s = 0; s < 4; ++s) {
                             const int q = nidx[t][s];
-                            const bool ok = q >= 0;
-                            float dx = gx[t][s] - r0x, dy = gy[t][s] - r0y, dz = gz[t][s] - r0z;
-                            float d0 = dx * dx + dy * dy + dz * dz;
-                            float w0 = fmaxf(0.f, 1.0f - d0 * inv_sigma);
-                            dx = gx[t][s] - r1x; dy = gy[t][s] - r1y; dz = gz[t][s] - r1z;
-                            float d1 = dx * dx + dy * dy + dz * dz;
-                            float w1 = fmaxf(0.f, 1.0f - d1 * inv_sigma);
-                            if (!ok) { w0 = 0.f; w1 = 0.f; }
-                            if (!k1ok) w1 = 0.f;
-                            const float* frow = Fb + ((size_t)(ok ? q : 0) * NA + a) * CIN + fr;
+                            const float w0 = fmaxf(0.f, fmaf(gz[t][s], r0z, fmaf(gy[t][s], r0y, fmaf(gx[t][s], r0x, ga[t][s] + rb0))));
+                            const float w1 = fmaxf(0.f, fmaf(gz[t][s], r1z, fmaf(gy[t][s], r1y, fmaf(gx[t][s], r1x, ga[t][s] + rb1))));
+                            const float* frow = Fb + ((size_t)(q < 0 ? 0 : q) * NA + a) * CIN + fr;
 #pragma unroll
                             for (int mi = 0; mi < MT1; ++mi) {
                                 const float av = frow[mi * 16];
@@ -153,14 +151,18 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
             for (int t = wave; t < KH / 16; t += 4) {
                 const float4 bv = *reinterpret_cast<const float4*>(&X1s[fr * S + t * 16 + fg * 4]);
                 const int tg = h * (KH / 16) + t;           // chunk index in the full K = c*24 + k order
+                float4 av[MT2];
 #pragma unroll
-                for (int mt = 0; mt < MT2; ++mt) {
-                    const float4 av = *reinterpret_cast<const float4*>(&Wp[(((size_t)tg * MT2 + mt) * 64 + lane) * 4]);
-                    y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, y[mt], 0, 0, 0);
-                    y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, y[mt], 0, 0, 0);
-                    y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, y[mt], 0, 0, 0);
-                    y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, y[mt], 0, 0, 0);
-                }
+                for (int mt = 0; mt < MT2; ++mt) av[mt] = *reinterpret_cast<const float4*>(&Wp[(((size_t)tg * MT2 + mt) * 64 + lane) * 4]);
+                // k-slice outermost so consecutive MFMAs use different accumulators (40-cycle dependent latency)
+#pragma unroll
+                for (int mt = 0; mt < MT2; ++mt) y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].x, bv.x, y[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT2; ++mt) y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].y, bv.y, y[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT2; ++mt) y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].z, bv.z, y[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT2; ++mt) y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].w, bv.w, y[mt], 0, 0, 0);
             }
         }
         // y[mt][q] = Y[o = 16mt + 4fg + q][col = fr]
@@ -294,17 +296,15 @@ __global__ void __launch_bounds__(256) intra_so3conv_kernel(int npts_total, int 
         float4 bv[PTS];
 #pragma unroll
         for (int pi = 0; pi < PTS; ++pi) bv[pi] = *reinterpret_cast<const float4*>(&Xs[(pi * NA + src) * LD + cb + fg * 4]);
+        float4 av[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const float4 av = *reinterpret_cast<const float4*>(&Wp[(((size_t)t * MT + mt) * 64 + lane) * 4]);
-#pragma unroll
-            for (int pi = 0; pi < PTS; ++pi) {
-                acc[pi][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv[pi].x, acc[pi][mt], 0, 0, 0);
-                acc[pi][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv[pi].y, acc[pi][mt], 0, 0, 0);
-                acc[pi][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv[pi].z, acc[pi][mt], 0, 0, 0);
-                acc[pi][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv[pi].w, acc[pi][mt], 0, 0, 0);
-            }
-        }
+        for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const float4*>(&Wp[(((size_t)t * MT + mt) * 64 + lane) * 4]);
+        // k-slice outermost so consecutive MFMAs use different accumulators (40-cycle dependent latency)
+#define I_STEP(C)                                                                                         \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int pi = 0; pi < PTS; ++pi)  \
+        acc[pi][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].C, bv[pi].C, acc[pi][mt], 0, 0, 0);
+        I_STEP(x) I_STEP(y) I_STEP(z) I_STEP(w)
+#undef I_STEP
     }
     if (a < NA) {
 #pragma unroll
