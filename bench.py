@@ -217,10 +217,14 @@ def main():
     tot_ms = sum(d["ms"] for d in agg.values())
     kern, d = max(agg.items(), key=lambda kv: kv[1]["ms"])
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+    # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    # runs of this same command, corrected as profiles/pmc_traffic.py documents); counters cannot be read inside this process
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(pmc):
-        traffic = json.load(open(pmc)).get(kern)
+        ent = json.load(open(pmc)).get(kern)
+        if ent:
+            traffic = round(ent["bytes_per_launch"])
     out["roofline"] = {"bound": "mfma", "kernel": kern, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                        "launches_per_step": d["calls"], "avg_launch_ms": round(d["ms"] / d["calls"], 4),

@@ -84,18 +84,24 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs a) {
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fg = lane >> 4;
+    float4 xv[2], wv[WL];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) xv[h] = ld4_guard<VECX>(xrow[h], sc4, a.K, xok[h]);
+#pragma unroll
+    for (int h = 0; h < WL; ++h) wv[h] = ld4_guard<VECW>(wrow[h], sc4, a.K, wok[h]);
     for (int k0 = 0; k0 < a.K; k0 += G_BK) {
-        float4 xv[2], wv[WL];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) xv[h] = ld4_guard<VECX>(xrow[h], k0 + sc4, a.K, xok[h]);
-#pragma unroll
-        for (int h = 0; h < WL; ++h) wv[h] = ld4_guard<VECW>(wrow[h], k0 + sc4, a.K, wok[h]);
         __syncthreads();   // previous tile fully consumed
 #pragma unroll
         for (int h = 0; h < 2; ++h) *reinterpret_cast<float4*>(&Xs[(srow + 32 * h) * G_LD + sc4]) = xv[h];
 #pragma unroll
         for (int h = 0; h < WL; ++h) *reinterpret_cast<float4*>(&Ws[(srow + 32 * h) * G_LD + sc4]) = wv[h];
         __syncthreads();
+        if (k0 + G_BK < a.K) {      // register prefetch of the next K tile: in flight while this tile is multiplied
+#pragma unroll
+            for (int h = 0; h < 2; ++h) xv[h] = ld4_guard<VECX>(xrow[h], k0 + G_BK + sc4, a.K, xok[h]);
+#pragma unroll
+            for (int h = 0; h < WL; ++h) wv[h] = ld4_guard<VECW>(wrow[h], k0 + G_BK + sc4, a.K, wok[h]);
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             float4 af[2], bf[NJ];
