@@ -18,7 +18,9 @@ import sys
 
 def short(name):
     name = re.sub(r"^void ", "", name)
-    m = re.match(r"([A-Za-z0-9_]+)(<[^>]*>)?", name)
+    m = re.match(r"([A-Za-z0-9_:]+)(<[^>]*>)?", name)
+    if m is None:
+        return name[:60]
     base, targs = m.group(1), (m.group(2) or "")
     if base == "gemm_nt_kernel":
         return base
