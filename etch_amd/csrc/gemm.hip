@@ -10,6 +10,7 @@
 // ds_read_b128 per operand feeds four MFMAs; A and B use the same order, so the sum is unchanged.
 #include "common.h"
 #include <cstdlib>
+#include <cstring>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -42,23 +43,25 @@ __device__ __forceinline__ float4 ld4_guard(const float* row, int k, int K, bool
     return v;
 }
 
-template <bool VECX, bool VECW, int BN>      // BN = output-tile width: 64, 128 or 192 (X is read once when BN >= O)
+template <bool VECX, bool VECW, int BN, int BM = 64>   // block tile BM rows x BN outputs (BM, BN multiples of 64)
 __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs a) {
-    constexpr int NJ = BN / 32;                // 16-wide output tiles per wave (wave tile = 32 rows x BN/2 outputs)
+    constexpr int NJ = BN / 32;                // 16-wide output tiles per wave (wave tile = BM/2 rows x BN/2 outputs)
+    constexpr int MI = BM / 32;                // 16-high row tiles per wave
     constexpr int WL = BN / 32;                // W float4 staging loads per thread
-    __shared__ __attribute__((aligned(16))) float Xs[G_BM * G_LD];
+    constexpr int XL = BM / 32;                // X float4 staging loads per thread
+    __shared__ __attribute__((aligned(16))) float Xs[BM * G_LD];
     __shared__ __attribute__((aligned(16))) float Ws[BN * G_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r0 = blockIdx.x * G_BM, o0 = blockIdx.y * BN;
+    const int r0 = blockIdx.x * BM, o0 = blockIdx.y * BN;
     const int wm = wave >> 1, wn = wave & 1;
     // staging coordinates: thread -> (row = tid/8 [+32h], float4 column = tid%8)
     const int srow = tid >> 3, sc4 = (tid & 7) * 4;
-    const float* xrow[2];
-    bool xok[2];
+    const float* xrow[XL];
+    bool xok[XL];
     const float* wrow[WL];
     bool wok[WL];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < XL; ++h) {
         const int r = r0 + srow + 32 * h;
         xok[h] = r < a.R;
         long src = 0;
@@ -77,42 +80,42 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs a) {
         wok[h] = o < a.O;
         wrow[h] = a.W + (long)(wok[h] ? o : 0) * a.ldw;
     }
-    f32x4 acc[2][NJ];
+    f32x4 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fg = lane >> 4;
-    float4 xv[2], wv[WL];
+    float4 xv[XL], wv[WL];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) xv[h] = ld4_guard<VECX>(xrow[h], sc4, a.K, xok[h]);
+    for (int h = 0; h < XL; ++h) xv[h] = ld4_guard<VECX>(xrow[h], sc4, a.K, xok[h]);
 #pragma unroll
     for (int h = 0; h < WL; ++h) wv[h] = ld4_guard<VECW>(wrow[h], sc4, a.K, wok[h]);
     for (int k0 = 0; k0 < a.K; k0 += G_BK) {
         __syncthreads();   // previous tile fully consumed
 #pragma unroll
-        for (int h = 0; h < 2; ++h) *reinterpret_cast<float4*>(&Xs[(srow + 32 * h) * G_LD + sc4]) = xv[h];
+        for (int h = 0; h < XL; ++h) *reinterpret_cast<float4*>(&Xs[(srow + 32 * h) * G_LD + sc4]) = xv[h];
 #pragma unroll
         for (int h = 0; h < WL; ++h) *reinterpret_cast<float4*>(&Ws[(srow + 32 * h) * G_LD + sc4]) = wv[h];
         __syncthreads();
         if (k0 + G_BK < a.K) {      // register prefetch of the next K tile: in flight while this tile is multiplied
 #pragma unroll
-            for (int h = 0; h < 2; ++h) xv[h] = ld4_guard<VECX>(xrow[h], k0 + G_BK + sc4, a.K, xok[h]);
+            for (int h = 0; h < XL; ++h) xv[h] = ld4_guard<VECX>(xrow[h], k0 + G_BK + sc4, a.K, xok[h]);
 #pragma unroll
             for (int h = 0; h < WL; ++h) wv[h] = ld4_guard<VECW>(wrow[h], k0 + G_BK + sc4, a.K, wok[h]);
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            float4 af[2], bf[NJ];
+            float4 af[MI], bf[NJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const float4*>(&Xs[(wm * 32 + i * 16 + fr) * G_LD + t * 16 + fg * 4]);
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const float4*>(&Xs[(wm * (BM / 2) + i * 16 + fr) * G_LD + t * 16 + fg * 4]);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const float4*>(&Ws[(wn * (BN / 2) + j * 16 + fr) * G_LD + t * 16 + fg * 4]);
             // k-slice outermost: consecutive MFMAs hit different accumulators (a 16x16x4 f32 MFMA has a 40-cycle
             // dependent latency vs a 32-cycle issue interval), so no accumulator is touched twice in a row
 #define G_STEP(C)                                                                                        \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j)         \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j)        \
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].C, bf[j].C, acc[i][j], 0, 0, 0);
             G_STEP(x) G_STEP(y) G_STEP(z) G_STEP(w)
 #undef G_STEP
@@ -127,10 +130,10 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs a) {
         const float sc = a.scale ? a.scale[o] : 1.f;
         const float sh = a.shift ? a.shift[o] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int r = r0 + wm * 32 + i * 16 + fg * 4 + q;
+                const int r = r0 + wm * (BM / 2) + i * 16 + fg * 4 + q;
                 if (r >= a.R) continue;
                 float v = acc[i][j][q] + bs;
                 if (a.scale) v = v * sc + sh;
@@ -143,13 +146,13 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs a) {
     }
 }
 
-template <int BN>
+template <int BN, int BM = 64>
 static void launch_tiled(const GemmArgs& a, bool vx, bool vw, hipStream_t st) {
-    dim3 grid((a.R + G_BM - 1) / G_BM, (a.O + BN - 1) / BN);
-    if (vx && vw) hipLaunchKernelGGL((gemm_nt_kernel<true, true, BN>), grid, dim3(256), 0, st, a);
-    else if (vx) hipLaunchKernelGGL((gemm_nt_kernel<true, false, BN>), grid, dim3(256), 0, st, a);
-    else if (vw) hipLaunchKernelGGL((gemm_nt_kernel<false, true, BN>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_nt_kernel<false, false, BN>), grid, dim3(256), 0, st, a);
+    dim3 grid((a.R + BM - 1) / BM, (a.O + BN - 1) / BN);
+    if (vx && vw) hipLaunchKernelGGL((gemm_nt_kernel<true, true, BN, BM>), grid, dim3(256), 0, st, a);
+    else if (vx) hipLaunchKernelGGL((gemm_nt_kernel<true, false, BN, BM>), grid, dim3(256), 0, st, a);
+    else if (vw) hipLaunchKernelGGL((gemm_nt_kernel<false, true, BN, BM>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<false, false, BN, BM>), grid, dim3(256), 0, st, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -276,7 +279,10 @@ extern "C" int etch_linear(int R, int K, int O, const float* X, long ldx, const 
     }
     // output-tile width 64: measured faster than 128 / 192 on every shape of the path (the X re-reads of the
     // narrower tile hit L2 / Infinity Cache; the wider tiles lose occupancy) -- see profiles/r01_gemm_shapes.txt
-    launch_tiled<64>(a, vx, vw, st);
+    static const char* tile_env = getenv("ETCH_GEMM_TILE");    // diagnostics: "128x64" / "128x128"
+    if (tile_env && !strcmp(tile_env, "128x64")) launch_tiled<64, 128>(a, vx, vw, st);
+    else if (tile_env && !strcmp(tile_env, "128x128")) launch_tiled<128, 128>(a, vx, vw, st);
+    else launch_tiled<64>(a, vx, vw, st);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }

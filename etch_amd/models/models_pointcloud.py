@@ -64,11 +64,49 @@ class GT_network_equiv(nn.Module):
     def decode_magnitude(self, inv_feat, xyz):
         return self.magnitude_encoder(self.preprocess_data(xyz, inv_feat))
 
+    fold_linear_chains = True   # exact algebra: head_combine(last MHSA) o net[0] and net[2] o so3_reg are linear o linear
+
+    def _folded(self):
+        """Consecutive linear maps of the direction head folded in fp64 on the host (no non-linearity sits between them):
+             H     = relu(att @ (W1 Wc)^T + (W1 bc + b1))     head_combine of the last MHSA layer, then direction_predictor.net[0]
+             anc_w = H @ (W2^T w_reg) + (b2 . w_reg + b_reg)   direction_predictor.net[2], then so3_reg (Conv1d 128 -> 1)
+           which removes two 128x128 GEMMs over all B*N*60 tokens (models_pointcloud.py:115-117 computes the same function)."""
+        last = self.direction_encoder.self_attention_layers[-1]
+        n0, n2 = self.direction_predictor.net[0], self.direction_predictor.net[2]
+        ps = [last.head_combine.weight, last.head_combine.bias, n0.weight, n0.bias, n2.weight, n2.bias, self.so3_reg.weight, self.so3_reg.bias]
+
+        def build():
+            d = lambda t: t.detach().double().cpu()
+            Wc, bc, W1, b1, W2, b2 = d(ps[0]), d(ps[1]), d(ps[2]), d(ps[3]), d(ps[4]), d(ps[5])
+            wr, br = d(ps[6]).view(-1), d(ps[7]).view(-1)
+            dev = ps[0].device
+            Wf = (W1 @ Wc).float().contiguous().to(dev)
+            bf = (W1 @ bc + b1).float().contiguous().to(dev)
+            v = (W2.t() @ wr).float().contiguous().to(dev)
+            c = float(b2 @ wr + br[0])
+            return Wf, bf, v, c
+
+        if not hasattr(self, "_fold_cache"):
+            from ..vgtk_so3conv import _Derived
+            self._fold_cache = _Derived()
+        return self._fold_cache.get(ps, build)
+
     def anchor_weights(self, tokens):
         """tokens [T, 60, C] -> anc_w [T, 60]: direction_encoder -> direction_predictor -> so3_reg (models_pointcloud.py:115-117)."""
-        x = self.direction_predictor(self.direction_encoder(tokens))
-        T = x.shape[0]
-        return ops.rowdot(x.view(T * 60, -1), self.so3_reg.weight.detach().view(-1), float(self.so3_reg.bias.detach().cpu())).view(T, 60)
+        T = tokens.shape[0]
+        if not self.fold_linear_chains:
+            x = self.direction_predictor(self.direction_encoder(tokens))
+            return ops.rowdot(x.view(T * 60, -1), self.so3_reg.weight.detach().view(-1), float(self.so3_reg.bias.detach().cpu())).view(T, 60)
+        layers = self.direction_encoder.self_attention_layers
+        x = tokens
+        for layer in layers[:-1]:
+            x = layer(x, x, x, residual=True)
+        last = layers[-1]
+        Wf, bf, v, c = self._folded()
+        qkv = ops.linear(x.reshape(T * 60, last.embedding_dim), last._wqkv())
+        att = ops.mhsa_attention(qkv, T, 0, 64, 128)
+        h = ops.linear(att, Wf, bias=bf, act="relu")
+        return ops.rowdot(h, v, c).view(T, 60)
 
     def decode_direction(self, equiv_feat, anchors, initial_vectors, tokens_cl=None):
         """models_pointcloud.py:111-126.  equiv_feat [B, N, C, 60] (reference layout) or tokens_cl [B, N, 60, C]."""

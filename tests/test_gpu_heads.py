@@ -98,3 +98,19 @@ def test_so3_mean_negative_det_and_rank_deficient():
     Rz = Rz.cpu().numpy()
     assert np.isfinite(Rz).all() and np.abs(np.linalg.det(Rz.astype(np.float64)) - 1).max() < 1e-5
     assert np.abs(Rz[1] - np.eye(3)).max() < 1e-6
+
+
+def test_folded_direction_head_equals_unfolded(tmp_path):
+    """head_combine o net[0] and net[2] o so3_reg folded on the host compute the same anchor weights (to fp32 rounding)."""
+    import types
+    from etch_amd import constants as K
+    from etch_amd.models.models_pointcloud import GT_network_equiv
+    from etch_amd.utils.weights import load_seeded
+    opt = types.SimpleNamespace(output_folder=str(tmp_path), EPN_input_radius=0.4, EPN_layer_num=2, device=torch.device("cuda"), markerset=K.default_markerset())
+    m = load_seeded(GT_network_equiv(option=opt), 3).cuda().eval()
+    tok = torch.randn(500, 60, 64, device="cuda")
+    m.fold_linear_chains = False
+    a = m.anchor_weights(tok).cpu().numpy()
+    m.fold_linear_chains = True
+    b = m.anchor_weights(tok).cpu().numpy()
+    assert rel_err(b, a) < 2e-6
