@@ -27,7 +27,7 @@ struct GemmArgs {
 #define G_BM 64
 #define G_BN 64
 #define G_BK 32
-#define G_LD 36   // padded LDS row (floats); 144 B keeps 16-B alignment
+#define G_LD 40   // padded LDS row (floats): 160 B keeps 16-B alignment and makes the ds_read_b128 fragment reads conflict-free (36 was 2-way)
 
 template <bool VEC>
 __device__ __forceinline__ float4 ld4_guard(const float* row, int k, int K, bool row_ok) {

@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
     constexpr int HALVES = CIN >= 64 ? 2 : 1;
     constexpr int MTH = MT1 / HALVES;      // c tiles per half
     constexpr int KH = KK / HALVES;        // contraction length per half
-    constexpr int S = KH + 4;              // LDS row stride (floats), 16-B aligned, S/4 odd
+    constexpr int S = KH + 40;             // LDS row stride (floats): S/4 = 10 (mod 16) keeps the ds_read_b128 B-fragment reads conflict-free
     constexpr int PS = COUT + 4;           // partial-tile row stride
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X1s = smem;                     // [16][S]
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(256) intra_so3conv_kernel(int npts_total, int 
                                                             const int* __restrict__ intra_idx, const float* __restrict__ Wp,
                                                             const float* __restrict__ bias, float* __restrict__ Y) {
     constexpr int MT = COUT / 16;
-    constexpr int LD = C + 4;
+    constexpr int LD = C == 16 ? 56 : C + 40;   // row stride (floats) with LD/4 = 10 or 14 (mod 16): conflict-free ds_read_b128 of the gathered rows
     constexpr int NT = 12 * C / 16;        // K chunks
     __shared__ __attribute__((aligned(16))) float Xs[PTS * NA * LD];
     __shared__ int iidx[NA * 12];
@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(256) instnorm_act_add_kernel(long n4, int rows
 template <int CIN, int COUT, int MAXT>
 static int launch_inter_t(int b, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz, const int* idx,
                           const float* feats, const float* rk, const float* Wp, const float* bias, float* out, hipStream_t st) {
-    const size_t lds = (size_t)(16 * (CIN * KS / (CIN >= 64 ? 2 : 1) + 4) + 4 * 16 * (COUT + 4)) * sizeof(float);
+    const size_t lds = (size_t)(16 * (CIN * KS / (CIN >= 64 ? 2 : 1) + 40) + 4 * 16 * (COUT + 4)) * sizeof(float);
     auto kern = inter_so3conv_kernel<CIN, COUT, MAXT>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
