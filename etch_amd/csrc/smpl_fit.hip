@@ -22,7 +22,7 @@
 #define DOF 85
 #define MAXM 86
 #define LDJ 88            // J row stride (floats), 16-B aligned
-#define LM_THREADS 384
+#define LM_THREADS 768
 
 struct SmplConsts {
     const float* J0;      // [24][3]      J_regressor @ v_template
@@ -85,6 +85,7 @@ __device__ inline void fk_chain(const int* parents, const double* R, const doubl
 
 // ---------------------------------------------------------------------------------------------- LM fit
 #define LM_WAVES (LM_THREADS / 64)
+#define LM_WS_OWN 6
 struct LmWaveScratch {               // per-wave staging of one marker
     float P[624];                    // posedirs columns of the marker: [207][3]
     float Ay[NJ][4];                 // W_vj * y_vj (xyz) and W_vj
@@ -112,8 +113,9 @@ struct LmShared {
     float target[3 * MAXM], mask[MAXM];  // LDS copies: no global load may sit between a prefetch and its use
     double err;
     long long phase[8];                 // s_memtime cycles per phase (thread 0), optional diagnostics
-    LmWaveScratch ws[LM_WAVES];
+    LmWaveScratch ws[LM_WS_OWN];        // staging of waves 0..LM_WS_OWN-1; the other waves stage inside A (dead while linearising)
 };
+static_assert((LM_WAVES - LM_WS_OWN) * sizeof(LmWaveScratch) <= sizeof(double) * (DOF + 1) * (DOF + 2) / 2, "aliased wave scratch must fit the packed matrix");
 
 __device__ inline double& Apk(double* A, int i, int j) { return A[i * (i + 1) / 2 + j]; }   // i >= j
 
@@ -207,7 +209,7 @@ __device__ void lm_linearize(LmShared& s, const SmplConsts& C, int M, int nb, co
     __syncthreads();
     if (tid == 0) { const long long t1 = wall_clock64(); s.phase[0] += t1 - t0; t0 = t1; }
     // ---- one wave per marker: forward, residual, and the marker's three Jacobian rows
-    LmWaveScratch& w = s.ws[wave];
+    LmWaveScratch& w = wave < LM_WS_OWN ? s.ws[wave] : reinterpret_cast<LmWaveScratch*>(s.A)[wave - LM_WS_OWN];
     float pre[11];                             // register prefetch of the next marker's P (10 / lane) and S|W (1 / lane)
     auto fetch = [&](int v) {
         const float* Pg = C.mk_P + (size_t)v * 621;
@@ -358,9 +360,10 @@ __device__ void lm_solve(LmShared& s, int M, double lambda) {
     // Right-looking Cholesky of the packed lower triangle with the rhs carried as an extra row (gives y = L^-1 g for
     // free), ONE barrier per column: the trailing update uses the unscaled column, A_ij -= A_ik A_jk / A_kk; columns
     // are scaled to L in one pass at the end.  The pair enumeration e -> (ii, jj) does not depend on the column.
-    unsigned pr[10];
+    constexpr int NPR = ((DOF + 1) * (DOF + 2) / 2 + LM_THREADS - 1) / LM_THREADS;
+    unsigned pr[NPR];
 #pragma unroll
-    for (int m = 0; m < 10; ++m) {
+    for (int m = 0; m < NPR; ++m) {
         const int e = tid + LM_THREADS * m;
         int ii = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
         while ((ii + 1) * (ii + 2) / 2 <= e) ++ii;
@@ -375,7 +378,7 @@ __device__ void lm_solve(LmShared& s, int M, double lambda) {
         const int npairs = n * (n + 1) / 2;
         const int tk = (k + 1) * (k + 2) / 2;               // packed offset of row k+1
 #pragma unroll
-        for (int m = 0; m < 10; ++m) {
+        for (int m = 0; m < NPR; ++m) {
             if (tid + LM_THREADS * m < npairs) {
                 const int ii = (int)(pr[m] >> 16), jj = (int)(pr[m] & 0xFFFFu);
                 const int ri = tk + ii * (ii + 1) / 2 + (k + 1) * ii, rj = tk + jj * (jj + 1) / 2 + (k + 1) * jj;   // row starts of i, j
@@ -389,7 +392,7 @@ __device__ void lm_solve(LmShared& s, int M, double lambda) {
     if (tid < DOF) s.rdiag[tid] = 1.0 / sqrt(Apk(s.A, tid, tid));
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < 10; ++m) {                          // scale: L_ik = A_ik / sqrt(A_kk) (i > k), y_k = A_85,k / sqrt(A_kk)
+    for (int m = 0; m < NPR; ++m) {                         // scale: L_ik = A_ik / sqrt(A_kk) (i > k), y_k = A_85,k / sqrt(A_kk)
         const int e = tid + LM_THREADS * m;
         const int i = (int)(pr[m] >> 16), k = (int)(pr[m] & 0xFFFFu);
         if (e < (DOF + 1) * (DOF + 2) / 2 && i != k && k < DOF) s.A[e] *= s.rdiag[k];
