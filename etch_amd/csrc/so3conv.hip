@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
     constexpr int KK = CIN * KS;           // contraction length of step 2
     // For CIN = 64 the X1 tile goes through LDS in two channel halves (the second half waits in registers), which
     // halves the LDS footprint and lets two workgroups share a CU (2 waves / SIMD hide the gather latency of step 1).
-    constexpr int HALVES = CIN >= 64 ? 2 : 1;
+    constexpr int HALVES = CIN >= 32 ? 2 : 1;
     constexpr int MTH = MT1 / HALVES;      // c tiles per half
     constexpr int KH = KK / HALVES;        // contraction length per half
     constexpr int S = KH + 40;             // LDS row stride (floats): S/4 = 10 (mod 16) keeps the ds_read_b128 B-fragment reads conflict-free
@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(256) instnorm_act_add_kernel(long n4, int rows
 template <int CIN, int COUT, int MAXT>
 static int launch_inter_t(int b, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz, const int* idx,
                           const float* feats, const float* rk, const float* Wp, const float* bias, float* out, hipStream_t st) {
-    const size_t lds = (size_t)(16 * (CIN * KS / (CIN >= 64 ? 2 : 1) + 40) + 4 * 16 * (COUT + 4)) * sizeof(float);
+    const size_t lds = (size_t)(16 * (CIN * KS / (CIN >= 32 ? 2 : 1) + 40) + 4 * 16 * (COUT + 4)) * sizeof(float);
     auto kern = inter_so3conv_kernel<CIN, COUT, MAXT>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
