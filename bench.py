@@ -152,6 +152,8 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: the product path has no CPU fallback")
+    if os.environ.get("ETCH_ALL_RANKS_DEVICE0"):      # smoke of the multi-rank control flow on a 1-GPU box (with ETCH_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     args, model = build(device)

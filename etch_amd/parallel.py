@@ -17,8 +17,17 @@ def init(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
+        backend = backend or os.environ.get("ETCH_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def _coll(t):
+    """Tensor as the active backend can take it: gloo collectives run on host copies (used by CPU tests and by the
+    single-GPU smoke of the multi-rank control flow); RCCL takes the device tensor as is."""
+    if dist.get_backend() == "gloo" and t.is_cuda:
+        return t.cpu()
+    return t
 
 
 def shard_range(total, rank, world):
@@ -34,6 +43,8 @@ def gather_rows(rows):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return rows
     world = dist.get_world_size()
+    dev = rows.device
+    rows = _coll(rows)
     n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n)
@@ -43,7 +54,7 @@ def gather_rows(rows):
     pad[: rows.shape[0]] = rows
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad)
-    return torch.cat([o[:c] for o, c in zip(out, counts)], 0)
+    return torch.cat([o[:c] for o, c in zip(out, counts)], 0).to(dev)
 
 
 def barrier():
@@ -54,6 +65,6 @@ def barrier():
 def max_over_ranks(value, device):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = _coll(torch.tensor([value], dtype=torch.float64, device=device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
