@@ -62,13 +62,14 @@ __global__ void __launch_bounds__(WAVES * 64) ball_query_kernel(int n, int m, fl
 // which reproduces the reference's per-thread strict '>' scan + LDS tree reduce tie-breaking
 // exactly (proved against the literal emulation in tests/test_oracle_ops.py).
 // Addressing: coordinate c of local point k is src[c * cs + k * ps].
-template <int THREADS, int PPT, bool REGS>
-__global__ void __launch_bounds__(THREADS) fps_kernel(const float* __restrict__ xyz, long cs, long ps,
+template <int THREADS, int PPT, bool REGS>   // lds_xyz = capacity (points) of the dynamic-LDS coordinate copy, 0 = none
+__global__ void __launch_bounds__(THREADS) fps_kernel(int lds_xyz, const float* __restrict__ xyz, long cs, long ps,
                                                       long batch_stride, int n_fixed, int m_fixed,
                                                       const int* __restrict__ offset, const int* __restrict__ new_offset,
                                                       int bs, int bs_bits, int skip_origin, int* __restrict__ idx) {
-    __shared__ unsigned long long red[THREADS / 64];
-    __shared__ int winner;
+    __shared__ unsigned long long red[2 * (THREADS / 64)];
+    extern __shared__ __attribute__((aligned(16))) float fps_xyz[];     // [3][lds_xyz]: the winner's coordinates are read from
+    const int CAP = lds_xyz;                                             // LDS each round instead of global memory
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int seg = blockIdx.x;
     int start_n, n, start_m, m;
@@ -95,6 +96,7 @@ __global__ void __launch_bounds__(THREADS) fps_kernel(const float* __restrict__ 
         if (k < n) {
             const float x = src[k * ps], y = src[cs + k * ps], z = src[2 * cs + k * ps];
             if (REGS) { px[i] = x; py[i] = y; pz[i] = z; }
+            if (lds_xyz) { fps_xyz[k] = x; fps_xyz[CAP + k] = y; fps_xyz[2 * CAP + k] = z; }
             bool ok = true;
             if (skip_origin) {
 #pragma clang fp contract(off)
@@ -105,9 +107,12 @@ __global__ void __launch_bounds__(THREADS) fps_kernel(const float* __restrict__ 
         }
     }
     if (tid == 0 && m > 0) idx[start_m] = start_n;
+    if (lds_xyz) __syncthreads();
     int old = 0;  // local index of the last selected point
     for (int j = 1; j < m; ++j) {
-        const float x1 = src[old * ps], y1 = src[cs + old * ps], z1 = src[2 * cs + old * ps];
+        float x1, y1, z1;
+        if (lds_xyz) { x1 = fps_xyz[old]; y1 = fps_xyz[CAP + old]; z1 = fps_xyz[2 * CAP + old]; }
+        else { x1 = src[old * ps]; y1 = src[cs + old * ps]; z1 = src[2 * cs + old * ps]; }
         unsigned long long best = 0ull;
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
@@ -127,25 +132,21 @@ __global__ void __launch_bounds__(THREADS) fps_kernel(const float* __restrict__ 
             }
         }
         best = etch_wave_max_u64_dpp(best);
-        if (lane == 0) red[wave] = best;
+        // one barrier per round: partial maxima are double-buffered and every wave reduces them redundantly
+        unsigned long long* rb = red + (j & 1) * (THREADS / 64);
+        if (lane == 0) rb[wave] = best;
         __syncthreads();
-        if (wave == 0) {
-            unsigned long long v = lane < THREADS / 64 ? red[lane] : 0ull;
-            v = etch_wave_max_u64_dpp(v);
-            if (lane == 0) {
-                int w = 0;  // no candidate at all -> local index 0 (reference: besti default)
-                if (v != 0ull) {
-                    const unsigned t = 0xFFFFFFFFu - (unsigned)(v & 0xFFFFFFFFull);
-                    const unsigned rev = t >> 16, hi = t & 0xFFFFu;
-                    const unsigned kl = bs_bits ? (__brev(rev) >> (32 - bs_bits)) : 0u;
-                    w = (int)(hi * (unsigned)bs + kl);
-                }
-                winner = w;
-                idx[start_m + j] = start_n + w;
-            }
+        unsigned long long v = lane < THREADS / 64 ? rb[lane] : 0ull;
+        v = etch_wave_max_u64_dpp(v);
+        int w = 0;  // no candidate at all -> local index 0 (reference: besti default)
+        if (v != 0ull) {
+            const unsigned t = 0xFFFFFFFFu - (unsigned)(v & 0xFFFFFFFFull);
+            const unsigned rev = t >> 16, hi = t & 0xFFFFu;
+            const unsigned kl = bs_bits ? (__brev(rev) >> (32 - bs_bits)) : 0u;
+            w = (int)(hi * (unsigned)bs + kl);
         }
-        __syncthreads();
-        old = winner;
+        if (tid == 0) idx[start_m + j] = start_n + w;
+        old = w;
     }
 }
 
@@ -331,8 +332,9 @@ static int launch_fps(int nseg, int n_max, const float* xyz, long cs, long ps, l
     const int bits = ilog2_floor_host(bs);
 #define FPS_CASE(T, P, R)                                                                                              \
     if (n_max <= T * P) {                                                                                              \
-        hipLaunchKernelGGL((fps_kernel<T, P, R>), dim3(nseg), dim3(T), 0, st, xyz, cs, ps, bstride, n_fixed, m_fixed,  \
-                           offset, new_offset, bs, bits, skip_origin, idx);                                            \
+        const int use_lds = (size_t)3 * n_max * sizeof(float) <= 62 * 1024 ? n_max : 0;                                \
+        hipLaunchKernelGGL((fps_kernel<T, P, R>), dim3(nseg), dim3(T), (size_t)3 * use_lds * sizeof(float), st,        \
+                           use_lds, xyz, cs, ps, bstride, n_fixed, m_fixed, offset, new_offset, bs, bits, skip_origin, idx);   \
         ETCH_RETURN_IF_LAUNCH_FAILED();                                                                                \
         return ETCH_OK;                                                                                                \
     }
