@@ -121,3 +121,60 @@ def test_stream_pipeline_matches_synchronous_path(tmp_path):
         for a, b in zip(i0, i1):
             assert np.array_equal(a, b)
         assert np.array_equal(m0[0].vertices, m1[0].vertices)
+
+
+def test_encoder_equivariance_property(tmp_path):
+    """Oracle-free pin: rotating the scan by an icosahedral anchor R_g permutes the encoder features over
+    anchors, feats'[..., a] = feats[..., a'] with R_a' = R_g^T R_a, and rotates `direction` by R_g wherever the so3_mean
+    projection is well conditioned.  Also validates the intra-neighbour index table.  The discrete sampling chain (FPS:
+    hundreds of dependent argmax steps) is only rotation-invariant up to fp32 rounding of the rotated coordinates
+    (at N = 5 000 a tie flips), so the property is checked at N = 1 024 on the first seed whose rotated scan
+    makes identical sampling decisions."""
+    from etch_amd import constants as K
+    args, model = make(tmp_path)
+    A = K.get_anchors().astype(np.float64)
+    g = 17
+    Rg = A[g]
+    perm = np.array([int(np.argmin(np.abs(A - (Rg.T @ A[a])[None]).reshape(60, -1).sum(1))) for a in range(60)])
+    assert sorted(perm.tolist()) == list(range(60))
+    checked = False
+    for seed in range(1000, 1006):
+        x = scan(seed, 1024)
+        xr = (x.astype(np.float64) @ Rg.T).astype(np.float32)
+        with torch.no_grad():
+            e0, _ = model.encoder(torch.from_numpy(x[None]).cuda())
+            e1, _ = model.encoder(torch.from_numpy(xr[None]).cuda())
+        same_xyz = np.abs(e1.xyz.cpu().numpy()[0].T - e0.xyz.cpu().numpy()[0].T @ Rg.T.astype(np.float32)).max()
+        if same_xyz > 1e-5:
+            continue                                                   # a sampling tie flipped under rounding: not comparable
+        with torch.no_grad():
+            r0, _ = model(torch.from_numpy(x[None]).cuda(), ["direction"], "standard_vector")
+            r1, _ = model(torch.from_numpy(xr[None]).cuda(), ["direction"], "standard_vector")
+        f0, f1 = e0.feats.cpu().numpy(), e1.feats.cpu().numpy()      # [1, 64, 256, 60]
+        scale = np.abs(f0).max()
+        assert np.abs(f1 - f0[..., perm]).max() / scale < 2e-4
+        assert np.abs(f1 - f0).max() / scale > 0.05                   # ... and the permutation is not the identity
+        d0, d1 = r0["direction"].cpu().numpy()[0], r1["direction"].cpu().numpy()[0]
+        err = np.abs(d1 - d0 @ Rg.T.astype(np.float32)).max(1)
+        assert np.median(err) < 1e-3 and (err < 1e-2).mean() > 0.5    # ill-conditioned projections excluded (SURVEY H3)
+        checked = True
+        break
+    assert checked, "no seed with rotation-stable sampling decisions"
+
+
+def test_degenerate_marker_sets_stay_finite(tmp_path):
+    """Scans whose labels hit very few / no markers: masked rows vanish from the normal equations, nothing turns NaN."""
+    from etch_amd.models.fit_SMPL import fit_smpl
+    args, _ = make(tmp_path)
+    B, K_ = 3, 500
+    pts = torch.from_numpy(np.stack([scan(300 + b, K_) for b in range(B)])).cuda()
+    labels = torch.zeros(B, K_, dtype=torch.int64).cuda()              # scan 0: only marker 0 present
+    labels[1] = torch.arange(K_).cuda() % 4                            # scan 1: four markers
+    labels[2] = 200                                                    # scan 2: no valid label at all
+    conf = torch.rand(B, K_, 1).cuda() + 0.1
+    meshes, markers, valid, info = fit_smpl(args, pts, labels, conf, "neutral")
+    assert valid.sum(1).tolist() == [1, 4, 0]
+    for a in info:
+        assert np.isfinite(a).all()
+    assert np.abs(info[0][2]).max() == 0 and np.abs(info[3][2]).max() == 0      # nothing to fit -> parameters stay at zero
+    assert all(np.isfinite(m.vertices).all() for m in meshes)
