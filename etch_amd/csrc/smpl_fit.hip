@@ -307,7 +307,11 @@ __device__ void lm_linearize(LmShared& s, const SmplConsts& C, int M, int nb, co
                 const int c = col - (NPOSE + NB + 3);
                 d[0] = c == 0 ? 1.f : 0.f; d[1] = c == 1 ? 1.f : 0.f; d[2] = c == 2 ? 1.f : 0.f;
             }
-            Jr[col] = -mk * d[0]; Jr[LDJ + col] = -mk * d[1]; Jr[2 * LDJ + col] = -mk * d[2];   // cols 85..87: zero padding
+            if (col == DOF) {      // column 85 carries the residual, so J^T r falls out of the J^T J tiles; 86, 87: zero padding
+                Jr[col] = s.resid[v * 3]; Jr[LDJ + col] = s.resid[v * 3 + 1]; Jr[2 * LDJ + col] = s.resid[v * 3 + 2];
+            } else {
+                Jr[col] = -mk * d[0]; Jr[LDJ + col] = -mk * d[1]; Jr[2 * LDJ + col] = -mk * d[2];
+            }
         }
         __builtin_amdgcn_wave_barrier();
         if (tid == 0) { const long long t1 = wall_clock64(); s.phase[7] += t1 - tm0; }
@@ -329,32 +333,42 @@ __device__ void lm_solve(LmShared& s, int M, double lambda) {
     const int rows = M * 3;
     long long t0 = 0;
     if (tid == 0) t0 = wall_clock64();
-    // 4x4 register blocks of the lower triangle: 22 block rows -> 253 blocks
-    if (tid < 253) {
-        int bi = 0;
-        while ((bi + 1) * (bi + 2) / 2 <= tid) ++bi;
-        const int bj = tid - bi * (bi + 1) / 2;
-        double acc[4][4] = {{0}};
-        for (int r = 0; r < rows; ++r) {
-            const float4 a = *reinterpret_cast<const float4*>(&s.Jm[r * LDJ + bi * 4]);
-            const float4 b = *reinterpret_cast<const float4*>(&s.Jm[r * LDJ + bj * 4]);
-            const double av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+    // J^T J on the fp32 matrix cores (the reference forms it with an fp32 matmul too): 6 x 6 tiles of 16 columns, lower
+    // triangle only = 21 tiles spread over the waves; K = marker rows, 4 per v_mfma_f32_16x16x4_f32.
+    {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const int fr = lane & 15, fg = lane >> 4;
+        const int wave = tid >> 6;
+        for (int tile = wave; tile < 21; tile += LM_WAVES) {
+            int mi = 0;
+            while ((mi + 1) * (mi + 2) / 2 <= tile) ++mi;
+            const int nj = tile - mi * (mi + 1) / 2;           // nj <= mi
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* pa = s.Jm + fg * LDJ + 16 * mi + fr;
+            const float* pb = s.Jm + fg * LDJ + 16 * nj + fr;
+            const int steps = (rows + 3) >> 2;
+            for (int t0 = 0; t0 < steps; t0 += 5) {              // 5 K-steps per trip: their 10 LDS reads are issued together
+                float av[5], bv[5];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int u = 0; u < 5; ++u) {
+                    const int t = t0 + u;
+                    const bool ok = 4 * t + fg < rows;
+                    av[u] = ok ? pa[t * 4 * LDJ] : 0.f;
+                    bv[u] = ok ? pb[t * 4 * LDJ] : 0.f;
+                }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
-        }
-        for (int i = 0; i < 4; ++i)
-            for (int j = 0; j < 4; ++j) {
-                const int gi = bi * 4 + i, gj = bj * 4 + j;
-                if (gi < DOF && gj <= gi) Apk(s.A, gi, gj) = acc[i][j] + (gi == gj ? lambda : 0.0);
+                for (int u = 0; u < 5; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
             }
-    } else if (tid >= 256 && tid < 256 + DOF) {
-        const int c = tid - 256;
-        double acc = 0.0;
-        for (int r = 0; r < rows; ++r) acc += (double)s.Jm[r * LDJ + c] * (double)s.resid[r];
-        Apk(s.A, DOF, c) = -acc;                            // rhs g = -J^T r stored as row 85 of the packed matrix
-    } else if (tid == 256 + DOF) Apk(s.A, DOF, DOF) = 1.0;
+            // D[row = 4fg + q][col = fr] = (J^T J)[16mi + 4fg + q][16nj + fr]
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gi = 16 * mi + 4 * fg + q, gj = 16 * nj + fr;
+                if (gi < DOF && gj <= gi) Apk(s.A, gi, gj) = (double)acc[q] + (gi == gj ? lambda : 0.0);
+                else if (gi == DOF && gj < DOF) Apk(s.A, DOF, gj) = -(double)acc[q];     // rhs g = -J^T r (row 85 of the packed matrix)
+                else if (gi == DOF && gj == DOF) Apk(s.A, DOF, DOF) = 1.0;
+            }
+        }
+    }
     __syncthreads();
     if (tid == 0) { const long long t1 = wall_clock64(); s.phase[2] += t1 - t0; t0 = t1; }
     // Right-looking Cholesky of the packed lower triangle with the rhs carried as an extra row (gives y = L^-1 g for
