@@ -43,18 +43,23 @@ __device__ __forceinline__ float4 ld4_guard(const float* row, int k, int K, bool
     return v;
 }
 
-template <bool VECX, bool VECW, int BN, int BM = 64>   // block tile BM rows x BN outputs (BM, BN multiples of 64)
-__global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs a) {
-    constexpr int NJ = BN / 32;                // 16-wide output tiles per wave (wave tile = BM/2 rows x BN/2 outputs)
-    constexpr int MI = BM / 32;                // 16-high row tiles per wave
-    constexpr int WL = BN / 32;                // W float4 staging loads per thread
-    constexpr int XL = BM / 32;                // X float4 staging loads per thread
+template <bool VECX, bool VECW, int BN, int BM = 64, int WAVES = 4>   // block tile BM rows x BN outputs, WAVES waves (2 along M)
+__global__ void __launch_bounds__(WAVES * 64) gemm_nt_kernel(GemmArgs a) {
+    constexpr int THREADS = WAVES * 64;
+    constexpr int NWN = WAVES / 2;             // waves along the output dimension
+    constexpr int WNS = BN / NWN;              // outputs per wave
+    constexpr int NJ = WNS / 16;               // 16-wide output tiles per wave
+    constexpr int MI = BM / 32;                // 16-high row tiles per wave (wave tile = BM/2 rows)
+    constexpr int RPP = THREADS / 8;           // rows staged per pass (8 float4 per 32-float row)
+    constexpr int WL = BN / RPP;               // W float4 staging loads per thread
+    constexpr int XL = BM / RPP;               // X float4 staging loads per thread
+    static_assert(WNS % 16 == 0 && BN % RPP == 0 && BM % RPP == 0, "tile / thread geometry");
     __shared__ __attribute__((aligned(16))) float Xs[BM * G_LD];
     __shared__ __attribute__((aligned(16))) float Ws[BN * G_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = blockIdx.x * BM, o0 = blockIdx.y * BN;
-    const int wm = wave >> 1, wn = wave & 1;
-    // staging coordinates: thread -> (row = tid/8 [+32h], float4 column = tid%8)
+    const int wm = wave / NWN, wn = wave % NWN;
+    // staging coordinates: thread -> (row = tid/8 [+RPP*h], float4 column = tid%8)
     const int srow = tid >> 3, sc4 = (tid & 7) * 4;
     const float* xrow[XL];
     bool xok[XL];
@@ -62,7 +67,7 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs a) {
     bool wok[WL];
 #pragma unroll
     for (int h = 0; h < XL; ++h) {
-        const int r = r0 + srow + 32 * h;
+        const int r = r0 + srow + RPP * h;
         xok[h] = r < a.R;
         long src = 0;
         if (xok[h]) {
@@ -76,7 +81,7 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs a) {
     }
 #pragma unroll
     for (int h = 0; h < WL; ++h) {
-        const int o = o0 + srow + 32 * h;
+        const int o = o0 + srow + RPP * h;
         wok[h] = o < a.O;
         wrow[h] = a.W + (long)(wok[h] ? o : 0) * a.ldw;
     }
@@ -95,9 +100,9 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs a) {
     for (int k0 = 0; k0 < a.K; k0 += G_BK) {
         __syncthreads();   // previous tile fully consumed
 #pragma unroll
-        for (int h = 0; h < XL; ++h) *reinterpret_cast<float4*>(&Xs[(srow + 32 * h) * G_LD + sc4]) = xv[h];
+        for (int h = 0; h < XL; ++h) *reinterpret_cast<float4*>(&Xs[(srow + RPP * h) * G_LD + sc4]) = xv[h];
 #pragma unroll
-        for (int h = 0; h < WL; ++h) *reinterpret_cast<float4*>(&Ws[(srow + 32 * h) * G_LD + sc4]) = wv[h];
+        for (int h = 0; h < WL; ++h) *reinterpret_cast<float4*>(&Ws[(srow + RPP * h) * G_LD + sc4]) = wv[h];
         __syncthreads();
         if (k0 + G_BK < a.K) {      // register prefetch of the next K tile: in flight while this tile is multiplied
 #pragma unroll
@@ -111,7 +116,7 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs a) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const float4*>(&Xs[(wm * (BM / 2) + i * 16 + fr) * G_LD + t * 16 + fg * 4]);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const float4*>(&Ws[(wn * (BN / 2) + j * 16 + fr) * G_LD + t * 16 + fg * 4]);
+            for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const float4*>(&Ws[(wn * WNS + j * 16 + fr) * G_LD + t * 16 + fg * 4]);
             // k-slice outermost: consecutive MFMAs hit different accumulators (a 16x16x4 f32 MFMA has a 40-cycle
             // dependent latency vs a 32-cycle issue interval), so no accumulator is touched twice in a row
 #define G_STEP(C)                                                                                        \
@@ -124,7 +129,7 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs a) {
     // epilogue: D[row = fg*4 + reg][col = fr]
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int o = o0 + wn * (BN / 2) + j * 16 + fr;
+        const int o = o0 + wn * WNS + j * 16 + fr;
         if (o >= a.O) continue;
         const float bs = a.bias ? a.bias[o] : 0.f;
         const float sc = a.scale ? a.scale[o] : 1.f;
@@ -146,13 +151,13 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs a) {
     }
 }
 
-template <int BN, int BM = 64>
+template <int BN, int BM = 64, int WAVES = 4>
 static void launch_tiled(const GemmArgs& a, bool vx, bool vw, hipStream_t st) {
     dim3 grid((a.R + BM - 1) / BM, (a.O + BN - 1) / BN);
-    if (vx && vw) hipLaunchKernelGGL((gemm_nt_kernel<true, true, BN, BM>), grid, dim3(256), 0, st, a);
-    else if (vx) hipLaunchKernelGGL((gemm_nt_kernel<true, false, BN, BM>), grid, dim3(256), 0, st, a);
-    else if (vw) hipLaunchKernelGGL((gemm_nt_kernel<false, true, BN, BM>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_nt_kernel<false, false, BN, BM>), grid, dim3(256), 0, st, a);
+    if (vx && vw) hipLaunchKernelGGL((gemm_nt_kernel<true, true, BN, BM, WAVES>), grid, dim3(WAVES * 64), 0, st, a);
+    else if (vx) hipLaunchKernelGGL((gemm_nt_kernel<true, false, BN, BM, WAVES>), grid, dim3(WAVES * 64), 0, st, a);
+    else if (vw) hipLaunchKernelGGL((gemm_nt_kernel<false, true, BN, BM, WAVES>), grid, dim3(WAVES * 64), 0, st, a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<false, false, BN, BM, WAVES>), grid, dim3(WAVES * 64), 0, st, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -282,6 +287,9 @@ extern "C" int etch_linear(int R, int K, int O, const float* X, long ldx, const 
     static const char* tile_env = getenv("ETCH_GEMM_TILE");    // diagnostics: "128x64" / "128x128"
     if (tile_env && !strcmp(tile_env, "128x64")) launch_tiled<64, 128>(a, vx, vw, st);
     else if (tile_env && !strcmp(tile_env, "128x128")) launch_tiled<128, 128>(a, vx, vw, st);
+    else if (tile_env && !strcmp(tile_env, "64x192w8") && O == 192) launch_tiled<192, 64, 8>(a, vx, vw, st);
+    else if (tile_env && !strcmp(tile_env, "64x128w8") && O >= 128) launch_tiled<128, 64, 8>(a, vx, vw, st);
+    else if (tile_env && !strcmp(tile_env, "128x128w8") && O >= 128) launch_tiled<128, 128, 8>(a, vx, vw, st);
     else launch_tiled<64>(a, vx, vw, st);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
