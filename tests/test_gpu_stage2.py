@@ -111,3 +111,27 @@ def test_lm_fit_vs_oracle():
     assert np.abs(x[:, 79:] - xr[:, 79:]).max() < 1e-4                            # orient, transl
     assert np.abs(x - xr).max() < 5e-3
     assert np.abs(aux["x_stage0"].cpu().numpy()[:, :69] - ref["x_stage0"].numpy()[:, :69]).max() < 5e-3
+
+
+def test_lm_fit_vs_committed_oracle_fixture(golden):
+    """Same comparison as test_lm_fit_vs_oracle against the committed run of the oracle (tests/golden/fit_oracle.npz,
+    emitted by oracle/gen_fit_fixture.py): per-iteration error trace, vertices, joints, parameters."""
+    from etch_amd import constants as K
+    from etch_amd import ops
+    from etch_amd.models.fit_SMPL import _device_body
+    from etch_amd.utils.body_model import SyntheticSMPL
+    g = golden("fit_oracle.npz")
+    bm = SyntheticSMPL(int(g["body_seed"]))
+    mv = np.array(list(K.default_markerset().values()))
+    db = _device_body(bm, mv, torch.device("cuda"))
+    markers = torch.from_numpy(g["markers"]).cuda()
+    valid = torch.from_numpy(g["valid"].astype(np.float32)).cuda()
+    x, x0, tr = ops.smpl_lm_fit(db.lm_consts, markers, valid, 30, 0.5, 0.01, 50, 0.2, 1e-3, True)
+    verts, joints = ops.smpl_lbs(db.lbs_consts, x, db.V, db.n_extra)
+    rt = g["err_trace"]
+    assert np.abs(tr.cpu().numpy() - rt).max() / rt.max() < 1e-4
+    assert (np.abs(tr.cpu().numpy() - rt) <= 2e-3 * rt + 1e-7).all()
+    assert np.abs(verts.cpu().numpy()[:, ::10] - g["verts_sub"]).max() < 1e-4
+    assert np.abs(joints.cpu().numpy() - g["joints"]).max() < 1e-4
+    assert np.abs(x.cpu().numpy()[:, 79:] - g["x"][:, 79:]).max() < 1e-4
+    assert np.abs(x.cpu().numpy() - g["x"]).max() < 5e-3

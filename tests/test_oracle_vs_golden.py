@@ -155,3 +155,23 @@ def test_whole_model_n1024(golden):
     ok = (out["sv"][..., 2] / out["sv"][..., 0]).numpy() > 0.1
     assert ok.mean() > 0.3
     assert np.abs(out["direction"].numpy() - g["direction"])[ok].max() < 1e-3
+
+
+def test_stage2_oracle_reproduces_its_fixture(golden):
+    """Regression pin of the stage-2 oracle (parity unpinned upstream, see oracle/stage2.py): a short prefix of the LM
+    schedule is re-run and must reproduce the committed per-iteration error trace of oracle/gen_fit_fixture.py."""
+    from etch_amd import constants as K
+    from etch_amd.utils.body_model import SyntheticSMPL
+    from oracle import stage2 as S2
+    g = golden("fit_oracle.npz")
+    bm = SyntheticSMPL(int(g["body_seed"]))
+    mv = np.array(list(K.default_markerset().values()))
+    trace = []
+    S2.fit_smpl(bm, mv, torch.from_numpy(g["markers"][:1]), torch.from_numpy(g["valid"][:1]), steps_stage0=3, steps_stage1=0, trace=trace)
+    got = torch.stack(trace[0], 1).numpy()
+    assert got.shape == (1, 4)
+    assert np.abs(got - g["err_trace"][:1, :4]).max() <= 1e-4 * g["err_trace"][:1, :4].max()
+    # the fixture itself: error decreases monotonically in stage 0 and the fit ends close to the generating body
+    tr = g["err_trace"]
+    assert (np.diff(tr[:, :31], axis=1) <= 1e-6).all() and (tr[:, -1] < 1e-3).all()
+    assert (g["v2v_vs_generating"] < 5e-3).all()            # markers carry 2 mm of noise: the fit lands within a few mm of the generating body
