@@ -67,7 +67,14 @@ def test_inference_demo_cli_end_to_end(tmp_path):
         for t in f:
             fh.write(f"f {t[0] + 1} {t[1] + 1} {t[2] + 1}\n")
     out = tmp_path / "out"
-    D.main(["--scan_path", str(obj), "--output_folder", str(out), "--num_point", "1024", "--synthetic_body", "--markerset_path", "missing.json"])
+    # a seeded checkpoint: without --model_path the weights are torch's unseeded default init (as in the reference) and the fit
+    # of a random network's output is chaotic, which made this test flaky
+    args0, model0 = make(tmp_path / "ckpt_model")
+    ckpt = tmp_path / "ckpt.pth"
+    torch.save({k: v.cpu() for k, v in model0.state_dict().items()}, ckpt)
+    argv = ["--scan_path", str(obj), "--output_folder", str(out), "--num_point", "1024", "--synthetic_body", "--markerset_path", "missing.json",
+            "--model_path", str(ckpt)]
+    D.main(argv)
     info = np.load(out / "scan_000_output_smpl_info.npz")
     assert {k: info[k].shape for k in info.files} == {"body_pose": (21, 3), "hand_pose": (2, 3), "betas": (10,), "global_orient": (3,),
                                                        "transl": (3,), "joints": (45, 3)}
@@ -77,6 +84,17 @@ def test_inference_demo_cli_end_to_end(tmp_path):
     centre = (v.min(0) + v.max(0)) / 2
     assert np.abs(mesh.vertices.mean(0) - centre).max() < 1.0
     assert os.path.exists(out / "EPN_model_setting_json")
+    # the CLI result is the library call's result: same sampled points through predict_smpl with the same checkpoint
+    centred, c0 = D.preprocess_scan(str(obj))
+    np.testing.assert_allclose(c0, centre, atol=1e-6)
+    m1, info1 = D.predict_smpl(args0, model0, D.sample_points_from_mesh(centred, 1024, 0))
+    np.testing.assert_array_equal(np.asarray(info1[1][0]), info["betas"])
+    np.testing.assert_allclose(m1.vertices + c0, mesh.vertices, atol=2e-6)   # OBJ text round trip
+    # and it is reproducible run to run
+    D.main(argv[:3] + [str(tmp_path / "out2")] + argv[4:])
+    info2 = np.load(tmp_path / "out2" / "scan_000_output_smpl_info.npz")
+    for k in info.files:
+        np.testing.assert_array_equal(info[k], info2[k])
 
 
 def test_eval_harness_gender_groups_and_metrics(tmp_path):
