@@ -108,7 +108,7 @@ def test_folded_direction_head_equals_unfolded(tmp_path):
     from etch_amd.utils.weights import load_seeded
     opt = types.SimpleNamespace(output_folder=str(tmp_path), EPN_input_radius=0.4, EPN_layer_num=2, device=torch.device("cuda"), markerset=K.default_markerset())
     m = load_seeded(GT_network_equiv(option=opt), 3).cuda().eval()
-    tok = torch.randn(500, 60, 64, device="cuda")
+    tok = torch.randn(500, 60, 64, generator=torch.Generator().manual_seed(0)).cuda()
     m.fold_linear_chains = False
     a = m.anchor_weights(tok).cpu().numpy()
     m.fold_linear_chains = True
