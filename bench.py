@@ -53,6 +53,9 @@ def algorithmic_flops(name, a):
     if name == "etch_linear":
         R, K, O = v[0], v[1], v[2]
         return 2.0 * R * K * O, f"gemm_nt_kernel"
+    if name == "etch_linear_relu_dot":
+        R, K, G, J = v[0], v[1], v[2], v[3]
+        return 2.0 * R * G * J * (K + 1), "linear_relu_dot_kernel"
     if name == "etch_inter_so3conv":
         b, cin, cout, p1, p2, nn = v[0:6]
         return 2.0 * b * p2 * 60 * 24 * (cin * nn + cout * cin), f"inter_so3conv_kernel<{cin},{cout},{(nn + 15) // 16 if nn <= 32 else 4}>"

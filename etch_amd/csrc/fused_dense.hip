@@ -1,0 +1,142 @@
+// Dense layer -> ReLU -> grouped dot, fused on the gfx950 fp32 matrix cores:
+//     out[r, g] = b2[g] + sum_{j < 128} relu( X[r, :] . W[g*128 + j, :] + b1[g*128 + j] ) * w2[g*128 + j]
+// Two call sites of the path end in exactly this chain and previously round-tripped the (R x G*128) hidden
+// activations through HBM:
+//   * the confidence head  Conv1d(128, 128k, 1) -> ReLU -> Conv1d(128k, k, 1, groups=k)   (G = k = 86, K = 128;
+//     /root/reference/src/models/pointtransformer_seg.py:145,183-189), hidden = 160 000 x 11 008 floats per batch;
+//   * the tail of the direction head  MLP.net[0] -> ReLU -> (net[2] o so3_reg folded)    (G = 1, K = 64;
+//     /root/reference/src/models/models_pointcloud.py:115-117), hidden = 9.6 M x 128 floats per batch.
+//
+// One workgroup = 128 rows of X, resident in LDS for all G groups (X is read from HBM exactly once); 8 waves, wave w
+// owns the 16-column strip w of the current group's 128 hidden columns: 8 row tiles x 1 column tile of 16x16x4 f32
+// MFMAs, B fragments (weights) streamed straight from L2 in fragment order with a one-step register prefetch, A fragments
+// (X) read from LDS with one conflict-free ds_read_b128 per four MFMAs (interleaved-K order, see gemm.hip).  The epilogue
+// applies bias / ReLU / w2 in registers, sums the strip's 16 columns with DPP row reductions, and the 8 strips through a
+// double-buffered LDS table (one barrier per group, fixed summation order: results are run-to-run reproducible).
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define FD_ROWS 128
+#define FD_J 128
+#define FD_PAD 40      // LDS row = K + 40 floats: (K+40)/4 = 10 (mod 16) for K in {64,128} -> conflict-free b128 fragment reads
+
+template <int CTRL>
+__device__ __forceinline__ float fd_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes of a DPP row; every lane of the row ends up with the total
+__device__ __forceinline__ float fd_row_sum16(float v) {
+    v += fd_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += fd_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += fd_dpp<0x141>(v);     // row_half_mirror
+    v += fd_dpp<0x140>(v);     // row_mirror
+    return v;
+}
+
+template <int K, bool PERM>
+__global__ void __launch_bounds__(512) linear_relu_dot_kernel(long R, int G, const float* __restrict__ X, long ldx,
+                                                              const float* __restrict__ W, long ldw, const float* __restrict__ b1,
+                                                              const float* __restrict__ w2, const float* __restrict__ b2,
+                                                              float* __restrict__ out, long ldo) {
+    constexpr int S = K + FD_PAD, KT = K / 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Xs = lds;                         // [128][S]
+    float* red = lds + FD_ROWS * S;          // [2][8][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const long r0 = (long)blockIdx.x * FD_ROWS;
+
+    // stage the 128-row X tile (rows past R are zero)
+    constexpr int C4 = K / 4;
+    for (int e = tid; e < FD_ROWS * C4; e += 512) {
+        const int row = e / C4, c = (e - row * C4) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + row < R) v = *reinterpret_cast<const float4*>(X + (r0 + row) * ldx + c);
+        *reinterpret_cast<float4*>(&Xs[row * S + c]) = v;
+    }
+    // weight fragment of (group g, k-step t) for this wave's strip.  PERM: W is pre-permuted to fragment order
+    // Wp[g][t][strip][lane][4] (one contiguous 1 KiB per wave load); else the plain row-major [G*128][ldw] matrix.
+    auto wfrag = [&](int g, int t) -> float4 {
+        if (PERM) return *reinterpret_cast<const float4*>(W + ((((long)g * KT + t) * 8 + wave) * 64 + lane) * 4);
+        return *reinterpret_cast<const float4*>(W + ((long)g * FD_J + wave * 16 + fr) * ldw + t * 16 + fg * 4);
+    };
+    float4 bn = wfrag(0, 0);
+    __syncthreads();
+
+    int buf = 0;
+    for (int g = 0; g < G; ++g) {
+        f32x4 acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            const float4 b = bn;
+            // prefetch the next fragment (next k-step, or the first of the next group; the last prefetch re-reads a valid one)
+            if (t + 1 < KT) bn = wfrag(g, t + 1);
+            else bn = wfrag(g + 1 < G ? g + 1 : g, 0);
+            float4 a[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const float4*>(&Xs[(i * 16 + fr) * S + t * 16 + fg * 4]);
+#define FD_STEP(C) _Pragma("unroll") for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].C, b.C, acc[i], 0, 0, 0);
+            FD_STEP(x) FD_STEP(y) FD_STEP(z) FD_STEP(w)
+#undef FD_STEP
+        }
+        // epilogue: D[row = 16 i + 4 fg + q][col = fr]
+        const int col = g * FD_J + wave * 16 + fr;
+        const float bs = b1[col], ww = w2[col];
+        float* rp = red + (buf * 8 + wave) * FD_ROWS;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float s = fd_row_sum16(fmaxf(acc[i][q] + bs, 0.f) * ww);
+                if (fr == ((i * 4 + q) & 15)) rp[i * 16 + fg * 4 + q] = s;    // spread the 32 stores over the row's lanes
+            }
+        __syncthreads();
+        if (tid < FD_ROWS && r0 + tid < R) {
+            const float* rr = red + buf * 8 * FD_ROWS + tid;
+            float s = rr[0];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) s += rr[w * FD_ROWS];
+            out[(r0 + tid) * ldo + g] = s + b2[g];
+        }
+        buf ^= 1;
+    }
+}
+
+template <int K>
+static int launch_lrd(long R, int G, const float* X, long ldx, const float* W, long ldw, const float* Wp, const float* b1,
+                      const float* w2, const float* b2, float* out, long ldo, hipStream_t st) {
+    const size_t lds = ((size_t)FD_ROWS * (K + FD_PAD) + 2 * 8 * FD_ROWS) * sizeof(float);
+    const dim3 grid((unsigned)((R + FD_ROWS - 1) / FD_ROWS));
+    if (Wp) {
+        auto kern = linear_relu_dot_kernel<K, true>;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, R, G, X, ldx, Wp, 0L, b1, w2, b2, out, ldo);
+    } else {
+        auto kern = linear_relu_dot_kernel<K, false>;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, R, G, X, ldx, W, ldw, b1, w2, b2, out, ldo);
+    }
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+extern "C" int etch_linear_relu_dot(long R, int K, int G, int J, const float* X, long ldx, const float* W, long ldw, const float* Wp,
+                                    const float* b1, const float* w2, const float* b2, float* out, long ldo, void* stream) {
+    if (R <= 0 || G <= 0) return ETCH_OK;
+    if (!X || !(W || Wp) || !b1 || !w2 || !b2 || !out) return ETCH_EINVAL;
+    if ((ldx & 3) || ((uintptr_t)X & 15) || (!Wp && ((ldw & 3) || ((uintptr_t)W & 15))) || (Wp && ((uintptr_t)Wp & 15))) return ETCH_EINVAL;
+    if (J != FD_J) return ETCH_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 64) return launch_lrd<64>(R, G, X, ldx, W, ldw, Wp, b1, w2, b2, out, ldo, st);
+    if (K == 128) return launch_lrd<128>(R, G, X, ldx, W, ldw, Wp, b1, w2, b2, out, ldo, st);
+    return ETCH_EUNSUPPORTED;
+}

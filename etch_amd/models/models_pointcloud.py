@@ -83,8 +83,8 @@ class GT_network_equiv(nn.Module):
             Wf = (W1 @ Wc).float().contiguous().to(dev)
             bf = (W1 @ bc + b1).float().contiguous().to(dev)
             v = (W2.t() @ wr).float().contiguous().to(dev)
-            c = float(b2 @ wr + br[0])
-            return Wf, bf, v, c
+            c = (b2 @ wr + br[0]).float().view(1).to(dev)
+            return Wf, bf, v, c, ops.permute_weight_frag_grouped(Wf)
 
         if not hasattr(self, "_fold_cache"):
             from ..vgtk_so3conv import _Derived
@@ -102,11 +102,11 @@ class GT_network_equiv(nn.Module):
         for layer in layers[:-1]:
             x = layer(x, x, x, residual=True)
         last = layers[-1]
-        Wf, bf, v, c = self._folded()
+        Wf, bf, v, c, Wfp = self._folded()
         qkv = ops.linear(x.reshape(T * 60, last.embedding_dim), last._wqkv())
         att = ops.mhsa_attention(qkv, T, 0, 64, 128)
-        h = ops.linear(att, Wf, bias=bf, act="relu")
-        return ops.rowdot(h, v, c).view(T, 60)
+        # relu(att Wf^T + bf) . v + c in one kernel: the (T*60, 128) hidden layer stays on chip
+        return ops.linear_relu_dot(att, Wf, bf, v, c, 1, wp=Wfp).view(T, 60)
 
     def decode_direction(self, equiv_feat, anchors, initial_vectors, tokens_cl=None):
         """models_pointcloud.py:111-126.  equiv_feat [B, N, C, 60] (reference layout) or tokens_cl [B, N, 60, C]."""

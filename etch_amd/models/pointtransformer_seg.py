@@ -206,7 +206,6 @@ class _PointTransformerBase(nn.Module):
 
 class PointTransformer_confidence(_PointTransformerBase):
     """pointtransformer_seg.py:125-195."""
-    CONFI_CHUNK = 16384   # rows per pass of the 128 -> 128*k hidden layer (keeps the hidden tile in L2/MALL)
 
     def __init__(self, block, blocks, c=6, k=13):
         super().__init__()
@@ -215,7 +214,7 @@ class PointTransformer_confidence(_PointTransformerBase):
         self._build(block, blocks, c, planes)
         self.cls = nn.Sequential(nn.Conv1d(planes[0], planes[0], 1), nn.BatchNorm1d(planes[0]), nn.ReLU(), nn.Conv1d(planes[0], k, 1))
         self.confi = nn.Sequential(nn.Conv1d(planes[0], planes[0] * k, 1), nn.ReLU(), nn.Conv1d(planes[0] * k, 1 * k, 1, groups=k))
-        self._d = _Derived()
+        self._d, self._dw = _Derived(), _Derived()
 
     def forward(self, pxo):
         p0, x0, o0 = pxo
@@ -230,13 +229,9 @@ class PointTransformer_confidence(_PointTransformerBase):
         b0 = self.confi[0].bias.detach()
         w2 = self.confi[2].weight.detach().view(self.k, -1).contiguous()
         b2 = self.confi[2].bias.detach()
-        J = w2.shape[1]
-        R = x1.shape[0]
-        conf_k = torch.empty((R, self.k), dtype=torch.float32, device=x1.device)
-        for r0 in range(0, R, self.CONFI_CHUNK):
-            r1 = min(R, r0 + self.CONFI_CHUNK)
-            hid = ops.linear(x1[r0:r1], w0, bias=b0, act="relu")                     # (chunk, 128*k)
-            ops.grouped_dot(hid, w2, b2, self.k, J, out=conf_k[r0:r1])
+        # confi: Conv1d(128, 128k) -> ReLU -> grouped Conv1d(128k, k) fused; the (B*N, 128k) hidden layer is never materialised
+        wp = self._dw.get([self.confi[0].weight], lambda: ops.permute_weight_frag_grouped(w0.contiguous(), w2.shape[1]))
+        conf_k = ops.linear_relu_dot(x1, w0, b0, w2.view(-1), b2, self.k, wp=wp)
         conf = ops.softmax_dot(logits, conf_k)
         return logits.view(B, N, self.k), conf.view(B, N, 1)
 

@@ -319,6 +319,29 @@ def grouped_dot(h, w, bias, G, J, out=None):
     return out
 
 
+def permute_weight_frag_grouped(w, J=128):
+    """[G*J, K] -> fragment order [G][K/16][J/16][64][4] for etch_linear_relu_dot."""
+    GJ, K = w.shape
+    return torch.cat([permute_weight_frag(w[g * J:(g + 1) * J].contiguous()) for g in range(GJ // J)])
+
+
+def linear_relu_dot(x, w, b1, w2, b2, G, wp=None, out=None):
+    """out[r,g] = b2[g] + sum_j relu(x[r] . w[g*J+j] + b1[g*J+j]) * w2[g*J+j]   (J = 128), hidden kept on chip."""
+    for t, n in ((w, "w"), (b1, "b1"), (w2, "w2"), (b2, "b2")):
+        _need(t, torch.float32, n)
+    if x.dtype != torch.float32 or not x.is_cuda:
+        raise _lib.EtchHipError("x must be a float32 CUDA(HIP) tensor")
+    R, K = x.shape
+    J = w.shape[0] // G
+    assert x.stride(1) == 1 and w.shape == (G * J, K) and b1.numel() == G * J and w2.numel() == G * J and b2.numel() == G
+    if out is None:
+        out = torch.empty((R, G), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().etch_linear_relu_dot(_c_long(R), int(K), int(G), int(J), _ptr(x), _c_long(x.stride(0) if R > 1 else K), _ptr(w),
+                                               _c_long(w.stride(0)), _optptr(wp), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(out),
+                                               _c_long(out.stride(0) if R > 1 else G), _stream()), "etch_linear_relu_dot")
+    return out
+
+
 def softmax_dot(logits, v):
     R, G = logits.shape
     out = torch.empty((R,), dtype=torch.float32, device=logits.device)

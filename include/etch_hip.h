@@ -160,6 +160,16 @@ int etch_concat_bcast(int n, int c, int nseg, const float* x, const float* g, co
 int etch_grouped_dot(long R, int G, int J, const float* h, long ldh, const float* w, const float* bias, float* out, long ldo,
                      void* stream);
 
+/* Fused Conv1d(K, G*J, 1) -> ReLU -> Conv1d(G*J, G, 1, groups=G) of the confidence head (pointtransformer_seg.py:145,
+ * applied at :183-189; G = k markers, J = K = 128) and of the direction-head tail MLP.net[0] -> ReLU -> (net[2] o so3_reg)
+ * (models_pointcloud.py:115-117, direction_backbones.py:38-75; G = 1, K = 64, J = 128):
+ *   out[r,g] = b2[g] + sum_{j<J} relu(X[r,:] . W[g*J+j,:] + b1[g*J+j]) * w2[g*J+j]
+ * The (R x G*J) hidden activations never leave the chip.  X (R,K) row stride ldx; W (G*J,K) row stride ldw; Wp = optional
+ * copy of W in MFMA fragment order [G][K/16][8][64][4] (Wp[g][t][s][l][e] = W[g*J+16s+l%16][16t+4(l/16)+e]; NULL -> W is
+ * read directly); out (R,G) row stride ldo.  J must be 128, K 64 or 128; ldx % 4 == 0, 16-byte aligned pointers. */
+int etch_linear_relu_dot(long R, int K, int G, int J, const float* X, long ldx, const float* W, long ldw, const float* Wp,
+                         const float* b1, const float* w2, const float* b2, float* out, long ldo, void* stream);
+
 /* confidence = sum_g softmax(logits)_g * v_g (pointtransformer_seg.py:183-189): (R,G),(R,G) -> (R). */
 int etch_softmax_dot(long R, int G, const float* logits, const float* v, float* out, void* stream);
 

@@ -114,3 +114,29 @@ def test_folded_direction_head_equals_unfolded(tmp_path):
     m.fold_linear_chains = True
     b = m.anchor_weights(tok).cpu().numpy()
     assert rel_err(b, a) < 2e-6
+
+
+@pytest.mark.parametrize("R,K,G,perm", [(1000, 128, 5, False), (1000, 128, 5, True), (333, 64, 1, True), (130, 64, 2, False), (1, 128, 86, True)])
+def test_linear_relu_dot_matches_unfused_chain(R, K, G, perm):
+    """etch_linear_relu_dot == Conv1d(K, G*128) -> ReLU -> grouped Conv1d (pointtransformer_seg.py:145): fp64 reference and the
+    unfused etch_linear + etch_grouped_dot chain; ragged row counts (partial 128-row tiles)."""
+    from etch_amd import ops
+    g = torch.Generator().manual_seed(R + K + G)
+    x = torch.randn(R, K, generator=g)
+    w = torch.randn(G * 128, K, generator=g) / K ** 0.5
+    b1 = torch.randn(G * 128, generator=g) * 0.1
+    w2 = torch.randn(G, 128, generator=g) / 128 ** 0.5
+    b2 = torch.randn(G, generator=g)
+    ref = (torch.relu(x.double() @ w.double().T + b1.double()).view(R, G, 128) * w2.double()).sum(-1) + b2.double()
+    xc, wc, b1c, w2c, b2c = (t.cuda() for t in (x, w, b1, w2, b2))
+    wp = ops.permute_weight_frag_grouped(wc) if perm else None
+    out = ops.linear_relu_dot(xc, wc, b1c, w2c.view(-1), b2c, G, wp=wp)
+    assert out.shape == (R, G)
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < 2e-6
+    chain = ops.grouped_dot(ops.linear(xc, wc, bias=b1c, act="relu"), w2c, b2c, G, 128)
+    assert rel_err(out.cpu().numpy(), chain.cpu().numpy()) < 2e-6
+    # a strided view of a wider matrix as input (row stride != K)
+    wide = torch.zeros(R, K + 8, device="cuda")
+    wide[:, :K] = xc
+    out2 = ops.linear_relu_dot(wide[:, :K], wc, b1c, w2c.view(-1), b2c, G, wp=wp)
+    assert torch.equal(out, out2)
