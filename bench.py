@@ -62,6 +62,9 @@ def algorithmic_flops(name, a):
     if name == "etch_intra_so3conv":
         b, c, cout, p = v[0:4]
         return 2.0 * b * p * 60 * 12 * c * cout, f"intra_so3conv_kernel<{c},{cout}>"
+    if name == "etch_mhsa_layer":
+        T, mode = v[0], v[7]
+        return T * (2.0 * 60 * 64 * 192 + 8 * (2.0 * 60 * 60 * 8 * 2) + (2.0 * 60 * 64 * 64 if mode != 2 else 0.0)), "mhsa_layer_kernel"
     if name == "etch_mhsa_attention":
         T = v[0]
         return T * 8 * (2.0 * 60 * 60 * 8 * 2), "mhsa_attention_kernel"

@@ -50,7 +50,8 @@ class DotProdAttention(nn.Module):
 
 class MultiHeadAttention(nn.Module):
     """direction_backbones.py:132-194.  forward(keys, queries, values) with keys is queries is values (self-attention
-    over the 60 anchor tokens, 8 heads of size 8): one fused QKV GEMM + attention kernel + head_combine GEMM."""
+    over the 60 anchor tokens, 8 heads of size 8): one fused kernel per layer (etch_mhsa_layer); the unfused QKV GEMM +
+    attention kernel + head_combine GEMM chain remains for value_dim != embedding_dim."""
 
     def __init__(self, embedding_dim, value_dim, num_heads):
         super().__init__()
@@ -72,6 +73,11 @@ class MultiHeadAttention(nn.Module):
         assert keys is queries and keys is values and keys.shape[1] == 60
         T = keys.shape[0]
         x = keys.reshape(T * 60, self.embedding_dim)
+        if self.value_dim == self.embedding_dim and x.is_contiguous():
+            # the whole layer in one kernel: q|k|v and the attention output never leave the chip
+            y = ops.mhsa_layer(x, self.query_transform.weight.detach(), self.key_transform.weight.detach(), self.value_transform.weight.detach(),
+                               self.head_combine.weight.detach(), self.head_combine.bias.detach(), mode=0 if residual else 1)
+            return y.view(T, 60, self.value_dim)
         qkv = ops.linear(x, self._wqkv())                               # [T*60, 192] = q | k | v
         att = ops.mhsa_attention(qkv, T, 0, 64, 128)
         y = ops.linear(att, self.head_combine.weight.detach(), bias=self.head_combine.bias.detach(),

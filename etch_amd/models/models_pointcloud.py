@@ -103,8 +103,8 @@ class GT_network_equiv(nn.Module):
             x = layer(x, x, x, residual=True)
         last = layers[-1]
         Wf, bf, v, c, Wfp = self._folded()
-        qkv = ops.linear(x.reshape(T * 60, last.embedding_dim), last._wqkv())
-        att = ops.mhsa_attention(qkv, T, 0, 64, 128)
+        att = ops.mhsa_layer(x.reshape(T * 60, last.embedding_dim), last.query_transform.weight.detach(), last.key_transform.weight.detach(),
+                             last.value_transform.weight.detach(), mode=2)            # concatenated heads; head_combine is folded into Wf
         # relu(att Wf^T + bf) . v + c in one kernel: the (T*60, 128) hidden layer stays on chip
         return ops.linear_relu_dot(att, Wf, bf, v, c, 1, wp=Wfp).view(T, 60)
 

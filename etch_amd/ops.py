@@ -220,6 +220,18 @@ def mhsa_attention(qkv, T, qoff, koff, voff):
     return out
 
 
+def mhsa_layer(x, wq, wk, wv, wc=None, bc=None, mode=0):
+    """x [T*60, 64] tokens -> [T*60, 64]: one fused MultiHeadAttention layer (mode 0 residual, 1 plain, 2 heads only)."""
+    for t, n in ((x, "x"), (wq, "wq"), (wk, "wk"), (wv, "wv")) + (((wc, "wc"), (bc, "bc")) if mode != 2 else ()):
+        _need(t, torch.float32, n)
+    assert x.shape[-1] == 64 and x.numel() % (60 * 64) == 0 and wq.shape == (64, 64)
+    T = x.numel() // (60 * 64)
+    out = torch.empty((T * 60, 64), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().etch_mhsa_layer(_c_long(T), _ptr(x), _ptr(wq), _ptr(wk), _ptr(wv), _optptr(wc), _optptr(bc), int(mode), _ptr(out),
+                                          _stream()), "etch_mhsa_layer")
+    return out
+
+
 def rowdot(x, w, bias):
     _need(x, torch.float32, "x"), _need(w, torch.float32, "w")
     R, K = x.shape

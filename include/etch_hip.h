@@ -110,6 +110,14 @@ int etch_prop_interp(int B, int N, int S, int A, int C, const float* feats, cons
  * 8 heads x 8 dims: rows [T*60][ld] hold q/k/v at column offsets qoff/koff/voff -> out rows [T*60][ldo] (64 cols). */
 int etch_mhsa_attention(long T, const float* qkv, long ld, int qoff, int koff, int voff, float* out, long ldo, void* stream);
 
+/* One whole MultiHeadAttention layer (direction_backbones.py:132-194; 64 dims, 8 heads x 8, 60 tokens per point) in a single
+ * kernel: q/k/v transforms (no bias, weights (64,64) row-major as in key/query/value_transform.weight) -> per-head softmax
+ * attention -> head_combine (Wc (64,64), bc (64)).  X, out: (T*60, 64) contiguous.
+ * mode 0: out = X + att Wc^T + bc  (the residual form StackedMHSA.forward :216-221 applies to all but the last layer)
+ * mode 1: out = att Wc^T + bc       mode 2: out = att (concatenated heads; Wc/bc unused -- head_combine folded downstream) */
+int etch_mhsa_layer(long T, const float* X, const float* Wq, const float* Wk, const float* Wv, const float* Wc, const float* bc,
+                    int mode, float* out, void* stream);
+
 /* y[r] = x[r,:K] . w + bias: so3_reg Conv1d(128,1,1) (src/models/models_pointcloud.py:54,117). */
 int etch_rowdot(long R, int K, const float* x, long ldx, const float* w, float bias, float* y, void* stream);
 

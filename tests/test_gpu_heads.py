@@ -140,3 +140,41 @@ def test_linear_relu_dot_matches_unfused_chain(R, K, G, perm):
     wide[:, :K] = xc
     out2 = ops.linear_relu_dot(wide[:, :K], wc, b1c, w2c.view(-1), b2c, G, wp=wp)
     assert torch.equal(out, out2)
+
+
+def _mhsa_reference(x, wq, wk, wv, wc, bc, mode):
+    """direction_backbones.py:160-194 in fp64: per-head scaled dot-product attention over the 60 tokens of each point."""
+    T = x.shape[0]
+    xd = x.double()
+    q, k, v = (xd @ w.double().T for w in (wq, wk, wv))
+    split = lambda t: t.view(T, 60, 8, 8).permute(0, 2, 1, 3)
+    att = torch.softmax(split(q) @ split(k).transpose(-1, -2) / 8 ** 0.5, -1) @ split(v)
+    att = att.permute(0, 2, 1, 3).reshape(T, 60, 64)
+    if mode == 2:
+        return att
+    y = att @ wc.double().T + bc.double()
+    return y + xd if mode == 0 else y
+
+
+@pytest.mark.parametrize("T,mode", [(1, 0), (37, 0), (37, 1), (37, 2), (1500, 0)])
+def test_fused_mhsa_layer_vs_fp64_and_unfused(T, mode):
+    """etch_mhsa_layer against an fp64 restatement and against the unfused etch_linear + etch_mhsa_attention + etch_linear chain."""
+    from etch_amd import ops
+    g = torch.Generator().manual_seed(T * 3 + mode)
+    x = torch.randn(T, 60, 64, generator=g)
+    wq, wk, wv, wc = (torch.randn(64, 64, generator=g) * 0.25 for _ in range(4))
+    bc = torch.randn(64, generator=g) * 0.1
+    ref = _mhsa_reference(x, wq, wk, wv, wc, bc, mode).reshape(T * 60, 64).numpy()
+    xc, wqc, wkc, wvc, wcc, bcc = (t.cuda().contiguous() for t in (x, wq, wk, wv, wc, bc))
+    out = ops.mhsa_layer(xc.view(T * 60, 64), wqc, wkc, wvc, wcc, bcc, mode=mode)
+    assert rel_err(out.cpu().numpy(), ref) < 3e-6
+    qkv = ops.linear(xc.view(T * 60, 64), torch.cat([wqc, wkc, wvc], 0).contiguous())
+    att = ops.mhsa_attention(qkv, T, 0, 64, 128)
+    if mode == 2:
+        chain = att
+    else:
+        chain = ops.linear(att, wcc, bias=bcc, res=xc.view(T * 60, 64) if mode == 0 else None, res_mode=2 if mode == 0 else 0)
+    assert rel_err(out.cpu().numpy(), chain.cpu().numpy()) < 3e-6
+    # large-magnitude scores: the running max keeps the softmax finite
+    big = ops.mhsa_layer((xc * 30).view(T * 60, 64), wqc, wkc, wvc, wcc, bcc, mode=mode)
+    assert bool(torch.isfinite(big).all())
