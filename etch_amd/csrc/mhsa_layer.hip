@@ -52,7 +52,7 @@ __device__ __forceinline__ void ml_softmax(f32x4 (&s)[4], int fg) {
 
 // MODE 0: out = X + att Wc^T + bc (residual layer);  1: out = att Wc^T + bc;  2: out = att (head_combine folded downstream)
 template <int MODE>
-__global__ void __launch_bounds__(256, 2) mhsa_layer_kernel(long T, const float* __restrict__ X, const float* __restrict__ Wq,
+__global__ void __launch_bounds__(256, 3) mhsa_layer_kernel(long T, const float* __restrict__ X, const float* __restrict__ Wq,
                                                             const float* __restrict__ Wk, const float* __restrict__ Wv,
                                                             const float* __restrict__ Wc, const float* __restrict__ bc,
                                                             float* __restrict__ out) {
