@@ -105,14 +105,32 @@ def fit_smpl_device(args, inner_points, part_labels, confidences, gender, steps_
     return dict(markers=markers, valid=valid_b, x=x, x_stage0=x0, err_trace=trace, verts=verts, joints=joints, faces=db.faces)
 
 
+def fit_smpl_stage_host(dev, pinned=None):
+    """Enqueue the device -> host copies of one fit on the CURRENT stream into pinned buffers (no host wait): a pipelined
+    caller records an event after this and later finalizes without touching the stream again.  `pinned` = buffers of an
+    earlier call to reuse (same shapes)."""
+    host = {}
+    for k in ("x", "verts", "joints"):
+        t = dev[k].detach()
+        buf = None if pinned is None else pinned.get(k)
+        if buf is None or buf.shape != t.shape:
+            buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        buf.copy_(t, non_blocking=True)
+        host[k] = buf
+    dev["host"] = host
+    return dev
+
+
 def fit_smpl_finalize(dev):
-    """Host-side part: copy the fit to the host in the reference's return format (fit_SMPL.py:261-269)."""
-    x = dev["x"]
-    B = x.shape[0]
-    xn = x.detach().cpu().numpy()
-    vn = dev["verts"].detach().cpu().numpy()
+    """Host-side part: the fit in the reference's return format (fit_SMPL.py:261-269).  Copies to the host here unless
+    fit_smpl_stage_host already enqueued them (the caller has then waited for its event)."""
+    B = dev["x"].shape[0]
+    if "host" in dev:
+        xn, vn, jn = (dev["host"][k].numpy().copy() for k in ("x", "verts", "joints"))
+    else:
+        xn, vn, jn = (dev[k].detach().cpu().numpy() for k in ("x", "verts", "joints"))
     meshes = [Mesh(vn[b], dev["faces"], process=False, maintain_order=True) for b in range(B)]
-    info = [xn[:, :69].reshape(B, 23, 3), xn[:, 69:79].copy(), xn[:, 79:82].copy(), xn[:, 82:85].copy(), dev["joints"].detach().cpu().numpy()]
+    info = [xn[:, :69].reshape(B, 23, 3), xn[:, 69:79].copy(), xn[:, 79:82].copy(), xn[:, 82:85].copy(), jn]
     return meshes, dev["markers"], dev["valid"], info
 
 

@@ -55,7 +55,7 @@ class GT_network_equiv(nn.Module):
         p = xyz.reshape(-1, 3)
         x = features.reshape(-1, C)
         oh = [N * (i + 1) for i in range(B)]
-        o = pointops.set_host_offsets(torch.tensor(oh, dtype=torch.int32).to(p.device), oh)
+        o = pointops.offsets_tensor(oh, p.device)
         return p, x, o
 
     def decode_confidence(self, inv_feat, xyz):
@@ -140,7 +140,7 @@ class GT_network_equiv(nn.Module):
         side.wait_stream(main)
         with torch.cuda.stream(side):
             oh = [N * (i + 1) for i in range(B)]
-            o = pointops.set_host_offsets(torch.tensor(oh, dtype=torch.int32).to(hitpts.device), oh)
+            o = pointops.offsets_tensor(oh, hitpts.device)
             made = prefetch_indices(hitpts.view(-1, 3), o)
             done = torch.cuda.Event()
             done.record(side)
@@ -154,7 +154,7 @@ class GT_network_equiv(nn.Module):
             idx_ready = self._prefetch_pt_indices(hitpts, B, N)
         r, sample_idx_lists = self.encode(hitpts)
         so3_anchors = r.anchors
-        selected_indexs = torch.arange(0, N).repeat(B, 1).unsqueeze(-1).expand(-1, -1, 3).to(hitpts.device)
+        selected_indexs = torch.arange(0, N, device=hitpts.device).repeat(B, 1).unsqueeze(-1).expand(-1, -1, 3)
         # 3-NN propagation of the [C*60] equivariant features to all N points + anchor mean (:181-184), channels-last
         point_equiv_cl, point_inv_feat = propagate_cl(hitpts, r.xyz, r.feats_cl)
         results = {}

@@ -26,6 +26,24 @@ def set_host_offsets(o, values):
     return o
 
 
+_offset_tensors = {}   # (values, device) -> device int32 tensor; offsets are a pure function of (B, N, strides)
+
+
+def offsets_tensor(values, device):
+    """Device int32 offsets carrying their host copy, built ONCE per distinct value list: uploading a small host list is a
+    synchronous pageable copy that would stall the host behind every kernel already queued (one stall per level per forward)."""
+    device = torch.device(device)
+    key = (tuple(int(v) for v in values), device.type, device.index if device.index is not None else torch.cuda.current_device())
+    t = _offset_tensors.get(key)
+    if t is None:
+        t = set_host_offsets(torch.tensor(list(key[0]), dtype=torch.int32, device=device), key[0])
+        torch.cuda.current_stream(device).synchronize()      # first use only: visible to every stream from here on
+        if len(_offset_tensors) > 256:
+            _offset_tensors.clear()
+        _offset_tensors[key] = t
+    return t
+
+
 class knn_scope:
     """Enables FPS / kNN / sub-sampling de-duplication for the duration of one forward.  Scopes nest: the model opens
     one around BOTH Point-Transformer nets, which see the same points and offsets and therefore the same indices."""
@@ -53,14 +71,9 @@ def _memo(key, keep, fn):
 
 
 def make_offsets(values, device, like=None):
-    """Device int32 offset tensor carrying its host copy; memoised per (parent offsets, stride) inside a knn_scope so the
-    two nets (and the index prefetch) share ONE tensor object per level (memo keys are tensor addresses)."""
-    def build():
-        return set_host_offsets(torch.tensor(values, dtype=torch.int32, device=device), values)
-    if like is None:
-        return build()
-    parent, stride = like
-    return _memo(("offs", parent.data_ptr(), stride, tuple(values)), (parent,), build)
+    """Device int32 offset tensor carrying its host copy: one shared tensor object per distinct offset list (both nets and the
+    index prefetch see the same object per level; built once, see offsets_tensor)."""
+    return offsets_tensor(values, device)
 
 
 def furthestsampling(xyz, offset, new_offset):

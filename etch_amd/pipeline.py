@@ -5,7 +5,7 @@ in-flight batches besides the (read-only) weights and body-model tables."""
 import torch
 
 from . import ops
-from .models.fit_SMPL import fit_smpl_device, fit_smpl_finalize
+from .models.fit_SMPL import fit_smpl_device, fit_smpl_finalize, fit_smpl_stage_host
 
 
 class Ticket:
@@ -20,6 +20,8 @@ class HotPathPipeline:
         self.s2 = torch.cuda.Stream()
         self.max_in_flight = max_in_flight
         self.in_flight = []
+        self._pinned = [None] * (max_in_flight + 1)     # ring of pinned host buffers, one set per batch in flight (+1 being read)
+        self._n = 0
 
     def submit(self, points):
         """Enqueue one batch (B,N,3) resident on the device; returns a Ticket.  Never blocks on the GPU."""
@@ -38,6 +40,11 @@ class HotPathPipeline:
             with torch.cuda.stream(self.s2):
                 self.s2.wait_event(ready)
                 fit = fit_smpl_device(self.args, inner, labels, conf, self.gender, **self.fit_kwargs)
+                # device -> host copies ride on s2 right behind this batch's fit (pinned, reused buffers): result() must
+                # not enqueue anything on s2, where it would queue behind the NEXT batch's fit
+                fit_smpl_stage_host(fit, self._pinned[self._n % len(self._pinned)])
+                self._pinned[self._n % len(self._pinned)] = fit["host"]
+                self._n += 1
                 done = torch.cuda.Event()
                 done.record(self.s2)
         t = Ticket(done, results, fit)
@@ -49,8 +56,7 @@ class HotPathPipeline:
         ticket.done.synchronize()
         if ticket in self.in_flight:
             self.in_flight.remove(ticket)
-        with torch.cuda.stream(self.s2):
-            return fit_smpl_finalize(ticket.fit)
+        return fit_smpl_finalize(ticket.fit)
 
     def run(self, batches):
         """Process an iterable of batches with at most `max_in_flight` enqueued; yields results in order."""
