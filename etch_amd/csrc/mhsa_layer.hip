@@ -52,7 +52,7 @@ __device__ __forceinline__ void ml_softmax(f32x4 (&s)[4], int fg) {
 
 // MODE 0: out = X + att Wc^T + bc (residual layer);  1: out = att Wc^T + bc;  2: out = att (head_combine folded downstream)
 template <int MODE>
-__global__ void __launch_bounds__(256, 3) mhsa_layer_kernel(long T, const float* __restrict__ X, const float* __restrict__ Wq,
+__global__ void __launch_bounds__(256, MODE == 2 ? 3 : 2) mhsa_layer_kernel(long T, const float* __restrict__ X, const float* __restrict__ Wq,
                                                             const float* __restrict__ Wk, const float* __restrict__ Wv,
                                                             const float* __restrict__ Wc, const float* __restrict__ bc,
                                                             float* __restrict__ out) {
@@ -78,25 +78,24 @@ __global__ void __launch_bounds__(256, 3) mhsa_layer_kernel(long T, const float*
     if (MODE != 2 && bc) bias = *reinterpret_cast<const float4*>(bc + 16 * w + 4 * fg);
     Xs[(ML_TOK + (tid >> 6)) * ML_S + (tid & 63)] = 0.f;      // token rows 60..63 stay zero for the whole kernel
 
-    float4 xn[4];
-    auto gload = [&](long p) {
-        const float4* src = reinterpret_cast<const float4*>(X + p * (ML_TOK * ML_C));
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const int e = tid + 256 * h;
-            if (e < ML_TOK * ML_C / 4) xn[h] = src[e];
-        }
-    };
+    // next point's tokens: 960 float4 over 256 threads, four named registers (an indexed array captured by a lambda ended up
+    // in scratch memory: +5 GB of HBM traffic per launch)
+    float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0, x2 = x0, x3 = x0;
+#define ML_GLOAD(P)                                                                          \
+    {                                                                                        \
+        const float4* src_ = reinterpret_cast<const float4*>(X + (P) * (ML_TOK * ML_C));     \
+        x0 = src_[tid]; x1 = src_[tid + 256]; x2 = src_[tid + 512];                          \
+        if (tid < ML_TOK * ML_C / 4 - 768) x3 = src_[tid + 768];                             \
+    }
     long pt = blockIdx.x;
-    if (pt < T) gload(pt);
+    if (pt < T) ML_GLOAD(pt)
     for (; pt < T; pt += gridDim.x) {
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const int e = tid + 256 * h;
-            if (e < ML_TOK * ML_C / 4) *reinterpret_cast<float4*>(&Xs[(e >> 4) * ML_S + (e & 15) * 4]) = xn[h];
-        }
+        *reinterpret_cast<float4*>(&Xs[(tid >> 4) * ML_S + (tid & 15) * 4]) = x0;
+        *reinterpret_cast<float4*>(&Xs[((tid >> 4) + 16) * ML_S + (tid & 15) * 4]) = x1;
+        *reinterpret_cast<float4*>(&Xs[((tid >> 4) + 32) * ML_S + (tid & 15) * 4]) = x2;
+        if (tid < ML_TOK * ML_C / 4 - 768) *reinterpret_cast<float4*>(&Xs[((tid >> 4) + 48) * ML_S + (tid & 15) * 4]) = x3;
         __syncthreads();
-        if (pt + gridDim.x < T) gload(pt + gridDim.x);       // next point's tokens: in flight during the whole layer
+        if (pt + gridDim.x < T) ML_GLOAD(pt + gridDim.x)      // next point's tokens: in flight during the whole layer
 
         // ---- A: projections of this wave's two heads
         f32x4 Q[4], Kt[4], V[4];
