@@ -237,11 +237,14 @@ def main():
     # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # runs of this same command, corrected as profiles/pmc_traffic.py documents); counters cannot be read inside this process
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc):
-        ent = json.load(open(pmc)).get(kern)
-        if ent:
-            traffic = round(ent["bytes_per_launch"])
+    import glob
+    for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):     # newest round / pass first
+        tab = json.load(open(pmc))
+        ents = [v for k, v in tab.items() if k == kern or k.startswith(kern + "<")]     # template variants of the kernel: launch-weighted mean
+        if ents:
+            n = sum(e["launches_profiled"] for e in ents)
+            traffic = round(sum(e["bytes_per_launch"] * e["launches_profiled"] for e in ents) / n)
+            break
     out["roofline"] = {"bound": "mfma", "kernel": kern, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                        "launches_per_step": d["calls"], "avg_launch_ms": round(d["ms"] / d["calls"], 4),

@@ -127,31 +127,47 @@ class GT_network_equiv(nn.Module):
         with pointops.knn_scope():
             return self._forward(hitpts, pred_items, direction_mode, B, N)
 
-    overlap_index_ops = True   # run the coordinate-only FPS / kNN of the Point-Transformer nets on a side stream
+    overlap_index_ops = True   # run every coordinate-only index op (EPN FPS / ball queries, PT FPS / kNN) on a side stream
+    input_producer = None      # stream that produced `hitpts` if it is not the current one (set by a pipelined caller)
 
-    def _prefetch_pt_indices(self, hitpts, B, N):
-        """All FPS / kNN queries of both Point-Transformer nets depend on the coordinates only: issue them on a side HIP
-        stream so they overlap the EPN encoder; the nets find them memoised (pointops.knn_scope)."""
+    def _prefetch_indices(self, hitpts, B, N, want_pt):
+        """FPS / ball queries of the EPN encoder and all FPS / kNN queries of both Point-Transformer nets depend on the
+        coordinates only: issue them on a side HIP stream; the layers find them memoised (pointops.knn_scope).  The side
+        stream waits for the producer of `hitpts`, not for the work already queued on the current stream: under the
+        2-deep pipeline the index ops of batch i+1 (latency-bound, 32 workgroups) run while batch i still computes.
+        Returns (event after the EPN part, event after everything)."""
         from .pointtransformer_seg import prefetch_indices
+        from .so3conv import input_xyz
         main = torch.cuda.current_stream()
         if not hasattr(self, "_side_stream"):
             self._side_stream = torch.cuda.Stream()
         side = self._side_stream
-        side.wait_stream(main)
+        side.wait_stream(self.input_producer if self.input_producer is not None else main)
+        made = []
         with torch.cuda.stream(side):
-            oh = [N * (i + 1) for i in range(B)]
-            o = pointops.offsets_tensor(oh, hitpts.device)
-            made = prefetch_indices(hitpts.view(-1, 3), o)
+            cur = input_xyz(hitpts)
+            made.append(cur)
+            for block in self.encoder.backbone:
+                for conv in block.blocks:
+                    ball, sidx, cur = conv.inter_conv.conv.group(cur)
+                    made += [ball, sidx, cur]
+            epn_ready = torch.cuda.Event()
+            epn_ready.record(side)
+            if want_pt:
+                oh = [N * (i + 1) for i in range(B)]
+                o = pointops.offsets_tensor(oh, hitpts.device)
+                made += prefetch_indices(hitpts.view(-1, 3), o)
             done = torch.cuda.Event()
             done.record(side)
         for t in made:
             t.record_stream(main)
-        return done
+        return epn_ready, done
 
     def _forward(self, hitpts, pred_items, direction_mode, B, N):
         idx_ready = None
-        if self.overlap_index_ops and hitpts.is_cuda and ("confidence" in pred_items or "magnitude" in pred_items):
-            idx_ready = self._prefetch_pt_indices(hitpts, B, N)
+        if self.overlap_index_ops and hitpts.is_cuda:
+            epn_ready, idx_ready = self._prefetch_indices(hitpts, B, N, "confidence" in pred_items or "magnitude" in pred_items)
+            torch.cuda.current_stream().wait_event(epn_ready)
         r, sample_idx_lists = self.encode(hitpts)
         so3_anchors = r.anchors
         selected_indexs = torch.arange(0, N, device=hitpts.device).repeat(B, 1).unsqueeze(-1).expand(-1, -1, 3)

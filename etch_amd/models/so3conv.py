@@ -6,12 +6,19 @@ from .. import ops
 from .. import vgtk_so3conv as sptk
 
 
+def input_xyz(x):
+    """(b, n, 3) -> (b, 3, n) contiguous; one tensor per input inside a pointops.knn_scope (the index prefetch and the
+    encoder must see the same object: memo keys are tensor addresses)."""
+    from . import pointops
+    return pointops._memo(("epn_xyz", x.data_ptr(), tuple(x.shape)), (x,), lambda: x.permute(0, 2, 1).contiguous())
+
+
 def preprocess_input(x, na, add_center=True):
     """so3conv.py:7-16 for xyz-only input and add_center=False (the only mode ETCH uses, so3net.py:27):
     occupancy features = ones [b, 1, n, na] (functional.py:70-89)."""
     assert x.shape[2] == 3 and not add_center
     b, n, _ = x.shape
-    xyz = x.permute(0, 2, 1).contiguous()
+    xyz = input_xyz(x)
     feats_cl = torch.ones((b, n, na, 1), dtype=torch.float32, device=x.device)
     return sptk.SphericalPointCloud(xyz, None, None, feats_cl=feats_cl)
 

@@ -29,7 +29,10 @@ class HotPathPipeline:
         self.s1.wait_stream(caller)
         with torch.no_grad():
             with torch.cuda.stream(self.s1):
+                # the model's index stream waits for the producer of `points` (the caller's stream), not for s1's queue
+                self.model.input_producer = caller
                 results, _ = self.model(points, pred_items=["confidence", "direction", "magnitude"], direction_mode="standard_vector")
+                self.model.input_producer = None
                 labels = ops.argmax_rows(results["part_labels"])
                 inner = ops.inner_points(points.contiguous(), results["direction"], results["magnitude"], float(self.args.scale_magnitude))
                 ready = torch.cuda.Event()

@@ -139,11 +139,17 @@ class InterSO3Conv(nn.Module):
         return self._d.get((W, bias, self.anchors, self.kernels), build)
 
     def group(self, xyz):
-        """functional.py:176-185 inter_spconv_grouping_ball (index part): -> ball_idx, sample_idx, new_xyz."""
-        n_sample = math.ceil(xyz.shape[2] / self.stride)
-        sidx, new_xyz = furthest_sample(xyz, n_sample, self.lazy_sample)
-        ball = ball_query_index(new_xyz, xyz, self.radius, self.n_neighbor)
-        return ball, sidx, new_xyz
+        """functional.py:176-185 inter_spconv_grouping_ball (index part): -> ball_idx, sample_idx, new_xyz.
+        Coordinates only, so the model may have issued it ahead of time on its index stream: inside an active
+        pointops.knn_scope the result is memoised per (conv, xyz tensor)."""
+        from .models import pointops
+
+        def compute():
+            n_sample = math.ceil(xyz.shape[2] / self.stride)
+            sidx, new_xyz = furthest_sample(xyz, n_sample, self.lazy_sample)
+            ball = ball_query_index(new_xyz, xyz, self.radius, self.n_neighbor)
+            return ball, sidx, new_xyz
+        return pointops._memo(("epn_group", id(self), xyz.data_ptr(), tuple(xyz.shape)), (xyz,), compute)
 
     def forward(self, x, inter_idx=None, inter_w=None):
         xyz = x.xyz
