@@ -245,6 +245,74 @@ __global__ void __launch_bounds__(256) inter_so3conv_small_kernel(
     }
 }
 
+// First EPN layer (CIN = 1, functional.py:286-324 with a single input channel): X1[a][k] = sum_n F[idx_n, a] * w[a,k,n].
+// There is no channel dimension to put on the matrix cores (the weights depend on the anchor), so this is VALU work:
+// 92 160 weights per output point at 5 ops each (the relu(ga_n + rb_k + G_n . r_k) form of the MFMA kernel above) + 1 FMA.
+// One workgroup per output point; thread = (anchor, group of 6 kernel points): 240 of 256 threads busy in one pass, the
+// per-neighbour terms (G_n, ga_n) and the gathered features F[idx_n, :] are staged once in LDS (one broadcast
+// ds_read_b128 + one ds_read_b32 per neighbour feed 36 VALU ops); two kernel points per instruction (v_pk_fma_f32).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(256) inter_so3conv_c1_kernel(
+    int cout, int p1, int p2, int nn, float inv_sigma, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+    const int* __restrict__ ball_idx, const float* __restrict__ feats, const float* __restrict__ rk, const float* __restrict__ W,
+    const float* __restrict__ bias, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float4* GA = reinterpret_cast<float4*>(smem);          // [nn]  (2/sigma * g, 1 - |g|^2/sigma)
+    float* Fn = smem + 4 * nn;                              // [nn][NA]
+    float* X1 = Fn + nn * NA;                               // [NA][KS]
+    float* Ws = X1 + NA * KS;                               // [cout][KS]
+    int* qi = reinterpret_cast<int*>(Ws + cout * KS);       // [nn]
+    const int tid = threadIdx.x, b = blockIdx.y, p = blockIdx.x;
+    const float* X = xyz + (size_t)b * 3 * p1;
+    for (int n = tid; n < nn; n += 256) {
+        const int q = ball_idx[((size_t)b * p2 + p) * nn + n];
+        qi[n] = q;
+        const float x = X[q] - new_xyz[((size_t)b * 3 + 0) * p2 + p], y = X[p1 + q] - new_xyz[((size_t)b * 3 + 1) * p2 + p],
+                    z = X[2 * p1 + q] - new_xyz[((size_t)b * 3 + 2) * p2 + p];
+        GA[n] = make_float4(2.0f * inv_sigma * x, 2.0f * inv_sigma * y, 2.0f * inv_sigma * z, 1.0f - (x * x + y * y + z * z) * inv_sigma);
+    }
+    for (int e = tid; e < cout * KS; e += 256) Ws[e] = W[e];
+    __syncthreads();
+    const float* Fb = feats + (size_t)b * p1 * NA;
+    for (int e = tid; e < nn * NA; e += 256) {
+        const int n = e / NA, a = e - n * NA;
+        Fn[e] = Fb[(size_t)qi[n] * NA + a];
+    }
+    __syncthreads();
+    if (tid < NA * 4) {
+        const int a = tid >> 2, k0 = (tid & 3) * 6;
+        f32x2 rx[3], ry[3], rz[3], rb[3], acc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float* r0 = rk + ((size_t)a * KS + k0 + 2 * j) * 3;
+            rx[j] = (f32x2){r0[0], r0[3]}; ry[j] = (f32x2){r0[1], r0[4]}; rz[j] = (f32x2){r0[2], r0[5]};
+            rb[j] = -(rx[j] * rx[j] + ry[j] * ry[j] + rz[j] * rz[j]) * inv_sigma;
+            acc[j] = (f32x2){0.f, 0.f};
+        }
+        for (int n = 0; n < nn; ++n) {
+            const float4 g = GA[n];
+            const float f = Fn[n * NA + a];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                f32x2 w = rz[j] * g.z + (ry[j] * g.y + (rx[j] * g.x + (rb[j] + g.w)));
+                w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f);
+                acc[j] += w * f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { X1[a * KS + k0 + 2 * j] = acc[j].x; X1[a * KS + k0 + 2 * j + 1] = acc[j].y; }
+    }
+    __syncthreads();
+    float* outp = out + ((size_t)b * p2 + p) * NA * cout;
+    for (int e = tid; e < NA * cout; e += 256) {
+        const int a = e / cout, o = e - a * cout;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) acc = fmaf(Ws[o * KS + i], X1[a * KS + i], acc);
+        outp[e] = acc + bias[o];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // intra conv: Y[b,p,a,o] = sum_{tap<12} sum_c act(X[b,p,intra_idx[a,tap],c]) * W[o, c*12+tap] + bias[o]
 // One workgroup = PTS points; the point's [60][C] tile is staged in LDS (optionally normalised +
@@ -441,6 +509,15 @@ int etch_inter_so3conv(int b, int cin, int cout, int p1, int p2, int nn, float s
     if (cin == CI && cout == CO) return launch_inter<CI, CO>(b, p1, p2, nn, sigma, xyz, new_xyz, ball_idx, feats, rk, Wp, bias, out, st);
     INTER_CASE(16, 16) INTER_CASE(16, 32) INTER_CASE(32, 32) INTER_CASE(32, 64) INTER_CASE(64, 64)
 #undef INTER_CASE
+    if (cin == 1 && cout <= 64) {
+        const size_t lds = ((size_t)4 * nn + (size_t)nn * NA + NA * KS + (size_t)cout * KS + nn) * sizeof(float);
+        if (lds <= 64 * 1024) {
+            hipLaunchKernelGGL(inter_so3conv_c1_kernel, dim3(p2, b), dim3(256), lds, st, cout, p1, p2, nn, 1.0f / sigma, xyz, new_xyz, ball_idx,
+                               feats, rk, W, bias, out);
+            ETCH_RETURN_IF_LAUNCH_FAILED();
+            return ETCH_OK;
+        }
+    }
     if (cin <= 8) {
         const size_t lds = (size_t)(4 * nn + NA * cin * KS) * sizeof(float);
         hipLaunchKernelGGL(inter_so3conv_small_kernel, dim3(p2, b), dim3(256), lds, st, cin, cout, p1, p2, nn, 1.0f / sigma, xyz,
