@@ -397,25 +397,39 @@ __global__ void __launch_bounds__(256) intra_so3conv_kernel(int npts_total, int 
 #define IN_CHUNKS 64
 __global__ void __launch_bounds__(256) instnorm_partial_kernel(int rows, int C, const float* __restrict__ x,
                                                                double* __restrict__ partial) {
-    // grid (IN_CHUNKS, b); thread -> channel lane (tid % C4) and row slice
-    extern __shared__ __attribute__((aligned(16))) double sred[];   // [256/C][2][C] ... sized 2*256
+    // grid (IN_CHUNKS, b); thread -> channel quad (tid % (C/4)) and row slice; 16-byte loads, two rows in flight per thread
+    extern __shared__ __attribute__((aligned(16))) double sred[];   // [2][256][4]
     const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-    const int tpr = C;                         // threads per row pass
-    const int rpp = 256 / tpr;                 // rows per pass (C <= 256, C divides 256)
-    const int c = tid % tpr, rsub = tid / tpr;
+    const int tpr = C >> 2;                    // threads per row (C % 4 == 0, C/4 divides 256)
+    const int rpp = 256 / tpr;                 // rows per pass
+    const int cq = tid % tpr, rsub = tid / tpr;
     const int r_begin = (int)(((long)rows * chunk) / IN_CHUNKS), r_end = (int)(((long)rows * (chunk + 1)) / IN_CHUNKS);
-    double s = 0.0, ss = 0.0;
-    const float* xb = x + (size_t)b * rows * C;
-    for (int r = r_begin + rsub; r < r_end; r += rpp) {
-        const double v = (double)xb[(size_t)r * C + c];
-        s += v; ss += v * v;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
+    const float4* xb = reinterpret_cast<const float4*>(x + (size_t)b * rows * C) + cq;
+    int r = r_begin + rsub;
+    for (; r + rpp < r_end; r += 2 * rpp) {
+        const float4 u = xb[(size_t)r * tpr], v = xb[(size_t)(r + rpp) * tpr];
+        s[0] += (double)u.x; ss[0] += (double)u.x * u.x; s[1] += (double)u.y; ss[1] += (double)u.y * u.y;
+        s[2] += (double)u.z; ss[2] += (double)u.z * u.z; s[3] += (double)u.w; ss[3] += (double)u.w * u.w;
+        s[0] += (double)v.x; ss[0] += (double)v.x * v.x; s[1] += (double)v.y; ss[1] += (double)v.y * v.y;
+        s[2] += (double)v.z; ss[2] += (double)v.z * v.z; s[3] += (double)v.w; ss[3] += (double)v.w * v.w;
     }
-    sred[tid] = s; sred[256 + tid] = ss;
+    if (r < r_end) {
+        const float4 u = xb[(size_t)r * tpr];
+        s[0] += (double)u.x; ss[0] += (double)u.x * u.x; s[1] += (double)u.y; ss[1] += (double)u.y * u.y;
+        s[2] += (double)u.z; ss[2] += (double)u.z * u.z; s[3] += (double)u.w; ss[3] += (double)u.w * u.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sred[tid * 4 + j] = s[j]; sred[1024 + tid * 4 + j] = ss[j]; }
     __syncthreads();
     if (rsub == 0) {
-        for (int k = 1; k < rpp; ++k) { s += sred[k * tpr + c]; ss += sred[256 + k * tpr + c]; }
-        partial[(((size_t)b * IN_CHUNKS + chunk) * 2 + 0) * C + c] = s;
-        partial[(((size_t)b * IN_CHUNKS + chunk) * 2 + 1) * C + c] = ss;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double a = s[j], q = ss[j];
+            for (int k = 1; k < rpp; ++k) { a += sred[(k * tpr + cq) * 4 + j]; q += sred[1024 + (k * tpr + cq) * 4 + j]; }
+            partial[(((size_t)b * IN_CHUNKS + chunk) * 2 + 0) * C + cq * 4 + j] = a;
+            partial[(((size_t)b * IN_CHUNKS + chunk) * 2 + 1) * C + cq * 4 + j] = q;
+        }
     }
 }
 
@@ -542,9 +556,9 @@ int etch_intra_so3conv(int b, int c, int cout, int p, const float* X, const floa
 // workspace: IN_CHUNKS * b * 2 * C doubles
 int etch_instnorm_stats(int b, int rows, int C, const float* x, double* workspace, float* mean, float* rstd, void* stream) {
     if (b <= 0) return ETCH_OK;
-    if (C <= 0 || C > 256 || (256 % C) != 0) return ETCH_EUNSUPPORTED;
+    if (C < 4 || C > 256 || (C & 3) || (256 % (C >> 2)) != 0 || ((uintptr_t)x & 15)) return ETCH_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(instnorm_partial_kernel, dim3(IN_CHUNKS, b), dim3(256), 2 * 256 * sizeof(double), st, rows, C, x, workspace);
+    hipLaunchKernelGGL(instnorm_partial_kernel, dim3(IN_CHUNKS, b), dim3(256), 2 * 1024 * sizeof(double), st, rows, C, x, workspace);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     hipLaunchKernelGGL(instnorm_final_kernel, dim3(b), dim3(256), 0, st, rows, C, 1e-5f, workspace, mean, rstd);
     ETCH_RETURN_IF_LAUNCH_FAILED();
