@@ -232,7 +232,14 @@ def main():
         agg = profile_pass(step)
         stage1_only()
     tot_ms = sum(d["ms"] for d in agg.values())
-    kern, d = max(agg.items(), key=lambda kv: kv[1]["ms"])
+    # dominant kernel = the kernel FUNCTION with the largest share of the step (template instantiations of one kernel are
+    # one kernel: the three inter_so3conv_kernel<CIN,COUT,MAXT> launches of a step are priced together)
+    fam = collections.OrderedDict()
+    for k, v in agg.items():
+        f = fam.setdefault(k.split("<")[0], dict(calls=0, ms=0.0, flops=0.0))
+        for key in ("calls", "ms", "flops"):
+            f[key] += v[key]
+    kern, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
     # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # runs of this same command, corrected as profiles/pmc_traffic.py documents); counters cannot be read inside this process
