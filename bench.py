@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--sync", action="store_true", help="synchronous steps (stage 2 of a batch finishes before stage 1 of the next starts). Default: the "
                     "2-deep stream pipeline of etch_amd.pipeline -- stage 2 of step i (32 persistent workgroups, 1/8 of the chip) runs on a second "
                     "HIP stream next to stage 1 of step i+1; every one of the K steps still completes inside the timed region")
+    ap.add_argument("--stage1-streams", type=int, default=1, help="stage-1 streams the pipeline alternates over (batches in flight = this + 1)")
     a = ap.parse_args()
     a.pipeline = not a.sync
 
@@ -175,7 +176,7 @@ def main():
         last.update(markers=markers, valid=valid, verts=aux["verts"], x=aux["x"], err=aux["err_trace"][:, -1])
 
     from etch_amd.pipeline import HotPathPipeline
-    pipe = HotPathPipeline(args, model, "neutral", max_in_flight=2, want_trace=True)
+    pipe = HotPathPipeline(args, model, "neutral", max_in_flight=a.stage1_streams + 1, stage1_streams=a.stage1_streams, want_trace=True)
 
     def run_steps(k):
         """k steps; with the pipeline, stage 2 of step i overlaps stage 1 of step i+1 (all k steps finish inside the call)."""

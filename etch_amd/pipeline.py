@@ -14,9 +14,11 @@ class Ticket:
 
 
 class HotPathPipeline:
-    def __init__(self, args, model, gender="neutral", max_in_flight=2, **fit_kwargs):
+    def __init__(self, args, model, gender="neutral", max_in_flight=2, stage1_streams=1, **fit_kwargs):
         self.args, self.model, self.gender, self.fit_kwargs = args, model, gender, fit_kwargs
-        self.s1 = torch.cuda.Stream()
+        # stage 1 of consecutive batches alternates over `stage1_streams` streams: with 2, the low-occupancy kernels of one
+        # batch (deep Point-Transformer levels: a few dozen workgroups) fill behind the chip-wide kernels of the other
+        self.s1s = [torch.cuda.Stream() for _ in range(stage1_streams)]
         self.s2 = torch.cuda.Stream()
         self.max_in_flight = max_in_flight
         self.in_flight = []
@@ -26,9 +28,10 @@ class HotPathPipeline:
     def submit(self, points):
         """Enqueue one batch (B,N,3) resident on the device; returns a Ticket.  Never blocks on the GPU."""
         caller = torch.cuda.current_stream()
-        self.s1.wait_stream(caller)
+        s1 = self.s1s[self._n % len(self.s1s)]
+        s1.wait_stream(caller)
         with torch.no_grad():
-            with torch.cuda.stream(self.s1):
+            with torch.cuda.stream(s1):
                 # the model's index stream waits for the producer of `points` (the caller's stream), not for s1's queue
                 self.model.input_producer = caller
                 results, _ = self.model(points, pred_items=["confidence", "direction", "magnitude"], direction_mode="standard_vector")
@@ -36,7 +39,7 @@ class HotPathPipeline:
                 labels = ops.argmax_rows(results["part_labels"])
                 inner = ops.inner_points(points.contiguous(), results["direction"], results["magnitude"], float(self.args.scale_magnitude))
                 ready = torch.cuda.Event()
-                ready.record(self.s1)
+                ready.record(s1)
             conf = results["confidences"]
             for t in (inner, labels, conf):
                 t.record_stream(self.s2)
