@@ -151,6 +151,7 @@ def main():
                     "2-deep stream pipeline of etch_amd.pipeline -- stage 2 of step i (32 persistent workgroups, 1/8 of the chip) runs on a second "
                     "HIP stream next to stage 1 of step i+1; every one of the K steps still completes inside the timed region")
     ap.add_argument("--stage1-streams", type=int, default=1, help="stage-1 streams the pipeline alternates over (batches in flight = this + 1)")
+    ap.add_argument("--concurrent-heads", type=int, default=1, help="1: confidence / magnitude nets on their own streams next to the direction head")
     a = ap.parse_args()
     a.pipeline = not a.sync
 
@@ -166,6 +167,7 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     args, model = build(device)
+    model.concurrent_heads = bool(a.concurrent_heads)
     B, N = a.batch, a.points
     s0, _ = P.shard_range(B * world, rank, world)
     pts = torch.from_numpy(np.stack([synth_scan(s0 + i, N) for i in range(B)])).to(device)

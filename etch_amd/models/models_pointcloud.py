@@ -177,18 +177,45 @@ class GT_network_equiv(nn.Module):
         if idx_ready is not None:
             torch.cuda.current_stream().wait_event(idx_ready)
         # both Point-Transformer nets share FPS / kNN indices (same points, same offsets) through the enclosing knn_scope
-        self._heads(results, pred_items, direction_mode, hitpts, point_inv_feat, point_equiv_cl, so3_anchors, B, N)
+        self._heads(results, pred_items, direction_mode, hitpts, point_inv_feat, point_equiv_cl, so3_anchors, B, N,
+                    indices_prefetched=idx_ready is not None)
         return results, selected_indexs
 
-    def _heads(self, results, pred_items, direction_mode, hitpts, point_inv_feat, point_equiv_cl, so3_anchors, B, N):
+    concurrent_heads = True    # run the confidence and magnitude nets on their own HIP streams next to the direction head
+
+    def _heads(self, results, pred_items, direction_mode, hitpts, point_inv_feat, point_equiv_cl, so3_anchors, B, N, indices_prefetched=False):
+        # The three heads are independent given the encoder output.  With `concurrent_heads` the two Point-Transformer nets
+        # (many small launches: a few dozen workgroups at the deep levels) run on side streams while the direction head keeps
+        # the matrix cores busy on the current one.  Only when every index tensor was produced ahead of time: a tensor
+        # memoised by one branch and read by another would otherwise cross streams unsynchronised.
+        fork = self.concurrent_heads and indices_prefetched and hitpts.is_cuda
+        main = torch.cuda.current_stream() if hitpts.is_cuda else None
+        if fork:
+            if not hasattr(self, "_head_streams"):
+                self._head_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+            for st in self._head_streams:
+                st.wait_stream(main)
+
+        def branch(k, fn):
+            if not fork:
+                return fn()
+            with torch.cuda.stream(self._head_streams[k]):
+                out = fn()
+            for t in (out if isinstance(out, tuple) else (out,)):
+                t.record_stream(main)
+            return out
+
         if "confidence" in pred_items:
-            part_labels, confidences = self.decode_confidence(point_inv_feat, hitpts)
+            part_labels, confidences = branch(0, lambda: self.decode_confidence(point_inv_feat, hitpts))
             results["confidences"] = confidences
             results["part_labels"] = part_labels
+        if "magnitude" in pred_items:
+            results["magnitude"] = branch(1, lambda: self.decode_magnitude(point_inv_feat, hitpts))
         if "direction" in pred_items:
             if direction_mode != "standard_vector":
                 raise AssertionError("Not implemented")   # same as the reference (:199,210)
             standard_vector = self.standard_vector.repeat(B, N, 1)
             results["direction"] = self.decode_direction(None, so3_anchors, standard_vector, tokens_cl=point_equiv_cl)
-        if "magnitude" in pred_items:
-            results["magnitude"] = self.decode_magnitude(point_inv_feat, hitpts)
+        if fork:
+            for st in self._head_streams:
+                main.wait_stream(st)

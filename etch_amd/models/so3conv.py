@@ -13,13 +13,30 @@ def input_xyz(x):
     return pointops._memo(("epn_xyz", x.data_ptr(), tuple(x.shape)), (x,), lambda: x.permute(0, 2, 1).contiguous())
 
 
+_ones_cache = {}
+
+
+def _occupancy_ones(b, n, na, device):
+    """The all-ones occupancy features (functional.py:70-89) are a constant of the input shape: one read-only tensor per shape
+    instead of a 38 MB fill per forward (0.9 ms at 32 x 5 000 points)."""
+    key = (b, n, na, device.type, device.index)
+    t = _ones_cache.get(key)
+    if t is None:
+        if len(_ones_cache) > 8:
+            _ones_cache.clear()
+        t = torch.ones((b, n, na, 1), dtype=torch.float32, device=device)
+        torch.cuda.current_stream(device).synchronize() if device.type == "cuda" else None
+        _ones_cache[key] = t
+    return t
+
+
 def preprocess_input(x, na, add_center=True):
     """so3conv.py:7-16 for xyz-only input and add_center=False (the only mode ETCH uses, so3net.py:27):
     occupancy features = ones [b, 1, n, na] (functional.py:70-89)."""
     assert x.shape[2] == 3 and not add_center
     b, n, _ = x.shape
     xyz = input_xyz(x)
-    feats_cl = torch.ones((b, n, na, 1), dtype=torch.float32, device=x.device)
+    feats_cl = _occupancy_ones(b, n, na, x.device)
     return sptk.SphericalPointCloud(xyz, None, None, feats_cl=feats_cl)
 
 

@@ -141,6 +141,31 @@ def test_stream_pipeline_matches_synchronous_path(tmp_path):
         assert np.array_equal(m0[0].vertices, m1[0].vertices)
 
 
+@pytest.mark.parametrize("B,N", [(2, 1500), (8, 5000)])
+def test_schedule_variants_are_bitwise_identical(tmp_path, B, N):
+    """Stream schedule must not change a bit: heads on their own streams vs one stream, index ops prefetched on the side
+    stream vs computed inline, repeated to give a cross-stream race the chance to show."""
+    args, model = make(tmp_path)
+    pts = torch.from_numpy(np.stack([scan(400 + b, N) for b in range(B)])).cuda()
+    items = ["confidence", "direction", "magnitude"]
+
+    def run(concurrent, overlap):
+        model.concurrent_heads, model.overlap_index_ops = concurrent, overlap
+        with torch.no_grad():
+            res, _ = model(pts, items, "standard_vector")
+        torch.cuda.synchronize()
+        return {k: v.clone() for k, v in res.items()}
+    try:
+        ref = run(False, False)
+        for rep in range(4):
+            for concurrent, overlap in ((True, True), (False, True), (True, False)):
+                got = run(concurrent, overlap)
+                for k in ref:
+                    assert torch.equal(ref[k], got[k]), (k, concurrent, overlap, rep)
+    finally:
+        model.concurrent_heads, model.overlap_index_ops = type(model).concurrent_heads, type(model).overlap_index_ops
+
+
 def test_encoder_equivariance_property(tmp_path):
     """Oracle-free pin: rotating the scan by an icosahedral anchor R_g permutes the encoder features over
     anchors, feats'[..., a] = feats[..., a'] with R_a' = R_g^T R_a, and rotates `direction` by R_g wherever the so3_mean
