@@ -192,7 +192,9 @@ class GT_network_equiv(nn.Module):
         main = torch.cuda.current_stream() if hitpts.is_cuda else None
         if fork:
             if not hasattr(self, "_head_streams"):
-                self._head_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+                # the nets are long chains of small kernels (the critical path of this phase), the direction head on the current
+                # stream is a few chip-wide kernels: high-priority queues let the chains go first whenever they have work
+                self._head_streams = (torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=-1))
             for st in self._head_streams:
                 st.wait_stream(main)
 

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Concurrency summary of a rocprofv3 kernel trace (rocpd sqlite): for the window spanned by the timed pipelined steps
+(between the first and last smpl_lm_fit_kernel of the longest run of evenly spaced fits) print, per HIP stream / HSA queue,
+the kernel-busy time, the union busy time of the device, and the largest idle gaps of the busiest queue.
+
+    python profiles/timeline_rocpd.py gpurun_out/prof/NAME_results.db
+"""
+import sqlite3
+import sys
+
+
+def union(iv):
+    iv = sorted(iv)
+    tot, cur_s, cur_e = 0, None, None
+    for s, e in iv:
+        if cur_e is None or s > cur_e:
+            if cur_e is not None:
+                tot += cur_e - cur_s
+            cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    if cur_e is not None:
+        tot += cur_e - cur_s
+    return tot
+
+
+def main(path):
+    c = sqlite3.connect(path)
+    rows = c.execute("select name, start, end, queue_id, stream_id from kernels order by start").fetchall()
+    lm = [r for r in rows if r[0].startswith("smpl_lm_fit_kernel")]
+    # timed pipelined steps: the longest run of consecutive fits whose spacing stays within 25 % of the run's first spacing
+    best = (0, 0)
+    i = 0
+    while i + 1 < len(lm):
+        j, d0 = i + 1, lm[i + 1][1] - lm[i][1]
+        while j + 1 < len(lm) and abs((lm[j + 1][1] - lm[j][1]) - d0) < 0.25 * d0:
+            j += 1
+        if j - i > best[1] - best[0]:
+            best = (i, j)
+        i = j
+    t0, t1 = lm[best[0]][1], lm[best[1]][1]
+    nsteps = best[1] - best[0]
+    win = [r for r in rows if r[1] >= t0 and r[2] <= t1]
+    wall = t1 - t0
+    print(f"# window: {nsteps} pipelined steps, {wall / 1e6:.2f} ms  ({wall / nsteps / 1e6:.2f} ms/step), {len(win)} kernels")
+    print(f"device busy (union of all kernels): {union([(r[1], r[2]) for r in win]) / wall * 100:.1f} % of the window")
+    by = {}
+    for r in win:
+        by.setdefault((r[3], r[4]), []).append(r)
+    print(f"{'queue':>6s} {'stream':>7s} {'kernels':>8s} {'busy ms/step':>13s} {'busy %':>7s}  top kernels")
+    for key, rs in sorted(by.items(), key=lambda kv: -sum(r[2] - r[1] for r in kv[1])):
+        busy = sum(r[2] - r[1] for r in rs)
+        agg = {}
+        for r in rs:
+            agg[r[0].split("(")[0][:40]] = agg.get(r[0].split("(")[0][:40], 0) + r[2] - r[1]
+        top = ", ".join(f"{k} {v / nsteps / 1e6:.1f}" for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:3])
+        print(f"{key[0]:6d} {key[1]:7d} {len(rs):8d} {busy / nsteps / 1e6:13.2f} {busy / wall * 100:7.1f}  {top}")
+    key, rs = max(by.items(), key=lambda kv: sum(r[2] - r[1] for r in kv[1]))
+    rs = sorted(rs, key=lambda r: r[1])
+    gaps = sorted(((rs[i + 1][1] - rs[i][2], rs[i][0].split("(")[0][:36], rs[i + 1][0].split("(")[0][:36]) for i in range(len(rs) - 1)), reverse=True)
+    tot_gap = sum(g[0] for g in gaps if g[0] > 0)
+    print(f"busiest stream: idle between its kernels {tot_gap / nsteps / 1e6:.2f} ms/step; largest gaps (us, after -> before):")
+    for g in gaps[:8]:
+        print(f"  {g[0] / 1e3:9.1f}  {g[1]} -> {g[2]}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
