@@ -165,18 +165,18 @@ __global__ void __launch_bounds__(256) pt_attn_aggregate_kernel(PtAttnParams a, 
     }
 }
 
-// rows[(i*ns + j)] = [ p[idx[i,j]] - new_p[i]  (3) | x[idx[i,j]] (c) ],   row length 3 + c
+// rows[(i*ns + j)] = [ p[idx[i,j]] - new_p[i]  (3) | x[idx[i,j]] (c) | 0 ... ],   row stride ld >= 3 + c (padding columns are zeroed,
+// so a consumer may treat the row as ld wide: ld % 4 == 0 keeps the following GEMM on its 16-byte load path)
 __global__ void __launch_bounds__(256) pt_group_kernel(int m, int ns, int c, const float* __restrict__ p, const float* __restrict__ new_p,
                                                        const float* __restrict__ x, long ldx, const int* __restrict__ idx,
-                                                       float* __restrict__ out) {
-    const int ld = 3 + c;
+                                                       float* __restrict__ out, int ld) {
     const size_t total = (size_t)m * ns * ld;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         const size_t row = e / ld;
         const int col = (int)(e - row * ld);
         const int i = (int)(row / ns);
         const int j = idx[row];
-        out[e] = col < 3 ? p[(size_t)j * 3 + col] - new_p[(size_t)i * 3 + col] : x[(size_t)j * ldx + col - 3];
+        out[e] = col < 3 ? p[(size_t)j * 3 + col] - new_p[(size_t)i * 3 + col] : (col < 3 + c ? x[(size_t)j * ldx + col - 3] : 0.f);
     }
 }
 
@@ -350,10 +350,11 @@ int etch_pt_attn_aggregate(int n, int c, int ns, const float* p, const float* xv
 }
 
 int etch_pt_group(int m, int ns, int c, const float* p, const float* new_p, const float* x, long ldx, const int* idx, float* out,
-                  void* stream) {
+                  long ldo, void* stream) {
     if (m <= 0) return ETCH_OK;
-    hipLaunchKernelGGL(pt_group_kernel, dim3(grid_for((size_t)m * ns * (3 + c), 256)), dim3(256), 0, (hipStream_t)stream, m, ns, c, p,
-                       new_p, x, ldx, idx, out);
+    if (ldo < 3 + c) return ETCH_EINVAL;
+    hipLaunchKernelGGL(pt_group_kernel, dim3(grid_for((size_t)m * ns * ldo, 256)), dim3(256), 0, (hipStream_t)stream, m, ns, c, p,
+                       new_p, x, ldx, idx, out, (int)ldo);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }

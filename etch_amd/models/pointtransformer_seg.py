@@ -76,7 +76,7 @@ class TransitionDown(nn.Module):
             self.linear = nn.Linear(in_planes, out_planes, bias=False)
         self.bn = nn.BatchNorm1d(out_planes)
         self.relu = nn.ReLU(inplace=True)
-        self._d = _Derived()
+        self._d, self._dw = _Derived(), _Derived()
 
     def forward(self, pxo):
         p, x, o = pxo
@@ -92,8 +92,10 @@ class TransitionDown(nn.Module):
             idx = pointops.furthestsampling(p, o, n_o_t)
             n_p = pointops.gather_rows(p, idx)
             kidx = pointops.knnquery(self.nsample, p, n_p, o, n_o_t)[0]
-            g = ops.pt_group(p, n_p, x, kidx)                                  # (m*ns, 3+c)
-            y = ops.linear(g, w, scale=s, shift=t, act="relu")                 # Linear -> BN -> ReLU
+            # rows and weight padded to a multiple of 4 columns with zeros (3 + c is odd): same sums, 16-byte load path in the GEMM
+            g = ops.pt_group(p, n_p, x, kidx, pad_to=4)                        # (m*ns, 3+c (+pad))
+            wp = self._dw.get([self.linear.weight], lambda: torch.nn.functional.pad(w, (0, g.shape[1] - w.shape[1])).contiguous())
+            y = ops.linear(g, wp, scale=s, shift=t, act="relu")                # Linear -> BN -> ReLU
             x = ops.rows_maxpool(y, self.nsample)
             p, o = n_p, n_o_t
         else:

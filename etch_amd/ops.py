@@ -279,11 +279,14 @@ def pt_attention_split(p, qkv, c, idx, params, ns, w2, b2, s3, t3, w5, b5):
     return out
 
 
-def pt_group(p, new_p, x, idx):
+def pt_group(p, new_p, x, idx, pad_to=1):
+    """-> (m*ns, ld) with ld = 3 + c rounded up to a multiple of `pad_to` (padding columns are zero)."""
     m, ns = idx.shape
     c = x.shape[1]
-    out = torch.empty((m * ns, 3 + c), dtype=torch.float32, device=p.device)
-    _lib.check(_lib.lib().etch_pt_group(m, ns, c, _ptr(p), _ptr(new_p), _ptr(x), _c_long(x.stride(0)), _ptr(idx), _ptr(out), _stream()), "etch_pt_group")
+    ld = -(-(3 + c) // pad_to) * pad_to
+    out = torch.empty((m * ns, ld), dtype=torch.float32, device=p.device)
+    _lib.check(_lib.lib().etch_pt_group(m, ns, c, _ptr(p), _ptr(new_p), _ptr(x), _c_long(x.stride(0)), _ptr(idx), _ptr(out), _c_long(ld), _stream()),
+               "etch_pt_group")
     return out
 
 

@@ -146,9 +146,9 @@ int etch_pt_attn_aggregate(int n, int c, int ns, const float* p, const float* xv
                            const float* const* params, float* out, long ldo, void* stream);
 
 /* queryandgroup(use_xyz=True) rows for TransitionDown (pointtransformer_seg.py:61, pointops.py:90-98):
- * out[(i*ns+j)] = [p[idx[i,j]] - new_p[i] | x[idx[i,j]]], row length 3+c. */
+ * out[(i*ns+j)] = [p[idx[i,j]] - new_p[i] | x[idx[i,j]] | 0...], row stride ldo >= 3+c (padding columns zeroed). */
 int etch_pt_group(int m, int ns, int c, const float* p, const float* new_p, const float* x, long ldx, const int* idx,
-                  float* out, void* stream);
+                  float* out, long ldo, void* stream);
 
 /* Row gather n_p = p[idx] (pointtransformer_seg.py:60): out[i,:c] = x[idx[i],:c]. */
 int etch_gather_rows(int m, int c, const float* x, long ldx, const int* idx, float* out, void* stream);
