@@ -99,6 +99,8 @@ class TransitionDown(nn.Module):
             x = ops.rows_maxpool(y, self.nsample)
             p, o = n_p, n_o_t
         else:
+            if x.shape[1] != w.shape[1]:                                       # zero-padded input columns (see _unet)
+                w = self._dw.get([self.linear.weight], lambda: torch.nn.functional.pad(w, (0, x.shape[1] - w.shape[1])).contiguous())
             x = ops.linear(x, w, scale=s, shift=t, act="relu")
         return [p, x, o]
 
@@ -192,7 +194,12 @@ class _PointTransformerBase(nn.Module):
 
     def _unet(self, pxo):
         p0, x0, o0 = pxo
-        x0 = p0 if self.c == 3 else torch.cat((p0, x0), 1)
+        if self.c != 3:
+            # [p | x] zero-padded to a multiple of 4 columns (enc1's weight is padded to match): 16-byte load path of the GEMM
+            pad = (-(p0.shape[1] + x0.shape[1])) % 4
+            x0 = torch.cat((p0, x0) + ((x0.new_zeros((x0.shape[0], pad)),) if pad else ()), 1)
+        else:
+            x0 = p0
         p1, x1, o1 = self.enc1([p0, x0, o0])
         p2, x2, o2 = self.enc2([p1, x1, o1])
         p3, x3, o3 = self.enc3([p2, x2, o2])
