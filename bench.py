@@ -222,7 +222,7 @@ def main():
                       "schedule": "synchronous steps" if not a.pipeline else "2-deep stream pipeline: stage 2 of step i overlaps stage 1 of step i+1",
                       "global_batch": B * world, "points": N, "parallelism": f"scan-sharded x{world}"},
            "mean_final_lm_error": float(allrows[:, 0].mean()), "scans_reported": int(allrows.shape[0]),
-           "ms_per_step_synchronous": round(sync_ms, 3)}
+           "ms_per_step_synchronous": round(sync_ms, 3), "peak_hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2)}
 
     # roofline of the dominant kernel: one instrumented pass of the same step (HIP events on the launch stream)
     model_results = {}

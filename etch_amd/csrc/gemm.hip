@@ -257,9 +257,12 @@ static int launch_wres(const GemmArgs& a, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
     }
     const int ntiles = (a.R + 15) / 16;
-    int per_cu = lds <= 40 * 1024 ? 4 : (lds <= 53 * 1024 ? 3 : (lds <= 80 * 1024 ? 2 : 1));
-    int blocks = 256 * per_cu;
-    if (blocks > (ntiles + 3) / 4) blocks = (ntiles + 3) / 4;
+    // NOT sized to the chip: the kernel usually runs next to kernels of other HIP streams (heads on their own streams, the
+    // 2-deep pipeline), where a grid of exactly CUs x occupancy blocks with a static share of the rows each ran 6x longer
+    // (blocks that do not fit immediately start late and finish late).  8 row tiles per wave amortise the weight staging;
+    // the dispatcher balances the rest.
+    int blocks = (ntiles + 31) / 32;
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, a);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
