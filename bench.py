@@ -58,7 +58,8 @@ def algorithmic_flops(name, a):
         return 2.0 * R * G * J * (K + 1), "linear_relu_dot_kernel"
     if name == "etch_inter_so3conv":
         b, cin, cout, p1, p2, nn = v[0:6]
-        return 2.0 * b * p2 * 60 * 24 * (cin * nn + cout * cin), f"inter_so3conv_kernel<{cin},{cout},{(nn + 15) // 16 if nn <= 32 else 4}>"
+        kern = "inter_so3conv_c1_kernel" if cin == 1 else f"inter_so3conv_kernel<{cin},{cout},{(nn + 15) // 16 if nn <= 32 else 4}>"
+        return 2.0 * b * p2 * 60 * 24 * (cin * nn + cout * cin), kern
     if name == "etch_intra_so3conv":
         b, c, cout, p = v[0:4]
         return 2.0 * b * p * 60 * 12 * c * cout, f"intra_so3conv_kernel<{c},{cout}>"
@@ -150,9 +151,12 @@ def main():
     ap.add_argument("--sync", action="store_true", help="synchronous steps (stage 2 of a batch finishes before stage 1 of the next starts). Default: the "
                     "2-deep stream pipeline of etch_amd.pipeline -- stage 2 of step i (32 persistent workgroups, 1/8 of the chip) runs on a second "
                     "HIP stream next to stage 1 of step i+1; every one of the K steps still completes inside the timed region")
+    ap.add_argument("--serial", action="store_true", help="profiling schedule: synchronous steps and every kernel on one stream")
     ap.add_argument("--stage1-streams", type=int, default=1, help="stage-1 streams the pipeline alternates over (batches in flight = this + 1)")
     ap.add_argument("--concurrent-heads", type=int, default=1, help="1: confidence / magnitude nets on their own streams next to the direction head")
     a = ap.parse_args()
+    if a.serial:
+        a.sync, a.concurrent_heads = True, 0
     a.pipeline = not a.sync
 
     from etch_amd import parallel as P
@@ -168,6 +172,8 @@ def main():
     device = torch.device("cuda", local)
     args, model = build(device)
     model.concurrent_heads = bool(a.concurrent_heads)
+    if a.serial:
+        model.overlap_index_ops = False
     B, N = a.batch, a.points
     s0, _ = P.shard_range(B * world, rank, world)
     pts = torch.from_numpy(np.stack([synth_scan(s0 + i, N) for i in range(B)])).to(device)
@@ -219,7 +225,7 @@ def main():
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"configs[2]: batch={B}/GPU synthetic {N}-pt Gaussian-blob scans, full pipeline (eq-net + 30+50-iter LM SMPL fit), "
                                   "seeded random weights, seeded SMPL-shaped body model, 86-marker superset",
-                      "schedule": "synchronous steps" if not a.pipeline else "2-deep stream pipeline: stage 2 of step i overlaps stage 1 of step i+1",
+                      "schedule": ("serial: synchronous steps, one stream" if a.serial else "synchronous steps") if not a.pipeline else "2-deep stream pipeline: stage 2 of step i overlaps stage 1 of step i+1",
                       "global_batch": B * world, "points": N, "parallelism": f"scan-sharded x{world}"},
            "mean_final_lm_error": float(allrows[:, 0].mean()), "scans_reported": int(allrows.shape[0]),
            "ms_per_step_synchronous": round(sync_ms, 3), "peak_hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2)}
@@ -231,8 +237,16 @@ def main():
         r, _ = model(pts, ["confidence", "direction", "magnitude"], "standard_vector")
         model_results.update(r)
 
+    # the instrumented pass runs the step on ONE stream (no heads / index ops on side streams): with kernels of several
+    # streams resident at once a HIP-event bracket measures contention, not the kernel (`bench.py --serial` runs the whole
+    # job in that schedule; profiles/*_serial_kernel_stats.txt is its rocprofv3 summary)
+    saved = (model.concurrent_heads, model.overlap_index_ops)
+    model.concurrent_heads, model.overlap_index_ops = False, False
     with torch.no_grad():
+        step()
+        torch.cuda.synchronize()
         agg = profile_pass(step)
+        model.concurrent_heads, model.overlap_index_ops = saved
         stage1_only()
     tot_ms = sum(d["ms"] for d in agg.values())
     # dominant kernel = the kernel FUNCTION with the largest share of the step (template instantiations of one kernel are

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Concurrency summary of a rocprofv3 kernel trace (rocpd sqlite): for the window spanned by the timed pipelined steps
-(between the first and last smpl_lm_fit_kernel of the longest run of evenly spaced fits) print, per HIP stream / HSA queue,
+(between the first and last smpl_lm_fit_kernel on the dedicated stage-2 stream) print, per HIP stream / HSA queue,
 the kernel-busy time, the union busy time of the device, and the largest idle gaps of the busiest queue.
 
     python profiles/timeline_rocpd.py gpurun_out/prof/NAME_results.db
@@ -28,18 +28,16 @@ def main(path):
     c = sqlite3.connect(path)
     rows = c.execute("select name, start, end, queue_id, stream_id from kernels order by start").fetchall()
     lm = [r for r in rows if r[0].startswith("smpl_lm_fit_kernel")]
-    # timed pipelined steps: the longest run of consecutive fits whose spacing stays within 25 % of the run's first spacing
-    best = (0, 0)
-    i = 0
-    while i + 1 < len(lm):
-        j, d0 = i + 1, lm[i + 1][1] - lm[i][1]
-        while j + 1 < len(lm) and abs((lm[j + 1][1] - lm[j][1]) - d0) < 0.25 * d0:
-            j += 1
-        if j - i > best[1] - best[0]:
-            best = (i, j)
-        i = j
-    t0, t1 = lm[best[0]][1], lm[best[1]][1]
-    nsteps = best[1] - best[0]
+    # pipelined steps: the fits that ran on the dedicated stage-2 stream (the stream that carries nothing but the fit, the final
+    # LBS and copies); fits of synchronous steps run on the stream that also carries the network
+    names = {}
+    for r in rows:
+        names.setdefault(r[4], set()).add(r[0].split("(")[0])
+    s2 = [sid for sid in {r[4] for r in lm} if len(names[sid]) <= 8]
+    if s2:
+        lm = [r for r in lm if r[4] == s2[0]]
+    t0, t1 = lm[0][1], lm[-1][1]
+    nsteps = len(lm) - 1
     win = [r for r in rows if r[1] >= t0 and r[2] <= t1]
     wall = t1 - t0
     print(f"# window: {nsteps} pipelined steps, {wall / 1e6:.2f} ms  ({wall / nsteps / 1e6:.2f} ms/step), {len(win)} kernels")
