@@ -166,6 +166,25 @@ def test_schedule_variants_are_bitwise_identical(tmp_path, B, N):
         model.concurrent_heads, model.overlap_index_ops = type(model).concurrent_heads, type(model).overlap_index_ops
 
 
+def test_pred_item_subsets_match_full_forward(tmp_path):
+    """forward(pred_items=...) with any subset of the heads (the reference's default is ["direction", "magnitude"],
+    models_pointcloud.py:146) returns exactly the entries of the full forward: no head depends on another having run."""
+    args, model = make(tmp_path)
+    pts = torch.from_numpy(np.stack([scan(500 + b, 1200) for b in range(2)])).cuda()
+    with torch.no_grad():
+        full, idx_full = model(pts, ["confidence", "direction", "magnitude"], "standard_vector")
+        for items in (["direction", "magnitude"], ["direction"], ["confidence"], ["magnitude"], ["magnitude", "confidence"]):
+            got, idx = model(pts, items, "standard_vector")
+            want = {"confidence": ("confidences", "part_labels"), "direction": ("direction",), "magnitude": ("magnitude",)}
+            keys = sorted(k for it in items for k in want[it])
+            assert sorted(got.keys()) == keys
+            for k in keys:
+                assert torch.equal(got[k], full[k]), (items, k)
+            assert torch.equal(idx, idx_full)
+        default, _ = model(pts)                       # reference default arguments
+        assert sorted(default.keys()) == ["direction", "magnitude"]
+
+
 def test_encoder_equivariance_property(tmp_path):
     """Oracle-free pin: rotating the scan by an icosahedral anchor R_g permutes the encoder features over
     anchors, feats'[..., a] = feats[..., a'] with R_a' = R_g^T R_a, and rotates `direction` by R_g wherever the so3_mean
