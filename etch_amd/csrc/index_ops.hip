@@ -161,6 +161,25 @@ __global__ void __launch_bounds__(256) gather_points_kernel(int c, int n, int m,
     }
 }
 
+// grad_points[b, ci, a] = sum over { j : idx[b, j] == a } of grad_out[b, ci, j], summed in ascending j.
+// The reference scatters with atomicAdd (gathering_cuda_kernel.cu:73-98), whose rounding depends on the arrival order when an
+// index repeats; this is the gather-side formulation of the same sum: one thread per destination point scans the index list,
+// so the result is reproducible (and equals the reference's exactly whenever the indices are unique, e.g. FPS output).
+__global__ void __launch_bounds__(256) gather_points_backward_kernel(int c, int n, int m, const float* __restrict__ grad_out,
+                                                                     const int* __restrict__ idx, float* __restrict__ grad_points) {
+    const int b = blockIdx.y;
+    const int* ib = idx + (size_t)b * m;
+    for (int a = blockIdx.x * 256 + threadIdx.x; a < n; a += gridDim.x * 256) {
+        for (int ci = 0; ci < c; ++ci) {
+            const float* g = grad_out + ((size_t)b * c + ci) * m;
+            float acc = 0.f;
+            for (int j = 0; j < m; ++j)
+                if (ib[j] == a) acc += g[j];
+            grad_points[((size_t)b * c + ci) * n + a] = acc;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ kNN
 // One thread per query, support points of the query's segment streamed through LDS tiles
 // (coalesced AoS loads -> SoA LDS, broadcast reads).  The k-slot max-heap of the reference is
@@ -378,6 +397,16 @@ int etch_gather_points(int b, int c, int n, int m, const float* points, const in
     int gx = (m + 255) / 256;
     if (gx > 8192) gx = 8192;
     hipLaunchKernelGGL(gather_points_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream, c, n, m, points, idx, out);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_gather_points_backward(int b, int c, int n, int m, const float* grad_out, const int* idx, float* grad_points, void* stream) {
+    if (b <= 0 || n <= 0 || c <= 0) return ETCH_OK;
+    if (m < 0) return ETCH_EINVAL;
+    int gx = (n + 255) / 256;
+    if (gx > 8192) gx = 8192;
+    hipLaunchKernelGGL(gather_points_backward_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream, c, n, m, grad_out, idx, grad_points);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }

@@ -62,6 +62,16 @@ def gather_points_forward(points, idx):
     return out
 
 
+def gather_points_backward(grad_out, idx, npoint):
+    """epn_gathering.gather_points_backward (gathering_cuda.cpp:45-60): (b,c,m),(b,m),n -> (b,c,n)."""
+    _need(grad_out, torch.float32, "grad_out"), _need(idx, torch.int32, "idx")
+    b, c, m = grad_out.shape
+    out = torch.empty((b, c, int(npoint)), dtype=torch.float32, device=grad_out.device)
+    _lib.check(_lib.lib().etch_gather_points_backward(b, c, int(npoint), m, _ptr(grad_out), _ptr(idx), _ptr(out), _stream()),
+               "etch_gather_points_backward")
+    return out
+
+
 # ------------------------------------------------------------------ pointops_cuda
 def _seg_max(offset_host):
     prev, mx = 0, 0

@@ -34,6 +34,11 @@ int etch_furthest_point_sampling(int b, int n, int m, const float* xyz, int* idx
  * points (b,c,n) f32, idx (b,m) i32 -> out (b,c,m) f32. */
 int etch_gather_points(int b, int c, int n, int m, const float* points, const int* idx, float* out, void* stream);
 
+/* Replaces epn_gathering.gather_points_backward: gathering_cuda.cpp:45-60 -> gathering_cuda_kernel.cu:73-98 (the
+ * first of the training-side ops): grad_out (b,c,m), idx (b,m) -> grad_points (b,c,n), every element written (no zero-fill needed);
+ * contributions of a repeated index are summed in ascending m order (the reference's atomicAdd order is unspecified). */
+int etch_gather_points_backward(int b, int c, int n, int m, const float* grad_out, const int* idx, float* grad_points, void* stream);
+
 /* ---- pointops_cuda (external/pointops/src) ------------------------------------------------------ */
 
 /* Replaces knnquery_cuda_launcher: knnquery/knnquery_cuda_kernel.h:10-16, kernel .cu:65-108.

@@ -162,6 +162,16 @@ void orc_gather_points(int b, int c, int n, int m, const float* points, const in
                 out[((size_t)bi * c + ci) * m + j] = points[((size_t)bi * c + ci) * n + idx[(size_t)bi * m + j]];
 }
 
+/* grad_out (b,c,m), idx (b,m) -> grad_points (b,c,n): external/vgtk/vgtk/cuda/gathering_cuda_kernel.cu:73-98 (atomicAdd scatter into a
+ * zeroed buffer, gathering_cuda.cpp:54-59); sequential here, i.e. repeated indices are summed in ascending m order */
+void orc_gather_points_backward(int b, int c, int n, int m, const float* grad_out, const int32_t* idx, float* grad_points) {
+    for (size_t e = 0; e < (size_t)b * c * n; ++e) grad_points[e] = 0.f;
+    for (int bi = 0; bi < b; ++bi)
+        for (int ci = 0; ci < c; ++ci)
+            for (int j = 0; j < m; ++j)
+                grad_points[((size_t)bi * c + ci) * n + idx[(size_t)bi * m + j]] += grad_out[((size_t)bi * c + ci) * m + j];
+}
+
 /* ---- pointops kNN: literal max-heap ---- */
 static void reheap(float* dist, int* idx, int k) {
     int root = 0, child = 1;

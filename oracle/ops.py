@@ -77,6 +77,15 @@ def gather_points_forward(points, idx):
     return out
 
 
+def gather_points_backward(grad_out, idx, npoint):
+    """grad_out (b,c,m), idx (b,m) -> grad_points (b,c,n)."""
+    grad_out, idx = _f32(grad_out), _i32(idx)
+    b, c, m = grad_out.shape
+    out = np.empty((b, c, int(npoint)), np.float32)
+    lib().orc_gather_points_backward(b, c, int(npoint), m, _p(grad_out), _p(idx), _p(out))
+    return out
+
+
 def knnquery(nsample, xyz, new_xyz, offset, new_offset):
     """xyz (n,3), new_xyz (m,3), offsets (b) -> idx (m,nsample) int32, dist2 (m,nsample) (SQUARED)."""
     assert nsample <= 100

@@ -131,3 +131,25 @@ def test_pybind_module_mirrors():
     out = torch.zeros(125, dtype=torch.int32).cuda()
     pointops_cuda.furthestsampling_cuda(2, 300, p, o, no, torch.empty(500).cuda(), out)
     assert np.array_equal(out.cpu().numpy(), O.furthestsampling(p.cpu().numpy(), o.cpu().numpy(), no.cpu().numpy()))
+
+
+@pytest.mark.parametrize("b,c,n,m,dup", [(3, 3, 5000, 2500, False), (2, 3, 700, 900, True), (1, 17, 129, 64, True), (2, 3, 50, 0, False)])
+def test_gather_points_backward_bit_exact(b, c, n, m, dup):
+    """epn_gathering.gather_points_backward vs the C oracle (ascending-index summation order on both sides) and vs torch autograd
+    of the forward gather."""
+    from etch_amd import epn_gathering
+    from oracle import ops as O
+    rng = np.random.default_rng(b * 100 + c + n)
+    if dup:
+        idx = rng.integers(0, n, size=(b, m)).astype(np.int32)
+    else:
+        idx = np.stack([rng.permutation(n)[:m] for _ in range(b)]).astype(np.int32).reshape(b, m)
+    g = rng.standard_normal((b, c, m)).astype(np.float32)
+    got = epn_gathering.gather_points_backward(torch.from_numpy(g).cuda(), torch.from_numpy(idx).cuda(), n)
+    want = O.gather_points_backward(g, idx, n)
+    assert got.shape == (b, c, n)
+    assert np.array_equal(got.cpu().numpy(), want)
+    if m:
+        x = torch.zeros(b, c, n, dtype=torch.float64, requires_grad=True)
+        torch.gather(x, 2, torch.from_numpy(idx).long()[:, None, :].expand(b, c, m)).backward(torch.from_numpy(g).double())
+        assert np.abs(got.cpu().numpy() - x.grad.numpy()).max() < 1e-5

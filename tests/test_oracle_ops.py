@@ -131,3 +131,24 @@ def test_fps_pointops_segments():
     assert O.furthestsampling(p, o, no).tolist() == [0, 3, 4, 6]
     no = np.array([3, 6], np.int32)
     assert O.furthestsampling(p, o, no).tolist() == [0, 3, 1, 4, 6, 5]
+
+
+def test_gather_points_backward_known_answer():
+    """gathering_cuda_kernel.cu:73-98: scatter-add of grad_out along idx; repeated indices accumulate; untouched points get 0."""
+    from oracle import ops as O
+    g = np.arange(1, 1 + 2 * 2 * 4, dtype=np.float32).reshape(2, 2, 4)          # (b=2, c=2, m=4)
+    idx = np.array([[0, 2, 2, 5], [1, 1, 1, 0]], np.int32)
+    out = O.gather_points_backward(g, idx, 6)
+    want = np.zeros((2, 2, 6), np.float32)
+    for b in range(2):
+        for c in range(2):
+            for j in range(4):
+                want[b, c, idx[b, j]] += g[b, c, j]
+    assert np.array_equal(out, want)
+    assert out[0, 0].tolist() == [1.0, 0.0, 5.0, 0.0, 0.0, 4.0]
+    # adjoint of the forward gather: <gather(x), g> == <x, gather_backward(g)>
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 2, 6)).astype(np.float32)
+    lhs = float((O.gather_points_forward(x, idx).astype(np.float64) * g).sum())
+    rhs = float((x.astype(np.float64) * out).sum())
+    assert abs(lhs - rhs) < 1e-4 * abs(lhs)
