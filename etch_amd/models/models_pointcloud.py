@@ -144,6 +144,7 @@ class GT_network_equiv(nn.Module):
         side = self._side_stream
         side.wait_stream(self.input_producer if self.input_producer is not None else main)
         made = []
+        hitpts.record_stream(side)
         with torch.cuda.stream(side):
             cur = input_xyz(hitpts)
             made.append(cur)

@@ -1,5 +1,6 @@
 """Throughput pipeline of the hot path: stage 1 (equivariant net) of batch i+1 overlaps stage 2 (marker fit, 32 persistent
-workgroups = 1/8 of the chip) of batch i on a second HIP stream.  Results are identical to the synchronous
+workgroups = 1/8 of the chip) of batch i on a second HIP stream, and the coordinate-only index ops of batch i+1 (the model's
+index stream) start as soon as its points are resident.  Results are identical to the synchronous
 `inference_demo.predict_smpl_batch`; only the schedule differs.  Scans are independent, so no state is shared between
 in-flight batches besides the (read-only) weights and body-model tables."""
 import torch
@@ -30,6 +31,7 @@ class HotPathPipeline:
         caller = torch.cuda.current_stream()
         s1 = self.s1s[self._n % len(self.s1s)]
         s1.wait_stream(caller)
+        points.record_stream(s1)        # the caller may drop `points` right after submit(): keep its memory until s1 is done with it
         with torch.no_grad():
             with torch.cuda.stream(s1):
                 # the model's index stream waits for the producer of `points` (the caller's stream), not for s1's queue
