@@ -413,3 +413,168 @@ int etch_softmax_dot(long R, int G, const float* logits, const float* v, float* 
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// PointTransformerLayer attention core (pointtransformer_seg.py:28-36) as ONE kernel on the matrix cores:
+//   w_in[j]  = relu(bn(x_k[idx_j] - x_q[i] + p_r[j]))                 (ns x c, built in registers from the gathered rows)
+//   hid^T    = relu(bn(W2 . w_in^T + b2))                             (cs x ns, cs = c/8)   MFMA, A = W2 rows, B = w_in rows
+//   logit^T  = W5 . hid^T + b5                                        (cs x ns)             MFMA, B = the accumulators of hid^T
+//   out[i,ch] = sum_j softmax_j(logit[j, ch % cs]) * (x_v[idx_j, ch] + p_r[j, ch])   (+ optional bn + relu)
+// One wave = 16 (point, neighbour) rows = 16/ns points; lane (fg, fr): row fr, channel quad 4fg.  Computing the first product
+// transposed makes its accumulators (row = hidden unit 4fg + r, column = neighbour fr) the B operand of the second one, and
+// leaves every logit of a point's neighbours in one 16-lane DPP row: softmax and the neighbour sum are DPP row reductions.
+// The n*ns x c / n*ns x cs intermediates of the split path (prep -> 2 GEMMs -> aggregate) never exist.
+// ------------------------------------------------------------------------------------------------
+typedef float pf32x4 __attribute__((ext_vector_type(4)));
+
+template <int CTRL>
+__device__ __forceinline__ float pt_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int NS>
+__device__ __forceinline__ float pt_group_sum(float v) {        // sum over the NS (8 or 16) lanes of a neighbour group
+    v += pt_dpp<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += pt_dpp<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += pt_dpp<0x141>(v);         // row_half_mirror
+    if (NS == 16) v += pt_dpp<0x140>(v);   // row_mirror
+    return v;
+}
+template <int NS>
+__device__ __forceinline__ float pt_group_max(float v) {
+    v = fmaxf(v, pt_dpp<0xB1>(v));
+    v = fmaxf(v, pt_dpp<0x4E>(v));
+    v = fmaxf(v, pt_dpp<0x141>(v));
+    if (NS == 16) v = fmaxf(v, pt_dpp<0x140>(v));
+    return v;
+}
+
+template <int C, int NS>
+__global__ void __launch_bounds__(256) pt_attention_mfma_kernel(PtAttnParams a, const float* __restrict__ W2) {
+    constexpr int CS = C / 8;                      // hidden width of linear_w
+    constexpr int MT = CS <= 16 ? 1 : CS / 16;     // 16-row tiles of the transposed products
+    constexpr int KT = C / 16;
+    constexpr int PPW = 16 / NS;                   // points per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int pw = fr / NS, jn = fr % NS;
+    const long base = ((long)blockIdx.x * 4 + wave) * PPW;
+    const bool valid = base + pw < a.n;
+    const int i = valid ? (int)(base + pw) : a.n - 1;
+    const int j = a.idx[(size_t)i * NS + jn];
+    float h[3];
+    pt_rel_hidden(a, i, j, h);
+    const float* kr = a.xk + (size_t)j * a.ldq;
+    const float* qr = a.xq + (size_t)i * a.ldq;
+    const float* vr = a.xv + (size_t)j * a.ldq;
+
+    // ---- hid^T = W2 . w_in^T
+    pf32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (pf32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int t = 0; t < KT; ++t) {
+        const int ch0 = t * 16 + fg * 4;
+        const float4 k4 = *reinterpret_cast<const float4*>(kr + ch0), q4 = *reinterpret_cast<const float4*>(qr + ch0);
+        const float4 wa = *reinterpret_cast<const float4*>(a.W3 + ch0 * 3), wb = *reinterpret_cast<const float4*>(a.W3 + ch0 * 3 + 4),
+                     wc = *reinterpret_cast<const float4*>(a.W3 + ch0 * 3 + 8);
+        const float4 b3 = *reinterpret_cast<const float4*>(a.b3 + ch0), sc = *reinterpret_cast<const float4*>(a.s_w0 + ch0),
+                     sh = *reinterpret_cast<const float4*>(a.t_w0 + ch0);
+        float w[4];
+        w[0] = fmaxf((k4.x - q4.x + (wa.x * h[0] + wa.y * h[1] + wa.z * h[2] + b3.x)) * sc.x + sh.x, 0.f);
+        w[1] = fmaxf((k4.y - q4.y + (wa.w * h[0] + wb.x * h[1] + wb.y * h[2] + b3.y)) * sc.y + sh.y, 0.f);
+        w[2] = fmaxf((k4.z - q4.z + (wb.z * h[0] + wb.w * h[1] + wc.x * h[2] + b3.z)) * sc.z + sh.z, 0.f);
+        w[3] = fmaxf((k4.w - q4.w + (wc.y * h[0] + wc.z * h[1] + wc.w * h[2] + b3.w)) * sc.w + sh.w, 0.f);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = mt * 16 + fr;                       // hidden unit
+            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < CS) f = *reinterpret_cast<const float4*>(W2 + (size_t)row * C + ch0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.x, w[0], acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.y, w[1], acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.z, w[2], acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w, w[3], acc[mt], 0, 0, 0);
+        }
+    }
+    // bias + BN + ReLU of linear_w[2..4]; acc[mt][r] = hid[neighbour fr][unit 16mt + 4fg + r]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int u = mt * 16 + fg * 4 + r;
+            float v = 0.f;
+            if (u < CS) v = fmaxf((acc[mt][r] + a.b2[u]) * a.s_w3[u] + a.t_w3[u], 0.f);
+            acc[mt][r] = v;
+        }
+    // ---- logit^T = W5 . hid^T + b5, then softmax over the point's neighbours (one DPP row / half row)
+    pf32x4 sm[MT];
+#pragma unroll
+    for (int mo = 0; mo < MT; ++mo) {
+        pf32x4 lg = {0.f, 0.f, 0.f, 0.f};
+        const int row = mo * 16 + fr;
+#pragma unroll
+        for (int mu = 0; mu < MT; ++mu) {
+            const int u0 = mu * 16 + fg * 4;
+            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < CS && u0 < CS) f = *reinterpret_cast<const float4*>(a.W5 + (size_t)row * CS + u0);
+            lg = __builtin_amdgcn_mfma_f32_16x16x4f32(f.x, acc[mu][0], lg, 0, 0, 0);
+            lg = __builtin_amdgcn_mfma_f32_16x16x4f32(f.y, acc[mu][1], lg, 0, 0, 0);
+            lg = __builtin_amdgcn_mfma_f32_16x16x4f32(f.z, acc[mu][2], lg, 0, 0, 0);
+            lg = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w, acc[mu][3], lg, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tt = mo * 16 + fg * 4 + r;
+            const float l = lg[r] + (tt < CS ? a.b5[tt] : 0.f);
+            const float m = pt_group_max<NS>(l);
+            const float e = __expf(l - m);
+            sm[mo][r] = e / pt_group_sum<NS>(e);
+        }
+    }
+    // ---- aggregation: channel ch uses the softmax of hidden unit ch % CS; this lane owns units 16mo + 4fg + r
+    float* orow = a.out + (size_t)i * a.ldo;
+#pragma unroll
+    for (int mo = 0; mo < MT; ++mo) {
+        if (mo * 16 + fg * 4 < CS) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int ch0 = m * CS + mo * 16 + fg * 4;
+                const float4 v4 = *reinterpret_cast<const float4*>(vr + ch0);
+                const float4 wa = *reinterpret_cast<const float4*>(a.W3 + ch0 * 3), wb = *reinterpret_cast<const float4*>(a.W3 + ch0 * 3 + 4),
+                             wc = *reinterpret_cast<const float4*>(a.W3 + ch0 * 3 + 8);
+                const float4 b3 = *reinterpret_cast<const float4*>(a.b3 + ch0);
+                float o0 = (v4.x + (wa.x * h[0] + wa.y * h[1] + wa.z * h[2] + b3.x)) * sm[mo][0];
+                float o1 = (v4.y + (wa.w * h[0] + wb.x * h[1] + wb.y * h[2] + b3.y)) * sm[mo][1];
+                float o2 = (v4.z + (wb.z * h[0] + wb.w * h[1] + wc.x * h[2] + b3.z)) * sm[mo][2];
+                float o3 = (v4.w + (wc.y * h[0] + wc.z * h[1] + wc.w * h[2] + b3.w)) * sm[mo][3];
+                o0 = pt_group_sum<NS>(o0); o1 = pt_group_sum<NS>(o1); o2 = pt_group_sum<NS>(o2); o3 = pt_group_sum<NS>(o3);
+                if (jn == 0 && valid) {
+                    if (a.s_out) {
+                        const float4 so = *reinterpret_cast<const float4*>(a.s_out + ch0), to = *reinterpret_cast<const float4*>(a.t_out + ch0);
+                        o0 = fmaxf(o0 * so.x + to.x, 0.f); o1 = fmaxf(o1 * so.y + to.y, 0.f);
+                        o2 = fmaxf(o2 * so.z + to.z, 0.f); o3 = fmaxf(o3 * so.w + to.w, 0.f);
+                    }
+                    *reinterpret_cast<float4*>(orow + ch0) = make_float4(o0, o1, o2, o3);
+                }
+            }
+        }
+    }
+}
+
+extern "C" int etch_pt_attention_mfma(int n, int c, int ns, const float* p, const float* xq, const float* xk, const float* xv, long ldq,
+                                      const int* idx, const float* const* params, const float* W2, float* out, long ldo, void* stream) {
+    if (n <= 0) return ETCH_OK;
+    if ((ldq & 3) || (ldo & 3) || !W2) return ETCH_EINVAL;
+    PtAttnParams a;
+    fill_pt_params(a, n, c, ns, p, xq, xk, xv, ldq, idx, params, out, ldo);
+    hipStream_t st = (hipStream_t)stream;
+#define PT_MFMA_CASE(C_, NS_)                                                                                              \
+    if (c == C_ && ns == NS_) {                                                                                            \
+        const int ppw = 16 / NS_;                                                                                          \
+        hipLaunchKernelGGL((pt_attention_mfma_kernel<C_, NS_>), dim3((n + 4 * ppw - 1) / (4 * ppw)), dim3(256), 0, st, a, W2); \
+        ETCH_RETURN_IF_LAUNCH_FAILED();                                                                                    \
+        return ETCH_OK;                                                                                                    \
+    }
+    PT_MFMA_CASE(64, 8) PT_MFMA_CASE(128, 8) PT_MFMA_CASE(64, 16) PT_MFMA_CASE(128, 16) PT_MFMA_CASE(256, 16) PT_MFMA_CASE(512, 16)
+#undef PT_MFMA_CASE
+    return ETCH_EUNSUPPORTED;
+}

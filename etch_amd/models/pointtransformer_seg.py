@@ -56,11 +56,15 @@ class PointTransformerLayer(nn.Module):
         qkv = ops.linear(x, wqkv, bias=bqkv)
         idx = pointops.knnquery(self.nsample, p, p, o, o)[0]
         allp = params + list(out_bn if out_bn is not None else (None, None))
-        if self.fused_kernel:
+        if self.attention_impl == "valu":
             return ops.pt_attention(p, qkv, self.out_planes, idx, allp, self.nsample)
+        if self.attention_impl == "mfma" and (self.out_planes, self.nsample) in ops.PT_MFMA_SHAPES:
+            return ops.pt_attention_mfma(p, qkv, self.out_planes, idx, allp, self.nsample, mlp[0])
         return ops.pt_attention_split(p, qkv, self.out_planes, idx, allp, self.nsample, *mlp)
 
-    fused_kernel = False   # True: the single-kernel VALU variant (etch_pt_attention); False: attention MLP on the matrix cores
+    # "mfma": the whole attention core in one matrix-core kernel (etch_pt_attention_mfma); "split": prep kernel -> 2 x etch_linear ->
+    # aggregate kernel (also the path of shapes the fused kernel is not instantiated for); "valu": the single-kernel VALU variant
+    attention_impl = "mfma"
 
 
 class TransitionDown(nn.Module):

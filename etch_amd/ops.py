@@ -272,6 +272,21 @@ def pt_attention(p, qkv, c, idx, params, ns):
     return out
 
 
+PT_MFMA_SHAPES = {(64, 8), (128, 8), (64, 16), (128, 16), (256, 16), (512, 16)}     # (c, nsample) instantiated in pt.hip
+
+
+def pt_attention_mfma(p, qkv, c, idx, params, ns, w2):
+    """Same result as pt_attention: gather, linear_w MLP (matrix cores), neighbour softmax and aggregation in one kernel."""
+    n = p.shape[0]
+    _need(w2, torch.float32, "w2")
+    out = torch.empty((n, c), dtype=torch.float32, device=p.device)
+    arr = (ctypes.c_void_p * 16)(*[(0 if t is None else t.data_ptr()) for t in params])
+    base = qkv.data_ptr()
+    _lib.check(_lib.lib().etch_pt_attention_mfma(n, c, ns, _ptr(p), _vp(base), _vp(base + 4 * c), _vp(base + 8 * c), _c_long(qkv.stride(0)),
+                                                 _ptr(idx), arr, _ptr(w2), _ptr(out), _c_long(c), _stream()), "etch_pt_attention_mfma")
+    return out
+
+
 def pt_attention_split(p, qkv, c, idx, params, ns, w2, b2, s3, t3, w5, b5):
     """Same result as pt_attention with the two Linear layers of linear_w on the matrix cores (etch_linear)."""
     n = p.shape[0]

@@ -150,6 +150,13 @@ int etch_pt_attn_prep(int n, int c, int ns, const float* p, const float* xq, con
 int etch_pt_attn_aggregate(int n, int c, int ns, const float* p, const float* xv, long ldq, const int* idx, const float* logits,
                            const float* const* params, float* out, long ldo, void* stream);
 
+/* The same attention core in one matrix-core kernel: the c -> c/8 -> c/8 MLP of linear_w runs as two chained MFMA products on
+ * w_in rows built in registers from the gathered k rows; softmax over the neighbours and the aggregation of (v + p_r) follow in
+ * the same wave.  W2 = linear_w[2].weight (c/8, c) row-major (params[8] holds its transpose for the other variants).
+ * (c, ns) in {(64,8), (128,8), (64,16), (128,16), (256,16), (512,16)}, otherwise ETCH_EUNSUPPORTED (-2). */
+int etch_pt_attention_mfma(int n, int c, int ns, const float* p, const float* xq, const float* xk, const float* xv, long ldq,
+                           const int* idx, const float* const* params, const float* W2, float* out, long ldo, void* stream);
+
 /* queryandgroup(use_xyz=True) rows for TransitionDown (pointtransformer_seg.py:61, pointops.py:90-98):
  * out[(i*ns+j)] = [p[idx[i,j]] - new_p[i] | x[idx[i,j]] | 0...], row stride ldo >= 3+c (padding columns zeroed). */
 int etch_pt_group(int m, int ns, int c, const float* p, const float* new_p, const float* x, long ldx, const int* idx,

@@ -105,8 +105,33 @@ def test_pt_layer_fused_and_split_variants_agree(golden):
     seeds = json.loads(str(g["seeds"]))
     d = lambda k: torch.from_numpy(g[k]).cuda()
     layer = load_seeded(P.PointTransformerLayer(32, 32, 8, 8), seeds["layer"]).cuda().eval()
-    layer.fused_kernel = True
+    layer.attention_impl = "valu"
     a = layer([d("p"), d("x"), d("o")]).cpu().numpy()
-    layer.fused_kernel = False
+    layer.attention_impl = "split"
     b = layer([d("p"), d("x"), d("o")]).cpu().numpy()
     assert rel_err(a, g["layer_out"]) < RTOL and rel_err(b, g["layer_out"]) < RTOL
+
+
+@pytest.mark.parametrize("c,ns,n", [(64, 8, 1003), (128, 8, 517), (64, 16, 300), (128, 16, 1001), (256, 16, 333), (512, 16, 97)])
+def test_pt_attention_mfma_kernel_matches_split_and_valu(c, ns, n):
+    """etch_pt_attention_mfma (the whole attention core on the matrix cores in one kernel) against the two older variants, which the
+    reference golden pins at c = 32: every instantiated (c, nsample), point counts that leave partial waves / workgroups, two
+    segments, with and without the fused output BatchNorm + ReLU."""
+    from etch_amd.models import pointtransformer_seg as P
+    from etch_amd.models import pointops
+    from etch_amd import ops
+    layer = load_seeded(P.PointTransformerLayer(c, c, 8, ns), 11).cuda().eval()
+    g = torch.Generator().manual_seed(c + ns + n)
+    pnt = (torch.randn(n, 3, generator=g) * 0.3).cuda()
+    x = torch.randn(n, c, generator=g).cuda()
+    o = pointops.offsets_tensor([n // 2, n], "cuda")
+    bn = (torch.rand(c, generator=g) + 0.5).cuda(), torch.randn(c, generator=g).cuda() * 0.1
+    assert (c, ns) in ops.PT_MFMA_SHAPES
+    for out_bn in (None, bn):
+        outs = {}
+        for impl in ("mfma", "split", "valu"):
+            layer.attention_impl = impl
+            with torch.no_grad():
+                outs[impl] = layer([pnt, x, o], out_bn=out_bn).cpu().numpy()
+        assert outs["mfma"].shape == (n, c) and np.isfinite(outs["mfma"]).all()
+        assert rel_err(outs["mfma"], outs["split"]) < 5e-6 and rel_err(outs["mfma"], outs["valu"]) < 5e-6
