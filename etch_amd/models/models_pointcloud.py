@@ -160,9 +160,18 @@ class GT_network_equiv(nn.Module):
                 made += prefetch_indices(hitpts.view(-1, 3), o)
             done = torch.cuda.Event()
             done.record(side)
+        users = [main] + (list(self._heads_streams()) if self.concurrent_heads else [])
         for t in made:
-            t.record_stream(main)
+            for st in users:
+                t.record_stream(st)
         return epn_ready, done
+
+    def _heads_streams(self):
+        if not hasattr(self, "_head_streams"):
+            # the nets are long chains of small kernels (the critical path of this phase), the direction head on the current
+            # stream is a few chip-wide kernels: high-priority queues let the chains go first whenever they have work
+            self._head_streams = (torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=-1))
+        return self._head_streams
 
     def _forward(self, hitpts, pred_items, direction_mode, B, N):
         idx_ready = None
@@ -183,6 +192,8 @@ class GT_network_equiv(nn.Module):
         return results, selected_indexs
 
     concurrent_heads = True    # run the confidence and magnitude nets on their own HIP streams next to the direction head
+    defer_join = False         # True (set by a pipelined caller around forward): leave `pending_join` events instead of joining
+    pending_join = None
 
     def _heads(self, results, pred_items, direction_mode, hitpts, point_inv_feat, point_equiv_cl, so3_anchors, B, N, indices_prefetched=False):
         # The three heads are independent given the encoder output.  With `concurrent_heads` the two Point-Transformer nets
@@ -192,12 +203,10 @@ class GT_network_equiv(nn.Module):
         fork = self.concurrent_heads and indices_prefetched and hitpts.is_cuda
         main = torch.cuda.current_stream() if hitpts.is_cuda else None
         if fork:
-            if not hasattr(self, "_head_streams"):
-                # the nets are long chains of small kernels (the critical path of this phase), the direction head on the current
-                # stream is a few chip-wide kernels: high-priority queues let the chains go first whenever they have work
-                self._head_streams = (torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=-1))
-            for st in self._head_streams:
+            for st in self._heads_streams():
                 st.wait_stream(main)
+                for t in (point_inv_feat, hitpts):      # read by the branch after this function returned (deferred join)
+                    t.record_stream(st)
 
         def branch(k, fn):
             if not fork:
@@ -219,6 +228,16 @@ class GT_network_equiv(nn.Module):
                 raise AssertionError("Not implemented")   # same as the reference (:199,210)
             standard_vector = self.standard_vector.repeat(B, N, 1)
             results["direction"] = self.decode_direction(None, so3_anchors, standard_vector, tokens_cl=point_equiv_cl)
+        self.pending_join = None
         if fork:
-            for st in self._head_streams:
-                main.wait_stream(st)
+            if self.defer_join:
+                # a pipelined caller joins on ITS stage-2 stream: the current stream goes on to the next batch's encoder while the
+                # tail of the confidence net (its 128 -> 11 008 -> 86 head, a chip-wide kernel) is still running
+                self.pending_join = []
+                for st in self._head_streams:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    self.pending_join.append(ev)
+            else:
+                for st in self._head_streams:
+                    main.wait_stream(st)

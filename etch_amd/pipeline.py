@@ -36,17 +36,24 @@ class HotPathPipeline:
             with torch.cuda.stream(s1):
                 # the model's index stream waits for the producer of `points` (the caller's stream), not for s1's queue
                 self.model.input_producer = caller
-                results, _ = self.model(points, pred_items=["confidence", "direction", "magnitude"], direction_mode="standard_vector")
-                self.model.input_producer = None
-                labels = ops.argmax_rows(results["part_labels"])
-                inner = ops.inner_points(points.contiguous(), results["direction"], results["magnitude"], float(self.args.scale_magnitude))
+                self.model.defer_join = True          # the heads on side streams are joined on s2 below, not on s1
+                try:
+                    results, _ = self.model(points, pred_items=["confidence", "direction", "magnitude"], direction_mode="standard_vector")
+                finally:
+                    self.model.input_producer, self.model.defer_join = None, False
+                joins = self.model.pending_join or []
+                self.model.pending_join = None
                 ready = torch.cuda.Event()
                 ready.record(s1)
             conf = results["confidences"]
-            for t in (inner, labels, conf):
+            for t in (points, conf, results["part_labels"], results["direction"], results["magnitude"]):
                 t.record_stream(self.s2)
             with torch.cuda.stream(self.s2):
                 self.s2.wait_event(ready)
+                for ev in joins:
+                    self.s2.wait_event(ev)
+                labels = ops.argmax_rows(results["part_labels"])
+                inner = ops.inner_points(points.contiguous(), results["direction"], results["magnitude"], float(self.args.scale_magnitude))
                 fit = fit_smpl_device(self.args, inner, labels, conf, self.gender, **self.fit_kwargs)
                 # device -> host copies ride on s2 right behind this batch's fit (pinned, reused buffers): result() must
                 # not enqueue anything on s2, where it would queue behind the NEXT batch's fit

@@ -148,19 +148,26 @@ def test_eval_harness_gender_groups_and_metrics(tmp_path):
     assert E.mpjpe(np.zeros((45, 3)), np.ones((45, 3))) == pytest.approx(np.sqrt(3))
 
 
-def test_stream_pipeline_matches_synchronous_path(tmp_path):
+@pytest.mark.parametrize("nb,B,N", [(3, 2, 640), (5, 8, 5000)])
+def test_stream_pipeline_matches_synchronous_path(tmp_path, nb, B, N):
+    """Two batches in flight, heads joined on the stage-2 stream, index ops of the next batch running early: same bits as one
+    batch at a time (the larger case keeps every stream busy long enough for a lifetime / ordering bug to bite; batches are
+    dropped by the caller right after submit)."""
     from etch_amd.inference_demo import predict_smpl_batch
     from etch_amd.pipeline import HotPathPipeline
     args, model = make(tmp_path)
-    batches = [torch.from_numpy(np.stack([scan(200 + 10 * k + b, 640) for b in range(2)])).cuda() for k in range(3)]
-    ref = [predict_smpl_batch(args, model, b, "neutral") for b in batches]
+    mk = lambda k: torch.from_numpy(np.stack([scan(200 + 10 * k + b, N) for b in range(B)])).cuda()
+    ref = [predict_smpl_batch(args, model, mk(k), "neutral") for k in range(nb)]
     pipe = HotPathPipeline(args, model, "neutral", max_in_flight=2)
-    got = list(pipe.run(batches))
+    got = list(pipe.run(mk(k) for k in range(nb)))
+    # NaN-aware: with seeded random weights some confidences are ~0.005, conf**20 underflows to 0 and the weighted marker centre is
+    # 0/0 -- in the reference as well (fit_SMPL.py:52-57); NaN markers must then be NaN in both schedules
+    same = lambda a, b: np.array_equal(np.asarray(a.cpu() if torch.is_tensor(a) else a), np.asarray(b.cpu() if torch.is_tensor(b) else b), equal_nan=True)
     for (m0, mk0, v0, i0), (m1, mk1, v1, i1) in zip(ref, got):
-        assert torch.equal(mk0, mk1) and torch.equal(v0, v1)
+        assert same(mk0, mk1) and same(v0, v1)
         for a, b in zip(i0, i1):
-            assert np.array_equal(a, b)
-        assert np.array_equal(m0[0].vertices, m1[0].vertices)
+            assert same(a, b)
+        assert same(m0[0].vertices, m1[0].vertices)
 
 
 @pytest.mark.parametrize("B,N", [(2, 1500), (8, 5000)])
