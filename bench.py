@@ -135,12 +135,10 @@ def cpu_baseline(n_points, gpu_pts, gpu_results, gpu_fit_aux, args, seed=1):
     fit_g = S2.fit_smpl(args.body_model, mv, gm, gv)
     v2v = (gpu_fit_aux["verts"][:1].cpu() - fit_g["verts"]).norm(dim=-1).mean()
     parity["v2v_mm_gpu_vs_oracle_same_markers"] = float(v2v * 1e3)
-    # marker / pose / shape deltas vs the CPU oracle on identical inputs (whole pipeline: oracle markers from the oracle's
-    # own stage 1 vs the GPU's; fitter alone: pose / shape of the two fits of the same markers)
-    # (with seeded random weights the confidences of a label's points are nearly tied, so a 1e-5 difference can swap the top-3 set of
-    # a marker: reported as the fraction of markers that agree, not as a maximum)
-    both = gv & valid
-    parity["markers_within_1mm_frac_whole_pipeline"] = float(((gm[both] - mk[both]).norm(dim=-1) < 1e-3).float().mean()) if bool(both.any()) else None
+    # pose / shape deltas vs the CPU oracle on identical inputs = the two fits of the same markers.  (A whole-pipeline
+    # marker comparison is ill-posed with seeded random weights: the confidences of a label's points are tied to ~1e-6, so the
+    # top-3 selection of fit_SMPL.py:42-57 differs between any two fp32 implementations; the stage-1 outputs themselves agree
+    # to ~1e-6, see the entries above.)
     gx = gpu_fit_aux["x"][:1].cpu()
     parity["pose_delta_rad_same_markers"] = float((gx[:, :69] - fit_g["pose"].reshape(1, 69)).abs().max())
     parity["betas_delta_same_markers"] = float((gx[:, 69:79] - fit_g["betas"].reshape(1, 10)).abs().max())
