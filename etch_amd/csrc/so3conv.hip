@@ -29,7 +29,7 @@ template <int CIN, int COUT, int MAXT>     // MAXT = ceil(nn / 16) neighbour chu
 __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
     int p1, int p2, int nn, float inv_sigma, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
     const int* __restrict__ ball_idx, const float* __restrict__ feats, const float* __restrict__ rk,
-    const float* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ out) {
+    const float* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ out, const int* __restrict__ order) {
     constexpr int MT1 = CIN / 16;          // c tiles in step 1
     constexpr int MT2 = COUT / 16;         // o tiles in step 2
     constexpr int KK = CIN * KS;           // contraction length of step 2
@@ -45,7 +45,17 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
     float* part = smem + 16 * S;           // [4 waves][16 cols][PS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int b = blockIdx.y, p = blockIdx.x;
+    const int b = blockIdx.y;
+    int p = blockIdx.x;
+    if (order) {
+        // spatially ordered schedule: `order` lists the output points of a scan along a space-filling curve.  Workgroup ids go
+        // round-robin over the 8 XCDs (grid.x is a multiple of 8), so XCD x gets the x-th contiguous eighth of the curve: the
+        // workgroups that share an L2 at any moment are spatial neighbours and gather from the same source rows.
+        const int per = gridDim.x >> 3;
+        const int slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (slot >= p2) return;
+        p = order[(size_t)b * p2 + slot];
+    }
     const int nchunk = (nn + 15) >> 4;
 
     // per-lane neighbour data for n = 16t + 4fg + s
@@ -479,24 +489,27 @@ __global__ void __launch_bounds__(256) instnorm_act_add_kernel(long n4, int rows
 // ------------------------------------------------------------------------------------------------ C ABI
 template <int CIN, int COUT, int MAXT>
 static int launch_inter_t(int b, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz, const int* idx,
-                          const float* feats, const float* rk, const float* Wp, const float* bias, float* out, hipStream_t st) {
+                          const float* feats, const float* rk, const float* Wp, const float* bias, float* out, const int* order,
+                          hipStream_t st) {
     const size_t lds = (size_t)(16 * (CIN * KS / (CIN >= 32 ? 2 : 1) + 40) + 4 * 16 * (COUT + 4)) * sizeof(float);
     auto kern = inter_so3conv_kernel<CIN, COUT, MAXT>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(p2, b), dim3(256), lds, st, p1, p2, nn, 1.0f / sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out);
+    const unsigned gx = order ? 8u * (unsigned)((p2 + 7) / 8) : (unsigned)p2;
+    hipLaunchKernelGGL(kern, dim3(gx, b), dim3(256), lds, st, p1, p2, nn, 1.0f / sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, order);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }
 
 template <int CIN, int COUT>
 static int launch_inter(int b, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz, const int* idx,
-                        const float* feats, const float* rk, const float* Wp, const float* bias, float* out, hipStream_t st) {
-    if (nn <= 16) return launch_inter_t<CIN, COUT, 1>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, st);
-    if (nn <= 32) return launch_inter_t<CIN, COUT, 2>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, st);
-    return launch_inter_t<CIN, COUT, 4>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, st);
+                        const float* feats, const float* rk, const float* Wp, const float* bias, float* out, const int* order,
+                        hipStream_t st) {
+    if (nn <= 16) return launch_inter_t<CIN, COUT, 1>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, order, st);
+    if (nn <= 32) return launch_inter_t<CIN, COUT, 2>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, order, st);
+    return launch_inter_t<CIN, COUT, 4>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, order, st);
 }
 
 template <int C, int COUT>
@@ -513,14 +526,24 @@ extern "C" {
 
 // W layouts: `W` = reference layout [cout][cin*24] (index c*24+k); `Wp` = fragment order produced by
 // etch_permute_weight_frag (only the MFMA path, cin % 16 == 0, reads it).
+int etch_inter_so3conv_ordered(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
+                               const int* ball_idx, const float* feats, const float* rk, const float* W, const float* Wp,
+                               const float* bias, float* out, const int* order, void* stream);
+
 int etch_inter_so3conv(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
                        const int* ball_idx, const float* feats, const float* rk, const float* W, const float* Wp,
                        const float* bias, float* out, void* stream) {
+    return etch_inter_so3conv_ordered(b, cin, cout, p1, p2, nn, sigma, xyz, new_xyz, ball_idx, feats, rk, W, Wp, bias, out, nullptr, stream);
+}
+
+int etch_inter_so3conv_ordered(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
+                               const int* ball_idx, const float* feats, const float* rk, const float* W, const float* Wp,
+                               const float* bias, float* out, const int* order, void* stream) {
     if (b <= 0 || p2 <= 0) return ETCH_OK;
     if (nn <= 0 || nn > 64 || sigma <= 0.f) return ETCH_EINVAL;
     hipStream_t st = (hipStream_t)stream;
 #define INTER_CASE(CI, CO) \
-    if (cin == CI && cout == CO) return launch_inter<CI, CO>(b, p1, p2, nn, sigma, xyz, new_xyz, ball_idx, feats, rk, Wp, bias, out, st);
+    if (cin == CI && cout == CO) return launch_inter<CI, CO>(b, p1, p2, nn, sigma, xyz, new_xyz, ball_idx, feats, rk, Wp, bias, out, order, st);
     INTER_CASE(16, 16) INTER_CASE(16, 32) INTER_CASE(32, 32) INTER_CASE(32, 64) INTER_CASE(64, 64)
 #undef INTER_CASE
     if (cin == 1 && cout <= 64) {

@@ -150,8 +150,12 @@ class GT_network_equiv(nn.Module):
             made.append(cur)
             for block in self.encoder.backbone:
                 for conv in block.blocks:
-                    ball, sidx, cur = conv.inter_conv.conv.group(cur)
+                    ic = conv.inter_conv.conv
+                    ball, sidx, cur = ic.group(cur)
                     made += [ball, sidx, cur]
+                    od = ic.order(cur)
+                    if od is not None:
+                        made.append(od)
             epn_ready = torch.cuda.Event()
             epn_ready.record(side)
             if want_pt:

@@ -153,18 +153,32 @@ def permute_weight_frag(w2):
 
 
 # ------------------------------------------------------------------ EPN encoder
-def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma):
-    """feats_cl (b,p1,60,cin) channels-last -> (b,p2,60,cout) pre-norm."""
+def spatial_order(xyz):
+    """xyz (b,3,n) -> (b,n) int32 Morton order of each scan (scheduling hint for inter_so3conv); None if n is unsupported."""
+    _need(xyz, torch.float32, "xyz")
+    b, _, n = xyz.shape
+    if n > 16384:
+        return None
+    order = torch.empty((b, n), dtype=torch.int32, device=xyz.device)
+    _lib.check(_lib.lib().etch_spatial_order(b, n, _ptr(xyz), _ptr(order), _stream()), "etch_spatial_order")
+    return order
+
+
+def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, order=None):
+    """feats_cl (b,p1,60,cin) channels-last -> (b,p2,60,cout) pre-norm.  order (b,p2) int32: processing order of the output points."""
     b, p1, na, cin = feats_cl.shape
     p2, nn = ball_idx.shape[1], ball_idx.shape[2]
     cout = W.shape[0]
     for t, n in ((xyz, "xyz"), (new_xyz, "new_xyz"), (feats_cl, "feats"), (rk, "rk"), (W, "W"), (bias, "bias")):
         _need(t, torch.float32, n)
     _need(ball_idx, torch.int32, "ball_idx")
+    if order is not None:
+        _need(order, torch.int32, "order")
+        assert tuple(order.shape) == (b, p2)
     out = torch.empty((b, p2, 60, cout), dtype=torch.float32, device=xyz.device)
-    _lib.check(_lib.lib().etch_inter_so3conv(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
-                                             _ptr(feats_cl), _ptr(rk), _ptr(W), _optptr(Wp), _ptr(bias), _ptr(out), _stream()),
-               "etch_inter_so3conv")
+    _lib.check(_lib.lib().etch_inter_so3conv_ordered(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
+                                                     _ptr(feats_cl), _ptr(rk), _ptr(W), _optptr(Wp), _ptr(bias), _ptr(out), _optptr(order),
+                                                     _stream()), "etch_inter_so3conv")
     return out
 
 

@@ -151,6 +151,16 @@ class InterSO3Conv(nn.Module):
             return ball, sidx, new_xyz
         return pointops._memo(("epn_group", id(self), xyz.data_ptr(), tuple(xyz.shape)), (xyz,), compute)
 
+    spatial_schedule = True   # walk the output points along a Morton curve (scheduling only: 3x less HBM traffic, same results)
+
+    def order(self, new_xyz):
+        """Processing order of the output points for the fused kernel; coordinates only, memoised like group() (and issued by
+        the model's index stream together with it)."""
+        if not self.spatial_schedule or self.dim_in < 16:
+            return None
+        from .models import pointops
+        return pointops._memo(("epn_order", new_xyz.data_ptr(), tuple(new_xyz.shape)), (new_xyz,), lambda: ops.spatial_order(new_xyz))
+
     def forward(self, x, inter_idx=None, inter_w=None):
         xyz = x.xyz
         if inter_idx is None:
@@ -158,7 +168,7 @@ class InterSO3Conv(nn.Module):
         else:
             sample_idx, new_xyz = None, xyz
         rk, W, Wp, bias = self._derived()
-        y = ops.inter_so3conv(xyz, new_xyz, inter_idx, x.feats_cl, rk, W, Wp, bias, self.sigma)
+        y = ops.inter_so3conv(xyz, new_xyz, inter_idx, x.feats_cl, rk, W, Wp, bias, self.sigma, order=self.order(new_xyz))
         return inter_idx, None, sample_idx, SphericalPointCloud(new_xyz, None, self.anchors, feats_cl=y)
 
 

@@ -82,6 +82,17 @@ int etch_inter_so3conv(int b, int cin, int cout, int p1, int p2, int nn, float s
                        const float* new_xyz, const int* ball_idx, const float* feats, const float* rk, const float* W,
                        const float* Wp, const float* bias, float* out, void* stream);
 
+/* The same convolution with an explicit processing order of the output points (a scheduling hint: results are identical).
+ * order (b,p2) int32 = a permutation of 0..p2-1 per scan, e.g. from etch_spatial_order; NULL = index order.  Workgroups walk
+ * `order`, one contiguous eighth per XCD, so that the workgroups sharing an L2 gather from the same source rows. */
+int etch_inter_so3conv_ordered(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
+                               const int* ball_idx, const float* feats, const float* rk, const float* W, const float* Wp,
+                               const float* bias, float* out, const int* order, void* stream);
+
+/* Morton (Z-curve) order of each scan's points on its own bounding box, ties by index: xyz (b,3,n) -> order (b,n) int32.
+ * n <= 16384.  No counterpart in the reference: it only feeds etch_inter_so3conv_ordered. */
+int etch_spatial_order(int b, int n, const float* xyz, int* order, void* stream);
+
 /* Fused intra-SO(3) convolution.  Replaces intra_so3conv_grouping (functional.py:331-378) + BasicSO3Conv
  * (modules.py:150-153).  X (b,p,60,c); if mean != NULL the input is first normalised per (b,c) and passed
  * through leaky_relu(0.01) on load (InstanceNorm of the preceding inter block, src/models/so3conv.py:96-99).

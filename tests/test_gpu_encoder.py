@@ -108,3 +108,54 @@ def test_encoder_vs_reference_golden(golden):
     f = out.feats.cpu().numpy()
     assert f.shape == (2, 64, 256, 60)
     assert rel_err(f[:, :, ::16, :], g["enc_feats_sub"]) < RTOL
+
+
+def _morton_reference(x):
+    """numpy restatement of etch_spatial_order: 10 bits per axis on the scan's bounding box, ties by index."""
+    x = x.astype(np.float32)
+    lo, hi = x.min(1, keepdims=True), x.max(1, keepdims=True)
+    sc = (np.float32(1023.0) / np.where(hi > lo, hi - lo, np.float32(1.0)) * (hi > lo)).astype(np.float32)
+    q = np.clip(((x - lo) * sc).astype(np.float32), 0, 1023).astype(np.uint64)
+
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+    key = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2)
+    return np.lexsort((np.arange(x.shape[1]), key))
+
+
+@pytest.mark.parametrize("b,n", [(3, 2500), (2, 1250), (1, 1), (2, 4097), (1, 16384)])
+def test_spatial_order_is_the_morton_permutation(b, n):
+    from etch_amd import ops
+    rng = np.random.default_rng(n)
+    xyz = (rng.standard_normal((b, 3, n)) * np.array([0.14, 0.31, 0.085])[None, :, None]).astype(np.float32)
+    if n > 10:
+        xyz[0, :, 5] = xyz[0, :, 3]                      # a duplicated point: tie broken by index
+    order = ops.spatial_order(torch.from_numpy(xyz).cuda()).cpu().numpy()
+    assert order.shape == (b, n) and order.dtype == np.int32
+    for i in range(b):
+        assert np.array_equal(np.sort(order[i]), np.arange(n))
+        assert np.array_equal(order[i], _morton_reference(xyz[i]))
+    assert ops.spatial_order(torch.zeros(1, 3, 20000).cuda()) is None
+
+
+def test_inter_conv_result_does_not_depend_on_the_schedule(golden):
+    """The spatial schedule only permutes which workgroup computes which output point: bitwise identical outputs, also with an
+    arbitrary permutation and with a point count that is not a multiple of 8 (empty slots of the XCD-striped grid)."""
+    from etch_amd import ops
+    from etch_amd import vgtk_so3conv as V
+    g = torch.Generator().manual_seed(5)
+    b, p1, p2, nn, cin, cout = 2, 301, 149, 32, 32, 64
+    xyz = (torch.randn(b, 3, p1, generator=g) * 0.2).cuda()
+    new_xyz = xyz[:, :, :p2].contiguous()
+    ball = ops.ball_query(new_xyz, xyz, 0.25, nn)
+    conv = load_seeded(V.InterSO3Conv(cin, cout, 1, 2, 0.25, 0.03, nn), 3).cuda()
+    rk, W, Wp, bias = conv._derived()
+    feats = torch.randn(b, p1, 60, cin, generator=g).cuda()
+    ref = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma)
+    for order in (ops.spatial_order(new_xyz), torch.stack([torch.randperm(p2, generator=g) for _ in range(b)]).int().cuda()):
+        out = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, order=order)
+        assert torch.equal(out, ref)
