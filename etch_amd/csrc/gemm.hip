@@ -268,6 +268,42 @@ static int launch_wres(const GemmArgs& a, hipStream_t st) {
     return ETCH_OK;
 }
 
+// K == 1 (the skip conv of the first EPN block: one input channel): Y[r, o] = epi(x[rowmap(r)] * W[o, 0]) is an outer product,
+// i.e. a pure store stream (614 MB at 4.8 M rows x 32 outputs); thread = (row, 4 outputs), 16-byte stores.
+__global__ void __launch_bounds__(256) linear_k1_kernel(GemmArgs a) {
+    const int o4n = (a.O + 3) >> 2;
+    const long total = (long)a.R * o4n;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / o4n;
+        const int o0 = (int)(e - r * o4n) * 4;
+        long src = r;
+        if (a.row_idx) {
+            const long q = r / a.grp;
+            src = ((q / a.p_out) * a.p_in + a.row_idx[q]) * a.grp + (r - q * a.grp);
+        }
+        const float x = a.X[src * a.ldx];
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int o = o0 + u;
+            float t = 0.f;
+            if (o < a.O) {
+                t = x * a.W[(long)o * a.ldw] + (a.bias ? a.bias[o] : 0.f);
+                if (a.scale) t = t * a.scale[o] + a.shift[o];
+                if (a.res_mode == 1) t += a.res[r * a.ldr + o];
+                if (a.act == 1) t = fmaxf(t, 0.f);
+                else if (a.act == 2) t = t > 0.f ? t : 0.01f * t;
+                if (a.res_mode == 2) t += a.res[r * a.ldr + o];
+            }
+            v[u] = t;
+        }
+        float* y = a.Y + r * a.ldy + o0;
+        if (o0 + 3 < a.O && !(a.ldy & 3) && !((uintptr_t)a.Y & 15)) *reinterpret_cast<float4*>(y) = make_float4(v[0], v[1], v[2], v[3]);
+        else
+            for (int u = 0; u < 4 && o0 + u < a.O; ++u) y[u] = v[u];
+    }
+}
+
 extern "C" int etch_linear(int R, int K, int O, const float* X, long ldx, const int* row_idx, int grp, int p_in, int p_out,
                            const float* W, long ldw, const float* bias, const float* scale, const float* shift, int act,
                            const float* res, long ldr, int res_mode, float* Y, long ldy, void* stream) {
@@ -280,6 +316,13 @@ extern "C" int etch_linear(int R, int K, int O, const float* X, long ldx, const 
     const bool vx = !(K & 3) && !(ldx & 3) && !((uintptr_t)X & 15);
     const bool vw = !(K & 3) && !(ldw & 3) && !((uintptr_t)W & 15);
     hipStream_t st = (hipStream_t)stream;
+    if (K == 1) {
+        long blocks = ((long)R * ((O + 3) / 4) + 255) / 256;
+        if (blocks > 65535L * 16) blocks = 65535L * 16;
+        hipLaunchKernelGGL(linear_k1_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+        ETCH_RETURN_IF_LAUNCH_FAILED();
+        return ETCH_OK;
+    }
     static const bool no_wres = getenv("ETCH_GEMM_NO_WRES") != nullptr;   // diagnostics: force the tiled kernel
     if (!no_wres && vx && vw && R >= 8192 && O <= 16) {   // weight-resident streaming kernel: narrow outputs only (measured)
         if (K == 64) return launch_wres<64, 1>(a, st);
