@@ -29,7 +29,8 @@ template <int CIN, int COUT, int MAXT>     // MAXT = ceil(nn / 16) neighbour chu
 __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
     int p1, int p2, int nn, float inv_sigma, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
     const int* __restrict__ ball_idx, const float* __restrict__ feats, const float* __restrict__ rk,
-    const float* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ out, const int* __restrict__ order) {
+    const float* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ out, const int* __restrict__ order,
+    float* __restrict__ stat_part) {
     constexpr int MT1 = CIN / 16;          // c tiles in step 1
     constexpr int MT2 = COUT / 16;         // o tiles in step 2
     constexpr int KK = CIN * KS;           // contraction length of step 2
@@ -85,6 +86,9 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
     float* outp = out + ((size_t)b * p2 + p) * NA * COUT;
     const bool k1ok = fr < 8;
 
+    // InstanceNorm statistics of the output, fused: this thread's output channel is fixed (256 % COUT == 0), so it keeps the sum
+    // and the sum of squares of everything it writes; reduced per workgroup at the end (stat_part [b][p2][2][COUT])
+    float st_s = 0.f, st_q = 0.f;
     for (int ag = 0; ag < 4; ++ag) {
         f32x4 keep[4][HALVES > 1 ? MTH : 1][2];        // second channel half of the wave's 4 anchors (HALVES == 2 only)
         // ---------------- step 1: 4 anchors per wave
@@ -186,10 +190,25 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
             if (a < NA) {
                 float v = part[(0 * 16 + col) * PS + o] + part[(1 * 16 + col) * PS + o];
                 v += part[(2 * 16 + col) * PS + o] + part[(3 * 16 + col) * PS + o];
-                outp[(size_t)a * COUT + o] = v + bias[o];
+                v += bias[o];
+                outp[(size_t)a * COUT + o] = v;
+                st_s += v; st_q += v * v;
             }
         }
         // next group's X1s / partial writes are ordered behind the barriers above
+    }
+    if (stat_part) {
+        static_assert(256 % COUT == 0, "a thread must keep one output channel");
+        __syncthreads();                                    // the partial tile is free again
+        part[tid] = st_s; part[256 + tid] = st_q;
+        __syncthreads();
+        if (tid < COUT) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 256 / COUT; ++k) { a0 += part[k * COUT + tid]; a1 += part[256 + k * COUT + tid]; }
+            float* sp = stat_part + ((size_t)b * p2 + p) * 2 * COUT;
+            sp[tid] = a0; sp[COUT + tid] = a1;
+        }
     }
 }
 
@@ -265,7 +284,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __global__ void __launch_bounds__(256) inter_so3conv_c1_kernel(
     int cout, int p1, int p2, int nn, float inv_sigma, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
     const int* __restrict__ ball_idx, const float* __restrict__ feats, const float* __restrict__ rk, const float* __restrict__ W,
-    const float* __restrict__ bias, float* __restrict__ out) {
+    const float* __restrict__ bias, float* __restrict__ out, float* __restrict__ stat_part) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float4* GA = reinterpret_cast<float4*>(smem);          // [nn]  (2/sigma * g, 1 - |g|^2/sigma)
     float* Fn = smem + 4 * nn;                              // [nn][NA]
@@ -314,12 +333,27 @@ __global__ void __launch_bounds__(256) inter_so3conv_c1_kernel(
     }
     __syncthreads();
     float* outp = out + ((size_t)b * p2 + p) * NA * cout;
+    float st_s = 0.f, st_q = 0.f;                           // fused InstanceNorm statistics (needs 256 % cout == 0: fixed channel per thread)
     for (int e = tid; e < NA * cout; e += 256) {
         const int a = e / cout, o = e - a * cout;
         float acc = 0.f;
 #pragma unroll
         for (int i = 0; i < KS; ++i) acc = fmaf(Ws[o * KS + i], X1[a * KS + i], acc);
-        outp[e] = acc + bias[o];
+        acc += bias[o];
+        outp[e] = acc;
+        st_s += acc; st_q += acc * acc;
+    }
+    if (stat_part) {
+        __syncthreads();
+        float* red = Fn;                                    // >= 512 floats (nn * 60), no longer needed
+        red[tid] = st_s; red[256 + tid] = st_q;
+        __syncthreads();
+        if (tid < cout) {
+            float a0 = 0.f, a1 = 0.f;
+            for (int k = 0; k < 256 / cout; ++k) { a0 += red[k * cout + tid]; a1 += red[256 + k * cout + tid]; }
+            float* sp = stat_part + ((size_t)b * p2 + p) * 2 * cout;
+            sp[tid] = a0; sp[cout + tid] = a1;
+        }
     }
 }
 
@@ -459,6 +493,39 @@ __global__ void instnorm_final_kernel(int rows, int C, float eps, const double* 
     rstd[(size_t)b * C + c] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// mean / rstd from per-workgroup partial sums written by the fused inter conv: part [b][nparts][2][C] (sum, sum of squares over
+// `count` values each) -> the same statistics as instnorm_partial/final over nparts * count values; fp64 accumulation in a fixed order
+__global__ void __launch_bounds__(1024) instnorm_from_partials_kernel(int nparts, int C, int count, float eps, const float* __restrict__ part,
+                                                                      float* __restrict__ mean, float* __restrict__ rstd) {
+    __shared__ double red[2][1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int c4 = C >> 2;                                 // thread -> channel quad and slice of the parts; 16-byte loads
+    const int cq = tid % c4, sl = tid / c4, nsl = 1024 / c4;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    const float* pb = part + (size_t)b * nparts * 2 * C;
+    for (int k = sl; k < nparts; k += nsl) {
+        const float4 u = *reinterpret_cast<const float4*>(pb + (size_t)k * 2 * C + cq * 4);
+        const float4 v = *reinterpret_cast<const float4*>(pb + (size_t)k * 2 * C + C + cq * 4);
+        s[0] += (double)u.x; s[1] += (double)u.y; s[2] += (double)u.z; s[3] += (double)u.w;
+        q[0] += (double)v.x; q[1] += (double)v.y; q[2] += (double)v.z; q[3] += (double)v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        __syncthreads();
+        red[0][tid] = s[j]; red[1][tid] = q[j];
+        __syncthreads();
+        if (sl == 0) {
+            double a = s[j], d = q[j];
+            for (int k = 1; k < nsl; ++k) { a += red[0][k * c4 + cq]; d += red[1][k * c4 + cq]; }
+            const double n = (double)nparts * count, m = a / n;
+            double var = d / n - m * m;
+            if (var < 0.0) var = 0.0;
+            mean[(size_t)b * C + cq * 4 + j] = (float)m;
+            rstd[(size_t)b * C + cq * 4 + j] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+    }
+}
+
 // out = lrelu((x1 - m1) * r1) [+ lrelu((x2 - m2) * r2)]     (elementwise, channels-last, float4)
 __global__ void __launch_bounds__(256) instnorm_act_add_kernel(long n4, int rows, int C, const float* __restrict__ x1,
                                                                const float* __restrict__ m1, const float* __restrict__ r1,
@@ -490,7 +557,7 @@ __global__ void __launch_bounds__(256) instnorm_act_add_kernel(long n4, int rows
 template <int CIN, int COUT, int MAXT>
 static int launch_inter_t(int b, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz, const int* idx,
                           const float* feats, const float* rk, const float* Wp, const float* bias, float* out, const int* order,
-                          hipStream_t st) {
+                          float* stat_part, hipStream_t st) {
     const size_t lds = (size_t)(16 * (CIN * KS / (CIN >= 32 ? 2 : 1) + 40) + 4 * 16 * (COUT + 4)) * sizeof(float);
     auto kern = inter_so3conv_kernel<CIN, COUT, MAXT>;
     if (lds > 64 * 1024) {
@@ -498,7 +565,8 @@ static int launch_inter_t(int b, int p1, int p2, int nn, float sigma, const floa
         if (e != hipSuccess) return (int)e;
     }
     const unsigned gx = order ? 8u * (unsigned)((p2 + 7) / 8) : (unsigned)p2;
-    hipLaunchKernelGGL(kern, dim3(gx, b), dim3(256), lds, st, p1, p2, nn, 1.0f / sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, order);
+    hipLaunchKernelGGL(kern, dim3(gx, b), dim3(256), lds, st, p1, p2, nn, 1.0f / sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, order,
+                       stat_part);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }
@@ -506,10 +574,10 @@ static int launch_inter_t(int b, int p1, int p2, int nn, float sigma, const floa
 template <int CIN, int COUT>
 static int launch_inter(int b, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz, const int* idx,
                         const float* feats, const float* rk, const float* Wp, const float* bias, float* out, const int* order,
-                        hipStream_t st) {
-    if (nn <= 16) return launch_inter_t<CIN, COUT, 1>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, order, st);
-    if (nn <= 32) return launch_inter_t<CIN, COUT, 2>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, order, st);
-    return launch_inter_t<CIN, COUT, 4>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, order, st);
+                        float* stat_part, hipStream_t st) {
+    if (nn <= 16) return launch_inter_t<CIN, COUT, 1>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, order, stat_part, st);
+    if (nn <= 32) return launch_inter_t<CIN, COUT, 2>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, order, stat_part, st);
+    return launch_inter_t<CIN, COUT, 4>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, order, stat_part, st);
 }
 
 template <int C, int COUT>
@@ -528,33 +596,34 @@ extern "C" {
 // etch_permute_weight_frag (only the MFMA path, cin % 16 == 0, reads it).
 int etch_inter_so3conv_ordered(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
                                const int* ball_idx, const float* feats, const float* rk, const float* W, const float* Wp,
-                               const float* bias, float* out, const int* order, void* stream);
+                               const float* bias, float* out, const int* order, float* stat_part, void* stream);
 
 int etch_inter_so3conv(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
                        const int* ball_idx, const float* feats, const float* rk, const float* W, const float* Wp,
                        const float* bias, float* out, void* stream) {
-    return etch_inter_so3conv_ordered(b, cin, cout, p1, p2, nn, sigma, xyz, new_xyz, ball_idx, feats, rk, W, Wp, bias, out, nullptr, stream);
+    return etch_inter_so3conv_ordered(b, cin, cout, p1, p2, nn, sigma, xyz, new_xyz, ball_idx, feats, rk, W, Wp, bias, out, nullptr, nullptr, stream);
 }
 
 int etch_inter_so3conv_ordered(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
                                const int* ball_idx, const float* feats, const float* rk, const float* W, const float* Wp,
-                               const float* bias, float* out, const int* order, void* stream) {
+                               const float* bias, float* out, const int* order, float* stat_part, void* stream) {
     if (b <= 0 || p2 <= 0) return ETCH_OK;
     if (nn <= 0 || nn > 64 || sigma <= 0.f) return ETCH_EINVAL;
     hipStream_t st = (hipStream_t)stream;
 #define INTER_CASE(CI, CO) \
-    if (cin == CI && cout == CO) return launch_inter<CI, CO>(b, p1, p2, nn, sigma, xyz, new_xyz, ball_idx, feats, rk, Wp, bias, out, order, st);
+    if (cin == CI && cout == CO) return launch_inter<CI, CO>(b, p1, p2, nn, sigma, xyz, new_xyz, ball_idx, feats, rk, Wp, bias, out, order, stat_part, st);
     INTER_CASE(16, 16) INTER_CASE(16, 32) INTER_CASE(32, 32) INTER_CASE(32, 64) INTER_CASE(64, 64)
 #undef INTER_CASE
-    if (cin == 1 && cout <= 64) {
+    if (cin == 1 && cout <= 64 && (!stat_part || (256 % cout == 0 && nn * NA >= 512))) {
         const size_t lds = ((size_t)4 * nn + (size_t)nn * NA + NA * KS + (size_t)cout * KS + nn) * sizeof(float);
         if (lds <= 64 * 1024) {
             hipLaunchKernelGGL(inter_so3conv_c1_kernel, dim3(p2, b), dim3(256), lds, st, cout, p1, p2, nn, 1.0f / sigma, xyz, new_xyz, ball_idx,
-                               feats, rk, W, bias, out);
+                               feats, rk, W, bias, out, stat_part);
             ETCH_RETURN_IF_LAUNCH_FAILED();
             return ETCH_OK;
         }
     }
+    if (stat_part) return ETCH_EUNSUPPORTED;               // the generic small-CIN kernel has no fused statistics
     if (cin <= 8) {
         const size_t lds = (size_t)(4 * nn + NA * cin * KS) * sizeof(float);
         hipLaunchKernelGGL(inter_so3conv_small_kernel, dim3(p2, b), dim3(256), lds, st, cin, cout, p1, p2, nn, 1.0f / sigma, xyz,
@@ -584,6 +653,14 @@ int etch_instnorm_stats(int b, int rows, int C, const float* x, double* workspac
     hipLaunchKernelGGL(instnorm_partial_kernel, dim3(IN_CHUNKS, b), dim3(256), 2 * 1024 * sizeof(double), st, rows, C, x, workspace);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     hipLaunchKernelGGL(instnorm_final_kernel, dim3(b), dim3(256), 0, st, rows, C, 1e-5f, workspace, mean, rstd);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_instnorm_from_partials(int b, int nparts, int C, int count, const float* partial, float* mean, float* rstd, void* stream) {
+    if (b <= 0) return ETCH_OK;
+    if (C < 4 || C > 256 || (C & 3) || (1024 % (C >> 2)) != 0 || nparts <= 0 || count <= 0 || ((uintptr_t)partial & 15)) return ETCH_EUNSUPPORTED;
+    hipLaunchKernelGGL(instnorm_from_partials_kernel, dim3(b), dim3(1024), 0, (hipStream_t)stream, nparts, C, count, 1e-5f, partial, mean, rstd);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }

@@ -75,7 +75,8 @@ class InterSO3ConvBlock(nn.Module):
 
     def forward(self, x, inter_idx=None, inter_w=None):
         inter_idx, inter_w, sample_idx, y = self.conv(x, inter_idx, inter_w)
-        return inter_idx, inter_w, sample_idx, sptk.SphericalPointCloud(y.xyz, None, y.anchors, feats_cl=_norm_act(y.feats_cl))
+        m, r = getattr(y, "in_stats", None) or ops.instnorm_stats(y.feats_cl)
+        return inter_idx, inter_w, sample_idx, sptk.SphericalPointCloud(y.xyz, None, y.anchors, feats_cl=ops.instnorm_act_add(y.feats_cl, m, r))
 
 
 class SeparableSO3ConvBlock(nn.Module):
@@ -98,7 +99,7 @@ class SeparableSO3ConvBlock(nn.Module):
     def forward(self, x, inter_idx, inter_w):
         conv = self.inter_conv.conv
         inter_idx, _, sample_idx, y = conv(x, inter_idx, inter_w)
-        m1, r1 = ops.instnorm_stats(y.feats_cl)
+        m1, r1 = getattr(y, "in_stats", None) or ops.instnorm_stats(y.feats_cl)     # from the conv's epilogue
         z = self.intra_conv.conv(y, m1, r1)                      # IN + lrelu of the inter output applied on load
         m2, r2 = ops.instnorm_stats(z.feats_cl)
         # skip branch: 1x1 conv on (optionally sub-sampled) input rows

@@ -164,8 +164,9 @@ def spatial_order(xyz):
     return order
 
 
-def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, order=None):
-    """feats_cl (b,p1,60,cin) channels-last -> (b,p2,60,cout) pre-norm.  order (b,p2) int32: processing order of the output points."""
+def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, order=None, want_stats=False):
+    """feats_cl (b,p1,60,cin) channels-last -> (b,p2,60,cout) pre-norm.  order (b,p2) int32: processing order of the output points.
+    want_stats: also return the InstanceNorm (mean, rstd) of the output, accumulated in the conv's epilogue."""
     b, p1, na, cin = feats_cl.shape
     p2, nn = ball_idx.shape[1], ball_idx.shape[2]
     cout = W.shape[0]
@@ -176,10 +177,19 @@ def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, orde
         _need(order, torch.int32, "order")
         assert tuple(order.shape) == (b, p2)
     out = torch.empty((b, p2, 60, cout), dtype=torch.float32, device=xyz.device)
+    fused = want_stats and 256 % cout == 0 and (cin >= 16 or cin == 1)
+    part = torch.empty((b, p2, 2, cout), dtype=torch.float32, device=xyz.device) if fused else None
     _lib.check(_lib.lib().etch_inter_so3conv_ordered(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
                                                      _ptr(feats_cl), _ptr(rk), _ptr(W), _optptr(Wp), _ptr(bias), _ptr(out), _optptr(order),
-                                                     _stream()), "etch_inter_so3conv")
-    return out
+                                                     _optptr(part), _stream()), "etch_inter_so3conv")
+    if not want_stats:
+        return out
+    if not fused:
+        return out, instnorm_stats(out)
+    mean = torch.empty((b, cout), dtype=torch.float32, device=xyz.device)
+    rstd = torch.empty((b, cout), dtype=torch.float32, device=xyz.device)
+    _lib.check(_lib.lib().etch_instnorm_from_partials(b, p2, cout, 60, _ptr(part), _ptr(mean), _ptr(rstd), _stream()), "etch_instnorm_from_partials")
+    return out, (mean, rstd)
 
 
 def intra_so3conv(x_cl, intra_idx32, Wp, bias, cout, mean=None, rstd=None):

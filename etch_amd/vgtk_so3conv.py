@@ -168,8 +168,10 @@ class InterSO3Conv(nn.Module):
         else:
             sample_idx, new_xyz = None, xyz
         rk, W, Wp, bias = self._derived()
-        y = ops.inter_so3conv(xyz, new_xyz, inter_idx, x.feats_cl, rk, W, Wp, bias, self.sigma, order=self.order(new_xyz))
-        return inter_idx, None, sample_idx, SphericalPointCloud(new_xyz, None, self.anchors, feats_cl=y)
+        y, stats = ops.inter_so3conv(xyz, new_xyz, inter_idx, x.feats_cl, rk, W, Wp, bias, self.sigma, order=self.order(new_xyz), want_stats=True)
+        cloud = SphericalPointCloud(new_xyz, None, self.anchors, feats_cl=y)
+        cloud.in_stats = stats          # InstanceNorm (mean, rstd) of the output, a by-product of the conv's epilogue
+        return inter_idx, None, sample_idx, cloud
 
 
 class IntraSO3Conv(nn.Module):

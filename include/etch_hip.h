@@ -84,10 +84,16 @@ int etch_inter_so3conv(int b, int cin, int cout, int p1, int p2, int nn, float s
 
 /* The same convolution with an explicit processing order of the output points (a scheduling hint: results are identical).
  * order (b,p2) int32 = a permutation of 0..p2-1 per scan, e.g. from etch_spatial_order; NULL = index order.  Workgroups walk
- * `order`, one contiguous eighth per XCD, so that the workgroups sharing an L2 gather from the same source rows. */
+ * `order`, one contiguous eighth per XCD, so that the workgroups sharing an L2 gather from the same source rows.
+ * stat_part (b,p2,2,cout) float or NULL: per output point the sum and the sum of squares of its 60 x cout outputs, i.e. the
+ * InstanceNorm2d statistics of so3conv.py:96-99 without a second pass over the output (etch_instnorm_from_partials finishes them). */
 int etch_inter_so3conv_ordered(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
                                const int* ball_idx, const float* feats, const float* rk, const float* W, const float* Wp,
-                               const float* bias, float* out, const int* order, void* stream);
+                               const float* bias, float* out, const int* order, float* stat_part, void* stream);
+
+/* mean / rstd (b,C) of InstanceNorm2d(affine=False, eps 1e-5) from per-part partial sums: partial (b,nparts,2,C), each over `count`
+ * values.  Same result as etch_instnorm_stats over the full tensor (fp64 accumulation, fixed order). */
+int etch_instnorm_from_partials(int b, int nparts, int C, int count, const float* partial, float* mean, float* rstd, void* stream);
 
 /* Morton (Z-curve) order of each scan's points on its own bounding box, ties by index: xyz (b,3,n) -> order (b,n) int32.
  * n <= 16384.  No counterpart in the reference: it only feeds etch_inter_so3conv_ordered. */

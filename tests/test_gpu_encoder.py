@@ -159,3 +159,27 @@ def test_inter_conv_result_does_not_depend_on_the_schedule(golden):
     for order in (ops.spatial_order(new_xyz), torch.stack([torch.randperm(p2, generator=g) for _ in range(b)]).int().cuda()):
         out = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, order=order)
         assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("cin,cout,nn", [(32, 64, 32), (64, 64, 20), (1, 32, 64)])
+def test_inter_conv_fused_instancenorm_statistics(cin, cout, nn):
+    """mean / rstd accumulated in the conv's epilogue (etch_inter_so3conv_ordered stat_part + etch_instnorm_from_partials) equal the
+    separate statistics pass over the written output (so3conv.py:96-99 InstanceNorm2d) to fp32 rounding; the output itself is untouched."""
+    from etch_amd import ops
+    from etch_amd import vgtk_so3conv as V
+    g = torch.Generator().manual_seed(cin + nn)
+    b, p1, p2 = 3, 211, 101
+    xyz = (torch.randn(b, 3, p1, generator=g) * 0.2).cuda()
+    new_xyz = xyz[:, :, :p2].contiguous()
+    ball = ops.ball_query(new_xyz, xyz, 0.25, nn)
+    conv = load_seeded(V.InterSO3Conv(cin, cout, 1, 2, 0.25, 0.03, nn), 3).cuda()
+    rk, W, Wp, bias = conv._derived()
+    feats = torch.randn(b, p1, 60, cin, generator=g).cuda()
+    ref = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma)
+    out, (m, r) = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, order=conv.order(new_xyz), want_stats=True)
+    assert torch.equal(out, ref)
+    m0, r0 = ops.instnorm_stats(ref)
+    assert rel_err(m.cpu().numpy(), m0.cpu().numpy()) < 2e-6 and rel_err(r.cpu().numpy(), r0.cpu().numpy()) < 2e-6
+    x64 = ref.double().reshape(b, -1, cout)
+    assert rel_err(m.cpu().numpy(), x64.mean(1).cpu().numpy()) < 2e-6
+    assert rel_err(r.cpu().numpy(), (1.0 / torch.sqrt(x64.var(1, unbiased=False) + 1e-5)).cpu().numpy()) < 2e-6
