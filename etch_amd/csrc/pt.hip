@@ -578,3 +578,51 @@ extern "C" int etch_pt_attention_mfma(int n, int c, int ns, const float* p, cons
 #undef PT_MFMA_CASE
     return ETCH_EUNSUPPORTED;
 }
+
+// ------------------------------------------------------------------------------------------------
+// TransitionDown (pointtransformer_seg.py:40-68, stride != 1) without the grouped rows: the reference builds m*ns rows
+// [p_j - p_i | x_j], applies Linear(3 + c -> c_out, bias=False) + BN + ReLU and max-pools over the ns neighbours.  The linear map
+// splits as  W [p_j - p_i | x_j] = Wp (p_j - p_i) + Wx x_j : the x part is a per-SOURCE-point product ux = x Wx^T (n rows instead
+// of m*ns = 4n), the coordinate part is 3 FMAs on the same difference the reference forms (no cancellation introduced).
+//   out[i, o] = max_j relu(bn(ux[idx[i,j], o] + Wp[o,:] . (p[idx[i,j]] - new_p[i])))
+// thread = (output point, 4 output channels).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pt_down_gather_max_kernel(int m, int ns, int co, const float* __restrict__ ux, long ldu,
+                                                                 const float* __restrict__ p, const float* __restrict__ new_p,
+                                                                 const int* __restrict__ idx, const float* __restrict__ Wp,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 float* __restrict__ out) {
+    const int c4 = co >> 2;
+    const size_t total = (size_t)m * c4;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int i = (int)(e / c4), o0 = (int)(e - (size_t)i * c4) * 4;
+        const float qx = new_p[(size_t)i * 3], qy = new_p[(size_t)i * 3 + 1], qz = new_p[(size_t)i * 3 + 2];
+        float w[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { w[u][0] = Wp[(o0 + u) * 3]; w[u][1] = Wp[(o0 + u) * 3 + 1]; w[u][2] = Wp[(o0 + u) * 3 + 2]; }
+        const float4 sc = *reinterpret_cast<const float4*>(scale + o0), sh = *reinterpret_cast<const float4*>(shift + o0);
+        float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        for (int j = 0; j < ns; ++j) {
+            const int q = idx[(size_t)i * ns + j];
+            const float rx = p[(size_t)q * 3] - qx, ry = p[(size_t)q * 3 + 1] - qy, rz = p[(size_t)q * 3 + 2] - qz;
+            const float4 v = *reinterpret_cast<const float4*>(ux + (size_t)q * ldu + o0);
+            best.x = fmaxf(best.x, fmaxf((v.x + (w[0][0] * rx + w[0][1] * ry + w[0][2] * rz)) * sc.x + sh.x, 0.f));
+            best.y = fmaxf(best.y, fmaxf((v.y + (w[1][0] * rx + w[1][1] * ry + w[1][2] * rz)) * sc.y + sh.y, 0.f));
+            best.z = fmaxf(best.z, fmaxf((v.z + (w[2][0] * rx + w[2][1] * ry + w[2][2] * rz)) * sc.z + sh.z, 0.f));
+            best.w = fmaxf(best.w, fmaxf((v.w + (w[3][0] * rx + w[3][1] * ry + w[3][2] * rz)) * sc.w + sh.w, 0.f));
+        }
+        *reinterpret_cast<float4*>(out + (size_t)i * co + o0) = best;
+    }
+}
+
+extern "C" int etch_pt_down_gather_max(int m, int ns, int co, const float* ux, long ldu, const float* p, const float* new_p, const int* idx,
+                                       const float* Wp, const float* scale, const float* shift, float* out, void* stream) {
+    if (m <= 0) return ETCH_OK;
+    if (co <= 0 || (co & 3) || (ldu & 3) || ns <= 0 || !scale || !shift) return ETCH_EINVAL;
+    size_t blocks = ((size_t)m * (co / 4) + 255) / 256;
+    if (blocks > 65535u * 16u) blocks = 65535u * 16u;
+    hipLaunchKernelGGL(pt_down_gather_max_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, m, ns, co, ux, ldu, p, new_p, idx,
+                       Wp, scale, shift, out);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}

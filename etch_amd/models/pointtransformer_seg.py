@@ -69,6 +69,7 @@ class PointTransformerLayer(nn.Module):
 
 class TransitionDown(nn.Module):
     """pointtransformer_seg.py:40-68."""
+    split_linear = True    # stride != 1: per-source-point GEMM + gather-max kernel instead of grouped rows -> GEMM -> maxpool
 
     def __init__(self, in_planes, out_planes, stride=1, nsample=16):
         super().__init__()
@@ -80,7 +81,7 @@ class TransitionDown(nn.Module):
             self.linear = nn.Linear(in_planes, out_planes, bias=False)
         self.bn = nn.BatchNorm1d(out_planes)
         self.relu = nn.ReLU(inplace=True)
-        self._d, self._dw = _Derived(), _Derived()
+        self._d, self._dw, self._ds = _Derived(), _Derived(), _Derived()
 
     def forward(self, pxo):
         p, x, o = pxo
@@ -96,11 +97,18 @@ class TransitionDown(nn.Module):
             idx = pointops.furthestsampling(p, o, n_o_t)
             n_p = pointops.gather_rows(p, idx)
             kidx = pointops.knnquery(self.nsample, p, n_p, o, n_o_t)[0]
-            # rows and weight padded to a multiple of 4 columns with zeros (3 + c is odd): same sums, 16-byte load path in the GEMM
-            g = ops.pt_group(p, n_p, x, kidx, pad_to=4)                        # (m*ns, 3+c (+pad))
-            wp = self._dw.get([self.linear.weight], lambda: torch.nn.functional.pad(w, (0, g.shape[1] - w.shape[1])).contiguous())
-            y = ops.linear(g, wp, scale=s, shift=t, act="relu")                # Linear -> BN -> ReLU
-            x = ops.rows_maxpool(y, self.nsample)
+            if self.split_linear and w.shape[0] % 4 == 0:
+                # W [p_j - p_i | x_j] = Wp (p_j - p_i) + Wx x_j: the feature part is one GEMM over the n SOURCE points (not the
+                # m*ns = 4n grouped rows); coordinate part, BN, ReLU and the neighbour max in one gather kernel
+                wpx = self._ds.get([self.linear.weight], lambda: (w[:, :3].contiguous(), w[:, 3:].contiguous()))
+                ux = ops.linear(x, wpx[1])
+                x = ops.pt_down_gather_max(ux, p, n_p, kidx, wpx[0], s, t)
+            else:
+                # rows and weight padded to a multiple of 4 columns with zeros (3 + c is odd): same sums, 16-byte load path in the GEMM
+                g = ops.pt_group(p, n_p, x, kidx, pad_to=4)                    # (m*ns, 3+c (+pad))
+                wp = self._dw.get([self.linear.weight], lambda: torch.nn.functional.pad(w, (0, g.shape[1] - w.shape[1])).contiguous())
+                y = ops.linear(g, wp, scale=s, shift=t, act="relu")            # Linear -> BN -> ReLU
+                x = ops.rows_maxpool(y, self.nsample)
             p, o = n_p, n_o_t
         else:
             if x.shape[1] != w.shape[1]:                                       # zero-padded input columns (see _unet)

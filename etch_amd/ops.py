@@ -339,6 +339,16 @@ def pt_group(p, new_p, x, idx, pad_to=1):
     return out
 
 
+def pt_down_gather_max(ux, p, new_p, idx, wp, scale, shift):
+    """out[i] = max_j relu(bn(ux[idx[i,j]] + wp @ (p[idx[i,j]] - new_p[i]))): TransitionDown without the grouped rows."""
+    m, ns = idx.shape
+    co = ux.shape[1]
+    out = torch.empty((m, co), dtype=torch.float32, device=ux.device)
+    _lib.check(_lib.lib().etch_pt_down_gather_max(m, ns, co, _ptr(ux), _c_long(ux.stride(0)), _ptr(p), _ptr(new_p), _ptr(idx), _ptr(wp), _ptr(scale),
+                                                  _ptr(shift), _ptr(out), _stream()), "etch_pt_down_gather_max")
+    return out
+
+
 def gather_rows(x, idx):
     m, c = idx.shape[0], x.shape[1]
     out = torch.empty((m, c), dtype=torch.float32, device=x.device)

@@ -182,6 +182,12 @@ int etch_pt_group(int m, int ns, int c, const float* p, const float* new_p, cons
 /* Row gather n_p = p[idx] (pointtransformer_seg.py:60): out[i,:c] = x[idx[i],:c]. */
 int etch_gather_rows(int m, int c, const float* x, long ldx, const int* idx, float* out, void* stream);
 
+/* TransitionDown with stride (pointtransformer_seg.py:40-68) without the m*ns grouped rows: ux = x Wx^T per SOURCE point (n, co),
+ * Wx = linear.weight[:, 3:]; this kernel adds the coordinate part Wp (p_j - p_i), Wp = linear.weight[:, :3] (co,3), applies the
+ * folded BatchNorm + ReLU and max-pools over the ns neighbours:  out[i,o] = max_j relu(bn(ux[idx[i,j],o] + Wp[o].(p[idx[i,j]] - new_p[i]))). */
+int etch_pt_down_gather_max(int m, int ns, int co, const float* ux, long ldu, const float* p, const float* new_p, const int* idx,
+                            const float* Wp, const float* scale, const float* shift, float* out, void* stream);
+
 /* MaxPool1d(nsample) over consecutive row groups (pointtransformer_seg.py:63): x (m*ns, c) -> out (m, c). */
 int etch_rows_maxpool(int m, int ns, int c, const float* x, float* out, void* stream);
 

@@ -41,6 +41,27 @@ def test_point_transformer_modules_vs_reference_golden(golden):
     assert rel_err(uph([p, x, o]).cpu().numpy(), g["uph_out"]) < RTOL
 
 
+@pytest.mark.parametrize("c,co,n", [(128, 128, 4001), (64, 128, 1000), (256, 512, 403)])
+def test_transition_down_split_linear_matches_grouped_rows(c, co, n):
+    """TransitionDown with the Linear split into per-source-point GEMM + gather-max kernel vs the literal grouped-rows form
+    (queryandgroup -> Linear -> BN -> ReLU -> MaxPool, pointtransformer_seg.py:55-63), which the reference golden pins at c = 32."""
+    from etch_amd.models import pointtransformer_seg as P
+    from etch_amd.models import pointops
+    down = load_seeded(P.TransitionDown(c, co, 4, 16), 5).cuda().eval()
+    g = torch.Generator().manual_seed(c + n)
+    pnt = (torch.randn(n, 3, generator=g) * 0.3).cuda()
+    x = torch.randn(n, c, generator=g).cuda()
+    o = pointops.offsets_tensor([n // 3, n], "cuda")
+    outs = []
+    for split in (True, False):
+        down.split_linear = split
+        with torch.no_grad():
+            p2, x2, o2 = down([pnt, x, o])
+        outs.append((p2.cpu().numpy(), x2.cpu().numpy(), o2.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][2], outs[1][2])
+    assert rel_err(outs[0][1], outs[1][1]) < 5e-6
+
+
 def build_model(tmp_path, seed):
     from etch_amd import constants as K
     from etch_amd.models.models_pointcloud import GT_network_equiv
