@@ -148,6 +148,9 @@ class GT_network_equiv(nn.Module):
         with torch.cuda.stream(side):
             cur = input_xyz(hitpts)
             made.append(cur)
+            od = self._input_order(hitpts)
+            if od is not None:
+                made.append(od)
             for block in self.encoder.backbone:
                 for conv in block.blocks:
                     ic = conv.inter_conv.conv
@@ -170,6 +173,15 @@ class GT_network_equiv(nn.Module):
                 t.record_stream(st)
         return epn_ready, done
 
+    def _input_order(self, hitpts):
+        """Morton order of the input points of each scan (scheduling hint for the gather-heavy kernels), memoised per forward and
+        issued by the index stream."""
+        if not hitpts.is_cuda:
+            return None
+        from .so3conv import input_xyz
+        xyz = input_xyz(hitpts)
+        return pointops._memo(("input_order", xyz.data_ptr(), tuple(xyz.shape)), (xyz,), lambda: ops.spatial_order(xyz))
+
     def _heads_streams(self):
         if not hasattr(self, "_head_streams"):
             # the nets are long chains of small kernels (the critical path of this phase), the direction head on the current
@@ -186,7 +198,7 @@ class GT_network_equiv(nn.Module):
         so3_anchors = r.anchors
         selected_indexs = torch.arange(0, N, device=hitpts.device).repeat(B, 1).unsqueeze(-1).expand(-1, -1, 3)
         # 3-NN propagation of the [C*60] equivariant features to all N points + anchor mean (:181-184), channels-last
-        point_equiv_cl, point_inv_feat = propagate_cl(hitpts, r.xyz, r.feats_cl)
+        point_equiv_cl, point_inv_feat = propagate_cl(hitpts, r.xyz, r.feats_cl, order=self._input_order(hitpts))
         results = {}
         if idx_ready is not None:
             torch.cuda.current_stream().wait_event(idx_ready)

@@ -13,7 +13,7 @@ def PointFeatPropagation(xyz1, xyz2, points2):
     return out_cl.permute(0, 1, 3, 2).reshape(B, -1, D)
 
 
-def propagate_cl(hitpts_bn3, xyz2_b3s, feats_cl):
-    """-> (point_equiv_feat (B,N,60,C) channels-last, point_inv_feat (B,N,C))."""
+def propagate_cl(hitpts_bn3, xyz2_b3s, feats_cl, order=None):
+    """-> (point_equiv_feat (B,N,60,C) channels-last, point_inv_feat (B,N,C)).  order: spatial processing order of the N points."""
     idx, w = ops.prop3nn(hitpts_bn3, xyz2_b3s)
-    return ops.prop_interp(feats_cl, idx, w)
+    return ops.prop_interp(feats_cl, idx, w, order=order)

@@ -234,14 +234,17 @@ def prop3nn(xyz1_bn3, xyz2_b3s):
     return idx, w
 
 
-def prop_interp(feats_cl, idx, w):
-    """feats_cl (B,S,A,C) -> out (B,N,A,C), inv (B,N,C)."""
+def prop_interp(feats_cl, idx, w, order=None):
+    """feats_cl (B,S,A,C) -> out (B,N,A,C), inv (B,N,C).  order (B,N) int32: processing order of the fine points (scheduling only)."""
     _need(feats_cl, torch.float32, "feats"), _need(idx, torch.int32, "idx"), _need(w, torch.float32, "w")
+    if order is not None:
+        _need(order, torch.int32, "order")
     B, S, A, C = feats_cl.shape
     N = idx.shape[1]
     out = torch.empty((B, N, A, C), dtype=torch.float32, device=feats_cl.device)
     inv = torch.empty((B, N, C), dtype=torch.float32, device=feats_cl.device)
-    _lib.check(_lib.lib().etch_prop_interp(B, N, S, A, C, _ptr(feats_cl), _ptr(idx), _ptr(w), _ptr(out), _ptr(inv), _stream()), "etch_prop_interp")
+    _lib.check(_lib.lib().etch_prop_interp_ordered(B, N, S, A, C, _ptr(feats_cl), _ptr(idx), _ptr(w), _ptr(out), _ptr(inv), _optptr(order),
+                                                   _stream()), "etch_prop_interp")
     return out, inv
 
 

@@ -127,6 +127,10 @@ int etch_prop3nn(int B, int N, int S, const float* xyz1, const float* xyz2, int*
  * -> out (B,N,A,C), inv (B,N,C) = mean over A.  C in {32,64,128}. */
 int etch_prop_interp(int B, int N, int S, int A, int C, const float* feats, const int* idx, const float* weight,
                      float* out, float* inv, void* stream);
+/* The same with a processing order of the fine points (scheduling hint, results identical): order (B,N) int32 from
+ * etch_spatial_order, NULL = index order. */
+int etch_prop_interp_ordered(int B, int N, int S, int A, int C, const float* feats, const int* idx, const float* weight,
+                             float* out, float* inv, const int* order, void* stream);
 
 /* DotProdAttention of MultiHeadAttention (src/models/direction_backbones.py:102-129,160-194) for 60 tokens,
  * 8 heads x 8 dims: rows [T*60][ld] hold q/k/v at column offsets qoff/koff/voff -> out rows [T*60][ldo] (64 cols). */
