@@ -7,8 +7,8 @@
 //   * the tail of the direction head  MLP.net[0] -> ReLU -> (net[2] o so3_reg folded)    (G = 1, K = 64;
 //     /root/reference/src/models/models_pointcloud.py:115-117), hidden = 9.6 M x 128 floats per batch.
 //
-// One workgroup = 128 rows of X, resident in LDS for all G groups (X is read from HBM exactly once); 8 waves, wave w
-// owns the 16-column strip w of the current group's 128 hidden columns: 8 row tiles x 1 column tile of 16x16x4 f32
+// One workgroup = 128 (K = 64) or 64 (K = 128) rows of X, resident in LDS for all G groups (X is read from HBM exactly once); 8 waves, wave w
+// owns the 16-column strip w of the current group's 128 hidden columns: 8 / 4 row tiles x 1 column tile of 16x16x4 f32
 // MFMAs, B fragments (weights) streamed straight from L2 in fragment order with a one-step register prefetch, A fragments
 // (X) read from LDS with one conflict-free ds_read_b128 per four MFMAs (interleaved-K order, see gemm.hip).  The epilogue
 // applies bias / ReLU / w2 in registers, sums the strip's 16 columns with DPP row reductions, and the 8 strips through a
@@ -17,7 +17,6 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define FD_ROWS 128
 #define FD_J 128
 #define FD_PAD 40      // LDS row = K + 40 floats: (K+40)/4 = 10 (mod 16) for K in {64,128} -> conflict-free b128 fragment reads
 
@@ -34,20 +33,20 @@ __device__ __forceinline__ float fd_row_sum16(float v) {
     return v;
 }
 
-template <int K, bool PERM>
+template <int K, bool PERM, int FD_ROWS>
 __global__ void __launch_bounds__(512) linear_relu_dot_kernel(long R, int G, const float* __restrict__ X, long ldx,
                                                               const float* __restrict__ W, long ldw, const float* __restrict__ b1,
                                                               const float* __restrict__ w2, const float* __restrict__ b2,
                                                               float* __restrict__ out, long ldo) {
     constexpr int S = K + FD_PAD, KT = K / 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Xs = lds;                         // [128][S]
-    float* red = lds + FD_ROWS * S;          // [2][8][128]
+    float* Xs = lds;                         // [FD_ROWS][S]
+    float* red = lds + FD_ROWS * S;          // [2][8][FD_ROWS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const long r0 = (long)blockIdx.x * FD_ROWS;
 
-    // stage the 128-row X tile (rows past R are zero)
+    // stage the X tile (rows past R are zero)
     constexpr int C4 = K / 4;
     for (int e = tid; e < FD_ROWS * C4; e += 512) {
         const int row = e / C4, c = (e - row * C4) * 4;
@@ -66,19 +65,20 @@ __global__ void __launch_bounds__(512) linear_relu_dot_kernel(long R, int G, con
 
     int buf = 0;
     for (int g = 0; g < G; ++g) {
-        f32x4 acc[8];
+        constexpr int RT = FD_ROWS / 16;
+        f32x4 acc[RT];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < RT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
             const float4 b = bn;
             // prefetch the next fragment (next k-step, or the first of the next group; the last prefetch re-reads a valid one)
             if (t + 1 < KT) bn = wfrag(g, t + 1);
             else bn = wfrag(g + 1 < G ? g + 1 : g, 0);
-            float4 a[8];
+            float4 a[RT];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const float4*>(&Xs[(i * 16 + fr) * S + t * 16 + fg * 4]);
-#define FD_STEP(C) _Pragma("unroll") for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].C, b.C, acc[i], 0, 0, 0);
+            for (int i = 0; i < RT; ++i) a[i] = *reinterpret_cast<const float4*>(&Xs[(i * 16 + fr) * S + t * 16 + fg * 4]);
+#define FD_STEP(C) _Pragma("unroll") for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].C, b.C, acc[i], 0, 0, 0);
             FD_STEP(x) FD_STEP(y) FD_STEP(z) FD_STEP(w)
 #undef FD_STEP
         }
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(512) linear_relu_dot_kernel(long R, int G, con
         const float bs = b1[col], ww = w2[col];
         float* rp = red + (buf * 8 + wave) * FD_ROWS;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float s = fd_row_sum16(fmaxf(acc[i][q] + bs, 0.f) * ww);
@@ -105,20 +105,20 @@ __global__ void __launch_bounds__(512) linear_relu_dot_kernel(long R, int G, con
     }
 }
 
-template <int K>
+template <int K, int FD_ROWS>
 static int launch_lrd(long R, int G, const float* X, long ldx, const float* W, long ldw, const float* Wp, const float* b1,
                       const float* w2, const float* b2, float* out, long ldo, hipStream_t st) {
     const size_t lds = ((size_t)FD_ROWS * (K + FD_PAD) + 2 * 8 * FD_ROWS) * sizeof(float);
     const dim3 grid((unsigned)((R + FD_ROWS - 1) / FD_ROWS));
     if (Wp) {
-        auto kern = linear_relu_dot_kernel<K, true>;
+        auto kern = linear_relu_dot_kernel<K, true, FD_ROWS>;
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
         }
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, R, G, X, ldx, Wp, 0L, b1, w2, b2, out, ldo);
     } else {
-        auto kern = linear_relu_dot_kernel<K, false>;
+        auto kern = linear_relu_dot_kernel<K, false, FD_ROWS>;
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
@@ -136,7 +136,9 @@ extern "C" int etch_linear_relu_dot(long R, int K, int G, int J, const float* X,
     if ((ldx & 3) || ((uintptr_t)X & 15) || (!Wp && ((ldw & 3) || ((uintptr_t)W & 15))) || (Wp && ((uintptr_t)Wp & 15))) return ETCH_EINVAL;
     if (J != FD_J) return ETCH_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if (K == 64) return launch_lrd<64>(R, G, X, ldx, W, ldw, Wp, b1, w2, b2, out, ldo, st);
-    if (K == 128) return launch_lrd<128>(R, G, X, ldx, W, ldw, Wp, b1, w2, b2, out, ldo, st);
+    // row-tile height: 128 for K = 64 (61 KB of LDS: 2 workgroups per CU); 64 for K = 128 (47 KB: 3 per CU instead of one 94 KB
+    // workgroup -- 4.07 -> 3.90 ms on the confidence head although every workgroup streams the weights)
+    if (K == 64) return launch_lrd<64, 128>(R, G, X, ldx, W, ldw, Wp, b1, w2, b2, out, ldo, st);
+    if (K == 128) return launch_lrd<128, 64>(R, G, X, ldx, W, ldw, Wp, b1, w2, b2, out, ldo, st);
     return ETCH_EUNSUPPORTED;
 }
