@@ -150,7 +150,7 @@ def cpu_baseline(n_points, gpu_pts, gpu_results, gpu_fit_aux, args, seed=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="scans per GPU")
     ap.add_argument("--points", type=int, default=5000)
