@@ -255,24 +255,14 @@ __global__ void __launch_bounds__(KNN_THREADS) knn_kernel(int nsample, const flo
 
 // kNN, one WAVE per query (the path the model uses; knn_kernel above is the thread-per-query form kept for tiny inputs):
 // the 64 lanes test 64 consecutive support points per step (coalesced AoS loads); lanes whose distance beats the
-// current heap top are collected with a ballot and inserted by lane 0 IN INDEX ORDER, re-testing each candidate against
-// the top as it evolves -- i.e. exactly the reference's sequential scan (same strict '<', same reheap / heap_sort),
-// only the distance evaluations run 64-wide.  Heap lives in LDS (k floats + k ints per wave).
+// current maximum are taken IN INDEX ORDER and re-tested against the maximum as it evolves -- the reference's sequential
+// scan (same strict '<'), only the distance evaluations run 64-wide.  Literal form: candidates staged by ballot, inserted by
+// lane 0 into a max-heap in LDS (same reheap / heap_sort as knnquery_cuda_kernel.cu:21-48).
 #define KNNW_WAVES 4
-__global__ void __launch_bounds__(KNNW_WAVES * 64) knn_wave_kernel(int nsample, int nseg, const float* __restrict__ xyz,
-                                                                    const float* __restrict__ new_xyz, const int* __restrict__ offset,
-                                                                    const int* __restrict__ new_offset, int m_total, int* __restrict__ idx,
-                                                                    float* __restrict__ dist2, int write_sqrt) {
-    extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* hd = smem_f + wave * 2 * nsample;          // heap distances [k]
-    int* hi = (int*)(hd + nsample);                   // heap indices   [k]
-    float* cand_d = smem_f + KNNW_WAVES * 2 * nsample + wave * 128;   // candidates of the current chunk
-    int* cand_i = (int*)(cand_d + 64);
-    for (int q = blockIdx.x * KNNW_WAVES + wave; q < m_total; q += gridDim.x * KNNW_WAVES) {
-        int seg = 0;
-        while (seg < nseg - 1 && q >= new_offset[seg]) ++seg;
-        const int start = seg == 0 ? 0 : offset[seg - 1], end = offset[seg];
+// the literal scan of ONE query by one wave (heap in LDS): identical to the reference down to the order of tied results
+__device__ __forceinline__ void knn_literal_query(int q, int start, int end, int nsample, int lane, const float* __restrict__ xyz,
+                                                  const float* __restrict__ new_xyz, float* hd, int* hi, float* cand_d, int* cand_i,
+                                                  int* __restrict__ idx, float* __restrict__ dist2, int write_sqrt) {
         const float qx = new_xyz[(size_t)q * 3], qy = new_xyz[(size_t)q * 3 + 1], qz = new_xyz[(size_t)q * 3 + 2];
         for (int i = lane; i < nsample; i += 64) { hd[i] = 1e10f; hi[i] = start; }
         __builtin_amdgcn_wave_barrier();
@@ -330,6 +320,67 @@ __global__ void __launch_bounds__(KNNW_WAVES * 64) knn_wave_kernel(int nsample, 
             dist2[(size_t)q * nsample + i] = write_sqrt ? sqrtf(d) : d;
         }
         __builtin_amdgcn_wave_barrier();
+}
+
+// One wave per query.  Fast path (nsample <= 16): the running k best live SORTED in the registers of lanes 0..k-1; a candidate
+// (taken in index order, re-tested with the same strict '<' against the current maximum as the reference's heap top) is placed
+// with one ballot + one DPP shift instead of an LDS reheap by a single lane -- the kernel was insertion-bound (k = 16 cost 5x
+// k = 1).  The SET of results evolves exactly like the reference's heap; its ascending output order is unique unless two results
+// have equal distances, and exactly then the query is redone by the literal heap scan above, so the output is the reference's in
+// every case.
+__global__ void __launch_bounds__(KNNW_WAVES * 64) knn_wave_kernel(int nsample, int nseg, const float* __restrict__ xyz,
+                                                                    const float* __restrict__ new_xyz, const int* __restrict__ offset,
+                                                                    const int* __restrict__ new_offset, int m_total, int* __restrict__ idx,
+                                                                    float* __restrict__ dist2, int write_sqrt) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* hd = smem_f + wave * 2 * nsample;          // heap distances [k]   (literal path)
+    int* hi = (int*)(hd + nsample);                   // heap indices   [k]
+    float* cand_d = smem_f + KNNW_WAVES * 2 * nsample + wave * 128;   // candidates of the current chunk
+    int* cand_i = (int*)(cand_d + 64);
+    for (int q = blockIdx.x * KNNW_WAVES + wave; q < m_total; q += gridDim.x * KNNW_WAVES) {
+        int seg = 0;
+        while (seg < nseg - 1 && q >= new_offset[seg]) ++seg;
+        const int start = seg == 0 ? 0 : offset[seg - 1], end = offset[seg];
+        if (nsample > 16) {
+            knn_literal_query(q, start, end, nsample, lane, xyz, new_xyz, hd, hi, cand_d, cand_i, idx, dist2, write_sqrt);
+            continue;
+        }
+        const float qx = new_xyz[(size_t)q * 3], qy = new_xyz[(size_t)q * 3 + 1], qz = new_xyz[(size_t)q * 3 + 2];
+        float bd = 1e10f;                             // lane l < k: l-th smallest distance so far (heap initialisation: (1e10, start))
+        int bi = start;
+        float top = 1e10f;
+        for (int k0 = start; k0 < end; k0 += 64) {
+            const int k = k0 + lane;
+            float d2 = 3e38f;
+            if (k < end) d2 = etch_sqdist(qx, qy, qz, xyz[(size_t)k * 3], xyz[(size_t)k * 3 + 1], xyz[(size_t)k * 3 + 2]);
+            unsigned long long mask = __ballot(d2 < top);
+            while (mask) {                                                   // wave-uniform: candidates in index order
+                const int e = __builtin_ctzll(mask);
+                mask &= mask - 1ull;
+                const float cd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), e));
+                if (cd < top) {                                              // re-test: the maximum shrinks as candidates go in
+                    const int pos = __popcll(__ballot(lane < nsample && bd <= cd));      // sorted list: a prefix
+                    const float pd = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bd), 0x111, 0xf, 0xf, true));   // row_shr:1
+                    const int pi = __builtin_amdgcn_update_dpp(0, bi, 0x111, 0xf, 0xf, true);
+                    if (lane == pos) { bd = cd; bi = k0 + e; }
+                    else if (lane > pos) { bd = pd; bi = pi; }
+                    top = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bd), nsample - 1));
+                }
+            }
+        }
+        // equal distances among the results (with different points): the order of the reference's heap_sort is not the sorted one
+        const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bd), 0x111, 0xf, 0xf, true));
+        const int previ = __builtin_amdgcn_update_dpp(0, bi, 0x111, 0xf, 0xf, true);
+        const bool tie = lane > 0 && lane < nsample && bd == prev && bi != previ;
+        if (__ballot(tie) != 0ull) {
+            knn_literal_query(q, start, end, nsample, lane, xyz, new_xyz, hd, hi, cand_d, cand_i, idx, dist2, write_sqrt);
+            continue;
+        }
+        if (lane < nsample) {
+            idx[(size_t)q * nsample + lane] = bi;
+            dist2[(size_t)q * nsample + lane] = write_sqrt ? sqrtf(bd) : bd;
+        }
     }
 }
 
