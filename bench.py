@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Headline benchmark of the ETCH hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU.  Either the driver launches the ranks (`python -m torch.distributed.run --nproc-per-node N bench.py ...`:
+RANK / LOCAL_RANK / WORLD_SIZE are then in the environment) or a plain `python bench.py --gpus N` launches them itself: the parent
+process -- which never touches the GPU -- starts N children with the rank environment, relays rank 0's JSON line and exits with
+the children's return code.  Every rank pins itself to the cores of its GPU's NUMA node before initialising the GPU.
 
 One step = one pass of the full hot path over one batch of synthetic scans already resident in HBM:
   stage 1  GT_network_equiv.forward (EPN encoder + confidence / direction / magnitude heads)
@@ -9,7 +14,8 @@ One step = one pass of the full hot path over one batch of synthetic scans alrea
   stage 2  get_markers + (30 + 50)-iteration LM SMPL fit + final full-mesh LBS
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 32 scans x 5000 points per GPU
 (weak scaling: every rank processes its own 32 scans; no collective on the data path; one RCCL all_gather of the
-per-scan result rows at the end of the job).  Prints ONE JSON line on rank 0.
+per-scan result rows at the end of the job).  Every step gets its own, distinct batch of scans (all resident in HBM before the
+timed region).  `--forward-only` measures BASELINE.json configs[1] (equivariant forward only) instead.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import collections
@@ -104,15 +110,18 @@ def profile_pass(run_step):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(n_points, gpu_pts, gpu_results, gpu_fit_aux, args, seed=1):
+def cpu_baseline(n_points, gpu_pts, gpu_results, gpu_fit_aux, args, seed=1, threads=None, forward_only=False):
     """The oracle (CPU restatement = "port") timed on this box's host cores on ONE scan of the same workload:
-    full stage 1 and the full 30 + 50 iteration LM fit.  Also returns parity numbers for that scan."""
+    full stage 1 and the full 30 + 50 iteration LM fit.  Also returns parity numbers for that scan.  `threads`: torch CPU
+    threads (default 32 or the core count if smaller: on the 128-thread GPU box the oracle's small-matrix stages run SLOWER
+    with every hardware thread than with 32, profiles/r02_cpu_baseline_threads.txt)."""
     from etch_amd.models.models_pointcloud import GT_network_equiv
     from etch_amd.utils.weights import seeded_state_dict
     from oracle import stage1 as S1
     from oracle import stage2 as S2
 
-    cores = torch.get_num_threads()
+    cores = threads or min(32, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
     cargs = types.SimpleNamespace(**{**vars(args), "device": torch.device("cpu")})
     sd = seeded_state_dict(GT_network_equiv(option=cargs), seed)
     table = S1.build_layer_table()
@@ -120,16 +129,19 @@ def cpu_baseline(n_points, gpu_pts, gpu_results, gpu_fit_aux, args, seed=1):
     t0 = time.time()
     out = S1.forward(sd, x, table, num_markers=len(args.markerset))
     t1 = time.time() - t0
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+    parity = {k: rel(gpu_results[k][:1].cpu(), out[k]) for k in ("part_labels", "confidences", "magnitude")}
     labels = out["part_labels"].argmax(-1)
+    parity["label_agreement"] = float((gpu_results["part_labels"][:1].cpu().argmax(-1) == labels).float().mean())
+    if forward_only:
+        return dict(value=1.0 / t1, unit="scans/s", cores=cores, kind="port",
+                    sample=f"1 scan x {n_points} pts: oracle stage 1 ({t1:.1f} s), torch CPU fp32, {cores} threads"), parity
     inner = x - out["direction"] * out["magnitude"] / args.scale_magnitude
     mv = np.array(list(args.markerset.values()))
     t0 = time.time()
     mk, valid = S2.get_markers(len(args.markerset), inner, labels, out["confidences"])
     fit = S2.fit_smpl(args.body_model, mv, mk, valid)
     t2 = time.time() - t0
-    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
-    parity = {k: rel(gpu_results[k][:1].cpu(), out[k]) for k in ("part_labels", "confidences", "magnitude")}
-    parity["label_agreement"] = float((gpu_results["part_labels"][:1].cpu().argmax(-1) == labels).float().mean())
     # fitter-only parity: the oracle LM on the GPU's own markers of scan 0
     gm, gv = gpu_fit_aux["markers"][:1].cpu(), gpu_fit_aux["valid"][:1].cpu()
     fit_g = S2.fit_smpl(args.body_model, mv, gm, gv)
@@ -143,7 +155,54 @@ def cpu_baseline(n_points, gpu_pts, gpu_results, gpu_fit_aux, args, seed=1):
     parity["pose_delta_rad_same_markers"] = float((gx[:, :69] - fit_g["pose"].reshape(1, 69)).abs().max())
     parity["betas_delta_same_markers"] = float((gx[:, 69:79] - fit_g["betas"].reshape(1, 10)).abs().max())
     return dict(value=1.0 / (t1 + t2), unit="scans/s", cores=cores, kind="port",
-                sample=f"1 scan x {n_points} pts: oracle stage 1 ({t1:.1f} s) + get_markers + full 30+50-iteration autograd LM fit ({t2:.1f} s), torch CPU fp32"), parity
+                sample=f"1 scan x {n_points} pts: oracle stage 1 ({t1:.1f} s) + get_markers + full 30+50-iteration autograd LM fit ({t2:.1f} s), torch CPU fp32, {cores} threads"), parity
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script as child processes and relay rank 0's output.
+    The parent must not (and does not) initialise the GPU; nothing is exec'ed.  Returns the exit code."""
+    import subprocess
+    import tempfile
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    with tempfile.TemporaryFile("w+") as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=None))
+        bad = []
+        while any(p.poll() is None for p in procs):
+            bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+            if bad:                                  # a rank died: its peers would wait in the next barrier for ever -> stop them (own children, by PID)
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                for p in procs:
+                    try:
+                        p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                break
+            time.sleep(0.05)
+        bad = bad or [(r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0]
+        out0.seek(0)
+        sys.stdout.write(out0.read())
+        sys.stdout.flush()
+    if bad:
+        print(f"bench.py: ranks failed (rank, rc): {bad}", file=sys.stderr)
+        return bad[0][1] if bad[0][1] and bad[0][1] > 0 else 1
+    return 0
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -154,7 +213,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="scans per GPU")
     ap.add_argument("--points", type=int, default=5000)
+    ap.add_argument("--forward-only", action="store_true", help="BASELINE.json configs[1]: a step is the equivariant forward only")
+    ap.add_argument("--same-batch", action="store_true", help="feed the same resident batch every step (default: a distinct batch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads of the cpu_baseline leg (0: min(32, cores))")
+    ap.add_argument("--no-pin", action="store_true", help="do not pin ranks to the cores of their GPU's NUMA node (N > 1 only)")
     ap.add_argument("--sync", action="store_true", help="synchronous steps (stage 2 of a batch finishes before stage 1 of the next starts). Default: the "
                     "2-deep stream pipeline of etch_amd.pipeline -- stage 2 of step i (32 persistent workgroups, 1/8 of the chip) runs on a second "
                     "HIP stream next to stage 1 of step i+1; every one of the K steps still completes inside the timed region")
@@ -162,88 +225,139 @@ def main():
     ap.add_argument("--stage1-streams", type=int, default=1, help="stage-1 streams the pipeline alternates over (batches in flight = this + 1)")
     ap.add_argument("--concurrent-heads", type=int, default=1, help="1: confidence / magnitude nets on their own streams next to the direction head")
     a = ap.parse_args()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))          # parent: no GPU call before or after this point
     if a.serial:
         a.sync, a.concurrent_heads = True, 0
-    a.pipeline = not a.sync
+    a.pipeline = not a.sync and not a.forward_only
 
     from etch_amd import parallel as P
-    from etch_amd.inference_demo import predict_smpl_batch
 
-    rank, world, local = P.init()
+    rank, world, local = P.env_rank_world()
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    if not torch.cuda.is_available():
-        raise RuntimeError("bench.py needs an MI355X: the product path has no CPU fallback")
-    if os.environ.get("ETCH_ALL_RANKS_DEVICE0"):      # smoke of the multi-rank control flow on a 1-GPU box (with ETCH_DIST_BACKEND=gloo)
-        local = 0
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    args, model = build(device)
-    model.concurrent_heads = bool(a.concurrent_heads)
-    if a.serial:
-        model.overlap_index_ops = False
+    pinned = None
+    if world > 1 and not a.no_pin:
+        pinned = P.pin_to_local_cores(local, world)             # before the GPU runtime starts its helper threads
+    dry = bool(os.environ.get("ETCH_BENCH_DRY"))                # control-flow test of the N > 1 path without a GPU (tests/test_parallel_gloo.py)
+    if dry and os.environ.get("ETCH_BENCH_DRY_FAIL_RANK") == str(rank):
+        sys.exit(3)                                             # failure injection for the launcher test
+    P.init("gloo" if dry else None)
+    if dry:
+        device = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise RuntimeError("bench.py needs an MI355X: the product path has no CPU fallback")
+        if os.environ.get("ETCH_ALL_RANKS_DEVICE0"):      # smoke of the multi-rank control flow on a 1-GPU box (with ETCH_DIST_BACKEND=gloo)
+            local = 0
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+    sync = (lambda: None) if dry else torch.cuda.synchronize
     B, N = a.batch, a.points
     s0, _ = P.shard_range(B * world, rank, world)
-    pts = torch.from_numpy(np.stack([synth_scan(s0 + i, N) for i in range(B)])).to(device)
+    # a distinct batch per timed step, all resident before the timed region: step k of rank r reads scans
+    # 1000 + k * (B * world) + [s0, s0 + B)  (k = 0 is the batch of the warm-up, the roofline pass and parity_scan0)
+    nbatch = 1 if a.same_batch else a.steps + 1
+    batches = [torch.from_numpy(np.stack([synth_scan(k * B * world + s0 + i, N) for i in range(B)])).to(device) for k in range(nbatch)]
+    pts = batches[0]
+    timed = [batches[(k + 1) % nbatch] for k in range(a.steps)]
     last = {}
+    if dry:
+        def step(p=pts):
+            time.sleep(0.002)
+            last.update(err=p[:, :, 0].mean(1).abs(), valid=torch.ones(B, 86, dtype=torch.bool), x=p[:, :85, 0].contiguous())
 
-    def step():
-        meshes, markers, valid, info, aux = predict_smpl_batch(args, model, pts, "neutral", return_trace=True)
-        last.update(markers=markers, valid=valid, verts=aux["verts"], x=aux["x"], err=aux["err_trace"][:, -1])
+        def run_steps(bs):
+            for p in bs:
+                step(p)
+    else:
+        from etch_amd.inference_demo import predict_smpl_batch
+        from etch_amd.pipeline import HotPathPipeline
+        args, model = build(device)
+        model.concurrent_heads = bool(a.concurrent_heads)
+        if a.serial:
+            model.overlap_index_ops = False
+        model_results = {}
 
-    from etch_amd.pipeline import HotPathPipeline
-    pipe = HotPathPipeline(args, model, "neutral", max_in_flight=a.stage1_streams + 1, stage1_streams=a.stage1_streams, want_trace=True)
+        def stage1_only(p=pts):
+            with torch.no_grad():
+                r, _ = model(p, ["confidence", "direction", "magnitude"], "standard_vector")
+            model_results.update(r)
 
-    def run_steps(k):
-        """k steps; with the pipeline, stage 2 of step i overlaps stage 1 of step i+1 (all k steps finish inside the call)."""
-        if not a.pipeline:
-            for _ in range(k):
-                step()
-            return
-        for meshes, markers, valid, info in pipe.run(pts for _ in range(k)):
-            pass
+        def full_step(p=pts):
+            meshes, markers, valid, info, aux = predict_smpl_batch(args, model, p, "neutral", return_trace=True)
+            last.update(markers=markers, valid=valid, verts=aux["verts"], x=aux["x"], err=aux["err_trace"][:, -1])
+
+        step = stage1_only if a.forward_only else full_step
+        pipe = HotPathPipeline(args, model, "neutral", max_in_flight=a.stage1_streams + 1, stage1_streams=a.stage1_streams, want_trace=True)
+
+        def run_steps(bs):
+            """One step per batch of `bs`; with the pipeline, stage 2 of step i overlaps stage 1 of step i+1 (all finish inside the call)."""
+            if not a.pipeline:
+                for p in bs:
+                    step(p)
+                return
+            for meshes, markers, valid, info in pipe.run(iter(bs)):
+                pass
 
     for _ in range(a.warmup):
         step()
-    run_steps(min(2, a.warmup))
+    run_steps([pts] * min(2, a.warmup))
     P.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
-    run_steps(a.steps)
-    torch.cuda.synchronize()
+    run_steps(timed)
+    sync()
     P.barrier()
     dt = P.max_over_ranks(time.perf_counter() - t0, device)
     # the same K steps without the cross-step overlap (untimed here; reported next to the headline for transparency)
-    torch.cuda.synchronize()
+    sync()
     ts = time.perf_counter()
-    for _ in range(min(a.steps, 5)):
-        step()      # synchronous steps; the last one also provides the per-scan result rows for the end-of-job gather
-    torch.cuda.synchronize()
-    sync_ms = (time.perf_counter() - ts) / min(a.steps, 5) * 1e3
+    for k in range(min(a.steps, 5)):
+        step(timed[k])
+    step(pts)           # batch 0 last: it provides the per-scan result rows for the end-of-job gather and parity_scan0
+    sync()
+    sync_ms = (time.perf_counter() - ts) / (min(a.steps, 5) + 1) * 1e3
 
-    # end-of-batch metric reduction: one all_gather of per-scan rows [final LM error, #valid markers, pose/shape norm]
-    rows = torch.stack([last["err"], last["valid"].float().sum(1), last["x"][:, :79].norm(dim=1)], 1)
+    # end-of-batch metric reduction (north_star: the only collective): ONE all_gather of per-scan result rows
+    #   [final LM error 0.5*|r|^2, #valid markers, RMS marker residual (mm), |pose| (rad), |betas|]
+    if a.forward_only and not dry:
+        conf = model_results["confidences"][..., 0]
+        rows = torch.stack([conf.mean(1), conf.amax(1), model_results["magnitude"][..., 0].mean(1)], 1)
+        row_names = ["mean confidence", "max confidence", "mean magnitude"]
+    else:
+        nv = last["valid"].float().sum(1)
+        rows = torch.stack([last["err"], nv, (2.0 * last["err"] / nv.clamp_min(1)).sqrt() * 1e3, last["x"][:, :69].norm(dim=1),
+                            last["x"][:, 69:79].norm(dim=1)], 1)
+        row_names = ["final LM error", "valid markers", "rms marker residual mm", "pose norm rad", "betas norm"]
     allrows = P.gather_rows(rows)
 
     if rank != 0:
         return
     value = world * B * a.steps / dt
-    out = {"metric": "scans/s (5k pts, eq-net + 50-iter SMPL fit)", "value": round(value, 3), "unit": "scans/s", "n_gpus": world,
+    finite = torch.isfinite(allrows).all(1)
+    cfg_name = (f"configs[1]: batch={B}/GPU synthetic {N}-pt Gaussian-blob scans, equivariant forward only (encoder + confidence / direction / "
+                "magnitude heads), seeded random weights" if a.forward_only else
+                f"configs[2]: batch={B}/GPU synthetic {N}-pt Gaussian-blob scans, full pipeline (eq-net + 30+50-iter LM SMPL fit), "
+                "seeded random weights, seeded SMPL-shaped body model, 86-marker superset")
+    sched = ("serial: synchronous steps, one stream" if a.serial else "synchronous steps") if not a.pipeline else \
+        "2-deep stream pipeline: stage 2 of step i overlaps stage 1 of step i+1"
+    out = {"metric": "scans/s (5k pts, eq-net forward only)" if a.forward_only else "scans/s (5k pts, eq-net + 50-iter SMPL fit)",
+           "value": round(value, 3), "unit": "scans/s", "n_gpus": world,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"configs[2]: batch={B}/GPU synthetic {N}-pt Gaussian-blob scans, full pipeline (eq-net + 30+50-iter LM SMPL fit), "
-                                  "seeded random weights, seeded SMPL-shaped body model, 86-marker superset",
-                      "schedule": ("serial: synchronous steps, one stream" if a.serial else "synchronous steps") if not a.pipeline else "2-deep stream pipeline: stage 2 of step i overlaps stage 1 of step i+1",
-                      "global_batch": B * world, "points": N, "parallelism": f"scan-sharded x{world}"},
-           "mean_final_lm_error": float(allrows[:, 0].mean()), "scans_reported": int(allrows.shape[0]),
-           "ms_per_step_synchronous": round(sync_ms, 3), "peak_hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2)}
+           "config": {"workload": cfg_name, "schedule": sched, "global_batch": B * world, "points": N, "parallelism": f"scan-sharded x{world}",
+                      "distinct_batches": nbatch, "launcher": "torchrun/env" if "TORCHELASTIC_RUN_ID" in os.environ else ("self" if world > 1 else "single"),
+                      "cpu_pinning": None if pinned is None else f"rank 0 on {len(pinned)} NUMA-local cores"},
+           "gathered_rows": {"columns": row_names, "scans_reported": int(allrows.shape[0]), "finite_scans": int(finite.sum()),
+                             "mean": [float(v) for v in allrows[finite].mean(0)] if bool(finite.any()) else None},
+           "ms_per_step_synchronous": round(sync_ms, 3)}
+    if dry:
+        out["dry_run"] = True
+        print(json.dumps(out), flush=True)
+        return
+    out["peak_hbm_gib"] = round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2)
 
-    # roofline of the dominant kernel: one instrumented pass of the same step (HIP events on the launch stream)
-    model_results = {}
-
-    def stage1_only():
-        r, _ = model(pts, ["confidence", "direction", "magnitude"], "standard_vector")
-        model_results.update(r)
-
+    # roofline of the dominant kernel: one instrumented pass of the same step (HIP events on the launch stream).
     # the instrumented pass runs the step on ONE stream (no heads / index ops on side streams): with kernels of several
     # streams resident at once a HIP-event bracket measures contention, not the kernel (`bench.py --serial` runs the whole
     # job in that schedule; profiles/*_serial_kernel_stats.txt is its rocprofv3 summary)
@@ -284,13 +398,13 @@ def main():
     out["kernel_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]}
     total_flops = sum(v["flops"] for v in agg.values())
     out["whole_step_mfma_frac"] = round(total_flops / (dt / a.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
-    if N == 5000:
+    if N == 5000 and not a.forward_only:
         # 152.4 GFLOP matmul / conv + 5.2 GFLOP kernel-weight generation per 5 000-point scan -> 1.0 ms at the fp32-MFMA
         # peak, HBM-side 0.05 ms: ceiling ~ 1 030 scans/s per GPU for the whole path
         out["path_roofline"] = {"ceiling_scans_per_s_per_gpu": 1030, "frac": round(value / world / 1030.0, 4)}
 
     if world == 1 and not a.no_cpu_baseline:
-        cb, parity = cpu_baseline(N, pts, model_results, last, args)
+        cb, parity = cpu_baseline(N, pts, model_results, last, args, threads=a.cpu_threads or None, forward_only=a.forward_only)
         out["cpu_baseline"] = cb
         out["parity_scan0"] = parity
     print(json.dumps(out), flush=True)

@@ -431,16 +431,9 @@ __device__ void lm_solve(LmShared& s, int M, double lambda) {
     if (tid == 0) { const long long t1 = wall_clock64(); s.phase[4] += t1 - t0; }
 }
 
-__global__ void __launch_bounds__(LM_THREADS) smpl_lm_fit_kernel(SmplConsts C, int M, const float* __restrict__ markers,
-                                                                const float* __restrict__ valid, int it0, float step0, float damp0,
-                                                                int it1, float step1, float damp1, float* __restrict__ x_out,
-                                                                float* __restrict__ x_stage0, float* __restrict__ err_trace, long long* __restrict__ phase_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lm_smem[];
-    LmShared& s = *reinterpret_cast<LmShared*>(lm_smem);
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const float* target = markers + (size_t)b * M * 3;
-    const float* mask = valid + (size_t)b * M;
-    if (tid < DOF) s.x[tid] = 0.0;
+// per-scan constants into LDS: parents, joint shape basis, targets, subtree membership masks
+__device__ void lm_setup(LmShared& s, const SmplConsts& C, int M, const float* target, const float* mask) {
+    const int tid = threadIdx.x;
     if (tid < 8) s.phase[tid] = 0;
     if (tid < NJ) s.parents[tid] = C.parents[tid];
     for (int i = tid; i < NJ * 3 * NB; i += LM_THREADS) s.Jd[i] = C.Jd[i];
@@ -458,6 +451,19 @@ __global__ void __launch_bounds__(LM_THREADS) smpl_lm_fit_kernel(SmplConsts C, i
         s.sub[tid] = m;
     }
     __syncthreads();
+}
+
+__global__ void __launch_bounds__(LM_THREADS) smpl_lm_fit_kernel(SmplConsts C, int M, const float* __restrict__ markers,
+                                                                const float* __restrict__ valid, int it0, float step0, float damp0,
+                                                                int it1, float step1, float damp1, float* __restrict__ x_out,
+                                                                float* __restrict__ x_stage0, float* __restrict__ err_trace, long long* __restrict__ phase_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lm_smem[];
+    LmShared& s = *reinterpret_cast<LmShared*>(lm_smem);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* target = markers + (size_t)b * M * 3;
+    const float* mask = valid + (size_t)b * M;
+    if (tid < DOF) s.x[tid] = 0.0;
+    lm_setup(s, C, M, target, mask);
     int trace_pos = 0;
     for (int stage = 0; stage < 2; ++stage) {
         const int iters = stage == 0 ? it0 : it1;
@@ -488,6 +494,43 @@ __global__ void __launch_bounds__(LM_THREADS) smpl_lm_fit_kernel(SmplConsts C, i
     }
     if (tid < DOF) x_out[(size_t)b * DOF + tid] = (float)s.x[tid];
     if (phase_out && tid < 8) phase_out[(size_t)b * 8 + tid] = s.phase[tid];
+}
+
+
+// ---------------------------------------------------------------------------------------------- diagnostics (tests)
+// One linearisation of the LM kernel at a caller-given x: residual (B,3M) and the analytic Jacobian (B,3M,85) exactly as the
+// fit forms them (same device function, same LDS state) -- lets a test compare the analytic marker-restricted Jacobian with
+// autograd through the full-mesh LBS (the reference's AutoDiffCostFunction formulation, fit_SMPL.py:176-183).
+__global__ void __launch_bounds__(LM_THREADS) smpl_lm_linearize_kernel(SmplConsts C, int M, int nb, const float* __restrict__ x_in,
+                                                                      const float* __restrict__ markers, const float* __restrict__ valid,
+                                                                      float* __restrict__ resid, float* __restrict__ jac) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lm_smem[];
+    LmShared& s = *reinterpret_cast<LmShared*>(lm_smem);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* target = markers + (size_t)b * M * 3;
+    const float* mask = valid + (size_t)b * M;
+    if (tid < DOF) s.x[tid] = (double)x_in[(size_t)b * DOF + tid];
+    lm_setup(s, C, M, target, mask);
+    lm_linearize(s, C, M, nb, target, mask);
+    for (int i = tid; i < M * 3; i += LM_THREADS) resid[(size_t)b * M * 3 + i] = s.resid[i];
+    for (int i = tid; i < M * 3 * DOF; i += LM_THREADS) {
+        const int r = i / DOF, c = i - r * DOF;
+        jac[(size_t)b * M * 3 * DOF + i] = s.Jm[r * LDJ + c];
+    }
+}
+
+// rodrigues_d of the LM / LBS kernels on n rotation vectors: R (n,9) fp64 and dR/dtheta_q (n,3,9) -- pinned by the golden
+// emitted from the in-tree batch_rodrigues (src/data_utils/GT_dataloader_mixed.py:29-64).
+__global__ void __launch_bounds__(64) rodrigues_kernel(int n, const float* __restrict__ theta, double* __restrict__ R, float* __restrict__ dR) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const double th[3] = {(double)theta[i * 3], (double)theta[i * 3 + 1], (double)theta[i * 3 + 2]};
+    double Rl[9];
+    float d[3][9];
+    rodrigues_d(th, Rl, d, true);
+    for (int e = 0; e < 9; ++e) R[(size_t)i * 9 + e] = Rl[e];
+    for (int q = 0; q < 3; ++q)
+        for (int e = 0; e < 9; ++e) dR[((size_t)i * 3 + q) * 9 + e] = d[q][e];
 }
 
 // ---------------------------------------------------------------------------------------------- full-mesh LBS
@@ -686,6 +729,27 @@ int etch_smpl_lm_fit(int B, int M, const void* const* consts, const float* marke
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(smpl_lm_fit_kernel, dim3(B), dim3(LM_THREADS), lds, (hipStream_t)stream, C, M, markers, valid, it0, step0, damp0, it1,
                        step1, damp1, x_out, x_stage0, err_trace, phase_ticks);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_smpl_lm_linearize(int B, int M, int nb, const void* const* consts, const float* x, const float* markers, const float* valid,
+                           float* resid, float* jac, void* stream) {
+    if (B <= 0) return ETCH_OK;
+    if (M <= 0 || M > MAXM || nb < 0 || nb > NB) return ETCH_EUNSUPPORTED;
+    SmplConsts C{(const float*)consts[0], (const float*)consts[1], (const int*)consts[2], (const float*)consts[3], (const float*)consts[4],
+                 (const float*)consts[5], (const float*)consts[6]};
+    const int lds = (int)sizeof(LmShared);
+    hipError_t e = hipFuncSetAttribute((const void*)smpl_lm_linearize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(smpl_lm_linearize_kernel, dim3(B), dim3(LM_THREADS), lds, (hipStream_t)stream, C, M, nb, x, markers, valid, resid, jac);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_rodrigues(int n, const float* theta, double* R, float* dR, void* stream) {
+    if (n <= 0) return ETCH_OK;
+    hipLaunchKernelGGL(rodrigues_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, theta, R, dR);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }

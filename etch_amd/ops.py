@@ -459,6 +459,27 @@ def smpl_lm_fit(consts, markers, valid_f, it0, step0, damp0, it1, step1, damp1, 
     return x, x0, tr
 
 
+def smpl_lm_linearize(consts, x, markers, valid_f, nb):
+    """Diagnostics: residual (B,3M) and analytic Jacobian (B,3M,85) of the LM kernel at x."""
+    B, M = valid_f.shape
+    arr = (ctypes.c_void_p * 7)(*[t.data_ptr() for t in consts])
+    r = torch.empty((B, 3 * M), dtype=torch.float32, device=x.device)
+    J = torch.empty((B, 3 * M, 85), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().etch_smpl_lm_linearize(B, M, int(nb), arr, _ptr(x), _ptr(markers), _ptr(valid_f), _ptr(r), _ptr(J), _stream()),
+               "etch_smpl_lm_linearize")
+    return r, J
+
+
+def rodrigues(theta):
+    """theta (n,3) fp32 -> R (n,3,3) fp64, dR (n,3,3,3) with dR[n,q] = dR/dtheta_q."""
+    _need(theta, torch.float32, "theta")
+    n = theta.shape[0]
+    R = torch.empty((n, 3, 3), dtype=torch.float64, device=theta.device)
+    dR = torch.empty((n, 3, 3, 3), dtype=torch.float32, device=theta.device)
+    _lib.check(_lib.lib().etch_rodrigues(n, _ptr(theta), _ptr(R), _ptr(dR), _stream()), "etch_rodrigues")
+    return R, dR
+
+
 def smpl_lbs(consts, x, V, n_extra):
     B = x.shape[0]
     arr = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in consts])

@@ -22,6 +22,92 @@ def init(backend=None):
     return rank, world, local
 
 
+# ---------------------------------------------------------------------------------------------- host-side placement
+def _read_props(path):
+    out = {}
+    try:
+        with open(path) as f:
+            for line in f:
+                k, _, v = line.strip().partition(" ")
+                if v.strip().lstrip("-").isdigit():
+                    out[k] = int(v)
+    except OSError:
+        pass
+    return out
+
+
+def _parse_cpulist(txt):
+    cpus = set()
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_nodes(kfd_root="/sys/class/kfd/kfd/topology/nodes"):
+    """NUMA node of every GPU in HIP ordinal order, read from the KFD topology in sysfs (NO HIP call: this runs before the
+    process touches the GPU).  KFD lists CPU nodes (cpu_cores_count > 0; node id == NUMA node) and GPU nodes (simd_count > 0,
+    in the order HIP enumerates them); a GPU's io_link to a CPU node names its NUMA-local socket.  [] when sysfs has no KFD."""
+    try:
+        ids = sorted(int(d) for d in os.listdir(kfd_root) if d.isdigit())
+    except OSError:
+        return []
+    props = {i: _read_props(os.path.join(kfd_root, str(i), "properties")) for i in ids}
+    cpu_nodes = [i for i in ids if props[i].get("cpu_cores_count", 0) > 0]
+    out = []
+    for i in ids:
+        if props[i].get("simd_count", 0) <= 0 or props[i].get("cpu_cores_count", 0) > 0:
+            continue
+        numa = None
+        links = os.path.join(kfd_root, str(i), "io_links")
+        try:
+            for l in sorted(os.listdir(links)):
+                to = _read_props(os.path.join(links, l, "properties")).get("node_to")
+                if to in cpu_nodes:
+                    numa = cpu_nodes.index(to)
+                    break
+        except OSError:
+            pass
+        out.append(numa)
+    return out
+
+
+def local_cpu_set(local, world, kfd_root="/sys/class/kfd/kfd/topology/nodes", node_root="/sys/devices/system/node"):
+    """The host cores rank `local` of `world` ranks on this node should run on: the cores of its GPU's NUMA node, split evenly
+    among the ranks whose GPUs share that node (the host enqueues ~400 launches per step, so each rank wants its own
+    NUMA-local cores).  Falls back to an even contiguous split of the current affinity mask when the topology is unreadable."""
+    avail = sorted(os.sched_getaffinity(0))
+    numa = gpu_numa_nodes(kfd_root)
+    if local < len(numa) and numa[local] is not None:
+        try:
+            with open(os.path.join(node_root, f"node{numa[local]}", "cpulist")) as f:
+                cpus = sorted(_parse_cpulist(f.read()) & set(avail))
+        except OSError:
+            cpus = []
+        sharing = [r for r in range(min(world, len(numa))) if numa[r] == numa[local]]
+        if cpus and local in sharing:
+            k, n = sharing.index(local), len(sharing)
+            per = max(1, len(cpus) // n)
+            mine = cpus[k * per:(k + 1) * per] if k < n - 1 else cpus[k * per:]
+            if mine:
+                return mine
+    per = max(1, len(avail) // max(world, 1))
+    mine = avail[local * per:(local + 1) * per]
+    return mine or avail
+
+
+def pin_to_local_cores(local, world):
+    """sched_setaffinity of the calling process (call BEFORE GPU initialisation so the runtime's helper threads inherit it)."""
+    cpus = local_cpu_set(local, world)
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        return sorted(os.sched_getaffinity(0))
+    return cpus
+
+
 def _coll(t):
     """Tensor as the active backend can take it: gloo collectives run on host copies (used by CPU tests and by the
     single-GPU smoke of the multi-rank control flow); RCCL takes the device tensor as is."""

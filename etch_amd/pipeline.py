@@ -12,6 +12,7 @@ from .models.fit_SMPL import fit_smpl_device, fit_smpl_finalize, fit_smpl_stage_
 class Ticket:
     def __init__(self, done, stage1, fit):
         self.done, self.stage1, self.fit = done, stage1, fit
+        self.finalized = None           # host-side result, set when the ticket was retired early to free its pinned buffers
 
 
 class HotPathPipeline:
@@ -27,7 +28,13 @@ class HotPathPipeline:
         self._n = 0
 
     def submit(self, points):
-        """Enqueue one batch (B,N,3) resident on the device; returns a Ticket.  Never blocks on the GPU."""
+        """Enqueue one batch (B,N,3) resident on the device; returns a Ticket.  Does not block on the GPU unless
+        `max_in_flight` batches are already outstanding: the pinned host buffers are a ring of max_in_flight + 1 slots, so the
+        oldest ticket is then retired first (host waits for it; its result is kept on the ticket for result())."""
+        while len(self.in_flight) >= self.max_in_flight:
+            oldest = self.in_flight.pop(0)
+            oldest.done.synchronize()
+            oldest.finalized = fit_smpl_finalize(oldest.fit)
         caller = torch.cuda.current_stream()
         s1 = self.s1s[self._n % len(self.s1s)]
         s1.wait_stream(caller)
@@ -68,6 +75,8 @@ class HotPathPipeline:
 
     def result(self, ticket):
         """Wait for one batch and return the reference's fit_smpl tuple (meshes, markers, valid, smpl_info)."""
+        if ticket.finalized is not None:
+            return ticket.finalized
         ticket.done.synchronize()
         if ticket in self.in_flight:
             self.in_flight.remove(ticket)

@@ -247,6 +247,16 @@ int etch_smpl_lm_fit(int B, int M, const void* const* consts, const float* marke
                      long long* phase_ticks, void* stream);
 int etch_smpl_lm_workspace_bytes(void);
 
+/* Diagnostics of the LM kernel (tests): ONE linearisation at a caller-given x (B,85) with nb active betas -> residual
+ * (B,3M) = mask * (target - markers(x)) (fit_SMPL.py:127-131) and the analytic Jacobian d resid / d x (B,3M,85) the fit uses in
+ * place of the reference's autograd Jacobian (AutoDiffCostFunction, fit_SMPL.py:176-183, 227-234). */
+int etch_smpl_lm_linearize(int B, int M, int nb, const void* const* consts, const float* x, const float* markers, const float* valid,
+                           float* resid, float* jac, void* stream);
+
+/* batch_rodrigues as the fit evaluates it (in-tree copy src/data_utils/GT_dataloader_mixed.py:29-64, angle = |theta + 1e-8|):
+ * theta (n,3) -> R (n,9) fp64 and dR/dtheta_q (n,3,9). */
+int etch_rodrigues(int n, const float* theta, double* R, float* dR, void* stream);
+
 /* Final smpl_model(...) (fit_SMPL.py:258-259, smplx.SMPL.forward upstream): x (B,85) -> verts (B,V,3), joints
  * (B,24+n_extra,3).  consts = 8 device pointers {v_template (V,3), shapedirs (V,3,10), posedirs (207,V*3),
  * lbs_weights (V,24), J0, Jd, parents, extra_vids (n_extra) i32}. */

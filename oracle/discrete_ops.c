@@ -23,11 +23,28 @@
 #include <stdlib.h>
 #include <string.h>
 
-static inline float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
-    float dx = ax - bx, dy = ay - by, dz = az - bz;
-    float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+/* ORC_FMA selects the contraction of a*a + b*b + c*c (default 0 = none, the contract of record).  The reference binary is
+ * built by nvcc, whose default -fmad=true MAY contract these expressions; which form it picks is not knowable here, so the two
+ * plausible ones are provided ONLY for tests/test_oracle_ops.py::test_fma_contraction_sensitivity, which counts how many index
+ * decisions depend on the choice:  1: fma(c,c, fma(b,b, a*a))   2: fma(c,c, fma(a,a, b*b)). */
+#ifndef ORC_FMA
+#define ORC_FMA 0
+#endif
+static inline float sumsq3(float a, float b, float c) {
+#if ORC_FMA == 1
+    return fmaf(c, c, fmaf(b, b, a * a));
+#elif ORC_FMA == 2
+    return fmaf(c, c, fmaf(a, a, b * b));
+#else
+    float xx = a * a, yy = b * b, zz = c * c;
     float s = xx + yy;
     return s + zz;
+#endif
+}
+
+static inline float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return sumsq3(dx, dy, dz);
 }
 
 /* min(1024, 2^floor(log2 n)) computed exactly the way the host code does (double log ratio). */
@@ -97,7 +114,7 @@ void orc_fps_vgtk(int b, int n, int m, const float* xyz, int32_t* idx) {
                 int besti = 0; float best = -1.0f;
                 for (int k = tid; k < n; k += bs) {
                     float x2 = X[k], y2 = X[n + k], z2 = X[2 * n + k];
-                    float mag = ((x2 * x2) + (y2 * y2)) + (z2 * z2);
+                    float mag = sumsq3(x2, y2, z2);
                     if ((double)mag <= 1e-3) continue;
                     float d = sqdist(x2, y2, z2, x1, y1, z1);
                     float d2 = d < temp[k] ? d : temp[k];   /* min(d, temp[k]) */
@@ -138,7 +155,7 @@ void orc_fps_vgtk_keyed(int b, int n, int m, const float* xyz, int32_t* idx) {
             uint64_t bestkey = 0; int besti = 0;
             for (int k = 0; k < n; ++k) {
                 float x2 = X[k], y2 = X[n + k], z2 = X[2 * n + k];
-                float mag = ((x2 * x2) + (y2 * y2)) + (z2 * z2);
+                float mag = sumsq3(x2, y2, z2);
                 if ((double)mag <= 1e-3) continue;
                 float d = sqdist(x2, y2, z2, x1, y1, z1);
                 float d2 = d < temp[k] ? d : temp[k];

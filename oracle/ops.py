@@ -14,10 +14,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "liboracle_ops.so")
 _lib = None
+_variants = {}
 
 
 def build(force=False):
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "discrete_ops.c")):
+    src_t = os.path.getmtime(os.path.join(_HERE, "discrete_ops.c"))
+    sos = [_SO] + [os.path.join(_HERE, "_build", f"liboracle_ops_fma{k}.so") for k in (1, 2)]
+    if force or any(not os.path.exists(p) or os.path.getmtime(p) < src_t for p in sos):
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _SO
 
@@ -29,6 +32,30 @@ def lib():
         _lib = ctypes.CDLL(_SO)
         _lib.orc_opt_n_threads.restype = ctypes.c_int
     return _lib
+
+
+class variant:
+    """Context manager: route every op of this module through liboracle_ops_fma<k>.so (k = 1, 2: the two plausible nvcc
+    contractions of the squared distance, discrete_ops.c ORC_FMA).  Tests only."""
+
+    def __init__(self, k):
+        self.k = int(k)
+
+    def __enter__(self):
+        global _lib
+        lib()
+        self.prev = _lib
+        if self.k:
+            if self.k not in _variants:
+                v = ctypes.CDLL(os.path.join(_HERE, "_build", f"liboracle_ops_fma{self.k}.so"))
+                v.orc_opt_n_threads.restype = ctypes.c_int
+                _variants[self.k] = v
+            _lib = _variants[self.k]
+        return self
+
+    def __exit__(self, *a):
+        global _lib
+        _lib = self.prev
 
 
 def _p(a):

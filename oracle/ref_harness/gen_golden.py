@@ -194,13 +194,125 @@ def gen_markers(ms, seed=6):
     save("markers.npz", points=pts, labels=labels, conf=conf, markers=mk, valid=valid)
 
 
+
+def _run_ref(model, x, seed=1, hooks=True):
+    """Reference forward with seeded weights; returns (out dict, anc_w [B,N,60])."""
+    model.load_state_dict(seeded_state_dict(model, seed))
+    cap = {}
+    h1 = model.so3_reg.register_forward_hook(lambda m, i, o: cap.__setitem__("anc_w", o.detach().squeeze(1)))
+    with torch.no_grad(), R.quiet():
+        out, _ = model(x, ["confidence", "direction", "magnitude"], "standard_vector")
+    h1.remove()
+    return out, cap["anc_w"].view(x.shape[0], x.shape[1], 60)
+
+
+def _save_model_run(name, x, out, anc_w, sub, **extra):
+    """Full-size runs are stored row-subsampled (every `sub`-th point) plus the argmax label of EVERY point, so a
+    5 000 / 20 000-point fixture stays small; `rows` names the stored points."""
+    rows = np.arange(0, x.shape[1], sub)
+    save(name, seed=1, points=x, rows=rows, part_labels=out["part_labels"][:, rows], labels=out["part_labels"].argmax(-1).to(torch.uint8),
+         confidences=out["confidences"], magnitude=out["magnitude"], direction=out["direction"], anc_w=anc_w[:, rows], **extra)
+
+
+def gen_scan4d(model):
+    """BASELINE configs[0]'s geometry: the bundled 4D-Dress scan, centred like inference_demo.py:19-34, 5 000 surface points
+    drawn by OUR seeded sampler (the reference's trimesh sampler is unseeded, inference_demo.py:38), through the
+    reference's Python forward with seeded weights."""
+    from etch_amd import inference_demo as D
+
+    obj = os.path.join(R.REF, "datafolder", "4D-DRESS", "data_processed", "model", "00122_Inner_Take2_00011", "00122_Inner_Take2_00011.obj")
+    centred, centre = D.preprocess_scan(obj)
+    pts = D.sample_points_from_mesh(centred, 5000, seed=0).astype(np.float32)
+    x = torch.from_numpy(pts[None])
+    out, anc_w = _run_ref(model, x)
+    _save_model_run("scan_4ddress_5k.npz", x, out, anc_w, 4, scan_center=centre)
+
+
+def gen_model5k(model):
+    """The metric's own workload (configs[1]/[2]: batch 32 of synthetic 5 000-point scans, seeds 1000 + b): scans 0 and 31
+    of that batch through the reference's Python."""
+    ids = [0, 31]
+    x = torch.from_numpy(np.stack([scan(1000 + i, 5000) for i in ids]))
+    out, anc_w = _run_ref(model, x)
+    _save_model_run("model_n5000.npz", x, out, anc_w, 4, scan_ids=np.array(ids))
+
+
+def gen_model20k(model):
+    """configs[4]'s geometry: one dense 20 000-point synthetic scan (bench seed 1000) through the reference's Python."""
+    x = torch.from_numpy(scan(1000, 20000)[None])
+    out, anc_w = _run_ref(model, x)
+    _save_model_run("model_n20000.npz", x, out, anc_w, 16)
+
+
+def gen_padding_fp64(model, ms):
+    """Conditioning evidence for SURVEY 8d's padding-heavy distribution (sigma = 0.20, 0.45, 0.12; B = 2, N = 2 000, seeds
+    700 + b): the REFERENCE Python run in fp32 and in fp64 on the same input and weights.  Stored: the fp64 anchor weights
+    and, per point, how far the reference's own fp32 run lands from them -- the error any fp32 implementation is entitled to."""
+    B, N = 2, 2000
+    x = torch.from_numpy(np.stack([(np.random.default_rng(700 + b).standard_normal((N, 3)) * np.array([0.20, 0.45, 0.12])).astype(np.float32)
+                                   for b in range(B)]))
+    out32, w32 = _run_ref(model, x)
+    m64 = R.build_reference_model(tempfile.mkdtemp(), ms).double()
+    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in seeded_state_dict(model, 1).items()}
+    m64.load_state_dict(sd)
+    m64.standard_vector = m64.standard_vector.double()          # plain attribute, not a buffer (models_pointcloud.py:64)
+    cap = {}
+    h = m64.so3_reg.register_forward_hook(lambda m, i, o: cap.__setitem__("anc_w", o.detach().squeeze(1)))
+    # the reference hard-codes `.float()` on freshly built tensors (occupancy features, shadow rows: vgtk functional.py:74,
+    # 98-104): for this one study they are redirected to double so that the whole encoder really runs in fp64
+    _float, _default = torch.Tensor.float, torch.get_default_dtype()
+    torch.Tensor.float = lambda self, *a, **k: self.double()
+    torch.set_default_dtype(torch.float64)
+    try:
+        with torch.no_grad(), R.quiet():
+            out64, _ = m64(x.double(), ["direction"], "standard_vector")
+    finally:
+        torch.Tensor.float = _float
+        torch.set_default_dtype(_default)
+    h.remove()
+    w64 = cap["anc_w"].view(B, N, 60)
+    scale = float(w64.abs().max())
+    dev32 = ((w32.double() - w64).abs().amax(-1) / scale).float()
+    save("padding_heavy_fp64.npz", points=x, anc_w_fp64=w64.float(), ref_fp32_dev=dev32, scale=scale)
+    print("padding-heavy: reference fp32 vs fp64 anc_w deviation  max %.3e  99.9%% %.3e  median %.3e" %
+          (float(dev32.max()), float(dev32.flatten().quantile(0.999)), float(dev32.median())))
+
+
+def gen_rodrigues():
+    """batch_rodrigues as the tree holds it (src/data_utils/GT_dataloader_mixed.py:29-64, the verbatim copy of
+    smplx.lbs.batch_rodrigues): the function is compiled FROM THE REFERENCE FILE at run time (its module imports packages
+    absent here), evaluated in fp32 and fp64, with its Jacobian dR/dtheta by autograd in fp64 -- at theta = 0, tiny, random,
+    and |theta| ~ pi."""
+    import ast
+
+    src = open(os.path.join(R.REF, "src", "data_utils", "GT_dataloader_mixed.py")).read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "batch_rodrigues")
+    ns = {"torch": torch, "Tensor": torch.Tensor}
+    exec(compile(ast.Module([fn], []), "GT_dataloader_mixed.py", "exec"), ns)
+    ref = ns["batch_rodrigues"]
+    rng = np.random.default_rng(11)
+    th = [np.zeros((1, 3)), np.array([[1e-6, -2e-6, 3e-7], [1e-4, 0, 0], [0, 0, -3e-3]]), rng.standard_normal((24, 3)) * 0.4,
+          rng.standard_normal((8, 3)) * 1.5]
+    d = rng.standard_normal((8, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    th.append(d * (np.pi + np.array([-1e-3, -1e-5, 0, 1e-5, 1e-3, 0.05, -0.05, 0.3])[:, None]))
+    th = np.concatenate(th).astype(np.float32)
+    t32, t64 = torch.from_numpy(th), torch.from_numpy(th).double()
+    with torch.no_grad():
+        R32, R64 = ref(t32), ref(t64)
+    J = torch.stack([torch.autograd.functional.jacobian(lambda v: ref(v[None])[0], t) for t in t64])   # [n,3,3,3]: dR_ij/dtheta_q at [..., q]
+    save("rodrigues.npz", theta=th, R_fp32=R32, R_fp64=R64, dR_fp64=J)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ms = json.load(open(MARKERSET))
     model = R.build_reference_model(tempfile.mkdtemp(), ms)
     only = sys.argv[1:]
     steps = {"constants": lambda: gen_constants(model, ms), "so3block": gen_so3_block, "direction": lambda: gen_direction(model),
-             "propagation": gen_propagation, "pt": gen_pt, "markers": lambda: gen_markers(ms), "model": lambda: gen_model(model)}
+             "propagation": gen_propagation, "pt": gen_pt, "markers": lambda: gen_markers(ms), "model": lambda: gen_model(model), "scan4d": lambda: gen_scan4d(model),
+             "model5k": lambda: gen_model5k(model), "model20k": lambda: gen_model20k(model), "padding_fp64": lambda: gen_padding_fp64(model, ms),
+             "rodrigues": gen_rodrigues}
     for name, fn in steps.items():
         if not only or name in only:
             fn()

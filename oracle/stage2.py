@@ -41,8 +41,9 @@ def get_markers(num_markers, inner_points, part_labels, confidences):
 
 
 class TorchBody:
-    def __init__(self, bm):
-        t = torch.from_numpy
+    def __init__(self, bm, dtype=torch.float32):
+        t = lambda a: torch.from_numpy(a).to(dtype) if a.dtype.kind == "f" else torch.from_numpy(a)
+        self.dtype = dtype
         self.v_t, self.S, self.P = t(bm.v_template), t(bm.shapedirs), t(bm.posedirs)
         self.Jreg, self.W = t(bm.J_regressor), t(bm.lbs_weights)
         self.parents = [int(p) for p in bm.parents]
@@ -58,7 +59,7 @@ def rodrigues(r):
     rx, ry, rz = d[:, 0:1], d[:, 1:2], d[:, 2:3]
     z = torch.zeros_like(rx)
     K = torch.cat([z, -rz, ry, rz, z, -rx, -ry, rx, z], 1).view(-1, 3, 3)
-    return torch.eye(3)[None] + s * K + (1 - c) * torch.bmm(K, K)
+    return torch.eye(3, dtype=r.dtype)[None] + s * K + (1 - c) * torch.bmm(K, K)
 
 
 def lbs(tb, betas, pose72, transl):
@@ -67,19 +68,19 @@ def lbs(tb, betas, pose72, transl):
     v_s = tb.v_t[None] + torch.einsum("bl,mkl->bmk", betas, tb.S)
     Jl = torch.einsum("bik,ji->bjk", v_s, tb.Jreg)
     R = rodrigues(pose72.reshape(-1, 3)).view(B, J, 3, 3)
-    pf = (R[:, 1:] - torch.eye(3)).reshape(B, -1)
+    pf = (R[:, 1:] - torch.eye(3, dtype=R.dtype)).reshape(B, -1)
     v_p = v_s + (pf @ tb.P).view(B, -1, 3)
     par = torch.tensor(tb.parents[1:])
     rel = torch.cat([Jl[:, :1], Jl[:, 1:] - Jl[:, par]], 1)
-    T = torch.cat([torch.cat([R, rel[..., None]], -1), torch.tensor([0, 0, 0, 1.0]).expand(B, J, 1, 4)], -2)
+    T = torch.cat([torch.cat([R, rel[..., None]], -1), torch.tensor([0, 0, 0, 1.0], dtype=R.dtype).expand(B, J, 1, 4)], -2)
     chain = [T[:, 0]]
     for i in range(1, J):
         chain.append(chain[tb.parents[i]] @ T[:, i])
     G = torch.stack(chain, 1)
-    Jh = torch.cat([Jl, torch.zeros(B, J, 1)], -1)[..., None]
+    Jh = torch.cat([Jl, torch.zeros(B, J, 1, dtype=R.dtype)], -1)[..., None]
     A = G - torch.nn.functional.pad(G @ Jh, (3, 0))
     Tm = (tb.W[None].expand(B, -1, -1) @ A.view(B, J, 16)).view(B, -1, 4, 4)
-    vh = torch.cat([v_p, torch.ones(B, v_p.shape[1], 1)], -1)[..., None]
+    vh = torch.cat([v_p, torch.ones(B, v_p.shape[1], 1, dtype=R.dtype)], -1)[..., None]
     verts = (Tm @ vh)[:, :, :3, 0]
     return verts + transl[:, None], G[:, :, :3, 3] + transl[:, None]
 
@@ -95,7 +96,7 @@ def residual_fn(tb, marker_vids, nb_opt):
 
     def f(x, target, mask):
         pose, b, go, t = x[:69], x[69:69 + nb_opt], x[69 + nb_opt:72 + nb_opt], x[72 + nb_opt:75 + nb_opt]
-        betas = torch.cat([b, torch.zeros(nb_total - nb_opt)])[None]
+        betas = torch.cat([b, torch.zeros(nb_total - nb_opt, dtype=x.dtype)])[None]
         v, _ = lbs(tb, betas, torch.cat([go, pose])[None], t[None])
         return ((target - v[0][marker_vids]) * mask[:, None]).reshape(-1)      # fit_SMPL.py:127-131
 
@@ -114,7 +115,7 @@ def lm(f, x, target, mask, iters, step, damping, trace=None):
     for _ in range(iters):
         r = rf(x, target, mask)
         Jm = jac(x, target, mask)
-        AtA = Jm.transpose(1, 2) @ Jm + damping * torch.eye(dof)
+        AtA = Jm.transpose(1, 2) @ Jm + damping * torch.eye(dof, dtype=x.dtype)
         Atb = -(Jm.transpose(1, 2) @ r[..., None])
         delta = torch.cholesky_solve(Atb, torch.linalg.cholesky(AtA))[..., 0]
         x = torch.where(conv[:, None], x, x + step * delta)
@@ -129,16 +130,20 @@ def lm(f, x, target, mask, iters, step, damping, trace=None):
     return x
 
 
-def fit_smpl(bm, marker_vids, markers, valid, steps_stage0=30, steps_stage1=50, lr_stage0=0.5, lr_stage1=0.2, trace=None):
-    """fit_SMPL.py:68-269 after get_markers.  Returns dict(pose [B,69], betas [B,10], orient, transl, verts, joints)."""
+def fit_smpl(bm, marker_vids, markers, valid, steps_stage0=30, steps_stage1=50, lr_stage0=0.5, lr_stage1=0.2, trace=None, dtype=torch.float32):
+    """fit_SMPL.py:68-269 after get_markers.  Returns dict(pose [B,69], betas [B,10], orient, transl, verts, joints).
+    dtype = float32 is the reference's arithmetic (Theseus / smplx run in fp32); float64 is the same algorithm as a
+    rounding-free yardstick: tests use |fp32 run - fp64 run| as the error any fp32 implementation is entitled to on the
+    weakly observed parameters."""
     with torch.no_grad():
-        tb = TorchBody(bm)
+        tb = TorchBody(bm, dtype)
+        markers = markers.to(dtype)
         mv = torch.as_tensor(np.asarray(marker_vids)).long()
         B = markers.shape[0]
-        mask = valid.float()
+        mask = valid.to(dtype)
         t0 = [] if trace is not None else None
-        x0 = lm(residual_fn(tb, mv, 2), torch.zeros(B, 77), markers, mask, steps_stage0, lr_stage0, 0.01, t0)
-        x1 = torch.cat([x0[:, :69], x0[:, 69:71], torch.zeros(B, 8), x0[:, 71:]], 1)
+        x0 = lm(residual_fn(tb, mv, 2), torch.zeros(B, 77, dtype=dtype), markers, mask, steps_stage0, lr_stage0, 0.01, t0)
+        x1 = torch.cat([x0[:, :69], x0[:, 69:71], torch.zeros(B, 8, dtype=dtype), x0[:, 71:]], 1)
         t1 = [] if trace is not None else None
         x1 = lm(residual_fn(tb, mv, 10), x1, markers, mask, steps_stage1, lr_stage1, 1e-3, t1)
         if trace is not None:

@@ -8,6 +8,8 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+DOF_GROUPS = {"body pose": slice(0, 63), "hands": slice(63, 69), "betas[:2]": slice(69, 71), "betas[2:]": slice(71, 79), "orient": slice(79, 82),
+              "transl": slice(82, 85)}
 
 
 def test_get_markers_vs_reference_golden(golden):
@@ -108,9 +110,10 @@ def test_lm_fit_vs_oracle():
     # raw parameters: weakly observed DoFs (hands, high betas) are ill conditioned at lambda = 1e-3
     x = aux["x"].cpu().numpy()
     xr = torch.cat([ref["pose"], ref["betas"], ref["orient"], ref["transl"]], 1).numpy()
-    assert np.abs(x[:, 79:] - xr[:, 79:]).max() < 1e-4                            # orient, transl
-    assert np.abs(x - xr).max() < 5e-3
-    assert np.abs(aux["x_stage0"].cpu().numpy()[:, :69] - ref["x_stage0"].numpy()[:, :69]).max() < 5e-3
+    dev = np.abs(x - xr)
+    print("LM parameter deviation vs oracle (fp32):", {k: float(dev[:, sl].max()) for k, sl in DOF_GROUPS.items()})
+    assert dev.max() < 1e-4                                                        # every DoF, north_star's bar
+    assert np.abs(aux["x_stage0"].cpu().numpy()[:, :69] - ref["x_stage0"].numpy()[:, :69]).max() < 1e-4
 
 
 def test_lm_fit_vs_committed_oracle_fixture(golden):
@@ -133,5 +136,50 @@ def test_lm_fit_vs_committed_oracle_fixture(golden):
     assert (np.abs(tr.cpu().numpy() - rt) <= 2e-3 * rt + 1e-7).all()
     assert np.abs(verts.cpu().numpy()[:, ::10] - g["verts_sub"]).max() < 1e-4
     assert np.abs(joints.cpu().numpy() - g["joints"]).max() < 1e-4
-    assert np.abs(x.cpu().numpy()[:, 79:] - g["x"][:, 79:]).max() < 1e-4
-    assert np.abs(x.cpu().numpy() - g["x"]).max() < 5e-3
+    dev = np.abs(x.cpu().numpy() - g["x"])
+    print("LM parameter deviation vs committed oracle run:", {k: float(dev[:, sl].max()) for k, sl in DOF_GROUPS.items()})
+    assert dev.max() < 1e-4
+
+
+def test_rodrigues_vs_in_tree_batch_rodrigues(golden):
+    """The device rodrigues_d of the LM / LBS kernels against the golden emitted from the reference's in-tree batch_rodrigues
+    (src/data_utils/GT_dataloader_mixed.py:29-64): R and dR/dtheta at theta = 0, tiny, random, |theta| ~ pi."""
+    from etch_amd import ops
+    g = golden("rodrigues.npz")
+    R, dR = ops.rodrigues(torch.from_numpy(g["theta"]).cuda())
+    assert np.abs(R.cpu().numpy() - g["R_fp64"]).max() < 1e-13
+    want = np.transpose(g["dR_fp64"], (0, 3, 1, 2))                                 # [n, i, j, q] -> [n, q, i, j]
+    assert np.abs(dR.cpu().numpy() - want).max() < 2e-7 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("nb", [2, 10])
+def test_analytic_jacobian_vs_autograd_through_full_lbs(nb):
+    """The LM kernel's analytic marker-restricted Jacobian against torch.func.jacrev through the oracle's
+    FULL-mesh LBS -- the reference's AutoDiffCostFunction formulation (fit_SMPL.py:176-183) -- in fp64, at random poses incl. the
+    zero pose the fit starts from; the residual alongside.  nb = active betas (stage 0: 2, stage 1: 10)."""
+    from etch_amd import ops
+    from etch_amd.models.fit_SMPL import _device_body
+    from oracle import stage2 as S2
+    B = 3
+    bm, ms, mv, tgt, valid, _ = _problem(B, seed=5)
+    db = _device_body(bm, mv, torch.device("cuda"))
+    g = torch.Generator().manual_seed(9)
+    x = torch.cat([torch.randn(B, 69, generator=g) * 0.3, torch.randn(B, 10, generator=g), torch.randn(B, 3, generator=g) * 0.8,
+                   torch.randn(B, 3, generator=g) * 0.1], 1)
+    x[0] = 0
+    if nb < 10:
+        x[:, 69 + nb:79] = 0
+    r, J = ops.smpl_lm_linearize(db.lm_consts, x.cuda(), tgt.cuda(), valid.float().cuda(), nb)
+    tb = S2.TorchBody(bm, torch.float64)
+    f = S2.residual_fn(tb, torch.as_tensor(mv).long(), nb)
+    keep = list(range(69 + nb)) + list(range(79, 85))                                # oracle's variable vector drops the inactive betas
+    xo = x.double()[:, keep]
+    rr = torch.func.vmap(f)(xo, tgt.double(), valid.double())
+    Jr = torch.func.vmap(torch.func.jacrev(f))(xo, tgt.double(), valid.double())
+    assert np.abs(r.cpu().numpy() - rr.numpy()).max() < 2e-6
+    Jg = J.cpu().numpy()
+    scale = np.abs(Jr.numpy()).max()
+    assert np.abs(Jg[:, :, keep] - Jr.numpy()).max() < 2e-6 * scale
+    drop = [c for c in range(85) if c not in keep]
+    assert not drop or np.abs(Jg[:, :, drop]).max() == 0                             # inactive betas: zero columns
+    assert (Jg[0, 15:18] == 0).all() and (r.cpu().numpy()[0, 15:18] == 0).all()      # masked marker (scan 0, marker 5): zero rows

@@ -80,3 +80,38 @@ def test_eval_metrics():
     assert v2v(np.ones((5, 3)), np.zeros((5, 3))) == np.sqrt(3.0)
     j = np.zeros((45, 3)); k = j.copy(); k[30:] = 9.0                             # joints beyond the first 22 are ignored
     assert mpjpe(j, k) == 0.0
+
+
+def test_load_smpl_pkl_key_layout(tmp_path):
+    """load_smpl_pkl on a synthetic pickle in the SMPL key layout (what SMPL_NEUTRAL_10pc_rmchumpy.pkl holds, fit_SMPL.py:92-101;
+    smplx.SMPL.__init__ upstream): posedirs stored (V,3,207) -> (207, V*3) as smplx reshapes it, J_regressor as a scipy sparse
+    matrix, kintree_table (2,24) uint32 whose root parent is 2^32 - 1, more than 10 shape components on disk."""
+    import pickle
+
+    import scipy.sparse as sp
+    import torch
+
+    from etch_amd.utils.body_model import SMPL_PARENTS, SyntheticSMPL, load_smpl_pkl
+    from oracle import stage2 as S2
+    V = 500
+    bm = SyntheticSMPL(3, V=V)
+    rng = np.random.default_rng(0)
+    extra_shapes = rng.standard_normal((V, 3, 6)).astype(np.float32)                  # the pickle holds more components than used
+    kin = np.stack([SMPL_PARENTS.astype(np.int64) % (1 << 32), np.arange(24)]).astype(np.uint32)
+    d = {"v_template": bm.v_template.astype(np.float64), "shapedirs": np.concatenate([bm.shapedirs, extra_shapes], 2),
+         "posedirs": bm.posedirs.T.reshape(V, 3, 207).copy(), "J_regressor": sp.csc_matrix(bm.J_regressor),
+         "weights": bm.lbs_weights, "kintree_table": kin, "f": bm.faces.astype(np.uint32)}
+    path = tmp_path / "SMPL_SYNTH.pkl"
+    with open(path, "wb") as f:
+        pickle.dump(d, f, protocol=2)
+    got = load_smpl_pkl(str(path))
+    assert got.parents.tolist() == SMPL_PARENTS.tolist() and got.parents.dtype == np.int32
+    for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights"):
+        assert getattr(got, k).dtype == np.float32 and np.array_equal(getattr(got, k), getattr(bm, k)), k
+    assert got.posedirs.shape == (207, V * 3) and got.shapedirs.shape == (V, 3, 10) and got.num_betas == 10
+    assert np.array_equal(got.faces, bm.faces)
+    # the element order is the one LBS consumes: posed vertices of the loaded model equal those of the source model
+    x = torch.from_numpy(rng.standard_normal((2, 85)).astype(np.float32) * 0.3)
+    a = S2.lbs(S2.TorchBody(got), x[:, 69:79], torch.cat([x[:, 79:82], x[:, :69]], 1), x[:, 82:85])[0]
+    b = S2.lbs(S2.TorchBody(bm), x[:, 69:79], torch.cat([x[:, 79:82], x[:, :69]], 1), x[:, 82:85])[0]
+    assert torch.equal(a, b)

@@ -152,3 +152,45 @@ def test_gather_points_backward_known_answer():
     lhs = float((O.gather_points_forward(x, idx).astype(np.float64) * g).sum())
     rhs = float((x.astype(np.float64) * out).sum())
     assert abs(lhs - rhs) < 1e-4 * abs(lhs)
+
+
+def test_fma_contraction_sensitivity():
+    """The distance contract of record is `((dx*dx)+(dy*dy))+(dz*dz)` WITHOUT fused multiply-add (oracle/discrete_ops.c, and the
+    HIP kernels).  The reference binary is built by nvcc whose default -fmad=true may contract that expression, so the contract is
+    self-consistent, not a pin.  This test measures what hangs on it: the index ops are re-run with the two plausible contracted
+    forms (ORC_FMA = 1, 2) on the bench's own scans (seeds 1000.., N = 5000, every radius / nsample the encoder uses, the kNN
+    sizes of the first Point-Transformer level).  About 20 % of the distances change by one ulp, yet a DECISION only flips when a
+    distance sits within an ulp of the radius / of a competitor: measured 0 flips on these inputs; the bar allows a handful."""
+    from oracle import ops as O
+    flips = {"fps": 0, "ball": 0, "knn": 0, "fps_pt": 0}
+    rows = {"ball": 0, "knn": 0}
+    for seed in (1000, 1001):
+        x = (np.random.default_rng(seed).standard_normal((5000, 3)) * np.array([0.14, 0.31, 0.085])).astype(np.float32)
+        xs = np.ascontiguousarray(x.T)[None]
+        off, off4 = np.array([5000], np.int32), np.array([1250], np.int32)
+
+        def run():
+            f = O.furthest_point_sampling(xs, 2500)
+            sub = np.ascontiguousarray(xs[:, :, f[0]])
+            balls = [O.ball_query(xs, xs, 0.2, 64), O.ball_query(sub, xs, 0.2828, 32), O.ball_query(sub, sub, 0.4, 64)]
+            fp = O.furthestsampling(x, off, off4)
+            knn = [O.knnquery(8, x, x, off, off), O.knnquery(16, x, np.ascontiguousarray(x[fp]), off, off4)]
+            return f, balls, fp, knn
+        f0, b0, p0, k0 = run()
+        changed = 0.0
+        for v in (1, 2):
+            with O.variant(v):
+                f1, b1, p1, k1 = run()
+            flips["fps"] += int((f0 != f1).sum())
+            flips["fps_pt"] += int((p0 != p1).sum())
+            for a, b in zip(b0, b1):
+                flips["ball"] += int((a != b).any(-1).sum())
+                rows["ball"] += a.shape[1]
+            for (ia, da), (ib, db) in zip(k0, k1):
+                flips["knn"] += int((ia != ib).any(-1).sum())
+                rows["knn"] += ia.shape[0]
+                changed = max(changed, float((da != db).mean()))
+            assert changed > 0.05                 # the variants really are different arithmetic
+    print("decisions that depend on the FMA contraction:", flips, "of rows", rows)
+    assert flips["fps"] == 0 and flips["fps_pt"] == 0            # a flip would cascade through the whole sampling chain
+    assert flips["ball"] <= 4 and flips["knn"] <= 4

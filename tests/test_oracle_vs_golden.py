@@ -175,3 +175,37 @@ def test_stage2_oracle_reproduces_its_fixture(golden):
     tr = g["err_trace"]
     assert (np.diff(tr[:, :31], axis=1) <= 1e-6).all() and (tr[:, -1] < 1e-3).all()
     assert (g["v2v_vs_generating"] < 5e-3).all()            # markers carry 2 mm of noise: the fit lands within a few mm of the generating body
+
+
+def test_rodrigues_vs_in_tree_batch_rodrigues(golden):
+    """oracle.stage2.rodrigues against the golden emitted from the reference's in-tree batch_rodrigues
+    (src/data_utils/GT_dataloader_mixed.py:29-64; generator: oracle/ref_harness/gen_golden.py::gen_rodrigues): values in fp32
+    and fp64, and the Jacobian dR/dtheta (autograd of the reference function, fp64) at theta = 0, tiny, random and |theta| ~ pi."""
+    from oracle import stage2 as S2
+    g = golden("rodrigues.npz")
+    th = torch.from_numpy(g["theta"])
+    assert np.array_equal(S2.rodrigues(th).numpy(), g["R_fp32"])                       # same torch ops in the same order
+    assert np.abs(S2.rodrigues(th.double()).numpy() - g["R_fp64"]).max() < 1e-15
+    J = torch.stack([torch.autograd.functional.jacobian(lambda v: S2.rodrigues(v[None])[0], t) for t in th.double()])
+    assert np.abs(J.numpy() - g["dR_fp64"]).max() < 1e-12
+    # sanity of the fixture itself: rotations up to the 1e-8 the formula's `theta + 1e-8` leaves in the axis norm (even in
+    # fp64), and the generators at theta = 0
+    R = g["R_fp64"]
+    assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-6 and np.abs(np.linalg.det(R) - 1).max() < 1e-6
+    G0 = g["dR_fp64"][0]                                                              # [i, j, q] at theta = 0
+    assert np.abs(G0[2, 1, 0] - 1).max() < 1e-7 and np.abs(G0[1, 2, 0] + 1).max() < 1e-7
+
+
+def test_whole_model_bundled_4ddress_scan_5k(golden):
+    """BASELINE configs[0]'s geometry -- the reference's bundled 4D-Dress scan, 5 000 surface points -- through the oracle's
+    stage-1 restatement against the reference's own Python run (tests/golden/scan_4ddress_5k.npz)."""
+    g = golden("scan_4ddress_5k.npz")
+    c = golden("constants.npz")
+    sd = model_state_dict(int(g["seed"]), c)
+    out = S.forward(sd, torch.from_numpy(g["points"]), S.build_layer_table(), return_aux=True)
+    rows = g["rows"]
+    for k, sub in (("part_labels", True), ("confidences", False), ("magnitude", False), ("anc_w", True)):
+        got = out[k].numpy()[:, rows] if sub else out[k].numpy()
+        scale = np.abs(g[k]).max()
+        assert np.abs(got - g[k]).max() <= 1e-5 * max(scale, 1.0), k
+    assert (out["part_labels"].argmax(-1).numpy() == g["labels"]).mean() > 0.9995

@@ -50,3 +50,64 @@ def test_two_rank_gather_gloo():
     expect = [[float(i), float(i * i)] for i in range(total)]
     assert res[0][2] == expect and res[1][2] == expect
     assert res[0][3] == 2.0 and res[1][3] == 2.0
+
+
+def _bench(extra_env, *argv, timeout=600):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_self_launch_two_ranks_control_flow():
+    """`python bench.py --gpus 2` from a plain interpreter (no torchrun): the parent starts the two ranks itself and relays rank 0's
+    JSON line.  ETCH_BENCH_DRY replaces the GPU step by a stub so the WHOLE control flow of the N > 1 path runs here on CPU over gloo:
+    rank environment, NUMA / core pinning, sharding of distinct batches, barrier + max-over-ranks timing, the end-of-job all_gather."""
+    import json
+    r = _bench({"ETCH_BENCH_DRY": "1"}, "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4", "--points", "128")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                    # ONE JSON line, from rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["config"]["global_batch"] == 8
+    assert out["config"]["launcher"] == "self" and out["config"]["distinct_batches"] == 4
+    assert out["gathered_rows"]["scans_reported"] == 8        # both ranks' rows arrived, in scan order
+    assert out["value"] == __import__("pytest").approx(2 * 4 * 3 / (out["ms_per_step"] * 3e-3), rel=1e-3)
+
+
+def test_bench_self_launch_propagates_a_rank_failure():
+    """A rank that dies must fail the job (and must not leave its peers waiting in a barrier)."""
+    r = _bench({"ETCH_BENCH_DRY": "1", "ETCH_BENCH_DRY_FAIL_RANK": "1"}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+               "--points", "64", timeout=300)
+    assert r.returncode == 3 and "ranks failed" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_core_pinning_from_kfd_topology(tmp_path):
+    """local_cpu_set on a fake sysfs tree shaped like an 8-GPU MI355X node: 2 CPU nodes (KFD nodes 0, 1), GPUs 0-3 linked to
+    socket 0 and GPUs 4-7 to socket 1 -> each rank gets its own quarter of its socket's cores."""
+    from etch_amd import parallel as P
+    kfd, nodes = tmp_path / "kfd", tmp_path / "node"
+    avail = sorted(os.sched_getaffinity(0))
+    half = max(1, len(avail) // 2)
+    lists = [avail[:half], avail[half:] or avail[:half]]
+    for i in range(10):
+        d = kfd / str(i)
+        (d / "io_links" / "0").mkdir(parents=True)
+        cpu = i < 2
+        (d / "properties").write_text(f"cpu_cores_count {64 if cpu else 0}\nsimd_count {0 if cpu else 1024}\n")
+        (d / "io_links" / "0" / "properties").write_text(f"type 2\nnode_from {i}\nnode_to {0 if cpu else (0 if i < 6 else 1)}\n")
+    for k in range(2):
+        (nodes / f"node{k}").mkdir(parents=True)
+        (nodes / f"node{k}" / "cpulist").write_text(",".join(str(c) for c in lists[k]) + "\n")
+    assert P.gpu_numa_nodes(str(kfd)) == [0, 0, 0, 0, 1, 1, 1, 1]
+    sets = [P.local_cpu_set(r, 8, str(kfd), str(nodes)) for r in range(8)]
+    assert all(s for s in sets)
+    for r in range(8):
+        assert set(sets[r]) <= set(lists[0 if r < 4 else 1])
+    if len(lists[0]) >= 4:
+        assert all(not (set(sets[a]) & set(sets[b])) for a in range(4) for b in range(a + 1, 4))
+    # unreadable topology -> even split of the affinity mask
+    assert P.local_cpu_set(1, 2, str(tmp_path / "none"), str(nodes)) == avail[len(avail) // 2:2 * (len(avail) // 2)]
