@@ -293,6 +293,28 @@ __global__ void __launch_bounds__(256) so3_mean_dir_kernel(long T, int A, const 
     if (sv) { sv[t * 3] = (float)S[0]; sv[t * 3 + 1] = (float)S[1]; sv[t * 3 + 2] = (float)S[2]; }
 }
 
+// so3_mean with the reference's general signature (so3conv.py:186-225): Rs (T,A,3,3) per row (rs_stride = A*9) or one shared set
+// (rs_stride = 0), weights (T,A) or none (all ones) -> R (T,3,3).  Same fp64 accumulation / Jacobi SVD / det fix as above.
+__global__ void __launch_bounds__(256) so3_mean_general_kernel(long T, int A, const float* __restrict__ Rs, long rs_stride,
+                                                               const float* __restrict__ w, float* __restrict__ Rout) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    double Ce[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float* rs = Rs + t * rs_stride;
+    for (int a = 0; a < A; ++a) {
+        const double wa = w ? (double)w[t * A + a] : 1.0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Ce[k] += wa * (double)rs[a * 9 + k];
+    }
+    double U[9], S[3], V[9];
+    jacobi_svd3(Ce, U, S, V);
+    const double detU = U[0] * (U[4] * U[8] - U[5] * U[7]) - U[1] * (U[3] * U[8] - U[5] * U[6]) + U[2] * (U[3] * U[7] - U[4] * U[6]);
+    const double detV = V[0] * (V[4] * V[8] - V[5] * V[7]) - V[1] * (V[3] * V[8] - V[5] * V[6]) + V[2] * (V[3] * V[7] - V[4] * V[6]);
+    const double d = detU * detV;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Rout[t * 9 + i * 3 + j] = (float)(U[i * 3] * V[j * 3] + U[i * 3 + 1] * V[j * 3 + 1] + d * U[i * 3 + 2] * V[j * 3 + 2]);
+}
+
 extern "C" {
 
 int etch_prop3nn(int B, int N, int S, const float* xyz1, const float* xyz2, int* idx, float* weight, void* stream) {
@@ -344,6 +366,14 @@ int etch_so3_mean_dir(long T, int A, const float* w, const float* anchors, float
     if (T <= 0) return ETCH_OK;
     if (A != 60) return ETCH_EUNSUPPORTED;
     hipLaunchKernelGGL(so3_mean_dir_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream, T, A, w, anchors, dir, R, sv);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_so3_mean(long T, int A, const float* Rs, long rs_stride, const float* w, float* R, void* stream) {
+    if (T <= 0) return ETCH_OK;
+    if (A <= 0 || (rs_stride != 0 && rs_stride != (long)A * 9)) return ETCH_EINVAL;
+    hipLaunchKernelGGL(so3_mean_general_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream, T, A, Rs, rs_stride, w, R);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }

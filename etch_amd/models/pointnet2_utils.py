@@ -1,5 +1,6 @@
-"""MI355X counterpart of /root/reference/src/models/pointnet2_utils.py (only what the path uses)."""
+"""MI355X counterpart of /root/reference/src/models/pointnet2_utils.py: square_distance, index_points, PointFeatPropagation."""
 from .. import ops
+from ..vgtk_functional import index_points, square_distance  # noqa: F401  (pointnet2_utils.py:4-43, HIP kernels)
 
 
 def PointFeatPropagation(xyz1, xyz2, points2):

@@ -154,3 +154,21 @@ class BasicSO3ConvBlock(nn.Module):
                 raise ValueError(f'No such type of SO3Conv {param["type"]}')
             sample_idx_list.append(sample_idx)
         return x, sample_idx_list
+
+
+def so3_mean(Rs, weights=None):
+    """so3conv.py:186-225: chordal-L2 mean of the rotations Rs (B,N,3,3) with optional weights (B,N) -> (B,3,3).  One thread per
+    row: fp64 accumulation of Ce = sum_n w_n R_n, one-sided Jacobi SVD, det(U V^T) fix (csrc/heads.hip).  An expanded view of one
+    shared rotation set (the way the model calls it, models_pointcloud.py:118-119) is read once instead of B times."""
+    import ctypes
+
+    from .. import _lib
+    B, N = Rs.shape[0], Rs.shape[1]
+    shared = Rs.stride(0) == 0
+    rs = (Rs[0] if shared else Rs).contiguous().float()
+    w = None if weights is None else weights.contiguous().float()
+    R = torch.empty((B, 3, 3), dtype=torch.float32, device=Rs.device)
+    _lib.check(_lib.lib().etch_so3_mean(ctypes.c_long(B), N, ctypes.c_void_p(rs.data_ptr()), ctypes.c_long(0 if shared else N * 9),
+                                        ctypes.c_void_p(0 if w is None else w.data_ptr()), ctypes.c_void_p(R.data_ptr()),
+                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "etch_so3_mean")
+    return R

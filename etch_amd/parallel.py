@@ -47,37 +47,62 @@ def _parse_cpulist(txt):
 
 
 def gpu_numa_nodes(kfd_root="/sys/class/kfd/kfd/topology/nodes"):
-    """NUMA node of every GPU in HIP ordinal order, read from the KFD topology in sysfs (NO HIP call: this runs before the
-    process touches the GPU).  KFD lists CPU nodes (cpu_cores_count > 0; node id == NUMA node) and GPU nodes (simd_count > 0,
-    in the order HIP enumerates them); a GPU's io_link to a CPU node names its NUMA-local socket.  [] when sysfs has no KFD."""
+    """NUMA node of every GPU this process can open, in HIP ordinal order, read from the KFD topology in sysfs (NO HIP call:
+    this runs before the process touches the GPU).  KFD lists CPU nodes first (cpu_cores_count > 0; the k-th CPU node is NUMA
+    node k) and then one node per GPU in the order HIP enumerates them.  The socket of a GPU is taken from the CPU node whose
+    io_links name it (the CPU side is always readable), else from the GPU's own links.  In a container that was handed a
+    subset of the GPUs the other GPUs' `properties` are unreadable (EPERM, seen on the bench pool): those are skipped, so
+    ordinal i is the i-th GPU this process may use.  [] when sysfs has no KFD."""
     try:
         ids = sorted(int(d) for d in os.listdir(kfd_root) if d.isdigit())
     except OSError:
         return []
     props = {i: _read_props(os.path.join(kfd_root, str(i), "properties")) for i in ids}
     cpu_nodes = [i for i in ids if props[i].get("cpu_cores_count", 0) > 0]
-    out = []
-    for i in ids:
-        if props[i].get("simd_count", 0) <= 0 or props[i].get("cpu_cores_count", 0) > 0:
-            continue
-        numa = None
-        links = os.path.join(kfd_root, str(i), "io_links")
+    gpus = [i for i in ids if i not in cpu_nodes]
+    readable = [i for i in gpus if props[i].get("simd_count", 0) > 0]
+    gpus = readable or gpus
+
+    def links(i):
+        d = os.path.join(kfd_root, str(i), "io_links")
         try:
-            for l in sorted(os.listdir(links)):
-                to = _read_props(os.path.join(links, l, "properties")).get("node_to")
-                if to in cpu_nodes:
-                    numa = cpu_nodes.index(to)
-                    break
+            return [_read_props(os.path.join(d, l, "properties")).get("node_to") for l in sorted(os.listdir(d))]
         except OSError:
-            pass
-        out.append(numa)
-    return out
+            return []
+
+    socket = {}
+    for k, c in enumerate(cpu_nodes):
+        for to in links(c):
+            if to in gpus:
+                socket.setdefault(to, k)
+    for g in gpus:
+        if g not in socket:
+            for to in links(g):
+                if to in cpu_nodes:
+                    socket[g] = cpu_nodes.index(to)
+                    break
+    return [socket.get(g) for g in gpus]
+
+
+def _split_by_core(cpus, k, n, cpu_root="/sys/devices/system/cpu"):
+    """k-th of n even parts of `cpus`, split by PHYSICAL core (SMT siblings stay together on one rank)."""
+    core = {}
+    for c in cpus:
+        try:
+            with open(os.path.join(cpu_root, f"cpu{c}", "topology", "thread_siblings_list")) as f:
+                core[c] = min(_parse_cpulist(f.read()))
+        except (OSError, ValueError):
+            core[c] = c
+    cores = sorted(set(core.values()))
+    per = max(1, len(cores) // n)
+    mine = set(cores[k * per:(k + 1) * per] if k < n - 1 else cores[k * per:])
+    return [c for c in cpus if core[c] in mine]
 
 
 def local_cpu_set(local, world, kfd_root="/sys/class/kfd/kfd/topology/nodes", node_root="/sys/devices/system/node"):
     """The host cores rank `local` of `world` ranks on this node should run on: the cores of its GPU's NUMA node, split evenly
-    among the ranks whose GPUs share that node (the host enqueues ~400 launches per step, so each rank wants its own
-    NUMA-local cores).  Falls back to an even contiguous split of the current affinity mask when the topology is unreadable."""
+    (by physical core) among the ranks whose GPUs share that node (the host enqueues ~400 launches per step, so each
+    rank wants its own NUMA-local cores).  Falls back to an even split of the current affinity mask when the topology is unreadable."""
     avail = sorted(os.sched_getaffinity(0))
     numa = gpu_numa_nodes(kfd_root)
     if local < len(numa) and numa[local] is not None:
@@ -88,14 +113,10 @@ def local_cpu_set(local, world, kfd_root="/sys/class/kfd/kfd/topology/nodes", no
             cpus = []
         sharing = [r for r in range(min(world, len(numa))) if numa[r] == numa[local]]
         if cpus and local in sharing:
-            k, n = sharing.index(local), len(sharing)
-            per = max(1, len(cpus) // n)
-            mine = cpus[k * per:(k + 1) * per] if k < n - 1 else cpus[k * per:]
+            mine = _split_by_core(cpus, sharing.index(local), len(sharing))
             if mine:
                 return mine
-    per = max(1, len(avail) // max(world, 1))
-    mine = avail[local * per:(local + 1) * per]
-    return mine or avail
+    return _split_by_core(avail, local % max(world, 1), max(world, 1)) or avail
 
 
 def pin_to_local_cores(local, world):

@@ -11,6 +11,7 @@ import torch.nn as nn
 
 from . import constants as K
 from . import ops
+from . import vgtk_functional as functional  # noqa: F401  (the reference's `vgtk.so3conv.functional`)
 
 
 class SphericalPointCloud:

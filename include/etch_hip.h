@@ -220,6 +220,32 @@ int etch_linear_relu_dot(long R, int K, int G, int J, const float* X, long ldx, 
 /* confidence = sum_g softmax(logits)_g * v_g (pointtransformer_seg.py:183-189): (R,G),(R,G) -> (R). */
 int etch_softmax_dot(long R, int G, const float* logits, const float* v, float* out, void* stream);
 
+/* so3_mean with the reference's own signature (src/models/so3conv.py:186-225): Rs (T,A,3,3) [rs_stride = A*9] or one rotation set
+ * shared by all rows [rs_stride = 0], weights w (T,A) or NULL (uniform) -> chordal-L2 mean rotation R (T,3,3). */
+int etch_so3_mean(long T, int A, const float* Rs, long rs_stride, const float* w, float* R, void* stream);
+
+/* ---- un-fused operator forms of the reference's functional API (never on the hot path; csrc/functional_ops.hip) ---------- */
+
+/* inter_so3conv_grouping_anchor (external/vgtk/vgtk/so3conv/functional.py:286-324): grouped_xyz (b,3,p,nn), rotated kernel points
+ * (na,ks,3) = anchors @ kernels^T -> w (b,p,na,ks,nn) = relu(1 - |g - R_a kappa_k|^2 / sigma). */
+int etch_inter_kernel_weights(int b, int p, int nn, int na, int ks, const float* grouped_xyz, const float* rotated_kernels, float sigma,
+                              float* w, void* stream);
+
+/* inter_so3conv_feat_grouping (functional.py:61-67): idx (b,p,nn) i32 into the q rows of feats (b,c,q,na) [q includes the shadow
+ * row of add_shadow_feature, :101-105], w (b,p,na,ks,nn) -> (b,c,ks,p,na). */
+int etch_inter_feat_grouping(int b, int c, int q, int p, int nn, int na, int ks, const int* idx, const float* w, const float* feats,
+                             float* out, void* stream);
+
+/* intra_so3conv_grouping (functional.py:331-378): intra_idx (na,nt) i64, feat (b,c,p,na) -> (b,c,nt,p,na). */
+int etch_intra_grouping(int b, int c, int p, int na, int nt, const long long* intra_idx, const float* feat, float* out, void* stream);
+
+/* square_distance (src/models/pointnet2_utils.py:4-23): src (B,N,C), dst (B,M,C) -> (B,N,M), expansion formula in the reference's
+ * operation order. */
+int etch_square_distance(int B, int N, int M, int C, const float* src, const float* dst, float* out, void* stream);
+
+/* index_points (pointnet2_utils.py:26-43): points (B,N,C), idx (B,S) i64 -> (B,S,C). */
+int etch_index_points(int B, int N, long S, int C, const float* points, const long long* idx, float* out, void* stream);
+
 /* ---- stage 2: markers + SMPL Levenberg-Marquardt fit ------------------------------------------------------ */
 
 /* torch.max(part_labels, -1) of predict_smpl (src/inference_demo.py:52-53): logits (R,G) -> int64 labels (R). */

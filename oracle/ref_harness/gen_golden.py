@@ -228,13 +228,20 @@ def gen_scan4d(model):
     _save_model_run("scan_4ddress_5k.npz", x, out, anc_w, 4, scan_center=centre)
 
 
-def gen_model5k(model):
+def gen_model5k(model, ms):
     """The metric's own workload (configs[1]/[2]: batch 32 of synthetic 5 000-point scans, seeds 1000 + b): scans 0 and 31
-    of that batch through the reference's Python."""
+    of that batch through the reference's Python.  The direction head's anchor weights are also run in fp64 (conditioning
+    yardstick: a handful of the 10 000 points carry saturated attention rows, see gen_padding_fp64)."""
     ids = [0, 31]
     x = torch.from_numpy(np.stack([scan(1000 + i, 5000) for i in ids]))
     out, anc_w = _run_ref(model, x)
-    _save_model_run("model_n5000.npz", x, out, anc_w, 4, scan_ids=np.array(ids))
+    w64 = _run_ref_fp64(model, ms, x)
+    scale = float(w64.abs().max())
+    dev32 = ((anc_w.double() - w64).abs().amax(-1) / scale).float()
+    print("model5k: reference fp32 vs fp64 anc_w deviation  max %.3e  99.9%% %.3e" % (float(dev32.max()), float(dev32.flatten().quantile(0.999))))
+    rows = np.arange(0, 5000, 4)
+    _save_model_run("model_n5000.npz", x, out, anc_w, 4, scan_ids=np.array(ids), anc_w_fp64=w64[:, rows].float(), ref_fp32_dev=dev32[:, rows],
+                    anc_w_scale=scale)
 
 
 def gen_model20k(model):
@@ -244,14 +251,9 @@ def gen_model20k(model):
     _save_model_run("model_n20000.npz", x, out, anc_w, 16)
 
 
-def gen_padding_fp64(model, ms):
-    """Conditioning evidence for SURVEY 8d's padding-heavy distribution (sigma = 0.20, 0.45, 0.12; B = 2, N = 2 000, seeds
-    700 + b): the REFERENCE Python run in fp32 and in fp64 on the same input and weights.  Stored: the fp64 anchor weights
-    and, per point, how far the reference's own fp32 run lands from them -- the error any fp32 implementation is entitled to."""
-    B, N = 2, 2000
-    x = torch.from_numpy(np.stack([(np.random.default_rng(700 + b).standard_normal((N, 3)) * np.array([0.20, 0.45, 0.12])).astype(np.float32)
-                                   for b in range(B)]))
-    out32, w32 = _run_ref(model, x)
+def _run_ref_fp64(model, ms, x):
+    """The reference's Python with every parameter, buffer and activation in fp64 (direction head only) -> anc_w [B,N,60] fp64."""
+    B, N = x.shape[:2]
     m64 = R.build_reference_model(tempfile.mkdtemp(), ms).double()
     sd = {k: (v.double() if v.is_floating_point() else v) for k, v in seeded_state_dict(model, 1).items()}
     m64.load_state_dict(sd)
@@ -270,7 +272,18 @@ def gen_padding_fp64(model, ms):
         torch.Tensor.float = _float
         torch.set_default_dtype(_default)
     h.remove()
-    w64 = cap["anc_w"].view(B, N, 60)
+    return cap["anc_w"].view(B, N, 60)
+
+
+def gen_padding_fp64(model, ms):
+    """Conditioning evidence for SURVEY 8d's padding-heavy distribution (sigma = 0.20, 0.45, 0.12; B = 2, N = 2 000, seeds
+    700 + b): the REFERENCE Python run in fp32 and in fp64 on the same input and weights.  Stored: the fp64 anchor weights
+    and, per point, how far the reference's own fp32 run lands from them -- the error any fp32 implementation is entitled to."""
+    B, N = 2, 2000
+    x = torch.from_numpy(np.stack([(np.random.default_rng(700 + b).standard_normal((N, 3)) * np.array([0.20, 0.45, 0.12])).astype(np.float32)
+                                   for b in range(B)]))
+    out32, w32 = _run_ref(model, x)
+    w64 = _run_ref_fp64(model, ms, x)
     scale = float(w64.abs().max())
     dev32 = ((w32.double() - w64).abs().amax(-1) / scale).float()
     save("padding_heavy_fp64.npz", points=x, anc_w_fp64=w64.float(), ref_fp32_dev=dev32, scale=scale)
@@ -311,7 +324,7 @@ def main():
     only = sys.argv[1:]
     steps = {"constants": lambda: gen_constants(model, ms), "so3block": gen_so3_block, "direction": lambda: gen_direction(model),
              "propagation": gen_propagation, "pt": gen_pt, "markers": lambda: gen_markers(ms), "model": lambda: gen_model(model), "scan4d": lambda: gen_scan4d(model),
-             "model5k": lambda: gen_model5k(model), "model20k": lambda: gen_model20k(model), "padding_fp64": lambda: gen_padding_fp64(model, ms),
+             "model5k": lambda: gen_model5k(model, ms), "model20k": lambda: gen_model20k(model), "padding_fp64": lambda: gen_padding_fp64(model, ms),
              "rodrigues": gen_rodrigues}
     for name, fn in steps.items():
         if not only or name in only:

@@ -48,8 +48,36 @@ def check_stage1_vs_fixture(res, anc_w, g, anchors, scans=None, tol=RTOL):
     assert out["label_agreement"] > 0.999, out["label_agreement"]      # an argmax may flip only where two logits tie within the tolerance
     aw = anc_w[sel].cpu().numpy()[:, rows]
     out["anc_w"] = rel_err(aw, g["anc_w"])
-    assert out["anc_w"] < tol, out["anc_w"]
+    if "anc_w_fp64" in g.files:
+        # conditioning yardstick stored with the fixture: the reference's Python run in fp64 and, per point, how far the reference's
+        # OWN fp32 run lands from it (a few points carry saturated attention rows that amplify fp32 rounding).  The GPU result
+        # must be within tol of the fp32 reference on (nearly) as many points as the fp32 reference is within tol of the truth, and as
+        # close to the fp64 truth as the reference's fp32 run is (x2 for a different summation order) everywhere.
+        scale = float(g["anc_w_scale"])
+        dev = np.abs(aw.astype(np.float64) - g["anc_w_fp64"]).max(-1) / scale
+        ref = g["ref_fp32_dev"].astype(np.float64)
+        per_point = np.abs(aw.astype(np.float64) - g["anc_w"]).max(-1) / np.abs(g["anc_w"]).max()
+        out["anc_w_vs_fp64"] = {"gpu_max": float(dev.max()), "ref_fp32_max": float(ref.max()), "gpu_q999": float(np.quantile(dev, 0.999)),
+                                "ref_fp32_q999": float(np.quantile(ref, 0.999))}
+        out["anc_w_vs_fp64"]["points_within_tol_of_fp32_ref"] = float((per_point < tol).mean())
+        assert (per_point < tol).mean() >= min(0.999, (ref < tol).mean() - 0.002), float((per_point < tol).mean())
+        assert dev.max() <= max(2.0 * ref.max(), tol), out["anc_w_vs_fp64"]
+        assert np.quantile(dev, 0.999) <= max(2.0 * np.quantile(ref, 0.999), tol), out["anc_w_vs_fp64"]
+    else:
+        assert out["anc_w"] < tol, out["anc_w"]
     d = res["direction"][sel].cpu().numpy()
     assert np.abs(np.linalg.norm(d, axis=-1) - 1).max() < 1e-4
     out["direction_tight_frac"] = direction_within_conditioning(d[:, rows], aw, g["anc_w"], g["direction"][:, rows], anchors)
     return out
+
+
+def oracle_trace(trace, it0=30, it1=50):
+    """Per-iteration error trace of oracle.stage2.fit_smpl as a (B, it0 + it1 + 2) array.  The oracle's LM loop ends as soon as
+    EVERY sample of the batch has converged; the kernel keeps reporting the frozen error for the remaining iterations."""
+    out = []
+    for tr, n in zip(trace, (it0 + 1, it1 + 1)):
+        t = torch.stack(tr, 1)
+        if t.shape[1] < n:
+            t = torch.cat([t, t[:, -1:].expand(-1, n - t.shape[1])], 1)
+        out.append(t)
+    return torch.cat(out, 1).numpy()

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from _parity import check_stage1_vs_fixture, rel_err
+from _parity import check_stage1_vs_fixture, oracle_trace, rel_err
 from etch_amd.utils.weights import load_seeded
 
 pytestmark = pytest.mark.gpu
@@ -63,7 +63,7 @@ def _check_fit_vs_oracle(args, markers, valid, aux, info, scans=None):
     mv = np.array(list(args.markerset.values()))
     trace = []
     ref = S2.fit_smpl(args.body_model, mv, markers[scans], valid[scans], trace=trace)
-    rt = torch.cat([torch.stack(trace[0], 1), torch.stack(trace[1], 1)], 1).numpy()
+    rt = oracle_trace(trace)
     gt = aux["err_trace"].cpu().numpy()[scans]
     assert np.abs(gt - rt).max() / rt.max() < 1e-4
     verts = aux["verts"].cpu().numpy()[scans]

@@ -115,3 +115,36 @@ def test_load_smpl_pkl_key_layout(tmp_path):
     a = S2.lbs(S2.TorchBody(got), x[:, 69:79], torch.cat([x[:, 79:82], x[:, :69]], 1), x[:, 82:85])[0]
     b = S2.lbs(S2.TorchBody(bm), x[:, 69:79], torch.cat([x[:, 79:82], x[:, :69]], 1), x[:, 82:85])[0]
     assert torch.equal(a, b)
+
+
+def test_reference_operator_names_are_exported():
+    """every operator name of the reference that sits on or beside the path resolves under the same module path
+    (importing needs no GPU; calling them does)."""
+    import importlib
+    want = {
+        "etch_amd.vgtk_so3conv": ["SphericalPointCloud", "BasicSO3Conv", "InterSO3Conv", "IntraSO3Conv", "functional", "batch_gather", "group_nd",
+                                  "ball_query_index", "furthest_sample_index", "furthest_sample", "get_anchors", "get_intra_idx"],
+        "etch_amd.vgtk_so3conv.functional".replace(".functional", ""): [],
+        "etch_amd.vgtk_functional": ["batched_index_select", "inter_so3conv_feat_grouping", "get_occupancy_features", "add_shadow_point",
+                                     "add_shadow_feature", "get_sphereical_kernel_points_from_ply", "ball_query", "inter_spconv_grouping_ball",
+                                     "inter_so3conv_grouping", "inter_so3conv_grouping_anchor", "intra_so3conv_grouping", "get_anchors",
+                                     "get_intra_idx"],
+        "etch_amd.models.so3conv": ["preprocess_input", "IntraSO3ConvBlock", "InterSO3ConvBlock", "BasicSO3ConvBlock", "SeparableSO3ConvBlock",
+                                    "so3_mean"],
+        "etch_amd.models.pointnet2_utils": ["square_distance", "index_points", "PointFeatPropagation"],
+        "etch_amd.models.pointops": ["furthestsampling", "knnquery", "queryandgroup", "interpolation"],
+        "etch_amd.models.direction_backbones": ["BatchLinear", "BatchMLP", "DotProdAttention", "MultiHeadAttention", "StackedMHSA"],
+        "etch_amd.models.fit_SMPL": ["get_markers", "fit_smpl"],
+        "etch_amd.models.so3net": ["build_model", "EquivBackbone"],
+        "etch_amd.epn_grouping": ["ball_query", "furthest_point_sampling"],
+        "etch_amd.epn_gathering": ["gather_points_forward", "gather_points_backward"],
+        "etch_amd.pointops_cuda": ["knnquery_cuda", "furthestsampling_cuda"],
+    }
+    for mod, names in want.items():
+        m = importlib.import_module(mod)
+        for n in names:
+            assert hasattr(m, n), (mod, n)
+    import etch_amd.vgtk_so3conv as V
+    assert V.functional.get_anchors(60).shape == (60, 3, 3) and V.functional.get_intra_idx().shape == (60, 12)
+    kp = V.functional.get_sphereical_kernel_points_from_ply(0.7 * 0.2, 1)
+    assert kp.shape == (24, 3) and abs(float(np.sqrt((kp ** 2).sum(1).max())) - 0.14) < 1e-6

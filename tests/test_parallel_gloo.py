@@ -86,28 +86,42 @@ def test_bench_self_launch_propagates_a_rank_failure():
 
 
 def test_core_pinning_from_kfd_topology(tmp_path):
-    """local_cpu_set on a fake sysfs tree shaped like an 8-GPU MI355X node: 2 CPU nodes (KFD nodes 0, 1), GPUs 0-3 linked to
-    socket 0 and GPUs 4-7 to socket 1 -> each rank gets its own quarter of its socket's cores."""
+    """local_cpu_set on a fake sysfs tree shaped like the 8-GPU MI355X node of the bench pool (gpurun_out/topology.txt): KFD nodes
+    0, 1 = the two sockets, whose io_links name GPU nodes 2-5 / 6-9; GPU `properties` are only readable for the GPUs the
+    container was handed.  Each rank gets its own quarter of its socket's cores."""
     from etch_amd import parallel as P
-    kfd, nodes = tmp_path / "kfd", tmp_path / "node"
     avail = sorted(os.sched_getaffinity(0))
     half = max(1, len(avail) // 2)
     lists = [avail[:half], avail[half:] or avail[:half]]
-    for i in range(10):
-        d = kfd / str(i)
-        (d / "io_links" / "0").mkdir(parents=True)
-        cpu = i < 2
-        (d / "properties").write_text(f"cpu_cores_count {64 if cpu else 0}\nsimd_count {0 if cpu else 1024}\n")
-        (d / "io_links" / "0" / "properties").write_text(f"type 2\nnode_from {i}\nnode_to {0 if cpu else (0 if i < 6 else 1)}\n")
-    for k in range(2):
-        (nodes / f"node{k}").mkdir(parents=True)
-        (nodes / f"node{k}" / "cpulist").write_text(",".join(str(c) for c in lists[k]) + "\n")
-    assert P.gpu_numa_nodes(str(kfd)) == [0, 0, 0, 0, 1, 1, 1, 1]
-    sets = [P.local_cpu_set(r, 8, str(kfd), str(nodes)) for r in range(8)]
+
+    def tree(name, readable):
+        kfd, nodes = tmp_path / name / "kfd", tmp_path / name / "node"
+        for i in range(10):
+            d = kfd / str(i)
+            cpu = i < 2
+            peers = ([1 - i] + list(range(2, 6) if i == 0 else range(6, 10))) if cpu else [0 if i < 6 else 1]
+            for k, to in enumerate(peers):
+                (d / "io_links" / str(k)).mkdir(parents=True)
+                (d / "io_links" / str(k) / "properties").write_text(f"type 2\nnode_from {i}\nnode_to {to}\n")
+            if cpu or i in readable:
+                (d / "properties").write_text(f"cpu_cores_count {64 if cpu else 0}\nsimd_count {0 if cpu else 1024}\n")
+        for k in range(2):
+            (nodes / f"node{k}").mkdir(parents=True)
+            (nodes / f"node{k}" / "cpulist").write_text(",".join(str(c) for c in lists[k]) + "\n")
+        return str(kfd), str(nodes)
+
+    kfd, nodes = tree("all8", range(2, 10))
+    assert P.gpu_numa_nodes(kfd) == [0, 0, 0, 0, 1, 1, 1, 1]
+    sets = [P.local_cpu_set(r, 8, kfd, nodes) for r in range(8)]
     assert all(s for s in sets)
     for r in range(8):
         assert set(sets[r]) <= set(lists[0 if r < 4 else 1])
     if len(lists[0]) >= 4:
         assert all(not (set(sets[a]) & set(sets[b])) for a in range(4) for b in range(a + 1, 4))
+    # a container that was handed one GPU of the second socket (KFD node 7): ordinal 0 is that GPU
+    kfd1, nodes1 = tree("one", [7])
+    assert P.gpu_numa_nodes(kfd1) == [1]
+    assert set(P.local_cpu_set(0, 1, kfd1, nodes1)) == set(lists[1])
     # unreadable topology -> even split of the affinity mask
-    assert P.local_cpu_set(1, 2, str(tmp_path / "none"), str(nodes)) == avail[len(avail) // 2:2 * (len(avail) // 2)]
+    got = P.local_cpu_set(1, 2, str(tmp_path / "none"), nodes)
+    assert got and set(got) <= set(avail) and (len(avail) < 2 or not set(got) & set(P.local_cpu_set(0, 2, str(tmp_path / "none"), nodes)))
