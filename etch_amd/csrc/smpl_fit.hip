@@ -1,38 +1,66 @@
-// Stage 2 of ETCH on gfx950: marker aggregation, the two-stage Levenberg-Marquardt SMPL fit and the final
-// full-mesh LBS (SURVEY 8 rows a17-a20, Appendix C).
+// Stage 2 of ETCH on gfx950: marker aggregation, the two-stage Levenberg-Marquardt body-model fit and the final
+// full-mesh LBS (SURVEY 8 rows a17-a20, f4, Appendix C).
 //
 //   etch_argmax_rows   torch.max(part_labels, -1) of predict_smpl (/root/reference/src/inference_demo.py:52-53)
 //   etch_get_markers   get_markers (/root/reference/src/models/fit_SMPL.py:17-62)
 //   etch_smpl_lm_fit   fit_smpl's two Theseus LevenbergMarquardt stages (fit_SMPL.py:161-249) with the residual of
-//                      marker_error_fn_{0,1} (:111-152).  The reference differentiates the FULL 6890-vertex LBS with
-//                      autograd (~2.2 GFLOP / scan / iteration); here the forward and an ANALYTIC Jacobian are
-//                      restricted to the 86 marker vertices (Appendix C): one persistent workgroup per scan keeps
-//                      J (258x85) and J^T J in LDS through all 30 + 50 iterations.
-//   etch_smpl_lbs      the final smpl_model(...) call (fit_SMPL.py:258-259): vertices (B,V,3) and 45 joints.
+//                      marker_error_fn_{0,1} (:111-152).  The reference differentiates the FULL-mesh LBS with autograd
+//                      (~2.2 GFLOP / scan / iteration); here the forward and an ANALYTIC Jacobian are restricted to the
+//                      marker vertices (Appendix C): one persistent workgroup per scan keeps the whole fit on chip
+//                      through all iterations.
+//   etch_smpl_lbs      the final smpl_model(...) call (fit_SMPL.py:258-259): vertices (B,V,3) and the joints.
+//
+// Body models: the kernels are templated on (joints NJ, shape coefficients NB) and instantiated for SMPL (24, 10: the
+// reference's model, fit_SMPL.py:100) and for an SMPL-X-sized model (55, 20: BASELINE configs[4]).  Variable
+// vector x = pose[3(NJ-1)] | betas[NB] | global_orient[3] | transl[3] (the reference's order, fit_SMPL.py:174,225); stage 0
+// optimises the first 2 betas only (:161-165), stage 1 all of them.
 //
 // [upstream, not in the reference tree] LBS = smplx.lbs.lbs, LM = theseus.LevenbergMarquardt (dense Cholesky, fixed
 // damping, no step rejection, per-sample freeze on |d err| < 1e-10 or |d err|/err < 1e-8).  batch_rodrigues follows
 // the in-tree copy src/data_utils/GT_dataloader_mixed.py:29-64 (angle = |theta + 1e-8|).
-// Arithmetic: forward kinematics, J^T J, Cholesky in fp64; J is stored in fp32 (like the reference's fp32 Jacobian).
+//
+// Arithmetic: kinematics, J^T J / J^T r (fp64 matrix cores, v_mfma_f64_16x16x4_f64, on the fp32 Jacobian rows -- the
+// reference's Jacobian is fp32 too) and the Cholesky solve in fp64.
+//
+// LDS plan (one workgroup = 12 waves per scan).  The Jacobian is never held whole: markers are linearised 12 at a time
+// (one per wave) into a double-buffered 36-row chunk, and every wave accumulates its share of the 16x16 tiles of the lower
+// triangle of [J | r]^T [J | r] in matrix-core accumulators across the chunks.  The packed normal matrix (fp64, 30 KB for
+// SMPL, 144 KB for the 188-DoF model) ALIASES the linearisation scratch: it is written from the accumulators after the last
+// chunk and consumed by the Cholesky solve before the next linearisation.
 #include "common.h"
 
-#define NJ 24
-#define NB 10
-#define NPOSE 69
-#define DOF 85
-#define MAXM 86
-#define LDJ 88            // J row stride (floats), 16-B aligned
-#define LM_THREADS 768
+#define LM_MAXM 128                 // markers per scan
+#define NB_STAGE0 2                 // fit_SMPL.py:161-165: stage 0 optimises betas[:2]
+
+template <int NJ_, int NB_, int THREADS_>
+struct Body {
+    static constexpr int NJ = NJ_, NB = NB_;
+    static constexpr int THREADS = THREADS_, WAVES = THREADS_ / 64;   // one workgroup per scan
+    static constexpr int CHUNK_ROWS = 3 * WAVES;        // markers are linearised WAVES at a time, 3 Jacobian rows each
+    static constexpr int NPOSE = 3 * (NJ - 1);          // body pose variables
+    static constexpr int NPF = 9 * (NJ - 1);            // pose-feature entries vec(R_k - I)
+    static constexpr int DOF = NPOSE + NB + 6;
+    static constexpr int NT = (DOF + 1 + 15) / 16;      // 16-column tiles of [J | r]
+    static constexpr int LDJ = NT * 16;
+    static constexpr int LDJS = LDJ + 16;               // row stride of a Jacobian chunk: the 4 rows of an MFMA K-step hit distinct banks
+    static constexpr int NTILES = NT * (NT + 1) / 2;    // lower triangle
+    static constexpr int TPW = (NTILES + WAVES - 1) / WAVES;
+    static constexpr int NPACK = (DOF + 1) * (DOF + 2) / 2;
+    static constexpr bool STAGE_P = NJ <= 24;           // the marker's posedirs columns staged in LDS (SMPL) or read through L1/L2
+    static constexpr int PFL = (3 * NPF + 63) / 64;     // floats per lane of a marker's posedirs block
+    static constexpr int NSW = 3 * NB + NJ;             // shapedirs rows + skinning weights of a marker
+    static constexpr int SWL = (NSW + 63) / 64;
+};
 
 struct SmplConsts {
-    const float* J0;      // [24][3]      J_regressor @ v_template
-    const float* Jd;      // [24][3][10]  J_regressor @ shapedirs
-    const int* parents;   // [24]
+    const float* J0;      // [NJ][3]      J_regressor @ v_template
+    const float* Jd;      // [NJ][3][NB]  J_regressor @ shapedirs
+    const int* parents;   // [NJ]
     // marker-restricted tables (M markers)
     const float* mk_vt;   // [M][3]
-    const float* mk_S;    // [M][3][10]
-    const float* mk_P;    // [M][207][3]
-    const float* mk_W;    // [M][24]
+    const float* mk_S;    // [M][3][NB]
+    const float* mk_P;    // [M][NPF][3]
+    const float* mk_W;    // [M][NJ]
 };
 
 // ---------------------------------------------------------------------------------------------- helpers
@@ -62,17 +90,17 @@ __device__ inline void rodrigues_d(const double th[3], double R[9], float dR[3][
     }
 }
 
-// x layout: pose[69] | betas[10] | orient[3] | transl[3]
-__device__ inline void joint_theta(const double* x, int j, double th[3]) {
-    const double* p = j == 0 ? x + NPOSE + NB : x + 3 * (j - 1);
+// x layout: pose[3(nj-1)] | betas[nb] | orient[3] | transl[3]
+__device__ inline void joint_theta(const double* x, int j, int npose, int nb, double th[3]) {
+    const double* p = j == 0 ? x + npose + nb : x + 3 * (j - 1);
     th[0] = p[0]; th[1] = p[1]; th[2] = p[2];
 }
 
 // Forward kinematics by one thread: Rw_j = Rw_p R_j, tw_j = Rw_p (J_j - J_p) + tw_p
-__device__ inline void fk_chain(const int* parents, const double* R, const double* Jj, double* Rw, double* tw) {
+__device__ inline void fk_chain(int nj, const int* parents, const double* R, const double* Jj, double* Rw, double* tw) {
     for (int i = 0; i < 9; ++i) Rw[i] = R[i];
     for (int i = 0; i < 3; ++i) tw[i] = Jj[i];
-    for (int j = 1; j < NJ; ++j) {
+    for (int j = 1; j < nj; ++j) {
         const int p = parents[j];
         const double* Rp = Rw + p * 9;
         const double* Rj = R + j * 9;
@@ -84,38 +112,44 @@ __device__ inline void fk_chain(const int* parents, const double* R, const doubl
 }
 
 // ---------------------------------------------------------------------------------------------- LM fit
-#define LM_WAVES (LM_THREADS / 64)
-#define LM_WS_OWN 6
-struct LmWaveScratch {               // per-wave staging of one marker
-    float P[624];                    // posedirs columns of the marker: [207][3]
-    float Ay[NJ][4];                 // W_vj * y_vj (xyz) and W_vj
-    float U[NJ][4];                  // subtree sum of Ay minus w * tw_k
-    float T[12];                     // sum_j W_vj Rw_j
-    float S[32];                     // shapedirs rows of the marker [3][10]
+template <class BM>
+struct LmWaveScratch {                // per-wave staging of one marker
+    float P[BM::STAGE_P ? 3 * BM::NPF + 3 : 4];   // posedirs columns of the marker: [NPF][3]
+    float Ay[BM::NJ][4];              // W_vj * y_vj (xyz) and W_vj
+    float U[BM::NJ][4];               // subtree sum of Ay minus w * tw_k
+    float T[12];                      // sum_j W_vj Rw_j
+    float S[(3 * BM::NB + 3) & ~3];   // shapedirs rows of the marker [3][NB]
 };
+
+template <class BM>
+struct LmLin {                        // linearisation scratch (dead during the solve)
+    double R[BM::NJ * 9], Rw[BM::NJ * 9], tw[BM::NJ * 3], Jj[BM::NJ * 3];
+    float dR[BM::NJ][3][9];
+    float omega[BM::NJ][3][4];
+    float twd[BM::NB][BM::NJ][3];
+    float pf[BM::NPF + 1];
+    float Jd[BM::NJ * 3 * BM::NB];    // LDS copy of the joint shape basis
+    float J0[BM::NJ * 3];
+    LmWaveScratch<BM> ws[BM::WAVES];
+    float Jc[2][BM::CHUNK_ROWS * BM::LDJS];   // double-buffered Jacobian chunk: 3 rows per wave, column DOF = residual
+};
+
+template <class BM>
 struct LmShared {
-    float Jm[3 * MAXM * LDJ];            // Jacobian rows (fp32)
-    double A[(DOF + 1) * (DOF + 2) / 2]; // packed lower triangle of [J^T J + lambda I ; g^T] (row 85 = rhs), then L and y
-    double x[DOF];
-    double R[NJ * 9], Rw[NJ * 9], tw[NJ * 3], Jj[NJ * 3];
-    double g[DOF + 3], delta[DOF + 3];
-    float dR[NJ][3][9];
-    float omega[NJ][3][4];
-    float twd[NB][NJ][3];
-    float pf[208];
-    float resid[3 * MAXM];
-    int parents[NJ];
-    unsigned sub[NJ];                    // bit j of sub[k]: joint j lies in the subtree of joint k
-    float Jd[NJ * 3 * NB];               // LDS copy of the joint shape basis
-    float J0[NJ * 3];
-    double rdiag[DOF + 3];               // 1 / L_ii
-    double rpiv;                         // 1 / A_kk of the column being eliminated
-    float target[3 * MAXM], mask[MAXM];  // LDS copies: no global load may sit between a prefetch and its use
+    union {
+        LmLin<BM> lin;
+        double A[BM::NPACK];          // packed lower triangle of [J^T J + lambda I ; g^T] (row DOF = rhs), then L and y
+    };
+    double x[BM::DOF];
+    double delta[BM::DOF + 3];
+    double rdiag[BM::DOF + 3];        // 1 / L_ii
+    double rpiv;                      // 1 / A_kk of the column being eliminated
     double err;
-    long long phase[8];                 // s_memtime cycles per phase (thread 0), optional diagnostics
-    LmWaveScratch ws[LM_WS_OWN];        // staging of waves 0..LM_WS_OWN-1; the other waves stage inside A (dead while linearising)
+    float target[3 * LM_MAXM], mask[LM_MAXM], resid[3 * LM_MAXM];
+    int parents[BM::NJ];
+    unsigned long long sub[BM::NJ];   // bit j of sub[k]: joint j lies in the subtree of joint k
+    long long phase[8];               // s_memtime cycles per phase (thread 0), optional diagnostics
 };
-static_assert((LM_WAVES - LM_WS_OWN) * sizeof(LmWaveScratch) <= sizeof(double) * (DOF + 1) * (DOF + 2) / 2, "aliased wave scratch must fit the packed matrix");
 
 __device__ inline double& Apk(double* A, int i, int j) { return A[i * (i + 1) / 2 + j]; }   // i >= j
 
@@ -136,249 +170,320 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
-// residual + Jacobian at s.x.  nb = number of active betas (2 in stage 0, 10 in stage 1).
-__device__ void lm_linearize(LmShared& s, const SmplConsts& C, int M, int nb, const float* target, const float* mask) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// per-scan constants into LDS: parents, targets, subtree membership masks
+template <class BM>
+__device__ void lm_setup(LmShared<BM>& s, const SmplConsts& C, int M, const float* target, const float* mask) {
+    constexpr int NJ = BM::NJ;
+    const int tid = threadIdx.x;
+    if (tid < 8) s.phase[tid] = 0;
+    if (tid < NJ) s.parents[tid] = C.parents[tid];
+    if (tid < M * 3) s.target[tid] = target[tid];
+    if (tid < M) s.mask[tid] = mask[tid];
+    __syncthreads();
+    if (tid < NJ) {                            // subtree membership masks
+        unsigned long long m = 0ull;
+        for (int j = 0; j < NJ; ++j) {
+            int a = j;
+            while (a > tid) a = s.parents[a];
+            if (a == tid) m |= 1ull << j;
+        }
+        s.sub[tid] = m;
+    }
+    __syncthreads();
+}
+
+// residual + normal equations at s.x.  nb = number of active betas (2 in stage 0, NB in stage 1).  On return s.A holds the packed
+// lower triangle of J^T J (no damping yet) with the right-hand side -J^T r as row DOF, s.resid / s.err the residual and 0.5 |r|^2.
+// jac_out (diagnostics): the marker rows of J (3M x DOF) are also written to global memory.
+template <class BM>
+__device__ void lm_linearize(LmShared<BM>& s, const SmplConsts& C, int M, int nb, float* __restrict__ jac_out) {
+    constexpr int NJ = BM::NJ, NB = BM::NB, NPOSE = BM::NPOSE, NPF = BM::NPF, DOF = BM::DOF, LDJ = BM::LDJ, LDJS = BM::LDJS;
+    LmLin<BM>& L = s.lin;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile indices stay in SGPRs
+    for (int i = tid; i < NJ * 3 * NB; i += BM::THREADS) L.Jd[i] = C.Jd[i];      // the solve overwrote this region: reload (L2-resident)
+    if (tid < NJ * 3) L.J0[tid] = C.J0[tid];
+    __syncthreads();
     if (tid < NJ) {
         double th[3];
-        joint_theta(s.x, tid, th);
-        rodrigues_d(th, s.R + tid * 9, s.dR[tid], true);
+        joint_theta(s.x, tid, NPOSE, NB, th);
+        rodrigues_d(th, L.R + tid * 9, L.dR[tid], true);
         for (int c = 0; c < 3; ++c) {
-            double v = s.J0[tid * 3 + c];
-            for (int l = 0; l < NB; ++l) v += (double)s.Jd[(tid * 3 + c) * NB + l] * s.x[NPOSE + l];
-            s.Jj[tid * 3 + c] = v;
+            double v = L.J0[tid * 3 + c];
+            for (int l = 0; l < NB; ++l) v += (double)L.Jd[(tid * 3 + c) * NB + l] * s.x[NPOSE + l];
+            L.Jj[tid * 3 + c] = v;
         }
     }
     __syncthreads();
     long long t0 = 0;
     if (tid == 0) t0 = wall_clock64();
     if (tid < 64) {                            // forward kinematics: 12 lanes per joint step (9 rotation entries + 3 translation)
-        if (lane < 9) s.Rw[lane] = s.R[lane];
-        else if (lane < 12) s.tw[lane - 9] = s.Jj[lane - 9];
+        if (lane < 9) L.Rw[lane] = L.R[lane];
+        else if (lane < 12) L.tw[lane - 9] = L.Jj[lane - 9];
         __builtin_amdgcn_wave_barrier();
         for (int j = 1; j < NJ; ++j) {
             const int p = s.parents[j];
-            const double* Rp = s.Rw + p * 9;
+            const double* Rp = L.Rw + p * 9;
             if (lane < 9) {
                 const int a = lane / 3, b = lane - a * 3;
-                s.Rw[j * 9 + lane] = Rp[a * 3] * s.R[j * 9 + b] + Rp[a * 3 + 1] * s.R[j * 9 + 3 + b] + Rp[a * 3 + 2] * s.R[j * 9 + 6 + b];
+                L.Rw[j * 9 + lane] = Rp[a * 3] * L.R[j * 9 + b] + Rp[a * 3 + 1] * L.R[j * 9 + 3 + b] + Rp[a * 3 + 2] * L.R[j * 9 + 6 + b];
             } else if (lane < 12) {
                 const int a = lane - 9;
-                s.tw[j * 3 + a] = Rp[a * 3] * (s.Jj[j * 3] - s.Jj[p * 3]) + Rp[a * 3 + 1] * (s.Jj[j * 3 + 1] - s.Jj[p * 3 + 1]) +
-                                  Rp[a * 3 + 2] * (s.Jj[j * 3 + 2] - s.Jj[p * 3 + 2]) + s.tw[p * 3 + a];
+                L.tw[j * 3 + a] = Rp[a * 3] * (L.Jj[j * 3] - L.Jj[p * 3]) + Rp[a * 3 + 1] * (L.Jj[j * 3 + 1] - L.Jj[p * 3 + 1]) +
+                                  Rp[a * 3 + 2] * (L.Jj[j * 3 + 2] - L.Jj[p * 3 + 2]) + L.tw[p * 3 + a];
             }
             __builtin_amdgcn_wave_barrier();
         }
     }
-    if (tid >= 64 && tid < 64 + 207) {         // pose feature vec(R_k - I), k = 1..23
-        const int e = tid - 64, k = 1 + e / 9, q = e - (k - 1) * 9;
-        s.pf[e] = (float)(s.R[k * 9 + q] - ((q % 4 == 0) ? 1.0 : 0.0));
+    for (int e = tid - 64; e >= 0 && e < NPF; e += BM::THREADS - 64) {   // pose feature vec(R_k - I), k = 1..NJ-1
+        const int k = 1 + e / 9, q = e - (k - 1) * 9;
+        L.pf[e] = (float)(L.R[k * 9 + q] - ((q % 4 == 0) ? 1.0 : 0.0));
     }
     __syncthreads();
     if (tid < NJ * 3) {                       // omega_kc = Rw_parent(k) * axial(dR_kc R_k^T)
         const int k = tid / 3, c = tid - k * 3;
-        const float* d = s.dR[k][c];
-        const double* Rk = s.R + k * 9;
+        const float* d = L.dR[k][c];
+        const double* Rk = L.R + k * 9;
         double Sk[9];
         for (int a = 0; a < 3; ++a)
             for (int b = 0; b < 3; ++b) Sk[a * 3 + b] = d[a * 3] * Rk[b * 3] + d[a * 3 + 1] * Rk[b * 3 + 1] + d[a * 3 + 2] * Rk[b * 3 + 2];
         const double ax[3] = {0.5 * (Sk[7] - Sk[5]), 0.5 * (Sk[2] - Sk[6]), 0.5 * (Sk[3] - Sk[1])};
-        if (k == 0) { for (int a = 0; a < 3; ++a) s.omega[k][c][a] = (float)ax[a]; }
+        if (k == 0) { for (int a = 0; a < 3; ++a) L.omega[k][c][a] = (float)ax[a]; }
         else {
-            const double* Rp = s.Rw + s.parents[k] * 9;
-            for (int a = 0; a < 3; ++a) s.omega[k][c][a] = (float)(Rp[a * 3] * ax[0] + Rp[a * 3 + 1] * ax[1] + Rp[a * 3 + 2] * ax[2]);
+            const double* Rp = L.Rw + s.parents[k] * 9;
+            for (int a = 0; a < 3; ++a) L.omega[k][c][a] = (float)(Rp[a * 3] * ax[0] + Rp[a * 3 + 1] * ax[1] + Rp[a * 3 + 2] * ax[2]);
         }
-    } else if (tid >= 128 && tid < 128 + NB) {   // d tw_j / d beta_l chain
-        const int l = tid - 128;
-        float (*t)[3] = s.twd[l];
-        for (int a = 0; a < 3; ++a) t[0][a] = s.Jd[(0 * 3 + a) * NB + l];
+    } else if (tid >= 256 && tid < 256 + NB) {   // d tw_j / d beta_l chain
+        const int l = tid - 256;
+        float (*t)[3] = L.twd[l];
+        for (int a = 0; a < 3; ++a) t[0][a] = L.Jd[(0 * 3 + a) * NB + l];
         for (int j = 1; j < NJ; ++j) {
             const int p = s.parents[j];
-            const double* Rp = s.Rw + p * 9;
-            const double d[3] = {(double)s.Jd[(j * 3 + 0) * NB + l] - s.Jd[(p * 3 + 0) * NB + l], (double)s.Jd[(j * 3 + 1) * NB + l] - s.Jd[(p * 3 + 1) * NB + l],
-                                 (double)s.Jd[(j * 3 + 2) * NB + l] - s.Jd[(p * 3 + 2) * NB + l]};
+            const double* Rp = L.Rw + p * 9;
+            const double d[3] = {(double)L.Jd[(j * 3 + 0) * NB + l] - L.Jd[(p * 3 + 0) * NB + l], (double)L.Jd[(j * 3 + 1) * NB + l] - L.Jd[(p * 3 + 1) * NB + l],
+                                 (double)L.Jd[(j * 3 + 2) * NB + l] - L.Jd[(p * 3 + 2) * NB + l]};
             for (int a = 0; a < 3; ++a) t[j][a] = (float)(Rp[a * 3] * d[0] + Rp[a * 3 + 1] * d[1] + Rp[a * 3 + 2] * d[2] + t[p][a]);
         }
     }
     __syncthreads();
-    for (int e = tid; e < NB * NJ * 3; e += LM_THREADS) {   // Q[l][j] = d tw_j/d beta_l - Rw_j Jd_j[:,l]  (in place)
+    for (int e = tid; e < NB * NJ * 3; e += BM::THREADS) {   // Q[l][j] = d tw_j/d beta_l - Rw_j Jd_j[:,l]  (in place)
         const int l = e / (NJ * 3), r = e - l * NJ * 3, j = r / 3, a = r - j * 3;
-        const double* Rj = s.Rw + j * 9;
-        s.twd[l][j][a] -= (float)(Rj[a * 3] * s.Jd[(j * 3 + 0) * NB + l] + Rj[a * 3 + 1] * s.Jd[(j * 3 + 1) * NB + l] + Rj[a * 3 + 2] * s.Jd[(j * 3 + 2) * NB + l]);
+        const double* Rj = L.Rw + j * 9;
+        L.twd[l][j][a] -= (float)(Rj[a * 3] * L.Jd[(j * 3 + 0) * NB + l] + Rj[a * 3 + 1] * L.Jd[(j * 3 + 1) * NB + l] + Rj[a * 3 + 2] * L.Jd[(j * 3 + 2) * NB + l]);
     }
     __syncthreads();
     if (tid == 0) { const long long t1 = wall_clock64(); s.phase[0] += t1 - t0; t0 = t1; }
-    // ---- one wave per marker: forward, residual, and the marker's three Jacobian rows
-    LmWaveScratch& w = wave < LM_WS_OWN ? s.ws[wave] : reinterpret_cast<LmWaveScratch*>(s.A)[wave - LM_WS_OWN];
-    float pre[11];                             // register prefetch of the next marker's P (10 / lane) and S|W (1 / lane)
-    auto fetch = [&](int v) {
-        const float* Pg = C.mk_P + (size_t)v * 621;
+
+    // ---- markers, 12 at a time (one per wave): forward, residual, the marker's three Jacobian rows into the chunk buffer; then every
+    // wave adds the chunk's contribution to its tiles of [J | r]^T [J | r] on the fp64 matrix cores.
+    LmWaveScratch<BM>& w = L.ws[wave];
+    f64x4 acc[BM::TPW];
+    int tmi[BM::TPW], tnj[BM::TPW];
 #pragma unroll
-        for (int q = 0; q < 10; ++q) { const int i = lane + 64 * q; pre[q] = i < 621 ? Pg[i] : 0.f; }
-        pre[10] = lane < 3 * NB ? C.mk_S[(size_t)v * 3 * NB + lane] : (lane >= 32 && lane < 32 + NJ ? C.mk_W[v * NJ + lane - 32] : 0.f);
+    for (int t = 0; t < BM::TPW; ++t) {
+        acc[t] = (f64x4){0.0, 0.0, 0.0, 0.0};
+        const int tile = wave + BM::WAVES * t;
+        int mi = 0;
+        while ((mi + 1) * (mi + 2) / 2 <= tile) ++mi;
+        tmi[t] = mi; tnj[t] = tile - mi * (mi + 1) / 2;            // nj <= mi
+    }
+    float pre[BM::PFL + BM::SWL];              // register prefetch of the next marker's P and S|W
+    auto fetch = [&](int v) {
+        const float* Pg = C.mk_P + (size_t)v * 3 * NPF;
+#pragma unroll
+        for (int q = 0; q < BM::PFL; ++q) { const int i = lane + 64 * q; pre[q] = i < 3 * NPF ? Pg[i] : 0.f; }
+#pragma unroll
+        for (int q = 0; q < BM::SWL; ++q) {
+            const int i = lane + 64 * q;
+            pre[BM::PFL + q] = i < 3 * NB ? C.mk_S[(size_t)v * 3 * NB + i] : (i < BM::NSW ? C.mk_W[(size_t)v * NJ + i - 3 * NB] : 0.f);
+        }
     };
     if (wave < M) fetch(wave);
-    for (int v = wave; v < M; v += LM_WAVES) {
+    const int nchunk = (M + BM::WAVES - 1) / BM::WAVES;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int v = ch * BM::WAVES + wave;
+        float* Jr = L.Jc[ch & 1] + (size_t)(wave * 3) * LDJS;
+        if (v < M) {
+            // this marker's P^T pf partial sums straight from the prefetch registers; S | W into the wave scratch
+            double acc3[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-        for (int q = 0; q < 10; ++q) { const int i = lane + 64 * q; if (i < 621) w.P[i] = pre[q]; }
-        if (lane < 3 * NB) w.S[lane] = pre[10];
-        if (lane >= 32 && lane < 32 + NJ) w.Ay[lane - 32][3] = pre[10];
-        if (v + LM_WAVES < M) fetch(v + LM_WAVES);
-        __builtin_amdgcn_wave_barrier();
-        long long tm0 = 0;
-        if (tid == 0) tm0 = wall_clock64();
-        // posed vertex v_p = v_t + S beta + P^T pf
-        double acc[3] = {0.0, 0.0, 0.0};
-        for (int e = lane; e < 207; e += 64) {
-            const double f = (double)s.pf[e];
-            acc[0] += f * (double)w.P[e * 3]; acc[1] += f * (double)w.P[e * 3 + 1]; acc[2] += f * (double)w.P[e * 3 + 2];
-        }
-        if (lane < 3 * NB) {                     // + S beta, one (c,l) term per lane
-            const int c = lane / NB, l = lane - c * NB;
-            const double sb = (double)w.S[lane] * s.x[NPOSE + l];
-            acc[0] += c == 0 ? sb : 0.0; acc[1] += c == 1 ? sb : 0.0; acc[2] += c == 2 ? sb : 0.0;
-        }
-        double vp[3];
-        for (int c = 0; c < 3; ++c) vp[c] = wave_sum_f64(acc[c]) + (double)C.mk_vt[v * 3 + c];
-        // per-joint contribution y_j (lane j)
-        double xy[3] = {0.0, 0.0, 0.0};
-        if (lane < NJ) {
-            const int j = lane;
-            const double wj = (double)w.Ay[j][3];
-            const double* Rj = s.Rw + j * 9;
-            const double d[3] = {vp[0] - s.Jj[j * 3], vp[1] - s.Jj[j * 3 + 1], vp[2] - s.Jj[j * 3 + 2]};
-            for (int a = 0; a < 3; ++a) {
-                const double y = Rj[a * 3] * d[0] + Rj[a * 3 + 1] * d[1] + Rj[a * 3 + 2] * d[2] + s.tw[j * 3 + a];
-                xy[a] = wj * y;
-                w.Ay[j][a] = (float)xy[a];
-            }
-        } else if (lane >= 32 && lane < 41) {    // T = sum_j W_vj Rw_j
-            const int i = lane - 32;
-            double t = 0.0;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) t += (double)w.Ay[j][3] * s.Rw[j * 9 + i];
-            w.T[i] = (float)t;
-        }
-        double xv[3];
-        for (int a = 0; a < 3; ++a) xv[a] = wave_sum_f64(xy[a]);
-        __builtin_amdgcn_wave_barrier();
-        if (tid == 0) { const long long t1 = wall_clock64(); s.phase[5] += t1 - tm0; tm0 = t1; }
-        if (lane < NJ) {                         // subtree sums relative to the joint origin
-            const int k = lane;
-            const unsigned m = s.sub[k];
-            float u0 = 0.f, u1 = 0.f, u2 = 0.f, uw = 0.f;
-            for (int j = 0; j < NJ; ++j)
-                if ((m >> j) & 1u) { u0 += w.Ay[j][0]; u1 += w.Ay[j][1]; u2 += w.Ay[j][2]; uw += w.Ay[j][3]; }
-            w.U[k][0] = u0 - uw * (float)s.tw[k * 3]; w.U[k][1] = u1 - uw * (float)s.tw[k * 3 + 1]; w.U[k][2] = u2 - uw * (float)s.tw[k * 3 + 2];
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (tid == 0) { const long long t1 = wall_clock64(); s.phase[6] += t1 - tm0; tm0 = t1; }
-        const float mk = s.mask[v];
-        if (lane < 3) s.resid[v * 3 + lane] = (float)((double)mk * ((double)s.target[v * 3 + lane] - (xv[lane] + s.x[NPOSE + NB + 3 + lane])));
-        float* Jr = s.Jm + (size_t)(v * 3) * LDJ;
-        for (int col = lane; col < LDJ; col += 64) {
-            float d[3] = {0.f, 0.f, 0.f};
-            if (col < NPOSE || (col >= NPOSE + NB && col < NPOSE + NB + 3)) {
-                const int k = col < NPOSE ? 1 + col / 3 : 0;
-                const int c = col < NPOSE ? col - 3 * (k - 1) : col - (NPOSE + NB);
-                const float* om = s.omega[k][c];
-                const float* u = w.U[k];
-                d[0] = om[1] * u[2] - om[2] * u[1]; d[1] = om[2] * u[0] - om[0] * u[2]; d[2] = om[0] * u[1] - om[1] * u[0];
-                if (k >= 1) {
-                    const float* P = w.P + (k - 1) * 27;
-                    const float* dr = s.dR[k][c];
-                    float q0 = 0.f, q1 = 0.f, q2 = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 9; ++e) { q0 += dr[e] * P[e * 3]; q1 += dr[e] * P[e * 3 + 1]; q2 += dr[e] * P[e * 3 + 2]; }
-                    for (int a = 0; a < 3; ++a) d[a] += w.T[a * 3] * q0 + w.T[a * 3 + 1] * q1 + w.T[a * 3 + 2] * q2;
+            for (int q = 0; q < BM::PFL; ++q) {
+                const int i = lane + 64 * q;
+                if (i < 3 * NPF) {
+                    if (BM::STAGE_P) w.P[i] = pre[q];
+                    const int e = i / 3, a = i - 3 * e;
+                    const double t = (double)L.pf[e] * (double)pre[q];
+                    acc3[0] += a == 0 ? t : 0.0; acc3[1] += a == 1 ? t : 0.0; acc3[2] += a == 2 ? t : 0.0;
                 }
-            } else if (col < NPOSE + NB) {
-                const int l = col - NPOSE;
-                if (l < nb) {
-                    const float sv[3] = {w.S[l], w.S[NB + l], w.S[2 * NB + l]};
-                    for (int a = 0; a < 3; ++a) d[a] = w.T[a * 3] * sv[0] + w.T[a * 3 + 1] * sv[1] + w.T[a * 3 + 2] * sv[2];
+            }
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        const float wj = w.Ay[j][3];
-                        d[0] += wj * s.twd[l][j][0]; d[1] += wj * s.twd[l][j][1]; d[2] += wj * s.twd[l][j][2];
+            for (int q = 0; q < BM::SWL; ++q) {
+                const int i = lane + 64 * q;
+                if (i < 3 * NB) {                                  // + S beta, one (c,l) term per lane
+                    w.S[i] = pre[BM::PFL + q];
+                    const int c = i / NB, l = i - c * NB;
+                    const double sb = (double)pre[BM::PFL + q] * s.x[NPOSE + l];
+                    acc3[0] += c == 0 ? sb : 0.0; acc3[1] += c == 1 ? sb : 0.0; acc3[2] += c == 2 ? sb : 0.0;
+                } else if (i < BM::NSW) w.Ay[i - 3 * NB][3] = pre[BM::PFL + q];
+            }
+            if (v + BM::WAVES < M) fetch(v + BM::WAVES);
+            __builtin_amdgcn_wave_barrier();
+            // posed vertex v_p = v_t + S beta + P^T pf
+            double vp[3];
+            for (int c = 0; c < 3; ++c) vp[c] = wave_sum_f64(acc3[c]) + (double)C.mk_vt[v * 3 + c];
+            // per-joint contribution y_j (lane j)
+            double xy[3] = {0.0, 0.0, 0.0};
+            if (lane < NJ) {
+                const int j = lane;
+                const double wj = (double)w.Ay[j][3];
+                const double* Rj = L.Rw + j * 9;
+                const double d[3] = {vp[0] - L.Jj[j * 3], vp[1] - L.Jj[j * 3 + 1], vp[2] - L.Jj[j * 3 + 2]};
+                for (int a = 0; a < 3; ++a) {
+                    const double y = Rj[a * 3] * d[0] + Rj[a * 3 + 1] * d[1] + Rj[a * 3 + 2] * d[2] + L.tw[j * 3 + a];
+                    xy[a] = wj * y;
+                    w.Ay[j][a] = (float)xy[a];
+                }
+            }
+            double xv[3];
+            for (int a = 0; a < 3; ++a) xv[a] = wave_sum_f64(xy[a]);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 9) {                          // T = sum_j W_vj Rw_j
+                double t = 0.0;
+#pragma unroll 8
+                for (int j = 0; j < NJ; ++j) t += (double)w.Ay[j][3] * L.Rw[j * 9 + lane];
+                w.T[lane] = (float)t;
+            }
+            if (lane < NJ) {                         // subtree sums relative to the joint origin
+                const int k = lane;
+                const unsigned long long m = s.sub[k];
+                float u0 = 0.f, u1 = 0.f, u2 = 0.f, uw = 0.f;
+                for (int j = 0; j < NJ; ++j)
+                    if ((m >> j) & 1ull) { u0 += w.Ay[j][0]; u1 += w.Ay[j][1]; u2 += w.Ay[j][2]; uw += w.Ay[j][3]; }
+                w.U[k][0] = u0 - uw * (float)L.tw[k * 3]; w.U[k][1] = u1 - uw * (float)L.tw[k * 3 + 1]; w.U[k][2] = u2 - uw * (float)L.tw[k * 3 + 2];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const float mk = s.mask[v];
+            float rres = 0.f;
+            if (lane < 3) {
+                rres = (float)((double)mk * ((double)s.target[v * 3 + lane] - (xv[lane] + s.x[NPOSE + NB + 3 + lane])));
+                s.resid[v * 3 + lane] = rres;
+            }
+            const float r0 = __shfl(rres, 0, 64), r1 = __shfl(rres, 1, 64), r2 = __shfl(rres, 2, 64);
+            for (int col = lane; col < LDJ; col += 64) {
+                float d[3] = {0.f, 0.f, 0.f};
+                if (col < NPOSE || (col >= NPOSE + NB && col < NPOSE + NB + 3)) {
+                    const int k = col < NPOSE ? 1 + col / 3 : 0;
+                    const int c = col < NPOSE ? col - 3 * (k - 1) : col - (NPOSE + NB);
+                    const float* om = L.omega[k][c];
+                    const float* u = w.U[k];
+                    d[0] = om[1] * u[2] - om[2] * u[1]; d[1] = om[2] * u[0] - om[0] * u[2]; d[2] = om[0] * u[1] - om[1] * u[0];
+                    if (k >= 1) {
+                        const float* dr = L.dR[k][c];
+                        float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+                        if (BM::STAGE_P) {
+                            const float* P = w.P + (k - 1) * 27;
+#pragma unroll
+                            for (int e = 0; e < 9; ++e) { q0 += dr[e] * P[e * 3]; q1 += dr[e] * P[e * 3 + 1]; q2 += dr[e] * P[e * 3 + 2]; }
+                        } else {
+                            const float* P = C.mk_P + (size_t)v * 3 * NPF + (k - 1) * 27;      // the wave just streamed this block: L1 / L2 hit
+#pragma unroll
+                            for (int e = 0; e < 9; ++e) { q0 += dr[e] * P[e * 3]; q1 += dr[e] * P[e * 3 + 1]; q2 += dr[e] * P[e * 3 + 2]; }
+                        }
+                        for (int a = 0; a < 3; ++a) d[a] += w.T[a * 3] * q0 + w.T[a * 3 + 1] * q1 + w.T[a * 3 + 2] * q2;
                     }
+                } else if (col < NPOSE + NB) {
+                    const int l = col - NPOSE;
+                    if (l < nb) {
+                        const float sv[3] = {w.S[l], w.S[NB + l], w.S[2 * NB + l]};
+                        for (int a = 0; a < 3; ++a) d[a] = w.T[a * 3] * sv[0] + w.T[a * 3 + 1] * sv[1] + w.T[a * 3 + 2] * sv[2];
+#pragma unroll 8
+                        for (int j = 0; j < NJ; ++j) {
+                            const float wj = w.Ay[j][3];
+                            d[0] += wj * L.twd[l][j][0]; d[1] += wj * L.twd[l][j][1]; d[2] += wj * L.twd[l][j][2];
+                        }
+                    }
+                } else if (col < DOF) {
+                    const int c = col - (NPOSE + NB + 3);
+                    d[0] = c == 0 ? 1.f : 0.f; d[1] = c == 1 ? 1.f : 0.f; d[2] = c == 2 ? 1.f : 0.f;
                 }
-            } else if (col < DOF) {
-                const int c = col - (NPOSE + NB + 3);
-                d[0] = c == 0 ? 1.f : 0.f; d[1] = c == 1 ? 1.f : 0.f; d[2] = c == 2 ? 1.f : 0.f;
+                float j0 = -mk * d[0], j1 = -mk * d[1], j2 = -mk * d[2];
+                if (jac_out && col < DOF) {
+                    float* jo = jac_out + (size_t)(v * 3) * DOF + col;
+                    jo[0] = j0; jo[DOF] = j1; jo[2 * DOF] = j2;
+                }
+                if (col == DOF) { j0 = r0; j1 = r1; j2 = r2; }      // column DOF carries the residual, so J^T r falls out of the J^T J tiles
+                Jr[col] = j0; Jr[LDJS + col] = j1; Jr[2 * LDJS + col] = j2;
             }
-            if (col == DOF) {      // column 85 carries the residual, so J^T r falls out of the J^T J tiles; 86, 87: zero padding
-                Jr[col] = s.resid[v * 3]; Jr[LDJ + col] = s.resid[v * 3 + 1]; Jr[2 * LDJ + col] = s.resid[v * 3 + 2];
-            } else {
-                Jr[col] = -mk * d[0]; Jr[LDJ + col] = -mk * d[1]; Jr[2 * LDJ + col] = -mk * d[2];
+        } else {
+            for (int col = lane; col < LDJ; col += 64) { Jr[col] = 0.f; Jr[LDJS + col] = 0.f; Jr[2 * LDJS + col] = 0.f; }
+        }
+        __syncthreads();       // chunk complete (the other buffer is free again: every wave passed its accumulation of chunk ch-1)
+        {
+            const float* Jb = L.Jc[ch & 1];
+            const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+            for (int t = 0; t < BM::TPW; ++t) {
+                if (wave + BM::WAVES * t < BM::NTILES) {
+                    const float* pa = Jb + fg * LDJS + 16 * tmi[t] + fr;
+                    const float* pb = Jb + fg * LDJS + 16 * tnj[t] + fr;
+                    float av[BM::CHUNK_ROWS / 4], bv[BM::CHUNK_ROWS / 4];
+#pragma unroll
+                    for (int u = 0; u < BM::CHUNK_ROWS / 4; ++u) { av[u] = pa[u * 4 * LDJS]; bv[u] = pb[u * 4 * LDJS]; }
+#pragma unroll
+                    for (int u = 0; u < BM::CHUNK_ROWS / 4; ++u) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[u], (double)bv[u], acc[t], 0, 0, 0);
+                }
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        if (tid == 0) { const long long t1 = wall_clock64(); s.phase[7] += t1 - tm0; }
     }
-    __syncthreads();
-    if (tid == 0) { const long long t1 = wall_clock64(); s.phase[1] += t1 - t0; }
+    if (tid == 0) { const long long t1 = wall_clock64(); s.phase[1] += t1 - t0; t0 = t1; }
     if (tid < 64) {
         float e = 0.f;                        // error metric 0.5 * |r|^2 accumulated in fp32, like the reference
         for (int i = lane; i < M * 3; i += 64) e += s.resid[i] * s.resid[i];
         e = etch_wave_sum_f32(e);
         if (lane == 0) s.err = 0.5 * (double)e;
     }
-    __syncthreads();
-}
-
-// delta = (J^T J + lambda I)^-1 J^T (-r)
-__device__ void lm_solve(LmShared& s, int M, double lambda) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int rows = M * 3;
-    long long t0 = 0;
-    if (tid == 0) t0 = wall_clock64();
-    // J^T J on the fp32 matrix cores (the reference forms it with an fp32 matmul too): 6 x 6 tiles of 16 columns, lower
-    // triangle only = 21 tiles spread over the waves; K = marker rows, 4 per v_mfma_f32_16x16x4_f32.
+    __syncthreads();           // every read of the linearisation scratch is done: the packed matrix may overwrite it
     {
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        // v_mfma_f64_16x16x4_f64 result layout: D[row = (lane >> 4) + 4 q][col = lane & 15]
         const int fr = lane & 15, fg = lane >> 4;
-        const int wave = tid >> 6;
-        for (int tile = wave; tile < 21; tile += LM_WAVES) {
-            int mi = 0;
-            while ((mi + 1) * (mi + 2) / 2 <= tile) ++mi;
-            const int nj = tile - mi * (mi + 1) / 2;           // nj <= mi
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const float* pa = s.Jm + fg * LDJ + 16 * mi + fr;
-            const float* pb = s.Jm + fg * LDJ + 16 * nj + fr;
-            const int steps = (rows + 3) >> 2;
-            for (int t0 = 0; t0 < steps; t0 += 5) {              // 5 K-steps per trip: their 10 LDS reads are issued together
-                float av[5], bv[5];
 #pragma unroll
-                for (int u = 0; u < 5; ++u) {
-                    const int t = t0 + u;
-                    const bool ok = 4 * t + fg < rows;
-                    av[u] = ok ? pa[t * 4 * LDJ] : 0.f;
-                    bv[u] = ok ? pb[t * 4 * LDJ] : 0.f;
+        for (int t = 0; t < BM::TPW; ++t) {
+            if (wave + BM::WAVES * t < BM::NTILES) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int gi = 16 * tmi[t] + fg + 4 * q, gj = 16 * tnj[t] + fr;
+                    if (gi < DOF && gj <= gi) Apk(s.A, gi, gj) = acc[t][q];
+                    else if (gi == DOF && gj < DOF) Apk(s.A, DOF, gj) = -acc[t][q];     // rhs g = -J^T r (row DOF of the packed matrix)
+                    else if (gi == DOF && gj == DOF) Apk(s.A, DOF, DOF) = 1.0;
                 }
-#pragma unroll
-                for (int u = 0; u < 5; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
-            }
-            // D[row = 4fg + q][col = fr] = (J^T J)[16mi + 4fg + q][16nj + fr]
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int gi = 16 * mi + 4 * fg + q, gj = 16 * nj + fr;
-                if (gi < DOF && gj <= gi) Apk(s.A, gi, gj) = (double)acc[q] + (gi == gj ? lambda : 0.0);
-                else if (gi == DOF && gj < DOF) Apk(s.A, DOF, gj) = -(double)acc[q];     // rhs g = -J^T r (row 85 of the packed matrix)
-                else if (gi == DOF && gj == DOF) Apk(s.A, DOF, DOF) = 1.0;
             }
         }
     }
     __syncthreads();
-    if (tid == 0) { const long long t1 = wall_clock64(); s.phase[2] += t1 - t0; t0 = t1; }
+    if (tid == 0) { const long long t1 = wall_clock64(); s.phase[2] += t1 - t0; }
+}
+
+// delta = (J^T J + lambda I)^-1 J^T (-r) from the packed normal equations left by lm_linearize
+template <class BM>
+__device__ void lm_solve(LmShared<BM>& s, double lambda) {
+    constexpr int DOF = BM::DOF, NPACK = BM::NPACK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    long long t0 = 0;
+    if (tid == 0) t0 = wall_clock64();
+    if (tid < DOF) Apk(s.A, tid, tid) += lambda;
+    __syncthreads();
     // Right-looking Cholesky of the packed lower triangle with the rhs carried as an extra row (gives y = L^-1 g for
     // free), ONE barrier per column: the trailing update uses the unscaled column, A_ij -= A_ik A_jk / A_kk; columns
     // are scaled to L in one pass at the end.  The pair enumeration e -> (ii, jj) does not depend on the column.
-    constexpr int NPR = ((DOF + 1) * (DOF + 2) / 2 + LM_THREADS - 1) / LM_THREADS;
+    constexpr int NPR = (NPACK + BM::THREADS - 1) / BM::THREADS;
     unsigned pr[NPR];
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));      // opaque copy: keeps this table from being hoisted out of the iteration loop (it would stay
+                                         // live through the linearisation and spill its accumulators)
 #pragma unroll
     for (int m = 0; m < NPR; ++m) {
-        const int e = tid + LM_THREADS * m;
+        const int e = tid_o + BM::THREADS * m;
         int ii = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
         while ((ii + 1) * (ii + 2) / 2 <= e) ++ii;
         while (ii * (ii + 1) / 2 > e) --ii;
@@ -388,12 +493,12 @@ __device__ void lm_solve(LmShared& s, int M, double lambda) {
     __syncthreads();
     for (int k = 0; k < DOF; ++k) {
         const double inv = s.rpiv;                          // 1 / A_kk, published by the thread that finished A_kk
-        const int n = DOF - k;                              // trailing rows k+1 .. 85 (incl. the rhs row)
+        const int n = DOF - k;                              // trailing rows k+1 .. DOF (incl. the rhs row)
         const int npairs = n * (n + 1) / 2;
         const int tk = (k + 1) * (k + 2) / 2;               // packed offset of row k+1
 #pragma unroll
         for (int m = 0; m < NPR; ++m) {
-            if (tid + LM_THREADS * m < npairs) {
+            if (tid + BM::THREADS * m < npairs) {
                 const int ii = (int)(pr[m] >> 16), jj = (int)(pr[m] & 0xFFFFu);
                 const int ri = tk + ii * (ii + 1) / 2 + (k + 1) * ii, rj = tk + jj * (jj + 1) / 2 + (k + 1) * jj;   // row starts of i, j
                 const double a = s.A[ri + k + 1 + jj] - s.A[ri + k] * s.A[rj + k] * inv;
@@ -406,117 +511,107 @@ __device__ void lm_solve(LmShared& s, int M, double lambda) {
     if (tid < DOF) s.rdiag[tid] = 1.0 / sqrt(Apk(s.A, tid, tid));
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < NPR; ++m) {                         // scale: L_ik = A_ik / sqrt(A_kk) (i > k), y_k = A_85,k / sqrt(A_kk)
-        const int e = tid + LM_THREADS * m;
+    for (int m = 0; m < NPR; ++m) {                         // scale: L_ik = A_ik / sqrt(A_kk) (i > k), y_k = A_DOF,k / sqrt(A_kk)
+        const int e = tid + BM::THREADS * m;
         const int i = (int)(pr[m] >> 16), k = (int)(pr[m] & 0xFFFFu);
-        if (e < (DOF + 1) * (DOF + 2) / 2 && i != k && k < DOF) s.A[e] *= s.rdiag[k];
+        if (e < NPACK && i != k && k < DOF) s.A[e] *= s.rdiag[k];
     }
     __syncthreads();
     if (tid == 0) { const long long t1 = wall_clock64(); s.phase[3] += t1 - t0; t0 = t1; }
-    // back substitution L^T delta = y by one wave (lane owns rows lane and lane + 64); pivots broadcast with v_readlane
+    // back substitution L^T delta = y by one wave (lane owns rows lane, lane + 64, ...); pivots broadcast with v_readlane
     if (tid < 64) {
-        double y0 = Apk(s.A, DOF, lane), y1 = lane + 64 < DOF ? Apk(s.A, DOF, lane + 64) : 0.0;
+        constexpr int NR = (DOF + 63) / 64;
+        double y[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) y[r] = lane + 64 * r < DOF ? Apk(s.A, DOF, lane + 64 * r) : 0.0;
         for (int i = DOF - 1; i >= 0; --i) {
-            const double src = i < 64 ? y0 : y1;
+            double src = y[0];
+#pragma unroll
+            for (int r = 1; r < NR; ++r) src = (i >> 6) == r ? y[r] : src;
             const int lo = __builtin_amdgcn_readlane(__double2loint(src), i & 63), hi = __builtin_amdgcn_readlane(__double2hiint(src), i & 63);
             const double di = __hiloint2double(hi, lo) * s.rdiag[i];
-            if (lane == (i & 63)) { if (i < 64) y0 = di; else y1 = di; }
-            if (lane < i) y0 -= Apk(s.A, i, lane) * di;
-            if (lane + 64 < i) y1 -= Apk(s.A, i, lane + 64) * di;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int row = lane + 64 * r;
+                if (row == i) y[r] = di;
+                else if (row < i) y[r] -= Apk(s.A, i, row) * di;
+            }
         }
-        s.delta[lane] = y0;
-        if (lane + 64 < DOF) s.delta[lane + 64] = y1;
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (lane + 64 * r < DOF) s.delta[lane + 64 * r] = y[r];
     }
     __syncthreads();
     if (tid == 0) { const long long t1 = wall_clock64(); s.phase[4] += t1 - t0; }
 }
 
-// per-scan constants into LDS: parents, joint shape basis, targets, subtree membership masks
-__device__ void lm_setup(LmShared& s, const SmplConsts& C, int M, const float* target, const float* mask) {
-    const int tid = threadIdx.x;
-    if (tid < 8) s.phase[tid] = 0;
-    if (tid < NJ) s.parents[tid] = C.parents[tid];
-    for (int i = tid; i < NJ * 3 * NB; i += LM_THREADS) s.Jd[i] = C.Jd[i];
-    if (tid < NJ * 3) s.J0[tid] = C.J0[tid];
-    if (tid < M * 3) s.target[tid] = target[tid];
-    if (tid < M) s.mask[tid] = mask[tid];
-    __syncthreads();
-    if (tid < NJ) {                            // subtree membership masks
-        unsigned m = 0u;
-        for (int j = 0; j < NJ; ++j) {
-            int a = j;
-            while (a > tid) a = s.parents[a];
-            if (a == tid) m |= 1u << j;
-        }
-        s.sub[tid] = m;
-    }
-    __syncthreads();
-}
-
-__global__ void __launch_bounds__(LM_THREADS) smpl_lm_fit_kernel(SmplConsts C, int M, const float* __restrict__ markers,
+template <class BM>
+__global__ void __launch_bounds__(BM::THREADS) smpl_lm_fit_kernel(SmplConsts C, int M, const float* __restrict__ markers,
                                                                 const float* __restrict__ valid, int it0, float step0, float damp0,
                                                                 int it1, float step1, float damp1, float* __restrict__ x_out,
                                                                 float* __restrict__ x_stage0, float* __restrict__ err_trace, long long* __restrict__ phase_out) {
+    constexpr int DOF = BM::DOF;
     extern __shared__ __attribute__((aligned(16))) unsigned char lm_smem[];
-    LmShared& s = *reinterpret_cast<LmShared*>(lm_smem);
+    LmShared<BM>& s = *reinterpret_cast<LmShared<BM>*>(lm_smem);
     const int b = blockIdx.x, tid = threadIdx.x;
-    const float* target = markers + (size_t)b * M * 3;
-    const float* mask = valid + (size_t)b * M;
-    if (tid < DOF) s.x[tid] = 0.0;
-    lm_setup(s, C, M, target, mask);
+    for (int i = tid; i < DOF; i += BM::THREADS) s.x[i] = 0.0;
+    lm_setup(s, C, M, markers + (size_t)b * M * 3, valid + (size_t)b * M);
     int trace_pos = 0;
     for (int stage = 0; stage < 2; ++stage) {
         const int iters = stage == 0 ? it0 : it1;
-        const int nb = stage == 0 ? 2 : NB;
+        const int nb = stage == 0 ? (BM::NB < NB_STAGE0 ? BM::NB : NB_STAGE0) : BM::NB;
         const double step = stage == 0 ? (double)step0 : (double)step1;
         const double lambda = stage == 0 ? (double)damp0 : (double)damp1;
-        lm_linearize(s, C, M, nb, target, mask);
-        float last = (float)s.err;
-        if (err_trace && tid == 0) err_trace[(size_t)b * (it0 + it1 + 2) + trace_pos] = last;
-        ++trace_pos;
+        float last = 0.f;
         bool conv = false;
-        for (int it = 0; it < iters; ++it) {
+        for (int it = -1; it < iters; ++it) {          // it = -1: the linearisation at the stage's starting point (error only)
             if (!conv) {
-                lm_solve(s, M, lambda);
-                if (tid < DOF) s.x[tid] += step * s.delta[tid];
-                __syncthreads();
-                lm_linearize(s, C, M, nb, target, mask);
+                if (it >= 0) {
+                    lm_solve(s, lambda);
+                    for (int i = tid; i < DOF; i += BM::THREADS) s.x[i] += step * s.delta[i];
+                    __syncthreads();
+                }
+                lm_linearize(s, C, M, nb, nullptr);
                 const float err = (float)s.err;
-                const float a = fabsf(last - err);
-                conv = (a < 1e-10f) || (a / last < 1e-8f);
+                if (it >= 0) {
+                    const float a = fabsf(last - err);
+                    conv = (a < 1e-10f) || (a / last < 1e-8f);
+                }
                 last = err;
             }
             if (err_trace && tid == 0) err_trace[(size_t)b * (it0 + it1 + 2) + trace_pos] = last;
             ++trace_pos;
         }
-        if (stage == 0 && x_stage0 && tid < DOF) x_stage0[(size_t)b * DOF + tid] = (float)s.x[tid];
+        if (stage == 0 && x_stage0)
+            for (int i = tid; i < DOF; i += BM::THREADS) x_stage0[(size_t)b * DOF + i] = (float)s.x[i];
         __syncthreads();
     }
-    if (tid < DOF) x_out[(size_t)b * DOF + tid] = (float)s.x[tid];
+    for (int i = tid; i < DOF; i += BM::THREADS) x_out[(size_t)b * DOF + i] = (float)s.x[i];
     if (phase_out && tid < 8) phase_out[(size_t)b * 8 + tid] = s.phase[tid];
 }
 
-
 // ---------------------------------------------------------------------------------------------- diagnostics (tests)
-// One linearisation of the LM kernel at a caller-given x: residual (B,3M) and the analytic Jacobian (B,3M,85) exactly as the
-// fit forms them (same device function, same LDS state) -- lets a test compare the analytic marker-restricted Jacobian with
-// autograd through the full-mesh LBS (the reference's AutoDiffCostFunction formulation, fit_SMPL.py:176-183).
-__global__ void __launch_bounds__(LM_THREADS) smpl_lm_linearize_kernel(SmplConsts C, int M, int nb, const float* __restrict__ x_in,
+// One linearisation of the LM kernel at a caller-given x: residual (B,3M), the analytic Jacobian (B,3M,DOF) and the normal
+// equations exactly as the fit forms them (same device function, same LDS state) -- lets a test compare the analytic
+// marker-restricted Jacobian with autograd through the full-mesh LBS (the reference's AutoDiffCostFunction formulation,
+// fit_SMPL.py:176-183) and the matrix-core J^T J / J^T r with their fp64 definition.
+template <class BM>
+__global__ void __launch_bounds__(BM::THREADS) smpl_lm_linearize_kernel(SmplConsts C, int M, int nb, const float* __restrict__ x_in,
                                                                       const float* __restrict__ markers, const float* __restrict__ valid,
-                                                                      float* __restrict__ resid, float* __restrict__ jac) {
+                                                                      float* __restrict__ resid, float* __restrict__ jac, double* __restrict__ normal) {
+    constexpr int DOF = BM::DOF;
     extern __shared__ __attribute__((aligned(16))) unsigned char lm_smem[];
-    LmShared& s = *reinterpret_cast<LmShared*>(lm_smem);
+    LmShared<BM>& s = *reinterpret_cast<LmShared<BM>*>(lm_smem);
     const int b = blockIdx.x, tid = threadIdx.x;
-    const float* target = markers + (size_t)b * M * 3;
-    const float* mask = valid + (size_t)b * M;
-    if (tid < DOF) s.x[tid] = (double)x_in[(size_t)b * DOF + tid];
-    lm_setup(s, C, M, target, mask);
-    lm_linearize(s, C, M, nb, target, mask);
-    for (int i = tid; i < M * 3; i += LM_THREADS) resid[(size_t)b * M * 3 + i] = s.resid[i];
-    for (int i = tid; i < M * 3 * DOF; i += LM_THREADS) {
-        const int r = i / DOF, c = i - r * DOF;
-        jac[(size_t)b * M * 3 * DOF + i] = s.Jm[r * LDJ + c];
-    }
+    for (int i = tid; i < DOF; i += BM::THREADS) s.x[i] = (double)x_in[(size_t)b * DOF + i];
+    lm_setup(s, C, M, markers + (size_t)b * M * 3, valid + (size_t)b * M);
+    lm_linearize(s, C, M, nb, jac + (size_t)b * M * 3 * DOF);
+    for (int i = tid; i < M * 3; i += BM::THREADS) resid[(size_t)b * M * 3 + i] = s.resid[i];
+    if (normal)                 // (DOF+1) x (DOF+1) lower triangle, row DOF = -J^T r
+        for (int e = tid; e < (DOF + 1) * (DOF + 1); e += BM::THREADS) {
+            const int i = e / (DOF + 1), j = e - i * (DOF + 1);
+            normal[(size_t)b * (DOF + 1) * (DOF + 1) + e] = j <= i ? Apk(s.A, i, j) : 0.0;
+        }
 }
 
 // rodrigues_d of the LM / LBS kernels on n rotation vectors: R (n,9) fp64 and dR/dtheta_q (n,3,9) -- pinned by the golden
@@ -534,27 +629,30 @@ __global__ void __launch_bounds__(64) rodrigues_kernel(int n, const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------- full-mesh LBS
+#define LBS_MAXJ 55
+#define LBS_MAXB 20
 struct LbsConsts {
     const float* v_template;   // [V][3]
-    const float* shapedirs;    // [V][3][10]
-    const float* posedirs;     // [207][V*3]
-    const float* weights;      // [V][24]
+    const float* shapedirs;    // [V][3][NB]
+    const float* posedirs;     // [9(NJ-1)][V*3]
+    const float* weights;      // [V][NJ]
     const float* J0; const float* Jd; const int* parents;
     const int* extra_vids; int n_extra;
 };
 
-__global__ void __launch_bounds__(256) smpl_lbs_kernel(LbsConsts C, int V, const float* __restrict__ x, float* __restrict__ verts,
+__global__ void __launch_bounds__(256) smpl_lbs_kernel(LbsConsts C, int NJ, int NB, int V, const float* __restrict__ x, float* __restrict__ verts,
                                                        float* __restrict__ joints) {
-    __shared__ double R[NJ * 9], Rw[NJ * 9], tw[NJ * 3], Jj[NJ * 3], xs[DOF];
-    __shared__ float A[NJ][12], pf[207];
-    __shared__ int parents[NJ];
+    __shared__ double R[LBS_MAXJ * 9], Rw[LBS_MAXJ * 9], tw[LBS_MAXJ * 3], Jj[LBS_MAXJ * 3], xs[3 * LBS_MAXJ + LBS_MAXB + 3];
+    __shared__ float A[LBS_MAXJ][12], pf[9 * (LBS_MAXJ - 1)];
+    __shared__ int parents[LBS_MAXJ];
+    const int NPOSE = 3 * (NJ - 1), NPF = 9 * (NJ - 1), DOF = NPOSE + NB + 6;
     const int b = blockIdx.y, tid = threadIdx.x;
     if (tid < DOF) xs[tid] = (double)x[(size_t)b * DOF + tid];
     if (tid < NJ) parents[tid] = C.parents[tid];
     __syncthreads();
     if (tid < NJ) {
         double th[3];
-        joint_theta(xs, tid, th);
+        joint_theta(xs, tid, NPOSE, NB, th);
         float dummy[3][9];
         rodrigues_d(th, R + tid * 9, dummy, false);
         for (int c = 0; c < 3; ++c) {
@@ -564,8 +662,8 @@ __global__ void __launch_bounds__(256) smpl_lbs_kernel(LbsConsts C, int V, const
         }
     }
     __syncthreads();
-    if (tid == 0) fk_chain(parents, R, Jj, Rw, tw);
-    if (tid < 207) { const int k = 1 + tid / 9, q = tid % 9; pf[tid] = (float)(R[k * 9 + q] - ((q % 4 == 0) ? 1.0 : 0.0)); }
+    if (tid == 0) fk_chain(NJ, parents, R, Jj, Rw, tw);
+    for (int e = tid; e < NPF; e += 256) { const int k = 1 + e / 9, q = e % 9; pf[e] = (float)(R[k * 9 + q] - ((q % 4 == 0) ? 1.0 : 0.0)); }
     __syncthreads();
     if (tid < NJ) {                            // A_j = [Rw_j | tw_j - Rw_j J_j]
         for (int a = 0; a < 3; ++a) {
@@ -585,7 +683,7 @@ __global__ void __launch_bounds__(256) smpl_lbs_kernel(LbsConsts C, int V, const
         for (int l = 0; l < NB; ++l) acc += C.shapedirs[((size_t)v * 3 + c) * NB + l] * (float)xs[NPOSE + l];
         vp[c] = acc;
     }
-    for (int e = 0; e < 207; ++e) {
+    for (int e = 0; e < NPF; ++e) {
         const float* P = C.posedirs + (size_t)e * V * 3 + v * 3;
         vp[0] += pf[e] * P[0]; vp[1] += pf[e] * P[1]; vp[2] += pf[e] * P[2];
     }
@@ -664,6 +762,23 @@ __global__ void __launch_bounds__(64) get_markers_kernel(int K, int M, const flo
     }
 }
 
+// scan_status[b]: bit 0 = some valid marker of the scan is non-finite (conf**20 underflowed to 0 for every one of a label's top-3
+// points: 0/0, exactly as fit_SMPL.py:52-57 computes it) -> the fit of that scan is NaN; bit 1 = the scan has no valid marker.
+__global__ void __launch_bounds__(64) marker_status_kernel(int M, const float* __restrict__ markers, const float* __restrict__ valid_f,
+                                                           int* __restrict__ status) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int bad = 0, any = 0;
+    for (int m = lane; m < M; m += 64) {
+        if (valid_f[(size_t)b * M + m] != 0.f) {
+            any = 1;
+            const float* p = markers + ((size_t)b * M + m) * 3;
+            if (!(isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]))) bad = 1;
+        }
+    }
+    bad = __any(bad); any = __any(any);
+    if (lane == 0) status[b] = (bad ? 1 : 0) | (any ? 0 : 2);
+}
+
 // labels[r] = argmax_g logits[r, g] (first maximum), int64 like torch.max
 __global__ void __launch_bounds__(256) argmax_rows_kernel(long R, int G, const float* __restrict__ logits, long long* __restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -685,6 +800,40 @@ __global__ void __launch_bounds__(256) inner_points_kernel(long n, const float* 
 #pragma clang fp contract(off)
         out[i] = pts[i] - (dir[i] * mag[i / 3]) / scale;
     }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+typedef Body<24, 10, 768> BodySMPL;       // the reference's model (fit_SMPL.py:100)
+typedef Body<55, 20, 512> BodySMPLX;      // SMPL-X-sized: 55 joints, 10 shape + 10 expression coefficients (BASELINE configs[4])
+
+static inline SmplConsts lm_consts(const void* const* consts) {
+    return SmplConsts{(const float*)consts[0], (const float*)consts[1], (const int*)consts[2], (const float*)consts[3], (const float*)consts[4],
+                      (const float*)consts[5], (const float*)consts[6]};
+}
+
+template <class BM>
+static int launch_lm_fit(int B, int M, const void* const* consts, const float* markers, const float* valid, int it0, float step0, float damp0,
+                         int it1, float step1, float damp1, float* x_out, float* x_stage0, float* err_trace, long long* phase_ticks, hipStream_t st) {
+    const int lds = (int)sizeof(LmShared<BM>);
+    static_assert(sizeof(LmShared<BM>) <= 160 * 1024, "LM state must fit the 160 KB LDS of a gfx950 CU");
+    hipError_t e = hipFuncSetAttribute((const void*)smpl_lm_fit_kernel<BM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(smpl_lm_fit_kernel<BM>, dim3(B), dim3(BM::THREADS), lds, st, lm_consts(consts), M, markers, valid, it0, step0, damp0, it1,
+                       step1, damp1, x_out, x_stage0, err_trace, phase_ticks);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+template <class BM>
+static int launch_lm_linearize(int B, int M, int nb, const void* const* consts, const float* x, const float* markers, const float* valid,
+                               float* resid, float* jac, double* normal, hipStream_t st) {
+    if (nb < 0 || nb > BM::NB) return ETCH_EINVAL;
+    const int lds = (int)sizeof(LmShared<BM>);
+    hipError_t e = hipFuncSetAttribute((const void*)smpl_lm_linearize_kernel<BM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(smpl_lm_linearize_kernel<BM>, dim3(B), dim3(BM::THREADS), lds, st, lm_consts(consts), M, nb, x, markers, valid, resid, jac, normal);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
 }
 
 extern "C" {
@@ -715,36 +864,39 @@ int etch_get_markers(int B, int K, int M, const float* pts, const long long* lab
     return ETCH_OK;
 }
 
-int etch_smpl_lm_workspace_bytes() { return (int)sizeof(LmShared); }
-
-// consts: 7 device pointers {J0, Jd, parents, mk_vt, mk_S, mk_P, mk_W}
-int etch_smpl_lm_fit(int B, int M, const void* const* consts, const float* markers, const float* valid, int it0, float step0,
-                     float damp0, int it1, float step1, float damp1, float* x_out, float* x_stage0, float* err_trace, long long* phase_ticks, void* stream) {
+int etch_marker_status(int B, int M, const float* markers, const float* valid_f, int* status, void* stream) {
     if (B <= 0) return ETCH_OK;
-    if (M <= 0 || M > MAXM) return ETCH_EUNSUPPORTED;
-    SmplConsts C{(const float*)consts[0], (const float*)consts[1], (const int*)consts[2], (const float*)consts[3], (const float*)consts[4],
-                 (const float*)consts[5], (const float*)consts[6]};
-    const int lds = (int)sizeof(LmShared);
-    hipError_t e = hipFuncSetAttribute((const void*)smpl_lm_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(smpl_lm_fit_kernel, dim3(B), dim3(LM_THREADS), lds, (hipStream_t)stream, C, M, markers, valid, it0, step0, damp0, it1,
-                       step1, damp1, x_out, x_stage0, err_trace, phase_ticks);
+    if (M <= 0) return ETCH_EINVAL;
+    hipLaunchKernelGGL(marker_status_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, M, markers, valid_f, status);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }
 
-int etch_smpl_lm_linearize(int B, int M, int nb, const void* const* consts, const float* x, const float* markers, const float* valid,
-                           float* resid, float* jac, void* stream) {
+int etch_smpl_lm_workspace_bytes(int nj, int nb) {
+    if (nj == 24 && nb == 10) return (int)sizeof(LmShared<BodySMPL>);
+    if (nj == 55 && nb == 20) return (int)sizeof(LmShared<BodySMPLX>);
+    return ETCH_EUNSUPPORTED;
+}
+
+// consts: 7 device pointers {J0, Jd, parents, mk_vt, mk_S, mk_P, mk_W}
+int etch_smpl_lm_fit(int B, int M, int nj, int nb, const void* const* consts, const float* markers, const float* valid, int it0, float step0,
+                     float damp0, int it1, float step1, float damp1, float* x_out, float* x_stage0, float* err_trace, long long* phase_ticks, void* stream) {
     if (B <= 0) return ETCH_OK;
-    if (M <= 0 || M > MAXM || nb < 0 || nb > NB) return ETCH_EUNSUPPORTED;
-    SmplConsts C{(const float*)consts[0], (const float*)consts[1], (const int*)consts[2], (const float*)consts[3], (const float*)consts[4],
-                 (const float*)consts[5], (const float*)consts[6]};
-    const int lds = (int)sizeof(LmShared);
-    hipError_t e = hipFuncSetAttribute((const void*)smpl_lm_linearize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(smpl_lm_linearize_kernel, dim3(B), dim3(LM_THREADS), lds, (hipStream_t)stream, C, M, nb, x, markers, valid, resid, jac);
-    ETCH_RETURN_IF_LAUNCH_FAILED();
-    return ETCH_OK;
+    if (M <= 0 || M > LM_MAXM) return ETCH_EUNSUPPORTED;
+    if (nj == 24 && nb == 10)
+        return launch_lm_fit<BodySMPL>(B, M, consts, markers, valid, it0, step0, damp0, it1, step1, damp1, x_out, x_stage0, err_trace, phase_ticks, (hipStream_t)stream);
+    if (nj == 55 && nb == 20)
+        return launch_lm_fit<BodySMPLX>(B, M, consts, markers, valid, it0, step0, damp0, it1, step1, damp1, x_out, x_stage0, err_trace, phase_ticks, (hipStream_t)stream);
+    return ETCH_EUNSUPPORTED;
+}
+
+int etch_smpl_lm_linearize(int B, int M, int nj, int nb_model, int nb_active, const void* const* consts, const float* x, const float* markers,
+                           const float* valid, float* resid, float* jac, double* normal, void* stream) {
+    if (B <= 0) return ETCH_OK;
+    if (M <= 0 || M > LM_MAXM) return ETCH_EUNSUPPORTED;
+    if (nj == 24 && nb_model == 10) return launch_lm_linearize<BodySMPL>(B, M, nb_active, consts, x, markers, valid, resid, jac, normal, (hipStream_t)stream);
+    if (nj == 55 && nb_model == 20) return launch_lm_linearize<BodySMPLX>(B, M, nb_active, consts, x, markers, valid, resid, jac, normal, (hipStream_t)stream);
+    return ETCH_EUNSUPPORTED;
 }
 
 int etch_rodrigues(int n, const float* theta, double* R, float* dR, void* stream) {
@@ -755,11 +907,12 @@ int etch_rodrigues(int n, const float* theta, double* R, float* dR, void* stream
 }
 
 // consts: 8 device pointers {v_template, shapedirs, posedirs, weights, J0, Jd, parents, extra_vids}
-int etch_smpl_lbs(int B, int V, int n_extra, const void* const* consts, const float* x, float* verts, float* joints, void* stream) {
+int etch_smpl_lbs(int B, int V, int nj, int nb, int n_extra, const void* const* consts, const float* x, float* verts, float* joints, void* stream) {
     if (B <= 0) return ETCH_OK;
+    if (nj < 1 || nj > LBS_MAXJ || nb < 0 || nb > LBS_MAXB || 3 * nj + nb + 3 > 256) return ETCH_EUNSUPPORTED;
     LbsConsts C{(const float*)consts[0], (const float*)consts[1], (const float*)consts[2], (const float*)consts[3], (const float*)consts[4],
                 (const float*)consts[5], (const int*)consts[6], (const int*)consts[7], n_extra};
-    hipLaunchKernelGGL(smpl_lbs_kernel, dim3((V + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, C, V, x, verts, joints);
+    hipLaunchKernelGGL(smpl_lbs_kernel, dim3((V + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, C, nj, nb, V, x, verts, joints);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }

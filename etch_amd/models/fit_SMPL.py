@@ -45,10 +45,12 @@ class _DeviceBody:
         d = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(device).contiguous()
         vids = np.asarray(marker_vids, np.int64)
         V = bm.num_verts
-        assert bm.num_joints == 24 and bm.num_betas == 10, "the LM kernel is specialised for SMPL (24 joints, 10 betas)"
-        J0 = bm.J_regressor.astype(np.float64) @ bm.v_template.astype(np.float64)                       # (24,3)
-        Jd = np.einsum("jv,vcl->jcl", bm.J_regressor.astype(np.float64), bm.shapedirs.astype(np.float64))  # (24,3,10)
-        P = bm.posedirs.reshape(207, V, 3)
+        self.nj, self.nb = bm.num_joints, bm.num_betas
+        if (self.nj, self.nb) not in ((24, 10), (55, 20)):
+            raise ValueError(f"the LM kernel is built for SMPL (24 joints, 10 betas) and an SMPL-X-sized model (55, 20); got ({self.nj}, {self.nb})")
+        J0 = bm.J_regressor.astype(np.float64) @ bm.v_template.astype(np.float64)                       # (nj,3)
+        Jd = np.einsum("jv,vcl->jcl", bm.J_regressor.astype(np.float64), bm.shapedirs.astype(np.float64))  # (nj,3,nb)
+        P = bm.posedirs.reshape(9 * (self.nj - 1), V, 3)
         self.M = len(vids)
         self.V = V
         self.n_extra = len(bm.extra_vids)
@@ -100,9 +102,13 @@ def fit_smpl_device(args, inner_points, part_labels, confidences, gender, steps_
     db = _device_body(bm, vids, inner_points.device)
     markers, valid_f, valid_b = ops.get_markers(inner_points.contiguous(), part_labels.contiguous(), confidences.contiguous(), M)
     # stage 0: damping 0.01 (fit_SMPL.py:200); stage 1: Theseus default damping 1e-3 (:249)
-    x, x0, trace = ops.smpl_lm_fit(db.lm_consts, markers, valid_f, steps_stage0, lr_stage0, 0.01, steps_stage1, lr_stage1, 1e-3, want_trace)
-    verts, joints = ops.smpl_lbs(db.lbs_consts, x, db.V, db.n_extra)
-    return dict(markers=markers, valid=valid_b, x=x, x_stage0=x0, err_trace=trace, verts=verts, joints=joints, faces=db.faces)
+    x, x0, trace = ops.smpl_lm_fit(db.lm_consts, markers, valid_f, steps_stage0, lr_stage0, 0.01, steps_stage1, lr_stage1, 1e-3, want_trace,
+                                   nj=db.nj, nb=db.nb)
+    verts, joints = ops.smpl_lbs(db.lbs_consts, x, db.V, db.n_extra, nj=db.nj, nb=db.nb)
+    # per-scan status word: bit 0 = NaN markers (conf**20 underflow, reproduced from the reference) -> NaN fit; bit 1 = no marker
+    status = ops.marker_status(markers, valid_f)
+    return dict(markers=markers, valid=valid_b, x=x, x_stage0=x0, err_trace=trace, verts=verts, joints=joints, faces=db.faces, status=status,
+                nj=db.nj, nb=db.nb)
 
 
 def fit_smpl_stage_host(dev, pinned=None):
@@ -130,7 +136,9 @@ def fit_smpl_finalize(dev):
     else:
         xn, vn, jn = (dev[k].detach().cpu().numpy() for k in ("x", "verts", "joints"))
     meshes = [Mesh(vn[b], dev["faces"], process=False, maintain_order=True) for b in range(B)]
-    info = [xn[:, :69].reshape(B, 23, 3), xn[:, 69:79].copy(), xn[:, 79:82].copy(), xn[:, 82:85].copy(), jn]
+    npose, nb = 3 * (dev.get("nj", 24) - 1), dev.get("nb", 10)
+    info = [xn[:, :npose].reshape(B, -1, 3), xn[:, npose:npose + nb].copy(), xn[:, npose + nb:npose + nb + 3].copy(),
+            xn[:, npose + nb + 3:npose + nb + 6].copy(), jn]
     return meshes, dev["markers"], dev["valid"], info
 
 

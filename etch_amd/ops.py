@@ -448,26 +448,40 @@ def get_markers(points, labels, conf, num_markers):
     return markers, valid_f, valid_b
 
 
-def smpl_lm_fit(consts, markers, valid_f, it0, step0, damp0, it1, step1, damp1, want_trace=False, phase_ticks=None):
+def smpl_lm_fit(consts, markers, valid_f, it0, step0, damp0, it1, step1, damp1, want_trace=False, phase_ticks=None, nj=24, nb=10):
+    """x (B, 3 nj + nb + 3) = pose | betas | orient | transl.  (nj, nb) = (24, 10) SMPL or (55, 20) SMPL-X-sized."""
     B, M = valid_f.shape
+    dof = 3 * nj + nb + 3
     arr = (ctypes.c_void_p * 7)(*[t.data_ptr() for t in consts])
-    x = torch.empty((B, 85), dtype=torch.float32, device=markers.device)
-    x0 = torch.empty((B, 85), dtype=torch.float32, device=markers.device)
+    x = torch.empty((B, dof), dtype=torch.float32, device=markers.device)
+    x0 = torch.empty((B, dof), dtype=torch.float32, device=markers.device)
     tr = torch.zeros((B, it0 + it1 + 2), dtype=torch.float32, device=markers.device) if want_trace else None
-    _lib.check(_lib.lib().etch_smpl_lm_fit(B, M, arr, _ptr(markers), _ptr(valid_f), int(it0), _c_float(step0), _c_float(damp0), int(it1),
-                                           _c_float(step1), _c_float(damp1), _ptr(x), _ptr(x0), _optptr(tr), _optptr(phase_ticks), _stream()), "etch_smpl_lm_fit")
+    _lib.check(_lib.lib().etch_smpl_lm_fit(B, M, int(nj), int(nb), arr, _ptr(markers), _ptr(valid_f), int(it0), _c_float(step0), _c_float(damp0),
+                                           int(it1), _c_float(step1), _c_float(damp1), _ptr(x), _ptr(x0), _optptr(tr), _optptr(phase_ticks),
+                                           _stream()), "etch_smpl_lm_fit")
     return x, x0, tr
 
 
-def smpl_lm_linearize(consts, x, markers, valid_f, nb):
-    """Diagnostics: residual (B,3M) and analytic Jacobian (B,3M,85) of the LM kernel at x."""
+def marker_status(markers, valid_f):
+    """(B,) int32: bit 0 = a valid marker is non-finite (the fit of that scan is NaN, as in the reference), bit 1 = no valid marker."""
     B, M = valid_f.shape
+    st = torch.empty((B,), dtype=torch.int32, device=markers.device)
+    _lib.check(_lib.lib().etch_marker_status(B, M, _ptr(markers), _ptr(valid_f), _ptr(st), _stream()), "etch_marker_status")
+    return st
+
+
+def smpl_lm_linearize(consts, x, markers, valid_f, nb_active, nj=24, nb=10, want_normal=False):
+    """Diagnostics: residual (B,3M), analytic Jacobian (B,3M,DOF) and optionally the matrix-core normal equations (B,DOF+1,DOF+1) fp64."""
+    B, M = valid_f.shape
+    dof = 3 * nj + nb + 3
+    assert x.shape == (B, dof)
     arr = (ctypes.c_void_p * 7)(*[t.data_ptr() for t in consts])
     r = torch.empty((B, 3 * M), dtype=torch.float32, device=x.device)
-    J = torch.empty((B, 3 * M, 85), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().etch_smpl_lm_linearize(B, M, int(nb), arr, _ptr(x), _ptr(markers), _ptr(valid_f), _ptr(r), _ptr(J), _stream()),
-               "etch_smpl_lm_linearize")
-    return r, J
+    J = torch.empty((B, 3 * M, dof), dtype=torch.float32, device=x.device)
+    N = torch.empty((B, dof + 1, dof + 1), dtype=torch.float64, device=x.device) if want_normal else None
+    _lib.check(_lib.lib().etch_smpl_lm_linearize(B, M, int(nj), int(nb), int(nb_active), arr, _ptr(x), _ptr(markers), _ptr(valid_f), _ptr(r),
+                                                 _ptr(J), _optptr(N), _stream()), "etch_smpl_lm_linearize")
+    return (r, J, N) if want_normal else (r, J)
 
 
 def rodrigues(theta):
@@ -480,12 +494,13 @@ def rodrigues(theta):
     return R, dR
 
 
-def smpl_lbs(consts, x, V, n_extra):
+def smpl_lbs(consts, x, V, n_extra, nj=24, nb=10):
     B = x.shape[0]
+    assert x.shape[1] == 3 * nj + nb + 3
     arr = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in consts])
     verts = torch.empty((B, V, 3), dtype=torch.float32, device=x.device)
-    joints = torch.empty((B, 24 + n_extra, 3), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().etch_smpl_lbs(B, V, n_extra, arr, _ptr(x), _ptr(verts), _ptr(joints), _stream()), "etch_smpl_lbs")
+    joints = torch.empty((B, nj + n_extra, 3), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().etch_smpl_lbs(B, V, int(nj), int(nb), n_extra, arr, _ptr(x), _ptr(verts), _ptr(joints), _stream()), "etch_smpl_lbs")
     return verts, joints
 
 

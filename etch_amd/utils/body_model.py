@@ -16,6 +16,12 @@ SMPL_EXTRA_JOINT_VIDS = np.array([332, 6260, 2800, 4071, 583, 3216, 3226, 3387, 
                                   2746, 2319, 2445, 2556, 2673, 6191, 5782, 5905, 6016, 6133], np.int32)
 
 
+# SMPL-X kinematic tree (55 joints: 22 body, jaw, 2 eyes, 2 x 15 finger joints) [upstream smplx, public]
+SMPLX_PARENTS = np.array([-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 15, 15, 15,
+                          20, 25, 26, 20, 28, 29, 20, 31, 32, 20, 34, 35, 20, 37, 38,
+                          21, 40, 41, 21, 43, 44, 21, 46, 47, 21, 49, 50, 21, 52, 53], np.int32)
+
+
 class BodyModel:
     """Plain numpy container (fp32)."""
 
@@ -40,9 +46,9 @@ class BodyModel:
         return len(self.parents)
 
 
-def SyntheticSMPL(seed=7, V=6890, NB=10):
+def _synthetic(seed, V, NB, parents, extra_vids):
     rng = np.random.default_rng(seed)
-    J = len(SMPL_PARENTS)
+    J = len(parents)
     v_t = rng.standard_normal((V, 3)) * np.array([0.15, 0.45, 0.10])
     # a crude skeleton: joint centres = random vertices; weights = softmax over the 4 nearest joints
     cent = v_t[rng.choice(V, J, replace=False)]
@@ -58,8 +64,18 @@ def SyntheticSMPL(seed=7, V=6890, NB=10):
     S = rng.standard_normal((V, 3, NB)) * 0.01
     P = rng.standard_normal((9 * (J - 1), V * 3)) * 0.001
     faces = np.stack([np.arange(V - 2), np.arange(1, V - 1), np.arange(2, V)], 1)[: 2 * V - 4 - (V - 2)]  # a strip, only for OBJ export
-    faces = np.concatenate([faces, faces[:, ::-1]])[:13776]
-    return BodyModel(v_t, S, P, Jreg, W, SMPL_PARENTS, faces)
+    faces = np.concatenate([faces, faces[:, ::-1]])[:2 * V - 4]
+    return BodyModel(v_t, S, P, Jreg, W, parents, faces, extra_vids)
+
+
+def SyntheticSMPL(seed=7, V=6890, NB=10):
+    return _synthetic(seed, V, NB, SMPL_PARENTS, SMPL_EXTRA_JOINT_VIDS)
+
+
+def SyntheticSMPLX(seed=7, V=10475, NB=20):
+    """Seeded SMPL-X-SIZED model (V = 10 475, J = 55 with the public SMPL-X tree, 10 shape + 10 expression coefficients as
+    one 20-vector, 486 pose-basis rows) for BASELINE configs[4].  The 21 vertex-picked extra joints reuse the SMPL ids (< V)."""
+    return _synthetic(seed, V, NB, SMPLX_PARENTS, SMPL_EXTRA_JOINT_VIDS)
 
 
 def load_smpl_pkl(path, num_betas=10):

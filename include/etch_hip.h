@@ -260,33 +260,40 @@ int etch_inner_points(long n, const float* pts, const float* dir, const float* m
 int etch_get_markers(int B, int K, int M, const float* pts, const long long* labels, const float* conf, float* markers,
                      float* valid_f, unsigned char* valid_b, void* stream);
 
-/* fit_smpl's two Levenberg-Marquardt stages (src/models/fit_SMPL.py:161-249; Theseus LM + smplx LBS upstream).
- * consts = 7 device pointers {J0 (24,3) = J_regressor @ v_template, Jd (24,3,10) = J_regressor @ shapedirs,
- * parents (24) i32, and for the M marker vertices: v_template rows (M,3), shapedirs rows (M,3,10),
- * posedirs columns as (M,207,3), lbs_weights rows (M,24)}.  markers (B,M,3), valid (B,M) float mask.
- * Stage 0: it0 iterations, step0, damp0 over pose|betas[:2]|orient|transl; stage 1: it1, step1, damp1 over all 85.
- * -> x_out (B,85) = pose(69) | betas(10) | global_orient(3) | transl(3); optional x_stage0 (B,85) and
- * err_trace (B, it0+it1+2) = 0.5|r|^2 before/after every iteration of both stages; optional phase_ticks (B,8) i64 =
- * 100 MHz wall-clock ticks spent in {kinematics, marker rows, J^T J, Cholesky, solves} (diagnostics). */
-int etch_smpl_lm_fit(int B, int M, const void* const* consts, const float* markers, const float* valid, int it0, float step0,
-                     float damp0, int it1, float step1, float damp1, float* x_out, float* x_stage0, float* err_trace,
-                     long long* phase_ticks, void* stream);
-int etch_smpl_lm_workspace_bytes(void);
+/* Per-scan status of the aggregated markers (NaN check on the marker weights at the boundary): status (B) i32,
+ * bit 0 = a valid marker of the scan is non-finite -- every one of a label's top-3 confidences underflowed in conf**20, so the
+ * weighted centre is 0/0 exactly as fit_SMPL.py:52-57 computes it, and the fit of that scan is NaN; bit 1 = no valid marker. */
+int etch_marker_status(int B, int M, const float* markers, const float* valid_f, int* status, void* stream);
 
-/* Diagnostics of the LM kernel (tests): ONE linearisation at a caller-given x (B,85) with nb active betas -> residual
- * (B,3M) = mask * (target - markers(x)) (fit_SMPL.py:127-131) and the analytic Jacobian d resid / d x (B,3M,85) the fit uses in
- * place of the reference's autograd Jacobian (AutoDiffCostFunction, fit_SMPL.py:176-183, 227-234). */
-int etch_smpl_lm_linearize(int B, int M, int nb, const void* const* consts, const float* x, const float* markers, const float* valid,
-                           float* resid, float* jac, void* stream);
+/* fit_smpl's two Levenberg-Marquardt stages (src/models/fit_SMPL.py:161-249; Theseus LM + smplx LBS upstream).
+ * Body model: nj joints, nb shape coefficients -- (24, 10) = SMPL, the reference's model (fit_SMPL.py:100); (55, 20) = an
+ * SMPL-X-sized model (BASELINE configs[4]); other sizes return ETCH_EUNSUPPORTED.  P = 9 (nj - 1) pose-feature rows.
+ * consts = 7 device pointers {J0 (nj,3) = J_regressor @ v_template, Jd (nj,3,nb) = J_regressor @ shapedirs, parents (nj) i32, and for
+ * the M <= 128 marker vertices: v_template rows (M,3), shapedirs rows (M,3,nb), posedirs columns as (M,P,3), lbs_weights rows (M,nj)}.
+ * markers (B,M,3), valid (B,M) float mask.  Variable vector x (B, 3 nj + nb + 3) = pose | betas | global_orient | transl
+ * (fit_SMPL.py:174,225).  Stage 0: it0 iterations, step0, damping damp0, betas[:2] only (:161-200); stage 1: it1, step1, damp1, all
+ * betas (:219-249).  x_stage0 / err_trace (B, it0+it1+2) / phase_ticks (B,8) may be NULL. */
+int etch_smpl_lm_fit(int B, int M, int nj, int nb, const void* const* consts, const float* markers, const float* valid, int it0, float step0,
+                     float damp0, int it1, float step1, float damp1, float* x_out, float* x_stage0, float* err_trace, long long* phase_ticks,
+                     void* stream);
+/* LDS bytes one scan's fit holds for its whole duration (one workgroup per scan); ETCH_EUNSUPPORTED for unknown (nj, nb). */
+int etch_smpl_lm_workspace_bytes(int nj, int nb);
+
+/* Diagnostics of the LM kernel (tests): ONE linearisation at a caller-given x (B,DOF) with nb_active betas -> residual
+ * (B,3M) = mask * (target - markers(x)) (fit_SMPL.py:127-131), the analytic Jacobian d resid / d x (B,3M,DOF) the fit uses in place
+ * of the reference's autograd Jacobian (AutoDiffCostFunction, fit_SMPL.py:176-183, 227-234), and (optional) the normal equations
+ * as the fit accumulates them on the fp64 matrix cores: (B, DOF+1, DOF+1) fp64, lower triangle = J^T J, row DOF = -J^T r. */
+int etch_smpl_lm_linearize(int B, int M, int nj, int nb_model, int nb_active, const void* const* consts, const float* x, const float* markers,
+                           const float* valid, float* resid, float* jac, double* normal, void* stream);
 
 /* batch_rodrigues as the fit evaluates it (in-tree copy src/data_utils/GT_dataloader_mixed.py:29-64, angle = |theta + 1e-8|):
  * theta (n,3) -> R (n,9) fp64 and dR/dtheta_q (n,3,9). */
 int etch_rodrigues(int n, const float* theta, double* R, float* dR, void* stream);
 
-/* Final smpl_model(...) (fit_SMPL.py:258-259, smplx.SMPL.forward upstream): x (B,85) -> verts (B,V,3), joints
- * (B,24+n_extra,3).  consts = 8 device pointers {v_template (V,3), shapedirs (V,3,10), posedirs (207,V*3),
- * lbs_weights (V,24), J0, Jd, parents, extra_vids (n_extra) i32}. */
-int etch_smpl_lbs(int B, int V, int n_extra, const void* const* consts, const float* x, float* verts, float* joints, void* stream);
+/* Final smpl_model(...) (fit_SMPL.py:258-259, smplx.SMPL.forward upstream): x (B, 3 nj + nb + 3) -> verts (B,V,3), joints
+ * (B, nj + n_extra, 3) = regressed joints + n_extra vertex-picked joints.  consts = 8 device pointers {v_template (V,3), shapedirs
+ * (V,3,nb), posedirs (9 (nj-1), V*3), lbs_weights (V,nj), J0, Jd, parents, extra_vids (n_extra) i32}.  nj <= 55, nb <= 20. */
+int etch_smpl_lbs(int B, int V, int nj, int nb, int n_extra, const void* const* consts, const float* x, float* verts, float* joints, void* stream);
 
 #ifdef __cplusplus
 }

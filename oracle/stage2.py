@@ -63,7 +63,7 @@ def rodrigues(r):
 
 
 def lbs(tb, betas, pose72, transl):
-    """[upstream] smplx.lbs.lbs.  betas [B,NB], pose72 [B,72] = orient|body_pose, transl [B,3] -> verts [B,V,3], joints24 [B,24,3]."""
+    """[upstream] smplx.lbs.lbs.  betas [B,NB], pose72 [B,3J] = orient|body_pose (SMPL: 72), transl [B,3] -> verts [B,V,3], joints [B,J,3]."""
     B, J = betas.shape[0], tb.J
     v_s = tb.v_t[None] + torch.einsum("bl,mkl->bmk", betas, tb.S)
     Jl = torch.einsum("bik,ji->bjk", v_s, tb.Jreg)
@@ -86,7 +86,7 @@ def lbs(tb, betas, pose72, transl):
 
 
 def smpl_forward(tb, betas, body_pose, orient, transl):
-    """smplx.SMPL.forward: vertices [B,V,3], joints [B,45,3] (24 regressed + 21 vertex-picked)."""
+    """smplx.SMPL.forward: vertices [B,V,3], joints [B,J+21,3] (J regressed + 21 vertex-picked; SMPL: 45)."""
     v, j = lbs(tb, betas, torch.cat([orient, body_pose], 1), transl)
     return v, torch.cat([j, v[:, tb.extra]], 1)
 
@@ -95,7 +95,8 @@ def residual_fn(tb, marker_vids, nb_opt):
     nb_total = tb.S.shape[2]
 
     def f(x, target, mask):
-        pose, b, go, t = x[:69], x[69:69 + nb_opt], x[69 + nb_opt:72 + nb_opt], x[72 + nb_opt:75 + nb_opt]
+        npose = 3 * (tb.J - 1)
+        pose, b, go, t = x[:npose], x[npose:npose + nb_opt], x[npose + nb_opt:npose + nb_opt + 3], x[npose + nb_opt + 3:npose + nb_opt + 6]
         betas = torch.cat([b, torch.zeros(nb_total - nb_opt, dtype=x.dtype)])[None]
         v, _ = lbs(tb, betas, torch.cat([go, pose])[None], t[None])
         return ((target - v[0][marker_vids]) * mask[:, None]).reshape(-1)      # fit_SMPL.py:127-131
@@ -142,12 +143,13 @@ def fit_smpl(bm, marker_vids, markers, valid, steps_stage0=30, steps_stage1=50, 
         B = markers.shape[0]
         mask = valid.to(dtype)
         t0 = [] if trace is not None else None
-        x0 = lm(residual_fn(tb, mv, 2), torch.zeros(B, 77, dtype=dtype), markers, mask, steps_stage0, lr_stage0, 0.01, t0)
-        x1 = torch.cat([x0[:, :69], x0[:, 69:71], torch.zeros(B, 8, dtype=dtype), x0[:, 71:]], 1)
+        npose, nbt = 3 * (tb.J - 1), tb.S.shape[2]          # SMPL: 69 pose variables, 10 betas -> 77 / 85 DoF
+        x0 = lm(residual_fn(tb, mv, 2), torch.zeros(B, npose + 2 + 6, dtype=dtype), markers, mask, steps_stage0, lr_stage0, 0.01, t0)
+        x1 = torch.cat([x0[:, :npose], x0[:, npose:npose + 2], torch.zeros(B, nbt - 2, dtype=dtype), x0[:, npose + 2:]], 1)
         t1 = [] if trace is not None else None
-        x1 = lm(residual_fn(tb, mv, 10), x1, markers, mask, steps_stage1, lr_stage1, 1e-3, t1)
+        x1 = lm(residual_fn(tb, mv, nbt), x1, markers, mask, steps_stage1, lr_stage1, 1e-3, t1)
         if trace is not None:
             trace.extend([t0, t1])
-        pose, betas, orient, transl = x1[:, :69], x1[:, 69:79], x1[:, 79:82], x1[:, 82:85]
+        pose, betas, orient, transl = x1[:, :npose], x1[:, npose:npose + nbt], x1[:, npose + nbt:npose + nbt + 3], x1[:, npose + nbt + 3:]
         v, j = smpl_forward(tb, betas, pose, orient, transl)
         return dict(pose=pose, betas=betas, orient=orient, transl=transl, verts=v, joints=j, x_stage0=x0)

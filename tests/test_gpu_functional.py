@@ -59,7 +59,7 @@ def test_intra_grouping_vs_reference_form_and_fused_kernel():
     want = x.index_select(3, ii.view(-1)).view(2, 32, 70, 60, 12).permute(0, 1, 4, 2, 3).contiguous()      # functional.py:343-344
     got = L.intra_so3conv_grouping(ii.cuda(), x.cuda())
     assert torch.equal(got.cpu(), want)
-    conv = load_seeded(V.IntraSO3Conv(32, 64), 5).cuda().eval()
+    conv = load_seeded(V.IntraSO3Conv(32, 32), 5).cuda().eval()
     y_unfused = conv.basic_conv(got)
     y = conv(V.SphericalPointCloud(None, x.cuda(), conv.anchors)).feats
     assert rel_err(y.cpu().numpy(), y_unfused.cpu().numpy()) < 2e-5
@@ -73,7 +73,7 @@ def test_square_distance_and_index_points():
     dst = torch.cat([src[:, :40], torch.from_numpy(rng.standard_normal((2, 37, 3)).astype(np.float32))], 1)   # coincident points: d ~ 0
     d = square_distance(src.cuda(), dst.cuda())
     ref = S1.square_distance(src, dst)
-    assert d.shape == (2, 130, 77) and float((d.cpu() - ref).abs().max()) < 2e-6
+    assert d.shape == (2, 130, 77) and float((d.cpu() - ref).abs().max()) < 1e-6 * float(ref.abs().max())   # CPU matmul sums in another order
     pts = torch.from_numpy(rng.standard_normal((2, 50, 7)).astype(np.float32))
     for shape in ((2, 9), (2, 5, 3)):
         idx = torch.from_numpy(rng.integers(0, 50, shape))

@@ -34,17 +34,17 @@ def test_argmax_rows():
     assert got.dtype == np.int64 and np.array_equal(got, x.argmax(-1))
 
 
-def _problem(B, seed=0):
+def _problem(B, seed=0, model="smpl"):
     from etch_amd import constants as K
-    from etch_amd.utils.body_model import SyntheticSMPL
+    from etch_amd.utils.body_model import SyntheticSMPL, SyntheticSMPLX
     from oracle import stage2 as S2
-    bm = SyntheticSMPL(7)
+    bm = SyntheticSMPL(7) if model == "smpl" else SyntheticSMPLX(7)
     ms = K.default_markerset()
     mv = np.array(list(ms.values()))
     tb = S2.TorchBody(bm)
     g = torch.Generator().manual_seed(seed)
-    gt_pose = torch.randn(B, 72, generator=g) * 0.2
-    gt_b = torch.randn(B, 10, generator=g) * 0.8
+    gt_pose = torch.randn(B, 3 * bm.num_joints, generator=g) * 0.2
+    gt_b = torch.randn(B, bm.num_betas, generator=g) * 0.8
     gt_t = torch.randn(B, 3, generator=g) * 0.05
     with torch.no_grad():
         vgt = S2.lbs(tb, gt_b, gt_pose, gt_t)[0]
@@ -55,19 +55,27 @@ def _problem(B, seed=0):
     return bm, ms, mv, tgt, valid, vgt
 
 
-def test_lbs_vs_oracle():
+def _split(bm, x):
+    """x (B,DOF) -> betas, body_pose, orient, transl (the oracle's argument order)."""
+    npose, nb = 3 * (bm.num_joints - 1), bm.num_betas
+    return x[:, npose:npose + nb], x[:, :npose], x[:, npose + nb:npose + nb + 3], x[:, npose + nb + 3:]
+
+
+@pytest.mark.parametrize("model", ["smpl", "smplx"])
+def test_lbs_vs_oracle(model):
     from etch_amd import ops
     from etch_amd.models.fit_SMPL import _device_body
     from oracle import stage2 as S2
-    bm, ms, mv, _, _, _ = _problem(1)
+    bm, ms, mv, _, _, _ = _problem(1, model=model)
     db = _device_body(bm, mv, torch.device("cuda"))
     g = torch.Generator().manual_seed(3)
-    x = torch.cat([torch.randn(4, 69, generator=g) * 0.3, torch.randn(4, 10, generator=g), torch.randn(4, 3, generator=g) * 0.5,
+    npose, nb = 3 * (bm.num_joints - 1), bm.num_betas
+    x = torch.cat([torch.randn(4, npose, generator=g) * 0.3, torch.randn(4, nb, generator=g), torch.randn(4, 3, generator=g) * 0.5,
                    torch.randn(4, 3, generator=g) * 0.1], 1)
-    verts, joints = ops.smpl_lbs(db.lbs_consts, x.cuda(), db.V, db.n_extra)
+    verts, joints = ops.smpl_lbs(db.lbs_consts, x.cuda(), db.V, db.n_extra, nj=db.nj, nb=db.nb)
     with torch.no_grad():
-        rv, rj = S2.smpl_forward(S2.TorchBody(bm), x[:, 69:79], x[:, :69], x[:, 79:82], x[:, 82:85])
-    assert joints.shape == (4, 45, 3)
+        rv, rj = S2.smpl_forward(S2.TorchBody(bm), *_split(bm, x))
+    assert joints.shape == (4, bm.num_joints + 21, 3) and verts.shape == (4, bm.num_verts, 3)
     assert np.abs(verts.cpu().numpy() - rv.numpy()).max() < 1e-5
     assert np.abs(joints.cpu().numpy() - rj.numpy()).max() < 1e-5
 
@@ -152,27 +160,30 @@ def test_rodrigues_vs_in_tree_batch_rodrigues(golden):
     assert np.abs(dR.cpu().numpy() - want).max() < 2e-7 * max(1.0, np.abs(want).max())
 
 
-@pytest.mark.parametrize("nb", [2, 10])
-def test_analytic_jacobian_vs_autograd_through_full_lbs(nb):
+@pytest.mark.parametrize("model,nb", [("smpl", 2), ("smpl", 10), ("smplx", 2), ("smplx", 20)])
+def test_analytic_jacobian_vs_autograd_through_full_lbs(model, nb):
     """The LM kernel's analytic marker-restricted Jacobian against torch.func.jacrev through the oracle's
     FULL-mesh LBS -- the reference's AutoDiffCostFunction formulation (fit_SMPL.py:176-183) -- in fp64, at random poses incl. the
-    zero pose the fit starts from; the residual alongside.  nb = active betas (stage 0: 2, stage 1: 10)."""
+    zero pose the fit starts from; the residual alongside.  nb = active betas (stage 0: 2, stage 1: all).  Also the normal equations
+    the kernel accumulates on the fp64 matrix cores against J^T J / -J^T r formed from the returned (fp32) Jacobian in fp64."""
     from etch_amd import ops
     from etch_amd.models.fit_SMPL import _device_body
     from oracle import stage2 as S2
     B = 3
-    bm, ms, mv, tgt, valid, _ = _problem(B, seed=5)
+    bm, ms, mv, tgt, valid, _ = _problem(B, seed=5, model=model)
     db = _device_body(bm, mv, torch.device("cuda"))
     g = torch.Generator().manual_seed(9)
-    x = torch.cat([torch.randn(B, 69, generator=g) * 0.3, torch.randn(B, 10, generator=g), torch.randn(B, 3, generator=g) * 0.8,
+    npose, nbt = 3 * (bm.num_joints - 1), bm.num_betas
+    dof = npose + nbt + 6
+    x = torch.cat([torch.randn(B, npose, generator=g) * 0.3, torch.randn(B, nbt, generator=g), torch.randn(B, 3, generator=g) * 0.8,
                    torch.randn(B, 3, generator=g) * 0.1], 1)
     x[0] = 0
-    if nb < 10:
-        x[:, 69 + nb:79] = 0
-    r, J = ops.smpl_lm_linearize(db.lm_consts, x.cuda(), tgt.cuda(), valid.float().cuda(), nb)
+    if nb < nbt:
+        x[:, npose + nb:npose + nbt] = 0
+    r, J, N = ops.smpl_lm_linearize(db.lm_consts, x.cuda(), tgt.cuda(), valid.float().cuda(), nb, nj=db.nj, nb=db.nb, want_normal=True)
     tb = S2.TorchBody(bm, torch.float64)
     f = S2.residual_fn(tb, torch.as_tensor(mv).long(), nb)
-    keep = list(range(69 + nb)) + list(range(79, 85))                                # oracle's variable vector drops the inactive betas
+    keep = list(range(npose + nb)) + list(range(npose + nbt, dof))                   # oracle's variable vector drops the inactive betas
     xo = x.double()[:, keep]
     rr = torch.func.vmap(f)(xo, tgt.double(), valid.double())
     Jr = torch.func.vmap(torch.func.jacrev(f))(xo, tgt.double(), valid.double())
@@ -180,6 +191,74 @@ def test_analytic_jacobian_vs_autograd_through_full_lbs(nb):
     Jg = J.cpu().numpy()
     scale = np.abs(Jr.numpy()).max()
     assert np.abs(Jg[:, :, keep] - Jr.numpy()).max() < 2e-6 * scale
-    drop = [c for c in range(85) if c not in keep]
+    drop = [c for c in range(dof) if c not in keep]
     assert not drop or np.abs(Jg[:, :, drop]).max() == 0                             # inactive betas: zero columns
     assert (Jg[0, 15:18] == 0).all() and (r.cpu().numpy()[0, 15:18] == 0).all()      # masked marker (scan 0, marker 5): zero rows
+    # normal equations: lower triangle = J^T J, last row = -J^T r, accumulated in fp64 from the fp32 rows
+    J64, r64, Ng = Jg.astype(np.float64), r.cpu().numpy().astype(np.float64), N.cpu().numpy()
+    JtJ = np.einsum("bri,brj->bij", J64, J64)
+    g64 = -np.einsum("bri,br->bi", J64, r64)
+    tril = np.tril(np.ones((dof, dof), bool))
+    assert np.abs((Ng[:, :dof, :dof] - JtJ)[:, tril]).max() < 1e-12 * max(1.0, np.abs(JtJ).max())
+    assert np.abs(Ng[:, dof, :dof] - g64).max() < 1e-12 * max(1.0, np.abs(g64).max())
+
+
+def test_lm_fit_smplx_sized_model_vs_oracle():
+    """SURVEY 8 f-4 / BASELINE configs[4]: the 188-DoF fit (55 joints, 20 shape + expression coefficients, 10 475 vertices) against the
+    oracle's autograd LM on the SMPL-X-sized synthetic body, a shortened schedule (the oracle differentiates the full mesh: ~1 s per
+    iteration and scan).  Same bars as the SMPL fit: error trace 1e-4, vertices / joints 1e-4 m, every parameter 1e-4."""
+    from _parity import oracle_trace
+    from etch_amd.models.fit_SMPL import fit_smpl
+    from oracle import stage2 as S2
+    B, it0, it1 = 2, 8, 10
+    bm, ms, mv, tgt, valid, vgt = _problem(B, seed=2, model="smplx")
+    trace = []
+    ref = S2.fit_smpl(bm, mv, tgt, valid, steps_stage0=it0, steps_stage1=it1, trace=trace)
+    pts = tgt.clone()
+    labels = torch.arange(86).repeat(B, 1)
+    for b in range(B):
+        labels[b, (~valid[b]).nonzero().flatten()] = int(valid[b].nonzero()[0])
+    conf = torch.ones(B, 86, 1)
+    conf[~valid] = 1e-3
+    args = types.SimpleNamespace(markerset=ms, device=torch.device("cuda"), body_model=bm)
+    meshes, markers, vmask, info, aux = fit_smpl(args, pts.cuda(), labels.cuda(), conf.cuda(), "neutral", steps_stage0=it0, steps_stage1=it1,
+                                                 return_trace=True)
+    assert np.array_equal(vmask.cpu().numpy(), valid.numpy())
+    rt, gt = oracle_trace(trace, it0, it1), aux["err_trace"].cpu().numpy()
+    assert gt.shape == rt.shape == (B, it0 + it1 + 2)
+    assert np.abs(gt - rt).max() / rt.max() < 1e-4
+    assert rt[:, -1].max() < 0.05 * rt[:, 0].min()                                  # the fit does descend
+    assert len(meshes) == B and meshes[0].vertices.shape == (10475, 3)
+    assert [a.shape for a in info] == [(B, 54, 3), (B, 20), (B, 3), (B, 3), (B, 76, 3)]
+    verts = aux["verts"].cpu().numpy()
+    assert np.abs(verts - ref["verts"].numpy()).max() < 1e-4
+    assert np.abs(info[4] - ref["joints"].numpy()).max() < 1e-4
+    x = aux["x"].cpu().numpy()
+    xr = torch.cat([ref["pose"], ref["betas"], ref["orient"], ref["transl"]], 1).numpy()
+    assert x.shape == xr.shape == (B, 188)
+    dev = np.abs(x - xr)
+    print("SMPL-X-sized LM parameter deviation vs oracle:", {"pose": float(dev[:, :162].max()), "betas": float(dev[:, 162:182].max()),
+                                                             "orient": float(dev[:, 182:185].max()), "transl": float(dev[:, 185:].max())})
+    assert dev.max() < 1e-4
+    assert (aux["status"].cpu().numpy() == 0).all()
+
+
+def test_marker_status_flags_nan_and_empty_scans():
+    """a status word per scan at the boundary instead of silent NaN: bit 0 when a valid marker's conf**20 weights all
+    underflow (0/0 centre, exactly what fit_SMPL.py:52-57 computes), bit 1 when the scan has no valid marker."""
+    from etch_amd import constants as K
+    from etch_amd.models.fit_SMPL import fit_smpl
+    from etch_amd.utils.body_model import SyntheticSMPL
+    ms = K.default_markerset()
+    args = types.SimpleNamespace(markerset=ms, device=torch.device("cuda"), body_model=SyntheticSMPL(7))
+    B, Kp = 3, 200
+    g = torch.Generator().manual_seed(1)
+    pts = torch.randn(B, Kp, 3, generator=g) * 0.3
+    labels = torch.arange(Kp).repeat(B, 1) % 86
+    conf = torch.full((B, Kp, 1), 0.9)
+    conf[1, labels[1] == 7] = 1e-3                     # 1e-3 ** 20 = 0 in fp32 for every point of label 7 -> NaN marker
+    labels[2] = 300                                    # no label of scan 2 is a marker
+    meshes, markers, valid, info, aux = fit_smpl(args, pts.cuda(), labels.cuda(), conf.cuda(), "neutral", steps_stage0=3, steps_stage1=3,
+                                                 return_trace=True)
+    assert aux["status"].cpu().tolist() == [0, 1, 2]
+    assert np.isfinite(info[0][0]).all() and np.isnan(info[0][1]).any() and np.isfinite(info[0][2]).all()
