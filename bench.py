@@ -40,14 +40,15 @@ def synth_scan(global_index, n):
     return (np.random.default_rng(1000 + global_index).standard_normal((n, 3)) * np.array([0.14, 0.31, 0.085])).astype(np.float32)
 
 
-def build(device, seed=1):
+def build(device, seed=1, body="smpl"):
     from etch_amd import constants as K
     from etch_amd.models.models_pointcloud import GT_network_equiv
-    from etch_amd.utils.body_model import SyntheticSMPL
+    from etch_amd.utils.body_model import SyntheticSMPL, SyntheticSMPLX
     from etch_amd.utils.weights import load_seeded
 
+    bm = SyntheticSMPL(7) if body == "smpl" else SyntheticSMPLX(7)
     args = types.SimpleNamespace(output_folder=os.path.join("/tmp", f"etch_bench_{os.getpid()}"), EPN_input_radius=0.4, EPN_layer_num=2,
-                                 device=device, markerset=K.default_markerset(), scale_magnitude=10, body_model=SyntheticSMPL(7))
+                                 device=device, markerset=K.default_markerset(), scale_magnitude=10, body_model=bm)
     model = load_seeded(GT_network_equiv(option=args), seed).to(device).eval()
     return args, model
 
@@ -110,7 +111,7 @@ def profile_pass(run_step):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(n_points, gpu_pts, gpu_results, gpu_fit_aux, args, seed=1, threads=None, forward_only=False):
+def cpu_baseline(n_points, gpu_pts, gpu_results, gpu_fit_aux, args, seed=1, threads=None, forward_only=False, iters=(30, 50), refit=None):
     """The oracle (CPU restatement = "port") timed on this box's host cores on ONE scan of the same workload:
     full stage 1 and the full 30 + 50 iteration LM fit.  Also returns parity numbers for that scan.  `threads`: torch CPU
     threads (default 32 or the core count if smaller: on the 128-thread GPU box the oracle's small-matrix stages run SLOWER
@@ -138,13 +139,19 @@ def cpu_baseline(n_points, gpu_pts, gpu_results, gpu_fit_aux, args, seed=1, thre
                     sample=f"1 scan x {n_points} pts: oracle stage 1 ({t1:.1f} s), torch CPU fp32, {cores} threads"), parity
     inner = x - out["direction"] * out["magnitude"] / args.scale_magnitude
     mv = np.array(list(args.markerset.values()))
+    # bounded sample: the autograd LM differentiates the full mesh (~0.15 s / iteration for SMPL, ~1 s for the SMPL-X-sized model), so
+    # long schedules are timed on a prefix of both stages and scaled to the full iteration count
+    full = iters[0] + iters[1]
+    run = iters if full <= 80 else (4, 6)
     t0 = time.time()
     mk, valid = S2.get_markers(len(args.markerset), inner, labels, out["confidences"])
-    fit = S2.fit_smpl(args.body_model, mv, mk, valid)
-    t2 = time.time() - t0
-    # fitter-only parity: the oracle LM on the GPU's own markers of scan 0
+    fit = S2.fit_smpl(args.body_model, mv, mk, valid, steps_stage0=run[0], steps_stage1=run[1])
+    t2 = (time.time() - t0) * full / (run[0] + run[1])
+    # fitter-only parity: the oracle LM on the GPU's own markers of scan 0 (same, possibly shortened, schedule on both sides)
     gm, gv = gpu_fit_aux["markers"][:1].cpu(), gpu_fit_aux["valid"][:1].cpu()
-    fit_g = S2.fit_smpl(args.body_model, mv, gm, gv)
+    fit_g = S2.fit_smpl(args.body_model, mv, gm, gv, steps_stage0=run[0], steps_stage1=run[1])
+    if run != tuple(iters):
+        gpu_fit_aux = refit(run)
     v2v = (gpu_fit_aux["verts"][:1].cpu() - fit_g["verts"]).norm(dim=-1).mean()
     parity["v2v_mm_gpu_vs_oracle_same_markers"] = float(v2v * 1e3)
     # pose / shape deltas vs the CPU oracle on identical inputs = the two fits of the same markers.  (A whole-pipeline
@@ -152,10 +159,12 @@ def cpu_baseline(n_points, gpu_pts, gpu_results, gpu_fit_aux, args, seed=1, thre
     # top-3 selection of fit_SMPL.py:42-57 differs between any two fp32 implementations; the stage-1 outputs themselves agree
     # to ~1e-6, see the entries above.)
     gx = gpu_fit_aux["x"][:1].cpu()
-    parity["pose_delta_rad_same_markers"] = float((gx[:, :69] - fit_g["pose"].reshape(1, 69)).abs().max())
-    parity["betas_delta_same_markers"] = float((gx[:, 69:79] - fit_g["betas"].reshape(1, 10)).abs().max())
+    npose, nbt = fit_g["pose"].shape[1], fit_g["betas"].shape[1]
+    parity["pose_delta_rad_same_markers"] = float((gx[:, :npose] - fit_g["pose"]).abs().max())
+    parity["betas_delta_same_markers"] = float((gx[:, npose:npose + nbt] - fit_g["betas"]).abs().max())
+    how = f"full {iters[0]}+{iters[1]}-iteration" if run == tuple(iters) else f"{run[0]}+{run[1]} of {iters[0]}+{iters[1]} iterations timed, scaled to the full schedule:"
     return dict(value=1.0 / (t1 + t2), unit="scans/s", cores=cores, kind="port",
-                sample=f"1 scan x {n_points} pts: oracle stage 1 ({t1:.1f} s) + get_markers + full 30+50-iteration autograd LM fit ({t2:.1f} s), torch CPU fp32, {cores} threads"), parity
+                sample=f"1 scan x {n_points} pts: oracle stage 1 ({t1:.1f} s) + get_markers + {how} autograd LM fit ({t2:.1f} s), torch CPU fp32, {cores} threads"), parity
 
 
 # ------------------------------------------------------------------------------------------------ launcher
@@ -211,8 +220,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="scans per GPU")
-    ap.add_argument("--points", type=int, default=5000)
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 4], help="BASELINE.json configs[k]: 2 (default, the configuration the metric is "
+                    "quoted on) = 32 x 5000 pts per GPU, forward + 30+50-iteration SMPL fit; 1 = the same batch, equivariant forward only; "
+                    "4 = the per-GPU shard of the 64 x 20000-pt stress config: 8 dense scans per GPU + 200-iteration (75+125) fit of the "
+                    "SMPL-X-sized 188-DoF body model")
+    ap.add_argument("--batch", type=int, default=0, help="scans per GPU (default: the config's)")
+    ap.add_argument("--points", type=int, default=0, help="points per scan (default: the config's)")
     ap.add_argument("--forward-only", action="store_true", help="BASELINE.json configs[1]: a step is the equivariant forward only")
     ap.add_argument("--same-batch", action="store_true", help="feed the same resident batch every step (default: a distinct batch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -229,6 +242,10 @@ def main():
         sys.exit(launch_ranks(a.gpus, sys.argv[1:]))          # parent: no GPU call before or after this point
     if a.serial:
         a.sync, a.concurrent_heads = True, 0
+    if a.config == 1:
+        a.forward_only = True
+    cfg = {"body": "smplx", "iters": (75, 125), "batch": 8, "points": 20000} if a.config == 4 else {"body": "smpl", "iters": (30, 50), "batch": 32, "points": 5000}
+    a.batch, a.points = a.batch or cfg["batch"], a.points or cfg["points"]
     a.pipeline = not a.sync and not a.forward_only
 
     from etch_amd import parallel as P
@@ -264,7 +281,8 @@ def main():
     if dry:
         def step(p=pts):
             time.sleep(0.002)
-            last.update(err=p[:, :, 0].mean(1).abs(), valid=torch.ones(B, 86, dtype=torch.bool), x=p[:, :85, 0].contiguous())
+            last.update(err=p[:, :, 0].mean(1).abs(), valid=torch.ones(B, 86, dtype=torch.bool), x=p[:, :85, 0].contiguous(),
+                        status=torch.zeros(B, dtype=torch.int32), frozen=torch.zeros(B, dtype=torch.int64))
 
         def run_steps(bs):
             for p in bs:
@@ -272,7 +290,8 @@ def main():
     else:
         from etch_amd.inference_demo import predict_smpl_batch
         from etch_amd.pipeline import HotPathPipeline
-        args, model = build(device)
+        args, model = build(device, body=cfg["body"])
+        fit_kw = dict(steps_stage0=cfg["iters"][0], steps_stage1=cfg["iters"][1])
         model.concurrent_heads = bool(a.concurrent_heads)
         if a.serial:
             model.overlap_index_ops = False
@@ -284,11 +303,13 @@ def main():
             model_results.update(r)
 
         def full_step(p=pts):
-            meshes, markers, valid, info, aux = predict_smpl_batch(args, model, p, "neutral", return_trace=True)
-            last.update(markers=markers, valid=valid, verts=aux["verts"], x=aux["x"], err=aux["err_trace"][:, -1])
+            meshes, markers, valid, info, aux = predict_smpl_batch(args, model, p, "neutral", return_trace=True, **fit_kw)
+            tr = aux["err_trace"]
+            last.update(markers=markers, valid=valid, verts=aux["verts"], x=aux["x"], err=tr[:, -1], status=aux["status"],
+                        frozen=(tr[:, 1:] == tr[:, :-1]).sum(1))
 
         step = stage1_only if a.forward_only else full_step
-        pipe = HotPathPipeline(args, model, "neutral", max_in_flight=a.stage1_streams + 1, stage1_streams=a.stage1_streams, want_trace=True)
+        pipe = HotPathPipeline(args, model, "neutral", max_in_flight=a.stage1_streams + 1, stage1_streams=a.stage1_streams, want_trace=True, **fit_kw)
 
         def run_steps(bs):
             """One step per batch of `bs`; with the pipeline, stage 2 of step i overlaps stage 1 of step i+1 (all finish inside the call)."""
@@ -326,9 +347,11 @@ def main():
         row_names = ["mean confidence", "max confidence", "mean magnitude"]
     else:
         nv = last["valid"].float().sum(1)
-        rows = torch.stack([last["err"], nv, (2.0 * last["err"] / nv.clamp_min(1)).sqrt() * 1e3, last["x"][:, :69].norm(dim=1),
-                            last["x"][:, 69:79].norm(dim=1)], 1)
-        row_names = ["final LM error", "valid markers", "rms marker residual mm", "pose norm rad", "betas norm"]
+        npose = last["x"].shape[1] - (26 if a.config == 4 else 16)
+        rows = torch.stack([last["err"], nv, (2.0 * last["err"] / nv.clamp_min(1)).sqrt() * 1e3, last["x"][:, :npose].norm(dim=1),
+                            last["x"][:, npose:-6].norm(dim=1), last["status"].float(), last["frozen"].float()], 1)
+        row_names = ["final LM error", "valid markers", "rms marker residual mm", "pose norm rad", "betas norm", "status word",
+                     "LM iterations skipped after the convergence freeze"]
     allrows = P.gather_rows(rows)
 
     if rank != 0:
@@ -337,11 +360,16 @@ def main():
     finite = torch.isfinite(allrows).all(1)
     cfg_name = (f"configs[1]: batch={B}/GPU synthetic {N}-pt Gaussian-blob scans, equivariant forward only (encoder + confidence / direction / "
                 "magnitude heads), seeded random weights" if a.forward_only else
+                f"configs[4] per-GPU shard: batch={B}/GPU dense synthetic {N}-pt scans, full pipeline (eq-net + 75+125-iter LM fit of the SMPL-X-sized "
+                "188-DoF body: 55 joints, 20 shape+expression coefficients, 10475 vertices), seeded random weights, 86 markers" if a.config == 4 else
                 f"configs[2]: batch={B}/GPU synthetic {N}-pt Gaussian-blob scans, full pipeline (eq-net + 30+50-iter LM SMPL fit), "
                 "seeded random weights, seeded SMPL-shaped body model, 86-marker superset")
     sched = ("serial: synchronous steps, one stream" if a.serial else "synchronous steps") if not a.pipeline else \
         "2-deep stream pipeline: stage 2 of step i overlaps stage 1 of step i+1"
-    out = {"metric": "scans/s (5k pts, eq-net forward only)" if a.forward_only else "scans/s (5k pts, eq-net + 50-iter SMPL fit)",
+    metric = "scans/s (5k pts, eq-net forward only)" if a.forward_only else "scans/s (5k pts, eq-net + 50-iter SMPL fit)"
+    if a.config == 4:
+        metric = "scans/s (20k pts, eq-net + 200-iter SMPL-X-sized fit)"
+    out = {"metric": metric,
            "value": round(value, 3), "unit": "scans/s", "n_gpus": world,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -404,7 +432,11 @@ def main():
         out["path_roofline"] = {"ceiling_scans_per_s_per_gpu": 1030, "frac": round(value / world / 1030.0, 4)}
 
     if world == 1 and not a.no_cpu_baseline:
-        cb, parity = cpu_baseline(N, pts, model_results, last, args, threads=a.cpu_threads or None, forward_only=a.forward_only)
+        def refit(run):          # the GPU fit of batch 0 with a shortened schedule (parity partner of the bounded oracle run)
+            _, mk_, va_, _, aux_ = predict_smpl_batch(args, model, pts, "neutral", return_trace=True, steps_stage0=run[0], steps_stage1=run[1])
+            return dict(markers=mk_, valid=va_, verts=aux_["verts"], x=aux_["x"])
+        cb, parity = cpu_baseline(N, pts, model_results, last, args, threads=a.cpu_threads or None, forward_only=a.forward_only,
+                                  iters=cfg["iters"], refit=refit)
         out["cpu_baseline"] = cb
         out["parity_scan0"] = parity
     print(json.dumps(out), flush=True)

@@ -62,14 +62,18 @@ __global__ void __launch_bounds__(WAVES * 64) ball_query_kernel(int n, int m, fl
 // which reproduces the reference's per-thread strict '>' scan + LDS tree reduce tie-breaking
 // exactly (proved against the literal emulation in tests/test_oracle_ops.py).
 // Addressing: coordinate c of local point k is src[c * cs + k * ps].
-template <int THREADS, int PPT, bool REGS>   // lds_xyz = capacity (points) of the dynamic-LDS coordinate copy, 0 = none
+// CARRY: the candidate's coordinates travel with its key through the reduction (scans too large for an LDS copy of the coordinates:
+// saves the dependent global read of the winner, 16 -> 2.7 us per round at 20 000 points); otherwise the winner is read from the LDS copy.
+template <int THREADS, int PPT, bool REGS, bool CARRY>   // lds_xyz = capacity (points) of the dynamic-LDS coordinate copy, 0 = none
 __global__ void __launch_bounds__(THREADS) fps_kernel(int lds_xyz, const float* __restrict__ xyz, long cs, long ps,
                                                       long batch_stride, int n_fixed, int m_fixed,
                                                       const int* __restrict__ offset, const int* __restrict__ new_offset,
                                                       int bs, int bs_bits, int skip_origin, int* __restrict__ idx) {
-    __shared__ unsigned long long red[2 * (THREADS / 64)];
-    extern __shared__ __attribute__((aligned(16))) float fps_xyz[];     // [3][lds_xyz]: the winner's coordinates are read from
-    const int CAP = lds_xyz;                                             // LDS each round instead of global memory
+    // per-wave partial maxima, double-buffered
+    struct Cand { unsigned long long key; float x, y, z, pad; };
+    __shared__ Cand red[2 * (THREADS / 64)];
+    extern __shared__ __attribute__((aligned(16))) float fps_xyz[];     // [3][lds_xyz]: non-REGS variants read the winner from here
+    const int CAP = lds_xyz;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int seg = blockIdx.x;
     int start_n, n, start_m, m;
@@ -84,19 +88,25 @@ __global__ void __launch_bounds__(THREADS) fps_kernel(int lds_xyz, const float* 
         m = new_offset[seg] - start_m;
         src = xyz + (size_t)start_n * ps;
     }
-    // REGS: coordinates cached in registers (small PPT); otherwise re-read (coalesced, L2-resident) every round.
+    // REGS: coordinates and tie keys cached in registers; otherwise re-read (coalesced, L2-resident) every round.
     float px[REGS ? PPT : 1], py[REGS ? PPT : 1], pz[REGS ? PPT : 1];
+    unsigned tie[REGS ? PPT : 1];
     float temp[PPT];
     unsigned valid = 0u;                     // bit i: point tid + i*THREADS is a candidate
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
         const int k = tid + i * THREADS;
         temp[i] = 1e10f;
-        if (REGS) px[i] = py[i] = pz[i] = 0.f;
+        if (REGS) {
+            px[i] = py[i] = pz[i] = 0.f;
+            const unsigned kl = (unsigned)k & (unsigned)(bs - 1);
+            const unsigned rev = bs_bits ? (__brev(kl) >> (32 - bs_bits)) : 0u;
+            tie[i] = 0xFFFFFFFFu - ((rev << 16) | ((unsigned)k / (unsigned)bs));
+        }
         if (k < n) {
             const float x = src[k * ps], y = src[cs + k * ps], z = src[2 * cs + k * ps];
             if (REGS) { px[i] = x; py[i] = y; pz[i] = z; }
-            if (lds_xyz) { fps_xyz[k] = x; fps_xyz[CAP + k] = y; fps_xyz[2 * CAP + k] = z; }
+            if (!CARRY && lds_xyz) { fps_xyz[k] = x; fps_xyz[CAP + k] = y; fps_xyz[2 * CAP + k] = z; }
             bool ok = true;
             if (skip_origin) {
 #pragma clang fp contract(off)
@@ -107,13 +117,17 @@ __global__ void __launch_bounds__(THREADS) fps_kernel(int lds_xyz, const float* 
         }
     }
     if (tid == 0 && m > 0) idx[start_m] = start_n;
-    if (lds_xyz) __syncthreads();
+    if (!CARRY && lds_xyz) __syncthreads();
     int old = 0;  // local index of the last selected point
+    float x1 = 0.f, y1 = 0.f, z1 = 0.f;
+    if (n > 0) { x1 = src[0]; y1 = src[cs]; z1 = src[2 * cs]; }
     for (int j = 1; j < m; ++j) {
-        float x1, y1, z1;
-        if (lds_xyz) { x1 = fps_xyz[old]; y1 = fps_xyz[CAP + old]; z1 = fps_xyz[2 * CAP + old]; }
-        else { x1 = src[old * ps]; y1 = src[cs + old * ps]; z1 = src[2 * cs + old * ps]; }
+        if (!CARRY) {
+            if (lds_xyz) { x1 = fps_xyz[old]; y1 = fps_xyz[CAP + old]; z1 = fps_xyz[2 * CAP + old]; }
+            else { x1 = src[old * ps]; y1 = src[cs + old * ps]; z1 = src[2 * cs + old * ps]; }
+        }
         unsigned long long best = 0ull;
+        float bx = 0.f, by = 0.f, bz = 0.f;
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             if (valid & (1u << i)) {
@@ -124,27 +138,45 @@ __global__ void __launch_bounds__(THREADS) fps_kernel(int lds_xyz, const float* 
                 float d = etch_sqdist(x, y, z, x1, y1, z1);
                 float d2 = d < temp[i] ? d : temp[i];
                 temp[i] = d2;
-                const unsigned kl = (unsigned)k & (unsigned)(bs - 1);
-                const unsigned rev = bs_bits ? (__brev(kl) >> (32 - bs_bits)) : 0u;
-                const unsigned tie = 0xFFFFFFFFu - ((rev << 16) | ((unsigned)k / (unsigned)bs));
-                unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | tie;
-                best = key > best ? key : best;
+                unsigned t;
+                if (REGS) t = tie[i];
+                else {
+                    const unsigned kl = (unsigned)k & (unsigned)(bs - 1);
+                    const unsigned rev = bs_bits ? (__brev(kl) >> (32 - bs_bits)) : 0u;
+                    t = 0xFFFFFFFFu - ((rev << 16) | ((unsigned)k / (unsigned)bs));
+                }
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | t;
+                const bool gt = key > best;
+                best = gt ? key : best;
+                if (CARRY) { bx = gt ? x : bx; by = gt ? y : by; bz = gt ? z : bz; }
             }
         }
-        best = etch_wave_max_u64_dpp(best);
+        const unsigned long long wbest = etch_wave_max_u64_dpp(best);
         // one barrier per round: partial maxima are double-buffered and every wave reduces them redundantly
-        unsigned long long* rb = red + (j & 1) * (THREADS / 64);
-        if (lane == 0) rb[wave] = best;
+        Cand* rb = red + (j & 1) * (THREADS / 64);
+        if (CARRY) {
+            // keys are unique per point, so exactly one lane holds the wave's best (or none when the wave has no candidate)
+            const unsigned long long hit = __ballot(best == wbest && wbest != 0ull);
+            const int srcl = hit ? (int)__builtin_ctzll(hit) : 0;
+            const float wx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bx), srcl));
+            const float wy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, by), srcl));
+            const float wz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bz), srcl));
+            if (lane == 0) { rb[wave].key = wbest; rb[wave].x = wx; rb[wave].y = wy; rb[wave].z = wz; }
+        } else if (lane == 0) rb[wave].key = wbest;
         __syncthreads();
-        unsigned long long v = lane < THREADS / 64 ? rb[lane] : 0ull;
-        v = etch_wave_max_u64_dpp(v);
+        const unsigned long long mine = lane < THREADS / 64 ? rb[lane].key : 0ull;
+        const unsigned long long v = etch_wave_max_u64_dpp(mine);
         int w = 0;  // no candidate at all -> local index 0 (reference: besti default)
         if (v != 0ull) {
             const unsigned t = 0xFFFFFFFFu - (unsigned)(v & 0xFFFFFFFFull);
             const unsigned rev = t >> 16, hi = t & 0xFFFFu;
             const unsigned kl = bs_bits ? (__brev(rev) >> (32 - bs_bits)) : 0u;
             w = (int)(hi * (unsigned)bs + kl);
-        }
+            if (CARRY) {
+                const int wl = (int)__builtin_ctzll(__ballot(mine == v));
+                x1 = rb[wl].x; y1 = rb[wl].y; z1 = rb[wl].z;
+            }
+        } else if (CARRY && n > 0) { x1 = src[0]; y1 = src[cs]; z1 = src[2 * cs]; }
         if (tid == 0) idx[start_m + j] = start_n + w;
         old = w;
     }
@@ -400,16 +432,18 @@ static int launch_fps(int nseg, int n_max, const float* xyz, long cs, long ps, l
                       const int* offset, const int* new_offset, int skip_origin, int* idx, hipStream_t st) {
     const int bs = opt_n_threads_host(n_max);
     const int bits = ilog2_floor_host(bs);
-#define FPS_CASE(T, P, R)                                                                                              \
-    if (n_max <= T * P) {                                                                                              \
-        const int use_lds = (size_t)3 * n_max * sizeof(float) <= 62 * 1024 ? n_max : 0;                                \
-        hipLaunchKernelGGL((fps_kernel<T, P, R>), dim3(nseg), dim3(T), (size_t)3 * use_lds * sizeof(float), st,        \
+    const bool fits_lds = (size_t)3 * n_max * sizeof(float) <= 62 * 1024;
+#define FPS_CASE(T, P, R, C, COND)                                                                                     \
+    if (n_max <= T * P && (COND)) {                                                                                    \
+        const int use_lds = !C && fits_lds ? n_max : 0;                                                                \
+        hipLaunchKernelGGL((fps_kernel<T, P, R, C>), dim3(nseg), dim3(T), (size_t)3 * use_lds * sizeof(float), st,     \
                            use_lds, xyz, cs, ps, bstride, n_fixed, m_fixed, offset, new_offset, bs, bits, skip_origin, idx);   \
         ETCH_RETURN_IF_LAUNCH_FAILED();                                                                                \
         return ETCH_OK;                                                                                                \
     }
-    FPS_CASE(64, 1, true) FPS_CASE(64, 4, true) FPS_CASE(256, 2, true) FPS_CASE(256, 8, true)
-    FPS_CASE(1024, 4, true) FPS_CASE(1024, 8, true) FPS_CASE(1024, 16, false) FPS_CASE(1024, 32, false)
+    FPS_CASE(64, 1, true, false, true) FPS_CASE(64, 4, true, false, true) FPS_CASE(256, 2, true, false, true) FPS_CASE(256, 8, true, false, true)
+    FPS_CASE(1024, 4, true, false, true) FPS_CASE(1024, 8, true, false, fits_lds) FPS_CASE(1024, 8, true, true, true)
+    FPS_CASE(1024, 12, true, true, true) FPS_CASE(1024, 20, true, true, true) FPS_CASE(1024, 32, false, false, true)
 #undef FPS_CASE
     return ETCH_EUNSUPPORTED;  // more than 32768 points per segment
 }
@@ -551,11 +585,80 @@ __global__ void __launch_bounds__(1024) spatial_order_kernel(int n, int np2, con
     for (int i = tid; i < n; i += 1024) order[(size_t)b * n + i] = (int)(unsigned)(keys[i] & 0xFFFFFFFFull);
 }
 
+// Scans of more than 16 384 points (BASELINE configs[4]: 20 000): 32-bit keys = 15-bit Morton code (32 cells per axis of the scan's
+// bounding box) | 17-bit index within a 32 768-point slice, one workgroup per (scan, slice) -- 128 KiB of LDS again.  Points of one
+// cell keep their index order; slices are sorted independently along the same curve (a scan of > 32 768 points is walked as that
+// many interleaved curves).  Like the 64-bit form this is a scheduling hint only: any permutation gives the same results.
+#define SO32_SLICE 32768
+__global__ void __launch_bounds__(1024) spatial_order32_kernel(int n, const float* __restrict__ xyz, int* __restrict__ order) {
+    extern __shared__ __attribute__((aligned(16))) unsigned keys32[];            // [np2 of the slice]
+    __shared__ float red[6][16];
+    const int b = blockIdx.x, base = blockIdx.y * SO32_SLICE, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cnt = min(n - base, SO32_SLICE);
+    int np2 = 2;
+    while (np2 < cnt) np2 <<= 1;
+    const float* X = xyz + (size_t)b * 3 * n;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = tid; i < n; i += 1024)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const float v = X[(size_t)a * n + i]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float l = lo[a], h = hi[a];
+        for (int o = 32; o > 0; o >>= 1) { l = fminf(l, __shfl_xor(l, o)); h = fmaxf(h, __shfl_xor(h, o)); }
+        if (lane == 0) { red[a][wave] = l; red[3 + a][wave] = h; }
+    }
+    __syncthreads();
+    float mn[3], sc[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float l = red[a][0], h = red[3 + a][0];
+        for (int w = 1; w < 16; ++w) { l = fminf(l, red[a][w]); h = fmaxf(h, red[3 + a][w]); }
+        mn[a] = l;
+        sc[a] = h > l ? 31.0f / (h - l) : 0.f;
+    }
+    for (int i = tid; i < np2; i += 1024) {
+        unsigned k = ~0u;                                            // padding sorts to the end
+        if (i < cnt) {
+            unsigned q[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float t = (X[(size_t)a * n + base + i] - mn[a]) * sc[a];
+                q[a] = (unsigned)fminf(fmaxf(t, 0.f), 31.f);
+            }
+            const unsigned m = etch_spread10(q[0]) | (etch_spread10(q[1]) << 1) | (etch_spread10(q[2]) << 2);     // 15 bits
+            k = (m << 17) | (unsigned)i;
+        }
+        keys32[i] = k;
+    }
+    __syncthreads();
+    for (int size = 2; size <= np2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < (np2 >> 1); i += 1024) {
+                const int lowi = ((i / stride) * (stride << 1)) + (i % stride), highi = lowi + stride;
+                const bool up = ((lowi & size) == 0);
+                const unsigned x = keys32[lowi], y = keys32[highi];
+                if ((x > y) == up) { keys32[lowi] = y; keys32[highi] = x; }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < cnt; i += 1024) order[(size_t)b * n + base + i] = base + (int)(keys32[i] & 0x1FFFFu);
+}
+
 extern "C" int etch_spatial_order(int b, int n, const float* xyz, int* order, void* stream) {
     if (b <= 0 || n <= 0) return ETCH_OK;
     int np2 = 2;
     while (np2 < n) np2 <<= 1;
-    if (np2 > 16384) return ETCH_EUNSUPPORTED;                       // 128 KiB of keys
+    if (np2 > 16384) {
+        const int slices = (n + SO32_SLICE - 1) / SO32_SLICE;
+        if (b > 65535 || slices > 65535) return ETCH_EUNSUPPORTED;
+        const int lds = SO32_SLICE * (int)sizeof(unsigned);           // 128 KiB
+        hipError_t e = hipFuncSetAttribute((const void*)spatial_order32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(spatial_order32_kernel, dim3(b, slices), dim3(1024), lds, (hipStream_t)stream, n, xyz, order);
+        ETCH_RETURN_IF_LAUNCH_FAILED();
+        return ETCH_OK;
+    }
     const size_t lds = (size_t)np2 * sizeof(unsigned long long);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)spatial_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -154,11 +154,10 @@ def permute_weight_frag(w2):
 
 # ------------------------------------------------------------------ EPN encoder
 def spatial_order(xyz):
-    """xyz (b,3,n) -> (b,n) int32 Morton order of each scan (scheduling hint for inter_so3conv); None if n is unsupported."""
+    """xyz (b,3,n) -> (b,n) int32 Morton order of each scan (scheduling hint for inter_so3conv / prop_interp: a permutation of
+    0..n-1 per scan; 30-bit codes up to 16 384 points, 15-bit codes in 32 768-point slices above)."""
     _need(xyz, torch.float32, "xyz")
     b, _, n = xyz.shape
-    if n > 16384:
-        return None
     order = torch.empty((b, n), dtype=torch.int32, device=xyz.device)
     _lib.check(_lib.lib().etch_spatial_order(b, n, _ptr(xyz), _ptr(order), _stream()), "etch_spatial_order")
     return order

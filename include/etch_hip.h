@@ -95,8 +95,9 @@ int etch_inter_so3conv_ordered(int b, int cin, int cout, int p1, int p2, int nn,
  * values.  Same result as etch_instnorm_stats over the full tensor (fp64 accumulation, fixed order). */
 int etch_instnorm_from_partials(int b, int nparts, int C, int count, const float* partial, float* mean, float* rstd, void* stream);
 
-/* Morton (Z-curve) order of each scan's points on its own bounding box, ties by index: xyz (b,3,n) -> order (b,n) int32.
- * n <= 16384.  No counterpart in the reference: it only feeds etch_inter_so3conv_ordered. */
+/* Morton (Z-curve) order of each scan's points on its own bounding box, ties by index: xyz (b,3,n) -> order (b,n) int32, a
+ * permutation of 0..n-1 per scan.  n <= 16384: 10 bits per axis; larger scans: 5 bits per axis, sorted in independent slices of
+ * 32768 points.  No counterpart in the reference: it only schedules etch_inter_so3conv_ordered / etch_prop_interp_ordered. */
 int etch_spatial_order(int b, int n, const float* xyz, int* order, void* stream);
 
 /* Fused intra-SO(3) convolution.  Replaces intra_so3conv_grouping (functional.py:331-378) + BasicSO3Conv

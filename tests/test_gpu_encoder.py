@@ -110,12 +110,14 @@ def test_encoder_vs_reference_golden(golden):
     assert rel_err(f[:, :, ::16, :], g["enc_feats_sub"]) < RTOL
 
 
-def _morton_reference(x):
-    """numpy restatement of etch_spatial_order: 10 bits per axis on the scan's bounding box, ties by index."""
+def _morton_reference(x, bits=10, base=0, count=None):
+    """numpy restatement of etch_spatial_order: `bits` per axis on the scan's bounding box, ties by index; for scans of more than
+    16 384 points: 5 bits per axis and independent 32 768-point slices [base, base + count)."""
     x = x.astype(np.float32)
+    cells = np.float32(2 ** bits - 1)
     lo, hi = x.min(1, keepdims=True), x.max(1, keepdims=True)
-    sc = (np.float32(1023.0) / np.where(hi > lo, hi - lo, np.float32(1.0)) * (hi > lo)).astype(np.float32)
-    q = np.clip(((x - lo) * sc).astype(np.float32), 0, 1023).astype(np.uint64)
+    sc = (cells / np.where(hi > lo, hi - lo, np.float32(1.0)) * (hi > lo)).astype(np.float32)
+    q = np.clip(((x - lo) * sc).astype(np.float32), 0, cells).astype(np.uint64)
 
     def spread(v):
         v = (v | (v << 16)) & 0x030000FF
@@ -124,7 +126,9 @@ def _morton_reference(x):
         v = (v | (v << 2)) & 0x09249249
         return v
     key = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2)
-    return np.lexsort((np.arange(x.shape[1]), key))
+    count = x.shape[1] - base if count is None else count
+    idx = np.arange(base, base + count)
+    return idx[np.lexsort((idx, key[idx]))]
 
 
 @pytest.mark.parametrize("b,n", [(3, 2500), (2, 1250), (1, 1), (2, 4097), (1, 16384)])
@@ -139,7 +143,21 @@ def test_spatial_order_is_the_morton_permutation(b, n):
     for i in range(b):
         assert np.array_equal(np.sort(order[i]), np.arange(n))
         assert np.array_equal(order[i], _morton_reference(xyz[i]))
-    assert ops.spatial_order(torch.zeros(1, 3, 20000).cuda()) is None
+
+
+@pytest.mark.parametrize("b,n", [(2, 20000), (1, 16385), (1, 32768), (1, 40001)])
+def test_spatial_order_beyond_one_lds_sort(b, n):
+    """BASELINE configs[4] sizes (20 000 points per scan): 15-bit codes, 32 768-point slices -- still a permutation of every scan, and
+    exactly the coarse Morton walk of each slice."""
+    from etch_amd import ops
+    rng = np.random.default_rng(n)
+    xyz = (rng.standard_normal((b, 3, n)) * np.array([0.14, 0.31, 0.085])[None, :, None]).astype(np.float32)
+    order = ops.spatial_order(torch.from_numpy(xyz).cuda()).cpu().numpy()
+    assert order.shape == (b, n) and order.dtype == np.int32
+    for i in range(b):
+        assert np.array_equal(np.sort(order[i]), np.arange(n))
+        want = np.concatenate([_morton_reference(xyz[i], 5, s, min(32768, n - s)) for s in range(0, n, 32768)])
+        assert np.array_equal(order[i], want)
 
 
 def test_inter_conv_result_does_not_depend_on_the_schedule(golden):

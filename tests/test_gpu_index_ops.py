@@ -18,7 +18,8 @@ def dev(a):
 
 @pytest.mark.parametrize("n,m,sigma", [(5000, 2500, (0.14, 0.31, 0.085)), (5000, 2500, (0.20, 0.45, 0.12)), (1024, 512, (0.14, 0.31, 0.085)),
                                        (160, 80, (0.14, 0.31, 0.085)), (37, 20, (0.5, 0.5, 0.5)), (9000, 300, (0.14, 0.31, 0.085)),
-                                       (20000, 200, (0.14, 0.31, 0.085))])
+                                       (20000, 200, (0.14, 0.31, 0.085)), (12000, 700, (0.14, 0.31, 0.085)), (20000, 10000, (0.14, 0.31, 0.085)),
+                                       (24000, 150, (0.14, 0.31, 0.085))])
 def test_fps_vgtk(n, m, sigma):
     from etch_amd import ops
     x = np.stack([scan(1000 + b, n, sigma).T for b in range(3)])
@@ -29,7 +30,7 @@ def test_fps_vgtk(n, m, sigma):
 def test_fps_vgtk_ties_and_origin_skip():
     from etch_amd import ops
     rng = np.random.default_rng(3)
-    for n in (37, 64, 200, 1500, 2600, 4100):
+    for n in (37, 64, 200, 1500, 2600, 4100, 9000, 17000):
         pts = rng.integers(-3, 4, (2, n, 3)).astype(np.float32) * 0.25 + 0.125
         pts[:, 5] = 0.0      # origin point: never a candidate
         pts[:, 7] = 0.01
@@ -101,7 +102,7 @@ def test_knn_exact_ties_follow_heap_order():
 
 
 @pytest.mark.parametrize("segs,stride", [([5000, 5000, 5000], 4), ([1250, 1250], 4), ([312, 312], 4), ([78, 78, 78], 4), ([19, 19], 4),
-                                         ([150, 90], 4), ([4999, 130, 2047], 3)])
+                                         ([150, 90], 4), ([4999, 130, 2047], 3), ([20000, 20000], 4), ([11000, 300, 20480], 4)])
 def test_fps_pointops(segs, stride):
     from etch_amd import ops
     p = np.concatenate([scan(5000 + i, n) for i, n in enumerate(segs)])
