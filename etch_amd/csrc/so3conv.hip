@@ -24,8 +24,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //       w[a,k,n] = relu(1 - |g_n - R_a kappa_k|^2 / sigma) generated per lane as the B fragment
 //   step 2 (16 anchors at a time):  Y[o,col] = sum_kappa W[o,kappa] * X1[col][kappa] + bias      MFMA M=o, N=col, K=CIN*24
 //       X1 goes through LDS ([col][kappa], row stride CIN*24+4), W is read pre-permuted in fragment order.
+// Channel order: a lane gathers VEC = CIN/16 CONSECUTIVE channels of a neighbour row with ONE 4/8/16-byte load (a (q,a) row is CIN
+// contiguous floats) and feeds one of them to each of the VEC c-tiles, i.e. row r of c-tile mi is channel VEC*r + mi.  The
+// contraction index of step 2 follows that order: kappa' = (half h, cc = r*MTH + (mi - h*MTH), k); the host permutes the columns
+// of W accordingly before the fragment permutation (ops.inter_weight_frag) -- the result is the same sum in a different order.
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int MAXT>     // MAXT = ceil(nn / 16) neighbour chunks held in registers (nn <= 16 * MAXT)
+template <int CIN, int COUT, int MAXT, int PD>     // MAXT = ceil(nn / 16) neighbour chunks held in registers (nn <= 16 * MAXT); PD = gather prefetch distance (chunk-steps)
 __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
     int p1, int p2, int nn, float inv_sigma, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
     const int* __restrict__ ball_idx, const float* __restrict__ feats, const float* __restrict__ rk,
@@ -59,85 +63,118 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
     }
     const int nchunk = (nn + 15) >> 4;
 
-    // per-lane neighbour data for n = 16t + 4fg + s
-    int nidx[MAXT][4];
-    float gx[MAXT][4], gy[MAXT][4], gz[MAXT][4], ga[MAXT][4];
-    {
-        const float cx = new_xyz[((size_t)b * 3 + 0) * p2 + p], cy = new_xyz[((size_t)b * 3 + 1) * p2 + p],
-                    cz = new_xyz[((size_t)b * 3 + 2) * p2 + p];
+    // neighbour table of this output point in LDS, one entry per neighbour slot n < 16 * MAXT (shared by all lanes and waves: the
+    // matrix-core steps read it with broadcast ds_reads instead of holding 5 * 4 * MAXT registers per lane):
+    //   nbt[n] = (2 g / sigma, 1 - |g|^2 / sigma)   for  w = relu(1 - |g - r|^2 / sigma) = relu(nbt.w + rb + nbt.xyz . r)  (5 VALU ops per weight)
+    //   noff[n] = float offset of the neighbour's anchor-0 feature row;  padded slots: weight forced to 0, row 0
+    constexpr int VEC = MT1;               // consecutive channels a lane gathers per neighbour row
+    float4* nbt = reinterpret_cast<float4*>(part + 4 * 16 * PS);       // [16 * MAXT]
+    unsigned* noff = reinterpret_cast<unsigned*>(nbt + 16 * MAXT);      // [16 * MAXT]
+    if (tid < 16 * MAXT) {
+        const int n = tid;
         const int* row = ball_idx + ((size_t)b * p2 + p) * nn;
+        int q = row[n < nn ? n : nn - 1];                                // branch-free: clamped read, masked below
+        q = n < nn ? q : -1;
+        const int qq = q < 0 ? 0 : q;
         const float* X = xyz + (size_t)b * 3 * p1;
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int n = 16 * t + 4 * fg + s;
-                int q = -1;
-                if (t < nchunk && n < nn) q = row[n];
-                nidx[t][s] = q;
-                const int qq = q < 0 ? 0 : q;
-                const float x = X[qq] - cx, y = X[p1 + qq] - cy, z = X[2 * p1 + qq] - cz;
-                // w = relu(1 - |g - r|^2 / sigma) = relu(ga + rb + G . r):  5 VALU ops per weight instead of 8
-                ga[t][s] = q < 0 ? -1e30f : 1.0f - (x * x + y * y + z * z) * inv_sigma;     // padded neighbour -> weight 0
-                gx[t][s] = 2.0f * inv_sigma * x; gy[t][s] = 2.0f * inv_sigma * y; gz[t][s] = 2.0f * inv_sigma * z;
-            }
+        const float x = X[qq] - new_xyz[((size_t)b * 3 + 0) * p2 + p], y = X[p1 + qq] - new_xyz[((size_t)b * 3 + 1) * p2 + p],
+                    z = X[2 * p1 + qq] - new_xyz[((size_t)b * 3 + 2) * p2 + p];
+        nbt[n] = make_float4(2.0f * inv_sigma * x, 2.0f * inv_sigma * y, 2.0f * inv_sigma * z,
+                             q < 0 ? -1e30f : 1.0f - (x * x + y * y + z * z) * inv_sigma);
+        noff[n] = (unsigned)qq * (unsigned)(NA * CIN);
     }
+    __syncthreads();
     const float* Fb = feats + (size_t)b * p1 * NA * CIN;
     float* outp = out + ((size_t)b * p2 + p) * NA * COUT;
     const bool k1ok = fr < 8;
+    const int k1 = k1ok ? 16 + fr : 0;
+
+    // Gathered neighbour rows travel through a register ring PD chunk-steps (4 neighbours each) ahead of the matrix cores, across
+    // anchors and across the anchor groups (the first chunks of the next group are in flight during step 2); the kernel points of
+    // the next anchor one anchor ahead.  A wave's own MFMAs then cover most of the L2 / HBM latency of its gathers.
+    typedef float VecT __attribute__((ext_vector_type(VEC)));
+    constexpr int NCS = 4 * MAXT;          // chunk-steps of one wave in one anchor group (4 anchors x MAXT chunks)
+    constexpr int NRING = PD + 1;
+    static_assert(NCS % NRING == 0, "ring slots must line up across anchor groups");
+    VecT ring[NRING][4];
+    float rkn[6];
+    auto issue = [&](int ag_, int cs, VecT (&dst)[4]) {
+        const int j = cs / MAXT, t = cs % MAXT;
+        int a = ag_ * 16 + wave * 4 + j;
+        a = a < NA ? a : NA - 1;
+        const float* Fa = Fb + (size_t)a * CIN;         // wave-uniform base + 32-bit lane offset
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dst[s] = *reinterpret_cast<const VecT*>(Fa + (noff[16 * t + 4 * fg + s] + (unsigned)(VEC * fr)));
+    };
+    auto issue_rk = [&](int a) {
+        a = a < NA ? a : NA - 1;
+        const float* rka = rk + (size_t)a * KS * 3;
+        rkn[0] = rka[fr * 3]; rkn[1] = rka[fr * 3 + 1]; rkn[2] = rka[fr * 3 + 2];
+        rkn[3] = rka[k1 * 3]; rkn[4] = rka[k1 * 3 + 1]; rkn[5] = rka[k1 * 3 + 2];
+    };
+    issue_rk(wave * 4);
+#pragma unroll
+    for (int c = 0; c < PD; ++c) issue(0, c, ring[c % NRING]);
 
     // InstanceNorm statistics of the output, fused: this thread's output channel is fixed (256 % COUT == 0), so it keeps the sum
     // and the sum of squares of everything it writes; reduced per workgroup at the end (stat_part [b][p2][2][COUT])
     float st_s = 0.f, st_q = 0.f;
+#pragma unroll 1
     for (int ag = 0; ag < 4; ++ag) {
         f32x4 keep[4][HALVES > 1 ? MTH : 1][2];        // second channel half of the wave's 4 anchors (HALVES == 2 only)
-        // ---------------- step 1: 4 anchors per wave
+        // ---------------- step 1: 4 anchors per wave, MAXT chunk-steps each
+        f32x4 acc[MT1][2];
+        float r0x = 0.f, r0y = 0.f, r0z = 0.f, r1x = 0.f, r1y = 0.f, r1z = 0.f, rb0 = 0.f, rb1 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int cs = 0; cs < NCS; ++cs) {
+            const int j = cs / MAXT, t = cs % MAXT;
             const int col = wave * 4 + j;
             const int a = ag * 16 + col;
-            f32x4 acc[MT1][2];
+            if (t == 0) {                                   // anchor start
+                asm volatile("" ::: "memory");              // keeps the (loop-invariant) neighbour-table reads in LDS instead of 80 hoisted registers
 #pragma unroll
-            for (int mi = 0; mi < MT1; ++mi) { acc[mi][0] = (f32x4){0, 0, 0, 0}; acc[mi][1] = (f32x4){0, 0, 0, 0}; }
-            if (a < NA) {                                   // wave-uniform
-                const float* rka = rk + (size_t)a * KS * 3;
-                const float r0x = rka[fr * 3], r0y = rka[fr * 3 + 1], r0z = rka[fr * 3 + 2];
-                const int k1 = k1ok ? 16 + fr : 0;
-                const float r1x = rka[k1 * 3], r1y = rka[k1 * 3 + 1], r1z = rka[k1 * 3 + 2];
-                const float rb0 = -(r0x * r0x + r0y * r0y + r0z * r0z) * inv_sigma;
-                const float rb1 = k1ok ? -(r1x * r1x + r1y * r1y + r1z * r1z) * inv_sigma : -1e30f;   // k >= 24: weight 0
+                for (int mi = 0; mi < MT1; ++mi) { acc[mi][0] = (f32x4){0, 0, 0, 0}; acc[mi][1] = (f32x4){0, 0, 0, 0}; }
+                r0x = rkn[0]; r0y = rkn[1]; r0z = rkn[2]; r1x = rkn[3]; r1y = rkn[4]; r1z = rkn[5];
+                rb0 = -(r0x * r0x + r0y * r0y + r0z * r0z) * inv_sigma;
+                rb1 = k1ok ? -(r1x * r1x + r1y * r1y + r1z * r1z) * inv_sigma : -1e30f;   // k >= 24: weight 0
+                issue_rk(j < 3 ? a + 1 : (ag + 1) * 16 + wave * 4);                        // next anchor's kernel points
+            }
+            {
+                constexpr int dummy = 0; (void)dummy;
+                const int nc = cs + PD;
+                if (nc < NCS) issue(ag, nc, ring[nc % NRING]);
+                else if (ag < 3) issue(ag + 1, nc - NCS, ring[nc % NRING]);               // wave-uniform
+            }
+            if (a < NA && t < nchunk) {                     // wave-uniform
+                VecT (&cur)[4] = ring[cs % NRING];
 #pragma unroll
-                for (int t = 0; t < MAXT; ++t) {
-                    if (t < nchunk) {
+                for (int s = 0; s < 4; ++s) {
+                    const float4 g = nbt[16 * t + 4 * fg + s];
+                    const float w0 = fmaxf(0.f, fmaf(g.z, r0z, fmaf(g.y, r0y, fmaf(g.x, r0x, g.w + rb0))));
+                    const float w1 = fmaxf(0.f, fmaf(g.z, r1z, fmaf(g.y, r1y, fmaf(g.x, r1x, g.w + rb1))));
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            const int q = nidx[t][s];
-                            const float w0 = fmaxf(0.f, fmaf(gz[t][s], r0z, fmaf(gy[t][s], r0y, fmaf(gx[t][s], r0x, ga[t][s] + rb0))));
-                            const float w1 = fmaxf(0.f, fmaf(gz[t][s], r1z, fmaf(gy[t][s], r1y, fmaf(gx[t][s], r1x, ga[t][s] + rb1))));
-                            const float* frow = Fb + ((size_t)(q < 0 ? 0 : q) * NA + a) * CIN + fr;
-#pragma unroll
-                            for (int mi = 0; mi < MT1; ++mi) {
-                                const float av = frow[mi * 16];
-                                acc[mi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w0, acc[mi][0], 0, 0, 0);
-                                acc[mi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w1, acc[mi][1], 0, 0, 0);
-                            }
-                        }
+                    for (int mi = 0; mi < MT1; ++mi) {
+                        const float av = cur[s][mi];
+                        acc[mi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w0, acc[mi][0], 0, 0, 0);
+                        acc[mi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w1, acc[mi][1], 0, 0, 0);
                     }
                 }
             }
-            // D[row = 4fg + q][col = fr]: row -> channel c (within the half), col -> kernel point k
-            float* xcol = X1s + col * S;
+            if (t == MAXT - 1) {                            // anchor end
+                // D[row r = 4fg + q][col = fr]: row r of c-tile mi -> channel VEC*r + mi = position cc = r*MTH + mi of the half, col -> kernel point k
+                float* xcol = X1s + col * S;
 #pragma unroll
-            for (int mi = 0; mi < MTH; ++mi)
+                for (int mi = 0; mi < MTH; ++mi)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = mi * 16 + fg * 4 + q;
-                    xcol[c * KS + fr] = acc[mi][0][q];
-                    if (k1ok) xcol[c * KS + 16 + fr] = acc[mi][1][q];
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = (fg * 4 + q) * MTH + mi;
+                        xcol[c * KS + fr] = acc[mi][0][q];
+                        if (k1ok) xcol[c * KS + 16 + fr] = acc[mi][1][q];
+                    }
+                if (HALVES > 1) {
+#pragma unroll
+                    for (int mi = 0; mi < MTH; ++mi) { keep[j][mi][0] = acc[MTH + mi][0]; keep[j][mi][1] = acc[MTH + mi][1]; }
                 }
-            if (HALVES > 1) {
-#pragma unroll
-                for (int mi = 0; mi < MTH; ++mi) { keep[j][mi][0] = acc[MTH + mi][0]; keep[j][mi][1] = acc[MTH + mi][1]; }
             }
         }
         f32x4 y[MT2];
@@ -154,20 +191,37 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
                     for (int mi = 0; mi < MTH; ++mi)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const int c = mi * 16 + fg * 4 + q;
+                            const int c = (fg * 4 + q) * MTH + mi;
                             xcol[c * KS + fr] = keep[j][mi][0][q];
                             if (k1ok) xcol[c * KS + 16 + fr] = keep[j][mi][1][q];
                         }
                 }
             }
             __syncthreads();
-            // ---------------- step 2: K split over the 4 waves (chunk t of 16 kappas -> wave t & 3)
-            for (int t = wave; t < KH / 16; t += 4) {
-                const float4 bv = *reinterpret_cast<const float4*>(&X1s[fr * S + t * 16 + fg * 4]);
-                const int tg = h * (KH / 16) + t;           // chunk index in the full K = c*24 + k order
-                float4 av[MT2];
+            // ---------------- step 2: K split over the 4 waves (chunk t of 16 kappas -> wave t & 3).  The W fragments (L2) and the
+            // X1 fragment (LDS) of iteration i+1 are in flight while the matrix cores work on iteration i.
+            constexpr int NIT = KH / 16 / 4;
+            static_assert(KH % 64 == 0, "K of a half must split evenly over the 4 waves");
+            float4 avn[MT2], bvn;
+            {
+                const int tg = h * (KH / 16) + wave;
 #pragma unroll
-                for (int mt = 0; mt < MT2; ++mt) av[mt] = *reinterpret_cast<const float4*>(&Wp[(((size_t)tg * MT2 + mt) * 64 + lane) * 4]);
+                for (int mt = 0; mt < MT2; ++mt) avn[mt] = *reinterpret_cast<const float4*>(&Wp[(((size_t)tg * MT2 + mt) * 64 + lane) * 4]);
+                bvn = *reinterpret_cast<const float4*>(&X1s[fr * S + wave * 16 + fg * 4]);
+            }
+#pragma unroll 1
+            for (int it = 0; it < NIT; ++it) {              // rolled on purpose: unrolled, every load is hoisted to the top and spills
+                float4 av[MT2];
+                const float4 bv = bvn;
+#pragma unroll
+                for (int mt = 0; mt < MT2; ++mt) av[mt] = avn[mt];
+                if (it + 1 < NIT) {
+                    const int t = wave + 4 * (it + 1);
+                    const int tg = h * (KH / 16) + t;       // chunk index in the kernel's K order
+#pragma unroll
+                    for (int mt = 0; mt < MT2; ++mt) avn[mt] = *reinterpret_cast<const float4*>(&Wp[(((size_t)tg * MT2 + mt) * 64 + lane) * 4]);
+                    bvn = *reinterpret_cast<const float4*>(&X1s[fr * S + t * 16 + fg * 4]);
+                }
                 // k-slice outermost so consecutive MFMAs use different accumulators (40-cycle dependent latency)
 #pragma unroll
                 for (int mt = 0; mt < MT2; ++mt) y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].x, bv.x, y[mt], 0, 0, 0);
@@ -554,12 +608,17 @@ __global__ void __launch_bounds__(256) instnorm_act_add_kernel(long n4, int rows
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
+// gather prefetch distance in chunk-steps (PD + 1 must divide 4 * MAXT): 1 or 3
+#ifndef INTER_PD
+#define INTER_PD(CIN, MAXT) ((MAXT) == 1 ? 1 : ((CIN) >= 64 ? 1 : 3))
+#endif
 template <int CIN, int COUT, int MAXT>
 static int launch_inter_t(int b, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz, const int* idx,
                           const float* feats, const float* rk, const float* Wp, const float* bias, float* out, const int* order,
                           float* stat_part, hipStream_t st) {
-    const size_t lds = (size_t)(16 * (CIN * KS / (CIN >= 32 ? 2 : 1) + 40) + 4 * 16 * (COUT + 4)) * sizeof(float);
-    auto kern = inter_so3conv_kernel<CIN, COUT, MAXT>;
+    const size_t lds = (size_t)(16 * (CIN * KS / (CIN >= 32 ? 2 : 1) + 40) + 4 * 16 * (COUT + 4) + 16 * MAXT * 5) * sizeof(float);
+    constexpr int PD = INTER_PD(CIN, MAXT);
+    auto kern = inter_so3conv_kernel<CIN, COUT, MAXT, PD>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;

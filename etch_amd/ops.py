@@ -152,6 +152,19 @@ def permute_weight_frag(w2):
     return w2.reshape(O // 16, 16, K // 16, 4, 4).permute(2, 0, 3, 1, 4).contiguous().reshape(-1)
 
 
+def inter_weight_frag(W, cin, ks=24):
+    """Fragment-ordered weight of the fused inter conv: the columns of W [cout, cin*ks] are first brought into the kernel's
+    contraction order (csrc/so3conv.hip: a lane gathers VEC = cin/16 consecutive channels per load, so row r of c-tile mi is channel
+    VEC*r + mi; halves h of the X1 tile hold the tiles [h*MTH, (h+1)*MTH)), then permuted into MFMA fragment order."""
+    vec = cin // 16
+    halves = 2 if cin >= 32 else 1
+    mth = vec // halves
+    order = [vec * (cc // mth) + h * mth + cc % mth for h in range(halves) for cc in range(cin // halves)]
+    assert sorted(order) == list(range(cin))
+    cols = torch.tensor([c * ks + k for c in order for k in range(ks)], dtype=torch.long, device=W.device)
+    return permute_weight_frag(W[:, cols].contiguous())
+
+
 # ------------------------------------------------------------------ EPN encoder
 def spatial_order(xyz):
     """xyz (b,3,n) -> (b,n) int32 Morton order of each scan (scheduling hint for inter_so3conv / prop_interp: a permutation of

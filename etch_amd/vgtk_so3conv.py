@@ -134,7 +134,7 @@ class InterSO3Conv(nn.Module):
             # rotated kernel points exactly as functional.py:296 (CPU matmul, then uploaded)
             rk = torch.matmul(self.anchors.cpu(), self.kernels.cpu().transpose(0, 1)).permute(0, 2, 1).contiguous()  # [60, 24, 3]
             Wd = W.detach().contiguous()
-            Wp = ops.permute_weight_frag(Wd) if self.dim_in % 16 == 0 else None
+            Wp = ops.inter_weight_frag(Wd, self.dim_in, self.kernel_size) if self.dim_in % 16 == 0 else None
             return rk.to(W.device), Wd, Wp, bias.detach().reshape(-1).contiguous()
 
         return self._d.get((W, bias, self.anchors, self.kernels), build)
