@@ -5,7 +5,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libetch_hip.so")
+LIB_PATH = os.environ.get("ETCH_HIP_LIB") or os.path.join(_HERE, "lib", "libetch_hip.so")   # override: kernel-variant experiments only
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "etch_hip.h")
 _lib = None
 

@@ -198,31 +198,14 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
                 }
             }
             __syncthreads();
-            // ---------------- step 2: K split over the 4 waves (chunk t of 16 kappas -> wave t & 3).  The W fragments (L2) and the
-            // X1 fragment (LDS) of iteration i+1 are in flight while the matrix cores work on iteration i.
-            constexpr int NIT = KH / 16 / 4;
-            static_assert(KH % 64 == 0, "K of a half must split evenly over the 4 waves");
-            float4 avn[MT2], bvn;
-            {
-                const int tg = h * (KH / 16) + wave;
-#pragma unroll
-                for (int mt = 0; mt < MT2; ++mt) avn[mt] = *reinterpret_cast<const float4*>(&Wp[(((size_t)tg * MT2 + mt) * 64 + lane) * 4]);
-                bvn = *reinterpret_cast<const float4*>(&X1s[fr * S + wave * 16 + fg * 4]);
-            }
-#pragma unroll 1
-            for (int it = 0; it < NIT; ++it) {              // rolled on purpose: unrolled, every load is hoisted to the top and spills
+            // ---------------- step 2: K split over the 4 waves (chunk t of 16 kappas -> wave t & 3).  (An explicitly double-buffered form of
+            // this loop measured 5 % slower: profiles/r02_inter_conv_experiments.txt.)
+            for (int t = wave; t < KH / 16; t += 4) {
+                const float4 bv = *reinterpret_cast<const float4*>(&X1s[fr * S + t * 16 + fg * 4]);
+                const int tg = h * (KH / 16) + t;           // chunk index in the full K = c*24 + k order
                 float4 av[MT2];
-                const float4 bv = bvn;
 #pragma unroll
-                for (int mt = 0; mt < MT2; ++mt) av[mt] = avn[mt];
-                if (it + 1 < NIT) {
-                    const int t = wave + 4 * (it + 1);
-                    const int tg = h * (KH / 16) + t;       // chunk index in the kernel's K order
-#pragma unroll
-                    for (int mt = 0; mt < MT2; ++mt) avn[mt] = *reinterpret_cast<const float4*>(&Wp[(((size_t)tg * MT2 + mt) * 64 + lane) * 4]);
-                    bvn = *reinterpret_cast<const float4*>(&X1s[fr * S + t * 16 + fg * 4]);
-                }
-                // k-slice outermost so consecutive MFMAs use different accumulators (40-cycle dependent latency)
+                for (int mt = 0; mt < MT2; ++mt) av[mt] = *reinterpret_cast<const float4*>(&Wp[(((size_t)tg * MT2 + mt) * 64 + lane) * 4]);
 #pragma unroll
                 for (int mt = 0; mt < MT2; ++mt) y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].x, bv.x, y[mt], 0, 0, 0);
 #pragma unroll
@@ -608,10 +591,8 @@ __global__ void __launch_bounds__(256) instnorm_act_add_kernel(long n4, int rows
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
-// gather prefetch distance in chunk-steps (PD + 1 must divide 4 * MAXT): 1 or 3
-#ifndef INTER_PD
-#define INTER_PD(CIN, MAXT) ((MAXT) == 1 ? 1 : ((CIN) >= 64 ? 1 : 3))
-#endif
+// gather prefetch distance in chunk-steps (PD + 1 must divide 4 * MAXT: 1 or 3; 3 measured 3-8 % slower: more registers, fewer waves)
+#define INTER_PD(CIN, MAXT) 1
 template <int CIN, int COUT, int MAXT>
 static int launch_inter_t(int b, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz, const int* idx,
                           const float* feats, const float* rk, const float* Wp, const float* bias, float* out, const int* order,
