@@ -382,6 +382,7 @@ __global__ void __launch_bounds__(KNNW_WAVES * 64) knn_wave_kernel(int nsample, 
         float bd = 1e10f;                             // lane l < k: l-th smallest distance so far (heap initialisation: (1e10, start))
         int bi = start;
         float top = 1e10f;
+        bool ambiguous = false;                       // wave-uniform: an eviction happened while two DIFFERENT points tied for the maximum
         for (int k0 = start; k0 < end; k0 += 64) {
             const int k = k0 + lane;
             float d2 = 3e38f;
@@ -392,6 +393,13 @@ __global__ void __launch_bounds__(KNNW_WAVES * 64) knn_wave_kernel(int nsample, 
                 mask &= mask - 1ull;
                 const float cd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), e));
                 if (cd < top) {                                              // re-test: the maximum shrinks as candidates go in
+                    if (nsample > 1) {
+                        // the sorted list evicts its LAST entry; the reference's reheap evicts the heap root.  They are the same point
+                        // unless two different points tie for the maximum -- then which one survives depends on the heap's shape, and
+                        // the survivor may be the only trace left at the end: remember it and redo the query literally.
+                        const float t2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bd), nsample - 2));
+                        if (t2 == top && __builtin_amdgcn_readlane(bi, nsample - 1) != __builtin_amdgcn_readlane(bi, nsample - 2)) ambiguous = true;
+                    }
                     const int pos = __popcll(__ballot(lane < nsample && bd <= cd));      // sorted list: a prefix
                     const float pd = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bd), 0x111, 0xf, 0xf, true));   // row_shr:1
                     const int pi = __builtin_amdgcn_update_dpp(0, bi, 0x111, 0xf, 0xf, true);
@@ -405,7 +413,7 @@ __global__ void __launch_bounds__(KNNW_WAVES * 64) knn_wave_kernel(int nsample, 
         const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bd), 0x111, 0xf, 0xf, true));
         const int previ = __builtin_amdgcn_update_dpp(0, bi, 0x111, 0xf, 0xf, true);
         const bool tie = lane > 0 && lane < nsample && bd == prev && bi != previ;
-        if (__ballot(tie) != 0ull) {
+        if (ambiguous || __ballot(tie) != 0ull) {
             knn_literal_query(q, start, end, nsample, lane, xyz, new_xyz, hd, hi, cand_d, cand_i, idx, dist2, write_sqrt);
             continue;
         }
@@ -499,8 +507,8 @@ int etch_gather_points_backward(int b, int c, int n, int m, const float* grad_ou
 int etch_knnquery(int b, int m_max, int m_total, int nsample, const float* xyz, const float* new_xyz, const int* offset,
                   const int* new_offset, int* idx, float* dist, int write_sqrt, void* stream) {
     if (b <= 0 || m_max <= 0) return ETCH_OK;
-    if (nsample <= 0 || nsample > 28) return ETCH_EUNSUPPORTED;  // heap columns must fit 64 KiB of LDS
-    if (m_total > 0) {            // wave-per-query kernel
+    if (nsample <= 0) return ETCH_EINVAL;
+    if (m_total > 0) {            // wave-per-query kernel: nsample <= 16 on the register list, up to the reference's 100 (knnquery_cuda_kernel.cu:86-87) on the LDS heap
         if (nsample > 100) return ETCH_EUNSUPPORTED;
         const size_t lds = (size_t)(KNNW_WAVES * 2 * nsample + KNNW_WAVES * 128) * 4;
         long blocks = ((long)m_total + KNNW_WAVES - 1) / KNNW_WAVES;
@@ -510,6 +518,7 @@ int etch_knnquery(int b, int m_max, int m_total, int nsample, const float* xyz, 
         ETCH_RETURN_IF_LAUNCH_FAILED();
         return ETCH_OK;
     }
+    if (nsample > 28) return ETCH_EUNSUPPORTED;  // thread-per-query form: heap columns must fit 64 KiB of LDS
     const size_t lds = (size_t)(3 * KNN_TILE + 2 * nsample * KNN_THREADS) * 4;
     hipLaunchKernelGGL(knn_kernel, dim3((m_max + KNN_THREADS - 1) / KNN_THREADS, b), dim3(KNN_THREADS), lds,
                        (hipStream_t)stream, nsample, xyz, new_xyz, offset, new_offset, idx, dist, write_sqrt);

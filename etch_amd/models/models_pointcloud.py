@@ -17,6 +17,9 @@ from .pointtransformer_seg import get_pointtransformer_confidence, get_pointtran
 from .so3net import build_model
 
 
+SUPPORTED_EPN_LAYER_NUMS = frozenset({2})
+
+
 class GT_network_equiv(nn.Module):
     def __init__(self, option=None):
         super().__init__()
@@ -28,6 +31,13 @@ class GT_network_equiv(nn.Module):
         strides_layers = [2, 2, 2, 2]
         self.standard_vector = torch.tensor([0, 0, 1], dtype=torch.float32, requires_grad=False)
         EPN_layer_n = option.EPN_layer_num
+        if EPN_layer_n not in SUPPORTED_EPN_LAYER_NUMS:
+            # the reference accepts 1..4 (models_pointcloud.py:34-48: feature widths 32 / 64 / 128 / 256); the HIP kernels are built for
+            # the released configuration only: conv channel pairs up to (64, 64), 64-wide 8-head attention over the 60 anchor tokens
+            raise NotImplementedError(
+                f"EPN_layer_num={EPN_layer_n} is not built: etch_amd instantiates the fused SO(3) convolutions and the attention head for "
+                f"EPN_layer_num in {sorted(SUPPORTED_EPN_LAYER_NUMS)} (the ETCH release and every published checkpoint use 2); "
+                "see INTEGRATION.md, 'Limits'")
         EPN_feat_dim = mlp_layers[EPN_layer_n - 1][0]
         os.makedirs(option.output_folder, exist_ok=True)
         self.encoder = build_model(EPN_cfg, mlps=mlp_layers[:EPN_layer_n], strides=strides_layers[:EPN_layer_n], to_file=model_setting_file)

@@ -154,3 +154,45 @@ def test_gather_points_backward_bit_exact(b, c, n, m, dup):
         x = torch.zeros(b, c, n, dtype=torch.float64, requires_grad=True)
         torch.gather(x, 2, torch.from_numpy(idx).long()[:, None, :].expand(b, c, m)).backward(torch.from_numpy(g).double())
         assert np.abs(got.cpu().numpy() - x.grad.numpy()).max() < 1e-5
+
+
+def test_knn_eviction_tie_straddling_the_kth_rank():
+    """Two DIFFERENT support points exactly tied at the current k-th distance when a closer candidate arrives: the reference's reheap
+    evicts whichever of them sits at the heap root, the register list its last entry.  If only one of the two survives to the end no
+    tie is visible in the final list any more -- the kernel has to notice the ambiguous eviction when it happens (and redo the query
+    with the literal heap).  Constructed cases + a random lattice sweep where such evictions are frequent."""
+    from etch_amd import ops
+    # query at the origin; k = 3.  Support in index order: a (d=4), b and c (both d=9, different points), then closer points arrive.
+    base = np.array([[2, 0, 0], [3, 0, 0], [0, 3, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1.5], [0, 0, 0.5]], np.float32)
+    for perm in ([0, 1, 2, 3, 4, 5, 6], [1, 2, 0, 3, 4, 5, 6], [2, 1, 0, 6, 5, 4, 3], [1, 0, 2, 5, 3, 6, 4]):
+        p = base[perm]
+        q = np.zeros((1, 3), np.float32)
+        o, qo = np.array([len(p)], np.int32), np.array([1], np.int32)
+        for k in (2, 3, 4, 5):
+            ri, rd2 = O.knnquery(k, p, q, o, qo)
+            idx, dist = ops.knnquery(k, dev(p), dev(q), dev(o), dev(qo), sqrt=False)
+            assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(dist.cpu().numpy(), rd2), (perm, k)
+    rng = np.random.default_rng(9)
+    for trial in range(6):
+        p = rng.integers(-3, 4, (700, 3)).astype(np.float32) * 0.25          # coarse lattice: ties everywhere, incl. at the k-th rank
+        p = p[rng.permutation(len(p))]
+        o = np.array([300, 700], np.int32)
+        for k in (2, 5, 8, 16):
+            ri, rd2 = O.knnquery(k, p, p, o, o)
+            idx, dist = ops.knnquery(k, dev(p), dev(p), dev(o), dev(o), sqrt=False)
+            assert np.array_equal(idx.cpu().numpy(), ri), (trial, k)
+            assert np.array_equal(dist.cpu().numpy(), rd2), (trial, k)
+
+
+@pytest.mark.parametrize("k", [17, 32, 64, 100])
+def test_knn_large_nsample_up_to_the_reference_limit(k):
+    """nsample up to 100, the capacity of the reference kernel's heap arrays (knnquery_cuda_kernel.cu:86-87): the literal LDS-heap scan."""
+    from etch_amd import ops
+    segs = [400, 150]
+    p = np.concatenate([scan(3100 + i, n) for i, n in enumerate(segs)])
+    o = np.cumsum(segs).astype(np.int32)
+    q = np.concatenate([scan(4100 + i, n) for i, n in enumerate([37, 21])])
+    qo = np.array([37, 58], np.int32)
+    ri, rd2 = O.knnquery(k, p, q, o, qo)
+    idx, dist = ops.knnquery(k, dev(p), dev(q), dev(o), dev(qo), sqrt=False)
+    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(dist.cpu().numpy(), rd2)

@@ -255,3 +255,24 @@ def test_bench_gpus2_self_launch_on_one_gpu():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["launcher"] == "self"
     assert out["gathered_rows"]["scans_reported"] == 4 and out["roofline"]["kernel"]
     assert "cpu_baseline" not in out                      # rank 0 at N = 1 only
+
+
+def test_evaluate_dataset_on_the_reference_folder_layout(tmp_path):
+    """eval.py's loop on a dataset folder in the reference's layout: every activated id evaluated once, per-sample outputs written,
+    v2v_score.txt closed by the reference's summary block, V2V consistent with the written body."""
+    from test_host_logic import make_eval_tree
+    from etch_amd import eval as E
+    from etch_amd import inference_demo as D
+    from etch_amd.utils.body_model import SyntheticSMPL
+    args, model = make(tmp_path / "m")
+    args.body_model = {"male": SyntheticSMPL(7), "female": SyntheticSMPL(8)}
+    args.output_folder = str(tmp_path / "out")
+    scan_dir, smpl_dir, info_dir, ids_pkl = make_eval_tree(tmp_path)
+    ds = E.EvalDataset(scan_dir, smpl_dir, info_dir, None, num_point=700, seed=0)
+    recs, avg = E.evaluate_dataset(args, model, ds, batch_size=2)
+    assert [r["id"] for r in recs] == ["id_a", "id_b", "id_c"]
+    assert avg == pytest.approx(np.mean([r["v2v"] for r in recs]))
+    lines = open(tmp_path / "out" / "v2v_score.txt").read().splitlines()
+    assert lines[3] == "==========" and lines[4].startswith("average v2v: ") and lines[6] == "sample num: 3"
+    body = D.load_obj(str(tmp_path / "out" / "id_b" / "forwarded_smpl_mesh_on_pred_id_b.obj"))
+    assert abs(E.v2v(ds[1]["gt_vertices"], body.vertices) - recs[1]["v2v"]) < 1e-5

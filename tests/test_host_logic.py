@@ -148,3 +148,64 @@ def test_reference_operator_names_are_exported():
     assert V.functional.get_anchors(60).shape == (60, 3, 3) and V.functional.get_intra_idx().shape == (60, 12)
     kp = V.functional.get_sphereical_kernel_points_from_ply(0.7 * 0.2, 1)
     assert kp.shape == (24, 3) and abs(float(np.sqrt((kp ** 2).sum(1).max())) - 0.14) < 1e-6
+
+
+def test_unsupported_encoder_depth_is_rejected_up_front(tmp_path):
+    """The reference builds EPN_layer_num 1..4 (models_pointcloud.py:34-48); this build instantiates depth 2 (the released
+    configuration).  Other depths must fail at construction with a message that says so -- not with a bare assert deep inside."""
+    import types
+
+    import pytest
+
+    from etch_amd import constants as K
+    from etch_amd import inference_demo as D
+    from etch_amd.models.models_pointcloud import GT_network_equiv
+    for n in (1, 3, 4):
+        opt = types.SimpleNamespace(output_folder=str(tmp_path), EPN_input_radius=0.4, EPN_layer_num=n, device="cpu", markerset=K.default_markerset())
+        with pytest.raises(NotImplementedError, match="EPN_layer_num"):
+            GT_network_equiv(option=opt)
+    with pytest.raises(SystemExit):
+        D.main(["--scan_path", "x.obj", "--EPN_layer_num", "3"])
+
+
+def _write_obj(path, v, f):
+    with open(path, "w") as fh:
+        for p in v:
+            fh.write(f"v {p[0]} {p[1]} {p[2]}\n")
+        for t in f:
+            fh.write(f"f {t[0] + 1} {t[1] + 1} {t[2] + 1}\n")
+
+
+def make_eval_tree(root, ids=("id_b", "id_a", "id_c"), V=6890):
+    """A dataset folder in the reference's layout (README.md:74-90) with synthetic content."""
+    import pickle
+    rng = np.random.default_rng(0)
+    scan_dir, smpl_dir, info_dir = root / "ds" / "model", root / "ds" / "smplh", root / "gt" / "npz"
+    info_dir.mkdir(parents=True)
+    for k, i in enumerate(ids):
+        (scan_dir / i).mkdir(parents=True)
+        (smpl_dir / i).mkdir(parents=True)
+        v = (rng.standard_normal((400, 3)) * np.array([0.14, 0.31, 0.085])).astype(np.float32)
+        _write_obj(scan_dir / i / f"{i}.obj", v, np.stack([np.arange(0, 398), np.arange(1, 399), np.arange(2, 400)], 1))
+        sv = rng.standard_normal((V, 3)).astype(np.float32)
+        _write_obj(smpl_dir / i / f"mesh_smpl_{i}.obj", sv, [[0, 1, 2]])
+        np.savez(smpl_dir / i / f"info_{i}.npz", gender=np.array([k % 2], np.int32), joints=rng.standard_normal((73, 3)).astype(np.float32),
+                 betas=np.zeros(10, np.float32))
+        np.savez(info_dir / f"{i}.npz", info_points=np.zeros((4, 3)), info_vectors=np.zeros((4, 3)))
+    (scan_dir / "not_in_smpl").mkdir()                     # no body model -> skipped (GT_dataloader_mixed.py:120-127)
+    ids_pkl = root / "val_ids.pkl"
+    with open(ids_pkl, "wb") as f:
+        pickle.dump(list(ids[:2]) + ["absent"], f)         # id_c is not activated
+    return str(scan_dir), str(smpl_dir), str(info_dir), str(ids_pkl)
+
+
+def test_eval_dataset_reads_the_reference_layout(tmp_path):
+    from etch_amd.eval import EvalDataset
+    scan_dir, smpl_dir, info_dir, ids_pkl = make_eval_tree(tmp_path)
+    ds = EvalDataset(scan_dir, smpl_dir, info_dir, ids_pkl, num_point=300, seed=3)
+    assert ds.id_list == ["id_a", "id_b"]                  # sorted, activated, complete entries only
+    a, b = ds[0], ds[1]
+    assert a["id"] == "id_a" and a["gender"] == "male" and b["gender"] == "female"     # gender 1 -> male (:133)
+    assert a["hitpts"].shape == (300, 3) and a["hitpts"].dtype == np.float32 and a["gt_vertices"].shape == (6890, 3) and a["gt_joints"].shape == (73, 3)
+    assert np.array_equal(ds[0]["hitpts"], a["hitpts"])    # seeded: reproducible
+    assert len(EvalDataset(scan_dir, smpl_dir, info_dir)) == 3
