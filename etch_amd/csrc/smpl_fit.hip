@@ -196,9 +196,10 @@ __device__ void lm_setup(LmShared<BM>& s, const SmplConsts& C, int M, const floa
 
 // residual + normal equations at s.x.  nb = number of active betas (2 in stage 0, NB in stage 1).  On return s.A holds the packed
 // lower triangle of J^T J (no damping yet) with the right-hand side -J^T r as row DOF, s.resid / s.err the residual and 0.5 |r|^2.
-// jac_out (diagnostics): the marker rows of J (3M x DOF) are also written to global memory.
+// jac_out (diagnostics): the marker rows of J (3M x DOF) are also written to global memory.  grad_only (first-order fitter): only the
+// tile row that holds -J^T r is accumulated; the J^T J entries of s.A are then undefined.
 template <class BM>
-__device__ void lm_linearize(LmShared<BM>& s, const SmplConsts& C, int M, int nb, float* __restrict__ jac_out) {
+__device__ void lm_linearize(LmShared<BM>& s, const SmplConsts& C, int M, int nb, float* __restrict__ jac_out, bool grad_only = false) {
     constexpr int NJ = BM::NJ, NB = BM::NB, NPOSE = BM::NPOSE, NPF = BM::NPF, DOF = BM::DOF, LDJ = BM::LDJ, LDJS = BM::LDJS;
     LmLin<BM>& L = s.lin;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile indices stay in SGPRs
@@ -424,7 +425,7 @@ __device__ void lm_linearize(LmShared<BM>& s, const SmplConsts& C, int M, int nb
             const int fr = lane & 15, fg = lane >> 4;
 #pragma unroll
             for (int t = 0; t < BM::TPW; ++t) {
-                if (wave + BM::WAVES * t < BM::NTILES) {
+                if (wave + BM::WAVES * t < BM::NTILES && (!grad_only || tmi[t] == BM::NT - 1)) {
                     const float* pa = Jb + fg * LDJS + 16 * tmi[t] + fr;
                     const float* pb = Jb + fg * LDJS + 16 * tnj[t] + fr;
                     float av[BM::CHUNK_ROWS / 4], bv[BM::CHUNK_ROWS / 4];
@@ -588,6 +589,66 @@ __global__ void __launch_bounds__(BM::THREADS) smpl_lm_fit_kernel(SmplConsts C, 
     }
     for (int i = tid; i < DOF; i += BM::THREADS) x_out[(size_t)b * DOF + i] = (float)s.x[i];
     if (phase_out && tid < 8) phase_out[(size_t)b * 8 + tid] = s.phase[tid];
+}
+
+
+// ---------------------------------------------------------------------------------------------- first-order fitter
+// fit_smpl of /root/reference/src/models/fit_SMPL_Adam.py:68-225: torch.optim.Adam (betas 0.9 / 0.999, eps 1e-8, bias-corrected) on
+// L = mse_loss(markers(x)[valid], target[valid]) -- the mean over ALL valid marker coordinates of the WHOLE batch (:142, :199), so
+// the only coupling between scans is the common factor 1 / n_valid_total.  Stage 0: it0 steps on pose, betas[:2], orient, transl
+// (:104-120); stage 1: it1 steps with a FRESH optimizer state on all betas (:166-183).  grad L = (2 / n) J^T r comes out of the same
+// marker-restricted linearisation as the LM fit (last tile row of the matrix-core accumulation) instead of autograd through the
+// full mesh.  x_last = parameters of the LAST forward pass, i.e. before the final optimizer step: the reference builds its output
+// meshes from that forward (:221-225).
+template <class BM>
+__global__ void __launch_bounds__(BM::THREADS) smpl_adam_fit_kernel(SmplConsts C, int M, int B, const float* __restrict__ markers,
+                                                                  const float* __restrict__ valid, int it0, int it1, float lr, float beta1,
+                                                                  float beta2, float eps, float* __restrict__ x_out, float* __restrict__ x_last,
+                                                                  float* __restrict__ loss_trace) {
+    constexpr int DOF = BM::DOF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lm_smem[];
+    LmShared<BM>& s = *reinterpret_cast<LmShared<BM>*>(lm_smem);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < DOF; i += BM::THREADS) s.x[i] = 0.0;
+    lm_setup(s, C, M, markers + (size_t)b * M * 3, valid + (size_t)b * M);
+    // n = number of valid marker coordinates of the whole batch (every workgroup counts them: B * M flags)
+    if (tid < 64) {
+        float cnt = 0.f;
+        for (int i = tid; i < B * M; i += 64) cnt += valid[i] != 0.f ? 3.f : 0.f;
+        cnt = etch_wave_sum_f32(cnt);
+        if (tid == 0) s.rpiv = (double)cnt;
+    }
+    __syncthreads();
+    const double ninv = s.rpiv > 0.0 ? 1.0 / s.rpiv : 0.0;
+    double* mom = s.delta;               // first / second moment estimates (the LM solve's vectors are free here)
+    double* var = s.rdiag;
+    int trace_pos = 0;
+    for (int stage = 0; stage < 2; ++stage) {
+        const int iters = stage == 0 ? it0 : it1;
+        const int nb = stage == 0 ? (BM::NB < NB_STAGE0 ? BM::NB : NB_STAGE0) : BM::NB;
+        for (int i = tid; i < DOF; i += BM::THREADS) { mom[i] = 0.0; var[i] = 0.0; }     // a fresh torch.optim.Adam per stage
+        __syncthreads();
+        double b1t = 1.0, b2t = 1.0;
+        for (int it = 0; it < iters; ++it) {
+            if (stage == 1 && it == iters - 1 && x_last)
+                for (int i = tid; i < DOF; i += BM::THREADS) x_last[(size_t)b * DOF + i] = (float)s.x[i];
+            lm_linearize(s, C, M, nb, nullptr, true);
+            if (loss_trace && tid == 0) loss_trace[(size_t)b * (it0 + it1) + trace_pos] = (float)(2.0 * s.err * ninv);   // this scan's share of L
+            ++trace_pos;
+            b1t *= (double)beta1; b2t *= (double)beta2;
+            for (int i = tid; i < DOF; i += BM::THREADS) {
+                const double g = -2.0 * ninv * Apk(s.A, DOF, i);           // row DOF of the packed matrix holds -J^T r
+                const double m1 = (double)beta1 * mom[i] + (1.0 - (double)beta1) * g;
+                const double v1 = (double)beta2 * var[i] + (1.0 - (double)beta2) * g * g;
+                mom[i] = m1; var[i] = v1;
+                s.x[i] -= ((double)lr / (1.0 - b1t)) * m1 / (sqrt(v1) / sqrt(1.0 - b2t) + (double)eps);
+            }
+            __syncthreads();
+        }
+    }
+    if (it1 == 0 && x_last)
+        for (int i = tid; i < DOF; i += BM::THREADS) x_last[(size_t)b * DOF + i] = (float)s.x[i];
+    for (int i = tid; i < DOF; i += BM::THREADS) x_out[(size_t)b * DOF + i] = (float)s.x[i];
 }
 
 // ---------------------------------------------------------------------------------------------- diagnostics (tests)
@@ -836,6 +897,18 @@ static int launch_lm_linearize(int B, int M, int nb, const void* const* consts, 
     return ETCH_OK;
 }
 
+template <class BM>
+static int launch_adam_fit(int B, int M, const void* const* consts, const float* markers, const float* valid, int it0, int it1, float lr,
+                           float beta1, float beta2, float eps, float* x_out, float* x_last, float* loss_trace, hipStream_t st) {
+    const int lds = (int)sizeof(LmShared<BM>);
+    hipError_t e = hipFuncSetAttribute((const void*)smpl_adam_fit_kernel<BM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(smpl_adam_fit_kernel<BM>, dim3(B), dim3(BM::THREADS), lds, st, lm_consts(consts), M, B, markers, valid, it0, it1, lr, beta1,
+                       beta2, eps, x_out, x_last, loss_trace);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
 extern "C" {
 
 int etch_inner_points(long n, const float* pts, const float* dir, const float* mag, float scale, float* out, void* stream) {
@@ -887,6 +960,17 @@ int etch_smpl_lm_fit(int B, int M, int nj, int nb, const void* const* consts, co
         return launch_lm_fit<BodySMPL>(B, M, consts, markers, valid, it0, step0, damp0, it1, step1, damp1, x_out, x_stage0, err_trace, phase_ticks, (hipStream_t)stream);
     if (nj == 55 && nb == 20)
         return launch_lm_fit<BodySMPLX>(B, M, consts, markers, valid, it0, step0, damp0, it1, step1, damp1, x_out, x_stage0, err_trace, phase_ticks, (hipStream_t)stream);
+    return ETCH_EUNSUPPORTED;
+}
+
+int etch_smpl_adam_fit(int B, int M, int nj, int nb, const void* const* consts, const float* markers, const float* valid, int it0, int it1,
+                       float lr, float beta1, float beta2, float eps, float* x_out, float* x_last, float* loss_trace, void* stream) {
+    if (B <= 0) return ETCH_OK;
+    if (M <= 0 || M > LM_MAXM) return ETCH_EUNSUPPORTED;
+    if (nj == 24 && nb == 10)
+        return launch_adam_fit<BodySMPL>(B, M, consts, markers, valid, it0, it1, lr, beta1, beta2, eps, x_out, x_last, loss_trace, (hipStream_t)stream);
+    if (nj == 55 && nb == 20)
+        return launch_adam_fit<BodySMPLX>(B, M, consts, markers, valid, it0, it1, lr, beta1, beta2, eps, x_out, x_last, loss_trace, (hipStream_t)stream);
     return ETCH_EUNSUPPORTED;
 }
 

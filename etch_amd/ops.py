@@ -474,6 +474,20 @@ def smpl_lm_fit(consts, markers, valid_f, it0, step0, damp0, it1, step1, damp1, 
     return x, x0, tr
 
 
+def smpl_adam_fit(consts, markers, valid_f, it0, it1, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-8, want_trace=False, nj=24, nb=10):
+    """First-order fitter (fit_SMPL_Adam.py): -> x (B,DOF), x_last (parameters of the last forward pass), loss trace (B, it0+it1) or None."""
+    B, M = valid_f.shape
+    dof = 3 * nj + nb + 3
+    arr = (ctypes.c_void_p * 7)(*[t.data_ptr() for t in consts])
+    x = torch.empty((B, dof), dtype=torch.float32, device=markers.device)
+    xl = torch.empty((B, dof), dtype=torch.float32, device=markers.device)
+    tr = torch.zeros((B, it0 + it1), dtype=torch.float32, device=markers.device) if want_trace else None
+    _lib.check(_lib.lib().etch_smpl_adam_fit(B, M, int(nj), int(nb), arr, _ptr(markers), _ptr(valid_f), int(it0), int(it1), _c_float(lr),
+                                             _c_float(beta1), _c_float(beta2), _c_float(eps), _ptr(x), _ptr(xl), _optptr(tr), _stream()),
+               "etch_smpl_adam_fit")
+    return x, xl, tr
+
+
 def marker_status(markers, valid_f):
     """(B,) int32: bit 0 = a valid marker is non-finite (the fit of that scan is NaN, as in the reference), bit 1 = no valid marker."""
     B, M = valid_f.shape

@@ -280,6 +280,14 @@ int etch_smpl_lm_fit(int B, int M, int nj, int nb, const void* const* consts, co
 /* LDS bytes one scan's fit holds for its whole duration (one workgroup per scan); ETCH_EUNSUPPORTED for unknown (nj, nb). */
 int etch_smpl_lm_workspace_bytes(int nj, int nb);
 
+/* fit_smpl of the first-order variant (src/models/fit_SMPL_Adam.py:68-225): torch.optim.Adam semantics (bias-corrected, betas / eps as
+ * given; the reference uses the defaults 0.9 / 0.999 / 1e-8 and lr 1e-2) on the batch-mean squared marker error over the valid marker
+ * coordinates; it0 steps on betas[:2] (:104-160), then it1 steps with a fresh optimizer state on all betas (:166-218).  Same consts /
+ * markers / valid / x layout as etch_smpl_lm_fit.  x_last (optional) = the parameters of the last forward pass (before the final
+ * step): the reference builds its output meshes from that forward.  loss_trace (B, it0+it1, optional): this scan's share of L. */
+int etch_smpl_adam_fit(int B, int M, int nj, int nb, const void* const* consts, const float* markers, const float* valid, int it0, int it1,
+                       float lr, float beta1, float beta2, float eps, float* x_out, float* x_last, float* loss_trace, void* stream);
+
 /* Diagnostics of the LM kernel (tests): ONE linearisation at a caller-given x (B,DOF) with nb_active betas -> residual
  * (B,3M) = mask * (target - markers(x)) (fit_SMPL.py:127-131), the analytic Jacobian d resid / d x (B,3M,DOF) the fit uses in place
  * of the reference's autograd Jacobian (AutoDiffCostFunction, fit_SMPL.py:176-183, 227-234), and (optional) the normal equations

@@ -153,3 +153,39 @@ def fit_smpl(bm, marker_vids, markers, valid, steps_stage0=30, steps_stage1=50, 
         pose, betas, orient, transl = x1[:, :npose], x1[:, npose:npose + nbt], x1[:, npose + nbt:npose + nbt + 3], x1[:, npose + nbt + 3:]
         v, j = smpl_forward(tb, betas, pose, orient, transl)
         return dict(pose=pose, betas=betas, orient=orient, transl=transl, verts=v, joints=j, x_stage0=x0)
+
+
+def fit_smpl_adam(bm, marker_vids, markers, valid, steps_stage0=400, steps_stage1=800, lr=1e-2, trace=None, dtype=torch.float32):
+    """src/models/fit_SMPL_Adam.py:68-225 after get_markers, restated literally: torch.optim.Adam on
+    mse_loss(markers(x)[valid], target[valid]) (mean over the valid coordinates of the whole batch), autograd through the full-mesh
+    LBS; stage 0 on betas[:2], stage 1 with a fresh optimizer on all betas.  `verts` are those of the LAST forward pass (the
+    parameters before the final step), as the reference returns them (:221-225)."""
+    tb = TorchBody(bm, dtype)
+    mv = torch.as_tensor(np.asarray(marker_vids)).long()
+    B = markers.shape[0]
+    npose, nbt = 3 * (tb.J - 1), tb.S.shape[2]
+    markers = markers.to(dtype)
+    pose = torch.nn.Parameter(torch.zeros(B, npose, dtype=dtype))
+    shape_opt = torch.nn.Parameter(torch.zeros(B, 2, dtype=dtype))
+    shape_frozen = torch.zeros(B, nbt - 2, dtype=dtype)
+    orient = torch.nn.Parameter(torch.zeros(B, 3, dtype=dtype))
+    transl = torch.nn.Parameter(torch.zeros(B, 3, dtype=dtype))
+
+    def run(params, betas_fn, steps):
+        opt = torch.optim.Adam(params, lr=lr)
+        verts = None
+        for _ in range(steps):
+            opt.zero_grad()
+            verts, _ = lbs(tb, betas_fn(), torch.cat([orient, pose], 1), transl)
+            loss = torch.nn.functional.mse_loss(verts[:, mv][valid], markers[valid])
+            if trace is not None:
+                trace.append(float(loss.detach()))
+            loss.backward()
+            opt.step()
+        return verts
+
+    verts = run([shape_opt, orient, pose, transl], lambda: torch.cat([shape_opt, shape_frozen], 1), steps_stage0)
+    shape = torch.nn.Parameter(torch.cat([shape_opt, shape_frozen], 1).detach())
+    v1 = run([shape, orient, pose, transl], lambda: shape, steps_stage1)
+    verts = v1 if v1 is not None else verts
+    return dict(pose=pose.detach(), betas=shape.detach(), orient=orient.detach(), transl=transl.detach(), verts=None if verts is None else verts.detach())

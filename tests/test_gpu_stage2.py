@@ -262,3 +262,37 @@ def test_marker_status_flags_nan_and_empty_scans():
                                                  return_trace=True)
     assert aux["status"].cpu().tolist() == [0, 1, 2]
     assert np.isfinite(info[0][0]).all() and np.isnan(info[0][1]).any() and np.isfinite(info[0][2]).all()
+
+
+@pytest.mark.parametrize("model,it0,it1", [("smpl", 60, 90), ("smplx", 12, 18)])
+def test_adam_fitter_vs_oracle(model, it0, it1):
+    """The first-order fitter (src/models/fit_SMPL_Adam.py:68-225) against its literal restatement -- torch.optim.Adam
+    with autograd through the full-mesh LBS -- on a shortened schedule: loss per step, parameters after the last step, and the
+    vertices of the last forward pass (what the reference returns).  The loss couples the scans of a batch through its mean."""
+    from etch_amd.models import fit_SMPL_Adam as FA
+    from oracle import stage2 as S2
+    B = 3
+    bm, ms, mv, tgt, valid, vgt = _problem(B, seed=4, model=model)
+    tr = []
+    ref = S2.fit_smpl_adam(bm, mv, tgt, valid, steps_stage0=it0, steps_stage1=it1, lr=1e-2, trace=tr)
+    pts = tgt.clone()
+    labels = torch.arange(86).repeat(B, 1)
+    for b in range(B):
+        labels[b, (~valid[b]).nonzero().flatten()] = int(valid[b].nonzero()[0])
+    conf = torch.ones(B, 86, 1)
+    conf[~valid] = 1e-3
+    args = types.SimpleNamespace(markerset=ms, device=torch.device("cuda"), body_model=bm)
+    meshes, markers, vmask, aux = FA.fit_smpl(args, pts.cuda(), labels.cuda(), conf.cuda(), steps_stage0=it0, steps_stage1=it1, lr=1e-2, return_aux=True)
+    assert np.array_equal(vmask.cpu().numpy(), valid.numpy()) and len(meshes) == B
+    loss = aux["loss_trace"].cpu().numpy().sum(0)                                  # per-scan shares -> the batch loss of each step
+    rt = np.asarray(tr)
+    assert loss.shape == rt.shape == (it0 + it1,)
+    assert np.abs(loss - rt).max() / rt.max() < 1e-4
+    assert rt[-1] < 0.2 * rt[0]
+    x = aux["x"].cpu().numpy()
+    xr = torch.cat([ref["pose"], ref["betas"], ref["orient"], ref["transl"]], 1).numpy()
+    dev = np.abs(x - xr)
+    print(f"Adam fitter ({model}) parameter deviation vs oracle:", float(dev.max()))
+    assert dev.max() < 2e-4                      # Adam normalises every coordinate's step by sqrt(v): fp32-vs-fp64 moments differ at 1e-5 relative
+    assert np.abs(aux["verts"].cpu().numpy() - ref["verts"].numpy()).max() < 1e-4
+    assert np.abs(meshes[0].vertices - ref["verts"].numpy()[0]).max() < 1e-4
