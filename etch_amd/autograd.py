@@ -1,0 +1,160 @@
+"""Differentiable forms of the encoder's native ops: torch.autograd.Function wrappers whose forward is the fused
+inference kernel and whose backward is hand-written HIP (csrc/backward.hip) -- what /root/reference/src/train.py:77-101 obtains from
+autograd through the un-fused vgtk forms (external/vgtk/vgtk/so3conv/functional.py:224-378, modules.py:33-39).
+
+Gradients are reproducible run to run (fixed reduction orders, no atomics).  Memory: the backward of the inter conv regenerates the
+kernel weights and the grouped features for `chunk` output points at a time instead of keeping the reference's [b,p,60,24,nn] and
+[b,c,24,p,60] tensors alive between forward and backward."""
+import ctypes
+
+import torch
+
+from . import _lib
+from . import ops
+from .ops import _c_float, _ptr, _stream
+
+
+def _check(status, what):
+    _lib.check(status, what)
+
+
+def gemm_tn(A, B, out=None, accumulate=False):
+    """A (R,M), B (R,N) -> A^T B (M,N)."""
+    R, M = A.shape
+    N = B.shape[1]
+    C = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=A.device)
+    ws = torch.empty((_lib.lib().etch_gemm_tn_workspace_floats(ctypes.c_long(R), M, N),), dtype=torch.float32, device=A.device)
+    _check(_lib.lib().etch_gemm_tn(ctypes.c_long(R), M, N, _ptr(A), ctypes.c_long(A.stride(0)), _ptr(B), ctypes.c_long(B.stride(0)), _ptr(C),
+                                   1 if accumulate else 0, _ptr(ws), _stream()), "etch_gemm_tn")
+    return C
+
+
+def colsum(x2d):
+    R, C = x2d.shape
+    ws = torch.empty((64 * C,), dtype=torch.float64, device=x2d.device)
+    out = torch.empty((C,), dtype=torch.float32, device=x2d.device)
+    _check(_lib.lib().etch_colsum(ctypes.c_long(R), C, _ptr(x2d), _ptr(ws), _ptr(out), _stream()), "etch_colsum")
+    return out
+
+
+class InterSO3ConvFunction(torch.autograd.Function):
+    """y (b,p2,60,cout) = fused inter conv of feats (b,p1,60,cin) [channels-last] with W (cout, cin*24), bias (cout)."""
+
+    @staticmethod
+    def forward(ctx, feats_cl, W, bias, xyz, new_xyz, ball_idx, rk, sigma, chunk):
+        feats_cl, Wc, bc = feats_cl.contiguous(), W.detach().contiguous(), bias.detach().reshape(-1).contiguous()
+        cin = feats_cl.shape[-1]
+        Wp = ops.inter_weight_frag(Wc, cin) if cin % 16 == 0 else None
+        y = ops.inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, Wc, Wp, bc, sigma)
+        ctx.save_for_backward(feats_cl, Wc, xyz, new_xyz, ball_idx, rk)
+        ctx.sigma, ctx.chunk, ctx.bias_shape = float(sigma), int(chunk), bias.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        feats, W, xyz, new_xyz, idx, rk = ctx.saved_tensors
+        dy = dy.contiguous()
+        b, p1, na, cin = feats.shape
+        p2, nn = idx.shape[1], idx.shape[2]
+        cout, kk = W.shape
+        lib = _lib.lib()
+        need_df = ctx.needs_input_grad[0]
+        dW = torch.zeros_like(W)
+        dfeats = torch.zeros_like(feats) if need_df else None
+        Wt = W.t().contiguous()                                              # (kk, cout): dX1 = dY W  as an NT product
+        for s in range(0, p2, ctx.chunk):
+            pc = min(ctx.chunk, p2 - s)
+            x1 = torch.empty((b, pc, na, kk), dtype=torch.float32, device=feats.device)
+            _check(lib.etch_inter_x1_rows(b, cin, p1, p2, s, pc, nn, _c_float(ctx.sigma), _ptr(xyz), _ptr(new_xyz), _ptr(idx), _ptr(feats), _ptr(rk),
+                                          _ptr(x1), _stream()), "etch_inter_x1_rows")
+            dyc = dy[:, s:s + pc].contiguous().view(b * pc * na, cout)
+            gemm_tn(dyc, x1.view(b * pc * na, kk), out=dW, accumulate=True)   # dW += dY^T X1
+            if need_df:
+                dx1 = ops.linear(dyc, Wt)                                    # (rows, kk) = dY W
+                _check(lib.etch_inter_dfeat(b, cin, p1, p2, s, pc, nn, _c_float(ctx.sigma), _ptr(xyz), _ptr(new_xyz), _ptr(idx), _ptr(rk), _ptr(dx1),
+                                            _ptr(dfeats), 1, _stream()), "etch_inter_dfeat")
+        dbias = colsum(dy.view(-1, cout)).view(ctx.bias_shape)
+        return dfeats, dW, dbias, None, None, None, None, None, None
+
+
+def inter_so3conv(feats_cl, W, bias, xyz, new_xyz, ball_idx, rk, sigma, chunk=256):
+    return InterSO3ConvFunction.apply(feats_cl, W, bias, xyz, new_xyz, ball_idx, rk, sigma, chunk)
+
+
+class IntraSO3ConvFunction(torch.autograd.Function):
+    """y (b,p,60,C) = fused intra conv of x (b,p,60,C) with W (C, C*12) [column c*12+t], bias (C); intra_idx (60,12) whose columns are
+    permutations of the anchors (so the data gradient is the same kernel run with the inverse tables and the transposed weight)."""
+
+    @staticmethod
+    def _frag(W, C, nt):
+        W2 = W.view(W.shape[0], C, nt).permute(0, 2, 1).reshape(W.shape[0], nt * C).contiguous()     # tap-major K, as the kernel reads it
+        return ops.permute_weight_frag(W2)
+
+    @staticmethod
+    def forward(ctx, x_cl, W, bias, intra_idx):
+        x_cl, Wc = x_cl.contiguous(), W.detach().contiguous()
+        C, nt = x_cl.shape[-1], intra_idx.shape[1]
+        idx32 = intra_idx.to(torch.int32).contiguous()
+        y = ops.intra_so3conv(x_cl, idx32, IntraSO3ConvFunction._frag(Wc, C, nt), bias.detach().reshape(-1).contiguous(), Wc.shape[0])
+        ctx.save_for_backward(x_cl, Wc, idx32)
+        ctx.bias_shape = bias.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, idx32 = ctx.saved_tensors
+        dy = dy.contiguous()
+        b, p, na, C = x.shape
+        nt = idx32.shape[1]
+        cout = W.shape[0]
+        lib = _lib.lib()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # dx[p,a',c] = sum_t sum_o W[o, c*nt+t] dy[p, inv_t(a'), o]: the forward kernel with inverse tables and W'[c, o*nt+t] = W[o, c*nt+t]
+            inv = torch.empty_like(idx32)
+            ar = torch.arange(na, dtype=torch.int32, device=x.device)
+            for t in range(nt):
+                inv[idx32[:, t].long(), t] = ar
+            Wb = W.view(cout, C, nt).permute(1, 0, 2).reshape(C, cout * nt).contiguous()
+            zero = torch.zeros((C,), dtype=torch.float32, device=x.device)
+            dx = ops.intra_so3conv(dy, inv.contiguous(), IntraSO3ConvFunction._frag(Wb, cout, nt), zero, C)
+        xg = torch.empty((b * p * na, nt * C), dtype=torch.float32, device=x.device)
+        _check(lib.etch_intra_rows(ctypes.c_long(b * p), C, nt, _ptr(idx32), _ptr(x), _ptr(xg), _stream()), "etch_intra_rows")
+        dW2 = gemm_tn(dy.view(b * p * na, cout), xg)                          # (cout, nt*C), tap-major columns
+        dW = dW2.view(cout, nt, C).permute(0, 2, 1).reshape(cout, C * nt).contiguous()
+        dbias = colsum(dy.view(-1, cout)).view(ctx.bias_shape)
+        return dx, dW, dbias, None
+
+
+def intra_so3conv(x_cl, W, bias, intra_idx):
+    return IntraSO3ConvFunction.apply(x_cl, W, bias, intra_idx)
+
+
+class InstanceNormLeakyReLUFunction(torch.autograd.Function):
+    """leaky_relu(InstanceNorm2d(affine=False, eps=1e-5)(x), 0.01) on channels-last x (b, ..., C) (so3conv.py:36-44)."""
+
+    @staticmethod
+    def forward(ctx, x_cl, slope):
+        x_cl = x_cl.contiguous()
+        mean, rstd = ops.instnorm_stats(x_cl)
+        assert abs(slope - 0.01) < 1e-12, "the fused forward kernel applies leaky_relu(0.01)"
+        y = ops.instnorm_act_add(x_cl, mean, rstd)
+        ctx.save_for_backward(x_cl, mean, rstd)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        b, C = x.shape[0], x.shape[-1]
+        rows = x.numel() // (b * C)
+        ws = torch.empty((_lib.lib().etch_instnorm_act_backward_workspace_bytes(b, C) // 8,), dtype=torch.float64, device=x.device)
+        dx = torch.empty_like(x)
+        _check(_lib.lib().etch_instnorm_act_backward(b, rows, C, _ptr(x), _ptr(dy), _ptr(mean), _ptr(rstd), _c_float(ctx.slope), _ptr(ws), _ptr(dx),
+                                                     _stream()), "etch_instnorm_act_backward")
+        return dx, None
+
+
+def instnorm_leaky_relu(x_cl, slope=0.01):
+    return InstanceNormLeakyReLUFunction.apply(x_cl, slope)

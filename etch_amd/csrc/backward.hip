@@ -1,0 +1,359 @@
+// Backward kernels of the EPN encoder's native ops for gfx950 (what train.py needs on MI355X next to
+// etch_gather_points_backward).  The reference obtains these gradients from torch.autograd through the UN-FUSED forms
+// (/root/reference/external/vgtk/vgtk/so3conv/functional.py:224-324 grouping + :61-67 einsum, modules.py:33-39 GEMM, :131-153 intra
+// gather; src/models/so3conv.py:24-44,85-99 InstanceNorm2d + leaky_relu; call sites src/train.py:77-101).  Here every gradient is a
+// hand-written kernel; kernel weights are regenerated from the coordinates (never stored), and every reduction runs in a FIXED order
+// (no atomics): results are reproducible run to run, like the gather backward.
+//
+//   etch_inter_x1_rows        X1[(b,p,a), c*24+k] = sum_n F[b,idx[p,n],a,c] w[p,a,k,n]         (the conv's grouped features, recomputed)
+//   etch_gemm_tn              C[M,N] (+)= A[R,M]^T B[R,N]                                      dW = dY^T X1 on the fp32 matrix cores
+//   etch_inter_dfeat          dF[b,q,a,c] (+)= sum_{(p,n): idx[p,n]=q} sum_k w[p,a,k,n] dX1[(b,p,a), c*24+k]   gather-side, index order
+//   etch_intra_rows           Xg[(b,p,a), t*C+c] = X[b,p,intra_idx[a,t],c]                     operand of the intra conv's dW
+//   etch_colsum               s[c] = sum_r x[r,c]                                              bias gradients
+//   etch_instnorm_act_backward  d/dx of leaky_relu(InstanceNorm(x)) given dy, mean, rstd
+// Activations are channels-last ([b, p, 60, c]) as in the forward kernels.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define NA 60
+#define KS 24
+
+// ---------------------------------------------------------------------------------------------- inter conv: grouped features
+// One workgroup per output point.  thread <-> (anchor a, kernel point k) pairs (1440 of them, 6 passes of 240 threads... 256);
+// the neighbour terms (2g/sigma, 1-|g|^2/sigma) and the source rows' offsets are staged in LDS once.
+__global__ void __launch_bounds__(256) inter_x1_rows_kernel(int cin, int p1, int p2, int p_begin, int nn, float inv_sigma,
+                                                            const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                            const int* __restrict__ ball_idx, const float* __restrict__ feats,
+                                                            const float* __restrict__ rk, float* __restrict__ x1) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float4* GA = reinterpret_cast<float4*>(smem);        // [nn]
+    int* qi = reinterpret_cast<int*>(smem + 4 * nn);     // [nn]  (-1: padded slot)
+    const int tid = threadIdx.x, b = blockIdx.y, pl = blockIdx.x, p = p_begin + pl;
+    const float* X = xyz + (size_t)b * 3 * p1;
+    for (int n = tid; n < nn; n += 256) {
+        const int q = ball_idx[((size_t)b * p2 + p) * nn + n];
+        qi[n] = q;
+        const float x = X[q] - new_xyz[((size_t)b * 3 + 0) * p2 + p], y = X[p1 + q] - new_xyz[((size_t)b * 3 + 1) * p2 + p],
+                    z = X[2 * p1 + q] - new_xyz[((size_t)b * 3 + 2) * p2 + p];
+        GA[n] = make_float4(2.0f * inv_sigma * x, 2.0f * inv_sigma * y, 2.0f * inv_sigma * z, 1.0f - (x * x + y * y + z * z) * inv_sigma);
+    }
+    __syncthreads();
+    const float* Fb = feats + (size_t)b * p1 * NA * cin;
+    const int kk = cin * KS;
+    float* out = x1 + ((size_t)b * gridDim.x + pl) * NA * kk;
+    for (int e = tid; e < NA * KS; e += 256) {
+        const int a = e / KS, k = e - a * KS;
+        const float rx = rk[(a * KS + k) * 3], ry = rk[(a * KS + k) * 3 + 1], rz = rk[(a * KS + k) * 3 + 2];
+        const float rb = -(rx * rx + ry * ry + rz * rz) * inv_sigma;
+        for (int c0 = 0; c0 < cin; c0 += 16) {
+            float acc[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+            for (int n = 0; n < nn; ++n) {
+                const float4 g = GA[n];
+                const float w = fmaxf(0.f, fmaf(g.z, rz, fmaf(g.y, ry, fmaf(g.x, rx, g.w + rb))));
+                if (w > 0.f) {
+                    const float* fr = Fb + ((size_t)qi[n] * NA + a) * cin + c0;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c)
+                        if (c0 + c < cin) acc[c] = fmaf(fr[c], w, acc[c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (c0 + c < cin) out[(size_t)a * kk + (c0 + c) * KS + k] = acc[c];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- C (+)= A^T B on the matrix cores
+// grid (N/64, M/64, splits): a workgroup owns a 64x64 tile of C and a contiguous range of the R rows; 32 rows at a time go through
+// LDS row-major (coalesced loads), the MFMA fragments are read transposed (row stride = 16 mod 64 floats: conflict-free).
+// Partial tiles [split][M][N] are summed in split order by gemm_tn_reduce_kernel (deterministic).
+#define TN_LD 80
+__global__ void __launch_bounds__(256) gemm_tn_kernel(long R, int M, int N, const float* __restrict__ A, long lda, const float* __restrict__ B,
+                                                      long ldb, float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float As[32 * TN_LD], Bs[32 * TN_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64, sp = blockIdx.z, nsp = gridDim.z;
+    const long r_begin = R * sp / nsp, r_end = R * (sp + 1) / nsp;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;          // the wave's 32x32 quadrant
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+    for (long r0 = r_begin; r0 < r_end; r0 += 32) {
+        __syncthreads();
+        for (int e = tid; e < 32 * 16; e += 256) {                  // 32 rows x 16 float4 per operand
+            const int r = e >> 4, c4 = (e & 15) * 4;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+            if (r0 + r < r_end) {
+                const float* ar = A + (r0 + r) * lda + m0 + c4;
+                const float* br = B + (r0 + r) * ldb + n0 + c4;
+                va = make_float4(m0 + c4 < M ? ar[0] : 0.f, m0 + c4 + 1 < M ? ar[1] : 0.f, m0 + c4 + 2 < M ? ar[2] : 0.f, m0 + c4 + 3 < M ? ar[3] : 0.f);
+                vb = make_float4(n0 + c4 < N ? br[0] : 0.f, n0 + c4 + 1 < N ? br[1] : 0.f, n0 + c4 + 2 < N ? br[2] : 0.f, n0 + c4 + 3 < N ? br[3] : 0.f);
+            }
+            *reinterpret_cast<float4*>(&As[r * TN_LD + c4]) = va;
+            *reinterpret_cast<float4*>(&Bs[r * TN_LD + c4]) = vb;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            float a[2], bq[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { a[i] = As[(4 * t + fg) * TN_LD + wm + 16 * i + fr]; bq[i] = Bs[(4 * t + fg) * TN_LD + wn + 16 * i + fr]; }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bq[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* P = part + (size_t)sp * M * N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + wm + 16 * i + 4 * fg + q, n = n0 + wn + 16 * j + fr;
+                if (m < M && n < N) P[(size_t)m * N + n] = acc[i][j][q];
+            }
+}
+
+__global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(long MN, int splits, const float* __restrict__ part, float* __restrict__ C, int accumulate) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < MN; i += (long)gridDim.x * 256) {
+        float s = accumulate ? C[i] : 0.f;
+        for (int k = 0; k < splits; ++k) s += part[(size_t)k * MN + i];
+        C[i] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- inter conv: d feats
+// One workgroup per SOURCE point q (gather side): the chunk's index list is scanned 256 slots at a time in index order; a matching
+// slot (p, n) contributes  sum_k w[p,a,k,n] dX1[(p,a), c*24+k]  to dF[q,a,c] with w regenerated from g = xyz_q - new_xyz_p.
+// thread <-> (anchor a, channel group): 240 threads = 60 anchors x 4 groups of cin/4 channels.
+__global__ void __launch_bounds__(256) inter_dfeat_kernel(int cin, int p1, int p2, int p_begin, int pc, int nn, float inv_sigma,
+                                                          const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                          const int* __restrict__ ball_idx, const float* __restrict__ rk,
+                                                          const float* __restrict__ dx1, float* __restrict__ dfeats, int accumulate) {
+    __shared__ int match[256];
+    __shared__ int nmatch_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, q = blockIdx.x;
+    const float* X = xyz + (size_t)b * 3 * p1;
+    const float qx = X[q], qy = X[p1 + q], qz = X[2 * p1 + q];
+    const int a = tid >> 2, cg = tid & 3, cper = cin >> 2, kk = cin * KS;
+    const bool worker = tid < NA * 4;
+    float acc[16];                                        // cin / 4 <= 16 channels per thread
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+    const int* idx = ball_idx + ((size_t)b * p2 + p_begin) * nn;
+    const long nslot = (long)pc * nn;
+    for (long s0 = 0; s0 < nslot; s0 += 256) {
+        const long sl = s0 + tid;
+        const bool hit = sl < nslot && idx[sl] == q;
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) nmatch_w[wave] = __popcll(m);
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += nmatch_w[w];
+        const int total = nmatch_w[0] + nmatch_w[1] + nmatch_w[2] + nmatch_w[3];
+        if (hit) match[base + __popcll(m & ((1ull << lane) - 1ull))] = (int)sl;      // compacted in slot order
+        __syncthreads();
+        if (worker) {
+            for (int e = 0; e < total; ++e) {
+                const int slot = match[e];
+                const int pl = slot / nn;
+                const int p = p_begin + pl;
+                const float gx = qx - new_xyz[((size_t)b * 3 + 0) * p2 + p], gy = qy - new_xyz[((size_t)b * 3 + 1) * p2 + p],
+                            gz = qz - new_xyz[((size_t)b * 3 + 2) * p2 + p];
+                const float ga = 1.0f - (gx * gx + gy * gy + gz * gz) * inv_sigma;
+                const float* drow = dx1 + (((size_t)b * pc + pl) * NA + a) * kk + (size_t)cg * cper * KS;
+                for (int k = 0; k < KS; ++k) {
+                    const float rx = rk[(a * KS + k) * 3], ry = rk[(a * KS + k) * 3 + 1], rz = rk[(a * KS + k) * 3 + 2];
+                    const float w = fmaxf(0.f, fmaf(2.0f * inv_sigma * gz, rz, fmaf(2.0f * inv_sigma * gy, ry, fmaf(2.0f * inv_sigma * gx, rx,
+                                                    ga - (rx * rx + ry * ry + rz * rz) * inv_sigma))));
+                    if (w > 0.f) {
+#pragma unroll
+                        for (int c = 0; c < 16; ++c)
+                            if (c < cper) acc[c] = fmaf(w, drow[c * KS + k], acc[c]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (worker) {
+        float* dst = dfeats + (((size_t)b * p1 + q) * NA + a) * cin + cg * cper;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < cper) dst[c] = (accumulate ? dst[c] : 0.f) + acc[c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- intra conv: gathered rows
+__global__ void __launch_bounds__(256) intra_rows_kernel(long total, int C, int nt, const int* __restrict__ intra_idx, const float* __restrict__ x,
+                                                         float* __restrict__ xg) {
+    // total = points * 60 * nt * C;  xg[((pt*60 + a) * nt + t) * C + c] = x[(pt*60 + idx[a,t]) * C + c]
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        long r = i / C;
+        const int t = (int)(r % nt); r /= nt;
+        const int a = (int)(r % NA);
+        const long pt = r / NA;
+        xg[i] = x[(pt * NA + intra_idx[a * nt + t]) * C + c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- column sums (bias gradients)
+__global__ void __launch_bounds__(256) colsum_partial_kernel(long R, int C, const float* __restrict__ x, double* __restrict__ part) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x, c = blockIdx.y, nb = gridDim.x;
+    const long r_begin = R * blockIdx.x / nb, r_end = R * (blockIdx.x + 1) / nb;
+    double s = 0.0;
+    for (long r = r_begin + tid; r < r_end; r += 256) s += (double)x[r * C + c];
+    red[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) part[(size_t)blockIdx.x * C + c] = red[0];
+}
+__global__ void colsum_final_kernel(int C, int nparts, const double* __restrict__ part, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < nparts; ++k) s += part[(size_t)k * C + c];
+    out[c] = (float)s;
+}
+
+// ---------------------------------------------------------------------------------------------- InstanceNorm + LeakyReLU backward
+// y = lrelu(xh), xh = (x - mean) * rstd over the rows of one (scan, channel):  g = dy * lrelu'(xh),
+// dx = rstd * (g - mean_rows(g) - xh * mean_rows(g * xh)).  Pass 1: per-chunk fp64 partial sums of g and g*xh; pass 2: apply.
+#define INB_CHUNKS 64
+__global__ void __launch_bounds__(256) instnorm_bwd_partial_kernel(int rows, int C, const float* __restrict__ x, const float* __restrict__ dy,
+                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                   float slope, double* __restrict__ part) {
+    __shared__ double red[2][256];
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int rpp = 256 / C > 0 ? 256 / C : 1;            // rows per pass (C <= 256, C divides 256)
+    const int c = tid % C, rsub = tid / C;
+    const int r_begin = (int)(((long)rows * chunk) / INB_CHUNKS), r_end = (int)(((long)rows * (chunk + 1)) / INB_CHUNKS);
+    const float mu = mean[(size_t)b * C + c], rs = rstd[(size_t)b * C + c];
+    double s1 = 0.0, s2 = 0.0;
+    if (rsub < rpp)
+        for (int r = r_begin + rsub; r < r_end; r += rpp) {
+            const size_t o = ((size_t)b * rows + r) * C + c;
+            const float xh = (x[o] - mu) * rs;
+            const float g = dy[o] * (xh > 0.f ? 1.0f : slope);
+            s1 += (double)g; s2 += (double)g * (double)xh;
+        }
+    red[0][tid] = s1; red[1][tid] = s2;
+    __syncthreads();
+    if (rsub == 0) {
+        for (int k = 1; k < rpp; ++k) { s1 += red[0][k * C + c]; s2 += red[1][k * C + c]; }
+        part[(((size_t)b * INB_CHUNKS + chunk) * 2 + 0) * C + c] = s1;
+        part[(((size_t)b * INB_CHUNKS + chunk) * 2 + 1) * C + c] = s2;
+    }
+}
+__global__ void __launch_bounds__(256) instnorm_bwd_apply_kernel(long n, int rows, int C, const float* __restrict__ x, const float* __restrict__ dy,
+                                                                 const float* __restrict__ mean, const float* __restrict__ rstd, float slope,
+                                                                 const double* __restrict__ part, float* __restrict__ dx) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long b = i / ((long)rows * C);
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < INB_CHUNKS; ++k) {
+            s1 += part[((b * INB_CHUNKS + k) * 2 + 0) * C + c];
+            s2 += part[((b * INB_CHUNKS + k) * 2 + 1) * C + c];
+        }
+        const float mu = mean[b * C + c], rs = rstd[b * C + c];
+        const float xh = (x[i] - mu) * rs;
+        const float g = dy[i] * (xh > 0.f ? 1.0f : slope);
+        dx[i] = rs * (float)((double)g - s1 / rows - (double)xh * (s2 / rows));
+    }
+}
+
+static inline unsigned grid_for(long total) {
+    long blocks = (total + 255) / 256;
+    if (blocks > 65535l * 16) blocks = 65535l * 16;
+    return (unsigned)blocks;
+}
+
+extern "C" {
+
+int etch_inter_x1_rows(int b, int cin, int p1, int p2, int p_begin, int pc, int nn, float sigma, const float* xyz, const float* new_xyz,
+                       const int* ball_idx, const float* feats, const float* rk, float* x1, void* stream) {
+    if (b <= 0 || pc <= 0) return ETCH_OK;
+    if (cin <= 0 || nn <= 0 || p_begin < 0 || p_begin + pc > p2 || b > 65535) return ETCH_EINVAL;
+    hipLaunchKernelGGL(inter_x1_rows_kernel, dim3(pc, b), dim3(256), (size_t)5 * nn * sizeof(float), (hipStream_t)stream, cin, p1, p2, p_begin, nn,
+                       1.0f / sigma, xyz, new_xyz, ball_idx, feats, rk, x1);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_gemm_tn_workspace_floats(long R, int M, int N) {
+    int splits = (int)((R + 2047) / 2048);
+    if (splits > 64) splits = 64;
+    if (splits < 1) splits = 1;
+    return splits * M * N;
+}
+
+int etch_gemm_tn(long R, int M, int N, const float* A, long lda, const float* B, long ldb, float* C, int accumulate, float* workspace,
+                 void* stream) {
+    if (M <= 0 || N <= 0) return ETCH_OK;
+    if (R < 0 || lda < M || ldb < N) return ETCH_EINVAL;
+    int splits = (int)((R + 2047) / 2048);
+    if (splits > 64) splits = 64;
+    if (splits < 1) splits = 1;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((N + 63) / 64, (M + 63) / 64, splits), dim3(256), 0, st, R, M, N, A, lda, B, ldb, workspace);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, st, (long)M * N, splits, workspace, C, accumulate);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_inter_dfeat(int b, int cin, int p1, int p2, int p_begin, int pc, int nn, float sigma, const float* xyz, const float* new_xyz,
+                     const int* ball_idx, const float* rk, const float* dx1, float* dfeats, int accumulate, void* stream) {
+    if (b <= 0 || p1 <= 0) return ETCH_OK;
+    if (cin <= 0 || (cin & 3) || cin > 64 || nn <= 0 || p_begin < 0 || p_begin + pc > p2 || b > 65535) return ETCH_EUNSUPPORTED;
+    hipLaunchKernelGGL(inter_dfeat_kernel, dim3(p1, b), dim3(256), 0, (hipStream_t)stream, cin, p1, p2, p_begin, pc, nn, 1.0f / sigma, xyz, new_xyz,
+                       ball_idx, rk, dx1, dfeats, accumulate);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_intra_rows(long points, int C, int nt, const int* intra_idx, const float* x, float* xg, void* stream) {
+    const long total = points * NA * nt * C;
+    if (total <= 0) return ETCH_OK;
+    hipLaunchKernelGGL(intra_rows_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, total, C, nt, intra_idx, x, xg);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_colsum(long R, int C, const float* x, double* workspace, float* out, void* stream) {
+    if (C <= 0) return ETCH_OK;
+    if (C > 65535) return ETCH_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(64, C), dim3(256), 0, st, R, C, x, workspace);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, C, 64, workspace, out);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_instnorm_act_backward(int b, int rows, int C, const float* x, const float* dy, const float* mean, const float* rstd, float slope,
+                               double* workspace, float* dx, void* stream) {
+    if (b <= 0 || rows <= 0) return ETCH_OK;
+    if (C <= 0 || C > 256 || (256 % C) != 0 || b > 65535) return ETCH_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(instnorm_bwd_partial_kernel, dim3(INB_CHUNKS, b), dim3(256), 0, st, rows, C, x, dy, mean, rstd, slope, workspace);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    const long n = (long)b * rows * C;
+    hipLaunchKernelGGL(instnorm_bwd_apply_kernel, dim3(grid_for(n)), dim3(256), 0, st, n, rows, C, x, dy, mean, rstd, slope, workspace, dx);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_instnorm_act_backward_workspace_bytes(int b, int C) { return (int)((size_t)INB_CHUNKS * b * 2 * C * sizeof(double)); }
+
+}  // extern "C"

@@ -247,6 +247,38 @@ int etch_square_distance(int B, int N, int M, int C, const float* src, const flo
 /* index_points (pointnet2_utils.py:26-43): points (B,N,C), idx (B,S) i64 -> (B,S,C). */
 int etch_index_points(int B, int N, long S, int C, const float* points, const long long* idx, float* out, void* stream);
 
+/* ---- backward kernels of the encoder's native ops (csrc/backward.hip).  The reference gets these gradients from
+ * torch.autograd through the un-fused forms (vgtk/so3conv/functional.py:224-324, :61-67; modules.py:33-39, :131-153; src/models/
+ * so3conv.py:24-44; call sites src/train.py:77-101).  All reductions run in a fixed order (no atomics). ---------------------------- */
+
+/* Grouped features of the inter conv, recomputed for output points [p_begin, p_begin + pc): x1 (b, pc, 60, cin*24) with
+ * x1[.., a, c*24+k] = sum_n feats[b, idx[b,p,n], a, c] * w[p,a,k,n]  (feats channels-last (b,p1,60,cin); w regenerated from xyz). */
+int etch_inter_x1_rows(int b, int cin, int p1, int p2, int p_begin, int pc, int nn, float sigma, const float* xyz, const float* new_xyz,
+                       const int* ball_idx, const float* feats, const float* rk, float* x1, void* stream);
+
+/* C (M,N) (+)= A (R,M)^T B (R,N) on the fp32 matrix cores (dW = dY^T X1): split over R, partial tiles in `workspace`
+ * (etch_gemm_tn_workspace_floats(R, M, N) floats), summed in split order. */
+int etch_gemm_tn_workspace_floats(long R, int M, int N);
+int etch_gemm_tn(long R, int M, int N, const float* A, long lda, const float* B, long ldb, float* C, int accumulate, float* workspace,
+                 void* stream);
+
+/* d feats of the inter conv from d x1 of the output points [p_begin, p_begin + pc): dfeats (b,p1,60,cin) (+)= the gather-side sum over
+ * the neighbour slots (p,n) with idx[b,p,n] == q, taken in slot order.  cin in {4..64}, multiple of 4. */
+int etch_inter_dfeat(int b, int cin, int p1, int p2, int p_begin, int pc, int nn, float sigma, const float* xyz, const float* new_xyz,
+                     const int* ball_idx, const float* rk, const float* dx1, float* dfeats, int accumulate, void* stream);
+
+/* Gathered operand of the intra conv's weight gradient: x (points,60,C) -> xg (points,60,nt,C) with xg[p,a,t,:] = x[p,intra_idx[a,t],:]
+ * (functional.py:331-378 in channels-last rows). */
+int etch_intra_rows(long points, int C, int nt, const int* intra_idx, const float* x, float* xg, void* stream);
+
+/* Column sums s[c] = sum_r x[r,c] (bias gradients): fp64, two levels, fixed order.  workspace: 64*C doubles. */
+int etch_colsum(long R, int C, const float* x, double* workspace, float* out, void* stream);
+
+/* d/dx of leaky_relu(InstanceNorm2d(x), slope) (so3conv.py:36-44): x, dy (b,rows,C) channels-last, mean / rstd (b,C) of the forward. */
+int etch_instnorm_act_backward_workspace_bytes(int b, int C);
+int etch_instnorm_act_backward(int b, int rows, int C, const float* x, const float* dy, const float* mean, const float* rstd, float slope,
+                               double* workspace, float* dx, void* stream);
+
 /* ---- stage 2: markers + SMPL Levenberg-Marquardt fit ------------------------------------------------------ */
 
 /* torch.max(part_labels, -1) of predict_smpl (src/inference_demo.py:52-53): logits (R,G) -> int64 labels (R). */

@@ -1,0 +1,138 @@
+"""GPU tests of the backward kernels: gradients of the fused inter / intra SO(3) convolutions and of
+InstanceNorm + LeakyReLU against torch.autograd through the oracle's un-fused restatement of the reference forms
+(vgtk/so3conv/functional.py:224-378, modules.py:33-39; so3conv.py:36-44) evaluated in fp64; reproducibility run to run."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _parity import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def scan(seed, n):
+    return (np.random.default_rng(seed).standard_normal((n, 3)) * np.array([0.14, 0.31, 0.085])).astype(np.float32)
+
+
+@pytest.mark.parametrize("stride,lazy,nn,cin,cout,chunk", [(2, False, 16, 16, 32, 64), (1, True, 32, 32, 32, 100), (2, False, 32, 64, 64, 256)])
+def test_inter_conv_gradients_vs_autograd_of_the_unfused_form(stride, lazy, nn, cin, cout, chunk):
+    import etch_amd.vgtk_so3conv as V
+    from etch_amd import autograd as A
+    from etch_amd.utils.weights import load_seeded
+    from oracle import stage1 as S1
+    b, n, radius, sigma = 2, 300, 0.2, 0.02
+    rng = np.random.default_rng(1)
+    xyz = torch.from_numpy(np.stack([scan(30 + i, n).T.copy() for i in range(b)]))
+    conv = load_seeded(V.InterSO3Conv(cin, cout, 1, stride, radius, sigma, nn, lazy_sample=lazy), 4).cuda().eval()
+    g_ref, ball, sidx, new_xyz = S1.inter_grouping(xyz, stride, radius, nn, lazy)
+    p2 = new_xyz.shape[2]
+    # reference gradients: fp64 autograd through weights -> grouping einsum -> GEMM
+    feats = torch.from_numpy(rng.standard_normal((b, cin, n, 60))).double().requires_grad_()
+    W = conv.basic_conv.W.detach().cpu().double().requires_grad_()
+    bias = conv.basic_conv.bias.detach().cpu().double().requires_grad_()
+    w = S1.inter_weights(g_ref.double(), conv.anchors.cpu().double(), conv.kernels.cpu().double(), sigma)
+    nf = S1.inter_feat_grouping(ball, w, torch.cat((feats, torch.zeros(b, cin, 1, 60, dtype=torch.float64)), 2))
+    y_ref = S1.basic_so3conv(W, bias, nf)                                   # (b, cout, p2, 60)
+    G = torch.from_numpy(rng.standard_normal(tuple(y_ref.shape)))
+    (y_ref * G).sum().backward()
+    # ours
+    rk, Wd, Wp, bd = conv._derived()
+    f_cl = feats.detach().float().permute(0, 2, 3, 1).contiguous().cuda().requires_grad_()
+    Wg = conv.basic_conv.W.detach().clone().requires_grad_()
+    bg = conv.basic_conv.bias.detach().clone().requires_grad_()
+    y = A.inter_so3conv(f_cl, Wg, bg, xyz.cuda(), new_xyz.cuda(), ball.cuda(), rk, sigma, chunk=chunk)
+    assert rel_err(y.detach().cpu().permute(0, 3, 1, 2).numpy(), y_ref.detach().numpy()) < 1e-4
+    (y * G.float().permute(0, 2, 3, 1).contiguous().cuda()).sum().backward()
+    assert rel_err(Wg.grad.cpu().numpy(), W.grad.numpy()) < 1e-4
+    assert rel_err(bg.grad.cpu().numpy(), bias.grad.numpy()) < 1e-4
+    assert rel_err(f_cl.grad.cpu().permute(0, 3, 1, 2).numpy(), feats.grad.numpy()) < 1e-4
+    # reproducible: a second backward gives the same bits
+    f2 = f_cl.detach().clone().requires_grad_()
+    W2 = Wg.detach().clone().requires_grad_()
+    b2 = bg.detach().clone().requires_grad_()
+    y2 = A.inter_so3conv(f2, W2, b2, xyz.cuda(), new_xyz.cuda(), ball.cuda(), rk, sigma, chunk=chunk)
+    (y2 * G.float().permute(0, 2, 3, 1).contiguous().cuda()).sum().backward()
+    assert torch.equal(W2.grad, Wg.grad) and torch.equal(f2.grad, f_cl.grad) and torch.equal(b2.grad, bg.grad)
+
+
+def test_first_conv_weight_gradient_single_input_channel():
+    """cin = 1 (the encoder's first conv: constant occupancy features, only W and bias receive gradients)."""
+    import etch_amd.vgtk_so3conv as V
+    from etch_amd import autograd as A
+    from etch_amd.utils.weights import load_seeded
+    from oracle import stage1 as S1
+    b, n, nn, cout, radius, sigma = 1, 260, 24, 32, 0.2, 0.02
+    xyz = torch.from_numpy(np.stack([scan(40, n).T.copy()]))
+    conv = load_seeded(V.InterSO3Conv(1, cout, 1, 1, radius, sigma, nn, lazy_sample=True), 6).cuda().eval()
+    g_ref, ball, sidx, new_xyz = S1.inter_grouping(xyz, 1, radius, nn, True)
+    feats = torch.ones(b, 1, n, 60, dtype=torch.float64)
+    W = conv.basic_conv.W.detach().cpu().double().requires_grad_()
+    bias = conv.basic_conv.bias.detach().cpu().double().requires_grad_()
+    w = S1.inter_weights(g_ref.double(), conv.anchors.cpu().double(), conv.kernels.cpu().double(), sigma)
+    y_ref = S1.basic_so3conv(W, bias, S1.inter_feat_grouping(ball, w, torch.cat((feats, torch.zeros(b, 1, 1, 60, dtype=torch.float64)), 2)))
+    G = torch.from_numpy(np.random.default_rng(2).standard_normal(tuple(y_ref.shape)))
+    (y_ref * G).sum().backward()
+    rk = conv._derived()[0]
+    Wg = conv.basic_conv.W.detach().clone().requires_grad_()
+    bg = conv.basic_conv.bias.detach().clone().requires_grad_()
+    y = A.inter_so3conv(torch.ones(b, n, 60, 1).cuda(), Wg, bg, xyz.cuda(), new_xyz.cuda(), ball.cuda(), rk, sigma, chunk=128)
+    (y * G.float().permute(0, 2, 3, 1).contiguous().cuda()).sum().backward()
+    assert rel_err(Wg.grad.cpu().numpy(), W.grad.numpy()) < 1e-4 and rel_err(bg.grad.cpu().numpy(), bias.grad.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("C", [16, 32, 64])
+def test_intra_conv_gradients_vs_autograd(C):
+    import etch_amd.vgtk_so3conv as V
+    from etch_amd import autograd as A
+    from etch_amd.utils.weights import load_seeded
+    from oracle import stage1 as S1
+    b, p = 2, 37
+    rng = np.random.default_rng(C)
+    conv = load_seeded(V.IntraSO3Conv(C, C), 7).cuda().eval()
+    ii = conv.intra_idx.cpu()
+    x = torch.from_numpy(rng.standard_normal((b, C, p, 60))).double().requires_grad_()
+    W = conv.basic_conv.W.detach().cpu().double().requires_grad_()
+    bias = conv.basic_conv.bias.detach().cpu().double().requires_grad_()
+    gf = x.index_select(3, ii.view(-1)).view(b, C, p, 60, 12).permute(0, 1, 4, 2, 3).contiguous()        # functional.py:343-344
+    y_ref = S1.basic_so3conv(W, bias, gf)
+    G = torch.from_numpy(rng.standard_normal(tuple(y_ref.shape)))
+    (y_ref * G).sum().backward()
+    x_cl = x.detach().float().permute(0, 2, 3, 1).contiguous().cuda().requires_grad_()
+    Wg = conv.basic_conv.W.detach().clone().requires_grad_()
+    bg = conv.basic_conv.bias.detach().clone().requires_grad_()
+    y = A.intra_so3conv(x_cl, Wg, bg, conv.intra_idx)
+    assert rel_err(y.detach().cpu().permute(0, 3, 1, 2).numpy(), y_ref.detach().numpy()) < 1e-4
+    (y * G.float().permute(0, 2, 3, 1).contiguous().cuda()).sum().backward()
+    assert rel_err(x_cl.grad.cpu().permute(0, 3, 1, 2).numpy(), x.grad.numpy()) < 1e-4
+    assert rel_err(Wg.grad.cpu().numpy(), W.grad.numpy()) < 1e-4
+    assert rel_err(bg.grad.cpu().numpy(), bias.grad.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("C,p", [(32, 41), (64, 130)])
+def test_instancenorm_leaky_relu_gradient_vs_autograd(C, p):
+    from etch_amd import autograd as A
+    rng = np.random.default_rng(C + p)
+    x = torch.from_numpy(rng.standard_normal((2, C, p, 60)) * 1.7 + 0.3).double().requires_grad_()
+    y_ref = F.leaky_relu(F.instance_norm(x, eps=1e-5), 0.01)
+    G = torch.from_numpy(rng.standard_normal(tuple(y_ref.shape)))
+    (y_ref * G).sum().backward()
+    x_cl = x.detach().float().permute(0, 2, 3, 1).contiguous().cuda().requires_grad_()
+    y = A.instnorm_leaky_relu(x_cl)
+    assert rel_err(y.detach().cpu().permute(0, 3, 1, 2).numpy(), y_ref.detach().numpy()) < 1e-5
+    (y * G.float().permute(0, 2, 3, 1).contiguous().cuda()).sum().backward()
+    assert rel_err(x_cl.grad.cpu().permute(0, 3, 1, 2).numpy(), x.grad.numpy()) < 1e-4
+
+
+def test_gemm_tn_and_colsum():
+    from etch_amd import autograd as A
+    rng = np.random.default_rng(0)
+    for R, M, N in ((5000, 64, 1536), (777, 32, 48), (33, 16, 16)):
+        a = torch.from_numpy(rng.standard_normal((R, M)).astype(np.float32)).cuda()
+        bm = torch.from_numpy(rng.standard_normal((R, N)).astype(np.float32)).cuda()
+        c = A.gemm_tn(a, bm)
+        ref = a.double().cpu().t() @ bm.double().cpu()
+        assert rel_err(c.cpu().numpy(), ref.numpy()) < 1e-5
+        c2 = A.gemm_tn(a, bm, out=c.clone(), accumulate=True)
+        assert rel_err(c2.cpu().numpy(), 2 * ref.numpy()) < 1e-5
+        assert rel_err(A.colsum(a).cpu().numpy(), a.double().cpu().sum(0).numpy()) < 1e-6
