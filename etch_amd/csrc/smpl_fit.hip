@@ -465,15 +465,29 @@ __device__ void lm_linearize(LmShared<BM>& s, const SmplConsts& C, int M, int nb
     if (tid == 0) { const long long t1 = wall_clock64(); s.phase[2] += t1 - t0; }
 }
 
-// delta = (J^T J + lambda I)^-1 J^T (-r) from the packed normal equations left by lm_linearize
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// delta = (J^T J + lambda I)^-1 J^T (-r) from the packed normal equations left by lm_linearize.
+// Large systems (the 188-DoF model): blocked right-looking Cholesky of the packed lower triangle, 16 pivots per block, the right-hand
+// side carried as the extra row DOF (its panel solves ARE the forward substitution y = L^-1 g).  Per block: (1) one wave factors the 16 x 16 diagonal block in
+// registers (a lane per row, pivots broadcast with v_readlane); (2) a thread per row below solves its 16 entries against it;
+// (3) the trailing matrix takes the rank-16 update on the fp64 matrix cores, one 16 x 16 tile per wave at a time.  3 barriers per
+// block (18 for SMPL, 36 for the 188-DoF model) instead of one per column (85 / 188).
 template <class BM>
 __device__ void lm_solve(LmShared<BM>& s, double lambda) {
-    constexpr int DOF = BM::DOF, NPACK = BM::NPACK;
-    const int tid = threadIdx.x, lane = tid & 63;
+    constexpr int DOF = BM::DOF, N = BM::DOF, NPACK = BM::NPACK;
+    constexpr int NBLK = (N + 15) / 16;                 // pivot blocks
+    constexpr int NRT = (N + 1 + 15) / 16;              // row tiles of the (N + 1)-row matrix
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     long long t0 = 0;
     if (tid == 0) t0 = wall_clock64();
-    if (tid < DOF) Apk(s.A, tid, tid) += lambda;
+    for (int i = tid; i < N; i += BM::THREADS) Apk(s.A, i, i) += lambda;
     __syncthreads();
+    if constexpr (N <= 100) {
+    // Small systems (SMPL: 85 pivots): column by column.  Measured 34 us against 38 us for the blocked form below, whose per-block
+    // sequential parts (diagonal factor by one wave, 16-step panel solves) do not amortise over 6 blocks.
     // Right-looking Cholesky of the packed lower triangle with the rhs carried as an extra row (gives y = L^-1 g for
     // free), ONE barrier per column: the trailing update uses the unscaled column, A_ij -= A_ik A_jk / A_kk; columns
     // are scaled to L in one pass at the end.  The pair enumeration e -> (ii, jj) does not depend on the column.
@@ -518,6 +532,86 @@ __device__ void lm_solve(LmShared<BM>& s, double lambda) {
         if (e < NPACK && i != k && k < DOF) s.A[e] *= s.rdiag[k];
     }
     __syncthreads();
+    } else {
+#pragma unroll 1
+    for (int kb = 0; kb < NBLK; ++kb) {
+        const int c0 = 16 * kb;
+        const int w = N - c0 < 16 ? N - c0 : 16;        // pivots of this block
+        const int c1 = c0 + w;
+        // ---- (1) diagonal block: lane r < w holds row c0 + r; rows / columns >= w are identity padding
+        if (wave == 0) {
+            double a[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = (lane < w && c <= lane) ? Apk(s.A, c0 + lane, c0 + c) : (c == lane ? 1.0 : 0.0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double dj = sqrt(readlane_f64(a[j], j));
+                const double lj = lane == j ? dj : a[j] * (1.0 / dj);       // column j of L (lanes >= j)
+                a[j] = lj;
+#pragma unroll
+                for (int c = j + 1; c < 16; ++c) {
+                    const double lc = readlane_f64(lj, c);
+                    a[c] -= lane >= c ? lj * lc : 0.0;
+                }
+            }
+            if (lane < w) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (c <= lane) Apk(s.A, c0 + lane, c0 + c) = a[c];
+                double dl = a[0];
+#pragma unroll
+                for (int c = 1; c < 16; ++c) dl = lane == c ? a[c] : dl;
+                s.rdiag[c0 + lane] = 1.0 / dl;
+            }
+        }
+        __syncthreads();
+        // ---- (2) panel: rows c1 .. N (the last one is the right-hand side), a thread per row
+        for (int i = c1 + tid; i <= N; i += BM::THREADS) {
+            double x[16];
+            double* row = s.A + i * (i + 1) / 2 + c0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                if (c < w) {
+                    double v = row[c];
+                    const double* lrow = s.A + (c0 + c) * (c0 + c + 1) / 2 + c0;
+#pragma unroll
+                    for (int k = 0; k < c; ++k) v -= x[k] * lrow[k];
+                    x[c] = v * s.rdiag[c0 + c];
+                    row[c] = x[c];
+                } else x[c] = 0.0;
+            }
+        }
+        __syncthreads();
+        // ---- (3) trailing update A_ij -= sum_k L_ik L_jk over the block's 16 columns, 16 x 16 tiles (ti >= tj > kb) on v_mfma_f64_16x16x4_f64
+        if (w == 16) {
+            const int T = NRT - (kb + 1);               // trailing row tiles
+            const int ntile = T * (T + 1) / 2;
+            const int fr = lane & 15, fg = lane >> 4;
+            for (int tile = wave; tile < ntile; tile += BM::WAVES) {
+                int ti = 0;
+                while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+                const int tj = tile - ti * (ti + 1) / 2;
+                const int ri = 16 * (kb + 1 + ti) + fr, rj = 16 * (kb + 1 + tj) + fr;          // operand rows of this lane
+                const bool vi = ri <= N, vj = rj <= N;
+                const double* pi = s.A + (vi ? ri : N) * ((vi ? ri : N) + 1) / 2 + c0 + fg;
+                const double* pj = s.A + (vj ? rj : N) * ((vj ? rj : N) + 1) / 2 + c0 + fg;
+                f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double av = vi ? pi[4 * t] : 0.0, bv = vj ? pj[4 * t] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+                // D[row = fg + 4 q][col = fr]
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int gi = 16 * (kb + 1 + ti) + fg + 4 * q, gj = 16 * (kb + 1 + tj) + fr;
+                    if (gi <= N && gj < N && gj <= gi) Apk(s.A, gi, gj) -= acc[q];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    }
     if (tid == 0) { const long long t1 = wall_clock64(); s.phase[3] += t1 - t0; t0 = t1; }
     // back substitution L^T delta = y by one wave (lane owns rows lane, lane + 64, ...); pivots broadcast with v_readlane
     if (tid < 64) {

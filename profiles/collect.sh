@@ -1,0 +1,51 @@
+#!/bin/bash
+# Collects the profiles committed under profiles/ for one round (run on the GPU box through gpurun, from the repo root):
+#   bash profiles/collect.sh r02
+# rocprofv3 passes (kernel trace / PMC in SEPARATE runs, the program itself after `--`), summarised on the box into small text / json
+# files under gpurun_out/ (the sqlite traces are deleted: gpurun_out is capped at 64 MiB).
+set -u
+tag=${1:-rXX}
+R=$PWD
+O=$R/gpurun_out/$tag
+mkdir -p $O
+export TMPDIR=/tmp
+run() { name=$1; shift; rocprofv3 "$@" > $O/$name.log 2>&1; }
+# default (overlapped) schedule and the serial schedule (every kernel on one stream: a duration is the kernel's own)
+run trace_default --kernel-trace --stats -d $O/prof_default -o default -- python3 $R/bench.py --steps 16 --warmup 3 --no-cpu-baseline
+grep '^{' $O/trace_default.log | tail -1 > $O/${tag}_bench_line_under_rocprof.json
+db=$(find $O/prof_default -name '*_results.db' | head -1)
+python3 profiles/summarize_rocpd.py $db > $O/${tag}_kernel_stats.txt
+python3 profiles/timeline_rocpd.py $db > $O/${tag}_stream_timeline.txt 2>&1
+rm -rf $O/prof_default
+run trace_serial --kernel-trace --stats -d $O/prof_serial -o serial -- python3 $R/bench.py --serial --steps 16 --warmup 3 --no-cpu-baseline
+db=$(find $O/prof_serial -name '*_results.db' | head -1)
+python3 profiles/summarize_rocpd.py $db > $O/${tag}_serial_kernel_stats.txt
+rm -rf $O/prof_serial
+# HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes of the same command
+run pmc_fetch --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o fetch -- python3 $R/bench.py --serial --steps 1 --warmup 1 --no-cpu-baseline
+run pmc_write --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o write -- python3 $R/bench.py --serial --steps 1 --warmup 1 --no-cpu-baseline
+python3 profiles/pmc_traffic.py $(find $O/pmc_fetch -name '*_results.db' | head -1) $(find $O/pmc_write -name '*_results.db' | head -1) > $O/${tag}_pmc_traffic.json
+rm -rf $O/pmc_fetch $O/pmc_write
+# matrix-pipe / wave-cycle counters of the dominant kernels
+run pmc_busy --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d $O/pmc_busy -o busy -- python3 $R/bench.py --serial --steps 1 --warmup 1 --no-cpu-baseline
+python3 - $(find $O/pmc_busy -name '*_results.db' | head -1) > $O/${tag}_pmc_mfma.txt <<'PY'
+import sqlite3, sys, re, collections
+c = sqlite3.connect(sys.argv[1])
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.Counter()
+for name, ctr, val in c.execute("select kernel_name, counter_name, value from counters_collection"):
+    k = re.sub(r"\(.*", "", re.sub(r"^void ", "", name))
+    agg[k][ctr] += val
+for (name,) in c.execute("select kernel_name from counters_collection where counter_name = 'SQ_WAVE_CYCLES'"):
+    cnt[re.sub(r"\(.*", "", re.sub(r"^void ", "", name))] += 1
+print("# per kernel, summed over the profiled launches: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES (matrix pipe busy share), wave cycles")
+for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:14]:
+    busy = d.get("SQ_BUSY_CYCLES", 0) or 1
+    print(f"{k[:70]:70s} launches {cnt[k]:4d}  mfma_busy/busy {d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / busy:6.3f}  wave_cycles {d.get('SQ_WAVE_CYCLES', 0):.3e}  mfma_mops_f32 {d.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0):.3e}")
+PY
+rm -rf $O/pmc_busy
+# the bench lines themselves (default run with the CPU baseline; forward only; the dense SMPL-X-sized config; two ranks on this one GPU)
+python3 $R/bench.py > $O/${tag}_bench_line_default_run.json 2> $O/bench_default.err
+python3 $R/bench.py --config 1 --steps 10 > $O/${tag}_bench_line_config1_forward_only.json 2> $O/bench_c1.err
+python3 $R/bench.py --config 4 --steps 5 --warmup 2 > $O/${tag}_bench_line_config4_dense20k_smplx.json 2> $O/bench_c4.err
+ls -la $O
