@@ -38,10 +38,11 @@ for name, ctr, val in c.execute("select kernel_name, counter_name, value from co
     agg[k][ctr] += val
 for (name,) in c.execute("select kernel_name from counters_collection where counter_name = 'SQ_WAVE_CYCLES'"):
     cnt[re.sub(r"\(.*", "", re.sub(r"^void ", "", name))] += 1
-print("# per kernel, summed over the profiled launches: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES (matrix pipe busy share), wave cycles")
+print("# per kernel, summed over the profiled launches.  SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, SQ_BUSY_CYCLES over the 32 shader")
+print("# engines: matrix-pipe busy share of the kernel = (MFMA_BUSY / 1024) / (SQ_BUSY / 32)")
 for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:14]:
     busy = d.get("SQ_BUSY_CYCLES", 0) or 1
-    print(f"{k[:70]:70s} launches {cnt[k]:4d}  mfma_busy/busy {d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / busy:6.3f}  wave_cycles {d.get('SQ_WAVE_CYCLES', 0):.3e}  mfma_mops_f32 {d.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0):.3e}")
+    print(f"{k[:70]:70s} launches {cnt[k]:4d}  matrix pipe busy {d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / busy / 32.0:6.3f}  MFMA_BUSY {d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0):.3e}  SQ_BUSY {busy:.3e}  wave_cycles {d.get('SQ_WAVE_CYCLES', 0):.3e}")
 PY
 rm -rf $O/pmc_busy
 # the bench lines themselves (default run with the CPU baseline; forward only; the dense SMPL-X-sized config; two ranks on this one GPU)

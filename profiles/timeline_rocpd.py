@@ -27,7 +27,7 @@ def union(iv):
 def main(path):
     c = sqlite3.connect(path)
     rows = c.execute("select name, start, end, queue_id, stream_id from kernels order by start").fetchall()
-    lm = [r for r in rows if r[0].startswith("smpl_lm_fit_kernel")]
+    lm = [r for r in rows if "smpl_lm_fit_kernel" in r[0]]
     # pipelined steps: the fits that ran on the dedicated stage-2 stream (the stream that carries nothing but the fit, the final
     # LBS and copies); fits of synchronous steps run on the stream that also carries the network
     names = {}
