@@ -29,14 +29,15 @@
 // chunk and consumed by the Cholesky solve before the next linearisation.
 #include "common.h"
 
-#define LM_MAXM 128                 // markers per scan
+#define LM_MAXM 96                  // markers per scan
 #define NB_STAGE0 2                 // fit_SMPL.py:161-165: stage 0 optimises betas[:2]
 
 template <int NJ_, int NB_, int THREADS_>
 struct Body {
     static constexpr int NJ = NJ_, NB = NB_;
     static constexpr int THREADS = THREADS_, WAVES = THREADS_ / 64;   // one workgroup per scan
-    static constexpr int CHUNK_ROWS = 3 * WAVES;        // markers are linearised WAVES at a time, 3 Jacobian rows each
+    static constexpr int MC = THREADS_ / NJ_;           // markers linearised per chunk: one (marker, joint) item per thread (SMPL 32, 188-DoF model 9)
+    static constexpr int CHUNK_ROWS = (3 * MC + 3) & ~3; // Jacobian rows of a chunk, padded to a multiple of 4 (MFMA K-steps); padding rows stay zero
     static constexpr int NPOSE = 3 * (NJ - 1);          // body pose variables
     static constexpr int NPF = 9 * (NJ - 1);            // pose-feature entries vec(R_k - I)
     static constexpr int DOF = NPOSE + NB + 6;
@@ -46,10 +47,10 @@ struct Body {
     static constexpr int NTILES = NT * (NT + 1) / 2;    // lower triangle
     static constexpr int TPW = (NTILES + WAVES - 1) / WAVES;
     static constexpr int NPACK = (DOF + 1) * (DOF + 2) / 2;
-    static constexpr bool STAGE_P = NJ <= 24;           // the marker's posedirs columns staged in LDS (SMPL) or read through L1/L2
-    static constexpr int PFL = (3 * NPF + 63) / 64;     // floats per lane of a marker's posedirs block
-    static constexpr int NSW = 3 * NB + NJ;             // shapedirs rows + skinning weights of a marker
-    static constexpr int SWL = (NSW + 63) / 64;
+    static constexpr int VPARTS = 8;                    // lanes sharing one posed-vertex dot product
+    static constexpr int EPP = (NPF + VPARTS - 1) / VPARTS;
+    static constexpr int NQ = (3 * NB + 15) & ~15;      // beta-gradient columns, padded to MFMA tiles
+    static constexpr int EPU = EPP <= 32 ? (EPP + 1) / 2 : 16;   // posedirs rows loaded back to back per wait (3 floats each)
 };
 
 struct SmplConsts {
@@ -113,25 +114,20 @@ __device__ inline void fk_chain(int nj, const int* parents, const double* R, con
 
 // ---------------------------------------------------------------------------------------------- LM fit
 template <class BM>
-struct LmWaveScratch {                // per-wave staging of one marker
-    float P[BM::STAGE_P ? 3 * BM::NPF + 3 : 4];   // posedirs columns of the marker: [NPF][3]
-    float Ay[BM::NJ][4];              // W_vj * y_vj (xyz) and W_vj
-    float U[BM::NJ][4];               // subtree sum of Ay minus w * tw_k
-    float T[12];                      // sum_j W_vj Rw_j
-    float S[(3 * BM::NB + 3) & ~3];   // shapedirs rows of the marker [3][NB]
-};
-
-template <class BM>
 struct LmLin {                        // linearisation scratch (dead during the solve)
     double R[BM::NJ * 9], Rw[BM::NJ * 9], tw[BM::NJ * 3], Jj[BM::NJ * 3];
+    double Ab[BM::NJ * 3];            // tw_j - Rw_j J_j
+    double vp[LM_MAXM][3];            // posed marker vertices  v_t + S beta + P^T pf
+    double Tbd[LM_MAXM][12];          // blended skinning transform sum_j W_vj [Rw_j | tw_j - Rw_j J_j]: rows a = 3 rotation entries + translation
+    float Wq[LM_MAXM][BM::NQ];        // sum_j W_vj d(tw_j - Rw_j J_j)/d beta_l  (column l*3 + a)
     float dR[BM::NJ][3][9];
     float omega[BM::NJ][3][4];
     float twd[BM::NB][BM::NJ][3];
     float pf[BM::NPF + 1];
     float Jd[BM::NJ * 3 * BM::NB];    // LDS copy of the joint shape basis
     float J0[BM::NJ * 3];
-    LmWaveScratch<BM> ws[BM::WAVES];
-    float Jc[2][BM::CHUNK_ROWS * BM::LDJS];   // double-buffered Jacobian chunk: 3 rows per wave, column DOF = residual
+    float Ay[BM::MC][BM::NJ][4];      // per chunk: W_vj * y_vj (xyz) and W_vj
+    float Jc[2][BM::CHUNK_ROWS * BM::LDJS];   // double-buffered Jacobian chunk: 3 rows per marker, column DOF = residual
 };
 
 template <class BM>
@@ -171,6 +167,7 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 }
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // per-scan constants into LDS: parents, targets, subtree membership masks
 template <class BM>
@@ -268,6 +265,11 @@ __device__ void lm_linearize(LmShared<BM>& s, const SmplConsts& C, int M, int nb
         }
     }
     __syncthreads();
+    for (int e = tid; e < NJ * 3; e += BM::THREADS) {        // translation column of the skinning transform of joint j
+        const int j = e / 3, a = e - j * 3;
+        const double* Rj = L.Rw + j * 9 + a * 3;
+        L.Ab[e] = L.tw[e] - (Rj[0] * L.Jj[j * 3] + Rj[1] * L.Jj[j * 3 + 1] + Rj[2] * L.Jj[j * 3 + 2]);
+    }
     for (int e = tid; e < NB * NJ * 3; e += BM::THREADS) {   // Q[l][j] = d tw_j/d beta_l - Rw_j Jd_j[:,l]  (in place)
         const int l = e / (NJ * 3), r = e - l * NJ * 3, j = r / 3, a = r - j * 3;
         const double* Rj = L.Rw + j * 9;
@@ -276,9 +278,113 @@ __device__ void lm_linearize(LmShared<BM>& s, const SmplConsts& C, int M, int nb
     __syncthreads();
     if (tid == 0) { const long long t1 = wall_clock64(); s.phase[0] += t1 - t0; t0 = t1; }
 
-    // ---- markers, 12 at a time (one per wave): forward, residual, the marker's three Jacobian rows into the chunk buffer; then every
-    // wave adds the chunk's contribution to its tiles of [J | r]^T [J | r] on the fp64 matrix cores.
-    LmWaveScratch<BM>& w = L.ws[wave];
+    // ---- markers as flat passes of the whole workgroup:
+    //   A   (all markers) posed vertices v_p = v_t + S beta + P^T pf; 8 lanes stream one marker's contiguous posedirs block
+    //   A2  (all markers, matrix cores) blended skinning transform Tbd = W [Rw | tw - Rw J] (fp64) and Wq = W Q (the joint-chain part of
+    //       the beta columns): the skinning weights are the A operand of both products
+    //   A3  residuals from Tbd and v_p (fp64)
+    //   per chunk of MC markers (one (marker, joint) item per thread):
+    //   B   per-joint contributions Ay = W_vj (Rw_j (v_p - J_j) + tw_j); the joint's posedirs block and the shapedirs entries needed in C
+    //       are requested here
+    //   C   the chunk's Jacobian rows: thread (m, k) writes joint k's three rotation columns (subtree sum + posedirs block), thread
+    //       (m, u) a beta column or the translation / residual / padding columns
+    //   then every wave adds the chunk's contribution to its tiles of [J | r]^T [J | r] on the fp64 matrix cores (double-buffered chunk).
+    constexpr int MC = BM::MC, NQ = BM::NQ;
+    long long tp = 0;
+    if (tid == 0) tp = wall_clock64();
+    for (int it = tid; it < M * BM::VPARTS; it += BM::THREADS) {
+        const int part = it % BM::VPARTS, v = it / BM::VPARTS;
+        const float* Pg = C.mk_P + (size_t)v * 3 * NPF;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        const int e0 = part * BM::EPP;
+#pragma unroll 1
+        for (int i0 = 0; i0 < BM::EPP; i0 += BM::EPU) {            // EPU rows (3 floats each) in flight per wait
+            float pv[BM::EPU][3];
+#pragma unroll
+            for (int i = 0; i < BM::EPU; ++i) {
+                const int e = e0 + i0 + i;
+                const float* q = Pg + (e < NPF && i0 + i < BM::EPP ? e : 0) * 3;
+                pv[i][0] = q[0]; pv[i][1] = q[1]; pv[i][2] = q[2];
+            }
+#pragma unroll
+            for (int i = 0; i < BM::EPU; ++i) {
+                const int e = e0 + i0 + i;
+                const double f = e < NPF && i0 + i < BM::EPP ? (double)L.pf[e] : 0.0;
+                s0 += f * (double)pv[i][0]; s1 += f * (double)pv[i][1]; s2 += f * (double)pv[i][2];
+            }
+        }
+        if (part < 3) {                                       // lane `part` adds component `part` of v_t + S beta
+            double t = (double)C.mk_vt[v * 3 + part];
+            const float* Sg = C.mk_S + ((size_t)v * 3 + part) * NB;
+            for (int l = 0; l < NB; ++l) t += (double)Sg[l] * s.x[NPOSE + l];
+            s0 += part == 0 ? t : 0.0; s1 += part == 1 ? t : 0.0; s2 += part == 2 ? t : 0.0;
+        }
+#pragma unroll
+        for (int o = 1; o < BM::VPARTS; o <<= 1) {
+            s0 += __hiloint2double(__shfl_xor(__double2hiint(s0), o, 64), __shfl_xor(__double2loint(s0), o, 64));
+            s1 += __hiloint2double(__shfl_xor(__double2hiint(s1), o, 64), __shfl_xor(__double2loint(s1), o, 64));
+            s2 += __hiloint2double(__shfl_xor(__double2hiint(s2), o, 64), __shfl_xor(__double2loint(s2), o, 64));
+        }
+        if (part == 0) { L.vp[v][0] = s0; L.vp[v][1] = s1; L.vp[v][2] = s2; }
+    }
+    // ---- A2 (independent of A): one 16-marker row tile per wave and product
+    {
+        const int fr = lane & 15, fg = lane >> 4;
+        const int nrt = (M + 15) >> 4;
+        constexpr int KJ = (NJ + 3) / 4;                      // K-steps over the joints
+        for (int tile = wave; tile < nrt * (1 + NQ / 16); tile += BM::WAVES) {
+            const int rt = tile % nrt, ct = tile / nrt;       // ct = 0: Tbd (fp64);  ct >= 1: Wq column tile ct - 1 (fp32)
+            const int v = 16 * rt + fr;
+            const float* Wg = C.mk_W + (size_t)(v < M ? v : 0) * NJ;
+            if (ct == 0) {
+                f64x4 d = {0.0, 0.0, 0.0, 0.0};
+                const int a = fr >> 2, c = fr & 3;
+#pragma unroll 2
+                for (int t = 0; t < KJ; ++t) {
+                    const int j = 4 * t + fg;
+                    const bool jo = j < NJ;
+                    const double av = jo && v < M ? (double)Wg[j] : 0.0;
+                    const double bv = !jo || fr >= 12 ? 0.0 : (c < 3 ? L.Rw[j * 9 + a * 3 + c] : L.Ab[j * 3 + a]);
+                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, d, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                 // D[row = fg + 4 q][col = fr]
+                    const int vr = 16 * rt + fg + 4 * q;
+                    if (vr < M && fr < 12) L.Tbd[vr][fr] = d[q];
+                }
+            } else {
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+                const int n = 16 * (ct - 1) + fr, l = n / 3, a = n - 3 * l;
+#pragma unroll 2
+                for (int t = 0; t < KJ; ++t) {
+                    const int j = 4 * t + fg;
+                    const bool jo = j < NJ;
+                    const float av = jo && v < M ? Wg[j] : 0.f;
+                    const float bv = jo && l < NB ? L.twd[l][j][a] : 0.f;
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, d, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                 // D[row = 4 fg + q][col = fr]
+                    const int vr = 16 * rt + 4 * fg + q;
+                    if (vr < M) L.Wq[vr][n] = d[q];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- A3
+    for (int it = tid; it < M * 3; it += BM::THREADS) {
+        const int v = it / 3, a = it - 3 * v;
+        const double* tb = L.Tbd[v] + 4 * a;
+        const double xv = tb[0] * L.vp[v][0] + tb[1] * L.vp[v][1] + tb[2] * L.vp[v][2] + tb[3];
+        s.resid[it] = (float)((double)s.mask[v] * ((double)s.target[it] - (xv + s.x[NPOSE + NB + 3 + a])));
+    }
+    if (BM::CHUNK_ROWS > 3 * MC)                                 // K-step padding rows of both chunk buffers
+        for (int e = tid; e < 2 * (BM::CHUNK_ROWS - 3 * MC) * LDJS; e += BM::THREADS) {
+            const int bsel = e / ((BM::CHUNK_ROWS - 3 * MC) * LDJS), r = e - bsel * (BM::CHUNK_ROWS - 3 * MC) * LDJS;
+            L.Jc[bsel][3 * MC * LDJS + r] = 0.f;
+        }
+    if (tid == 0) { const long long t1 = wall_clock64(); s.phase[5] += t1 - tp; tp = t1; }
     f64x4 acc[BM::TPW];
     int tmi[BM::TPW], tnj[BM::TPW];
 #pragma unroll
@@ -289,150 +395,133 @@ __device__ void lm_linearize(LmShared<BM>& s, const SmplConsts& C, int M, int nb
         while ((mi + 1) * (mi + 2) / 2 <= tile) ++mi;
         tmi[t] = mi; tnj[t] = tile - mi * (mi + 1) / 2;            // nj <= mi
     }
-    float pre[BM::PFL + BM::SWL];              // register prefetch of the next marker's P and S|W
-    auto fetch = [&](int v) {
-        const float* Pg = C.mk_P + (size_t)v * 3 * NPF;
-#pragma unroll
-        for (int q = 0; q < BM::PFL; ++q) { const int i = lane + 64 * q; pre[q] = i < 3 * NPF ? Pg[i] : 0.f; }
-#pragma unroll
-        for (int q = 0; q < BM::SWL; ++q) {
-            const int i = lane + 64 * q;
-            pre[BM::PFL + q] = i < 3 * NB ? C.mk_S[(size_t)v * 3 * NB + i] : (i < BM::NSW ? C.mk_W[(size_t)v * NJ + i - 3 * NB] : 0.f);
-        }
-    };
-    if (wave < M) fetch(wave);
-    const int nchunk = (M + BM::WAVES - 1) / BM::WAVES;
+    const int nchunk = (M + MC - 1) / MC;
+    constexpr int NU = NB + 1;                                     // (marker, u) items of pass C besides the joints
     for (int ch = 0; ch < nchunk; ++ch) {
-        const int v = ch * BM::WAVES + wave;
-        float* Jr = L.Jc[ch & 1] + (size_t)(wave * 3) * LDJS;
-        if (v < M) {
-            // this marker's P^T pf partial sums straight from the prefetch registers; S | W into the wave scratch
-            double acc3[3] = {0.0, 0.0, 0.0};
+        const int v0 = ch * MC;
+        float* Jb = L.Jc[ch & 1];
+        if (tid == 0) tp = wall_clock64();
+        // ---- B: thread (m, j)
+        const int jm = tid / NJ, jj = tid - jm * NJ, jv = v0 + jm;
+        const bool jlive = tid < MC * NJ && jv < M;
+        float Pk[27];
+        if (tid < MC * NJ) {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (jlive) {
+                const double wj = (double)C.mk_W[(size_t)jv * NJ + jj];
+                if (jj >= 1) {
+                    const float* P = C.mk_P + (size_t)jv * 3 * NPF + (jj - 1) * 27;
 #pragma unroll
-            for (int q = 0; q < BM::PFL; ++q) {
-                const int i = lane + 64 * q;
-                if (i < 3 * NPF) {
-                    if (BM::STAGE_P) w.P[i] = pre[q];
-                    const int e = i / 3, a = i - 3 * e;
-                    const double t = (double)L.pf[e] * (double)pre[q];
-                    acc3[0] += a == 0 ? t : 0.0; acc3[1] += a == 1 ? t : 0.0; acc3[2] += a == 2 ? t : 0.0;
+                    for (int e = 0; e < 27; ++e) Pk[e] = P[e];
                 }
+                const double* Rj = L.Rw + jj * 9;
+                const double d[3] = {L.vp[jv][0] - L.Jj[jj * 3], L.vp[jv][1] - L.Jj[jj * 3 + 1], L.vp[jv][2] - L.Jj[jj * 3 + 2]};
+                o.x = (float)(wj * (Rj[0] * d[0] + Rj[1] * d[1] + Rj[2] * d[2] + L.tw[jj * 3]));
+                o.y = (float)(wj * (Rj[3] * d[0] + Rj[4] * d[1] + Rj[5] * d[2] + L.tw[jj * 3 + 1]));
+                o.z = (float)(wj * (Rj[6] * d[0] + Rj[7] * d[1] + Rj[8] * d[2] + L.tw[jj * 3 + 2]));
+                o.w = (float)wj;
             }
-#pragma unroll
-            for (int q = 0; q < BM::SWL; ++q) {
-                const int i = lane + 64 * q;
-                if (i < 3 * NB) {                                  // + S beta, one (c,l) term per lane
-                    w.S[i] = pre[BM::PFL + q];
-                    const int c = i / NB, l = i - c * NB;
-                    const double sb = (double)pre[BM::PFL + q] * s.x[NPOSE + l];
-                    acc3[0] += c == 0 ? sb : 0.0; acc3[1] += c == 1 ? sb : 0.0; acc3[2] += c == 2 ? sb : 0.0;
-                } else if (i < BM::NSW) w.Ay[i - 3 * NB][3] = pre[BM::PFL + q];
-            }
-            if (v + BM::WAVES < M) fetch(v + BM::WAVES);
-            __builtin_amdgcn_wave_barrier();
-            // posed vertex v_p = v_t + S beta + P^T pf
-            double vp[3];
-            for (int c = 0; c < 3; ++c) vp[c] = wave_sum_f64(acc3[c]) + (double)C.mk_vt[v * 3 + c];
-            // per-joint contribution y_j (lane j)
-            double xy[3] = {0.0, 0.0, 0.0};
-            if (lane < NJ) {
-                const int j = lane;
-                const double wj = (double)w.Ay[j][3];
-                const double* Rj = L.Rw + j * 9;
-                const double d[3] = {vp[0] - L.Jj[j * 3], vp[1] - L.Jj[j * 3 + 1], vp[2] - L.Jj[j * 3 + 2]};
-                for (int a = 0; a < 3; ++a) {
-                    const double y = Rj[a * 3] * d[0] + Rj[a * 3 + 1] * d[1] + Rj[a * 3 + 2] * d[2] + L.tw[j * 3 + a];
-                    xy[a] = wj * y;
-                    w.Ay[j][a] = (float)xy[a];
-                }
-            }
-            double xv[3];
-            for (int a = 0; a < 3; ++a) xv[a] = wave_sum_f64(xy[a]);
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 9) {                          // T = sum_j W_vj Rw_j
-                double t = 0.0;
-#pragma unroll 8
-                for (int j = 0; j < NJ; ++j) t += (double)w.Ay[j][3] * L.Rw[j * 9 + lane];
-                w.T[lane] = (float)t;
-            }
-            if (lane < NJ) {                         // subtree sums relative to the joint origin
-                const int k = lane;
-                const unsigned long long m = s.sub[k];
+            *reinterpret_cast<float4*>(L.Ay[jm][jj]) = o;
+        }
+        // shapedirs entries of this thread's beta item of pass C
+        const int um = tid / NU, uu = tid - um * NU, uv = v0 + um;
+        const bool ulive = tid < MC * NU && uv < M;
+        float sv0 = 0.f, sv1 = 0.f, sv2 = 0.f;
+        if (ulive && uu < nb) { const float* Sg = C.mk_S + (size_t)uv * 3 * NB + uu; sv0 = Sg[0]; sv1 = Sg[NB]; sv2 = Sg[2 * NB]; }
+        __syncthreads();
+        if (tid == 0) { const long long t1 = wall_clock64(); s.phase[6] += t1 - tp; tp = t1; }
+        // ---- C: thread (m, k) writes joint k's three rotation columns of marker m ...
+        if (tid < MC * NJ) {
+            const int m = jm, k = jj, v = jv;
+            float* Jr = Jb + (size_t)(m * 3) * LDJS;
+            const float mk = jlive ? s.mask[v] : 0.f;
+            float d[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};     // [c][a]
+            if (jlive) {
+                const unsigned long long msk = s.sub[k];
                 float u0 = 0.f, u1 = 0.f, u2 = 0.f, uw = 0.f;
-                for (int j = 0; j < NJ; ++j)
-                    if ((m >> j) & 1ull) { u0 += w.Ay[j][0]; u1 += w.Ay[j][1]; u2 += w.Ay[j][2]; uw += w.Ay[j][3]; }
-                w.U[k][0] = u0 - uw * (float)L.tw[k * 3]; w.U[k][1] = u1 - uw * (float)L.tw[k * 3 + 1]; w.U[k][2] = u2 - uw * (float)L.tw[k * 3 + 2];
-            }
-            __builtin_amdgcn_wave_barrier();
-            const float mk = s.mask[v];
-            float rres = 0.f;
-            if (lane < 3) {
-                rres = (float)((double)mk * ((double)s.target[v * 3 + lane] - (xv[lane] + s.x[NPOSE + NB + 3 + lane])));
-                s.resid[v * 3 + lane] = rres;
-            }
-            const float r0 = __shfl(rres, 0, 64), r1 = __shfl(rres, 1, 64), r2 = __shfl(rres, 2, 64);
-            for (int col = lane; col < LDJ; col += 64) {
-                float d[3] = {0.f, 0.f, 0.f};
-                if (col < NPOSE || (col >= NPOSE + NB && col < NPOSE + NB + 3)) {
-                    const int k = col < NPOSE ? 1 + col / 3 : 0;
-                    const int c = col < NPOSE ? col - 3 * (k - 1) : col - (NPOSE + NB);
+                for (int j = k; j < NJ; ++j)                  // descendants have larger indices than their ancestor
+                    if ((msk >> j) & 1ull) { const float4 ay = *reinterpret_cast<const float4*>(L.Ay[m][j]); u0 += ay.x; u1 += ay.y; u2 += ay.z; uw += ay.w; }
+                u0 -= uw * (float)L.tw[k * 3]; u1 -= uw * (float)L.tw[k * 3 + 1]; u2 -= uw * (float)L.tw[k * 3 + 2];
+                const double* Td = L.Tbd[v];
+                const float T0[3] = {(float)Td[0], (float)Td[1], (float)Td[2]}, T1[3] = {(float)Td[4], (float)Td[5], (float)Td[6]},
+                            T2[3] = {(float)Td[8], (float)Td[9], (float)Td[10]};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
                     const float* om = L.omega[k][c];
-                    const float* u = w.U[k];
-                    d[0] = om[1] * u[2] - om[2] * u[1]; d[1] = om[2] * u[0] - om[0] * u[2]; d[2] = om[0] * u[1] - om[1] * u[0];
+                    d[c][0] = om[1] * u2 - om[2] * u1; d[c][1] = om[2] * u0 - om[0] * u2; d[c][2] = om[0] * u1 - om[1] * u0;
                     if (k >= 1) {
                         const float* dr = L.dR[k][c];
                         float q0 = 0.f, q1 = 0.f, q2 = 0.f;
-                        if (BM::STAGE_P) {
-                            const float* P = w.P + (k - 1) * 27;
 #pragma unroll
-                            for (int e = 0; e < 9; ++e) { q0 += dr[e] * P[e * 3]; q1 += dr[e] * P[e * 3 + 1]; q2 += dr[e] * P[e * 3 + 2]; }
-                        } else {
-                            const float* P = C.mk_P + (size_t)v * 3 * NPF + (k - 1) * 27;      // the wave just streamed this block: L1 / L2 hit
-#pragma unroll
-                            for (int e = 0; e < 9; ++e) { q0 += dr[e] * P[e * 3]; q1 += dr[e] * P[e * 3 + 1]; q2 += dr[e] * P[e * 3 + 2]; }
-                        }
-                        for (int a = 0; a < 3; ++a) d[a] += w.T[a * 3] * q0 + w.T[a * 3 + 1] * q1 + w.T[a * 3 + 2] * q2;
+                        for (int e = 0; e < 9; ++e) { q0 += dr[e] * Pk[e * 3]; q1 += dr[e] * Pk[e * 3 + 1]; q2 += dr[e] * Pk[e * 3 + 2]; }
+                        d[c][0] += T0[0] * q0 + T0[1] * q1 + T0[2] * q2;
+                        d[c][1] += T1[0] * q0 + T1[1] * q1 + T1[2] * q2;
+                        d[c][2] += T2[0] * q0 + T2[1] * q1 + T2[2] * q2;
                     }
-                } else if (col < NPOSE + NB) {
-                    const int l = col - NPOSE;
-                    if (l < nb) {
-                        const float sv[3] = {w.S[l], w.S[NB + l], w.S[2 * NB + l]};
-                        for (int a = 0; a < 3; ++a) d[a] = w.T[a * 3] * sv[0] + w.T[a * 3 + 1] * sv[1] + w.T[a * 3 + 2] * sv[2];
-#pragma unroll 8
-                        for (int j = 0; j < NJ; ++j) {
-                            const float wj = w.Ay[j][3];
-                            d[0] += wj * L.twd[l][j][0]; d[1] += wj * L.twd[l][j][1]; d[2] += wj * L.twd[l][j][2];
-                        }
-                    }
-                } else if (col < DOF) {
-                    const int c = col - (NPOSE + NB + 3);
-                    d[0] = c == 0 ? 1.f : 0.f; d[1] = c == 1 ? 1.f : 0.f; d[2] = c == 2 ? 1.f : 0.f;
                 }
-                float j0 = -mk * d[0], j1 = -mk * d[1], j2 = -mk * d[2];
-                if (jac_out && col < DOF) {
-                    float* jo = jac_out + (size_t)(v * 3) * DOF + col;
-                    jo[0] = j0; jo[DOF] = j1; jo[2 * DOF] = j2;
-                }
-                if (col == DOF) { j0 = r0; j1 = r1; j2 = r2; }      // column DOF carries the residual, so J^T r falls out of the J^T J tiles
-                Jr[col] = j0; Jr[LDJS + col] = j1; Jr[2 * LDJS + col] = j2;
             }
-        } else {
-            for (int col = lane; col < LDJ; col += 64) { Jr[col] = 0.f; Jr[LDJS + col] = 0.f; Jr[2 * LDJS + col] = 0.f; }
+            const int col0 = k >= 1 ? 3 * (k - 1) : NPOSE + NB;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float val = -mk * d[c][a];
+                    Jr[a * LDJS + col0 + c] = val;
+                    if (jac_out && jlive) jac_out[(size_t)(v * 3 + a) * DOF + col0 + c] = val;
+                }
         }
-        __syncthreads();       // chunk complete (the other buffer is free again: every wave passed its accumulation of chunk ch-1)
+        // ... and thread (m, u): u < NB: beta column l = u; u == NB: translation columns, the residual column DOF, zero padding
+        if (tid < MC * NU) {
+            const int m = um, u = uu, v = uv;
+            float* Jr = Jb + (size_t)(m * 3) * LDJS;
+            const float mk = ulive ? s.mask[v] : 0.f;
+            if (u < NB) {
+                float d[3] = {0.f, 0.f, 0.f};
+                if (ulive && u < nb) {
+                    const double* Td = L.Tbd[v];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+                        d[a] = (float)Td[4 * a] * sv0 + (float)Td[4 * a + 1] * sv1 + (float)Td[4 * a + 2] * sv2 + L.Wq[v][u * 3 + a];
+                }
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float val = -mk * d[a];
+                    Jr[a * LDJS + NPOSE + u] = val;
+                    if (jac_out && ulive) jac_out[(size_t)(v * 3 + a) * DOF + NPOSE + u] = val;
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float val = -mk * (a == c ? 1.f : 0.f);
+                        Jr[a * LDJS + NPOSE + NB + 3 + c] = val;
+                        if (jac_out && ulive) jac_out[(size_t)(v * 3 + a) * DOF + NPOSE + NB + 3 + c] = val;
+                    }
+                    Jr[a * LDJS + DOF] = ulive ? s.resid[v * 3 + a] : 0.f;
+                    for (int col = DOF + 1; col < LDJ; ++col) Jr[a * LDJS + col] = 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) { const long long t1 = wall_clock64(); s.phase[7] += t1 - tp; }
+        // ---- the chunk's contribution to this wave's tiles
         {
-            const float* Jb = L.Jc[ch & 1];
             const int fr = lane & 15, fg = lane >> 4;
 #pragma unroll
             for (int t = 0; t < BM::TPW; ++t) {
                 if (wave + BM::WAVES * t < BM::NTILES && (!grad_only || tmi[t] == BM::NT - 1)) {
                     const float* pa = Jb + fg * LDJS + 16 * tmi[t] + fr;
                     const float* pb = Jb + fg * LDJS + 16 * tnj[t] + fr;
-                    float av[BM::CHUNK_ROWS / 4], bv[BM::CHUNK_ROWS / 4];
+                    constexpr int KSTEPS = BM::CHUNK_ROWS / 4, KB = KSTEPS % 8 == 0 ? 8 : (KSTEPS % 7 == 0 ? 7 : (KSTEPS % 9 == 0 ? 9 : 1));
+#pragma unroll 1
+                    for (int u0 = 0; u0 < KSTEPS; u0 += KB) {
+                        float av[KB], bv[KB];
 #pragma unroll
-                    for (int u = 0; u < BM::CHUNK_ROWS / 4; ++u) { av[u] = pa[u * 4 * LDJS]; bv[u] = pb[u * 4 * LDJS]; }
+                        for (int u = 0; u < KB; ++u) { av[u] = pa[(u0 + u) * 4 * LDJS]; bv[u] = pb[(u0 + u) * 4 * LDJS]; }
 #pragma unroll
-                    for (int u = 0; u < BM::CHUNK_ROWS / 4; ++u) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[u], (double)bv[u], acc[t], 0, 0, 0);
+                        for (int u = 0; u < KB; ++u) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[u], (double)bv[u], acc[t], 0, 0, 0);
+                    }
                 }
             }
         }
