@@ -144,6 +144,7 @@ struct LmShared {
     float target[3 * LM_MAXM], mask[LM_MAXM], resid[3 * LM_MAXM];
     int parents[BM::NJ];
     unsigned long long sub[BM::NJ];   // bit j of sub[k]: joint j lies in the subtree of joint k
+    int lorder[BM::NJ], lstart[BM::NJ + 2], nlev;   // joints sorted by depth in the kinematic tree: level l = lorder[lstart[l] .. lstart[l+1])
     long long phase[8];               // s_memtime cycles per phase (thread 0), optional diagnostics
 };
 
@@ -188,6 +189,17 @@ __device__ void lm_setup(LmShared<BM>& s, const SmplConsts& C, int M, const floa
         }
         s.sub[tid] = m;
     }
+    if (tid == 0) {                            // kinematic levels (parents precede their children: depth by one pass)
+        int depth[NJ], cnt[NJ + 2];
+        int maxd = 0;
+        for (int j = 0; j < NJ; ++j) { depth[j] = j == 0 ? 0 : depth[s.parents[j]] + 1; maxd = depth[j] > maxd ? depth[j] : maxd; }
+        for (int l = 0; l <= maxd + 1; ++l) cnt[l] = 0;
+        for (int j = 0; j < NJ; ++j) ++cnt[depth[j] + 1];
+        for (int l = 0; l <= maxd; ++l) cnt[l + 1] += cnt[l];
+        for (int l = 0; l <= maxd + 1; ++l) s.lstart[l] = cnt[l];
+        for (int j = 0; j < NJ; ++j) s.lorder[cnt[depth[j]]++] = j;
+        s.nlev = maxd + 1;
+    }
     __syncthreads();
 }
 
@@ -216,29 +228,39 @@ __device__ void lm_linearize(LmShared<BM>& s, const SmplConsts& C, int M, int nb
     __syncthreads();
     long long t0 = 0;
     if (tid == 0) t0 = wall_clock64();
-    if (tid < 64) {                            // forward kinematics: 12 lanes per joint step (9 rotation entries + 3 translation)
-        if (lane < 9) L.Rw[lane] = L.R[lane];
-        else if (lane < 12) L.tw[lane - 9] = L.Jj[lane - 9];
-        __builtin_amdgcn_wave_barrier();
-        for (int j = 1; j < NJ; ++j) {
-            const int p = s.parents[j];
-            const double* Rp = L.Rw + p * 9;
-            if (lane < 9) {
-                const int a = lane / 3, b = lane - a * 3;
-                L.Rw[j * 9 + lane] = Rp[a * 3] * L.R[j * 9 + b] + Rp[a * 3 + 1] * L.R[j * 9 + 3 + b] + Rp[a * 3 + 2] * L.R[j * 9 + 6 + b];
-            } else if (lane < 12) {
-                const int a = lane - 9;
-                L.tw[j * 3 + a] = Rp[a * 3] * (L.Jj[j * 3] - L.Jj[p * 3]) + Rp[a * 3 + 1] * (L.Jj[j * 3 + 1] - L.Jj[p * 3 + 1]) +
-                                  Rp[a * 3 + 2] * (L.Jj[j * 3 + 2] - L.Jj[p * 3 + 2]) + L.tw[p * 3 + a];
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    for (int e = tid - 64; e >= 0 && e < NPF; e += BM::THREADS - 64) {   // pose feature vec(R_k - I), k = 1..NJ-1
+    for (int e = tid; e < NPF; e += BM::THREADS) {            // pose feature vec(R_k - I), k = 1..NJ-1
         const int k = 1 + e / 9, q = e - (k - 1) * 9;
         L.pf[e] = (float)(L.R[k * 9 + q] - ((q % 4 == 0) ? 1.0 : 0.0));
     }
+    // forward kinematics and the d tw_j / d beta_l chain, one tree LEVEL per barrier (9 levels for SMPL instead of 23 dependent joint
+    // steps): per joint of the level 12 threads (9 rotation entries + 3 translation) + 3 NB threads (one per (beta, component))
+    if (tid < 9) L.Rw[tid] = L.R[tid];
+    else if (tid < 12) L.tw[tid - 9] = L.Jj[tid - 9];
+    else if (tid >= 64 && tid < 64 + 3 * NB) { const int l = (tid - 64) / 3, a = (tid - 64) - 3 * l; L.twd[l][0][a] = L.Jd[(0 * 3 + a) * NB + l]; }
     __syncthreads();
+    for (int lv = 1; lv < s.nlev; ++lv) {
+        const int lb = s.lstart[lv], cnt = s.lstart[lv + 1] - lb;
+        constexpr int PER = 12 + 3 * NB;
+        for (int it = tid; it < cnt * PER; it += BM::THREADS) {
+            const int js = it / PER, e = it - js * PER;
+            const int j = s.lorder[lb + js], p = s.parents[j];
+            const double* Rp = L.Rw + p * 9;
+            if (e < 9) {
+                const int a = e / 3, b = e - a * 3;
+                L.Rw[j * 9 + e] = Rp[a * 3] * L.R[j * 9 + b] + Rp[a * 3 + 1] * L.R[j * 9 + 3 + b] + Rp[a * 3 + 2] * L.R[j * 9 + 6 + b];
+            } else if (e < 12) {
+                const int a = e - 9;
+                L.tw[j * 3 + a] = Rp[a * 3] * (L.Jj[j * 3] - L.Jj[p * 3]) + Rp[a * 3 + 1] * (L.Jj[j * 3 + 1] - L.Jj[p * 3 + 1]) +
+                                  Rp[a * 3 + 2] * (L.Jj[j * 3 + 2] - L.Jj[p * 3 + 2]) + L.tw[p * 3 + a];
+            } else {
+                const int l = (e - 12) / 3, a = (e - 12) - 3 * l;
+                const double d[3] = {(double)L.Jd[(j * 3 + 0) * NB + l] - L.Jd[(p * 3 + 0) * NB + l], (double)L.Jd[(j * 3 + 1) * NB + l] - L.Jd[(p * 3 + 1) * NB + l],
+                                     (double)L.Jd[(j * 3 + 2) * NB + l] - L.Jd[(p * 3 + 2) * NB + l]};
+                L.twd[l][j][a] = (float)(Rp[a * 3] * d[0] + Rp[a * 3 + 1] * d[1] + Rp[a * 3 + 2] * d[2] + L.twd[l][p][a]);
+            }
+        }
+        __syncthreads();
+    }
     if (tid < NJ * 3) {                       // omega_kc = Rw_parent(k) * axial(dR_kc R_k^T)
         const int k = tid / 3, c = tid - k * 3;
         const float* d = L.dR[k][c];
@@ -251,17 +273,6 @@ __device__ void lm_linearize(LmShared<BM>& s, const SmplConsts& C, int M, int nb
         else {
             const double* Rp = L.Rw + s.parents[k] * 9;
             for (int a = 0; a < 3; ++a) L.omega[k][c][a] = (float)(Rp[a * 3] * ax[0] + Rp[a * 3 + 1] * ax[1] + Rp[a * 3 + 2] * ax[2]);
-        }
-    } else if (tid >= 256 && tid < 256 + NB) {   // d tw_j / d beta_l chain
-        const int l = tid - 256;
-        float (*t)[3] = L.twd[l];
-        for (int a = 0; a < 3; ++a) t[0][a] = L.Jd[(0 * 3 + a) * NB + l];
-        for (int j = 1; j < NJ; ++j) {
-            const int p = s.parents[j];
-            const double* Rp = L.Rw + p * 9;
-            const double d[3] = {(double)L.Jd[(j * 3 + 0) * NB + l] - L.Jd[(p * 3 + 0) * NB + l], (double)L.Jd[(j * 3 + 1) * NB + l] - L.Jd[(p * 3 + 1) * NB + l],
-                                 (double)L.Jd[(j * 3 + 2) * NB + l] - L.Jd[(p * 3 + 2) * NB + l]};
-            for (int a = 0; a < 3; ++a) t[j][a] = (float)(Rp[a * 3] * d[0] + Rp[a * 3 + 1] * d[1] + Rp[a * 3 + 2] * d[2] + t[p][a]);
         }
     }
     __syncthreads();
@@ -554,6 +565,13 @@ __device__ void lm_linearize(LmShared<BM>& s, const SmplConsts& C, int M, int nb
     if (tid == 0) { const long long t1 = wall_clock64(); s.phase[2] += t1 - t0; }
 }
 
+// 1 / a from v_rcp_f64 and one Newton step (full fp64 accuracy to ~1 ulp) instead of the ~10-instruction correctly rounded division:
+// the pivot reciprocal sits in the serial chain of the column-by-column Cholesky
+__device__ __forceinline__ double fast_rcp_f64(double a) {
+    const double r = __builtin_amdgcn_rcp(a);
+    return fma(fma(-a, r, 1.0), r, r);
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
@@ -593,7 +611,7 @@ __device__ void lm_solve(LmShared<BM>& s, double lambda) {
         while (ii * (ii + 1) / 2 > e) --ii;
         pr[m] = ((unsigned)ii << 16) | (unsigned)(e - ii * (ii + 1) / 2);
     }
-    if (tid == 0) s.rpiv = 1.0 / Apk(s.A, 0, 0);
+    if (tid == 0) s.rpiv = fast_rcp_f64(Apk(s.A, 0, 0));
     __syncthreads();
     for (int k = 0; k < DOF; ++k) {
         const double inv = s.rpiv;                          // 1 / A_kk, published by the thread that finished A_kk
@@ -607,7 +625,7 @@ __device__ void lm_solve(LmShared<BM>& s, double lambda) {
                 const int ri = tk + ii * (ii + 1) / 2 + (k + 1) * ii, rj = tk + jj * (jj + 1) / 2 + (k + 1) * jj;   // row starts of i, j
                 const double a = s.A[ri + k + 1 + jj] - s.A[ri + k] * s.A[rj + k] * inv;
                 s.A[ri + k + 1 + jj] = a;
-                if (m == 0 && tid == 0) s.rpiv = 1.0 / a;   // pair (k+1, k+1): the next pivot
+                if (m == 0 && tid == 0) s.rpiv = fast_rcp_f64(a);   // pair (k+1, k+1): the next pivot
             }
         }
         __syncthreads();
@@ -702,23 +720,37 @@ __device__ void lm_solve(LmShared<BM>& s, double lambda) {
     }
     }
     if (tid == 0) { const long long t1 = wall_clock64(); s.phase[3] += t1 - t0; t0 = t1; }
-    // back substitution L^T delta = y by one wave (lane owns rows lane, lane + 64, ...); pivots broadcast with v_readlane
+    // back substitution L^T delta = y by one wave (lane owns rows lane, lane + 64, ...); pivots broadcast with v_readlane.  The L
+    // entries of 4 pivots are loaded BEFORE their dependent chain (delta_i -> y -> delta_{i-1} ...), so the chain itself is
+    // register-only: ~40 cycles per pivot instead of an LDS round trip.
     if (tid < 64) {
         constexpr int NR = (DOF + 63) / 64;
         double y[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) y[r] = lane + 64 * r < DOF ? Apk(s.A, DOF, lane + 64 * r) : 0.0;
-        for (int i = DOF - 1; i >= 0; --i) {
-            double src = y[0];
+        for (int i0 = DOF - 1; i0 >= 0; i0 -= 4) {
+            double l[4][NR], rd[4];
 #pragma unroll
-            for (int r = 1; r < NR; ++r) src = (i >> 6) == r ? y[r] : src;
-            const int lo = __builtin_amdgcn_readlane(__double2loint(src), i & 63), hi = __builtin_amdgcn_readlane(__double2hiint(src), i & 63);
-            const double di = __hiloint2double(hi, lo) * s.rdiag[i];
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 - u;
+                rd[u] = i >= 0 ? s.rdiag[i] : 0.0;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const int row = lane + 64 * r;
-                if (row == i) y[r] = di;
-                else if (row < i) y[r] -= Apk(s.A, i, row) * di;
+                for (int r = 0; r < NR; ++r) { const int row = lane + 64 * r; l[u][r] = i >= 0 && row < i ? Apk(s.A, i, row) : 0.0; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 - u;
+                if (i >= 0) {                                     // wave-uniform
+                    double src = y[0];
+#pragma unroll
+                    for (int r = 1; r < NR; ++r) src = (i >> 6) == r ? y[r] : src;
+                    const double di = readlane_f64(src, i & 63) * rd[u];
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const int row = lane + 64 * r;
+                        y[r] = row == i ? di : y[r] - l[u][r] * di;      // rows > i: l = 0, their final values stay
+                    }
+                }
             }
         }
 #pragma unroll
