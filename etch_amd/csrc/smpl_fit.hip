@@ -60,7 +60,8 @@ struct SmplConsts {
     // marker-restricted tables (M markers)
     const float* mk_vt;   // [M][3]
     const float* mk_S;    // [M][3][NB]
-    const float* mk_P;    // [M][NPF][3]
+    const float* mk_P;    // [M][NJ-1][28]: per joint k >= 1 the 9 x 3 posedirs block of the marker (entry (e, a) at 3 e + a), padded to 28 floats
+                          //                so that a thread fetches its block with seven 16-byte loads
     const float* mk_W;    // [M][NJ]
 };
 
@@ -208,7 +209,7 @@ __device__ void lm_setup(LmShared<BM>& s, const SmplConsts& C, int M, const floa
 // jac_out (diagnostics): the marker rows of J (3M x DOF) are also written to global memory.  grad_only (first-order fitter): only the
 // tile row that holds -J^T r is accumulated; the J^T J entries of s.A are then undefined.
 template <class BM>
-__device__ void lm_linearize(LmShared<BM>& s, const SmplConsts& C, int M, int nb, float* __restrict__ jac_out, bool grad_only = false) {
+__device__ __attribute__((noinline)) void lm_linearize(LmShared<BM>& s, const SmplConsts& C, int M, int nb, float* __restrict__ jac_out, bool grad_only = false) {
     constexpr int NJ = BM::NJ, NB = BM::NB, NPOSE = BM::NPOSE, NPF = BM::NPF, DOF = BM::DOF, LDJ = BM::LDJ, LDJS = BM::LDJS;
     LmLin<BM>& L = s.lin;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile indices stay in SGPRs
@@ -305,7 +306,7 @@ __device__ void lm_linearize(LmShared<BM>& s, const SmplConsts& C, int M, int nb
     if (tid == 0) tp = wall_clock64();
     for (int it = tid; it < M * BM::VPARTS; it += BM::THREADS) {
         const int part = it % BM::VPARTS, v = it / BM::VPARTS;
-        const float* Pg = C.mk_P + (size_t)v * 3 * NPF;
+        const float* Pg = C.mk_P + (size_t)v * 28 * (NJ - 1);    // row e = 9 (k-1) + q of the pose feature sits at 28 (k-1) + 3 q
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
         const int e0 = part * BM::EPP;
 #pragma unroll 1
@@ -314,7 +315,8 @@ __device__ void lm_linearize(LmShared<BM>& s, const SmplConsts& C, int M, int nb
 #pragma unroll
             for (int i = 0; i < BM::EPU; ++i) {
                 const int e = e0 + i0 + i;
-                const float* q = Pg + (e < NPF && i0 + i < BM::EPP ? e : 0) * 3;
+                const int ec = e < NPF && i0 + i < BM::EPP ? e : 0;
+                const float* q = Pg + (ec / 9) * 28 + (ec % 9) * 3;
                 pv[i][0] = q[0]; pv[i][1] = q[1]; pv[i][2] = q[2];
             }
 #pragma unroll
@@ -347,14 +349,17 @@ __device__ void lm_linearize(LmShared<BM>& s, const SmplConsts& C, int M, int nb
             const int rt = tile % nrt, ct = tile / nrt;       // ct = 0: Tbd (fp64);  ct >= 1: Wq column tile ct - 1 (fp32)
             const int v = 16 * rt + fr;
             const float* Wg = C.mk_W + (size_t)(v < M ? v : 0) * NJ;
+            float wreg[KJ];                                   // this lane's skinning weights W[v][4 t + fg]: all loads in flight before the first MFMA
+#pragma unroll
+            for (int t = 0; t < KJ; ++t) { const int j = 4 * t + fg; wreg[t] = j < NJ && v < M ? Wg[j] : 0.f; }
             if (ct == 0) {
                 f64x4 d = {0.0, 0.0, 0.0, 0.0};
                 const int a = fr >> 2, c = fr & 3;
-#pragma unroll 2
+#pragma unroll
                 for (int t = 0; t < KJ; ++t) {
                     const int j = 4 * t + fg;
                     const bool jo = j < NJ;
-                    const double av = jo && v < M ? (double)Wg[j] : 0.0;
+                    const double av = (double)wreg[t];
                     const double bv = !jo || fr >= 12 ? 0.0 : (c < 3 ? L.Rw[j * 9 + a * 3 + c] : L.Ab[j * 3 + a]);
                     d = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, d, 0, 0, 0);
                 }
@@ -366,11 +371,11 @@ __device__ void lm_linearize(LmShared<BM>& s, const SmplConsts& C, int M, int nb
             } else {
                 f32x4 d = {0.f, 0.f, 0.f, 0.f};
                 const int n = 16 * (ct - 1) + fr, l = n / 3, a = n - 3 * l;
-#pragma unroll 2
+#pragma unroll
                 for (int t = 0; t < KJ; ++t) {
                     const int j = 4 * t + fg;
                     const bool jo = j < NJ;
-                    const float av = jo && v < M ? Wg[j] : 0.f;
+                    const float av = wreg[t];
                     const float bv = jo && l < NB ? L.twd[l][j][a] : 0.f;
                     d = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, d, 0, 0, 0);
                 }
@@ -408,6 +413,8 @@ __device__ void lm_linearize(LmShared<BM>& s, const SmplConsts& C, int M, int nb
     }
     const int nchunk = (M + MC - 1) / MC;
     constexpr int NU = NB + 1;                                     // (marker, u) items of pass C besides the joints
+    float wnext = 0.f;                                             // skinning weight of this thread's (marker, joint) item of the NEXT chunk
+    if (tid < MC * NJ && tid / NJ < M) wnext = C.mk_W[(size_t)(tid / NJ) * NJ + tid % NJ];
     for (int ch = 0; ch < nchunk; ++ch) {
         const int v0 = ch * MC;
         float* Jb = L.Jc[ch & 1];
@@ -415,15 +422,17 @@ __device__ void lm_linearize(LmShared<BM>& s, const SmplConsts& C, int M, int nb
         // ---- B: thread (m, j)
         const int jm = tid / NJ, jj = tid - jm * NJ, jv = v0 + jm;
         const bool jlive = tid < MC * NJ && jv < M;
-        float Pk[27];
+        float Pk[28];
         if (tid < MC * NJ) {
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float wcur = wnext;
+            if (v0 + MC + jm < M) wnext = C.mk_W[(size_t)(v0 + MC + jm) * NJ + jj];
             if (jlive) {
-                const double wj = (double)C.mk_W[(size_t)jv * NJ + jj];
+                const double wj = (double)wcur;
                 if (jj >= 1) {
-                    const float* P = C.mk_P + (size_t)jv * 3 * NPF + (jj - 1) * 27;
+                    const float4* P = reinterpret_cast<const float4*>(C.mk_P + ((size_t)jv * (NJ - 1) + (jj - 1)) * 28);
 #pragma unroll
-                    for (int e = 0; e < 27; ++e) Pk[e] = P[e];
+                    for (int e = 0; e < 7; ++e) { const float4 t4 = P[e]; Pk[4 * e] = t4.x; Pk[4 * e + 1] = t4.y; Pk[4 * e + 2] = t4.z; Pk[4 * e + 3] = t4.w; }
                 }
                 const double* Rj = L.Rw + jj * 9;
                 const double d[3] = {L.vp[jv][0] - L.Jj[jj * 3], L.vp[jv][1] - L.Jj[jj * 3 + 1], L.vp[jv][2] - L.Jj[jj * 3 + 2]};
@@ -583,7 +592,7 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 // (3) the trailing matrix takes the rank-16 update on the fp64 matrix cores, one 16 x 16 tile per wave at a time.  3 barriers per
 // block (18 for SMPL, 36 for the 188-DoF model) instead of one per column (85 / 188).
 template <class BM>
-__device__ void lm_solve(LmShared<BM>& s, double lambda) {
+__device__ __attribute__((noinline)) void lm_solve(LmShared<BM>& s, double lambda) {
     constexpr int DOF = BM::DOF, N = BM::DOF, NPACK = BM::NPACK;
     constexpr int NBLK = (N + 15) / 16;                 // pivot blocks
     constexpr int NRT = (N + 1 + 15) / 16;              // row tiles of the (N + 1)-row matrix
@@ -593,11 +602,14 @@ __device__ void lm_solve(LmShared<BM>& s, double lambda) {
     for (int i = tid; i < N; i += BM::THREADS) Apk(s.A, i, i) += lambda;
     __syncthreads();
     if constexpr (N <= 100) {
-    // Small systems (SMPL: 85 pivots): column by column.  Measured 34 us against 38 us for the blocked form below, whose per-block
-    // sequential parts (diagonal factor by one wave, 16-step panel solves) do not amortise over 6 blocks.
-    // Right-looking Cholesky of the packed lower triangle with the rhs carried as an extra row (gives y = L^-1 g for
-    // free), ONE barrier per column: the trailing update uses the unscaled column, A_ij -= A_ik A_jk / A_kk; columns
-    // are scaled to L in one pass at the end.  The pair enumeration e -> (ii, jj) does not depend on the column.
+    // Small systems (SMPL: 85 pivots): right-looking elimination of TWO columns per barrier.  For columns k, k+1 with the pivot block
+    // [m00; m10 m11]:  c = m10 / m00,  p1 = m11 - m10 c,  a'_{i,k+1} = a_{i,k+1} - a_{ik} c,  and every trailing entry takes
+    //     A_ij -= a_ik a_jk / m00 + a'_{i,k+1} a'_{j,k+1} / p1
+    // in one step (each thread recomputes c, 1/m00, 1/p1 from three broadcast reads: no pivot is published through LDS).  The panel
+    // entries stay unscaled and un-transformed in place; three short passes at the end turn them into L (odd columns first, they read
+    // their even neighbour).  43 barriers instead of 85.  Measured alternatives: one column per barrier 33.5 us, this 29 us, the blocked
+    // form below 38 us (its per-block sequential parts do not amortise over 6 blocks), the matrix distributed over the workgroup's
+    // REGISTERS with only the two active columns in LDS 79 us (the per-entry case analysis spills).
     constexpr int NPR = (NPACK + BM::THREADS - 1) / BM::THREADS;
     unsigned pr[NPR];
     int tid_o = tid;
@@ -611,32 +623,47 @@ __device__ void lm_solve(LmShared<BM>& s, double lambda) {
         while (ii * (ii + 1) / 2 > e) --ii;
         pr[m] = ((unsigned)ii << 16) | (unsigned)(e - ii * (ii + 1) / 2);
     }
-    if (tid == 0) s.rpiv = fast_rcp_f64(Apk(s.A, 0, 0));
-    __syncthreads();
-    for (int k = 0; k < DOF; ++k) {
-        const double inv = s.rpiv;                          // 1 / A_kk, published by the thread that finished A_kk
-        const int n = DOF - k;                              // trailing rows k+1 .. DOF (incl. the rhs row)
+    for (int k = 0; k + 1 < N; k += 2) {
+        const double m00 = Apk(s.A, k, k), m10 = Apk(s.A, k + 1, k), m11 = Apk(s.A, k + 1, k + 1);
+        const double r0 = fast_rcp_f64(m00), c = m10 * r0, r1 = fast_rcp_f64(m11 - m10 * c);
+        const int n = N - k - 1;                            // trailing rows k+2 .. N (incl. the rhs row)
         const int npairs = n * (n + 1) / 2;
-        const int tk = (k + 1) * (k + 2) / 2;               // packed offset of row k+1
+        const int tk = (k + 2) * (k + 3) / 2;               // packed offset of row k+2
 #pragma unroll
         for (int m = 0; m < NPR; ++m) {
             if (tid + BM::THREADS * m < npairs) {
                 const int ii = (int)(pr[m] >> 16), jj = (int)(pr[m] & 0xFFFFu);
-                const int ri = tk + ii * (ii + 1) / 2 + (k + 1) * ii, rj = tk + jj * (jj + 1) / 2 + (k + 1) * jj;   // row starts of i, j
-                const double a = s.A[ri + k + 1 + jj] - s.A[ri + k] * s.A[rj + k] * inv;
-                s.A[ri + k + 1 + jj] = a;
-                if (m == 0 && tid == 0) s.rpiv = fast_rcp_f64(a);   // pair (k+1, k+1): the next pivot
+                const int ri = tk + ii * (ii + 1) / 2 + (k + 2) * ii, rj = tk + jj * (jj + 1) / 2 + (k + 2) * jj;   // row starts of i, j
+                const double ai0 = s.A[ri + k], aj0 = s.A[rj + k];
+                const double ai1 = s.A[ri + k + 1] - ai0 * c, aj1 = s.A[rj + k + 1] - aj0 * c;
+                s.A[ri + k + 2 + jj] -= ai0 * aj0 * r0 + ai1 * aj1 * r1;
             }
         }
         __syncthreads();
     }
-    if (tid < DOF) s.rdiag[tid] = 1.0 / sqrt(Apk(s.A, tid, tid));
+    // L from the unscaled panels: (1) per column pair the factor c and the reciprocal roots of both pivots, (2) odd columns, (3) even columns
+    for (int k = 2 * tid; k < N; k += 2 * BM::THREADS) {
+        const double m00 = Apk(s.A, k, k);
+        s.rdiag[k] = 1.0 / sqrt(m00);
+        if (k + 1 < N) {
+            const double m10 = Apk(s.A, k + 1, k), cc = m10 / m00;
+            s.delta[k >> 1] = cc;                           // delta is free until the back-substitution writes it
+            s.rdiag[k + 1] = 1.0 / sqrt(Apk(s.A, k + 1, k + 1) - m10 * cc);
+        }
+    }
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < NPR; ++m) {                         // scale: L_ik = A_ik / sqrt(A_kk) (i > k), y_k = A_DOF,k / sqrt(A_kk)
+    for (int m = 0; m < NPR; ++m) {                         // odd columns: L_{i,k+1} = (a_{i,k+1} - a_{ik} c) / sqrt(p1)
         const int e = tid + BM::THREADS * m;
-        const int i = (int)(pr[m] >> 16), k = (int)(pr[m] & 0xFFFFu);
-        if (e < NPACK && i != k && k < DOF) s.A[e] *= s.rdiag[k];
+        const int i = (int)(pr[m] >> 16), col = (int)(pr[m] & 0xFFFFu);
+        if (e < NPACK && i != col && col < N && (col & 1)) s.A[e] = (s.A[e] - s.A[e - 1] * s.delta[col >> 1]) * s.rdiag[col];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < NPR; ++m) {                         // even columns: L_ik = a_ik / sqrt(m00)
+        const int e = tid + BM::THREADS * m;
+        const int i = (int)(pr[m] >> 16), col = (int)(pr[m] & 0xFFFFu);
+        if (e < NPACK && i != col && col < N && !(col & 1)) s.A[e] *= s.rdiag[col];
     }
     __syncthreads();
     } else {

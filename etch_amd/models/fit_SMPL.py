@@ -56,8 +56,10 @@ class _DeviceBody:
         self.n_extra = len(bm.extra_vids)
         self.faces = bm.faces
         self.J0, self.Jd, self.parents = d(J0), d(Jd), d(bm.parents, torch.int32)
-        self.lm_consts = [self.J0, self.Jd, self.parents, d(bm.v_template[vids]), d(bm.shapedirs[vids]),
-                          d(np.transpose(P[:, vids, :], (1, 0, 2))), d(bm.lbs_weights[vids])]
+        # marker posedirs table for the LM kernel: (M, nj-1, 28) = per joint the 9 x 3 block (entry (e, a) at 3 e + a) padded to 28 floats
+        Pm = np.transpose(P[:, vids, :], (1, 0, 2)).reshape(len(vids), self.nj - 1, 27)
+        Pm = np.concatenate([Pm, np.zeros((len(vids), self.nj - 1, 1), Pm.dtype)], 2)
+        self.lm_consts = [self.J0, self.Jd, self.parents, d(bm.v_template[vids]), d(bm.shapedirs[vids]), d(Pm), d(bm.lbs_weights[vids])]
         self.lbs_consts = [d(bm.v_template), d(bm.shapedirs), d(bm.posedirs), d(bm.lbs_weights), self.J0, self.Jd, self.parents,
                            d(bm.extra_vids, torch.int32)]
 

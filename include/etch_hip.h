@@ -302,7 +302,8 @@ int etch_marker_status(int B, int M, const float* markers, const float* valid_f,
  * Body model: nj joints, nb shape coefficients -- (24, 10) = SMPL, the reference's model (fit_SMPL.py:100); (55, 20) = an
  * SMPL-X-sized model (BASELINE configs[4]); other sizes return ETCH_EUNSUPPORTED.  P = 9 (nj - 1) pose-feature rows.
  * consts = 7 device pointers {J0 (nj,3) = J_regressor @ v_template, Jd (nj,3,nb) = J_regressor @ shapedirs, parents (nj) i32, and for
- * the M <= 96 marker vertices: v_template rows (M,3), shapedirs rows (M,3,nb), posedirs columns as (M,P,3), lbs_weights rows (M,nj)}.
+ * the M <= 96 marker vertices: v_template rows (M,3), shapedirs rows (M,3,nb), posedirs columns as (M, nj-1, 28): per joint k >= 1 its 9 x 3 block (pose-feature row e, component a at 3 e + a) zero-padded to 28 floats,
+ * lbs_weights rows (M,nj)}.
  * markers (B,M,3), valid (B,M) float mask.  Variable vector x (B, 3 nj + nb + 3) = pose | betas | global_orient | transl
  * (fit_SMPL.py:174,225).  Stage 0: it0 iterations, step0, damping damp0, betas[:2] only (:161-200); stage 1: it1, step1, damp1, all
  * betas (:219-249).  x_stage0 / err_trace (B, it0+it1+2) / phase_ticks (B,8) may be NULL. */
