@@ -73,6 +73,8 @@ def algorithmic_flops(name, a):
     if name == "etch_mhsa_layer":
         T, mode = v[0], v[7]
         return T * (2.0 * 60 * 64 * 192 + 8 * (2.0 * 60 * 60 * 8 * 2) + (2.0 * 60 * 64 * 64 if mode != 2 else 0.0)), "mhsa_layer_kernel"
+    if name == "etch_mhsa_interp_layer":   # mode-0 layer on tokens interpolated in the kernel
+        return float(v[0]) * v[1] * (2.0 * 60 * 64 * 192 + 8 * (2.0 * 60 * 60 * 8 * 2) + 2.0 * 60 * 64 * 64), "mhsa_interp_layer_kernel"
     if name == "etch_mhsa_attention":
         T = v[0]
         return T * 8 * (2.0 * 60 * 60 * 8 * 2), "mhsa_attention_kernel"
@@ -269,6 +271,7 @@ def main():
                     "2-deep stream pipeline of etch_amd.pipeline -- stage 2 of step i (32 persistent workgroups, 1/8 of the chip) runs on a second "
                     "HIP stream next to stage 1 of step i+1; every one of the K steps still completes inside the timed region")
     ap.add_argument("--serial", action="store_true", help="profiling schedule: synchronous steps and every kernel on one stream")
+    ap.add_argument("--unfused-interp", action="store_true", help="A/B: separate 3-NN interpolation kernel in front of the direction head")
     ap.add_argument("--stage1-streams", type=int, default=1, help="stage-1 streams the pipeline alternates over (batches in flight = this + 1)")
     ap.add_argument("--concurrent-heads", type=int, default=1, help="1: confidence / magnitude nets on their own streams next to the direction head")
     a = ap.parse_args()

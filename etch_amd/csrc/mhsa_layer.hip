@@ -24,6 +24,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define ML_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// reductions over the 4 lane groups (lanes l, l^16, l^32, l^48) with the gfx950 row / half swaps: v_permlane16_swap exchanges the odd
+// 16-lane rows of one register with the even rows of another, v_permlane32_swap the upper half of one with the lower half of the other;
+// fed the same value twice they put x[l] and x[l^16] (resp. x[l^32]) side by side in every lane -- one VALU op instead of a
+// ds_bpermute round trip through LDS (8 of them sat on the softmax's critical path per 16-query tile)
+typedef unsigned ml_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float ml_xmax(float v) {
+    ml_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float ml_xsum(float v) {
+    ml_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // softmax over the 64 (60 valid) keys of one query, scores spread over the 4 lane groups x 16 registers; returns P / sum
 __device__ __forceinline__ void ml_softmax(f32x4 (&s)[4], int fg) {
     const float c = 0.35355339059327373f * 1.4426950408889634f;     // 1/sqrt(8) * log2(e)
@@ -31,8 +49,7 @@ __device__ __forceinline__ void ml_softmax(f32x4 (&s)[4], int fg) {
     float m = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 4; ++j) m = fmaxf(fmaxf(fmaxf(s[j][0], s[j][1]), fmaxf(s[j][2], s[j][3])), m);
-    m = fmaxf(m, __shfl_xor(m, 16));
-    m = fmaxf(m, __shfl_xor(m, 32));
+    m = ml_xmax(m);
     const float mc = m * c;
     float sum = 0.f;
 #pragma unroll
@@ -43,8 +60,7 @@ __device__ __forceinline__ void ml_softmax(f32x4 (&s)[4], int fg) {
             s[j][r] = p;
             sum += p;
         }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
+    sum = ml_xsum(sum);
     const float inv = 1.0f / sum;
 #pragma unroll
     for (int j = 0; j < 4; ++j) s[j] *= inv;
@@ -186,6 +202,219 @@ __global__ void __launch_bounds__(256, MODE == 2 ? 3 : 2) mhsa_layer_kernel(long
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// First layer of the direction head on INTERPOLATED tokens without a separate interpolation pass: the tokens of a scan point are the
+// 3-NN blend X = w0 F[i0] + w1 F[i1] + w2 F[i2] of coarse token tiles (pointnet2_utils.py:45-74); mhsa_interp_layer_kernel forms the
+// tile on its way into LDS (same arithmetic as prop_interp_kernel) and runs the layer on it.  The interpolated tokens (2.46 GB
+// written and read back per batch) and the interpolation kernel disappear; the workgroups of an XCD walk one contiguous eighth of
+// the scans' spatial order so that the three coarse rows of a point (shared with its neighbours) hit in that XCD's L2.
+// Also measured (scratch/dirhead_time.py, 32 x 5000 points): the q / k / v transforms are linear and bias-free, so they can be
+// evaluated once per COARSE point (4x fewer) and blended per scan point in the attention phase's register layout.  Blending all three
+// removes 768 of 1 760 MFMAs per point but reads 192 KB per point from L2 (68 % hit rate): 4.93 ms + 0.71 ms projection; q and k
+// only 4.96 + 0.53; q only 5.17 + 0.29 -- against 5.56 ms for this form, i.e. the same within noise: the layer is bound by
+// its dependent phases at 2 - 3 waves per SIMD, not by the matrix-core count, so the simple form is kept.
+#ifndef MHSA_INTERP_WGS
+#define MHSA_INTERP_WGS 2
+#endif
+__device__ __forceinline__ f32x4 ml_blend(const float4 a, const float4 b, const float4 c, float w0, float w1, float w2) {
+#pragma clang fp contract(off)      // the arithmetic of prop_interp_kernel, bit for bit
+    f32x4 r;
+    r[0] = (a.x * w0 + b.x * w1) + c.x * w2;
+    r[1] = (a.y * w0 + b.y * w1) + c.y * w2;
+    r[2] = (a.z * w0 + b.z * w1) + c.z * w2;
+    r[3] = (a.w * w0 + b.w * w1) + c.w * w2;
+    return r;
+}
+
+// sched[slot] = {output row b N + n, coarse rows b S + idx[0..2], weights[0..2], 0} for slot = position of (b, n) in the processing order
+__global__ void __launch_bounds__(256) interp_schedule_kernel(int B, int N, int S, const int* __restrict__ idx, const float* __restrict__ wgt,
+                                                              const int* __restrict__ order, int4* __restrict__ sched) {
+    const long slot = (long)blockIdx.x * 256 + threadIdx.x;
+    if (slot >= (long)B * N) return;
+    const long b = slot / N, s = slot - b * N;
+    const long pt = b * N + (order ? order[slot] : s);
+    const int cb = (int)(b * S);
+    sched[2 * slot] = make_int4((int)pt, cb + idx[pt * 3], cb + idx[pt * 3 + 1], cb + idx[pt * 3 + 2]);
+    sched[2 * slot + 1] = make_int4(__float_as_int(wgt[pt * 3]), __float_as_int(wgt[pt * 3 + 1]), __float_as_int(wgt[pt * 3 + 2]), 0);
+}
+
+// out[b,n] = X + att Wc^T + bc with X = blend of three rows of F (B,S,60,64), sched from interp_schedule_kernel.  Grid = multiple of 8
+// workgroups.  Per scan point: its three coarse token rows were requested during the previous point (12 float4 in registers) and are
+// blended into LDS; the rows of the NEXT point are requested before the layer's three phases start.
+__global__ void __launch_bounds__(256, MHSA_INTERP_WGS) mhsa_interp_layer_kernel(int B, int N, int S, const float* __restrict__ F,
+                                                                   const int* __restrict__ sched, const float* __restrict__ Wq,
+                                                                   const float* __restrict__ Wk, const float* __restrict__ Wv,
+                                                                   const float* __restrict__ Wc, const float* __restrict__ bc,
+                                                                   float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float Xs[64 * ML_S];
+    __shared__ __attribute__((aligned(16))) float As[64 * ML_S];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    float4 wq[4], wk[4], wv[4], wc[4];
+    {
+        const int chq = 8 * (2 * w + ((fr & 3) >> 1)) + 2 * (fr >> 2) + (fr & 1);
+        const int chv = 16 * w + fr;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            wq[t] = *reinterpret_cast<const float4*>(Wq + chq * ML_C + t * 16 + fg * 4);
+            wk[t] = *reinterpret_cast<const float4*>(Wk + chq * ML_C + t * 16 + fg * 4);
+            wv[t] = *reinterpret_cast<const float4*>(Wv + chv * ML_C + t * 16 + fg * 4);
+            wc[t] = *reinterpret_cast<const float4*>(Wc + chv * ML_C + t * 16 + fg * 4);
+        }
+    }
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bc) bias = *reinterpret_cast<const float4*>(bc + 16 * w + 4 * fg);
+    Xs[(ML_TOK + (tid >> 6)) * ML_S + (tid & 63)] = 0.f;      // token rows 60..63 stay zero for the whole kernel
+
+    const long T = (long)B * N;
+    const long share = (T + 7) >> 3;                    // contiguous slots of the spatial order per XCD
+    const int per = gridDim.x >> 3, xcd = blockIdx.x & 7;
+    const long lim = share < T - xcd * share ? share : T - xcd * share;
+    long q = blockIdx.x >> 3;
+    // Scalar state of a point = one 32-byte record of `sched` (output row, three coarse rows, three weights), read two points ahead:
+    // the record of point k+2 is requested while point k computes, so that the token rows of k+1 can be requested at the top of k
+    // without waiting for a scalar load (order -> idx -> rows would be three dependent latencies per point).
+    const int4* rec = reinterpret_cast<const int4*>(sched) + 2 * (xcd * share);
+    int4 c_i = make_int4(0, 0, 0, 0), c_w = c_i, n_i = c_i, n_w = c_i;
+    if (q < lim) { c_i = rec[2 * q]; c_w = rec[2 * q + 1]; }
+    if (q + per < lim) { n_i = rec[2 * (q + per)]; n_w = rec[2 * (q + per) + 1]; }
+    // raw token rows of a point: element e = tid + 256 h of each of its three coarse rows
+    float4 xa[4], xb[4], xc[4];
+#define ML_XLOAD(R)                                                                        \
+    {                                                                                      \
+        const float4* r0_ = reinterpret_cast<const float4*>(F + (size_t)(R).y * (ML_TOK * ML_C));  \
+        const float4* r1_ = reinterpret_cast<const float4*>(F + (size_t)(R).z * (ML_TOK * ML_C));  \
+        const float4* r2_ = reinterpret_cast<const float4*>(F + (size_t)(R).w * (ML_TOK * ML_C));  \
+        _Pragma("unroll") for (int h = 0; h < 4; ++h) {                                    \
+            const int e = tid + 256 * h;                                                   \
+            if (h < 3 || e < ML_TOK * ML_C / 4) { xa[h] = r0_[e]; xb[h] = r1_[e]; xc[h] = r2_[e]; }  \
+        }                                                                                  \
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) xa[h] = xb[h] = xc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < lim) ML_XLOAD(c_i)
+    for (; q < lim; q += per) {
+        const long cpt = c_i.x;
+        const float a0 = __int_as_float(c_w.x), a1 = __int_as_float(c_w.y), a2 = __int_as_float(c_w.z);
+        // the token tile itself (projections, residual)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int e = tid + 256 * h;
+            if (h < 3 || e < ML_TOK * ML_C / 4) {
+                const f32x4 v = ml_blend(xa[h], xb[h], xc[h], a0, a1, a2);
+                *reinterpret_cast<float4*>(&Xs[(e >> 4) * ML_S + (e & 15) * 4]) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        // the next point's token rows: in flight during the whole layer
+        if (q + per < lim) ML_XLOAD(n_i)
+        c_i = n_i; c_w = n_w;
+        if (q + 2 * per < lim) { n_i = rec[2 * (q + 2 * per)]; n_w = rec[2 * (q + 2 * per) + 1]; }
+        __syncthreads();
+
+        f32x4 Q[4], Kt[4], V[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            float4 xf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xf[t] = *reinterpret_cast<const float4*>(&Xs[(tt * 16 + fr) * ML_S + t * 16 + fg * 4]);
+            f32x4 k = {0.f, 0.f, 0.f, 0.f}, v = k, qq = k;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#define ML_STEP(C)                      \
+    qq = ML_MFMA(wq[t].C, xf[t].C, qq); \
+    k = ML_MFMA(wk[t].C, xf[t].C, k);   \
+    v = ML_MFMA(xf[t].C, wv[t].C, v);
+                ML_STEP(x) ML_STEP(y) ML_STEP(z) ML_STEP(w)
+#undef ML_STEP
+            }
+            Kt[tt] = k; V[tt] = v; Q[tt] = qq;
+        }
+
+        // ---- B: attention of heads 2w / 2w+1 (as in mhsa_layer_kernel)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            f32x4 sa[4], sb[4];
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                sa[jt] = ML_MFMA(Kt[jt][0], Q[it][0], z);
+                sb[jt] = ML_MFMA(Kt[jt][2], Q[it][2], z);
+            }
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                sa[jt] = ML_MFMA(Kt[jt][1], Q[it][1], sa[jt]);
+                sb[jt] = ML_MFMA(Kt[jt][3], Q[it][3], sb[jt]);
+            }
+            ml_softmax(sa, fg);
+            ml_softmax(sb, fg);
+            f32x4 oa = z, ob = z;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    oa = ML_MFMA(sa[jt][r], V[jt][r], oa);
+                    ob = ML_MFMA(sb[jt][r], V[jt][r], ob);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) As[(it * 16 + fg * 4 + r) * ML_S + 16 * w + fr] = fr < 8 ? oa[r] : ob[r];
+        }
+        __syncthreads();
+
+        // ---- C: head_combine + bias + residual
+        f32x4 y[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) y[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float4 af[4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) af[tt] = *reinterpret_cast<const float4*>(&As[(tt * 16 + fr) * ML_S + t * 16 + fg * 4]);
+#define ML_STEP(C) _Pragma("unroll") for (int tt = 0; tt < 4; ++tt) y[tt] = ML_MFMA(wc[t].C, af[tt].C, y[tt]);
+            ML_STEP(x) ML_STEP(y) ML_STEP(z) ML_STEP(w)
+#undef ML_STEP
+        }
+        float* dst = out + cpt * (ML_TOK * ML_C);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int tok = tt * 16 + fr;
+            if (tok < ML_TOK) {
+                const float4 rx = *reinterpret_cast<const float4*>(&Xs[tok * ML_S + 16 * w + 4 * fg]);
+                *reinterpret_cast<float4*>(dst + tok * ML_C + 16 * w + 4 * fg) =
+                    make_float4(y[tt][0] + bias.x + rx.x, y[tt][1] + bias.y + rx.y, y[tt][2] + bias.z + rx.z, y[tt][3] + bias.w + rx.w);
+            }
+        }
+        __syncthreads();      // Xs / As are rewritten by the next point
+    }
+#undef ML_XLOAD
+}
+
+// mean over the A tokens of each point: X (T, A, C) -> mean (T, C); C <= 256, C % 4 == 0
+__global__ void __launch_bounds__(256) token_mean_kernel(long T, int A, int C, const float* __restrict__ X, float* __restrict__ mean) {
+    __shared__ float4 part[256];
+    const int C4 = C >> 2, c4 = threadIdx.x % C4, a0 = threadIdx.x / C4, AP = 256 / C4;
+    for (long pt = blockIdx.x; pt < T; pt += gridDim.x) {
+        const float4* src = reinterpret_cast<const float4*>(X + (size_t)pt * A * C);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a0 < AP)
+            for (int a = a0; a < A; a += AP) {
+                const float4 v = src[a * C4 + c4];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        part[threadIdx.x] = acc;
+        __syncthreads();
+        if (threadIdx.x < C4) {
+            float4 t = part[threadIdx.x];
+            for (int k = 1; k < AP; ++k) {
+                const float4 u = part[k * C4 + threadIdx.x];
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            const float ia = 1.0f / (float)A;
+            reinterpret_cast<float4*>(mean + (size_t)pt * C)[threadIdx.x] = make_float4(t.x * ia, t.y * ia, t.z * ia, t.w * ia);
+        }
+        __syncthreads();
+    }
+}
+
 template <int MODE>
 static int launch_layer(long T, const float* X, const float* Wq, const float* Wk, const float* Wv, const float* Wc, const float* bc,
                         float* out, hipStream_t st) {
@@ -213,4 +442,35 @@ extern "C" int etch_mhsa_layer(long T, const float* X, const float* Wq, const fl
     if (mode == 1) return launch_layer<1>(T, X, Wq, Wk, Wv, Wc, bc, out, st);
     if (mode == 2) return launch_layer<2>(T, X, Wq, Wk, Wv, Wc, bc, out, st);
     return ETCH_EINVAL;
+}
+
+extern "C" int etch_mhsa_interp_layer(int B, int N, int S, const float* F, const int* idx, const float* weight,
+                                      const int* order, const float* Wq, const float* Wk, const float* Wv, const float* Wc, const float* bc,
+                                      float* out, int* sched, void* stream) {
+    if (B <= 0 || N <= 0) return ETCH_OK;
+    if (S <= 0 || !F || !Wq || !idx || !weight || !Wk || !Wv || !Wc || !out || !sched) return ETCH_EINVAL;
+    if ((long)B * N > 0x7fffffffL || (long)B * S > 0x7fffffffL) return ETCH_EUNSUPPORTED;
+    if (((uintptr_t)F | (uintptr_t)Wq | (uintptr_t)Wk | (uintptr_t)Wv | (uintptr_t)Wc | (uintptr_t)bc | (uintptr_t)out | (uintptr_t)sched) & 15)
+        return ETCH_EINVAL;
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)mhsa_interp_layer_kernel, 256, 0) != hipSuccess || n < 1) n = 2;
+        per_cu = n;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(interp_schedule_kernel, dim3((unsigned)(((long)B * N + 255) / 256)), dim3(256), 0, st, B, N, S, idx, weight, order,
+                       reinterpret_cast<int4*>(sched));
+    hipLaunchKernelGGL(mhsa_interp_layer_kernel, dim3(256u * per_cu), dim3(256), 0, st, B, N, S, F, sched, Wq, Wk, Wv, Wc, bc, out);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+extern "C" int etch_token_mean(long T, int A, int C, const float* X, float* mean, void* stream) {
+    if (T <= 0) return ETCH_OK;
+    if (A <= 0 || C <= 0 || C > 256 || (C & 3) || 256 % (C >> 2) || !X || !mean) return ETCH_EINVAL;
+    long blocks = T < 256L * 16 ? T : 256L * 16;
+    hipLaunchKernelGGL(token_mean_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, T, A, C, X, mean);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
 }

@@ -101,15 +101,34 @@ class GT_network_equiv(nn.Module):
             self._fold_cache = _Derived()
         return self._fold_cache.get(ps, build)
 
-    def anchor_weights(self, tokens):
-        """tokens [T, 60, C] -> anc_w [T, 60]: direction_encoder -> direction_predictor -> so3_reg (models_pointcloud.py:115-117)."""
-        T = tokens.shape[0]
-        if not self.fold_linear_chains:
-            x = self.direction_predictor(self.direction_encoder(tokens))
-            return ops.rowdot(x.view(T * 60, -1), self.so3_reg.weight.detach().view(-1), float(self.so3_reg.bias.detach().cpu())).view(T, 60)
+    fuse_direction_interp = True   # the first MHSA layer forms the 3-NN interpolated tokens itself (they are never written out)
+
+    def _can_fuse_interp(self):
         layers = self.direction_encoder.self_attention_layers
-        x = tokens
-        for layer in layers[:-1]:
+        return (self.fuse_direction_interp and self.fold_linear_chains and len(layers) >= 2 and layers[0].embedding_dim == 64
+                and layers[0].value_dim == 64)
+
+    def anchor_weights(self, tokens, interp=None):
+        """tokens [T, 60, C] -> anc_w [T, 60]: direction_encoder -> direction_predictor -> so3_reg (models_pointcloud.py:115-117).
+        interp = (coarse tokens (B,S,60,C), idx (B,N,3), w (B,N,3), order) instead of `tokens`: the 3-NN interpolation of :181-183 is
+        done inside the first attention layer's kernel; the interpolated tokens are never written out."""
+        layers = self.direction_encoder.self_attention_layers
+        if interp is not None:
+            feats_cl, idx3, w3, order = interp
+            l0 = layers[0]
+            x = ops.mhsa_interp_layer(feats_cl, idx3, w3, l0.query_transform.weight.detach(), l0.key_transform.weight.detach(),
+                                      l0.value_transform.weight.detach(), l0.head_combine.weight.detach(), l0.head_combine.bias.detach(), order=order)
+            T = x.shape[0] // 60
+            x = x.view(T, 60, l0.value_dim)
+            first = 1
+        else:
+            T = tokens.shape[0]
+            if not self.fold_linear_chains:
+                x = self.direction_predictor(self.direction_encoder(tokens))
+                return ops.rowdot(x.view(T * 60, -1), self.so3_reg.weight.detach().view(-1), float(self.so3_reg.bias.detach().cpu())).view(T, 60)
+            x = tokens
+            first = 0
+        for layer in layers[first:-1]:
             x = layer(x, x, x, residual=True)
         last = layers[-1]
         Wf, bf, v, c, Wfp = self._folded()
@@ -118,12 +137,17 @@ class GT_network_equiv(nn.Module):
         # relu(att Wf^T + bf) . v + c in one kernel: the (T*60, 128) hidden layer stays on chip
         return ops.linear_relu_dot(att, Wf, bf, v, c, 1, wp=Wfp).view(T, 60)
 
-    def decode_direction(self, equiv_feat, anchors, initial_vectors, tokens_cl=None):
-        """models_pointcloud.py:111-126.  equiv_feat [B, N, C, 60] (reference layout) or tokens_cl [B, N, 60, C]."""
-        if tokens_cl is None:
-            tokens_cl = equiv_feat.permute(0, 1, 3, 2).contiguous()
-        B, N, na, C = tokens_cl.shape
-        anc_w = self.anchor_weights(tokens_cl.view(B * N, na, C))
+    def decode_direction(self, equiv_feat, anchors, initial_vectors, tokens_cl=None, interp=None):
+        """models_pointcloud.py:111-126.  equiv_feat [B, N, C, 60] (reference layout) or tokens_cl [B, N, 60, C], or `interp` (see
+        anchor_weights)."""
+        if interp is not None:
+            B, N, na = interp[1].shape[0], interp[1].shape[1], interp[0].shape[2]
+            anc_w = self.anchor_weights(None, interp=interp)
+        else:
+            if tokens_cl is None:
+                tokens_cl = equiv_feat.permute(0, 1, 3, 2).contiguous()
+            B, N, na, C = tokens_cl.shape
+            anc_w = self.anchor_weights(tokens_cl.view(B * N, na, C))
         self.last_anc_w = anc_w.view(B, N, na)
         iv = initial_vectors.reshape(-1, 3)[0].tolist()
         assert iv == [0.0, 0.0, 1.0], "only direction_mode='standard_vector' is implemented (as in the reference, :198-208)"
@@ -208,20 +232,32 @@ class GT_network_equiv(nn.Module):
         so3_anchors = r.anchors
         selected_indexs = torch.arange(0, N, device=hitpts.device).repeat(B, 1).unsqueeze(-1).expand(-1, -1, 3)
         # 3-NN propagation of the [C*60] equivariant features to all N points + anchor mean (:181-184), channels-last
-        point_equiv_cl, point_inv_feat = propagate_cl(hitpts, r.xyz, r.feats_cl, order=self._input_order(hitpts))
+        order = self._input_order(hitpts)
+        interp = None
+        if hitpts.is_cuda and self._can_fuse_interp():
+            # the anchor mean is linear too: mean over the anchors at the COARSE points, then the 64-wide 3-NN blend (the nets that read
+            # it start ~1 ms earlier); the equivariant tokens themselves are blended inside the first attention layer
+            idx3, w3 = ops.prop3nn(hitpts, r.xyz)
+            Bc, S, na, C = r.feats_cl.shape
+            cmean = ops.token_mean(r.feats_cl.view(Bc * S, na, C))
+            _, point_inv_feat = ops.prop_interp(cmean.view(Bc, S, 1, C), idx3, w3, order=order)
+            point_equiv_cl, interp = None, (r.feats_cl, idx3, w3, order)
+        else:
+            point_equiv_cl, point_inv_feat = propagate_cl(hitpts, r.xyz, r.feats_cl, order=order)
         results = {}
         if idx_ready is not None:
             torch.cuda.current_stream().wait_event(idx_ready)
         # both Point-Transformer nets share FPS / kNN indices (same points, same offsets) through the enclosing knn_scope
         self._heads(results, pred_items, direction_mode, hitpts, point_inv_feat, point_equiv_cl, so3_anchors, B, N,
-                    indices_prefetched=idx_ready is not None)
+                    indices_prefetched=idx_ready is not None, interp=interp)
         return results, selected_indexs
 
     concurrent_heads = True    # run the confidence and magnitude nets on their own HIP streams next to the direction head
     defer_join = False         # True (set by a pipelined caller around forward): leave `pending_join` events instead of joining
     pending_join = None
 
-    def _heads(self, results, pred_items, direction_mode, hitpts, point_inv_feat, point_equiv_cl, so3_anchors, B, N, indices_prefetched=False):
+    def _heads(self, results, pred_items, direction_mode, hitpts, point_inv_feat, point_equiv_cl, so3_anchors, B, N, indices_prefetched=False,
+               interp=None):
         # The three heads are independent given the encoder output.  With `concurrent_heads` the two Point-Transformer nets
         # (many small launches: a few dozen workgroups at the deep levels) run on side streams while the direction head keeps
         # the matrix cores busy on the current one.  Only when every index tensor was produced ahead of time: a tensor
@@ -253,7 +289,7 @@ class GT_network_equiv(nn.Module):
             if direction_mode != "standard_vector":
                 raise AssertionError("Not implemented")   # same as the reference (:199,210)
             standard_vector = self.standard_vector.repeat(B, N, 1)
-            results["direction"] = self.decode_direction(None, so3_anchors, standard_vector, tokens_cl=point_equiv_cl)
+            results["direction"] = self.decode_direction(None, so3_anchors, standard_vector, tokens_cl=point_equiv_cl, interp=interp)
         self.pending_join = None
         if fork:
             if self.defer_join:

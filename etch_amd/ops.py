@@ -281,6 +281,35 @@ def mhsa_layer(x, wq, wk, wv, wc=None, bc=None, mode=0):
     return out
 
 
+def mhsa_interp_layer(feats_cl, idx, w, wq, wk, wv, wc, bc, order=None):
+    """First (residual) MHSA layer on the 3-NN interpolated tokens, which are formed inside the kernel: feats_cl (B,S,60,64) coarse
+    tokens, idx / w (B,N,3) from prop3nn -> (B*N*60, 64).  order (B,N) int32: processing order of the fine points (scheduling only)."""
+    for t, n in ((feats_cl, "feats"), (w, "w"), (wq, "wq"), (wk, "wk"), (wv, "wv"), (wc, "wc")):
+        _need(t, torch.float32, n)
+    _need(idx, torch.int32, "idx")
+    if order is not None:
+        _need(order, torch.int32, "order")
+    if bc is not None:
+        _need(bc, torch.float32, "bc")
+    B, S, A, C = feats_cl.shape
+    assert (A, C) == (60, 64) and idx.shape[0] == B and idx.shape == w.shape
+    N = idx.shape[1]
+    out = torch.empty((B * N * 60, 64), dtype=torch.float32, device=feats_cl.device)
+    sched = torch.empty((B * N, 8), dtype=torch.int32, device=feats_cl.device)      # workspace: per-slot records of the processing order
+    _lib.check(_lib.lib().etch_mhsa_interp_layer(B, N, S, _ptr(feats_cl), _ptr(idx), _ptr(w), _optptr(order), _ptr(wq), _ptr(wk), _ptr(wv), _ptr(wc),
+                                                 _optptr(bc), _ptr(out), _ptr(sched), _stream()), "etch_mhsa_interp_layer")
+    return out
+
+
+def token_mean(x):
+    """x (T, A, C) -> mean over the A tokens (T, C)."""
+    _need(x, torch.float32, "x")
+    T, A, C = x.shape
+    out = torch.empty((T, C), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().etch_token_mean(_c_long(T), A, C, _ptr(x), _ptr(out), _stream()), "etch_token_mean")
+    return out
+
+
 def rowdot(x, w, bias):
     _need(x, torch.float32, "x"), _need(w, torch.float32, "w")
     R, K = x.shape

@@ -145,6 +145,16 @@ int etch_mhsa_attention(long T, const float* qkv, long ld, int qoff, int koff, i
 int etch_mhsa_layer(long T, const float* X, const float* Wq, const float* Wk, const float* Wv, const float* Wc, const float* bc,
                     int mode, float* out, void* stream);
 
+/* The first MultiHeadAttention layer of the direction head applied to 3-NN INTERPOLATED tokens (PointFeatPropagation,
+ * pointnet2_utils.py:45-74, feeding StackedMHSA, direction_backbones.py:216-221) without writing them out: F (B,S,60,64) coarse
+ * tokens, idx / weight (B,N,3) from etch_prop3nn, order (B,N) int32 or NULL (scheduling only), weights as etch_mhsa_layer
+ * -> out (B*N*60, 64) = X + att Wc^T + bc with X = the interpolated tokens (mode 0 of etch_mhsa_layer on etch_prop_interp's output).
+ * sched: workspace of B*N*8 int32 (16-byte aligned).
+ * etch_token_mean: X (T,A,C) -> mean over the A tokens (T,C) (the anchor mean of models_pointcloud.py:184 at the coarse points). */
+int etch_mhsa_interp_layer(int B, int N, int S, const float* F, const int* idx, const float* weight, const int* order, const float* Wq,
+                           const float* Wk, const float* Wv, const float* Wc, const float* bc, float* out, int* sched, void* stream);
+int etch_token_mean(long T, int A, int C, const float* X, float* mean, void* stream);
+
 /* y[r] = x[r,:K] . w + bias: so3_reg Conv1d(128,1,1) (src/models/models_pointcloud.py:54,117). */
 int etch_rowdot(long R, int K, const float* x, long ldx, const float* w, float bias, float* y, void* stream);
 

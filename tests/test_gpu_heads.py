@@ -178,3 +178,51 @@ def test_fused_mhsa_layer_vs_fp64_and_unfused(T, mode):
     # large-magnitude scores: the running max keeps the softmax finite
     big = ops.mhsa_layer((xc * 30).view(T * 60, 64), wqc, wkc, wvc, wcc, bcc, mode=mode)
     assert bool(torch.isfinite(big).all())
+
+
+@pytest.mark.parametrize("B,N,S,ordered", [(1, 37, 9, False), (2, 1501, 400, True), (3, 700, 175, True)])
+def test_interpolating_mhsa_layer_equals_interpolation_then_layer(B, N, S, ordered):
+    """etch_mhsa_interp_layer (3-NN blend of the coarse token tiles formed inside the first attention layer) against
+    etch_prop_interp + etch_mhsa_layer(mode 0): the blend is the same arithmetic and the layer the same MFMA sequence -> bitwise equal,
+    for every processing order; the anchor mean taken at the coarse points and blended (etch_token_mean) within fp32 rounding."""
+    from etch_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    pts = (torch.randn(B, N, 3, generator=g) * torch.tensor([0.14, 0.31, 0.085])).cuda()
+    sel = torch.stack([torch.randperm(N, generator=g)[:S] for _ in range(B)]).cuda()
+    xyz2 = torch.gather(pts, 1, sel[..., None].expand(-1, -1, 3)).permute(0, 2, 1).contiguous()
+    F = torch.randn(B, S, 60, 64, generator=g).cuda()
+    W = [(torch.randn(64, 64, generator=g) * 0.125).cuda() for _ in range(4)]
+    bc = (torch.randn(64, generator=g) * 0.1).cuda()
+    idx, w = ops.prop3nn(pts, xyz2)
+    order = ops.spatial_order(pts.permute(0, 2, 1).contiguous()) if ordered else None
+    x, inv = ops.prop_interp(F, idx, w, order=order)
+    ref = ops.mhsa_layer(x.view(-1, 64), W[0], W[1], W[2], W[3], bc, mode=0)
+    got = ops.mhsa_interp_layer(F, idx, w, W[0], W[1], W[2], W[3], bc, order=order)
+    assert torch.equal(got, ref)
+    if ordered:
+        assert torch.equal(ops.mhsa_interp_layer(F, idx, w, W[0], W[1], W[2], W[3], bc, order=None), ref)
+    cmean = ops.token_mean(F.view(B * S, 60, 64))
+    assert rel_err(cmean.cpu().numpy(), F.mean(2).view(B * S, 64).cpu().numpy()) < 1e-6
+    _, inv2 = ops.prop_interp(cmean.view(B, S, 1, 64), idx, w, order=order)
+    assert rel_err(inv2.cpu().numpy(), inv.cpu().numpy()) < 2e-6
+
+
+def test_model_with_and_without_fused_interpolation(tmp_path):
+    """GT_network_equiv.forward with the interpolation folded into the first attention layer vs the separate interpolation kernel."""
+    import types
+    from etch_amd import constants as K
+    from etch_amd.models.models_pointcloud import GT_network_equiv
+    from etch_amd.utils.weights import load_seeded
+    args = types.SimpleNamespace(output_folder=str(tmp_path), EPN_input_radius=0.4, EPN_layer_num=2, device="cuda", markerset=K.default_markerset(),
+                                 scale_magnitude=10)
+    model = load_seeded(GT_network_equiv(option=args), 3).cuda().eval()
+    pts = (torch.randn(2, 1024, 3, generator=torch.Generator().manual_seed(1)) * torch.tensor([0.14, 0.31, 0.085])).cuda()
+    outs = []
+    for fuse in (True, False):
+        model.fuse_direction_interp = fuse
+        with torch.no_grad():
+            r, _ = model(pts, pred_items=["direction", "magnitude", "confidence"])
+        outs.append({k: v.float().cpu().numpy() for k, v in r.items()} | {"anc_w": model.last_anc_w.cpu().numpy()})
+    assert np.array_equal(outs[0]["anc_w"], outs[1]["anc_w"]) and np.array_equal(outs[0]["direction"], outs[1]["direction"])
+    for k in ("magnitude", "confidences", "part_labels"):     # the anchor mean is blended at the coarse points: fp32 rounding only
+        assert rel_err(outs[0][k], outs[1][k]) < 1e-5, k
