@@ -158,3 +158,41 @@ class InstanceNormLeakyReLUFunction(torch.autograd.Function):
 
 def instnorm_leaky_relu(x_cl, slope=0.01):
     return InstanceNormLeakyReLUFunction.apply(x_cl, slope)
+
+
+class MHSALayerFunction(torch.autograd.Function):
+    """One MultiHeadAttention layer of the direction head (direction_backbones.py:132-194, + the residual of :216-221): forward = the
+    fused inference kernel (etch_mhsa_layer); backward recomputes q|k|v and the head outputs with the un-fused kernels, runs the
+    attention core's hand-written backward (etch_mhsa_attention_backward) and closes the linear maps with the matrix-core GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv, wc, bc, residual):
+        T = x.shape[0]
+        x2 = x.reshape(T * 60, 64).contiguous()
+        ws = [t.detach().contiguous() for t in (wq, wk, wv, wc)]
+        y = ops.mhsa_layer(x2, ws[0], ws[1], ws[2], ws[3], bc.detach().contiguous(), mode=0 if residual else 1)
+        ctx.save_for_backward(x2, *ws)
+        ctx.residual, ctx.xshape = bool(residual), x.shape
+        return y.view(T, 60, 64)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wq, wk, wv, wc = ctx.saved_tensors
+        T = x2.shape[0] // 60
+        dy2 = dy.reshape(T * 60, 64).contiguous()
+        wqkv = torch.cat([wq, wk, wv], 0).contiguous()                       # (192, 64)
+        qkv = ops.linear(x2, wqkv)                                           # recomputed, not kept from the forward
+        att = ops.mhsa_attention(qkv, T, 0, 64, 128)
+        dO = ops.linear(dy2, wc.t().contiguous())                            # dY Wc
+        dqkv = torch.empty_like(qkv)
+        _check(_lib.lib().etch_mhsa_attention_backward(ctypes.c_long(T), _ptr(qkv), ctypes.c_long(192), 0, 64, 128, _ptr(dO), ctypes.c_long(64),
+                                                       _ptr(dqkv), _stream()), "etch_mhsa_attention_backward")
+        dx = ops.linear(dqkv, wqkv.t().contiguous(), res=dy2 if ctx.residual else None, res_mode=2 if ctx.residual else 0)
+        dwqkv = gemm_tn(dqkv, x2)                                            # (192, 64)
+        dwc = gemm_tn(dy2, att)
+        return dx.view(ctx.xshape), dwqkv[:64], dwqkv[64:128], dwqkv[128:], dwc, colsum(dy2), None
+
+
+def mhsa_layer(x, wq, wk, wv, wc, bc, residual=True):
+    """x (T,60,64) -> (T,60,64), differentiable in x and all five parameters."""
+    return MHSALayerFunction.apply(x, wq, wk, wv, wc, bc, residual)

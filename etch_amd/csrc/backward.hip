@@ -357,3 +357,114 @@ int etch_instnorm_act_backward(int b, int rows, int C, const float* x, const flo
 int etch_instnorm_act_backward_workspace_bytes(int b, int C) { return (int)((size_t)INB_CHUNKS * b * 2 * C * sizeof(double)); }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Backward of DotProdAttention inside MultiHeadAttention (direction_backbones.py:102-129,160-194) for the ETCH head: 60 tokens per
+// point, 8 heads x 8 dims, scores scaled by 1/sqrt(8).  Inputs: qkv rows [T*60][ld] (q | k | v at column offsets qoff / koff / voff,
+// head h in columns 8h..8h+7 of each) as the forward's fused QKV GEMM produces them, dO rows [T*60][ldo] (gradient of the concatenated
+// head outputs).  Output: dqkv rows [T*60][ld] at the same offsets.
+//   P = softmax(S), S = Q K^T / sqrt(8);  dP = dO V^T;  D_i = sum_j dP_ij P_ij;  dS = P * (dP - D) / sqrt(8)
+//   dQ = dS K;  dK = dS^T Q;  dV = P^T dO
+// One workgroup (4 waves) per point, wave = head (two rounds of 4 heads), lane = token.  Pass 1 (lane = query i): softmax statistics,
+// D_i and dQ_i; pass 2 (lane = key j): the scores are formed again column-wise, dK_j and dV_j accumulate in the lane -- no atomics and
+// no cross-lane reductions, every sum runs over the 60 tokens in index order: reproducible bit for bit.
+// ------------------------------------------------------------------------------------------------
+#define MB_L 60
+#define MB_HD 8
+__global__ void __launch_bounds__(256) mhsa_attention_backward_kernel(const float* __restrict__ qkv, long ld, int qoff, int koff, int voff,
+                                                                      const float* __restrict__ dO, long ldo, float* __restrict__ dqkv) {
+    __shared__ float qs[4][MB_L][MB_HD], ks[4][MB_L][MB_HD], vs[4][MB_L][MB_HD], gs[4][MB_L][MB_HD];
+    __shared__ float st_m[4][64], st_l[4][64], st_d[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t row0 = (size_t)blockIdx.x * MB_L;
+    const float scale = 0.35355339059327373f;                  // 1/sqrt(8)
+    for (int round = 0; round < 2; ++round) {
+        const int h = round * 4 + w;
+        for (int e = lane; e < MB_L * 2; e += 64) {
+            const int r = e >> 1, half = (e & 1) * 4;
+            const float* base = qkv + (row0 + r) * ld + h * MB_HD + half;
+            *reinterpret_cast<float4*>(&qs[w][r][half]) = *reinterpret_cast<const float4*>(base + qoff);
+            *reinterpret_cast<float4*>(&ks[w][r][half]) = *reinterpret_cast<const float4*>(base + koff);
+            *reinterpret_cast<float4*>(&vs[w][r][half]) = *reinterpret_cast<const float4*>(base + voff);
+            *reinterpret_cast<float4*>(&gs[w][r][half]) = *reinterpret_cast<const float4*>(dO + (row0 + r) * ldo + h * MB_HD + half);
+        }
+        __syncthreads();
+        const int i = lane < MB_L ? lane : MB_L - 1;           // lanes 60..63 shadow token 59 and store nothing
+        // ---- pass 1: lane = query i
+        {
+            float q[MB_HD], g[MB_HD];
+#pragma unroll
+            for (int d = 0; d < MB_HD; ++d) { q[d] = qs[w][i][d]; g[d] = gs[w][i][d]; }
+            float m = -INFINITY;
+            for (int j = 0; j < MB_L; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int d = 0; d < MB_HD; ++d) s += q[d] * ks[w][j][d];
+                m = fmaxf(m, s * scale);
+            }
+            float l = 0.f, D = 0.f;
+            for (int j = 0; j < MB_L; ++j) {
+                float s = 0.f, dp = 0.f;
+#pragma unroll
+                for (int d = 0; d < MB_HD; ++d) { s += q[d] * ks[w][j][d]; dp += g[d] * vs[w][j][d]; }
+                const float e = __expf(s * scale - m);
+                l += e;
+                D += e * dp;
+            }
+            const float il = 1.0f / l;
+            D *= il;
+            float dq[MB_HD];
+#pragma unroll
+            for (int d = 0; d < MB_HD; ++d) dq[d] = 0.f;
+            for (int j = 0; j < MB_L; ++j) {
+                float s = 0.f, dp = 0.f;
+#pragma unroll
+                for (int d = 0; d < MB_HD; ++d) { s += q[d] * ks[w][j][d]; dp += g[d] * vs[w][j][d]; }
+                const float ds = __expf(s * scale - m) * il * (dp - D) * scale;
+#pragma unroll
+                for (int d = 0; d < MB_HD; ++d) dq[d] += ds * ks[w][j][d];
+            }
+            st_m[w][lane] = m; st_l[w][lane] = il; st_d[w][lane] = D;
+            if (lane < MB_L) {
+                float* o = dqkv + (row0 + lane) * ld + qoff + h * MB_HD;
+                *reinterpret_cast<float4*>(o) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+                *reinterpret_cast<float4*>(o + 4) = make_float4(dq[4], dq[5], dq[6], dq[7]);
+            }
+        }
+        __syncthreads();
+        // ---- pass 2: lane = key j
+        {
+            float k[MB_HD], v[MB_HD], dk[MB_HD], dv[MB_HD];
+#pragma unroll
+            for (int d = 0; d < MB_HD; ++d) { k[d] = ks[w][i][d]; v[d] = vs[w][i][d]; dk[d] = 0.f; dv[d] = 0.f; }
+            for (int t = 0; t < MB_L; ++t) {                   // query t: broadcast reads
+                float s = 0.f, dp = 0.f;
+#pragma unroll
+                for (int d = 0; d < MB_HD; ++d) { s += qs[w][t][d] * k[d]; dp += gs[w][t][d] * v[d]; }
+                const float p = __expf(s * scale - st_m[w][t]) * st_l[w][t];
+                const float ds = p * (dp - st_d[w][t]) * scale;
+#pragma unroll
+                for (int d = 0; d < MB_HD; ++d) { dk[d] += ds * qs[w][t][d]; dv[d] += p * gs[w][t][d]; }
+            }
+            if (lane < MB_L) {
+                float* ok = dqkv + (row0 + lane) * ld + koff + h * MB_HD;
+                float* ov = dqkv + (row0 + lane) * ld + voff + h * MB_HD;
+                *reinterpret_cast<float4*>(ok) = make_float4(dk[0], dk[1], dk[2], dk[3]);
+                *reinterpret_cast<float4*>(ok + 4) = make_float4(dk[4], dk[5], dk[6], dk[7]);
+                *reinterpret_cast<float4*>(ov) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+                *reinterpret_cast<float4*>(ov + 4) = make_float4(dv[4], dv[5], dv[6], dv[7]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int etch_mhsa_attention_backward(long T, const float* qkv, long ld, int qoff, int koff, int voff, const float* dO, long ldo,
+                                            float* dqkv, void* stream) {
+    if (T <= 0) return ETCH_OK;
+    if (!qkv || !dO || !dqkv) return ETCH_EINVAL;
+    if ((ld & 3) || (ldo & 3) || (qoff & 3) || (koff & 3) || (voff & 3) || (((uintptr_t)qkv | (uintptr_t)dO | (uintptr_t)dqkv) & 15)) return ETCH_EINVAL;
+    hipLaunchKernelGGL(mhsa_attention_backward_kernel, dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, qkv, ld, qoff, koff, voff, dO, ldo, dqkv);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}

@@ -281,6 +281,12 @@ int etch_inter_dfeat(int b, int cin, int p1, int p2, int p_begin, int pc, int nn
  * (functional.py:331-378 in channels-last rows). */
 int etch_intra_rows(long points, int C, int nt, const int* intra_idx, const float* x, float* xg, void* stream);
 
+/* Backward of the 8-head dot-product attention over a point's 60 tokens (direction_backbones.py:102-129; autograd through it in
+ * train.py:77-101): qkv rows [T*60][ld] with q / k / v at column offsets qoff / koff / voff (the layout of etch_mhsa_attention), dO rows
+ * [T*60][ldo] = gradient of the concatenated head outputs -> dqkv rows [T*60][ld] at the same offsets.  Fixed summation order. */
+int etch_mhsa_attention_backward(long T, const float* qkv, long ld, int qoff, int koff, int voff, const float* dO, long ldo, float* dqkv,
+                                 void* stream);
+
 /* Column sums s[c] = sum_r x[r,c] (bias gradients): fp64, two levels, fixed order.  workspace: 64*C doubles. */
 int etch_colsum(long R, int C, const float* x, double* workspace, float* out, void* stream);
 

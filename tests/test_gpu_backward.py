@@ -136,3 +136,38 @@ def test_gemm_tn_and_colsum():
         c2 = A.gemm_tn(a, bm, out=c.clone(), accumulate=True)
         assert rel_err(c2.cpu().numpy(), 2 * ref.numpy()) < 1e-5
         assert rel_err(A.colsum(a).cpu().numpy(), a.double().cpu().sum(0).numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("T,residual", [(1, True), (37, True), (37, False)])
+def test_mhsa_layer_gradients_vs_autograd_of_the_oracle_form(T, residual):
+    """etch_amd.autograd.mhsa_layer (fused forward; attention-core backward kernel + matrix-core GEMMs) against fp64 autograd through
+    the oracle's restatement of MultiHeadAttention (direction_backbones.py:132-194); reproducible run to run."""
+    from etch_amd import autograd as A
+    from oracle import stage1 as S1
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(T, 60, 64, generator=g)
+    W = [torch.randn(64, 64, generator=g) * 0.2 for _ in range(4)]
+    bc = torch.randn(64, generator=g) * 0.1
+    G = torch.randn(T, 60, 64, generator=g)
+    sd = {"l.query_transform.weight": W[0], "l.key_transform.weight": W[1], "l.value_transform.weight": W[2], "l.head_combine.weight": W[3],
+          "l.head_combine.bias": bc}
+    sd64 = {k: v.double().requires_grad_() for k, v in sd.items()}
+    x64 = x.double().requires_grad_()
+    y_ref = S1.mhsa_layer(sd64, "l.", x64)
+    if residual:
+        y_ref = y_ref + x64
+    (y_ref * G.double()).sum().backward()
+    ref = [x64.grad] + [sd64[k].grad for k in sd]
+
+    def ours():
+        ts = [t.cuda().requires_grad_() for t in [x] + W + [bc]]
+        y = A.mhsa_layer(*ts, residual=residual)
+        (y * G.cuda()).sum().backward()
+        return y.detach().cpu(), [t.grad.cpu() for t in ts]
+    y, grads = ours()
+    assert rel_err(y.numpy(), y_ref.detach().numpy()) < 1e-5
+    for name, a, b in zip(["x", "wq", "wk", "wv", "wc", "bc"], grads, ref):
+        assert rel_err(a.numpy(), b.numpy()) < 1e-4, name
+    _, again = ours()
+    for a, b in zip(grads, again):
+        assert torch.equal(a, b)
