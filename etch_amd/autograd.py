@@ -196,3 +196,64 @@ class MHSALayerFunction(torch.autograd.Function):
 def mhsa_layer(x, wq, wk, wv, wc, bc, residual=True):
     """x (T,60,64) -> (T,60,64), differentiable in x and all five parameters."""
     return MHSALayerFunction.apply(x, wq, wk, wv, wc, bc, residual)
+
+
+def segment_sum_rows(src, index, nseg):
+    """dst[q] = sum of the rows e of src with index[e] == q, summed in increasing e: scatter-add with a fixed order."""
+    key, perm = torch.sort(index.reshape(-1).long(), stable=True)
+    seg = torch.searchsorted(key, torch.arange(nseg + 1, device=key.device, dtype=torch.int64)).contiguous()
+    dst = torch.empty((nseg, src.shape[1]), dtype=torch.float32, device=src.device)
+    _check(_lib.lib().etch_segment_sum_rows(ctypes.c_long(nseg), src.shape[1], _ptr(src), _ptr(perm.contiguous()), _ptr(seg), _ptr(dst), _stream()),
+           "etch_segment_sum_rows")
+    return dst
+
+
+class PTVectorAttentionFunction(torch.autograd.Function):
+    """The vector-attention core of PointTransformerLayer (pointtransformer_seg.py:28-36 after the q / k / v Linear layers) with eval-mode
+    BatchNorm as folded per-channel (scale, shift) constants.  Differentiable in xq, xk, xv and in the Linear layers of linear_p / linear_w;
+    forward = etch_pt_attention, backward = etch_pt_attention_backward + matrix-core GEMMs / column sums / ordered segment sums."""
+
+    @staticmethod
+    def forward(ctx, p, xq, xk, xv, idx, W0, b0, s_p, t_p, W3, b3, s_w0, t_w0, W2, b2, s_w3, t_w3, W5, b5):
+        d = lambda t: t.detach().contiguous()
+        n, c = xq.shape
+        ns = idx.shape[1]
+        qkv = torch.cat([d(xq), d(xk), d(xv)], 1).contiguous()
+        params = [d(W0), d(b0), d(s_p), d(t_p), d(W3), d(b3), d(s_w0), d(t_w0), d(W2).t().contiguous(), d(b2), d(s_w3), d(t_w3), d(W5), d(b5)]
+        out = ops.pt_attention(p, qkv, c, idx, params + [None, None], ns)
+        ctx.save_for_backward(p, qkv, idx, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        p, qkv, idx, *params = ctx.saved_tensors
+        n, ns = idx.shape
+        c = qkv.shape[1] // 3
+        cs, E = c // 8, n * ns
+        dev = qkv.device
+        dout = dout.contiguous()
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        GV, GU, A, DZ, G, DL, H4, DH4, R4, dxq = (new(E, c), new(E, c), new(E, c), new(E, cs), new(E, cs), new(E, cs), new(E, 4), new(E, 4),
+                                                  new(E, 4), new(n, c))
+        outs = [GV, GU, A, DZ, G, DL, H4, DH4, R4, dxq]
+        parr = (ctypes.c_void_p * 16)(*([t.data_ptr() for t in params] + [0, 0]))
+        oarr = (ctypes.c_void_p * 10)(*[t.data_ptr() for t in outs])
+        base = qkv.data_ptr()
+        vp = ctypes.c_void_p
+        _check(_lib.lib().etch_pt_attention_backward(n, c, ns, _ptr(p), vp(base), vp(base + 4 * c), vp(base + 8 * c), ctypes.c_long(qkv.stride(0)),
+                                                     _ptr(idx), parr, _ptr(dout), ctypes.c_long(dout.stride(0)), oarr, _stream()),
+               "etch_pt_attention_backward")
+        dxk = segment_sum_rows(GU, idx, n)
+        dxv = segment_sum_rows(GV, idx, n)
+        dW5, db5 = gemm_tn(DL, G), colsum(DL)
+        dW2, db2 = gemm_tn(DZ, A), colsum(DZ)
+        dW3 = gemm_tn(GU, H4, out=gemm_tn(GV, H4), accumulate=True)[:, :3].contiguous()
+        db3 = colsum(GV) + colsum(GU)
+        dW0, db0 = gemm_tn(DH4, R4)[:3, :3].contiguous(), colsum(DH4)[:3].contiguous()
+        return (None, dxq, dxk, dxv, None, dW0, db0, None, None, dW3, db3, None, None, dW2, db2, None, None, dW5, db5)
+
+
+def pt_vector_attention(p, xq, xk, xv, idx, W0, b0, s_p, t_p, W3, b3, s_w0, t_w0, W2, b2, s_w3, t_w3, W5, b5):
+    """p (n,3), xq / xk / xv (n,c), idx (n,ns) int32 kNN indices, linear_p = [W0 (3,3), b0, BN(s_p, t_p), ReLU, W3 (c,3), b3],
+    linear_w = [BN(s_w0, t_w0), ReLU, W2 (c/8,c), b2, BN(s_w3, t_w3), ReLU, W5 (c/8,c/8), b5] -> (n,c)."""
+    return PTVectorAttentionFunction.apply(p, xq, xk, xv, idx, W0, b0, s_p, t_p, W3, b3, s_w0, t_w0, W2, b2, s_w3, t_w3, W5, b5)

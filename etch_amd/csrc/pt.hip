@@ -293,6 +293,178 @@ static inline unsigned grid_for(size_t total, int per_block) {
     return (unsigned)b;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward of the vector-attention core (the function pt_attention_kernel computes, without the optional output BN; eval-mode BatchNorm
+// = the folded per-channel (scale, shift), treated as constants): autograd through pointtransformer_seg.py:28-36 as train.py:77-101
+// obtains it.  One workgroup per point i recomputes the forward in LDS and writes, per (point, neighbour) row e = i ns + j:
+//   GV[e][c]  = dout[c] w_j[c % cs]                       gradient of (x_v[idx] + p_r)         -> scattered to dx_v by idx
+//   GU[e][c]  = gradient of u = x_k[idx] - x_q + p_r      -> scattered to dx_k by idx;  dx_q[i] = - sum_j GU
+//   A[e][c], DZ[e][cs]     input / output-gradient rows of linear_w[2]:  dW2 = DZ^T A,  db2 = colsum DZ
+//   G[e][cs], DL[e][cs]    input / output-gradient rows of linear_w[5]:  dW5 = DL^T G,  db5 = colsum DL
+//   H4, DH4, R4 [e][4]     linear_p: hidden (post ReLU), gradient at linear_p[0]'s output, relative position (3 used + 0):
+//                          dW3 = (GV + GU)^T H4, db3 = colsum(GV + GU);  dW0 = DH4^T R4, db0 = colsum DH4
+// The sums over rows (matrix-core GEMMs, column sums, per-source-point segment sums) run in fixed orders: reproducible bit for bit.
+// ------------------------------------------------------------------------------------------------
+struct PtAttnBwdOut {
+    float* GV; float* GU; float* A; float* DZ; float* G; float* DL; float* H4; float* DH4; float* R4; float* dxq;
+};
+
+__global__ void __launch_bounds__(128) pt_attention_backward_kernel(PtAttnParams a, const float* __restrict__ dout, long lddo, PtAttnBwdOut o) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int c = a.c, ns = a.ns, cs = c >> 3;
+    float* s_pr = sm;                    // [ns][c]   p_r, later d p_r
+    float* s_a = s_pr + ns * c;          // [ns][c]   a = relu(bn0(u))
+    float* s_gv = s_a + ns * c;          // [ns][c]   GV
+    float* s_g = s_gv + ns * c;          // [ns][cs]  g = relu(bn3(z))
+    float* s_w = s_g + ns * cs;          // [ns][cs]  logits -> softmax weights
+    float* s_d = s_w + ns * cs;          // [ns][cs]  dw -> dl -> dz
+    float* s_h = s_d + ns * cs;          // [ns][4]   h (post ReLU)
+    float* s_r = s_h + ns * 4;           // [ns][4]   relative position
+    int* s_idx = (int*)(s_r + ns * 4);   // [ns]
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const size_t e0 = (size_t)i * ns;
+    if (tid < ns) {
+        const int j = a.idx[e0 + tid];
+        s_idx[tid] = j;
+        const float r[3] = {a.p[(size_t)j * 3] - a.p[(size_t)i * 3], a.p[(size_t)j * 3 + 1] - a.p[(size_t)i * 3 + 1],
+                            a.p[(size_t)j * 3 + 2] - a.p[(size_t)i * 3 + 2]};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            float h = a.W0[q * 3] * r[0] + a.W0[q * 3 + 1] * r[1] + a.W0[q * 3 + 2] * r[2] + a.b0[q];
+            h = h * a.s_p[q] + a.t_p[q];
+            s_h[tid * 4 + q] = fmaxf(h, 0.f);
+            s_r[tid * 4 + q] = r[q];
+        }
+        s_h[tid * 4 + 3] = 0.f; s_r[tid * 4 + 3] = 0.f;
+    }
+    __syncthreads();
+    // ---- forward (as pt_attention_kernel)
+    for (int e = tid; e < ns * c; e += 128) {
+        const int j = e / c, ch = e - j * c;
+        const float pr = a.W3[ch * 3] * s_h[j * 4] + a.W3[ch * 3 + 1] * s_h[j * 4 + 1] + a.W3[ch * 3 + 2] * s_h[j * 4 + 2] + a.b3[ch];
+        s_pr[e] = pr;
+        float u = a.xk[(size_t)s_idx[j] * a.ldq + ch] - a.xq[(size_t)i * a.ldq + ch] + pr;
+        u = u * a.s_w0[ch] + a.t_w0[ch];
+        s_a[e] = fmaxf(u, 0.f);
+    }
+    __syncthreads();
+    for (int e = tid; e < ns * cs; e += 128) {
+        const int j = e / cs, t = e - j * cs;
+        float acc = 0.f;
+        const float* ar = s_a + j * c;
+        for (int ch = 0; ch < c; ++ch) acc = fmaf(a.W2T[(size_t)ch * cs + t], ar[ch], acc);
+        acc += a.b2[t];
+        acc = acc * a.s_w3[t] + a.t_w3[t];
+        s_g[e] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    for (int e = tid; e < ns * cs; e += 128) {
+        const int j = e / cs, t = e - j * cs;
+        float acc = 0.f;
+        for (int u = 0; u < cs; ++u) acc = fmaf(a.W5[t * cs + u], s_g[j * cs + u], acc);
+        s_w[e] = acc + a.b5[t];
+    }
+    __syncthreads();
+    for (int t = tid; t < cs; t += 128) {
+        float mx = -INFINITY;
+        for (int j = 0; j < ns; ++j) mx = fmaxf(mx, s_w[j * cs + t]);
+        float den = 0.f;
+        for (int j = 0; j < ns; ++j) { const float ev = __expf(s_w[j * cs + t] - mx); s_w[j * cs + t] = ev; den += ev; }
+        const float inv = 1.0f / den;
+        for (int j = 0; j < ns; ++j) s_w[j * cs + t] *= inv;
+    }
+    __syncthreads();
+    // ---- backward
+    // GV and dw[j][t] = sum over the 8 shared planes of dout * (x_v + p_r)
+    for (int e = tid; e < ns * c; e += 128) {
+        const int j = e / c, ch = e - j * c;
+        const float gv = dout[(size_t)i * lddo + ch] * s_w[j * cs + ch % cs];
+        s_gv[e] = gv;
+        o.GV[(e0 + j) * c + ch] = gv;
+    }
+    for (int e = tid; e < ns * cs; e += 128) {
+        const int j = e / cs, t = e - j * cs;
+        float acc = 0.f;
+        for (int sh = 0; sh < 8; ++sh) {
+            const int ch = sh * cs + t;
+            acc += dout[(size_t)i * lddo + ch] * (a.xv[(size_t)s_idx[j] * a.ldq + ch] + s_pr[j * c + ch]);
+        }
+        s_d[e] = acc;
+    }
+    __syncthreads();
+    // softmax backward over the neighbours: dl = w (dw - sum_j dw w)
+    for (int t = tid; t < cs; t += 128) {
+        float D = 0.f;
+        for (int j = 0; j < ns; ++j) D += s_d[j * cs + t] * s_w[j * cs + t];
+        for (int j = 0; j < ns; ++j) {
+            const float dl = s_w[j * cs + t] * (s_d[j * cs + t] - D);
+            s_w[j * cs + t] = dl;                                       // s_w now holds dl
+            o.DL[(e0 + j) * cs + t] = dl;
+            o.G[(e0 + j) * cs + t] = s_g[j * cs + t];
+        }
+    }
+    __syncthreads();
+    // dz = (W5^T dl) * s_w3 * [g > 0]
+    for (int e = tid; e < ns * cs; e += 128) {
+        const int j = e / cs, u = e - j * cs;
+        float acc = 0.f;
+        for (int t = 0; t < cs; ++t) acc = fmaf(a.W5[t * cs + u], s_w[j * cs + t], acc);
+        const float dz = s_g[e] > 0.f ? acc * a.s_w3[u] : 0.f;
+        s_d[e] = dz;
+        o.DZ[(e0 + j) * cs + u] = dz;
+    }
+    __syncthreads();
+    // du = (W2^T dz) * s_w0 * [a > 0];  d p_r = GV + du
+    for (int e = tid; e < ns * c; e += 128) {
+        const int j = e / c, ch = e - j * c;
+        float acc = 0.f;
+        for (int u = 0; u < cs; ++u) acc = fmaf(a.W2T[(size_t)ch * cs + u], s_d[j * cs + u], acc);
+        const float av = s_a[e];
+        const float du = av > 0.f ? acc * a.s_w0[ch] : 0.f;
+        o.GU[(e0 + j) * c + ch] = du;
+        o.A[(e0 + j) * c + ch] = av;
+        s_a[e] = du;                                                    // s_a now holds du
+        s_pr[e] = s_gv[e] + du;                                         // s_pr now holds d p_r
+    }
+    __syncthreads();
+    for (int ch = tid; ch < c; ch += 128) {
+        float acc = 0.f;
+        for (int j = 0; j < ns; ++j) acc += s_a[j * c + ch];
+        o.dxq[(size_t)i * c + ch] = -acc;
+    }
+    // dh = W3^T d p_r;  gradient at linear_p[0]'s output = dh * s_p * [h > 0]
+    for (int e = tid; e < ns * 4; e += 128) {
+        const int j = e >> 2, q = e & 3;
+        float v = 0.f;
+        if (q < 3) {
+            float acc = 0.f;
+            for (int ch = 0; ch < c; ++ch) acc = fmaf(a.W3[ch * 3 + q], s_pr[j * c + ch], acc);
+            v = s_h[e] > 0.f ? acc * a.s_p[q] : 0.f;
+        }
+        o.DH4[(e0 + j) * 4 + q] = v;
+        o.H4[(e0 + j) * 4 + q] = s_h[e];
+        o.R4[(e0 + j) * 4 + q] = s_r[e];
+    }
+}
+
+// dst[q][:] = sum over the rows perm[seg[q] .. seg[q+1]) of src, in that order (a stable sort of the index list by source point):
+// the deterministic form of scatter-add
+__global__ void __launch_bounds__(256) segment_sum_rows_kernel(long nseg, int C, const float* __restrict__ src, const long long* __restrict__ perm,
+                                                               const long long* __restrict__ seg, float* __restrict__ dst) {
+    const int c4 = C >> 2;
+    const long total = nseg * c4;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long q = e / c4;
+        const int ch = (int)(e - q * c4) * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (long long k = seg[q]; k < seg[q + 1]; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)perm[k] * C + ch);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(dst + (size_t)q * C + ch) = acc;
+    }
+}
+
 extern "C" {
 
 // params: 16 device pointers in the order of PtAttnParams (W0,b0,s_p,t_p,W3,b3,s_w0,t_w0,W2T,b2,s_w3,t_w3,W5,b5,s_out,t_out)
@@ -408,6 +580,40 @@ int etch_grouped_dot(long R, int G, int J, const float* h, long ldh, const float
 int etch_softmax_dot(long R, int G, const float* logits, const float* v, float* out, void* stream) {
     if (R <= 0) return ETCH_OK;
     hipLaunchKernelGGL(softmax_dot_kernel, dim3(grid_for((size_t)R, 4)), dim3(256), 0, (hipStream_t)stream, R, G, logits, v, out);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_pt_attention_backward(int n, int c, int ns, const float* p, const float* xq, const float* xk, const float* xv, long ldq, const int* idx,
+                               const float* const* params, const float* dout, long lddo, float* const* outs, void* stream) {
+    if (n <= 0) return ETCH_OK;
+    if (c <= 0 || (c & 7) || ns <= 0 || ns > 128 || !params || !outs || !dout) return ETCH_EINVAL;
+    PtAttnParams a;
+    a.p = p; a.xq = xq; a.xk = xk; a.xv = xv; a.ldq = ldq; a.idx = idx;
+    a.W0 = params[0]; a.b0 = params[1]; a.s_p = params[2]; a.t_p = params[3]; a.W3 = params[4]; a.b3 = params[5];
+    a.s_w0 = params[6]; a.t_w0 = params[7]; a.W2T = params[8]; a.b2 = params[9]; a.s_w3 = params[10]; a.t_w3 = params[11];
+    a.W5 = params[12]; a.b5 = params[13]; a.s_out = nullptr; a.t_out = nullptr;
+    a.out = nullptr; a.ldo = 0; a.n = n; a.c = c; a.ns = ns;
+    PtAttnBwdOut o{outs[0], outs[1], outs[2], outs[3], outs[4], outs[5], outs[6], outs[7], outs[8], outs[9]};
+    for (int k = 0; k < 10; ++k) if (!outs[k]) return ETCH_EINVAL;
+    const int cs = c / 8;
+    const size_t lds = (size_t)(3 * ns * c + 3 * ns * cs + ns * 8 + ns) * sizeof(float);
+    if (lds > 160 * 1024) return ETCH_EUNSUPPORTED;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)pt_attention_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(pt_attention_backward_kernel, dim3(n), dim3(128), lds, (hipStream_t)stream, a, dout, lddo, o);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_segment_sum_rows(long nseg, int C, const float* src, const long long* perm, const long long* seg, float* dst, void* stream) {
+    if (nseg <= 0) return ETCH_OK;
+    if (C <= 0 || (C & 3) || !src || !perm || !seg || !dst) return ETCH_EINVAL;
+    long blocks = (nseg * (C >> 2) + 255) / 256;
+    if (blocks > 65535L * 16) blocks = 65535L * 16;
+    hipLaunchKernelGGL(segment_sum_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, nseg, C, src, perm, seg, dst);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }

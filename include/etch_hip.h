@@ -281,6 +281,18 @@ int etch_inter_dfeat(int b, int cin, int p1, int p2, int p_begin, int pc, int nn
  * (functional.py:331-378 in channels-last rows). */
 int etch_intra_rows(long points, int C, int nt, const int* intra_idx, const float* x, float* xg, void* stream);
 
+/* Backward of the vector-attention core of etch_pt_attention (pointtransformer_seg.py:28-36, eval-mode BatchNorm as folded constants, no
+ * output BN): arguments as etch_pt_attention (params[0..13]) + dout (n,c) rows with leading dimension lddo.  outs = 10 device pointers,
+ * rows indexed by e = i*ns + j:  GV (E,c) gradient of (x_v[idx] + p_r);  GU (E,c) gradient of x_k[idx] - x_q + p_r;  A (E,c), DZ (E,c/8)
+ * input / output-gradient rows of linear_w[2];  G (E,c/8), DL (E,c/8) the same for linear_w[5];  H4, DH4, R4 (E,4) hidden, output
+ * gradient of linear_p[0] and relative positions (3 used);  dxq (n,c) = -sum_j GU.  The caller closes the sums over rows with
+ * etch_gemm_tn / etch_colsum and scatters GV / GU to the source points with etch_segment_sum_rows (etch_amd/autograd.py). */
+int etch_pt_attention_backward(int n, int c, int ns, const float* p, const float* xq, const float* xk, const float* xv, long ldq, const int* idx,
+                               const float* const* params, const float* dout, long lddo, float* const* outs, void* stream);
+/* dst[q,:] = sum of src[perm[k],:] for k in [seg[q], seg[q+1]) in that order (perm = stable sort of an index list by target row, seg its
+ * segment offsets, int64): the reproducible form of scatter-add.  C % 4 == 0. */
+int etch_segment_sum_rows(long nseg, int C, const float* src, const long long* perm, const long long* seg, float* dst, void* stream);
+
 /* Backward of the 8-head dot-product attention over a point's 60 tokens (direction_backbones.py:102-129; autograd through it in
  * train.py:77-101): qkv rows [T*60][ld] with q / k / v at column offsets qoff / koff / voff (the layout of etch_mhsa_attention), dO rows
  * [T*60][ldo] = gradient of the concatenated head outputs -> dqkv rows [T*60][ld] at the same offsets.  Fixed summation order. */

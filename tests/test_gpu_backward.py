@@ -171,3 +171,51 @@ def test_mhsa_layer_gradients_vs_autograd_of_the_oracle_form(T, residual):
     _, again = ours()
     for a, b in zip(grads, again):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,c,ns", [(50, 32, 8), (300, 64, 16), (40, 256, 16)])
+def test_pt_vector_attention_gradients_vs_fp64_autograd(n, c, ns):
+    """etch_amd.autograd.pt_vector_attention against fp64 autograd through the oracle's statement of PointTransformerLayer's core
+    (oracle/stage1.py::pt_layer after the q/k/v Linear layers; eval BatchNorm as scale / shift); reproducible run to run."""
+    from etch_amd import autograd as A
+    cs = c // 8
+    g = torch.Generator().manual_seed(n + c)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    p = rn(n, 3) * 0.2
+    xq, xk, xv = rn(n, c), rn(n, c), rn(n, c)
+    d2 = ((p[:, None] - p[None]) ** 2).sum(-1)
+    idx = d2.topk(ns, largest=False).indices.int()
+    P = dict(W0=rn(3, 3) * 2, b0=rn(3) * 0.1, s_p=rn(3).abs() + 0.5, t_p=rn(3) * 0.1, W3=rn(c, 3), b3=rn(c) * 0.1, s_w0=rn(c).abs() + 0.5, t_w0=rn(c) * 0.1,
+             W2=rn(cs, c) / c ** 0.5, b2=rn(cs) * 0.1, s_w3=rn(cs).abs() + 0.5, t_w3=rn(cs) * 0.1, W5=rn(cs, cs) / cs ** 0.5, b5=rn(cs) * 0.1)
+    order = ["W0", "b0", "s_p", "t_p", "W3", "b3", "s_w0", "t_w0", "W2", "b2", "s_w3", "t_w3", "W5", "b5"]
+    diff = ["xq", "xk", "xv", "W0", "b0", "W3", "b3", "W2", "b2", "W5", "b5"]
+    Gd = rn(n, c)
+
+    def ref(xq, xk, xv, P):
+        li = idx.long()
+        r = p.double()[li] - p.double()[:, None]                                  # (n, ns, 3)
+        h = F.relu(F.linear(r, P["W0"], P["b0"]) * P["s_p"] + P["t_p"])
+        pr = F.linear(h, P["W3"], P["b3"])
+        w = F.relu((xk[li] - xq[:, None] + pr) * P["s_w0"] + P["t_w0"])
+        w = F.relu(F.linear(w, P["W2"], P["b2"]) * P["s_w3"] + P["t_w3"])
+        w = F.softmax(F.linear(w, P["W5"], P["b5"]), dim=1)
+        return ((xv[li] + pr).view(n, ns, 8, cs) * w.unsqueeze(2)).sum(1).view(n, c)
+    t64 = {k: v.double().requires_grad_(k in diff) for k, v in dict(xq=xq, xk=xk, xv=xv, **P).items()}
+    y_ref = ref(t64["xq"], t64["xk"], t64["xv"], t64)
+    (y_ref * Gd.double()).sum().backward()
+
+    def ours():
+        t = {k: v.cuda().requires_grad_(k in diff) for k, v in dict(xq=xq, xk=xk, xv=xv, **P).items()}
+        y = A.pt_vector_attention(p.cuda(), t["xq"], t["xk"], t["xv"], idx.cuda(), *[t[k] for k in order])
+        (y * Gd.cuda()).sum().backward()
+        return y.detach().cpu(), {k: t[k].grad.cpu() for k in diff}
+    y, grads = ours()
+    assert rel_err(y.numpy(), y_ref.detach().numpy()) < 1e-5
+    for k in diff:
+        if k == "b5":      # softmax over the neighbours is shift-invariant: the gradient is analytically zero (1e-15 in fp64)
+            assert np.abs(grads[k].numpy()).max() < 1e-5 * np.abs(t64["W5"].grad.numpy()).max()
+        else:
+            assert rel_err(grads[k].numpy(), t64[k].grad.numpy()) < 1e-4, k
+    _, again = ours()
+    for k in diff:
+        assert torch.equal(grads[k], again[k]), k
