@@ -29,6 +29,13 @@
 // chunk and consumed by the Cholesky solve before the next linearisation.
 #include "common.h"
 
+#ifndef LM_ELIM_COLS
+#define LM_ELIM_COLS 3    // pivots eliminated per barrier in the 85-DoF solve (2: the two-column form, kept for A/B)
+#endif
+#ifndef LM_TIMERS
+#define LM_TIMERS 1      // per-phase s_memrealtime breakdown in `phase_out` (scratch/lm_time.py); measured cost: none (82.4 vs 82.8 us / iteration without)
+#endif
+
 #define LM_MAXM 96                  // markers per scan
 #define NB_STAGE0 2                 // fit_SMPL.py:161-165: stage 0 optimises betas[:2]
 
@@ -228,7 +235,9 @@ __device__ __attribute__((noinline)) void lm_linearize(LmShared<BM>& s, const Sm
     }
     __syncthreads();
     long long t0 = 0;
+#if LM_TIMERS
     if (tid == 0) t0 = wall_clock64();
+#endif
     for (int e = tid; e < NPF; e += BM::THREADS) {            // pose feature vec(R_k - I), k = 1..NJ-1
         const int k = 1 + e / 9, q = e - (k - 1) * 9;
         L.pf[e] = (float)(L.R[k * 9 + q] - ((q % 4 == 0) ? 1.0 : 0.0));
@@ -288,7 +297,9 @@ __device__ __attribute__((noinline)) void lm_linearize(LmShared<BM>& s, const Sm
         L.twd[l][j][a] -= (float)(Rj[a * 3] * L.Jd[(j * 3 + 0) * NB + l] + Rj[a * 3 + 1] * L.Jd[(j * 3 + 1) * NB + l] + Rj[a * 3 + 2] * L.Jd[(j * 3 + 2) * NB + l]);
     }
     __syncthreads();
+#if LM_TIMERS
     if (tid == 0) { const long long t1 = wall_clock64(); s.phase[0] += t1 - t0; t0 = t1; }
+#endif
 
     // ---- markers as flat passes of the whole workgroup:
     //   A   (all markers) posed vertices v_p = v_t + S beta + P^T pf; 8 lanes stream one marker's contiguous posedirs block
@@ -303,7 +314,9 @@ __device__ __attribute__((noinline)) void lm_linearize(LmShared<BM>& s, const Sm
     //   then every wave adds the chunk's contribution to its tiles of [J | r]^T [J | r] on the fp64 matrix cores (double-buffered chunk).
     constexpr int MC = BM::MC, NQ = BM::NQ;
     long long tp = 0;
+#if LM_TIMERS
     if (tid == 0) tp = wall_clock64();
+#endif
     for (int it = tid; it < M * BM::VPARTS; it += BM::THREADS) {
         const int part = it % BM::VPARTS, v = it / BM::VPARTS;
         const float* Pg = C.mk_P + (size_t)v * 28 * (NJ - 1);    // row e = 9 (k-1) + q of the pose feature sits at 28 (k-1) + 3 q
@@ -400,7 +413,9 @@ __device__ __attribute__((noinline)) void lm_linearize(LmShared<BM>& s, const Sm
             const int bsel = e / ((BM::CHUNK_ROWS - 3 * MC) * LDJS), r = e - bsel * (BM::CHUNK_ROWS - 3 * MC) * LDJS;
             L.Jc[bsel][3 * MC * LDJS + r] = 0.f;
         }
+#if LM_TIMERS
     if (tid == 0) { const long long t1 = wall_clock64(); s.phase[5] += t1 - tp; tp = t1; }
+#endif
     f64x4 acc[BM::TPW];
     int tmi[BM::TPW], tnj[BM::TPW];
 #pragma unroll
@@ -418,7 +433,9 @@ __device__ __attribute__((noinline)) void lm_linearize(LmShared<BM>& s, const Sm
     for (int ch = 0; ch < nchunk; ++ch) {
         const int v0 = ch * MC;
         float* Jb = L.Jc[ch & 1];
+#if LM_TIMERS
         if (tid == 0) tp = wall_clock64();
+#endif
         // ---- B: thread (m, j)
         const int jm = tid / NJ, jj = tid - jm * NJ, jv = v0 + jm;
         const bool jlive = tid < MC * NJ && jv < M;
@@ -449,7 +466,9 @@ __device__ __attribute__((noinline)) void lm_linearize(LmShared<BM>& s, const Sm
         float sv0 = 0.f, sv1 = 0.f, sv2 = 0.f;
         if (ulive && uu < nb) { const float* Sg = C.mk_S + (size_t)uv * 3 * NB + uu; sv0 = Sg[0]; sv1 = Sg[NB]; sv2 = Sg[2 * NB]; }
         __syncthreads();
+#if LM_TIMERS
         if (tid == 0) { const long long t1 = wall_clock64(); s.phase[6] += t1 - tp; tp = t1; }
+#endif
         // ---- C: thread (m, k) writes joint k's three rotation columns of marker m ...
         if (tid < MC * NJ) {
             const int m = jm, k = jj, v = jv;
@@ -524,7 +543,9 @@ __device__ __attribute__((noinline)) void lm_linearize(LmShared<BM>& s, const Sm
             }
         }
         __syncthreads();
+#if LM_TIMERS
         if (tid == 0) { const long long t1 = wall_clock64(); s.phase[7] += t1 - tp; }
+#endif
         // ---- the chunk's contribution to this wave's tiles
         {
             const int fr = lane & 15, fg = lane >> 4;
@@ -546,7 +567,9 @@ __device__ __attribute__((noinline)) void lm_linearize(LmShared<BM>& s, const Sm
             }
         }
     }
+#if LM_TIMERS
     if (tid == 0) { const long long t1 = wall_clock64(); s.phase[1] += t1 - t0; t0 = t1; }
+#endif
     if (tid < 64) {
         float e = 0.f;                        // error metric 0.5 * |r|^2 accumulated in fp32, like the reference
         for (int i = lane; i < M * 3; i += 64) e += s.resid[i] * s.resid[i];
@@ -571,7 +594,9 @@ __device__ __attribute__((noinline)) void lm_linearize(LmShared<BM>& s, const Sm
         }
     }
     __syncthreads();
+#if LM_TIMERS
     if (tid == 0) { const long long t1 = wall_clock64(); s.phase[2] += t1 - t0; }
+#endif
 }
 
 // 1 / a from v_rcp_f64 and one Newton step (full fp64 accuracy to ~1 ulp) instead of the ~10-instruction correctly rounded division:
@@ -598,7 +623,9 @@ __device__ __attribute__((noinline)) void lm_solve(LmShared<BM>& s, double lambd
     constexpr int NRT = (N + 1 + 15) / 16;              // row tiles of the (N + 1)-row matrix
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     long long t0 = 0;
+#if LM_TIMERS
     if (tid == 0) t0 = wall_clock64();
+#endif
     for (int i = tid; i < N; i += BM::THREADS) Apk(s.A, i, i) += lambda;
     __syncthreads();
     if constexpr (N <= 100) {
@@ -623,6 +650,68 @@ __device__ __attribute__((noinline)) void lm_solve(LmShared<BM>& s, double lambd
         while (ii * (ii + 1) / 2 > e) --ii;
         pr[m] = ((unsigned)ii << 16) | (unsigned)(e - ii * (ii + 1) / 2);
     }
+#if LM_ELIM_COLS == 3
+    // THREE columns per barrier (29 barriers instead of 43; 8 instead of 9 LDS accesses per entry and three columns).  Pivot block
+    // [m00; m10 m11; m20 m21 m22] = L D L^T with l10 = m10/d0, l20 = m20/d0, d1 = m11 - m10 l10, l21 = (m21 - m20 l10)/d1,
+    // d2 = m22 - m20 l20 - (m21 - m20 l10) l21;  a row's three panel entries become a0, a1 = a_{k+1} - a0 l10, a2 = a_{k+2} - a0 l20 - a1 l21
+    // and every trailing entry takes  A_ij -= a0_i a0_j / d0 + a1_i a1_j / d1 + a2_i a2_j / d2.
+    static_assert(N % 3 != 2, "the remainder after the 3-column steps must be empty or a single column");
+    for (int k = 0; k + 2 < N; k += 3) {
+        const double m00 = Apk(s.A, k, k), m10 = Apk(s.A, k + 1, k), m11 = Apk(s.A, k + 1, k + 1);
+        const double m20 = Apk(s.A, k + 2, k), m21 = Apk(s.A, k + 2, k + 1), m22 = Apk(s.A, k + 2, k + 2);
+        const double r0 = fast_rcp_f64(m00), l10 = m10 * r0, l20 = m20 * r0;
+        const double r1 = fast_rcp_f64(m11 - m10 * l10), t21 = m21 - m20 * l10, l21 = t21 * r1;
+        const double r2 = fast_rcp_f64(m22 - m20 * l20 - t21 * l21);
+        const int n = N - k - 2;                            // trailing rows k+3 .. N (incl. the rhs row)
+        const int npairs = n * (n + 1) / 2;
+        const int tk = (k + 3) * (k + 4) / 2;               // packed offset of row k+3
+#pragma unroll
+        for (int m = 0; m < NPR; ++m) {
+            if (tid + BM::THREADS * m < npairs) {
+                const int ii = (int)(pr[m] >> 16), jj = (int)(pr[m] & 0xFFFFu);
+                const int ri = tk + ii * (ii + 1) / 2 + (k + 3) * ii, rj = tk + jj * (jj + 1) / 2 + (k + 3) * jj;   // row starts of i, j
+                const double ai0 = s.A[ri + k], aj0 = s.A[rj + k];
+                const double ai1 = s.A[ri + k + 1] - ai0 * l10, aj1 = s.A[rj + k + 1] - aj0 * l10;
+                const double ai2 = s.A[ri + k + 2] - ai0 * l20 - ai1 * l21, aj2 = s.A[rj + k + 2] - aj0 * l20 - aj1 * l21;
+                s.A[ri + k + 3 + jj] -= ai0 * aj0 * r0 + ai1 * aj1 * r1 + ai2 * aj2 * r2;
+            }
+        }
+        __syncthreads();
+    }
+    // L from the unscaled panels: (1) per column triple the factors and the reciprocal roots of the pivots, (2) columns = 2, 1, 0 (mod 3)
+    // in that order (a column reads its raw left neighbours)
+    for (int k = 3 * tid; k < N; k += 3 * BM::THREADS) {
+        const double m00 = Apk(s.A, k, k);
+        s.rdiag[k] = 1.0 / sqrt(m00);
+        if (k + 2 < N) {
+            const double m10 = Apk(s.A, k + 1, k), m20 = Apk(s.A, k + 2, k), m21 = Apk(s.A, k + 2, k + 1);
+            const double l10 = m10 / m00, l20 = m20 / m00, d1 = Apk(s.A, k + 1, k + 1) - m10 * l10, t21 = m21 - m20 * l10, l21 = t21 / d1;
+            s.delta[k] = l10; s.delta[k + 1] = l20; s.delta[k + 2] = l21;      // delta is free until the back-substitution writes it
+            s.rdiag[k + 1] = 1.0 / sqrt(d1);
+            s.rdiag[k + 2] = 1.0 / sqrt(Apk(s.A, k + 2, k + 2) - m20 * l20 - t21 * l21);
+        }
+    }
+    __syncthreads();
+    constexpr int K3 = (N / 3) * 3;                         // columns below K3 belong to a triple
+#pragma unroll 1
+    for (int role = 2; role >= 0; --role) {
+#pragma unroll
+        for (int m = 0; m < NPR; ++m) {
+            const int e = tid + BM::THREADS * m;
+            const int i = (int)(pr[m] >> 16), col = (int)(pr[m] & 0xFFFFu);
+            if (e < NPACK && i != col && col < N) {
+                const int rr = col < K3 ? col % 3 : 0, k0 = col - rr;
+                if (rr == role) {
+                    double v = s.A[e];
+                    if (rr == 1) v -= s.A[e - 1] * s.delta[k0];
+                    if (rr == 2) { const double a0 = s.A[e - 2], a1 = s.A[e - 1] - a0 * s.delta[k0]; v -= a0 * s.delta[k0 + 1] + a1 * s.delta[k0 + 2]; }
+                    s.A[e] = v * s.rdiag[col];
+                }
+            }
+        }
+        __syncthreads();
+    }
+#else
     for (int k = 0; k + 1 < N; k += 2) {
         const double m00 = Apk(s.A, k, k), m10 = Apk(s.A, k + 1, k), m11 = Apk(s.A, k + 1, k + 1);
         const double r0 = fast_rcp_f64(m00), c = m10 * r0, r1 = fast_rcp_f64(m11 - m10 * c);
@@ -666,6 +755,7 @@ __device__ __attribute__((noinline)) void lm_solve(LmShared<BM>& s, double lambd
         if (e < NPACK && i != col && col < N && !(col & 1)) s.A[e] *= s.rdiag[col];
     }
     __syncthreads();
+#endif
     } else {
 #pragma unroll 1
     for (int kb = 0; kb < NBLK; ++kb) {
@@ -746,7 +836,9 @@ __device__ __attribute__((noinline)) void lm_solve(LmShared<BM>& s, double lambd
         __syncthreads();
     }
     }
+#if LM_TIMERS
     if (tid == 0) { const long long t1 = wall_clock64(); s.phase[3] += t1 - t0; t0 = t1; }
+#endif
     // back substitution L^T delta = y by one wave (lane owns rows lane, lane + 64, ...); pivots broadcast with v_readlane.  The L
     // entries of 4 pivots are loaded BEFORE their dependent chain (delta_i -> y -> delta_{i-1} ...), so the chain itself is
     // register-only: ~40 cycles per pivot instead of an LDS round trip.
@@ -785,7 +877,9 @@ __device__ __attribute__((noinline)) void lm_solve(LmShared<BM>& s, double lambd
             if (lane + 64 * r < DOF) s.delta[lane + 64 * r] = y[r];
     }
     __syncthreads();
+#if LM_TIMERS
     if (tid == 0) { const long long t1 = wall_clock64(); s.phase[4] += t1 - t0; }
+#endif
 }
 
 template <class BM>
