@@ -291,7 +291,10 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     pinned = None
     if world > 1 and not a.no_pin:
-        pinned = P.pin_to_local_cores(local, world)             # before the GPU runtime starts its helper threads
+        try:
+            pinned = P.pin_to_local_cores(local, world)         # before the GPU runtime starts its helper threads
+        except Exception as e:                                  # an unreadable / unexpected topology must not stop the job
+            print(f"[bench] rank {rank}: CPU pinning skipped ({type(e).__name__}: {e})", file=sys.stderr)
     dry = bool(os.environ.get("ETCH_BENCH_DRY"))                # control-flow test of the N > 1 path without a GPU (tests/test_parallel_gloo.py)
     if dry and os.environ.get("ETCH_BENCH_DRY_FAIL_RANK") == str(rank):
         sys.exit(3)                                             # failure injection for the launcher test
