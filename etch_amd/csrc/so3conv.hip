@@ -155,22 +155,22 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
 #pragma unroll
                     for (int mi = 0; mi < MT1; ++mi) {
                         const float av = cur[s][mi];
-                        acc[mi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w0, acc[mi][0], 0, 0, 0);
-                        acc[mi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w1, acc[mi][1], 0, 0, 0);
+                        acc[mi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, av, acc[mi][0], 0, 0, 0);      // D[k][c]: weights as the row operand
+                        acc[mi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, av, acc[mi][1], 0, 0, 0);
                     }
                 }
             }
             if (t == MAXT - 1) {                            // anchor end
-                // D[row r = 4fg + q][col = fr]: row r of c-tile mi -> channel VEC*r + mi = position cc = r*MTH + mi of the half, col -> kernel point k
+                // D[row = kernel point 4fg + q (+ 16)][col r = fr]: column r of c-tile mi = channel VEC*r + mi -> position cc = 16 mi + r of the
+                // half; a lane's 4 accumulator registers are 4 CONSECUTIVE kernel points of one channel: one 16-byte LDS store per tile
+                // (the transposed product -- channels as rows -- needed 4-byte stores, 2-way bank conflicts: 8 % of the LDS cycles)
                 float* xcol = X1s + col * S;
 #pragma unroll
-                for (int mi = 0; mi < MTH; ++mi)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int c = (fg * 4 + q) * MTH + mi;
-                        xcol[c * KS + fr] = acc[mi][0][q];
-                        if (k1ok) xcol[c * KS + 16 + fr] = acc[mi][1][q];
-                    }
+                for (int mi = 0; mi < MTH; ++mi) {
+                    float* xr = xcol + (mi * 16 + fr) * KS + 4 * fg;
+                    *reinterpret_cast<float4*>(xr) = make_float4(acc[mi][0][0], acc[mi][0][1], acc[mi][0][2], acc[mi][0][3]);
+                    if (fg < 2) *reinterpret_cast<float4*>(xr + 16) = make_float4(acc[mi][1][0], acc[mi][1][1], acc[mi][1][2], acc[mi][1][3]);
+                }
                 if (HALVES > 1) {
 #pragma unroll
                     for (int mi = 0; mi < MTH; ++mi) { keep[j][mi][0] = acc[MTH + mi][0]; keep[j][mi][1] = acc[MTH + mi][1]; }
@@ -188,13 +188,11 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
                 for (int j = 0; j < 4; ++j) {
                     float* xcol = X1s + (wave * 4 + j) * S;
 #pragma unroll
-                    for (int mi = 0; mi < MTH; ++mi)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int c = (fg * 4 + q) * MTH + mi;
-                            xcol[c * KS + fr] = keep[j][mi][0][q];
-                            if (k1ok) xcol[c * KS + 16 + fr] = keep[j][mi][1][q];
-                        }
+                    for (int mi = 0; mi < MTH; ++mi) {
+                        float* xr = xcol + (mi * 16 + fr) * KS + 4 * fg;
+                        *reinterpret_cast<float4*>(xr) = make_float4(keep[j][mi][0][0], keep[j][mi][0][1], keep[j][mi][0][2], keep[j][mi][0][3]);
+                        if (fg < 2) *reinterpret_cast<float4*>(xr + 16) = make_float4(keep[j][mi][1][0], keep[j][mi][1][1], keep[j][mi][1][2], keep[j][mi][1][3]);
+                    }
                 }
             }
             __syncthreads();

@@ -154,12 +154,13 @@ def permute_weight_frag(w2):
 
 def inter_weight_frag(W, cin, ks=24):
     """Fragment-ordered weight of the fused inter conv: the columns of W [cout, cin*ks] are first brought into the kernel's
-    contraction order (csrc/so3conv.hip: a lane gathers VEC = cin/16 consecutive channels per load, so row r of c-tile mi is channel
-    VEC*r + mi; halves h of the X1 tile hold the tiles [h*MTH, (h+1)*MTH)), then permuted into MFMA fragment order."""
+    contraction order (csrc/so3conv.hip: a lane gathers VEC = cin/16 consecutive channels per load, so column r of c-tile mi is channel
+    VEC*r + mi and sits at position 16*mi + r of its half; halves h of the X1 tile hold the tiles [h*MTH, (h+1)*MTH)), then permuted into
+    MFMA fragment order."""
     vec = cin // 16
     halves = 2 if cin >= 32 else 1
     mth = vec // halves
-    order = [vec * (cc // mth) + h * mth + cc % mth for h in range(halves) for cc in range(cin // halves)]
+    order = [vec * (cc % 16) + h * mth + cc // 16 for h in range(halves) for cc in range(cin // halves)]
     assert sorted(order) == list(range(cin))
     cols = torch.tensor([c * ks + k for c in order for k in range(ks)], dtype=torch.long, device=W.device)
     return permute_weight_frag(W[:, cols].contiguous())
