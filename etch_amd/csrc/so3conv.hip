@@ -402,7 +402,8 @@ template <int C, int COUT, int PTS>
 __global__ void __launch_bounds__(256) intra_so3conv_kernel(int npts_total, int pts_per_batch, const float* __restrict__ X,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const int* __restrict__ intra_idx, const float* __restrict__ Wp,
-                                                            const float* __restrict__ bias, float* __restrict__ Y) {
+                                                            const float* __restrict__ bias, float* __restrict__ Y,
+                                                            float* __restrict__ stat_part) {
     constexpr int MT = COUT / 16;
     constexpr int LD = C == 16 ? 56 : C + 40;   // row stride (floats) with LD/4 = 10 or 14 (mod 16): conflict-free ds_read_b128 of the gathered rows
     constexpr int NT = 12 * C / 16;        // K chunks
@@ -453,6 +454,11 @@ __global__ void __launch_bounds__(256) intra_so3conv_kernel(int npts_total, int 
         I_STEP(x) I_STEP(y) I_STEP(z) I_STEP(w)
 #undef I_STEP
     }
+    // InstanceNorm statistics of the output, fused (stat_part != NULL; the host guarantees pts_per_batch % PTS == 0, so a workgroup's
+    // points belong to one sample): per lane the sum / sum of squares of its 4 channels per tile over the workgroup's points
+    float4 ss[MT], sq[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) ss[mt] = sq[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a < NA) {
 #pragma unroll
         for (int pi = 0; pi < PTS; ++pi) {
@@ -462,9 +468,30 @@ __global__ void __launch_bounds__(256) intra_so3conv_kernel(int npts_total, int 
             for (int mt = 0; mt < MT; ++mt) {
                 const int o = mt * 16 + fg * 4;
                 const float4 bs = *reinterpret_cast<const float4*>(bias + o);
-                *reinterpret_cast<float4*>(Y + ((size_t)pt * NA + a) * COUT + o) =
-                    make_float4(acc[pi][mt][0] + bs.x, acc[pi][mt][1] + bs.y, acc[pi][mt][2] + bs.z, acc[pi][mt][3] + bs.w);
+                const float4 v = make_float4(acc[pi][mt][0] + bs.x, acc[pi][mt][1] + bs.y, acc[pi][mt][2] + bs.z, acc[pi][mt][3] + bs.w);
+                *reinterpret_cast<float4*>(Y + ((size_t)pt * NA + a) * COUT + o) = v;
+                ss[mt].x += v.x; ss[mt].y += v.y; ss[mt].z += v.z; ss[mt].w += v.w;
+                sq[mt].x += v.x * v.x; sq[mt].y += v.y * v.y; sq[mt].z += v.z * v.z; sq[mt].w += v.w * v.w;
             }
+        }
+    }
+    if (stat_part) {
+        // [64 anchor slots][2][COUT] through the (now free) input tile, row stride + 4 floats against bank conflicts; then one thread per
+        // (statistic, channel) sums the 64 slots in order
+        constexpr int RS = 2 * COUT + 4;
+        static_assert(64 * RS <= PTS * NA * LD, "statistics staging must fit the input tile");
+        __syncthreads();
+        float* red = Xs + (wave * 16 + fr) * RS;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            *reinterpret_cast<float4*>(red + mt * 16 + fg * 4) = ss[mt];
+            *reinterpret_cast<float4*>(red + COUT + mt * 16 + fg * 4) = sq[mt];
+        }
+        __syncthreads();
+        if (tid < 2 * COUT) {
+            float t = 0.f;
+            for (int k = 0; k < 64; ++k) t += Xs[k * RS + tid];
+            stat_part[(size_t)blockIdx.x * 2 * COUT + tid] = t;
         }
     }
 }
@@ -620,10 +647,11 @@ static int launch_inter(int b, int p1, int p2, int nn, float sigma, const float*
 
 template <int C, int COUT>
 static int launch_intra(int npts, int ppb, const float* X, const float* mean, const float* rstd, const int* intra_idx,
-                        const float* Wp, const float* bias, float* Y, hipStream_t st) {
+                        const float* Wp, const float* bias, float* Y, float* stat_part, hipStream_t st) {
     constexpr int PTS = 2;
+    if (stat_part && (ppb % PTS) != 0) return ETCH_EUNSUPPORTED;      // a workgroup's points must belong to one sample
     hipLaunchKernelGGL((intra_so3conv_kernel<C, COUT, PTS>), dim3((npts + PTS - 1) / PTS), dim3(256), 0, st, npts, ppb, X, mean,
-                       rstd, intra_idx, Wp, bias, Y);
+                       rstd, intra_idx, Wp, bias, Y, stat_part);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }
@@ -672,15 +700,20 @@ int etch_inter_so3conv_ordered(int b, int cin, int cout, int p1, int p2, int nn,
     return ETCH_EUNSUPPORTED;
 }
 
-int etch_intra_so3conv(int b, int c, int cout, int p, const float* X, const float* mean, const float* rstd,
-                       const int* intra_idx, const float* Wp, const float* bias, float* Y, void* stream) {
+int etch_intra_so3conv_stats(int b, int c, int cout, int p, const float* X, const float* mean, const float* rstd,
+                             const int* intra_idx, const float* Wp, const float* bias, float* Y, float* stat_part, void* stream) {
     if (b <= 0 || p <= 0) return ETCH_OK;
     hipStream_t st = (hipStream_t)stream;
 #define INTRA_CASE(CI, CO) \
-    if (c == CI && cout == CO) return launch_intra<CI, CO>(b * p, p, X, mean, rstd, intra_idx, Wp, bias, Y, st);
+    if (c == CI && cout == CO) return launch_intra<CI, CO>(b * p, p, X, mean, rstd, intra_idx, Wp, bias, Y, stat_part, st);
     INTRA_CASE(16, 16) INTRA_CASE(32, 32) INTRA_CASE(64, 64)
 #undef INTRA_CASE
     return ETCH_EUNSUPPORTED;
+}
+
+int etch_intra_so3conv(int b, int c, int cout, int p, const float* X, const float* mean, const float* rstd,
+                       const int* intra_idx, const float* Wp, const float* bias, float* Y, void* stream) {
+    return etch_intra_so3conv_stats(b, c, cout, p, X, mean, rstd, intra_idx, Wp, bias, Y, nullptr, stream);
 }
 
 // workspace: IN_CHUNKS * b * 2 * C doubles

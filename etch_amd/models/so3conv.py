@@ -100,8 +100,8 @@ class SeparableSO3ConvBlock(nn.Module):
         conv = self.inter_conv.conv
         inter_idx, _, sample_idx, y = conv(x, inter_idx, inter_w)
         m1, r1 = getattr(y, "in_stats", None) or ops.instnorm_stats(y.feats_cl)     # from the conv's epilogue
-        z = self.intra_conv.conv(y, m1, r1)                      # IN + lrelu of the inter output applied on load
-        m2, r2 = ops.instnorm_stats(z.feats_cl)
+        z = self.intra_conv.conv(y, m1, r1, want_stats=True)     # IN + lrelu of the inter output applied on load; statistics of z in the epilogue
+        m2, r2 = z.in_stats
         # skip branch: 1x1 conv on (optionally sub-sampled) input rows
         fin = x.feats_cl
         b, p1, na, cin = fin.shape

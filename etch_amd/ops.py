@@ -205,13 +205,24 @@ def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, orde
     return out, (mean, rstd)
 
 
-def intra_so3conv(x_cl, intra_idx32, Wp, bias, cout, mean=None, rstd=None):
+def intra_so3conv(x_cl, intra_idx32, Wp, bias, cout, mean=None, rstd=None, want_stats=False):
+    """want_stats: also return the InstanceNorm (mean, rstd) of the output, accumulated in the conv's epilogue (even point counts;
+    otherwise by the separate statistics pass)."""
     b, p, na, c = x_cl.shape
     _need(x_cl, torch.float32, "x"), _need(intra_idx32, torch.int32, "intra_idx"), _need(Wp, torch.float32, "Wp")
     out = torch.empty((b, p, 60, cout), dtype=torch.float32, device=x_cl.device)
-    _lib.check(_lib.lib().etch_intra_so3conv(b, c, cout, p, _ptr(x_cl), _optptr(mean), _optptr(rstd), _ptr(intra_idx32), _ptr(Wp),
-                                             _ptr(bias), _ptr(out), _stream()), "etch_intra_so3conv")
-    return out
+    fused = want_stats and p % 2 == 0
+    part = torch.empty((b * (p // 2), 2, cout), dtype=torch.float32, device=x_cl.device) if fused else None
+    _lib.check(_lib.lib().etch_intra_so3conv_stats(b, c, cout, p, _ptr(x_cl), _optptr(mean), _optptr(rstd), _ptr(intra_idx32), _ptr(Wp),
+                                                   _ptr(bias), _ptr(out), _optptr(part), _stream()), "etch_intra_so3conv")
+    if not want_stats:
+        return out
+    if not fused:
+        return out, instnorm_stats(out)
+    m = torch.empty((b, cout), dtype=torch.float32, device=x_cl.device)
+    r = torch.empty((b, cout), dtype=torch.float32, device=x_cl.device)
+    _lib.check(_lib.lib().etch_instnorm_from_partials(b, p // 2, cout, 120, _ptr(part), _ptr(m), _ptr(r), _stream()), "etch_instnorm_from_partials")
+    return out, (m, r)
 
 
 def instnorm_stats(x_cl):

@@ -199,8 +199,13 @@ class IntraSO3Conv(nn.Module):
 
         return self._d.get((W, bias, self.intra_idx), build)
 
-    def forward(self, x, mean=None, rstd=None):
+    def forward(self, x, mean=None, rstd=None, want_stats=False):
         Wp, bias, idx32 = self._derived()
+        if want_stats:
+            y, stats = ops.intra_so3conv(x.feats_cl, idx32, Wp, bias, self.dim_out, mean, rstd, want_stats=True)
+            cloud = SphericalPointCloud(x.xyz, None, self.anchors, feats_cl=y)
+            cloud.in_stats = stats      # InstanceNorm (mean, rstd) of the output, a by-product of the conv's epilogue
+            return cloud
         y = ops.intra_so3conv(x.feats_cl, idx32, Wp, bias, self.dim_out, mean, rstd)
         return SphericalPointCloud(x.xyz, None, self.anchors, feats_cl=y)
 

@@ -106,6 +106,10 @@ int etch_spatial_order(int b, int n, const float* xyz, int* order, void* stream)
  * intra_idx (60,12) i32; Wp = fragment order of W2[o][tap*c + ch] = W[o][ch*12 + tap]; -> Y (b,p,60,cout). */
 int etch_intra_so3conv(int b, int c, int cout, int p, const float* X, const float* mean, const float* rstd,
                        const int* intra_idx, const float* Wp, const float* bias, float* Y, void* stream);
+/* The same with the InstanceNorm partial sums of Y from the epilogue: stat_part (b * p/2, 2, cout) = per workgroup (2 points) the sum and
+ * the sum of squares per output channel; finish with etch_instnorm_from_partials(b, p/2, cout, 120, ...).  p must be even; NULL = plain. */
+int etch_intra_so3conv_stats(int b, int c, int cout, int p, const float* X, const float* mean, const float* rstd,
+                             const int* intra_idx, const float* Wp, const float* bias, float* Y, float* stat_part, void* stream);
 
 /* InstanceNorm2d(affine=False, eps=1e-5) statistics over (p,a) per (b,c) (src/models/so3conv.py:24,85,168).
  * x (b,rows,C) -> mean (b,C), rstd (b,C).  workspace: etch_instnorm_stats_workspace_bytes(b, C) bytes. */

@@ -201,3 +201,23 @@ def test_inter_conv_fused_instancenorm_statistics(cin, cout, nn):
     x64 = ref.double().reshape(b, -1, cout)
     assert rel_err(m.cpu().numpy(), x64.mean(1).cpu().numpy()) < 2e-6
     assert rel_err(r.cpu().numpy(), (1.0 / torch.sqrt(x64.var(1, unbiased=False) + 1e-5)).cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("c,p,normed", [(32, 100, True), (64, 58, False), (16, 6, True), (32, 51, True)])
+def test_intra_conv_fused_instancenorm_statistics(c, p, normed):
+    """mean / rstd from the intra conv's epilogue (etch_intra_so3conv_stats + etch_instnorm_from_partials) equal the separate statistics
+    pass over the written output; the output itself is untouched; odd point counts take the separate pass."""
+    from etch_amd import ops
+    from etch_amd import vgtk_so3conv as V
+    g = torch.Generator().manual_seed(c + p)
+    b = 3
+    conv = load_seeded(V.IntraSO3Conv(c, c), 5).cuda()
+    Wp, bias, idx32 = conv._derived()
+    x = (torch.randn(b, p, 60, c, generator=g) * 2 + 0.5).cuda()
+    m1, r1 = ops.instnorm_stats(x) if normed else (None, None)
+    ref = ops.intra_so3conv(x, idx32, Wp, bias, c, m1, r1)
+    out, (m, r) = ops.intra_so3conv(x, idx32, Wp, bias, c, m1, r1, want_stats=True)
+    assert torch.equal(out, ref)
+    x64 = ref.double().reshape(b, -1, c)
+    assert rel_err(m.cpu().numpy(), x64.mean(1).cpu().numpy()) < 2e-6
+    assert rel_err(r.cpu().numpy(), (1.0 / torch.sqrt(x64.var(1, unbiased=False) + 1e-5)).cpu().numpy()) < 2e-6
