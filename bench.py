@@ -112,6 +112,23 @@ def profile_pass(run_step):
     return agg
 
 
+def single_scan_latency(args, model, device, n_points, reps=15):
+    """BASELINE configs[0]'s shape (ONE scan, the reference's inference_demo.py:41-66): wall time of the whole hot path, host copy of the
+    result included, eager (~430 launches from Python).  Same caveat as the pipeline's stage 2: with the bench's random weights the
+    marker fit freezes early; add stage2_latency's batch_1 figure for a well-posed fit.  (The same path as ONE HIP graph,
+    etch_amd.graph.GraphedHotPath, measures 9.5 ms against 10.2 ms in a fresh process -- scratch/graph_time3.py; it is not timed here
+    because a process that already owns the pipeline's streams maps the graph's branches onto shared hardware queues.)"""
+    from etch_amd.inference_demo import predict_smpl_batch
+    pts = torch.from_numpy(synth_scan(777, n_points)[None]).to(device)
+    predict_smpl_batch(args, model, pts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        predict_smpl_batch(args, model, pts)
+    torch.cuda.synchronize()
+    return {"eager_ms": round((time.perf_counter() - t0) / reps * 1e3, 3), "points": n_points}
+
+
 def stage2_latency(args, device, iters, batch):
     """The LM fit kernel alone on WELL-POSED markers (all 86 valid, 2 mm noise, drawn from the body model at a random pose): with the
     bench's seeded random network weights most labels never win the argmax, a scan keeps ~2 valid markers and its fit freezes early
@@ -474,6 +491,8 @@ def main():
     out["whole_step_mfma_frac"] = round(total_flops / (dt / a.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
     if not a.forward_only:
         out["stage2_latency"] = stage2_latency(args, device, cfg["iters"], B)
+    if world == 1 and a.config == 2 and not a.forward_only:
+        out["single_scan_latency"] = single_scan_latency(args, model, device, N)
     if N == 5000 and not a.forward_only:
         # 152.4 GFLOP matmul / conv + 5.2 GFLOP kernel-weight generation per 5 000-point scan -> 1.0 ms at the fp32-MFMA
         # peak, HBM-side 0.05 ms: ceiling ~ 1 030 scans/s per GPU for the whole path

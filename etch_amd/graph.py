@@ -1,0 +1,58 @@
+"""The hot path of one fixed batch shape as ONE HIP graph (hipGraph through torch.cuda.CUDAGraph).
+
+A latency-bound caller (a single scan: BASELINE configs[0], the reference's inference_demo.py:41-66) spends its time in ~430 small
+dependent launches on five streams; captured once, the whole stage 1 -> labels / inner points -> marker fit -> LBS chain is replayed
+with one host call.  Everything the eager path does is capturable as is: every op launches through the C ABI on the current stream,
+outputs come from torch's caching allocator (graph-private pool), the side streams of the eager schedule fork and join inside the
+capture.  Results are bit-identical to `predict_smpl_batch` (tests/test_gpu_pipeline.py).
+
+Measured (one 5 000-point scan, MI355X, fresh process): 10.2 ms eager -> 9.5 ms replayed: the chain is bound by its dependent kernels
+(FPS 2.7 ms, the marker fit, the deep Point-Transformer levels), not by the host's launches.  Note: HIP maps streams onto a few hardware
+queues (GPU_MAX_HW_QUEUES, default 4); a process that also runs the eager multi-stream pipeline shares them with the graph's branches
+and both paths slow down by 30 - 40 % -- use one or the other in a process, or raise GPU_MAX_HW_QUEUES."""
+import torch
+
+from . import ops
+from .models.fit_SMPL import fit_smpl_device, fit_smpl_finalize
+
+
+class GraphedHotPath:
+    """predict = GraphedHotPath(args, model, B, N, gender);  meshes, markers, valid, info = predict(points (B,N,3) on the device).
+
+    Stage 2 runs with the reference's schedule (30 + 50 LM iterations) unless `fit_kwargs` say otherwise.  The device results of a
+    replay live in static buffers that the next replay overwrites: `__call__` copies them to the host before it returns."""
+
+    def __init__(self, args, model, B, N, gender="neutral", warmup=2, **fit_kwargs):
+        self.args, self.model, self.gender, self.fit_kwargs = args, model, gender, fit_kwargs
+        dev = next(model.parameters()).device
+        self.static_in = torch.zeros((B, N, 3), dtype=torch.float32, device=dev)
+        self.graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            # caches (folded weights, weight fragments, device body tables, occupancy queries, dynamic-LDS attributes) fill outside the capture
+            self.static_in.normal_(0.0, 0.15)
+            for _ in range(max(1, warmup)):
+                self._device_part()
+            side.synchronize()
+            with torch.cuda.graph(self.graph, stream=side):
+                self.dev = self._device_part()
+        torch.cuda.current_stream().wait_stream(side)
+
+    def _device_part(self):
+        pts = self.static_in
+        results, _ = self.model(pts, pred_items=["confidence", "direction", "magnitude"], direction_mode="standard_vector")
+        labels = ops.argmax_rows(results["part_labels"])
+        inner = ops.inner_points(pts, results["direction"], results["magnitude"], float(self.args.scale_magnitude))
+        dev = fit_smpl_device(self.args, inner, labels, results["confidences"], self.gender, **self.fit_kwargs)
+        dev["results"] = results
+        return dev
+
+    def replay(self, points):
+        """Enqueue one pass on the current stream; returns the dict of STATIC device tensors (valid until the next replay)."""
+        self.static_in.copy_(points, non_blocking=True)
+        self.graph.replay()
+        return self.dev
+
+    def __call__(self, points):
+        return fit_smpl_finalize(dict(self.replay(points)))

@@ -276,3 +276,23 @@ def test_evaluate_dataset_on_the_reference_folder_layout(tmp_path):
     assert lines[3] == "==========" and lines[4].startswith("average v2v: ") and lines[6] == "sample num: 3"
     body = D.load_obj(str(tmp_path / "out" / "id_b" / "forwarded_smpl_mesh_on_pred_id_b.obj"))
     assert abs(E.v2v(ds[1]["gt_vertices"], body.vertices) - recs[1]["v2v"]) < 1e-5
+
+
+@pytest.mark.parametrize("B,N", [(1, 1024), (2, 1500)])
+def test_hip_graph_replay_matches_eager_path(tmp_path, B, N):
+    """etch_amd.graph.GraphedHotPath: the whole hot path of a fixed shape captured into one HIP graph and replayed on new inputs returns
+    what predict_smpl_batch returns, bit for bit (meshes, markers, fitted parameters), for several different batches."""
+    from etch_amd.graph import GraphedHotPath
+    from etch_amd.inference_demo import predict_smpl_batch
+    args, model = make(tmp_path)
+    g = GraphedHotPath(args, model, B, N)
+    for rep in range(3):
+        pts = torch.from_numpy(np.stack([scan(900 + 10 * rep + b, N) for b in range(B)])).cuda()
+        meshes, markers, valid, info = g(pts)
+        markers, valid = markers.clone(), valid.clone()         # static buffers of the graph
+        meshes0, markers0, valid0, info0 = predict_smpl_batch(args, model, pts)
+        assert torch.equal(valid, valid0) and torch.equal(markers[valid], markers0[valid0])
+        for a, b in zip(info, info0):
+            assert np.array_equal(a, b, equal_nan=True)
+        for m, m0 in zip(meshes, meshes0):
+            assert np.array_equal(m.vertices, m0.vertices, equal_nan=True)
