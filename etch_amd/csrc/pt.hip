@@ -654,16 +654,50 @@ __device__ __forceinline__ float pt_group_max(float v) {
     return v;
 }
 
+// Per-channel constants (linear_p[3], its bias, the BN of linear_w[0], the output BN), linear_w's small tensors and -- up to c = 256 --
+// the c/8 x c matrix W2 are staged in LDS once per (persistent) workgroup: read from global per 16-channel step they were 8 of the 10
+// vector-memory instructions of the inner loop and the kernel ran at 60 % of the CU's texture-address rate, not on its MFMAs.
 template <int C, int NS>
-__global__ void __launch_bounds__(256) pt_attention_mfma_kernel(PtAttnParams a, const float* __restrict__ W2) {
+__global__ void __launch_bounds__(256) pt_attention_mfma_kernel(PtAttnParams a, const float* __restrict__ W2, long ntiles) {
     constexpr int CS = C / 8;                      // hidden width of linear_w
     constexpr int MT = CS <= 16 ? 1 : CS / 16;     // 16-row tiles of the transposed products
     constexpr int KT = C / 16;
     constexpr int PPW = 16 / NS;                   // points per wave
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr bool W2_LDS = C <= 256;
+    constexpr int LDW = C + 4;                     // W2 row stride in LDS: (C + 4) / 4 odd -> conflict-free ds_read_b128 over the 16 rows
+    extern __shared__ __attribute__((aligned(16))) float cst[];
+    float* W3s = cst;                              // [C][3]
+    float* b3s = W3s + 3 * C;                      // [C]
+    float* scs = b3s + C;                          // [C]  s_w0
+    float* shs = scs + C;                          // [C]  t_w0
+    float* sos = shs + C;                          // [C]  s_out
+    float* tos = sos + C;                          // [C]  t_out
+    float* b2s = tos + C;                          // [CS]
+    float* s3s = b2s + CS;                         // [CS]
+    float* t3s = s3s + CS;                         // [CS]
+    float* b5s = t3s + CS;                         // [CS]
+    float* W5s = b5s + CS;                         // [CS][CS]
+    float* W2s = W5s + CS * CS;                    // [CS][LDW]  (W2_LDS only)
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 3 * C; e += 256) W3s[e] = a.W3[e];
+    for (int e = tid; e < C; e += 256) {
+        b3s[e] = a.b3[e]; scs[e] = a.s_w0[e]; shs[e] = a.t_w0[e];
+        sos[e] = a.s_out ? a.s_out[e] : 1.f; tos[e] = a.s_out ? a.t_out[e] : 0.f;
+    }
+    for (int e = tid; e < CS; e += 256) { b2s[e] = a.b2[e]; s3s[e] = a.s_w3[e]; t3s[e] = a.t_w3[e]; b5s[e] = a.b5[e]; }
+    for (int e = tid; e < CS * CS; e += 256) W5s[e] = a.W5[e];
+    if (W2_LDS)
+        for (int e = tid; e < CS * C / 4; e += 256) {
+            const int row = e / (C / 4), c4 = e - row * (C / 4);
+            *reinterpret_cast<float4*>(&W2s[row * LDW + c4 * 4]) = *reinterpret_cast<const float4*>(W2 + (size_t)row * C + c4 * 4);
+        }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int pw = fr / NS, jn = fr % NS;
-    const long base = ((long)blockIdx.x * 4 + wave) * PPW;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    asm volatile("" ::: "memory");                 // the staged constants stay in LDS: hoisted out of this loop they took 150+ registers
+    const long base = (tile * 4 + wave) * PPW;
     const bool valid = base + pw < a.n;
     const int i = valid ? (int)(base + pw) : a.n - 1;
     const int j = a.idx[(size_t)i * NS + jn];
@@ -681,10 +715,10 @@ __global__ void __launch_bounds__(256) pt_attention_mfma_kernel(PtAttnParams a, 
     for (int t = 0; t < KT; ++t) {
         const int ch0 = t * 16 + fg * 4;
         const float4 k4 = *reinterpret_cast<const float4*>(kr + ch0), q4 = *reinterpret_cast<const float4*>(qr + ch0);
-        const float4 wa = *reinterpret_cast<const float4*>(a.W3 + ch0 * 3), wb = *reinterpret_cast<const float4*>(a.W3 + ch0 * 3 + 4),
-                     wc = *reinterpret_cast<const float4*>(a.W3 + ch0 * 3 + 8);
-        const float4 b3 = *reinterpret_cast<const float4*>(a.b3 + ch0), sc = *reinterpret_cast<const float4*>(a.s_w0 + ch0),
-                     sh = *reinterpret_cast<const float4*>(a.t_w0 + ch0);
+        const float4 wa = *reinterpret_cast<const float4*>(W3s + ch0 * 3), wb = *reinterpret_cast<const float4*>(W3s + ch0 * 3 + 4),
+                     wc = *reinterpret_cast<const float4*>(W3s + ch0 * 3 + 8);
+        const float4 b3 = *reinterpret_cast<const float4*>(b3s + ch0), sc = *reinterpret_cast<const float4*>(scs + ch0),
+                     sh = *reinterpret_cast<const float4*>(shs + ch0);
         float w[4];
         w[0] = fmaxf((k4.x - q4.x + (wa.x * h[0] + wa.y * h[1] + wa.z * h[2] + b3.x)) * sc.x + sh.x, 0.f);
         w[1] = fmaxf((k4.y - q4.y + (wa.w * h[0] + wb.x * h[1] + wb.y * h[2] + b3.y)) * sc.y + sh.y, 0.f);
@@ -694,7 +728,7 @@ __global__ void __launch_bounds__(256) pt_attention_mfma_kernel(PtAttnParams a, 
         for (int mt = 0; mt < MT; ++mt) {
             const int row = mt * 16 + fr;                       // hidden unit
             float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < CS) f = *reinterpret_cast<const float4*>(W2 + (size_t)row * C + ch0);
+            if (row < CS) f = W2_LDS ? *reinterpret_cast<const float4*>(W2s + row * LDW + ch0) : *reinterpret_cast<const float4*>(W2 + (size_t)row * C + ch0);
             acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.x, w[0], acc[mt], 0, 0, 0);
             acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.y, w[1], acc[mt], 0, 0, 0);
             acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.z, w[2], acc[mt], 0, 0, 0);
@@ -708,7 +742,7 @@ __global__ void __launch_bounds__(256) pt_attention_mfma_kernel(PtAttnParams a, 
         for (int r = 0; r < 4; ++r) {
             const int u = mt * 16 + fg * 4 + r;
             float v = 0.f;
-            if (u < CS) v = fmaxf((acc[mt][r] + a.b2[u]) * a.s_w3[u] + a.t_w3[u], 0.f);
+            if (u < CS) v = fmaxf((acc[mt][r] + b2s[u]) * s3s[u] + t3s[u], 0.f);
             acc[mt][r] = v;
         }
     // ---- logit^T = W5 . hid^T + b5, then softmax over the point's neighbours (one DPP row / half row)
@@ -721,7 +755,7 @@ __global__ void __launch_bounds__(256) pt_attention_mfma_kernel(PtAttnParams a, 
         for (int mu = 0; mu < MT; ++mu) {
             const int u0 = mu * 16 + fg * 4;
             float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < CS && u0 < CS) f = *reinterpret_cast<const float4*>(a.W5 + (size_t)row * CS + u0);
+            if (row < CS && u0 < CS) f = *reinterpret_cast<const float4*>(W5s + row * CS + u0);
             lg = __builtin_amdgcn_mfma_f32_16x16x4f32(f.x, acc[mu][0], lg, 0, 0, 0);
             lg = __builtin_amdgcn_mfma_f32_16x16x4f32(f.y, acc[mu][1], lg, 0, 0, 0);
             lg = __builtin_amdgcn_mfma_f32_16x16x4f32(f.z, acc[mu][2], lg, 0, 0, 0);
@@ -730,7 +764,7 @@ __global__ void __launch_bounds__(256) pt_attention_mfma_kernel(PtAttnParams a, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int tt = mo * 16 + fg * 4 + r;
-            const float l = lg[r] + (tt < CS ? a.b5[tt] : 0.f);
+            const float l = lg[r] + (tt < CS ? b5s[tt] : 0.f);
             const float m = pt_group_max<NS>(l);
             const float e = __expf(l - m);
             sm[mo][r] = e / pt_group_sum<NS>(e);
@@ -745,9 +779,9 @@ __global__ void __launch_bounds__(256) pt_attention_mfma_kernel(PtAttnParams a, 
             for (int m = 0; m < 8; ++m) {
                 const int ch0 = m * CS + mo * 16 + fg * 4;
                 const float4 v4 = *reinterpret_cast<const float4*>(vr + ch0);
-                const float4 wa = *reinterpret_cast<const float4*>(a.W3 + ch0 * 3), wb = *reinterpret_cast<const float4*>(a.W3 + ch0 * 3 + 4),
-                             wc = *reinterpret_cast<const float4*>(a.W3 + ch0 * 3 + 8);
-                const float4 b3 = *reinterpret_cast<const float4*>(a.b3 + ch0);
+                const float4 wa = *reinterpret_cast<const float4*>(W3s + ch0 * 3), wb = *reinterpret_cast<const float4*>(W3s + ch0 * 3 + 4),
+                             wc = *reinterpret_cast<const float4*>(W3s + ch0 * 3 + 8);
+                const float4 b3 = *reinterpret_cast<const float4*>(b3s + ch0);
                 float o0 = (v4.x + (wa.x * h[0] + wa.y * h[1] + wa.z * h[2] + b3.x)) * sm[mo][0];
                 float o1 = (v4.y + (wa.w * h[0] + wb.x * h[1] + wb.y * h[2] + b3.y)) * sm[mo][1];
                 float o2 = (v4.z + (wb.z * h[0] + wb.w * h[1] + wc.x * h[2] + b3.z)) * sm[mo][2];
@@ -755,7 +789,7 @@ __global__ void __launch_bounds__(256) pt_attention_mfma_kernel(PtAttnParams a, 
                 o0 = pt_group_sum<NS>(o0); o1 = pt_group_sum<NS>(o1); o2 = pt_group_sum<NS>(o2); o3 = pt_group_sum<NS>(o3);
                 if (jn == 0 && valid) {
                     if (a.s_out) {
-                        const float4 so = *reinterpret_cast<const float4*>(a.s_out + ch0), to = *reinterpret_cast<const float4*>(a.t_out + ch0);
+                        const float4 so = *reinterpret_cast<const float4*>(sos + ch0), to = *reinterpret_cast<const float4*>(tos + ch0);
                         o0 = fmaxf(o0 * so.x + to.x, 0.f); o1 = fmaxf(o1 * so.y + to.y, 0.f);
                         o2 = fmaxf(o2 * so.z + to.z, 0.f); o3 = fmaxf(o3 * so.w + to.w, 0.f);
                     }
@@ -764,6 +798,27 @@ __global__ void __launch_bounds__(256) pt_attention_mfma_kernel(PtAttnParams a, 
             }
         }
     }
+    }
+}
+
+template <int C_, int NS_>
+static int launch_pt_mfma(const PtAttnParams& a, const float* W2, hipStream_t st) {
+    constexpr int CS = C_ / 8, PPW = 16 / NS_;
+    const size_t lds = (size_t)(8 * C_ + 4 * CS + CS * CS + (C_ <= 256 ? CS * (C_ + 4) : 0)) * sizeof(float);
+    auto kern = pt_attention_mfma_kernel<C_, NS_>;
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ETCH_EUNSUPPORTED;
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, lds) != hipSuccess || nb < 1) nb = 1;
+        per_cu = nb > 4 ? 4 : nb;
+    }
+    const long ntiles = ((long)a.n + 4 * PPW - 1) / (4 * PPW);
+    long blocks = 256L * per_cu;
+    if (blocks > ntiles) blocks = ntiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, a, W2, ntiles);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
 }
 
 extern "C" int etch_pt_attention_mfma(int n, int c, int ns, const float* p, const float* xq, const float* xk, const float* xv, long ldq,
@@ -773,13 +828,8 @@ extern "C" int etch_pt_attention_mfma(int n, int c, int ns, const float* p, cons
     PtAttnParams a;
     fill_pt_params(a, n, c, ns, p, xq, xk, xv, ldq, idx, params, out, ldo);
     hipStream_t st = (hipStream_t)stream;
-#define PT_MFMA_CASE(C_, NS_)                                                                                              \
-    if (c == C_ && ns == NS_) {                                                                                            \
-        const int ppw = 16 / NS_;                                                                                          \
-        hipLaunchKernelGGL((pt_attention_mfma_kernel<C_, NS_>), dim3((n + 4 * ppw - 1) / (4 * ppw)), dim3(256), 0, st, a, W2); \
-        ETCH_RETURN_IF_LAUNCH_FAILED();                                                                                    \
-        return ETCH_OK;                                                                                                    \
-    }
+#define PT_MFMA_CASE(C_, NS_) \
+    if (c == C_ && ns == NS_) return launch_pt_mfma<C_, NS_>(a, W2, st);
     PT_MFMA_CASE(64, 8) PT_MFMA_CASE(128, 8) PT_MFMA_CASE(64, 16) PT_MFMA_CASE(128, 16) PT_MFMA_CASE(256, 16) PT_MFMA_CASE(512, 16)
 #undef PT_MFMA_CASE
     return ETCH_EUNSUPPORTED;
