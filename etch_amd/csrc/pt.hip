@@ -654,11 +654,14 @@ __device__ __forceinline__ float pt_group_max(float v) {
     return v;
 }
 
+#ifndef PT_MFMA_WGS
+#define PT_MFMA_WGS 4
+#endif
 // Per-channel constants (linear_p[3], its bias, the BN of linear_w[0], the output BN), linear_w's small tensors and -- up to c = 256 --
 // the c/8 x c matrix W2 are staged in LDS once per (persistent) workgroup: read from global per 16-channel step they were 8 of the 10
 // vector-memory instructions of the inner loop and the kernel ran at 60 % of the CU's texture-address rate, not on its MFMAs.
 template <int C, int NS>
-__global__ void __launch_bounds__(256) pt_attention_mfma_kernel(PtAttnParams a, const float* __restrict__ W2, long ntiles) {
+__global__ void __launch_bounds__(256, PT_MFMA_WGS) pt_attention_mfma_kernel(PtAttnParams a, const float* __restrict__ W2, long ntiles) {
     constexpr int CS = C / 8;                      // hidden width of linear_w
     constexpr int MT = CS <= 16 ? 1 : CS / 16;     // 16-row tiles of the transposed products
     constexpr int KT = C / 16;
@@ -811,7 +814,7 @@ static int launch_pt_mfma(const PtAttnParams& a, const float* W2, hipStream_t st
         if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ETCH_EUNSUPPORTED;
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, lds) != hipSuccess || nb < 1) nb = 1;
-        per_cu = nb > 4 ? 4 : nb;
+        per_cu = nb > 8 ? 8 : nb;
     }
     const long ntiles = ((long)a.n + 4 * PPW - 1) / (4 * PPW);
     long blocks = 256L * per_cu;
