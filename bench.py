@@ -67,7 +67,7 @@ def algorithmic_flops(name, a):
         b, cin, cout, p1, p2, nn = v[0:6]
         kern = "inter_so3conv_c1_kernel" if cin == 1 else f"inter_so3conv_kernel<{cin},{cout},{(nn + 15) // 16 if nn <= 32 else 4}>"
         return 2.0 * b * p2 * 60 * 24 * (cin * nn + cout * cin), kern
-    if name == "etch_intra_so3conv":
+    if name in ("etch_intra_so3conv", "etch_intra_so3conv_stats"):
         b, c, cout, p = v[0:4]
         return 2.0 * b * p * 60 * 12 * c * cout, f"intra_so3conv_kernel<{c},{cout}>"
     if name == "etch_mhsa_layer":
@@ -75,6 +75,9 @@ def algorithmic_flops(name, a):
         return T * (2.0 * 60 * 64 * 192 + 8 * (2.0 * 60 * 60 * 8 * 2) + (2.0 * 60 * 64 * 64 if mode != 2 else 0.0)), "mhsa_layer_kernel"
     if name == "etch_mhsa_interp_layer":   # mode-0 layer on tokens interpolated in the kernel
         return float(v[0]) * v[1] * (2.0 * 60 * 64 * 192 + 8 * (2.0 * 60 * 60 * 8 * 2) + 2.0 * 60 * 64 * 64), "mhsa_interp_layer_kernel"
+    if name == "etch_pt_attention_mfma":     # the c -> c/8 -> c/8 MLP of linear_w over the n * ns (point, neighbour) rows
+        n, c, ns = v[0:3]
+        return float(n) * ns * (2.0 * c * (c // 8) + 2.0 * (c // 8) ** 2), "pt_attention_mfma_kernel"
     if name == "etch_mhsa_attention":
         T = v[0]
         return T * 8 * (2.0 * 60 * 60 * 8 * 2), "mhsa_attention_kernel"
