@@ -285,6 +285,8 @@ def main():
     ap.add_argument("--forward-only", action="store_true", help="BASELINE.json configs[1]: a step is the equivariant forward only")
     ap.add_argument("--same-batch", action="store_true", help="feed the same resident batch every step (default: a distinct batch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the stage2_latency / single_scan_latency legs (profiling runs: their launches "
+                    "of other batch sizes would mix into the per-kernel averages of the trace)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads of the cpu_baseline leg (0: min(32, cores))")
     ap.add_argument("--no-pin", action="store_true", help="do not pin ranks to the cores of their GPU's NUMA node (N > 1 only)")
     ap.add_argument("--sync", action="store_true", help="synchronous steps (stage 2 of a batch finishes before stage 1 of the next starts). Default: the "
@@ -492,9 +494,9 @@ def main():
     out["kernel_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]}
     total_flops = sum(v["flops"] for v in agg.values())
     out["whole_step_mfma_frac"] = round(total_flops / (dt / a.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
-    if not a.forward_only:
+    if not a.forward_only and not a.no_extras:
         out["stage2_latency"] = stage2_latency(args, device, cfg["iters"], B)
-    if world == 1 and a.config == 2 and not a.forward_only:
+    if world == 1 and a.config == 2 and not a.forward_only and not a.no_extras:
         out["single_scan_latency"] = single_scan_latency(args, model, device, N)
     if N == 5000 and not a.forward_only:
         # 152.4 GFLOP matmul / conv + 5.2 GFLOP kernel-weight generation per 5 000-point scan -> 1.0 ms at the fp32-MFMA

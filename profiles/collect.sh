@@ -10,24 +10,26 @@ O=$R/gpurun_out/$tag
 mkdir -p $O
 export TMPDIR=/tmp
 run() { name=$1; shift; rocprofv3 "$@" > $O/$name.log 2>&1; }
+# (--no-cpu-baseline --no-extras only drop legs that run AFTER the timed region -- the CPU oracle, the stage-2 / single-scan latency legs --
+# whose launches of other batch sizes would mix into the per-kernel averages of the trace)
 # default (overlapped) schedule and the serial schedule (every kernel on one stream: a duration is the kernel's own)
-run trace_default --kernel-trace --stats -d $O/prof_default -o default -- python3 $R/bench.py --steps 16 --warmup 3 --no-cpu-baseline
+run trace_default --kernel-trace --stats -d $O/prof_default -o default -- python3 $R/bench.py --steps 16 --warmup 3 --no-cpu-baseline --no-extras
 grep '^{' $O/trace_default.log | tail -1 > $O/${tag}_bench_line_under_rocprof.json
 db=$(find $O/prof_default -name '*_results.db' | head -1)
 python3 profiles/summarize_rocpd.py $db > $O/${tag}_kernel_stats.txt
 python3 profiles/timeline_rocpd.py $db > $O/${tag}_stream_timeline.txt 2>&1
 rm -rf $O/prof_default
-run trace_serial --kernel-trace --stats -d $O/prof_serial -o serial -- python3 $R/bench.py --serial --steps 16 --warmup 3 --no-cpu-baseline
+run trace_serial --kernel-trace --stats -d $O/prof_serial -o serial -- python3 $R/bench.py --serial --steps 16 --warmup 3 --no-cpu-baseline --no-extras
 db=$(find $O/prof_serial -name '*_results.db' | head -1)
 python3 profiles/summarize_rocpd.py $db > $O/${tag}_serial_kernel_stats.txt
 rm -rf $O/prof_serial
 # HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes of the same command
-run pmc_fetch --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o fetch -- python3 $R/bench.py --serial --steps 1 --warmup 1 --no-cpu-baseline
-run pmc_write --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o write -- python3 $R/bench.py --serial --steps 1 --warmup 1 --no-cpu-baseline
+run pmc_fetch --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o fetch -- python3 $R/bench.py --serial --steps 1 --warmup 1 --no-cpu-baseline --no-extras
+run pmc_write --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o write -- python3 $R/bench.py --serial --steps 1 --warmup 1 --no-cpu-baseline --no-extras
 python3 profiles/pmc_traffic.py $(find $O/pmc_fetch -name '*_results.db' | head -1) $(find $O/pmc_write -name '*_results.db' | head -1) > $O/${tag}_pmc_traffic.json
 rm -rf $O/pmc_fetch $O/pmc_write
 # matrix-pipe / wave-cycle counters of the dominant kernels
-run pmc_busy --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d $O/pmc_busy -o busy -- python3 $R/bench.py --serial --steps 1 --warmup 1 --no-cpu-baseline
+run pmc_busy --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d $O/pmc_busy -o busy -- python3 $R/bench.py --serial --steps 1 --warmup 1 --no-cpu-baseline --no-extras
 python3 - $(find $O/pmc_busy -name '*_results.db' | head -1) > $O/${tag}_pmc_mfma.txt <<'PY'
 import sqlite3, sys, re, collections
 c = sqlite3.connect(sys.argv[1])
