@@ -15,6 +15,22 @@ def fold_bn(bn):
     return s.contiguous(), (bn.bias.detach() - bn.running_mean * s).contiguous()
 
 
+
+def downsampled_offsets(oh, stride):
+    """TransitionDown's per-scan point counts (pointtransformer_seg.py:55-59: count += (o[i] - o[i-1]) // stride) as cumulative offsets.
+    A scan that runs out of points before the last level (fewer than 256 points for the 4 x stride-4 nets) leaves the reference with
+    empty segments and undefined neighbour queries; here it is an error instead of an out-of-bounds read on the GPU."""
+    n_o, count, prev = [], 0, 0
+    for i, end in enumerate(oh):
+        m = (end - prev) // stride
+        if m <= 0:
+            raise ValueError(f"scan {i} has {end - prev} points at a stride-{stride} TransitionDown: too few for the five-level "
+                             f"Point-Transformer nets (a scan needs at least 256 points)")
+        count += m
+        n_o.append(count)
+        prev = end
+    return n_o
+
 class PointTransformerLayer(nn.Module):
     """pointtransformer_seg.py:8-37."""
 
@@ -89,10 +105,7 @@ class TransitionDown(nn.Module):
         w = self.linear.weight.detach()
         if self.stride != 1:
             oh = pointops.host_offsets(o)
-            n_o, count = [oh[0] // self.stride], oh[0] // self.stride
-            for i in range(1, len(oh)):
-                count += (oh[i] - oh[i - 1]) // self.stride
-                n_o.append(count)
+            n_o = downsampled_offsets(oh, self.stride)
             n_o_t = pointops.make_offsets(n_o, p.device, like=(o, self.stride))
             idx = pointops.furthestsampling(p, o, n_o_t)
             n_p = pointops.gather_rows(p, idx)
@@ -300,10 +313,7 @@ def prefetch_indices(p0, o0, strides=(1, 4, 4, 4, 4), nsamples=(8, 16, 16, 16, 1
     for li in range(5):
         if strides[li] != 1:
             oh = pointops.host_offsets(o)
-            n_o, count = [oh[0] // strides[li]], oh[0] // strides[li]
-            for i in range(1, len(oh)):
-                count += (oh[i] - oh[i - 1]) // strides[li]
-                n_o.append(count)
+            n_o = downsampled_offsets(oh, strides[li])
             n_o_t = pointops.make_offsets(n_o, p.device, like=(o, strides[li]))
             idx = pointops.furthestsampling(p, o, n_o_t)
             n_p = pointops.gather_rows(p, idx)

@@ -296,3 +296,21 @@ def test_hip_graph_replay_matches_eager_path(tmp_path, B, N):
             assert np.array_equal(a, b, equal_nan=True)
         for m, m0 in zip(meshes, meshes0):
             assert np.array_equal(m.vertices, m0.vertices, equal_nan=True)
+
+
+def test_smallest_scans_and_the_too_small_error(tmp_path):
+    """256 points is the smallest scan the five-level nets can take (one point left at the deepest level): parity with the oracle there,
+    a ValueError -- not a GPU fault -- below."""
+    from oracle import stage1 as S1
+    args, model = make(tmp_path)
+    sd = {k: v.cpu() for k, v in seeded_state_dict(model, 1).items()}
+    for B, N in ((1, 256), (2, 257)):
+        pts = torch.from_numpy(np.stack([scan(70 + b, N) for b in range(B)]))
+        with torch.no_grad():
+            res, _ = model(pts.cuda(), ["confidence", "direction", "magnitude"], "standard_vector")
+        ref = S1.forward(sd, pts, S1.build_layer_table(), return_aux=True)
+        for k in ("part_labels", "confidences", "magnitude"):
+            assert float((res[k].cpu() - ref[k]).abs().max() / ref[k].abs().max()) < 1e-4, (N, k)
+    with pytest.raises(ValueError, match="at least 256 points"):
+        with torch.no_grad():
+            model(torch.from_numpy(scan(1, 130)[None]).cuda(), ["confidence"], "standard_vector")

@@ -209,3 +209,14 @@ def test_eval_dataset_reads_the_reference_layout(tmp_path):
     assert a["hitpts"].shape == (300, 3) and a["hitpts"].dtype == np.float32 and a["gt_vertices"].shape == (6890, 3) and a["gt_joints"].shape == (73, 3)
     assert np.array_equal(ds[0]["hitpts"], a["hitpts"])    # seeded: reproducible
     assert len(EvalDataset(scan_dir, smpl_dir, info_dir)) == 3
+
+
+def test_transition_down_offsets_and_too_small_scans():
+    """TransitionDown's per-scan counts (pointtransformer_seg.py:55-59) and the loud failure for scans that run out of points before
+    the last level (the reference is left with empty segments there; a GPU path must not read out of bounds instead)."""
+    import pytest
+    from etch_amd.models.pointtransformer_seg import downsampled_offsets
+    assert downsampled_offsets([5000, 10000, 15001], 4) == [1250, 2500, 3750]
+    assert downsampled_offsets([7, 19], 4) == [1, 4]
+    with pytest.raises(ValueError, match="at least 256 points"):
+        downsampled_offsets([1250, 1253], 4)
