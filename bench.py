@@ -119,7 +119,7 @@ def single_scan_latency(args, model, device, n_points, reps=15):
     """BASELINE configs[0]'s shape (ONE scan, the reference's inference_demo.py:41-66): wall time of the whole hot path, host copy of the
     result included, eager (~430 launches from Python).  Same caveat as the pipeline's stage 2: with the bench's random weights the
     marker fit freezes early; add stage2_latency's batch_1 figure for a well-posed fit.  (The same path as ONE HIP graph,
-    etch_amd.graph.GraphedHotPath, measures 9.5 ms against 10.2 ms in a fresh process -- scratch/graph_time3.py; it is not timed here
+    etch_amd.graph.GraphedHotPath, measures 9.5 ms against 10.2 ms in a fresh process -- profiles/scripts/graph_time3.py; it is not timed here
     because a process that already owns the pipeline's streams maps the graph's branches onto shared hardware queues.)"""
     from etch_amd.inference_demo import predict_smpl_batch
     pts = torch.from_numpy(synth_scan(777, n_points)[None]).to(device)

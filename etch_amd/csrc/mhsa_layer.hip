@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256, MODE == 2 ? 3 : 2) mhsa_layer_kernel(long
 // tile on its way into LDS (same arithmetic as prop_interp_kernel) and runs the layer on it.  The interpolated tokens (2.46 GB
 // written and read back per batch) and the interpolation kernel disappear; the workgroups of an XCD walk one contiguous eighth of
 // the scans' spatial order so that the three coarse rows of a point (shared with its neighbours) hit in that XCD's L2.
-// Also measured (scratch/dirhead_time.py, 32 x 5000 points): the q / k / v transforms are linear and bias-free, so they can be
+// Also measured (profiles/scripts/dirhead_time.py, 32 x 5000 points): the q / k / v transforms are linear and bias-free, so they can be
 // evaluated once per COARSE point (4x fewer) and blended per scan point in the attention phase's register layout.  Blending all three
 // removes 768 of 1 760 MFMAs per point but reads 192 KB per point from L2 (68 % hit rate): 4.93 ms + 0.71 ms projection; q and k
 // only 4.96 + 0.53; q only 5.17 + 0.29 -- against 5.56 ms for this form, i.e. the same within noise: the layer is bound by

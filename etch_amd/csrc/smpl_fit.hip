@@ -33,7 +33,7 @@
 #define LM_ELIM_COLS 3    // pivots eliminated per barrier in the 85-DoF solve (2: the two-column form, kept for A/B)
 #endif
 #ifndef LM_TIMERS
-#define LM_TIMERS 1      // per-phase s_memrealtime breakdown in `phase_out` (scratch/lm_time.py); measured cost: none (82.4 vs 82.8 us / iteration without)
+#define LM_TIMERS 1      // per-phase s_memrealtime breakdown in `phase_out` (profiles/scripts/lm_time.py); measured cost: none (82.4 vs 82.8 us / iteration without)
 #endif
 
 #define LM_MAXM 96                  // markers per scan
