@@ -44,26 +44,45 @@ __global__ void __launch_bounds__(512) linear_relu_dot_kernel(long R, int G, con
     float* red = lds + FD_ROWS * S;          // [2][8][FD_ROWS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const long r0 = (long)blockIdx.x * FD_ROWS;
-
-    // stage the X tile (rows past R are zero)
+    // Persistent workgroup over the row tiles: the NEXT tile's rows travel through registers while the current tile is multiplied (with
+    // one group -- the direction head's tail -- a tile is loaded for 2 us and multiplied for 2 us: un-overlapped, the matrix cores idled
+    // 40 % of the time)
     constexpr int C4 = K / 4;
-    for (int e = tid; e < FD_ROWS * C4; e += 512) {
-        const int row = e / C4, c = (e - row * C4) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r0 + row < R) v = *reinterpret_cast<const float4*>(X + (r0 + row) * ldx + c);
-        *reinterpret_cast<float4*>(&Xs[row * S + c]) = v;
-    }
+    constexpr int XL = FD_ROWS * C4 / 512;   // float4 per thread and tile
+    static_assert(FD_ROWS * C4 % 512 == 0, "tile / thread geometry");
+    const long ntiles = (R + FD_ROWS - 1) / FD_ROWS;
+    float4 xn[XL];
+    auto fetch = [&](long tile) {
+        const long rt = tile * FD_ROWS;
+#pragma unroll
+        for (int h = 0; h < XL; ++h) {
+            const int e = tid + 512 * h;
+            const int row = e / C4, c = (e - row * C4) * 4;
+            xn[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tile < ntiles && rt + row < R) xn[h] = *reinterpret_cast<const float4*>(X + (rt + row) * ldx + c);   // rows past R are zero
+        }
+    };
     // weight fragment of (group g, k-step t) for this wave's strip.  PERM: W is pre-permuted to fragment order
     // Wp[g][t][strip][lane][4] (one contiguous 1 KiB per wave load); else the plain row-major [G*128][ldw] matrix.
     auto wfrag = [&](int g, int t) -> float4 {
         if (PERM) return *reinterpret_cast<const float4*>(W + ((((long)g * KT + t) * 8 + wave) * 64 + lane) * 4);
         return *reinterpret_cast<const float4*>(W + ((long)g * FD_J + wave * 16 + fr) * ldw + t * 16 + fg * 4);
     };
+    fetch(blockIdx.x);
+    int buf = 0;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long r0 = tile * FD_ROWS;
+    __syncthreads();                         // the previous tile (and its last reduction table) is consumed
+#pragma unroll
+    for (int h = 0; h < XL; ++h) {
+        const int e = tid + 512 * h;
+        const int row = e / C4, c = (e - row * C4) * 4;
+        *reinterpret_cast<float4*>(&Xs[row * S + c]) = xn[h];
+    }
     float4 bn = wfrag(0, 0);
     __syncthreads();
+    fetch(tile + gridDim.x);                 // in flight during all G groups of this tile
 
-    int buf = 0;
     for (int g = 0; g < G; ++g) {
         constexpr int RT = FD_ROWS / 16;
         f32x4 acc[RT];
@@ -103,28 +122,28 @@ __global__ void __launch_bounds__(512) linear_relu_dot_kernel(long R, int G, con
         }
         buf ^= 1;
     }
+    }
 }
 
 template <int K, int FD_ROWS>
 static int launch_lrd(long R, int G, const float* X, long ldx, const float* W, long ldw, const float* Wp, const float* b1,
                       const float* w2, const float* b2, float* out, long ldo, hipStream_t st) {
     const size_t lds = ((size_t)FD_ROWS * (K + FD_PAD) + 2 * 8 * FD_ROWS) * sizeof(float);
-    const dim3 grid((unsigned)((R + FD_ROWS - 1) / FD_ROWS));
-    if (Wp) {
-        auto kern = linear_relu_dot_kernel<K, true, FD_ROWS>;
+    const long ntiles = (R + FD_ROWS - 1) / FD_ROWS;
+    auto go = [&](auto kern, const float* Wk, long ldk) -> int {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
         }
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, R, G, X, ldx, Wp, 0L, b1, w2, b2, out, ldo);
-    } else {
-        auto kern = linear_relu_dot_kernel<K, false, FD_ROWS>;
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-        }
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, R, G, X, ldx, W, ldw, b1, w2, b2, out, ldo);
-    }
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 512, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        long blocks = 256L * per_cu;             // persistent: every resident workgroup walks the tiles with this stride
+        if (blocks > ntiles) blocks = ntiles;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, st, R, G, X, ldx, Wk, ldk, b1, w2, b2, out, ldo);
+        return ETCH_OK;
+    };
+    const int rc = Wp ? go(linear_relu_dot_kernel<K, true, FD_ROWS>, Wp, 0L) : go(linear_relu_dot_kernel<K, false, FD_ROWS>, W, ldw);
+    if (rc != ETCH_OK) return rc;
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }
