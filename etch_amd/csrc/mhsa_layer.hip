@@ -45,7 +45,7 @@ __device__ __forceinline__ float ml_xsum(float v) {
 // softmax over the 64 (60 valid) keys of one query, scores spread over the 4 lane groups x 16 registers; returns P / sum
 __device__ __forceinline__ void ml_softmax(f32x4 (&s)[4], int fg) {
     const float c = 0.35355339059327373f * 1.4426950408889634f;     // 1/sqrt(8) * log2(e)
-    if (fg == 3) s[3] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};   // keys 60..63 do not exist
+    // keys 60..63 do not exist: their scores arrive as -1e30 (the accumulators of the last key tile start there in lane group 3)
     float m = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 4; ++j) m = fmaxf(fmaxf(fmaxf(s[j][0], s[j][1]), fmaxf(s[j][2], s[j][3])), m);
@@ -138,10 +138,12 @@ __global__ void __launch_bounds__(256, MODE == 2 ? 3 : 2) mhsa_layer_kernel(long
         for (int it = 0; it < 4; ++it) {
             f32x4 sa[4], sb[4];
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const float pad = fg == 3 ? -1e30f : 0.f;                     // padded keys 60..63 (tile 3, lane group 3): exp2 -> 0
+            const f32x4 zpad = {pad, pad, pad, pad};
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) {
-                sa[jt] = ML_MFMA(Kt[jt][0], Q[it][0], z);
-                sb[jt] = ML_MFMA(Kt[jt][2], Q[it][2], z);
+                sa[jt] = ML_MFMA(Kt[jt][0], Q[it][0], jt == 3 ? zpad : z);
+                sb[jt] = ML_MFMA(Kt[jt][2], Q[it][2], jt == 3 ? zpad : z);
             }
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) {
@@ -335,10 +337,12 @@ __global__ void __launch_bounds__(256, MHSA_INTERP_WGS) mhsa_interp_layer_kernel
         for (int it = 0; it < 4; ++it) {
             f32x4 sa[4], sb[4];
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const float pad = fg == 3 ? -1e30f : 0.f;                     // padded keys 60..63 (tile 3, lane group 3): exp2 -> 0
+            const f32x4 zpad = {pad, pad, pad, pad};
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) {
-                sa[jt] = ML_MFMA(Kt[jt][0], Q[it][0], z);
-                sb[jt] = ML_MFMA(Kt[jt][2], Q[it][2], z);
+                sa[jt] = ML_MFMA(Kt[jt][0], Q[it][0], jt == 3 ? zpad : z);
+                sb[jt] = ML_MFMA(Kt[jt][2], Q[it][2], jt == 3 ? zpad : z);
             }
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) {
