@@ -21,6 +21,13 @@ def declared_symbols():
     return sorted(set(re.findall(r"\bint\s+(etch_\w+)\s*\(", txt)))
 
 
+def declared_launchers():
+    """The reference's own launcher symbols re-exported with their exact signatures (`void <name>_launcher(...)`)."""
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\bvoid\s+(\w+_launcher)\s*\(", txt)))
+
+
 class _Proxy:
     """Attribute access -> C function.  When a profiler callback is installed (bench.py) every call is
     bracketed by HIP events on the current stream; otherwise the raw ctypes function is returned."""
@@ -48,6 +55,8 @@ def lib():
         for name in declared_symbols():
             fn = getattr(cdll, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = ctypes.c_int
+        for name in declared_launchers():
+            getattr(cdll, name).restype = None
         _lib = _Proxy(cdll)
     return _lib
 

@@ -9,6 +9,7 @@
 // Built with -ffp-contract=off: distance arithmetic is "bit-defined fp32" (common.h).
 #include "common.h"
 #include <cmath>
+#include <cstdio>
 
 // ------------------------------------------------------------------------------------ ball query
 // One WAVE per query: the 64 lanes test 64 consecutive support points per step (coalesced SoA
@@ -524,6 +525,54 @@ int etch_knnquery(int b, int m_max, int m_total, int nsample, const float* xyz, 
                        (hipStream_t)stream, nsample, xyz, new_xyz, offset, new_offset, idx, dist, write_sqrt);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
+}
+
+// Segment lookup on the device (knnquery_cuda_kernel.cu:52-62 get_bt_idx: the scan over new_offset ends because q < m = new_offset[b-1]):
+// the caller needs neither the number of segments nor the largest one -- no host read of the offsets.
+int etch_knnquery_dev(int m, int nsample, const float* xyz, const float* new_xyz, const int* offset, const int* new_offset, int* idx,
+                      float* dist, int write_sqrt, void* stream) {
+    if (m <= 0) return ETCH_OK;
+    if (nsample <= 0) return ETCH_EINVAL;
+    if (nsample > 100) return ETCH_EUNSUPPORTED;          // the reference's best_dist[100] (knnquery_cuda_kernel.cu:86-87)
+    const size_t lds = (size_t)(KNNW_WAVES * 2 * nsample + KNNW_WAVES * 128) * 4;
+    long blocks = ((long)m + KNNW_WAVES - 1) / KNNW_WAVES;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(knn_wave_kernel, dim3((unsigned)blocks), dim3(KNNW_WAVES * 64), lds, (hipStream_t)stream, nsample, 0x7fffffff, xyz,
+                       new_xyz, offset, new_offset, m, idx, dist, write_sqrt);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+// ---- the reference's launchers under their own names and signatures (null stream, void, errors printed like grouping_cuda_kernel.cu:486-488)
+static void report_launcher(const char* name, int rc) {
+    if (rc != ETCH_OK) fprintf(stderr, "Error: %s failed (%d%s%s)\n", name, rc, rc > 0 ? ": " : "", rc > 0 ? hipGetErrorString((hipError_t)rc) : "");
+}
+
+void knnquery_cuda_launcher(int m, int nsample, const float* xyz, const float* new_xyz, const int* offset, const int* new_offset, int* idx,
+                            float* dist2) {
+    report_launcher("knnquery_cuda_launcher", etch_knnquery_dev(m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, 0, nullptr));
+}
+
+void furthestsampling_cuda_launcher(int b, int n, const float* xyz, const int* offset, const int* new_offset, float* tmp, int* idx) {
+    (void)tmp;      // the reference's running minimum distances (caller-filled with 1e10, sampling_cuda_kernel.cu:24-60) live in registers here
+    report_launcher("furthestsampling_cuda_launcher", etch_furthestsampling(b, n, xyz, offset, new_offset, idx, nullptr));
+}
+
+void ball_query_cuda_launcher(int b, int n, int m, float radius, int nsample, const float* new_xyz, const float* xyz, int* idx) {
+    report_launcher("ball_query_cuda_launcher", etch_ball_query(b, n, m, radius, nsample, new_xyz, xyz, idx, nullptr));
+}
+
+void furthest_point_sampling_cuda_launcher(int b, int n, int m, const float* dataset, float* temp, int* idxs) {
+    (void)temp;     // grouping_cuda_kernel.cu:352-466 keeps the running minimum distances in `temp` [b, n]; registers here
+    report_launcher("furthest_point_sampling_cuda_launcher", etch_furthest_point_sampling(b, n, m, dataset, idxs, nullptr));
+}
+
+void gather_points_forward_cuda_launcher(int b, int c, int n, int m, const float* points, const int* idx, float* out) {
+    report_launcher("gather_points_forward_cuda_launcher", etch_gather_points(b, c, n, m, points, idx, out, nullptr));
+}
+
+void gather_points_backward_cuda_launcher(int b, int c, int n, int m, const float* grad_out, const int* idx, float* grad_points) {
+    report_launcher("gather_points_backward_cuda_launcher", etch_gather_points_backward(b, c, n, m, grad_out, idx, grad_points, nullptr));
 }
 
 }  // extern "C"

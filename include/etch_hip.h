@@ -46,7 +46,8 @@ int etch_gather_points_backward(int b, int c, int n, int m, const float* grad_ou
  * `m_max` = largest number of queries in one segment, `m_total` = total number of queries (grid sizing; known to the
  * host that built the offsets).  m_total > 0 selects the wave-per-query kernel (64-wide distance evaluation, the
  * reference's sequential heap updates preserved); m_total == 0 the thread-per-query kernel.  Results are identical.
- * write_sqrt != 0 stores sqrt(d2) (what pointops.py:43 returns), else d2.  nsample <= 28. */
+ * write_sqrt != 0 stores sqrt(d2) (what pointops.py:43 returns), else d2.  nsample <= 100 (the reference's best_dist[100],
+ * knnquery_cuda_kernel.cu:86-87) on the wave-per-query kernel, <= 28 on the thread-per-query form. */
 int etch_knnquery(int b, int m_max, int m_total, int nsample, const float* xyz, const float* new_xyz, const int* offset,
                   const int* new_offset, int* idx, float* dist, int write_sqrt, void* stream);
 
@@ -56,6 +57,31 @@ int etch_knnquery(int b, int m_max, int m_total, int nsample, const float* xyz, 
 int etch_furthestsampling(int b, int n_max, const float* xyz, const int* offset, const int* new_offset, int* idx,
                           void* stream);
 
+/* etch_knnquery without any host knowledge of the offsets: every query finds its segment on the device by scanning new_offset the way
+ * the reference kernel does (knnquery_cuda_kernel.cu:52-62 get_bt_idx, :74-80), the grid is sized from m alone.  Same results as
+ * etch_knnquery; this is the form a binding calls when the offsets only exist on the device (no .tolist() / .item() sync). */
+int etch_knnquery_dev(int m, int nsample, const float* xyz, const float* new_xyz, const int* offset, const int* new_offset, int* idx,
+                      float* dist, int write_sqrt, void* stream);
+
+/* ---- the reference's own launcher symbols --------------------------------------------------------------
+ * Exactly the names and signatures the reference's host wrappers link against, so knnquery_cuda.cpp / sampling_cuda.cpp (and a
+ * pointer-level wrapper of the vgtk kernels) build against libetch_hip.so unchanged.  Like the reference they launch on the NULL
+ * stream (`<<<blocks, threads, 0>>>`), return void, and report a failed launch on stderr.  dist2 receives SQUARED distances. */
+
+/* external/pointops/src/knnquery/knnquery_cuda_kernel.h:14 (definition knnquery_cuda_kernel.cu:111-116). */
+void knnquery_cuda_launcher(int m, int nsample, const float* xyz, const float* new_xyz, const int* offset, const int* new_offset, int* idx,
+                            float* dist2);
+/* external/pointops/src/sampling/sampling_cuda_kernel.h:14 (definition sampling_cuda_kernel.cu:131-171).  n = largest segment
+ * (pointops.py:20-24); tmp (n_total) is accepted and left untouched (the running minimum distances live in registers). */
+void furthestsampling_cuda_launcher(int b, int n, const float* xyz, const int* offset, const int* new_offset, float* tmp, int* idx);
+/* Pointer-level forms of the vgtk launches, argument order of the kernels they start:
+ * ball_query_cuda_kernel<<<b, opt_n_threads(m)>>>(b,n,m,radius,nsample,new_xyz,xyz,idx)   grouping_cuda_kernel.cu:68-73,476-481
+ * furthest_point_sampling_cuda_kernel<<<nb, n_threads>>>(nb,nq,m,source,temp,idx)         grouping_cuda_kernel.cu:352-354,637-642
+ * gather_points_forward_kernel / gather_points_backward_kernel                            gathering_cuda_kernel.cu:43-98,103-165 */
+void ball_query_cuda_launcher(int b, int n, int m, float radius, int nsample, const float* new_xyz, const float* xyz, int* idx);
+void furthest_point_sampling_cuda_launcher(int b, int n, int m, const float* dataset, float* temp, int* idxs);
+void gather_points_forward_cuda_launcher(int b, int c, int n, int m, const float* points, const int* idx, float* out);
+void gather_points_backward_cuda_launcher(int b, int c, int n, int m, const float* grad_out, const int* idx, float* grad_points);
 
 /* ---- dense per-point layers ----------------------------------------------------------------------- */
 

@@ -196,3 +196,71 @@ def test_knn_large_nsample_up_to_the_reference_limit(k):
     ri, rd2 = O.knnquery(k, p, q, o, qo)
     idx, dist = ops.knnquery(k, dev(p), dev(q), dev(o), dev(qo), sqrt=False)
     assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(dist.cpu().numpy(), rd2)
+
+
+def test_reference_launcher_symbols_without_host_offsets():
+    """The reference's OWN launcher symbols (knnquery_cuda_kernel.h:14, sampling_cuda_kernel.h:14, + pointer-level forms of the vgtk
+    launches) called through ctypes with device pointers only: the offsets are built on the device and never read back by the host;
+    results must equal the oracle's and etch_knnquery's (which is handed the segment count and sizes by the host)."""
+    import ctypes
+
+    from etch_amd import _lib, ops
+    L = _lib.lib()
+    vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    segs, qsegs = [700, 1300, 64, 2000], [300, 41, 64, 500]
+    p = np.concatenate([scan(5100 + i, n) for i, n in enumerate(segs)])
+    q = np.concatenate([scan(6100 + i, n) for i, n in enumerate(qsegs)])
+    dp, dq = dev(p), dev(q)
+    o = torch.cumsum(torch.tensor(segs, dtype=torch.int32, device="cuda"), 0).int()          # device-resident offsets
+    qo = torch.cumsum(torch.tensor(qsegs, dtype=torch.int32, device="cuda"), 0).int()
+    m = int(sum(qsegs))
+    for k in (1, 3, 8, 16, 40):
+        idx = torch.empty((m, k), dtype=torch.int32, device="cuda")
+        d2 = torch.empty((m, k), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        L.knnquery_cuda_launcher(ci(m), ci(k), vp(dp.data_ptr()), vp(dq.data_ptr()), vp(o.data_ptr()), vp(qo.data_ptr()), vp(idx.data_ptr()),
+                                 vp(d2.data_ptr()))
+        torch.cuda.synchronize()
+        ri, rd2 = O.knnquery(k, p, q, np.cumsum(segs).astype(np.int32), np.cumsum(qsegs).astype(np.int32))
+        assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(d2.cpu().numpy(), rd2), k
+        i2, dd = ops.knnquery(k, dp, dq, o, qo, sqrt=False)
+        assert torch.equal(i2, idx) and torch.equal(dd, d2)
+        # the pybind-module mirror takes the same route (no .tolist() of the offsets)
+        from etch_amd import pointops_cuda
+        idx3, d3 = torch.empty_like(idx), torch.empty_like(d2)
+        pointops_cuda.knnquery_cuda(m, k, dp, dq, o, qo, idx3, d3)
+        assert torch.equal(idx3, idx) and torch.equal(d3, d2)
+    # furthestsampling_cuda_launcher(b, n_max, xyz, offset, new_offset, tmp, idx)
+    no = torch.cumsum(torch.tensor([s // 4 for s in segs], dtype=torch.int32, device="cuda"), 0).int()
+    mt = sum(s // 4 for s in segs)
+    fidx = torch.zeros((mt,), dtype=torch.int32, device="cuda")
+    tmp = torch.full((len(p),), 1e10, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    L.furthestsampling_cuda_launcher(ci(len(segs)), ci(max(segs)), vp(dp.data_ptr()), vp(o.data_ptr()), vp(no.data_ptr()), vp(tmp.data_ptr()),
+                                     vp(fidx.data_ptr()))
+    torch.cuda.synchronize()
+    want = O.furthestsampling(p, np.cumsum(segs).astype(np.int32), np.cumsum([s // 4 for s in segs]).astype(np.int32))
+    assert np.array_equal(fidx.cpu().numpy(), want)
+    # vgtk launches, pointer level
+    x = np.stack([scan(7000 + b, 900).T for b in range(2)])
+    dx = dev(x)
+    nq = 450
+    fi = torch.zeros((2, nq), dtype=torch.int32, device="cuda")
+    temp = torch.full((2, 900), 1e10, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    L.furthest_point_sampling_cuda_launcher(ci(2), ci(900), ci(nq), vp(dx.data_ptr()), vp(temp.data_ptr()), vp(fi.data_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(fi.cpu().numpy(), O.furthest_point_sampling(x, nq))
+    new = torch.empty((2, 3, nq), dtype=torch.float32, device="cuda")
+    L.gather_points_forward_cuda_launcher(ci(2), ci(3), ci(900), ci(nq), vp(dx.data_ptr()), vp(fi.data_ptr()), vp(new.data_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(new.cpu().numpy(), np.take_along_axis(x, fi.cpu().numpy()[:, None, :].astype(np.int64), 2))
+    bi = torch.empty((2, nq, 32), dtype=torch.int32, device="cuda")
+    L.ball_query_cuda_launcher(ci(2), ci(900), ci(nq), cf(0.12), ci(32), vp(new.data_ptr()), vp(dx.data_ptr()), vp(bi.data_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(bi.cpu().numpy(), O.ball_query(new.cpu().numpy(), x, 0.12, 32))
+    g = torch.randn(2, 3, nq, device="cuda")
+    gp = torch.empty((2, 3, 900), dtype=torch.float32, device="cuda")
+    L.gather_points_backward_cuda_launcher(ci(2), ci(3), ci(900), ci(nq), vp(g.data_ptr()), vp(fi.data_ptr()), vp(gp.data_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(gp.cpu().numpy(), O.gather_points_backward(g.cpu().numpy(), fi.cpu().numpy(), 900))
