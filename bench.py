@@ -437,7 +437,9 @@ def main():
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": cfg_name, "schedule": sched, "global_batch": B * world, "points": N, "parallelism": f"scan-sharded x{world}",
                       "distinct_batches": nbatch, "launcher": "torchrun/env" if "TORCHELASTIC_RUN_ID" in os.environ else ("self" if world > 1 else "single"),
-                      "cpu_pinning": None if pinned is None else f"rank 0 on {len(pinned)} NUMA-local cores"},
+                      "cpu_pinning": None if pinned is None else f"rank 0 on {len(pinned)} NUMA-local cores",
+                      "collective_backend": (torch.distributed.get_backend() + (" (forced world-size-1 group: ETCH_FORCE_DIST)" if world == 1 else ""))
+                      if torch.distributed.is_initialized() else None},
            "gathered_rows": {"columns": row_names, "scans_reported": int(allrows.shape[0]), "finite_scans": int(finite.sum()),
                              "mean": [float(v) for v in allrows[finite].mean(0)] if bool(finite.any()) else None},
            "ms_per_step_synchronous": round(sync_ms, 3)}

@@ -20,7 +20,7 @@ class GraphedHotPath:
     """predict = GraphedHotPath(args, model, B, N, gender);  meshes, markers, valid, info = predict(points (B,N,3) on the device).
 
     Stage 2 runs with the reference's schedule (30 + 50 LM iterations) unless `fit_kwargs` say otherwise.  The device results of a
-    replay live in static buffers that the next replay overwrites: `__call__` copies them to the host before it returns."""
+    replay live in static buffers that the next replay overwrites: `__call__` returns host copies (meshes, info) and clones (markers, valid), never the static buffers themselves."""
 
     def __init__(self, args, model, B, N, gender="neutral", warmup=2, **fit_kwargs):
         self.args, self.model, self.gender, self.fit_kwargs = args, model, gender, fit_kwargs
@@ -55,4 +55,8 @@ class GraphedHotPath:
         return self.dev
 
     def __call__(self, points):
-        return fit_smpl_finalize(dict(self.replay(points)))
+        """One pass in the reference's return format.  Nothing returned aliases the graph's static buffers: meshes / info are host
+        copies and `markers` / `valid` are cloned (a result kept from one call survives the next; `replay()` is the aliasing form)."""
+        dev = dict(self.replay(points))
+        dev["markers"], dev["valid"] = dev["markers"].clone(), dev["valid"].clone()
+        return fit_smpl_finalize(dev)

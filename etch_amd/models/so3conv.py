@@ -115,7 +115,8 @@ class SeparableSO3ConvBlock(nn.Module):
         s = s.view(b, p2, na, -1)
         m3, r3 = ops.instnorm_stats(s)
         out = ops.instnorm_act_add(z.feats_cl, m2, r2, s, m3, r3)
-        return inter_idx, None, sample_idx, sptk.SphericalPointCloud(y.xyz, None, y.anchors, feats_cl=out)
+        # x.anchors after the intra conv = the INTRA conv's anchors buffer (vgtk modules.py:153; so3conv.py:182 passes it on)
+        return inter_idx, None, sample_idx, sptk.SphericalPointCloud(y.xyz, None, z.anchors, feats_cl=out)
 
 
 class BasicSO3ConvBlock(nn.Module):

@@ -11,11 +11,22 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def forced():
+    """ETCH_FORCE_DIST=1: run the collective path even with ONE rank (a world-size-1 RCCL process group), so that RCCL initialisation,
+    the device-tensor all_gather and the fp64 all_reduce(MAX) execute on a 1-GPU box exactly as they will on an 8-GPU node."""
+    return os.environ.get("ETCH_FORCE_DIST", "") not in ("", "0")
+
+
+def _active():
+    return dist.is_initialized() and (dist.get_world_size() > 1 or forced())
+
+
 def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+    """Initialise torch.distributed from the torchrun environment (no-op for a single process unless ETCH_FORCE_DIST is set)."""
     rank, world, local = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = backend or os.environ.get("ETCH_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend, rank=rank, world_size=world)
@@ -147,7 +158,7 @@ def shard_range(total, rank, world):
 def gather_rows(rows):
     """all_gather of per-scan result rows (n_local, k) -> (n_total, k) on every rank, rank order == scan order.
     Ranks may hold different n_local (ragged shards are padded to the maximum and trimmed)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return rows
     world = dist.get_world_size()
     dev = rows.device
@@ -165,12 +176,15 @@ def gather_rows(rows):
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+    if _active():
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(value, device):
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return value
     t = _coll(torch.tensor([value], dtype=torch.float64, device=device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

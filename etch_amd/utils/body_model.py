@@ -46,7 +46,7 @@ class BodyModel:
         return len(self.parents)
 
 
-def _synthetic(seed, V, NB, parents, extra_vids):
+def _synthetic(seed, V, NB, parents, extra_vids, shape_scale=0.01, pose_scale=0.001):
     rng = np.random.default_rng(seed)
     J = len(parents)
     v_t = rng.standard_normal((V, 3)) * np.array([0.15, 0.45, 0.10])
@@ -61,15 +61,17 @@ def _synthetic(seed, V, NB, parents, extra_vids):
     Jreg = np.zeros((J, V))
     for j in range(J):
         Jreg[j, np.argsort(d2[:, j])[:50]] = 1.0 / 50
-    S = rng.standard_normal((V, 3, NB)) * 0.01
-    P = rng.standard_normal((9 * (J - 1), V * 3)) * 0.001
+    S = rng.standard_normal((V, 3, NB)) * shape_scale
+    P = rng.standard_normal((9 * (J - 1), V * 3)) * pose_scale
     faces = np.stack([np.arange(V - 2), np.arange(1, V - 1), np.arange(2, V)], 1)[: 2 * V - 4 - (V - 2)]  # a strip, only for OBJ export
     faces = np.concatenate([faces, faces[:, ::-1]])[:2 * V - 4]
     return BodyModel(v_t, S, P, Jreg, W, parents, faces, extra_vids)
 
 
-def SyntheticSMPL(seed=7, V=6890, NB=10):
-    return _synthetic(seed, V, NB, SMPL_PARENTS, SMPL_EXTRA_JOINT_VIDS)
+def SyntheticSMPL(seed=7, V=6890, NB=10, shape_scale=0.01, pose_scale=0.001):
+    """shape_scale / pose_scale: standard deviation of the shape / pose blend-shape entries (real SMPL: ~3e-2 / ~1e-2 m; the defaults
+    are the gentler values every round-1/2 fixture was generated with)."""
+    return _synthetic(seed, V, NB, SMPL_PARENTS, SMPL_EXTRA_JOINT_VIDS, shape_scale, pose_scale)
 
 
 def SyntheticSMPLX(seed=7, V=10475, NB=20):

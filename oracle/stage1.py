@@ -392,7 +392,11 @@ def forward(sd, hitpts, table, num_markers=86, return_aux=False):
         o = torch.tensor([N * (i + 1) for i in range(B)], dtype=torch.int32)
         labels, conf = pt_confidence(sd, "confidence_encoder.", p, x, o, num_markers)
         anc_w = direction_anchor_weights(sd, pef)
-        anchors = sd["encoder.backbone.0.blocks.0.inter_conv.conv.anchors"]
+        # r.anchors of models_pointcloud.py:162 = the anchors buffer of the LAST conv the cloud went through: the intra conv of the last
+        # separable block (so3conv.py:176-182 passes x.anchors on; vgtk modules.py:153 IntraSO3Conv returns self.anchors)
+        last = max((k for k in sd if k.startswith("encoder.backbone.") and k.endswith(".intra_conv.conv.anchors")),
+                   key=lambda k: tuple(int(t) for t in k.split(".") if t.isdigit()))
+        anchors = sd[last]
         R, Ce, sv = so3_mean(anchors, anc_w)
         direction = R.reshape(B, N, 3, 3)[..., 2].contiguous()  # R @ [0,0,1]
         mag = pt_magnitude(sd, "magnitude_encoder.", p, x, o)

@@ -286,10 +286,15 @@ def test_hip_graph_replay_matches_eager_path(tmp_path, B, N):
     from etch_amd.inference_demo import predict_smpl_batch
     args, model = make(tmp_path)
     g = GraphedHotPath(args, model, B, N)
+    held = None
     for rep in range(3):
         pts = torch.from_numpy(np.stack([scan(900 + 10 * rep + b, N) for b in range(B)])).cuda()
-        meshes, markers, valid, info = g(pts)
-        markers, valid = markers.clone(), valid.clone()         # static buffers of the graph
+        meshes, markers, valid, info = g(pts)                   # __call__ returns clones, never the graph's static buffers
+        if held is not None:
+            # outputs kept from the previous call survive this replay
+            assert torch.equal(held[0], held[2]) and torch.equal(held[1], held[3])
+        held = (markers, valid, markers.clone(), valid.clone())
+        assert markers.data_ptr() != g.dev["markers"].data_ptr() and valid.data_ptr() != g.dev["valid"].data_ptr()
         meshes0, markers0, valid0, info0 = predict_smpl_batch(args, model, pts)
         assert torch.equal(valid, valid0) and torch.equal(markers[valid], markers0[valid0])
         for a, b in zip(info, info0):
