@@ -159,5 +159,7 @@ extern "C" int etch_linear_relu_dot(long R, int K, int G, int J, const float* X,
     // workgroup -- 4.07 -> 3.90 ms on the confidence head although every workgroup streams the weights)
     if (K == 64) return launch_lrd<64, 128>(R, G, X, ldx, W, ldw, Wp, b1, w2, b2, out, ldo, st);
     if (K == 128) return launch_lrd<128, 64>(R, G, X, ldx, W, ldw, Wp, b1, w2, b2, out, ldo, st);
+    if (K == 32) return launch_lrd<32, 128>(R, G, X, ldx, W, ldw, Wp, b1, w2, b2, out, ldo, st);      // direction tail of encoder depth 1
+    if (K == 256) return launch_lrd<256, 32>(R, G, X, ldx, W, ldw, Wp, b1, w2, b2, out, ldo, st);     // ... of depth 4
     return ETCH_EUNSUPPORTED;
 }

@@ -183,6 +183,83 @@ __global__ void __launch_bounds__(512) mhsa_attention_kernel(const float* __rest
     }
 }
 
+// The same attention core for the other encoder depths (models_pointcloud.py:34-48: embedding 32 / 128 / 256 -> 8 heads of HD = 4 / 16 / 32,
+// direction_backbones.py:151 head_size = embedding_dim // num_heads; logits scaled by 1/sqrt(HD), :125).  Same geometry: wave = head,
+// lane = query token, K / V of the 8 heads staged in (dynamic) LDS: 8 x 60 x HD x 2 floats = 15 / 61 / 123 KB.
+template <int HD>
+__global__ void __launch_bounds__(512) mhsa_attention_hd_kernel(const float* __restrict__ qkv, long ld, int qoff, int koff, int voff,
+                                                                float inv_sqrt_dk, float* __restrict__ out, long ldo) {
+    extern __shared__ __attribute__((aligned(16))) float mh_lds[];
+    const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
+    float* ks = mh_lds + (size_t)h * MH_L * HD;                    // [60][HD] of this head
+    float* vs = mh_lds + (size_t)8 * MH_L * HD + (size_t)h * MH_L * HD;
+    const size_t row0 = (size_t)blockIdx.x * MH_L;
+    constexpr int Q4 = HD / 4;
+    for (int e = lane; e < MH_L * Q4; e += 64) {
+        const int r = e / Q4, c = (e - r * Q4) * 4;
+        const float* base = qkv + (row0 + r) * ld + h * HD + c;
+        *reinterpret_cast<float4*>(&ks[r * HD + c]) = *reinterpret_cast<const float4*>(base + koff);
+        *reinterpret_cast<float4*>(&vs[r * HD + c]) = *reinterpret_cast<const float4*>(base + voff);
+    }
+    __syncthreads();
+    if (lane < MH_L) {
+        const float* qp = qkv + (row0 + lane) * ld + qoff + h * HD;
+        float q[HD];
+#pragma unroll
+        for (int c = 0; c < HD; c += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(qp + c);
+            q[c] = t.x; q[c + 1] = t.y; q[c + 2] = t.z; q[c + 3] = t.w;
+        }
+        float lg[MH_L];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < MH_L; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < HD; c += 4) {
+                const float4 kk = *reinterpret_cast<const float4*>(&ks[j * HD + c]);       // broadcast read: every lane reads key j
+                s = c == 0 ? q[0] * kk.x : fmaf(q[c], kk.x, s);
+                s = fmaf(q[c + 1], kk.y, s); s = fmaf(q[c + 2], kk.z, s); s = fmaf(q[c + 3], kk.w, s);
+            }
+            s *= inv_sqrt_dk;
+            lg[j] = s;
+            mx = fmaxf(mx, s);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < MH_L; ++j) { lg[j] = __expf(lg[j] - mx); den += lg[j]; }
+        const float inv = 1.0f / den;
+        float o[HD];
+#pragma unroll
+        for (int c = 0; c < HD; ++c) o[c] = 0.f;
+#pragma unroll
+        for (int j = 0; j < MH_L; ++j) {
+            const float pj = lg[j] * inv;
+#pragma unroll
+            for (int c = 0; c < HD; c += 4) {
+                const float4 vv = *reinterpret_cast<const float4*>(&vs[j * HD + c]);
+                o[c] = fmaf(pj, vv.x, o[c]); o[c + 1] = fmaf(pj, vv.y, o[c + 1]); o[c + 2] = fmaf(pj, vv.z, o[c + 2]); o[c + 3] = fmaf(pj, vv.w, o[c + 3]);
+            }
+        }
+        float* op = out + (row0 + lane) * ldo + h * HD;
+#pragma unroll
+        for (int c = 0; c < HD; c += 4) *reinterpret_cast<float4*>(op + c) = make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]);
+    }
+}
+
+template <int HD>
+static int launch_mhsa_hd(long T, const float* qkv, long ld, int qoff, int koff, int voff, float* out, long ldo, hipStream_t st) {
+    const size_t lds = (size_t)2 * 8 * MH_L * HD * sizeof(float);
+    auto kern = mhsa_attention_hd_kernel<HD>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)T), dim3(512), lds, st, qkv, ld, qoff, koff, voff, (float)(1.0 / sqrt((double)HD)), out, ldo);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
 // y[r] = x[r,:] . w + bias   (K % 4 == 0): 16 lanes per row, float4 loads, 4 rows per wave
 __global__ void __launch_bounds__(256) rowdot_kernel(long R, int K, const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ w, float bias, float* __restrict__ y) {
@@ -333,6 +410,7 @@ int etch_prop_interp_ordered(int B, int N, int S, int A, int C, const float* fea
     if (C == 64) hipLaunchKernelGGL(prop_interp_kernel<64>, grid, dim3(256), 0, st, N, S, A, feats, idx, weight, out, inv, order);
     else if (C == 32) hipLaunchKernelGGL(prop_interp_kernel<32>, grid, dim3(256), 0, st, N, S, A, feats, idx, weight, out, inv, order);
     else if (C == 128) hipLaunchKernelGGL(prop_interp_kernel<128>, grid, dim3(256), 0, st, N, S, A, feats, idx, weight, out, inv, order);
+    else if (C == 256) hipLaunchKernelGGL(prop_interp_kernel<256>, grid, dim3(256), 0, st, N, S, A, feats, idx, weight, out, inv, order);
     else return ETCH_EUNSUPPORTED;
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
@@ -341,6 +419,21 @@ int etch_prop_interp_ordered(int B, int N, int S, int A, int C, const float* fea
 int etch_prop_interp(int B, int N, int S, int A, int C, const float* feats, const int* idx, const float* weight, float* out,
                      float* inv, void* stream) {
     return etch_prop_interp_ordered(B, N, S, A, C, feats, idx, weight, out, inv, nullptr, stream);
+}
+
+int etch_mhsa_attention(long T, const float* qkv, long ld, int qoff, int koff, int voff, float* out, long ldo, void* stream);
+
+int etch_mhsa_attention_dim(long T, int embedding_dim, const float* qkv, long ld, int qoff, int koff, int voff, float* out, long ldo, void* stream) {
+    if (T <= 0) return ETCH_OK;
+    if ((ld & 3) || (ldo & 3) || (qoff & 3) || (koff & 3) || (voff & 3)) return ETCH_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    switch (embedding_dim) {
+        case 32: return launch_mhsa_hd<4>(T, qkv, ld, qoff, koff, voff, out, ldo, st);
+        case 64: return etch_mhsa_attention(T, qkv, ld, qoff, koff, voff, out, ldo, stream);
+        case 128: return launch_mhsa_hd<16>(T, qkv, ld, qoff, koff, voff, out, ldo, st);
+        case 256: return launch_mhsa_hd<32>(T, qkv, ld, qoff, koff, voff, out, ldo, st);
+    }
+    return ETCH_EUNSUPPORTED;
 }
 
 int etch_mhsa_attention(long T, const float* qkv, long ld, int qoff, int koff, int voff, float* out, long ldo, void* stream) {

@@ -19,7 +19,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define KS 24
 
 // ------------------------------------------------------------------------------------------------
-// inter conv, CIN in {16,32,64}: one workgroup (4 waves) per output point.
+// inter conv, CIN in {16,32,64} (+ 128 / 256 in passes of 64 input channels): one workgroup (4 waves) per output point.
 //   step 1 (per anchor, per wave):  X1[c,k] = sum_n F[idx[n], a, c] * w[a,k,n]      MFMA M=c, N=k(24->32), K=n
 //       w[a,k,n] = relu(1 - |g_n - R_a kappa_k|^2 / sigma) generated per lane as the B fragment
 //   step 2 (16 anchors at a time):  Y[o,col] = sum_kappa W[o,kappa] * X1[col][kappa] + bias      MFMA M=o, N=col, K=CIN*24
@@ -35,12 +35,18 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
     const int* __restrict__ ball_idx, const float* __restrict__ feats, const float* __restrict__ rk,
     const float* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ out, const int* __restrict__ order,
     float* __restrict__ stat_part) {
-    constexpr int MT1 = CIN / 16;          // c tiles in step 1
+    // CIN > 64 (encoder depths 3 / 4: 128 / 256 channels): the input channels are processed in NCC passes of CCH = 64 channels -- step 1
+    // on that slice of the gathered rows (kernel weights regenerated per pass: 5 VALU ops against 2 * MT1 MFMAs), step 2 accumulating
+    // Y over the slice's part of the contraction; registers and LDS stay those of the 64-channel kernel.  NCC = 1: the code below folds
+    // to the single-pass form.
+    constexpr int CCH = CIN > 64 ? 64 : CIN;
+    constexpr int NCC = CIN / CCH;
+    constexpr int MT1 = CCH / 16;          // c tiles in step 1 (per pass)
     constexpr int MT2 = COUT / 16;         // o tiles in step 2
-    constexpr int KK = CIN * KS;           // contraction length of step 2
+    constexpr int KK = CCH * KS;           // contraction length of step 2 (per pass)
     // For CIN = 64 the X1 tile goes through LDS in two channel halves (the second half waits in registers), which
     // halves the LDS footprint and lets two workgroups share a CU (2 waves / SIMD hide the gather latency of step 1).
-    constexpr int HALVES = CIN >= 32 ? 2 : 1;
+    constexpr int HALVES = CCH >= 32 ? 2 : 1;
     constexpr int MTH = MT1 / HALVES;      // c tiles per half
     constexpr int KH = KK / HALVES;        // contraction length per half
     constexpr int S = KH + 40;             // LDS row stride (floats): S/4 = 10 (mod 16) keeps the ds_read_b128 B-fragment reads conflict-free
@@ -98,11 +104,11 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
     static_assert(NCS % NRING == 0, "ring slots must line up across anchor groups");
     VecT ring[NRING][4];
     float rkn[6];
-    auto issue = [&](int ag_, int cs, VecT (&dst)[4]) {
+    auto issue = [&](int it_, int cs, VecT (&dst)[4]) {    // it_ = anchor group * NCC + channel pass
         const int j = cs / MAXT, t = cs % MAXT;
-        int a = ag_ * 16 + wave * 4 + j;
+        int a = (it_ / NCC) * 16 + wave * 4 + j;
         a = a < NA ? a : NA - 1;
-        const float* Fa = Fb + (size_t)a * CIN;         // wave-uniform base + 32-bit lane offset
+        const float* Fa = Fb + (size_t)a * CIN + (it_ % NCC) * CCH;         // wave-uniform base + 32-bit lane offset
 #pragma unroll
         for (int s = 0; s < 4; ++s) dst[s] = *reinterpret_cast<const VecT*>(Fa + (noff[16 * t + 4 * fg + s] + (unsigned)(VEC * fr)));
     };
@@ -119,8 +125,10 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
     // InstanceNorm statistics of the output, fused: this thread's output channel is fixed (256 % COUT == 0), so it keeps the sum
     // and the sum of squares of everything it writes; reduced per workgroup at the end (stat_part [b][p2][2][COUT])
     float st_s = 0.f, st_q = 0.f;
+    f32x4 y[MT2];
 #pragma unroll 1
-    for (int ag = 0; ag < 4; ++ag) {
+    for (int it = 0; it < 4 * NCC; ++it) {
+        const int ag = it / NCC, cc = it % NCC;
         f32x4 keep[4][HALVES > 1 ? MTH : 1][2];        // second channel half of the wave's 4 anchors (HALVES == 2 only)
         // ---------------- step 1: 4 anchors per wave, MAXT chunk-steps each
         f32x4 acc[MT1][2];
@@ -137,13 +145,13 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
                 r0x = rkn[0]; r0y = rkn[1]; r0z = rkn[2]; r1x = rkn[3]; r1y = rkn[4]; r1z = rkn[5];
                 rb0 = -(r0x * r0x + r0y * r0y + r0z * r0z) * inv_sigma;
                 rb1 = k1ok ? -(r1x * r1x + r1y * r1y + r1z * r1z) * inv_sigma : -1e30f;   // k >= 24: weight 0
-                issue_rk(j < 3 ? a + 1 : (ag + 1) * 16 + wave * 4);                        // next anchor's kernel points
+                issue_rk(j < 3 ? a + 1 : ((it + 1) / NCC) * 16 + wave * 4);                // next anchor's kernel points
             }
             {
                 constexpr int dummy = 0; (void)dummy;
                 const int nc = cs + PD;
-                if (nc < NCS) issue(ag, nc, ring[nc % NRING]);
-                else if (ag < 3) issue(ag + 1, nc - NCS, ring[nc % NRING]);               // wave-uniform
+                if (nc < NCS) issue(it, nc, ring[nc % NRING]);
+                else if (it < 4 * NCC - 1) issue(it + 1, nc - NCS, ring[nc % NRING]);     // wave-uniform
             }
             if (a < NA && t < nchunk) {                     // wave-uniform
                 VecT (&cur)[4] = ring[cs % NRING];
@@ -177,9 +185,10 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
                 }
             }
         }
-        f32x4 y[MT2];
+        if (cc == 0) {
 #pragma unroll
-        for (int mt = 0; mt < MT2; ++mt) y[mt] = (f32x4){0, 0, 0, 0};
+            for (int mt = 0; mt < MT2; ++mt) y[mt] = (f32x4){0, 0, 0, 0};
+        }
 #pragma unroll
         for (int h = 0; h < HALVES; ++h) {
             if (h > 0) {
@@ -200,19 +209,27 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
             // this loop measured 5 % slower: profiles/r02_inter_conv_experiments.txt.)
             for (int t = wave; t < KH / 16; t += 4) {
                 const float4 bv = *reinterpret_cast<const float4*>(&X1s[fr * S + t * 16 + fg * 4]);
-                const int tg = h * (KH / 16) + t;           // chunk index in the full K = c*24 + k order
-                float4 av[MT2];
+                const int tg = (cc * HALVES + h) * (KH / 16) + t;           // chunk index in the kernel's contraction order
+                constexpr int MB = MT2 > 8 ? 4 : MT2;       // W fragments in registers at a time (COUT = 256: four batches of 4 tiles, the accumulators alone take 64 registers)
 #pragma unroll
-                for (int mt = 0; mt < MT2; ++mt) av[mt] = *reinterpret_cast<const float4*>(&Wp[(((size_t)tg * MT2 + mt) * 64 + lane) * 4]);
+                for (int m0 = 0; m0 < MT2; m0 += MB) {
+                    float4 av[MB];
 #pragma unroll
-                for (int mt = 0; mt < MT2; ++mt) y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].x, bv.x, y[mt], 0, 0, 0);
+                    for (int mt = 0; mt < MB; ++mt) av[mt] = *reinterpret_cast<const float4*>(&Wp[(((size_t)tg * MT2 + m0 + mt) * 64 + lane) * 4]);
 #pragma unroll
-                for (int mt = 0; mt < MT2; ++mt) y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].y, bv.y, y[mt], 0, 0, 0);
+                    for (int mt = 0; mt < MB; ++mt) y[m0 + mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].x, bv.x, y[m0 + mt], 0, 0, 0);
 #pragma unroll
-                for (int mt = 0; mt < MT2; ++mt) y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].z, bv.z, y[mt], 0, 0, 0);
+                    for (int mt = 0; mt < MB; ++mt) y[m0 + mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].y, bv.y, y[m0 + mt], 0, 0, 0);
 #pragma unroll
-                for (int mt = 0; mt < MT2; ++mt) y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].w, bv.w, y[mt], 0, 0, 0);
+                    for (int mt = 0; mt < MB; ++mt) y[m0 + mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].z, bv.z, y[m0 + mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MB; ++mt) y[m0 + mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].w, bv.w, y[m0 + mt], 0, 0, 0);
+                }
             }
+        }
+        if (NCC > 1 && cc < NCC - 1) {
+            __syncthreads();                                // every wave finished reading this pass's X1 tile before the next pass rewrites it
+            continue;
         }
         // y[mt][q] = Y[o = 16mt + 4fg + q][col = fr]
 #pragma unroll
@@ -398,7 +415,7 @@ __global__ void __launch_bounds__(256) inter_so3conv_c1_kernel(
 // leaky-relu'ed on the way in), each wave owns 16 anchors (N tile) x all output tiles.
 // K order inside the kernel: kappa = tap*C + c; W is pre-permuted on the host into fragment order.
 // ------------------------------------------------------------------------------------------------
-template <int C, int COUT, int PTS>
+template <int C, int COUT, int PTS>     // C >= 128 (encoder depths 3 / 4): PTS = 1, the input tile in dynamic LDS (71 KB at C = 256), no fused statistics
 __global__ void __launch_bounds__(256) intra_so3conv_kernel(int npts_total, int pts_per_batch, const float* __restrict__ X,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const int* __restrict__ intra_idx, const float* __restrict__ Wp,
@@ -407,7 +424,10 @@ __global__ void __launch_bounds__(256) intra_so3conv_kernel(int npts_total, int 
     constexpr int MT = COUT / 16;
     constexpr int LD = C == 16 ? 56 : C + 40;   // row stride (floats) with LD/4 = 10 or 14 (mod 16): conflict-free ds_read_b128 of the gathered rows
     constexpr int NT = 12 * C / 16;        // K chunks
-    __shared__ __attribute__((aligned(16))) float Xs[PTS * NA * LD];
+    constexpr bool STATIC_TILE = (size_t)PTS * NA * LD * sizeof(float) <= 60 * 1024;
+    __shared__ __attribute__((aligned(16))) float Xs_static[STATIC_TILE ? PTS * NA * LD : 4];
+    extern __shared__ __attribute__((aligned(16))) float Xs_dynamic[];
+    float* Xs = STATIC_TILE ? Xs_static : Xs_dynamic;
     __shared__ int iidx[NA * 12];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -475,11 +495,10 @@ __global__ void __launch_bounds__(256) intra_so3conv_kernel(int npts_total, int 
             }
         }
     }
-    if (stat_part) {
+    constexpr int RS = 2 * COUT + 4;
+    if constexpr (64 * RS <= PTS * NA * LD) if (stat_part) {
         // [64 anchor slots][2][COUT] through the (now free) input tile, row stride + 4 floats against bank conflicts; then one thread per
-        // (statistic, channel) sums the 64 slots in order
-        constexpr int RS = 2 * COUT + 4;
-        static_assert(64 * RS <= PTS * NA * LD, "statistics staging must fit the input tile");
+        // (statistic, channel) sums the 64 slots in order (the host only asks for it where the staging fits the input tile)
         __syncthreads();
         float* red = Xs + (wave * 16 + fr) * RS;
 #pragma unroll
@@ -622,7 +641,8 @@ template <int CIN, int COUT, int MAXT>
 static int launch_inter_t(int b, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz, const int* idx,
                           const float* feats, const float* rk, const float* Wp, const float* bias, float* out, const int* order,
                           float* stat_part, hipStream_t st) {
-    const size_t lds = (size_t)(16 * (CIN * KS / (CIN >= 32 ? 2 : 1) + 40) + 4 * 16 * (COUT + 4) + 16 * MAXT * 5) * sizeof(float);
+    constexpr int CCH = CIN > 64 ? 64 : CIN;
+    const size_t lds = (size_t)(16 * (CCH * KS / (CCH >= 32 ? 2 : 1) + 40) + 4 * 16 * (COUT + 4) + 16 * MAXT * 5) * sizeof(float);
     constexpr int PD = INTER_PD(CIN, MAXT);
     auto kern = inter_so3conv_kernel<CIN, COUT, MAXT, PD>;
     if (lds > 64 * 1024) {
@@ -648,9 +668,17 @@ static int launch_inter(int b, int p1, int p2, int nn, float sigma, const float*
 template <int C, int COUT>
 static int launch_intra(int npts, int ppb, const float* X, const float* mean, const float* rstd, const int* intra_idx,
                         const float* Wp, const float* bias, float* Y, float* stat_part, hipStream_t st) {
-    constexpr int PTS = 2;
-    if (stat_part && (ppb % PTS) != 0) return ETCH_EUNSUPPORTED;      // a workgroup's points must belong to one sample
-    hipLaunchKernelGGL((intra_so3conv_kernel<C, COUT, PTS>), dim3((npts + PTS - 1) / PTS), dim3(256), 0, st, npts, ppb, X, mean,
+    constexpr int PTS = C >= 128 ? 1 : 2;
+    constexpr int LD = C == 16 ? 56 : C + 40;
+    if (stat_part && ((ppb % PTS) != 0 || C >= 128)) return ETCH_EUNSUPPORTED;      // a workgroup's points must belong to one sample
+    const size_t tile = (size_t)PTS * NA * LD * sizeof(float);
+    const size_t dyn = tile <= 60 * 1024 ? 0 : tile;
+    auto kern = intra_so3conv_kernel<C, COUT, PTS>;
+    if (dyn + NA * 12 * sizeof(int) > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3((npts + PTS - 1) / PTS), dim3(256), dyn, st, npts, ppb, X, mean,
                        rstd, intra_idx, Wp, bias, Y, stat_part);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
@@ -679,6 +707,7 @@ int etch_inter_so3conv_ordered(int b, int cin, int cout, int p1, int p2, int nn,
 #define INTER_CASE(CI, CO) \
     if (cin == CI && cout == CO) return launch_inter<CI, CO>(b, p1, p2, nn, sigma, xyz, new_xyz, ball_idx, feats, rk, Wp, bias, out, order, stat_part, st);
     INTER_CASE(16, 16) INTER_CASE(16, 32) INTER_CASE(32, 32) INTER_CASE(32, 64) INTER_CASE(64, 64)
+    INTER_CASE(64, 128) INTER_CASE(128, 128) INTER_CASE(128, 256) INTER_CASE(256, 256)       // encoder depths 3 / 4 (models_pointcloud.py:34-48)
 #undef INTER_CASE
     if (cin == 1 && cout <= 64 && (!stat_part || (256 % cout == 0 && nn * NA >= 512))) {
         const size_t lds = ((size_t)4 * nn + (size_t)nn * NA + NA * KS + (size_t)cout * KS + nn) * sizeof(float);
@@ -706,7 +735,7 @@ int etch_intra_so3conv_stats(int b, int c, int cout, int p, const float* X, cons
     hipStream_t st = (hipStream_t)stream;
 #define INTRA_CASE(CI, CO) \
     if (c == CI && cout == CO) return launch_intra<CI, CO>(b * p, p, X, mean, rstd, intra_idx, Wp, bias, Y, stat_part, st);
-    INTRA_CASE(16, 16) INTRA_CASE(32, 32) INTRA_CASE(64, 64)
+    INTRA_CASE(16, 16) INTRA_CASE(32, 32) INTRA_CASE(64, 64) INTRA_CASE(128, 128) INTRA_CASE(256, 256)
 #undef INTRA_CASE
     return ETCH_EUNSUPPORTED;
 }

@@ -89,8 +89,8 @@ def main(argv=None):
     parser.add_argument("--num_point", type=int, default=5000)
     parser.add_argument("--scale_magnitude", type=int, default=10)
     parser.add_argument("--EPN_input_radius", type=float, default=0.4)
-    parser.add_argument("--EPN_layer_num", type=int, default=2, choices=[2],
-                        help="encoder depth; the reference accepts 1-4, this build instantiates the released configuration (2) only")
+    parser.add_argument("--EPN_layer_num", type=int, default=2, choices=[1, 2, 3, 4],
+                        help="encoder depth (models_pointcloud.py:34-48: feature widths 32 / 64 / 128 / 256); the release uses 2")
     parser.add_argument("--body_model", type=str, default="", help="chumpy-free SMPL .pkl (else the reference's gender paths)")
     parser.add_argument("--synthetic_body", action="store_true", help="use the seeded SMPL-shaped stand-in body model")
     parser.add_argument("--seed", type=int, default=0, help="surface-sampling seed (the reference is unseeded)")

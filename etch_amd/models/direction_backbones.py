@@ -49,13 +49,18 @@ class DotProdAttention(nn.Module):
 
 
 class MultiHeadAttention(nn.Module):
-    """direction_backbones.py:132-194.  forward(keys, queries, values) with keys is queries is values (self-attention
-    over the 60 anchor tokens, 8 heads of size 8): one fused kernel per layer (etch_mhsa_layer); the unfused QKV GEMM +
-    attention kernel + head_combine GEMM chain remains for value_dim != embedding_dim."""
+    """direction_backbones.py:132-194.  forward(keys, queries, values) with keys is queries is values (self-attention over the 60
+    anchor tokens, 8 heads of embedding_dim / 8).  The ETCH release (embedding 64 -> heads of 8) runs one fused kernel per layer
+    (etch_mhsa_layer); other widths (encoder depths 1 / 3 / 4: 32 / 128 / 256, models_pointcloud.py:34-48) and value_dim != embedding_dim
+    run the QKV GEMM + attention kernel + head_combine GEMM chain."""
+
+    SUPPORTED_DIMS = (32, 64, 128, 256)
 
     def __init__(self, embedding_dim, value_dim, num_heads):
         super().__init__()
-        assert embedding_dim == 64 and num_heads == 8, "kernel is specialised for the ETCH head (64 dims, 8 heads, 60 tokens)"
+        if num_heads != 8 or embedding_dim not in self.SUPPORTED_DIMS:
+            raise NotImplementedError(f"MultiHeadAttention: 8 heads over embedding_dim in {self.SUPPORTED_DIMS} are built (got {num_heads} heads, "
+                                      f"{embedding_dim} dims)")
         self.embedding_dim, self.num_heads, self.value_dim = embedding_dim, num_heads, value_dim
         self.head_size = embedding_dim // num_heads
         self.key_transform = BatchLinear(embedding_dim, embedding_dim, bias=False)
@@ -69,17 +74,26 @@ class MultiHeadAttention(nn.Module):
         ws = (self.query_transform.weight, self.key_transform.weight, self.value_transform.weight)
         return self._d.get(ws, lambda: torch.cat([w.detach() for w in ws], 0).contiguous())
 
+    def heads(self, x):
+        """x [T*60, E] -> the concatenated head outputs [T*60, E] (before head_combine)."""
+        E = self.embedding_dim
+        T = x.shape[0] // 60
+        if E == 64 and x.is_contiguous():
+            return ops.mhsa_layer(x, self.query_transform.weight.detach(), self.key_transform.weight.detach(), self.value_transform.weight.detach(),
+                                  mode=2)
+        qkv = ops.linear(x, self._wqkv())                               # [T*60, 3E] = q | k | v
+        return ops.mhsa_attention(qkv, T, 0, E, 2 * E, embedding_dim=E)
+
     def forward(self, keys, queries, values, residual=False):
         assert keys is queries and keys is values and keys.shape[1] == 60
         T = keys.shape[0]
         x = keys.reshape(T * 60, self.embedding_dim)
-        if self.value_dim == self.embedding_dim and x.is_contiguous():
+        if self.embedding_dim == 64 and self.value_dim == 64 and x.is_contiguous():
             # the whole layer in one kernel: q|k|v and the attention output never leave the chip
             y = ops.mhsa_layer(x, self.query_transform.weight.detach(), self.key_transform.weight.detach(), self.value_transform.weight.detach(),
                                self.head_combine.weight.detach(), self.head_combine.bias.detach(), mode=0 if residual else 1)
             return y.view(T, 60, self.value_dim)
-        qkv = ops.linear(x, self._wqkv())                               # [T*60, 192] = q | k | v
-        att = ops.mhsa_attention(qkv, T, 0, 64, 128)
+        att = self.heads(x)
         y = ops.linear(att, self.head_combine.weight.detach(), bias=self.head_combine.bias.detach(),
                        res=x if residual else None, res_mode=2 if residual else 0)
         return y.view(T, 60, self.value_dim)

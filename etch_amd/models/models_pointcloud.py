@@ -17,7 +17,7 @@ from .pointtransformer_seg import get_pointtransformer_confidence, get_pointtran
 from .so3net import build_model
 
 
-SUPPORTED_EPN_LAYER_NUMS = frozenset({2})
+SUPPORTED_EPN_LAYER_NUMS = frozenset({1, 2, 3, 4})       # models_pointcloud.py:34-48: feature widths 32 / 64 / 128 / 256
 
 
 class GT_network_equiv(nn.Module):
@@ -32,12 +32,7 @@ class GT_network_equiv(nn.Module):
         self.standard_vector = torch.tensor([0, 0, 1], dtype=torch.float32, requires_grad=False)
         EPN_layer_n = option.EPN_layer_num
         if EPN_layer_n not in SUPPORTED_EPN_LAYER_NUMS:
-            # the reference accepts 1..4 (models_pointcloud.py:34-48: feature widths 32 / 64 / 128 / 256); the HIP kernels are built for
-            # the released configuration only: conv channel pairs up to (64, 64), 64-wide 8-head attention over the 60 anchor tokens
-            raise NotImplementedError(
-                f"EPN_layer_num={EPN_layer_n} is not built: etch_amd instantiates the fused SO(3) convolutions and the attention head for "
-                f"EPN_layer_num in {sorted(SUPPORTED_EPN_LAYER_NUMS)} (the ETCH release and every published checkpoint use 2); "
-                "see INTEGRATION.md, 'Limits'")
+            raise ValueError(f"EPN_layer_num must be one of {sorted(SUPPORTED_EPN_LAYER_NUMS)} (models_pointcloud.py:34-48), got {EPN_layer_n}")
         EPN_feat_dim = mlp_layers[EPN_layer_n - 1][0]
         os.makedirs(option.output_folder, exist_ok=True)
         self.encoder = build_model(EPN_cfg, mlps=mlp_layers[:EPN_layer_n], strides=strides_layers[:EPN_layer_n], to_file=model_setting_file)
@@ -132,8 +127,7 @@ class GT_network_equiv(nn.Module):
             x = layer(x, x, x, residual=True)
         last = layers[-1]
         Wf, bf, v, c, Wfp = self._folded()
-        att = ops.mhsa_layer(x.reshape(T * 60, last.embedding_dim), last.query_transform.weight.detach(), last.key_transform.weight.detach(),
-                             last.value_transform.weight.detach(), mode=2)            # concatenated heads; head_combine is folded into Wf
+        att = last.heads(x.reshape(T * 60, last.embedding_dim))                       # concatenated heads; head_combine is folded into Wf
         # relu(att Wf^T + bf) . v + c in one kernel: the (T*60, 128) hidden layer stays on chip
         return ops.linear_relu_dot(att, Wf, bf, v, c, 1, wp=Wfp).view(T, 60)
 

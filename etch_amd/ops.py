@@ -154,13 +154,15 @@ def permute_weight_frag(w2):
 
 def inter_weight_frag(W, cin, ks=24):
     """Fragment-ordered weight of the fused inter conv: the columns of W [cout, cin*ks] are first brought into the kernel's
-    contraction order (csrc/so3conv.hip: a lane gathers VEC = cin/16 consecutive channels per load, so column r of c-tile mi is channel
-    VEC*r + mi and sits at position 16*mi + r of its half; halves h of the X1 tile hold the tiles [h*MTH, (h+1)*MTH)), then permuted into
-    MFMA fragment order."""
-    vec = cin // 16
-    halves = 2 if cin >= 32 else 1
+    contraction order (csrc/so3conv.hip: channels are processed in passes of CCH = min(cin, 64); within a pass a lane gathers
+    VEC = CCH/16 consecutive channels per load, so column r of c-tile mi is channel VEC*r + mi and sits at position 16*mi + r of its
+    half; halves h of the X1 tile hold the tiles [h*MTH, (h+1)*MTH)), then permuted into MFMA fragment order."""
+    cch = min(cin, 64)
+    vec = cch // 16
+    halves = 2 if cch >= 32 else 1
     mth = vec // halves
-    order = [vec * (cc % 16) + h * mth + cc // 16 for h in range(halves) for cc in range(cin // halves)]
+    one = [vec * (cc % 16) + h * mth + cc // 16 for h in range(halves) for cc in range(cch // halves)]
+    order = [p * cch + c for p in range(cin // cch) for c in one]
     assert sorted(order) == list(range(cin))
     cols = torch.tensor([c * ks + k for c in order for k in range(ks)], dtype=torch.long, device=W.device)
     return permute_weight_frag(W[:, cols].contiguous())
@@ -211,7 +213,7 @@ def intra_so3conv(x_cl, intra_idx32, Wp, bias, cout, mean=None, rstd=None, want_
     b, p, na, c = x_cl.shape
     _need(x_cl, torch.float32, "x"), _need(intra_idx32, torch.int32, "intra_idx"), _need(Wp, torch.float32, "Wp")
     out = torch.empty((b, p, 60, cout), dtype=torch.float32, device=x_cl.device)
-    fused = want_stats and p % 2 == 0
+    fused = want_stats and p % 2 == 0 and c <= 64        # wider tiles (encoder depths 3 / 4) take the separate statistics pass
     part = torch.empty((b * (p // 2), 2, cout), dtype=torch.float32, device=x_cl.device) if fused else None
     _lib.check(_lib.lib().etch_intra_so3conv_stats(b, c, cout, p, _ptr(x_cl), _optptr(mean), _optptr(rstd), _ptr(intra_idx32), _ptr(Wp),
                                                    _ptr(bias), _ptr(out), _optptr(part), _stream()), "etch_intra_so3conv")
@@ -272,12 +274,13 @@ def prop_interp(feats_cl, idx, w, order=None):
     return out, inv
 
 
-def mhsa_attention(qkv, T, qoff, koff, voff):
-    """qkv [T*60, ld] -> [T*60, 64]."""
+def mhsa_attention(qkv, T, qoff, koff, voff, embedding_dim=64):
+    """qkv [T*60, ld] -> [T*60, embedding_dim]: 8-head attention over each point's 60 tokens (heads of embedding_dim / 8)."""
     _need(qkv, torch.float32, "qkv")
-    out = torch.empty((T * 60, 64), dtype=torch.float32, device=qkv.device)
-    _lib.check(_lib.lib().etch_mhsa_attention(_c_long(T), _ptr(qkv), _c_long(qkv.stride(0)), qoff, koff, voff, _ptr(out), _c_long(64), _stream()),
-               "etch_mhsa_attention")
+    E = int(embedding_dim)
+    out = torch.empty((T * 60, E), dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.lib().etch_mhsa_attention_dim(_c_long(T), E, _ptr(qkv), _c_long(qkv.stride(0)), qoff, koff, voff, _ptr(out), _c_long(E), _stream()),
+               "etch_mhsa_attention_dim")
     return out
 
 

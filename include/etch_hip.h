@@ -166,6 +166,10 @@ int etch_prop_interp_ordered(int B, int N, int S, int A, int C, const float* fea
 /* DotProdAttention of MultiHeadAttention (src/models/direction_backbones.py:102-129,160-194) for 60 tokens,
  * 8 heads x 8 dims: rows [T*60][ld] hold q/k/v at column offsets qoff/koff/voff -> out rows [T*60][ldo] (64 cols). */
 int etch_mhsa_attention(long T, const float* qkv, long ld, int qoff, int koff, int voff, float* out, long ldo, void* stream);
+/* The same attention core for the other encoder depths (models_pointcloud.py:34-48: embedding_dim 32 / 64 / 128 / 256 -> 8 heads of
+ * 4 / 8 / 16 / 32, direction_backbones.py:151; logits / sqrt(head size), :125).  out (T*60, ldo) = concatenated heads. */
+int etch_mhsa_attention_dim(long T, int embedding_dim, const float* qkv, long ld, int qoff, int koff, int voff, float* out, long ldo,
+                            void* stream);
 
 /* One whole MultiHeadAttention layer (direction_backbones.py:132-194; 64 dims, 8 heads x 8, 60 tokens per point) in a single
  * kernel: q/k/v transforms (no bias, weights (64,64) row-major as in key/query/value_transform.weight) -> per-head softmax

@@ -251,10 +251,10 @@ def gen_model20k(model):
     _save_model_run("model_n20000.npz", x, out, anc_w, 16)
 
 
-def _run_ref_fp64(model, ms, x):
+def _run_ref_fp64(model, ms, x, layers=2):
     """The reference's Python with every parameter, buffer and activation in fp64 (direction head only) -> anc_w [B,N,60] fp64."""
     B, N = x.shape[:2]
-    m64 = R.build_reference_model(tempfile.mkdtemp(), ms).double()
+    m64 = R.build_reference_model(tempfile.mkdtemp(), ms, layers=layers).double()
     sd = {k: (v.double() if v.is_floating_point() else v) for k, v in seeded_state_dict(model, 1).items()}
     m64.load_state_dict(sd)
     m64.standard_vector = m64.standard_vector.double()          # plain attribute, not a buffer (models_pointcloud.py:64)
@@ -291,6 +291,31 @@ def gen_padding_fp64(model, ms):
           (float(dev32.max()), float(dev32.flatten().quantile(0.999)), float(dev32.median())))
 
 
+def gen_model_depth(ms, layers, n, b=2):
+    """The other encoder depths the reference builds (models_pointcloud.py:34-48: EPN_layer_num 1 / 3 / 4 -> feature widths 32 / 128 / 256,
+    8-head attention over 32 / 128 / 256 dims, Point-Transformer inputs of 35 / 131 / 259 channels): b synthetic n-point scans (bench seeds
+    1000 + i) through the reference's own Python with seeded weights; the direction head's anchor weights also in fp64 (conditioning
+    yardstick, see gen_padding_fp64).  Emits model_l<layers>_n<n>.npz and the state-dict manifest of that depth."""
+    model = R.build_reference_model(tempfile.mkdtemp(), ms, layers=layers)
+    x = torch.from_numpy(np.stack([scan(1000 + i, n) for i in range(b)]))
+    out, anc_w = _run_ref(model, x)
+    w64 = _run_ref_fp64(model, ms, x, layers=layers)
+    scale = float(w64.abs().max())
+    dev32 = ((anc_w.double() - w64).abs().amax(-1) / scale).float()
+    print("depth %d: reference fp32 vs fp64 anc_w deviation  max %.3e  99.9%% %.3e" % (layers, float(dev32.max()), float(dev32.flatten().quantile(0.999))))
+    sub = 2
+    rows = np.arange(0, n, sub)
+    _save_model_run(f"model_l{layers}_n{n}.npz", x, out, anc_w, sub, layers=layers, anc_w_fp64=w64[:, rows].float(), ref_fp32_dev=dev32[:, rows],
+                    anc_w_scale=scale)
+    manifest = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in model.state_dict().items()]
+    with open(os.path.join(OUT, f"state_dict_manifest_l{layers}.json"), "w") as f:
+        json.dump(manifest, f)
+    with open(os.path.join(model.option.output_folder, "EPN_model_setting_json")) as f:
+        table = json.load(f)
+    with open(os.path.join(OUT, f"epn_model_setting_l{layers}.json"), "w") as f:
+        json.dump(table, f, indent=1)
+
+
 def gen_rodrigues():
     """batch_rodrigues as the tree holds it (src/data_utils/GT_dataloader_mixed.py:29-64, the verbatim copy of
     smplx.lbs.batch_rodrigues): the function is compiled FROM THE REFERENCE FILE at run time (its module imports packages
@@ -325,7 +350,8 @@ def main():
     steps = {"constants": lambda: gen_constants(model, ms), "so3block": gen_so3_block, "direction": lambda: gen_direction(model),
              "propagation": gen_propagation, "pt": gen_pt, "markers": lambda: gen_markers(ms), "model": lambda: gen_model(model), "scan4d": lambda: gen_scan4d(model),
              "model5k": lambda: gen_model5k(model, ms), "model20k": lambda: gen_model20k(model), "padding_fp64": lambda: gen_padding_fp64(model, ms),
-             "rodrigues": gen_rodrigues}
+             "rodrigues": gen_rodrigues, "depth1": lambda: gen_model_depth(ms, 1, 1024), "depth3": lambda: gen_model_depth(ms, 3, 1024),
+             "depth4": lambda: gen_model_depth(ms, 4, 512)}
     for name, fn in steps.items():
         if not only or name in only:
             fn()

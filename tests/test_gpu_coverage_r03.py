@@ -28,11 +28,11 @@ def scan(seed, n, sigma=(0.14, 0.31, 0.085)):
     return (np.random.default_rng(seed).standard_normal((n, 3)) * np.array(sigma)).astype(np.float32)
 
 
-def make(tmp_path, seed=1, body=None):
+def make(tmp_path, seed=1, body=None, layers=2):
     from etch_amd import constants as K
     from etch_amd.models.models_pointcloud import GT_network_equiv
     from etch_amd.utils.body_model import SyntheticSMPL
-    args = types.SimpleNamespace(output_folder=str(tmp_path), EPN_input_radius=0.4, EPN_layer_num=2, device=torch.device("cuda"),
+    args = types.SimpleNamespace(output_folder=str(tmp_path), EPN_input_radius=0.4, EPN_layer_num=layers, device=torch.device("cuda"),
                                  markerset=K.default_markerset(), scale_magnitude=10, body_model=body or SyntheticSMPL(7))
     return args, load_seeded(GT_network_equiv(option=args), seed).cuda().eval()
 
@@ -106,30 +106,42 @@ def test_config4_full_size_shard_8x20000_with_188dof_fit(tmp_path, golden):
     assert np.array_equal(full[:, :pre[0] + 1 + pre[1] + 1], gt)
 
 
-def test_well_posed_188dof_fit_across_the_stage_handover_vs_oracle():
-    """The 188-DoF fit on WELL-POSED markers (all 86, 2 mm noise) over 75 + 10 iterations -- every stage-0 iteration and the
-    hand-over to the 20-coefficient stage -- against the oracle's autograd LM (r02 compared 8 + 10)."""
-    from test_gpu_stage2 import _problem
-    from etch_amd.models.fit_SMPL import fit_smpl
-    from oracle import stage2 as S2
-    B, it0, it1 = 2, 75, 10
-    bm, ms, mv, tgt, valid, vgt = _problem(B, seed=6, model="smplx")
-    trace = []
-    ref = S2.fit_smpl(bm, mv, tgt, valid, steps_stage0=it0, steps_stage1=it1, trace=trace)
-    labels = torch.arange(86).repeat(B, 1)
-    for b in range(B):
-        labels[b, (~valid[b]).nonzero().flatten()] = int(valid[b].nonzero()[0])
-    conf = torch.ones(B, 86, 1)
-    conf[~valid] = 1e-3
-    args = types.SimpleNamespace(markerset=ms, device=torch.device("cuda"), body_model=bm)
-    _, _, _, info, aux = fit_smpl(args, tgt.clone().cuda(), labels.cuda(), conf.cuda(), "neutral", steps_stage0=it0, steps_stage1=it1, return_trace=True)
-    rt, gt = oracle_trace(trace, it0, it1), aux["err_trace"].cpu().numpy()
-    assert np.abs(gt - rt).max() / rt.max() < 1e-4
-    assert np.abs(aux["verts"].cpu().numpy() - ref["verts"].numpy()).max() < 1e-4
-    xr = torch.cat([ref["pose"], ref["betas"], ref["orient"], ref["transl"]], 1).numpy()
-    d = np.abs(aux["x"].cpu().numpy() - xr)
-    print("188-DoF 75+10 well-posed parameter deviation vs oracle:", float(d.max()))
-    assert d.max() < 1e-4
+def test_well_posed_188dof_fit_across_the_stage_handover_vs_oracle(golden):
+    """The 188-DoF fit on WELL-POSED markers (86 minus a few masked, 2 mm noise) over 75 + 10 iterations -- every stage-0 iteration of
+    configs[4]'s schedule and the hand-over to the 20-coefficient stage (r02 compared 8 + 10) -- against the committed oracle runs of
+    tests/golden/fit_smplx_handover.npz (oracle/gen_fit_smplx_fixture.py; the oracle differentiates the full 10 475-vertex mesh: 2.5 min
+    of CPU, hence a fixture).  30 finger joints are seen by few markers: the oracle's own fp32 and fp64 runs differ by 3.5e-4 in those
+    pose parameters, so raw parameters are held to the fp64-yardstick rule (as close to the fp64 run as the fp32 oracle, x2); error trace,
+    vertices and joints (well conditioned) to 1e-4."""
+    from etch_amd import constants as K
+    from etch_amd import ops
+    from etch_amd.models.fit_SMPL import _device_body
+    from etch_amd.utils.body_model import SyntheticSMPLX
+    g = golden("fit_smplx_handover.npz")
+    it0, it1 = (int(v) for v in g["iters"])
+    bm = SyntheticSMPLX(7)
+    mv = np.array(list(K.default_markerset().values()))
+    db = _device_body(bm, mv, torch.device("cuda"))
+    x, x0, tr = ops.smpl_lm_fit(db.lm_consts, torch.from_numpy(g["markers"]).cuda(), torch.from_numpy(g["valid"].astype(np.float32)).cuda(),
+                                it0, 0.5, 0.01, it1, 0.2, 1e-3, True, nj=db.nj, nb=db.nb)
+    verts, joints = ops.smpl_lbs(db.lbs_consts, x, db.V, db.n_extra, nj=db.nj, nb=db.nb)
+    t64 = g["trace_fp64"]
+    assert tr.shape == t64.shape == (2, it0 + it1 + 2)
+    assert np.abs(tr.cpu().numpy() - t64).max() / t64.max() < 1e-4
+    assert np.abs(tr.cpu().numpy() - g["trace_fp32"]).max() / t64.max() < 1e-4
+    assert t64[:, it0].max() < 0.05 * t64[:, 0].min()                              # stage 0 did descend before the hand-over
+    x, x64, x32 = x.cpu().numpy().astype(np.float64), g["x_fp64"], g["x_fp32"].astype(np.float64)
+    report = {}
+    for name, sl in (("pose", slice(0, 162)), ("betas", slice(162, 182)), ("orient", slice(182, 185)), ("transl", slice(185, 188))):
+        gpu, ref = float(np.abs(x[:, sl] - x64[:, sl]).max()), float(np.abs(x32[:, sl] - x64[:, sl]).max())
+        report[name] = "%.1e / %.1e" % (gpu, ref)
+        assert gpu <= max(2.0 * ref, 1e-4), (name, gpu, ref)
+    print("188-DoF 75+10: |x - x_fp64| per group (gpu / oracle fp32):", report)
+    v64 = g["verts_fp64"]
+    assert np.abs(verts.cpu().numpy()[:, ::10] - v64).max() < 1e-4
+    assert np.abs(joints.cpu().numpy() - g["joints_fp64"]).max() < 1e-4
+    d0 = np.abs(x0.cpu().numpy()[:, :162] - g["x_stage0_fp64"][:, :162]).max()
+    assert d0 <= max(2.0 * np.abs(g["x_stage0_fp32"] - g["x_stage0_fp64"])[:, :162].max(), 1e-4), d0
 
 
 def test_checkpoint_supplied_anchor_buffers_are_honoured(tmp_path, golden):
@@ -225,3 +237,25 @@ def test_rccl_world_size_1_collective_path():
     env["MASTER_PORT"] = "29548"
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rccl ok" in r.stdout, r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("layers,n", [(1, 1024), (3, 1024), (4, 512)])
+def test_encoder_depths_1_3_4_vs_reference(tmp_path, golden, layers, n):
+    """EPN_layer_num 1 / 3 / 4 (models_pointcloud.py:34-48: feature widths 32 / 128 / 256; 8-head attention over 32 / 128 / 256 dims; conv
+    channel pairs up to (256, 256)) against the reference's own Python run of that depth (tests/golden/model_l<d>_n<n>.npz), same 1e-4 bar
+    and fp64 conditioning yardstick as the released depth; then the whole pipeline on that model."""
+    from etch_amd.inference_demo import predict_smpl_batch
+    g, c = golden(f"model_l{layers}_n{n}.npz"), golden("constants.npz")
+    args, model = make(tmp_path, int(g["seed"]), layers=layers)
+    manifest = json.load(open(os.path.join(ROOT, "tests", "golden", f"state_dict_manifest_l{layers}.json")))
+    assert [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in model.state_dict().items()] == manifest
+    pts = torch.from_numpy(g["points"]).cuda()
+    with torch.no_grad():
+        res, sel = model(pts, ITEMS, "standard_vector")
+        anc_w = model.last_anc_w.clone()
+        print(f"depth {layers} deviations:", check_stage1_vs_fixture(res, anc_w, g, c["anchors"]))
+        solo, _ = model(pts[:1].contiguous(), ITEMS, "standard_vector")
+    for k in res:
+        assert torch.equal(solo[k][0], res[k][0]), k
+    meshes, markers, valid, info = predict_smpl_batch(args, model, pts, "neutral", steps_stage0=5, steps_stage1=5)
+    assert len(meshes) == pts.shape[0] and markers.shape == (pts.shape[0], 86, 3)

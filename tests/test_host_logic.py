@@ -150,9 +150,10 @@ def test_reference_operator_names_are_exported():
     assert kp.shape == (24, 3) and abs(float(np.sqrt((kp ** 2).sum(1).max())) - 0.14) < 1e-6
 
 
-def test_unsupported_encoder_depth_is_rejected_up_front(tmp_path):
-    """The reference builds EPN_layer_num 1..4 (models_pointcloud.py:34-48); this build instantiates depth 2 (the released
-    configuration).  Other depths must fail at construction with a message that says so -- not with a bare assert deep inside."""
+def test_every_encoder_depth_constructs_with_the_reference_state_dict(tmp_path):
+    """The reference builds EPN_layer_num 1..4 (models_pointcloud.py:34-48: feature widths 32 / 64 / 128 / 256); so does this build: same
+    state-dict keys / shapes / dtypes as the reference's constructor emitted (tests/golden/state_dict_manifest*.json) and the same
+    EPN_model_setting_json dump per depth.  Anything else is rejected at construction; the CLI takes 1-4."""
     import types
 
     import pytest
@@ -160,12 +161,21 @@ def test_unsupported_encoder_depth_is_rejected_up_front(tmp_path):
     from etch_amd import constants as K
     from etch_amd import inference_demo as D
     from etch_amd.models.models_pointcloud import GT_network_equiv
-    for n in (1, 3, 4):
+    for n in (1, 2, 3, 4):
+        out = tmp_path / f"l{n}"
+        opt = types.SimpleNamespace(output_folder=str(out), EPN_input_radius=0.4, EPN_layer_num=n, device="cpu", markerset=K.default_markerset())
+        m = GT_network_equiv(option=opt)
+        mine = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()]
+        tag = "" if n == 2 else f"_l{n}"
+        assert mine == json.load(open(os.path.join(GOLDEN, f"state_dict_manifest{tag}.json"))), n
+        dump = json.load(open(out / "EPN_model_setting_json"))
+        assert json.dumps(dump) == json.dumps(json.load(open(os.path.join(GOLDEN, f"epn_model_setting{tag}.json")))), n
+    for n in (0, 5):
         opt = types.SimpleNamespace(output_folder=str(tmp_path), EPN_input_radius=0.4, EPN_layer_num=n, device="cpu", markerset=K.default_markerset())
-        with pytest.raises(NotImplementedError, match="EPN_layer_num"):
+        with pytest.raises(ValueError, match="EPN_layer_num"):
             GT_network_equiv(option=opt)
     with pytest.raises(SystemExit):
-        D.main(["--scan_path", "x.obj", "--EPN_layer_num", "3"])
+        D.main(["--scan_path", "x.obj", "--EPN_layer_num", "5"])
 
 
 def _write_obj(path, v, f):

@@ -209,3 +209,52 @@ def test_whole_model_bundled_4ddress_scan_5k(golden):
         scale = np.abs(g[k]).max()
         assert np.abs(got - g[k]).max() <= 1e-5 * max(scale, 1.0), k
     assert (out["part_labels"].argmax(-1).numpy() == g["labels"]).mean() > 0.9995
+
+
+DEPTH_MLPS = [[32, 32], [64, 64], [128, 128], [256, 256]]
+
+
+def depth_state_dict(layers, seed, consts):
+    """State dict of an EPN_layer_num = `layers` model from ITS manifest (emitted by the reference's own constructor) + seed + constants;
+    the kernel-point buffers of the deeper blocks follow functional.py:146-157 on the golden's raw kpsphere24 points."""
+    table = S.build_layer_table(mlps=DEPTH_MLPS[:layers], strides=[2] * layers)
+    kp = consts["kp24_raw"]
+    r = np.sqrt((kp ** 2).sum(1).max())
+    sd = {}
+    for name, shape, dt in json.load(open(os.path.join(GOLDEN, f"state_dict_manifest_l{layers}.json"))):
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf == "anchors":
+            sd[name] = torch.from_numpy(consts["anchors"])
+        elif leaf == "intra_idx":
+            sd[name] = torch.from_numpy(consts["intra_idx"])
+        elif leaf == "kernels":
+            b, c = int(name.split(".")[2]), int(name.split(".")[4])
+            sd[name] = torch.from_numpy((kp * (0.7 * table[b][c]["radius"]) / r).astype(np.float32))
+        elif leaf == "num_batches_tracked":
+            sd[name] = torch.zeros((), dtype=torch.int64)
+        else:
+            sd[name] = seeded_tensor(name, shape, getattr(torch, dt), seed)
+    return sd, table
+
+
+@pytest.mark.parametrize("layers,n", [(1, 1024), (3, 1024), (4, 512)])
+def test_whole_model_other_encoder_depths(golden, layers, n):
+    """EPN_layer_num 1 / 3 / 4 (models_pointcloud.py:34-48: feature widths 32 / 128 / 256): the oracle's restatement with the depth's layer
+    table against the reference's own Python run of that depth (tests/golden/model_l<d>_n<n>.npz, gen_golden.gen_model_depth)."""
+    g, c = golden(f"model_l{layers}_n{n}.npz"), golden("constants.npz")
+    assert int(g["layers"]) == layers
+    ref_table = json.load(open(os.path.join(GOLDEN, f"epn_model_setting_l{layers}.json")))
+    sd, table = depth_state_dict(layers, int(g["seed"]), c)
+    for bi, block in enumerate(ref_table["backbone"]):
+        for ci, conv in enumerate(block):
+            for k, v in table[bi][ci].items():
+                assert conv["args"][k] == v, (bi, ci, k)
+    assert sd[f"encoder.backbone.{layers - 1}.blocks.1.inter_conv.conv.basic_conv.W"].shape[0] == DEPTH_MLPS[layers - 1][0]
+    out = S.forward(sd, torch.from_numpy(g["points"]), table, return_aux=True)
+    rows = g["rows"]
+    for k, sub in (("part_labels", True), ("confidences", False), ("magnitude", False), ("anc_w", True)):
+        got = out[k].numpy()
+        got = got[:, rows] if sub else got
+        scale = np.abs(g[k]).max()
+        assert np.abs(got - g[k]).max() <= 1e-5 * max(scale, 1.0), k
+    assert np.array_equal(out["part_labels"].argmax(-1).numpy(), g["labels"])
