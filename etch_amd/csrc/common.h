@@ -12,6 +12,18 @@
     } while (0)
 
 // status codes returned by every C-ABI entry point (0 = ok, >0 = hipError_t, <0 = argument error)
+// compute units of the current device, queried once (256 on MI355X; partitioned or smaller parts report fewer): persistent kernels size
+// their grids from it instead of assuming 256
+static inline int etch_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        cus = n;
+    }
+    return cus;
+}
+
 #define ETCH_OK 0
 #define ETCH_EINVAL (-1)
 #define ETCH_EUNSUPPORTED (-2)

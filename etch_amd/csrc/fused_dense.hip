@@ -131,13 +131,19 @@ static int launch_lrd(long R, int G, const float* X, long ldx, const float* W, l
     const size_t lds = ((size_t)FD_ROWS * (K + FD_PAD) + 2 * 8 * FD_ROWS) * sizeof(float);
     const long ntiles = (R + FD_ROWS - 1) / FD_ROWS;
     auto go = [&](auto kern, const float* Wk, long ldk) -> int {
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
+        // per kernel instantiation, once per process (never inside a HIP-graph capture: the first call of a shape happens in the warm-up
+        // passes): the dynamic-LDS attribute, the resident workgroups per CU and the CU count of the current device
+        static int blocks_resident = 0;
+        if (blocks_resident == 0) {
+            if (lds > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return (int)e;
+            }
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 512, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+            blocks_resident = etch_cu_count() * per_cu;
         }
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 512, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-        long blocks = 256L * per_cu;             // persistent: every resident workgroup walks the tiles with this stride
+        long blocks = blocks_resident;           // persistent: every resident workgroup walks the tiles with this stride
         if (blocks > ntiles) blocks = ntiles;
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, st, R, G, X, ldx, Wk, ldk, b1, w2, b2, out, ldo);
         return ETCH_OK;

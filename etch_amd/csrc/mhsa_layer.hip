@@ -429,7 +429,7 @@ static int launch_layer(long T, const float* X, const float* Wq, const float* Wk
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)kern, 256, 0) != hipSuccess || n < 1) n = 2;
         per_cu = n;
     }
-    long blocks = 256L * per_cu;
+    long blocks = (long)etch_cu_count() * per_cu;
     if (blocks > T) blocks = T;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, T, X, Wq, Wk, Wv, Wc, bc, out);
     ETCH_RETURN_IF_LAUNCH_FAILED();
@@ -465,7 +465,7 @@ extern "C" int etch_mhsa_interp_layer(int B, int N, int S, const float* F, const
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(interp_schedule_kernel, dim3((unsigned)(((long)B * N + 255) / 256)), dim3(256), 0, st, B, N, S, idx, weight, order,
                        reinterpret_cast<int4*>(sched));
-    hipLaunchKernelGGL(mhsa_interp_layer_kernel, dim3(256u * per_cu), dim3(256), 0, st, B, N, S, F, sched, Wq, Wk, Wv, Wc, bc, out);
+    hipLaunchKernelGGL(mhsa_interp_layer_kernel, dim3((unsigned)(((etch_cu_count() + 7) / 8) * 8 * per_cu)), dim3(256), 0, st, B, N, S, F, sched, Wq, Wk, Wv, Wc, bc, out);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }

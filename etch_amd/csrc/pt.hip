@@ -817,7 +817,7 @@ static int launch_pt_mfma(const PtAttnParams& a, const float* W2, hipStream_t st
         per_cu = nb > 8 ? 8 : nb;
     }
     const long ntiles = ((long)a.n + 4 * PPW - 1) / (4 * PPW);
-    long blocks = 256L * per_cu;
+    long blocks = (long)etch_cu_count() * per_cu;
     if (blocks > ntiles) blocks = ntiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, a, W2, ntiles);
     ETCH_RETURN_IF_LAUNCH_FAILED();

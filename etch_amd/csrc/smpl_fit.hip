@@ -936,6 +936,10 @@ __global__ void __launch_bounds__(BM::THREADS) smpl_lm_fit_kernel(SmplConsts C, 
 // marker-restricted linearisation as the LM fit (last tile row of the matrix-core accumulation) instead of autograd through the
 // full mesh.  x_last = parameters of the LAST forward pass, i.e. before the final optimizer step: the reference builds its output
 // meshes from that forward (:221-225).
+// Deliberate divergence: the reference's loss is ONE mean over the batch, so a scan whose valid marker is NaN (conf**20 underflow, flagged by
+// etch_marker_status) turns the loss -- and through Adam's moments every scan's parameters -- into NaN.  Here the scans only share the
+// factor 1 / n_valid_total; a NaN stays in its own scan (its status word says so) and the others are fitted as if it were absent from the
+// gradient but present in n.  Finite inputs give the reference's numbers.
 template <class BM>
 __global__ void __launch_bounds__(BM::THREADS) smpl_adam_fit_kernel(SmplConsts C, int M, int B, const float* __restrict__ markers,
                                                                   const float* __restrict__ valid, int it0, int it1, float lr, float beta1,
@@ -966,7 +970,9 @@ __global__ void __launch_bounds__(BM::THREADS) smpl_adam_fit_kernel(SmplConsts C
         __syncthreads();
         double b1t = 1.0, b2t = 1.0;
         for (int it = 0; it < iters; ++it) {
-            if (stage == 1 && it == iters - 1 && x_last)
+            // the parameters of the LAST forward pass of the whole schedule: the last stage-1 iteration, or -- when stage 1 is empty --
+            // the last stage-0 iteration (the reference's `verts` then still hold that forward, fit_SMPL_Adam.py:221-225)
+            if (x_last && it == iters - 1 && (stage == 1 || it1 == 0))
                 for (int i = tid; i < DOF; i += BM::THREADS) x_last[(size_t)b * DOF + i] = (float)s.x[i];
             lm_linearize(s, C, M, nb, nullptr, true);
             if (loss_trace && tid == 0) loss_trace[(size_t)b * (it0 + it1) + trace_pos] = (float)(2.0 * s.err * ninv);   // this scan's share of L
@@ -982,7 +988,7 @@ __global__ void __launch_bounds__(BM::THREADS) smpl_adam_fit_kernel(SmplConsts C
             __syncthreads();
         }
     }
-    if (it1 == 0 && x_last)
+    if (it0 == 0 && it1 == 0 && x_last)
         for (int i = tid; i < DOF; i += BM::THREADS) x_last[(size_t)b * DOF + i] = (float)s.x[i];
     for (int i = tid; i < DOF; i += BM::THREADS) x_out[(size_t)b * DOF + i] = (float)s.x[i];
 }

@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
     int p1, int p2, int nn, float inv_sigma, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
     const int* __restrict__ ball_idx, const float* __restrict__ feats, const float* __restrict__ rk,
     const float* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ out, const int* __restrict__ order,
-    float* __restrict__ stat_part) {
+    double* __restrict__ stat_part) {
     // CIN > 64 (encoder depths 3 / 4: 128 / 256 channels): the input channels are processed in NCC passes of CCH = 64 channels -- step 1
     // on that slice of the gathered rows (kernel weights regenerated per pass: 5 VALU ops against 2 * MT1 MFMAs), step 2 accumulating
     // Y over the slice's part of the contraction; registers and LDS stay those of the 64-channel kernel.  NCC = 1: the code below folds
@@ -123,8 +123,10 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
     for (int c = 0; c < PD; ++c) issue(0, c, ring[c % NRING]);
 
     // InstanceNorm statistics of the output, fused: this thread's output channel is fixed (256 % COUT == 0), so it keeps the sum
-    // and the sum of squares of everything it writes; reduced per workgroup at the end (stat_part [b][p2][2][COUT])
-    float st_s = 0.f, st_q = 0.f;
+    // and the sum of squares of everything it writes; reduced per workgroup at the end (stat_part [b][p2][2][COUT]).  In fp64: squares
+    // formed in fp32 lose (mean/std)^2 * 6e-8 of the variance to rounding when a channel's mean dominates its spread (32 fp64 ops per
+    // thread and point against ~10^4 matrix-core cycles)
+    double st_s = 0.0, st_q = 0.0;
     f32x4 y[MT2];
 #pragma unroll 1
     for (int it = 0; it < 4 * NCC; ++it) {
@@ -244,7 +246,7 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
                 v += part[(2 * 16 + col) * PS + o] + part[(3 * 16 + col) * PS + o];
                 v += bias[o];
                 outp[(size_t)a * COUT + o] = v;
-                st_s += v; st_q += v * v;
+                st_s += (double)v; st_q += (double)v * (double)v;
             }
         }
         // next group's X1s / partial writes are ordered behind the barriers above
@@ -252,13 +254,14 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
     if (stat_part) {
         static_assert(256 % COUT == 0, "a thread must keep one output channel");
         __syncthreads();                                    // the partial tile is free again
-        part[tid] = st_s; part[256 + tid] = st_q;
+        double* dred = reinterpret_cast<double*>(part);      // 512 doubles <= 4 * 16 * PS floats
+        dred[tid] = st_s; dred[256 + tid] = st_q;
         __syncthreads();
         if (tid < COUT) {
-            float a0 = 0.f, a1 = 0.f;
+            double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-            for (int k = 0; k < 256 / COUT; ++k) { a0 += part[k * COUT + tid]; a1 += part[256 + k * COUT + tid]; }
-            float* sp = stat_part + ((size_t)b * p2 + p) * 2 * COUT;
+            for (int k = 0; k < 256 / COUT; ++k) { a0 += dred[k * COUT + tid]; a1 += dred[256 + k * COUT + tid]; }
+            double* sp = stat_part + ((size_t)b * p2 + p) * 2 * COUT;
             sp[tid] = a0; sp[COUT + tid] = a1;
         }
     }
@@ -336,7 +339,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __global__ void __launch_bounds__(256) inter_so3conv_c1_kernel(
     int cout, int p1, int p2, int nn, float inv_sigma, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
     const int* __restrict__ ball_idx, const float* __restrict__ feats, const float* __restrict__ rk, const float* __restrict__ W,
-    const float* __restrict__ bias, float* __restrict__ out, float* __restrict__ stat_part) {
+    const float* __restrict__ bias, float* __restrict__ out, double* __restrict__ stat_part) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float4* GA = reinterpret_cast<float4*>(smem);          // [nn]  (2/sigma * g, 1 - |g|^2/sigma)
     float* Fn = smem + 4 * nn;                              // [nn][NA]
@@ -385,7 +388,7 @@ __global__ void __launch_bounds__(256) inter_so3conv_c1_kernel(
     }
     __syncthreads();
     float* outp = out + ((size_t)b * p2 + p) * NA * cout;
-    float st_s = 0.f, st_q = 0.f;                           // fused InstanceNorm statistics (needs 256 % cout == 0: fixed channel per thread)
+    double st_s = 0.0, st_q = 0.0;                          // fused InstanceNorm statistics in fp64 (needs 256 % cout == 0: fixed channel per thread)
     for (int e = tid; e < NA * cout; e += 256) {
         const int a = e / cout, o = e - a * cout;
         float acc = 0.f;
@@ -393,17 +396,17 @@ __global__ void __launch_bounds__(256) inter_so3conv_c1_kernel(
         for (int i = 0; i < KS; ++i) acc = fmaf(Ws[o * KS + i], X1[a * KS + i], acc);
         acc += bias[o];
         outp[e] = acc;
-        st_s += acc; st_q += acc * acc;
+        st_s += (double)acc; st_q += (double)acc * (double)acc;
     }
     if (stat_part) {
         __syncthreads();
-        float* red = Fn;                                    // >= 512 floats (nn * 60), no longer needed
+        double* red = reinterpret_cast<double*>(smem + ((4 * nn + 1) & ~1));   // the gathered-feature tile (>= 1024 floats: nn * 60), no longer needed
         red[tid] = st_s; red[256 + tid] = st_q;
         __syncthreads();
         if (tid < cout) {
-            float a0 = 0.f, a1 = 0.f;
+            double a0 = 0.0, a1 = 0.0;
             for (int k = 0; k < 256 / cout; ++k) { a0 += red[k * cout + tid]; a1 += red[256 + k * cout + tid]; }
-            float* sp = stat_part + ((size_t)b * p2 + p) * 2 * cout;
+            double* sp = stat_part + ((size_t)b * p2 + p) * 2 * cout;
             sp[tid] = a0; sp[cout + tid] = a1;
         }
     }
@@ -420,7 +423,7 @@ __global__ void __launch_bounds__(256) intra_so3conv_kernel(int npts_total, int 
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const int* __restrict__ intra_idx, const float* __restrict__ Wp,
                                                             const float* __restrict__ bias, float* __restrict__ Y,
-                                                            float* __restrict__ stat_part) {
+                                                            double* __restrict__ stat_part) {
     constexpr int MT = COUT / 16;
     constexpr int LD = C == 16 ? 56 : C + 40;   // row stride (floats) with LD/4 = 10 or 14 (mod 16): conflict-free ds_read_b128 of the gathered rows
     constexpr int NT = 12 * C / 16;        // K chunks
@@ -476,9 +479,11 @@ __global__ void __launch_bounds__(256) intra_so3conv_kernel(int npts_total, int 
     }
     // InstanceNorm statistics of the output, fused (stat_part != NULL; the host guarantees pts_per_batch % PTS == 0, so a workgroup's
     // points belong to one sample): per lane the sum / sum of squares of its 4 channels per tile over the workgroup's points
-    float4 ss[MT], sq[MT];
+    // (squares in fp64: formed in fp32 they lose (mean/std)^2 * 6e-8 of the variance when a channel's mean dominates its spread)
+    float4 ss[MT];
+    double sq[MT][4];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) ss[mt] = sq[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int mt = 0; mt < MT; ++mt) { ss[mt] = make_float4(0.f, 0.f, 0.f, 0.f); sq[mt][0] = sq[mt][1] = sq[mt][2] = sq[mt][3] = 0.0; }
     if (a < NA) {
 #pragma unroll
         for (int pi = 0; pi < PTS; ++pi) {
@@ -491,25 +496,30 @@ __global__ void __launch_bounds__(256) intra_so3conv_kernel(int npts_total, int 
                 const float4 v = make_float4(acc[pi][mt][0] + bs.x, acc[pi][mt][1] + bs.y, acc[pi][mt][2] + bs.z, acc[pi][mt][3] + bs.w);
                 *reinterpret_cast<float4*>(Y + ((size_t)pt * NA + a) * COUT + o) = v;
                 ss[mt].x += v.x; ss[mt].y += v.y; ss[mt].z += v.z; ss[mt].w += v.w;
-                sq[mt].x += v.x * v.x; sq[mt].y += v.y * v.y; sq[mt].z += v.z * v.z; sq[mt].w += v.w * v.w;
+                sq[mt][0] += (double)v.x * v.x; sq[mt][1] += (double)v.y * v.y; sq[mt][2] += (double)v.z * v.z; sq[mt][3] += (double)v.w * v.w;
             }
         }
     }
-    constexpr int RS = 2 * COUT + 4;
-    if constexpr (64 * RS <= PTS * NA * LD) if (stat_part) {
-        // [64 anchor slots][2][COUT] through the (now free) input tile, row stride + 4 floats against bank conflicts; then one thread per
-        // (statistic, channel) sums the 64 slots in order (the host only asks for it where the staging fits the input tile)
+    constexpr int RS = 3 * COUT + 4;                        // per anchor slot: COUT float sums + COUT double sums of squares (+ pad, even)
+    if constexpr (NA * RS <= PTS * NA * LD) if (stat_part) {
+        // [60 anchor slots][sum fp32 x COUT | sum of squares fp64 x COUT] through the (now free) input tile; then one thread per
+        // (statistic, channel) sums the 60 slots in order, in fp64 (the host only asks for it where the staging fits the input tile)
         __syncthreads();
-        float* red = Xs + (wave * 16 + fr) * RS;
+        if (a < NA) {
+            float* red = Xs + a * RS;
+            double* redq = reinterpret_cast<double*>(red + COUT);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            *reinterpret_cast<float4*>(red + mt * 16 + fg * 4) = ss[mt];
-            *reinterpret_cast<float4*>(red + COUT + mt * 16 + fg * 4) = sq[mt];
+            for (int mt = 0; mt < MT; ++mt) {
+                *reinterpret_cast<float4*>(red + mt * 16 + fg * 4) = ss[mt];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) redq[mt * 16 + fg * 4 + q] = sq[mt][q];
+            }
         }
         __syncthreads();
         if (tid < 2 * COUT) {
-            float t = 0.f;
-            for (int k = 0; k < 64; ++k) t += Xs[k * RS + tid];
+            double t = 0.0;
+            if (tid < COUT) { for (int k = 0; k < NA; ++k) t += (double)Xs[k * RS + tid]; }
+            else { for (int k = 0; k < NA; ++k) t += reinterpret_cast<const double*>(Xs + k * RS + COUT)[tid - COUT]; }
             stat_part[(size_t)blockIdx.x * 2 * COUT + tid] = t;
         }
     }
@@ -576,19 +586,20 @@ __global__ void instnorm_final_kernel(int rows, int C, float eps, const double* 
 
 // mean / rstd from per-workgroup partial sums written by the fused inter conv: part [b][nparts][2][C] (sum, sum of squares over
 // `count` values each) -> the same statistics as instnorm_partial/final over nparts * count values; fp64 accumulation in a fixed order
-__global__ void __launch_bounds__(1024) instnorm_from_partials_kernel(int nparts, int C, int count, float eps, const float* __restrict__ part,
+__global__ void __launch_bounds__(1024) instnorm_from_partials_kernel(int nparts, int C, int count, float eps, const double* __restrict__ part,
                                                                       float* __restrict__ mean, float* __restrict__ rstd) {
     __shared__ double red[2][1024];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int c4 = C >> 2;                                 // thread -> channel quad and slice of the parts; 16-byte loads
     const int cq = tid % c4, sl = tid / c4, nsl = 1024 / c4;
     double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
-    const float* pb = part + (size_t)b * nparts * 2 * C;
+    const double* pb = part + (size_t)b * nparts * 2 * C;
     for (int k = sl; k < nparts; k += nsl) {
-        const float4 u = *reinterpret_cast<const float4*>(pb + (size_t)k * 2 * C + cq * 4);
-        const float4 v = *reinterpret_cast<const float4*>(pb + (size_t)k * 2 * C + C + cq * 4);
-        s[0] += (double)u.x; s[1] += (double)u.y; s[2] += (double)u.z; s[3] += (double)u.w;
-        q[0] += (double)v.x; q[1] += (double)v.y; q[2] += (double)v.z; q[3] += (double)v.w;
+        const double2* u = reinterpret_cast<const double2*>(pb + (size_t)k * 2 * C + cq * 4);
+        const double2* v = reinterpret_cast<const double2*>(pb + (size_t)k * 2 * C + C + cq * 4);
+        const double2 u0 = u[0], u1 = u[1], v0 = v[0], v1 = v[1];
+        s[0] += u0.x; s[1] += u0.y; s[2] += u1.x; s[3] += u1.y;
+        q[0] += v0.x; q[1] += v0.y; q[2] += v1.x; q[3] += v1.y;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -640,7 +651,7 @@ __global__ void __launch_bounds__(256) instnorm_act_add_kernel(long n4, int rows
 template <int CIN, int COUT, int MAXT>
 static int launch_inter_t(int b, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz, const int* idx,
                           const float* feats, const float* rk, const float* Wp, const float* bias, float* out, const int* order,
-                          float* stat_part, hipStream_t st) {
+                          double* stat_part, hipStream_t st) {
     constexpr int CCH = CIN > 64 ? 64 : CIN;
     const size_t lds = (size_t)(16 * (CCH * KS / (CCH >= 32 ? 2 : 1) + 40) + 4 * 16 * (COUT + 4) + 16 * MAXT * 5) * sizeof(float);
     constexpr int PD = INTER_PD(CIN, MAXT);
@@ -659,7 +670,7 @@ static int launch_inter_t(int b, int p1, int p2, int nn, float sigma, const floa
 template <int CIN, int COUT>
 static int launch_inter(int b, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz, const int* idx,
                         const float* feats, const float* rk, const float* Wp, const float* bias, float* out, const int* order,
-                        float* stat_part, hipStream_t st) {
+                        double* stat_part, hipStream_t st) {
     if (nn <= 16) return launch_inter_t<CIN, COUT, 1>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, order, stat_part, st);
     if (nn <= 32) return launch_inter_t<CIN, COUT, 2>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, order, stat_part, st);
     return launch_inter_t<CIN, COUT, 4>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, order, stat_part, st);
@@ -667,7 +678,7 @@ static int launch_inter(int b, int p1, int p2, int nn, float sigma, const float*
 
 template <int C, int COUT>
 static int launch_intra(int npts, int ppb, const float* X, const float* mean, const float* rstd, const int* intra_idx,
-                        const float* Wp, const float* bias, float* Y, float* stat_part, hipStream_t st) {
+                        const float* Wp, const float* bias, float* Y, double* stat_part, hipStream_t st) {
     constexpr int PTS = C >= 128 ? 1 : 2;
     constexpr int LD = C == 16 ? 56 : C + 40;
     if (stat_part && ((ppb % PTS) != 0 || C >= 128)) return ETCH_EUNSUPPORTED;      // a workgroup's points must belong to one sample
@@ -690,7 +701,7 @@ extern "C" {
 // etch_permute_weight_frag (only the MFMA path, cin % 16 == 0, reads it).
 int etch_inter_so3conv_ordered(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
                                const int* ball_idx, const float* feats, const float* rk, const float* W, const float* Wp,
-                               const float* bias, float* out, const int* order, float* stat_part, void* stream);
+                               const float* bias, float* out, const int* order, double* stat_part, void* stream);
 
 int etch_inter_so3conv(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
                        const int* ball_idx, const float* feats, const float* rk, const float* W, const float* Wp,
@@ -700,7 +711,7 @@ int etch_inter_so3conv(int b, int cin, int cout, int p1, int p2, int nn, float s
 
 int etch_inter_so3conv_ordered(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
                                const int* ball_idx, const float* feats, const float* rk, const float* W, const float* Wp,
-                               const float* bias, float* out, const int* order, float* stat_part, void* stream) {
+                               const float* bias, float* out, const int* order, double* stat_part, void* stream) {
     if (b <= 0 || p2 <= 0) return ETCH_OK;
     if (nn <= 0 || nn > 64 || sigma <= 0.f) return ETCH_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -709,7 +720,7 @@ int etch_inter_so3conv_ordered(int b, int cin, int cout, int p1, int p2, int nn,
     INTER_CASE(16, 16) INTER_CASE(16, 32) INTER_CASE(32, 32) INTER_CASE(32, 64) INTER_CASE(64, 64)
     INTER_CASE(64, 128) INTER_CASE(128, 128) INTER_CASE(128, 256) INTER_CASE(256, 256)       // encoder depths 3 / 4 (models_pointcloud.py:34-48)
 #undef INTER_CASE
-    if (cin == 1 && cout <= 64 && (!stat_part || (256 % cout == 0 && nn * NA >= 512))) {
+    if (cin == 1 && cout <= 64 && (!stat_part || (256 % cout == 0 && nn * NA >= 1026))) {
         const size_t lds = ((size_t)4 * nn + (size_t)nn * NA + NA * KS + (size_t)cout * KS + nn) * sizeof(float);
         if (lds <= 64 * 1024) {
             hipLaunchKernelGGL(inter_so3conv_c1_kernel, dim3(p2, b), dim3(256), lds, st, cout, p1, p2, nn, 1.0f / sigma, xyz, new_xyz, ball_idx,
@@ -730,7 +741,7 @@ int etch_inter_so3conv_ordered(int b, int cin, int cout, int p1, int p2, int nn,
 }
 
 int etch_intra_so3conv_stats(int b, int c, int cout, int p, const float* X, const float* mean, const float* rstd,
-                             const int* intra_idx, const float* Wp, const float* bias, float* Y, float* stat_part, void* stream) {
+                             const int* intra_idx, const float* Wp, const float* bias, float* Y, double* stat_part, void* stream) {
     if (b <= 0 || p <= 0) return ETCH_OK;
     hipStream_t st = (hipStream_t)stream;
 #define INTRA_CASE(CI, CO) \
@@ -757,7 +768,7 @@ int etch_instnorm_stats(int b, int rows, int C, const float* x, double* workspac
     return ETCH_OK;
 }
 
-int etch_instnorm_from_partials(int b, int nparts, int C, int count, const float* partial, float* mean, float* rstd, void* stream) {
+int etch_instnorm_from_partials(int b, int nparts, int C, int count, const double* partial, float* mean, float* rstd, void* stream) {
     if (b <= 0) return ETCH_OK;
     if (C < 4 || C > 256 || (C & 3) || (1024 % (C >> 2)) != 0 || nparts <= 0 || count <= 0 || ((uintptr_t)partial & 15)) return ETCH_EUNSUPPORTED;
     hipLaunchKernelGGL(instnorm_from_partials_kernel, dim3(b), dim3(1024), 0, (hipStream_t)stream, nparts, C, count, 1e-5f, partial, mean, rstd);

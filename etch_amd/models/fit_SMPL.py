@@ -95,14 +95,19 @@ def get_markers(args, inner_points, part_labels, confidences):
 
 
 def fit_smpl_device(args, inner_points, part_labels, confidences, gender, steps_stage0=30, steps_stage1=50, lr_stage0=5e-1, lr_stage1=2e-1,
-                    want_trace=False):
+                    want_trace=False, markers_override=None):
     """Device-side part of fit_smpl: every kernel is enqueued on the current HIP stream, nothing is copied to the host.
-    Returns a dict of device tensors (markers, valid, x, x_stage0, err_trace, verts, joints) + the face array."""
+    Returns a dict of device tensors (markers, valid, x, x_stage0, err_trace, verts, joints) + the face array.
+    markers_override = (markers (B,M,3), valid_f (B,M) float, valid_b (B,M) bool): measurement aid of bench.py -- get_markers still runs
+    on the network's output, but the fit consumes these markers instead (a seeded random network yields ~2 valid markers per scan and a
+    fit that freezes early; see bench.py `well_posed_fit`)."""
     M = len(args.markerset)
     vids = list(args.markerset.values())
     bm = _resolve_body_model(args, gender)
     db = _device_body(bm, vids, inner_points.device)
     markers, valid_f, valid_b = ops.get_markers(inner_points.contiguous(), part_labels.contiguous(), confidences.contiguous(), M)
+    if markers_override is not None:
+        markers, valid_f, valid_b = markers_override
     # stage 0: damping 0.01 (fit_SMPL.py:200); stage 1: Theseus default damping 1e-3 (:249)
     x, x0, trace = ops.smpl_lm_fit(db.lm_consts, markers, valid_f, steps_stage0, lr_stage0, 0.01, steps_stage1, lr_stage1, 1e-3, want_trace,
                                    nj=db.nj, nb=db.nb)
@@ -145,10 +150,11 @@ def fit_smpl_finalize(dev):
 
 
 def fit_smpl(args, inner_points, part_labels, confidences, gender, steps_stage0=30, steps_stage1=50, lr_stage0=5e-1, lr_stage1=2e-1,
-             return_trace=False):
+             return_trace=False, markers_override=None):
     """fit_SMPL.py:68-269.  Returns (list of meshes, pred_markers_position (B,M,3), valid_mask (B,M) bool,
     [pose (B,23,3), shape (B,10), global_orient (B,3), translation (B,3), joints (B,45,3)] as numpy)."""
-    dev = fit_smpl_device(args, inner_points, part_labels, confidences, gender, steps_stage0, steps_stage1, lr_stage0, lr_stage1, return_trace)
+    dev = fit_smpl_device(args, inner_points, part_labels, confidences, gender, steps_stage0, steps_stage1, lr_stage0, lr_stage1, return_trace,
+                          markers_override=markers_override)
     out = fit_smpl_finalize(dev)
     if return_trace:
         return out + (dev,)

@@ -4,6 +4,11 @@ same return value (list of meshes, pred_markers_position, valid_mask).  The refe
 autograd 1 200 times per batch; here one persistent HIP kernel per batch runs the whole schedule on chip, with the gradient
 (2 / n) J^T r taken from the marker-restricted analytic linearisation of csrc/smpl_fit.hip (etch_smpl_adam_fit).
 
+Divergence to know (csrc/smpl_fit.hip, smpl_adam_fit_kernel): the reference's mse_loss is one mean over the whole batch, so one scan with a
+NaN marker makes every scan's result NaN; here a NaN stays in its own scan (flagged by ops.marker_status) and the other scans are fitted.
+The returned meshes come from the parameters of the last forward pass (before the final optimizer step), as in the reference (:221-225),
+also when steps_stage1 == 0.
+
 Body model: the reference hard-codes the neutral SMPL pickle (fit_SMPL_Adam.py:92-94); here `args.body_model` (or its "neutral" entry)
 is used, falling back to that pickle path."""
 import numpy as np

@@ -193,7 +193,7 @@ def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, orde
         assert tuple(order.shape) == (b, p2)
     out = torch.empty((b, p2, 60, cout), dtype=torch.float32, device=xyz.device)
     fused = want_stats and 256 % cout == 0 and (cin >= 16 or cin == 1)
-    part = torch.empty((b, p2, 2, cout), dtype=torch.float32, device=xyz.device) if fused else None
+    part = torch.empty((b, p2, 2, cout), dtype=torch.float64, device=xyz.device) if fused else None
     _lib.check(_lib.lib().etch_inter_so3conv_ordered(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
                                                      _ptr(feats_cl), _ptr(rk), _ptr(W), _optptr(Wp), _ptr(bias), _ptr(out), _optptr(order),
                                                      _optptr(part), _stream()), "etch_inter_so3conv")
@@ -214,7 +214,7 @@ def intra_so3conv(x_cl, intra_idx32, Wp, bias, cout, mean=None, rstd=None, want_
     _need(x_cl, torch.float32, "x"), _need(intra_idx32, torch.int32, "intra_idx"), _need(Wp, torch.float32, "Wp")
     out = torch.empty((b, p, 60, cout), dtype=torch.float32, device=x_cl.device)
     fused = want_stats and p % 2 == 0 and c <= 64        # wider tiles (encoder depths 3 / 4) take the separate statistics pass
-    part = torch.empty((b * (p // 2), 2, cout), dtype=torch.float32, device=x_cl.device) if fused else None
+    part = torch.empty((b * (p // 2), 2, cout), dtype=torch.float64, device=x_cl.device) if fused else None
     _lib.check(_lib.lib().etch_intra_so3conv_stats(b, c, cout, p, _ptr(x_cl), _optptr(mean), _optptr(rstd), _ptr(intra_idx32), _ptr(Wp),
                                                    _ptr(bias), _ptr(out), _optptr(part), _stream()), "etch_intra_so3conv")
     if not want_stats:

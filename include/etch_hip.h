@@ -111,15 +111,16 @@ int etch_inter_so3conv(int b, int cin, int cout, int p1, int p2, int nn, float s
 /* The same convolution with an explicit processing order of the output points (a scheduling hint: results are identical).
  * order (b,p2) int32 = a permutation of 0..p2-1 per scan, e.g. from etch_spatial_order; NULL = index order.  Workgroups walk
  * `order`, one contiguous eighth per XCD, so that the workgroups sharing an L2 gather from the same source rows.
- * stat_part (b,p2,2,cout) float or NULL: per output point the sum and the sum of squares of its 60 x cout outputs, i.e. the
- * InstanceNorm2d statistics of so3conv.py:96-99 without a second pass over the output (etch_instnorm_from_partials finishes them). */
+ * stat_part (b,p2,2,cout) fp64 or NULL: per output point the sum and the sum of squares of its 60 x cout outputs, i.e. the
+ * InstanceNorm2d statistics of so3conv.py:96-99 without a second pass over the output (etch_instnorm_from_partials finishes them);
+ * accumulated in fp64 so that a channel whose mean dominates its spread keeps its variance. */
 int etch_inter_so3conv_ordered(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
                                const int* ball_idx, const float* feats, const float* rk, const float* W, const float* Wp,
-                               const float* bias, float* out, const int* order, float* stat_part, void* stream);
+                               const float* bias, float* out, const int* order, double* stat_part, void* stream);
 
-/* mean / rstd (b,C) of InstanceNorm2d(affine=False, eps 1e-5) from per-part partial sums: partial (b,nparts,2,C), each over `count`
+/* mean / rstd (b,C) of InstanceNorm2d(affine=False, eps 1e-5) from per-part partial sums: partial (b,nparts,2,C) fp64, each over `count`
  * values.  Same result as etch_instnorm_stats over the full tensor (fp64 accumulation, fixed order). */
-int etch_instnorm_from_partials(int b, int nparts, int C, int count, const float* partial, float* mean, float* rstd, void* stream);
+int etch_instnorm_from_partials(int b, int nparts, int C, int count, const double* partial, float* mean, float* rstd, void* stream);
 
 /* Morton (Z-curve) order of each scan's points on its own bounding box, ties by index: xyz (b,3,n) -> order (b,n) int32, a
  * permutation of 0..n-1 per scan.  n <= 16384: 10 bits per axis; larger scans: 5 bits per axis, sorted in independent slices of
@@ -135,7 +136,7 @@ int etch_intra_so3conv(int b, int c, int cout, int p, const float* X, const floa
 /* The same with the InstanceNorm partial sums of Y from the epilogue: stat_part (b * p/2, 2, cout) = per workgroup (2 points) the sum and
  * the sum of squares per output channel; finish with etch_instnorm_from_partials(b, p/2, cout, 120, ...).  p must be even; NULL = plain. */
 int etch_intra_so3conv_stats(int b, int c, int cout, int p, const float* X, const float* mean, const float* rstd,
-                             const int* intra_idx, const float* Wp, const float* bias, float* Y, float* stat_part, void* stream);
+                             const int* intra_idx, const float* Wp, const float* bias, float* Y, double* stat_part, void* stream);
 
 /* InstanceNorm2d(affine=False, eps=1e-5) statistics over (p,a) per (b,c) (src/models/so3conv.py:24,85,168).
  * x (b,rows,C) -> mean (b,C), rstd (b,C).  workspace: etch_instnorm_stats_workspace_bytes(b, C) bytes. */

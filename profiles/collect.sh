@@ -47,6 +47,9 @@ for k, d in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[
     print(f"{k[:70]:70s} launches {cnt[k]:4d}  matrix pipe busy {d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / busy / 32.0:6.3f}  MFMA_BUSY {d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0):.3e}  SQ_BUSY {busy:.3e}  wave_cycles {d.get('SQ_WAVE_CYCLES', 0):.3e}")
 PY
 rm -rf $O/pmc_busy
+# the bench lines read the newest profiles/r*_pmc_traffic.json for `roofline.traffic`: put THIS round's pass there first, so that every
+# committed line of the round quotes the same counter file
+cp $O/${tag}_pmc_traffic.json $R/profiles/${tag}_pmc_traffic.json
 # the bench lines themselves (default run with the CPU baseline; forward only; the dense SMPL-X-sized config; two ranks on this one GPU)
 python3 $R/bench.py > $O/${tag}_bench_line_default_run.json 2> $O/bench_default.err
 python3 $R/bench.py --config 1 --steps 10 > $O/${tag}_bench_line_config1_forward_only.json 2> $O/bench_c1.err

@@ -221,3 +221,40 @@ def test_intra_conv_fused_instancenorm_statistics(c, p, normed):
     x64 = ref.double().reshape(b, -1, c)
     assert rel_err(m.cpu().numpy(), x64.mean(1).cpu().numpy()) < 2e-6
     assert rel_err(r.cpu().numpy(), (1.0 / torch.sqrt(x64.var(1, unbiased=False) + 1e-5)).cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("kind", ["inter", "intra"])
+def test_fused_instancenorm_statistics_with_a_dominant_channel_mean(kind):
+    """A channel whose mean dominates its spread (bias of 300 on outputs of spread ~1: mean/std ~ 300): squares formed in fp32 would lose
+    ~ (mean/std)^2 * 6e-8 = 5e-3 of the variance; the epilogue accumulates them in fp64 and must match the fp64 statistics of the written
+    output to 1e-5 in rstd (what remains is the fp32 rounding of the outputs themselves)."""
+    from etch_amd import ops
+    from etch_amd import vgtk_so3conv as V
+    g = torch.Generator().manual_seed(17)
+    b = 2
+    if kind == "inter":
+        cin, cout, nn, p1, p2 = 32, 32, 24, 180, 90
+        xyz = (torch.randn(b, 3, p1, generator=g) * 0.2).cuda()
+        new_xyz = xyz[:, :, :p2].contiguous()
+        ball = ops.ball_query(new_xyz, xyz, 0.25, nn)
+        conv = load_seeded(V.InterSO3Conv(cin, cout, 1, 2, 0.25, 0.03, nn), 3).cuda()
+        rk, W, Wp, bias = conv._derived()
+        bias = bias.clone()
+        bias[::2] += 300.0
+        feats = torch.randn(b, p1, 60, cin, generator=g).cuda()
+        out, (m, r) = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, order=conv.order(new_xyz), want_stats=True)
+    else:
+        c, p = 32, 64
+        cout = c
+        conv = load_seeded(V.IntraSO3Conv(c, c), 5).cuda()
+        Wp, bias, idx32 = conv._derived()
+        bias = bias.clone()
+        bias[::2] += 300.0
+        x = torch.randn(b, p, 60, c, generator=g).cuda()
+        out, (m, r) = ops.intra_so3conv(x, idx32, Wp, bias, c, None, None, want_stats=True)
+    x64 = out.double().reshape(b, -1, cout)
+    std = x64.std(1, unbiased=False)
+    assert float((x64.mean(1).abs() / std).max()) > 100
+    assert rel_err(m.cpu().numpy(), x64.mean(1).cpu().numpy()) < 1e-6
+    want = (1.0 / torch.sqrt(x64.var(1, unbiased=False) + 1e-5)).cpu().numpy()
+    assert np.abs(r.cpu().numpy() / want - 1).max() < 1e-5

@@ -264,7 +264,7 @@ def test_marker_status_flags_nan_and_empty_scans():
     assert np.isfinite(info[0][0]).all() and np.isnan(info[0][1]).any() and np.isfinite(info[0][2]).all()
 
 
-@pytest.mark.parametrize("model,it0,it1", [("smpl", 60, 90), ("smplx", 12, 18)])
+@pytest.mark.parametrize("model,it0,it1", [("smpl", 60, 90), ("smplx", 12, 18), ("smpl", 25, 0)])
 def test_adam_fitter_vs_oracle(model, it0, it1):
     """The first-order fitter (src/models/fit_SMPL_Adam.py:68-225) against its literal restatement -- torch.optim.Adam
     with autograd through the full-mesh LBS -- on a shortened schedule: loss per step, parameters after the last step, and the
