@@ -203,7 +203,7 @@ def test_checkpoint_supplied_anchor_buffers_are_honoured(tmp_path, golden):
     res2, aw2 = compare(sd2, "different buffers")
     from _parity import direction_within_conditioning
     ref2 = S1.forward({k: v.cpu() for k, v in sd2.items()}, pts, table, return_aux=True)
-    last_anchors = sd2["encoder.backbone.1.blocks.1.intra_conv.conv.anchors"].numpy()
+    last_anchors = sd2["encoder.backbone.1.blocks.1.intra_conv.conv.anchors"].cpu().numpy()
     direction_within_conditioning(res2["direction"].numpy().reshape(-1, 3), aw2.numpy().reshape(-1, 60), ref2["anc_w"].numpy().reshape(-1, 60),
                                   ref2["direction"].numpy().reshape(-1, 3), last_anchors)
     assert float((res2["part_labels"] - res0["part_labels"]).abs().max() / res0["part_labels"].abs().max()) > 1e-3   # ... and they do change the function
