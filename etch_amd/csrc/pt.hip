@@ -885,3 +885,345 @@ extern "C" int etch_pt_down_gather_max(int m, int ns, int co, const float* ux, l
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// PointTransformerBlock (pointtransformer_seg.py:101-122) in TWO kernels instead of four, and consecutive blocks of a level chained:
+//   K1  pt_block_k1_kernel      qkv = (relu(bn1(x W1^T))) Wqkv^T + bqkv                              (linear1 -> bn1 -> ReLU -> linear_q|k|v)
+//   K2  pt_block_k2_kernel      att = relu(bn2(vector attention(qkv, kNN idx)))                       (transformer2, bn2, ReLU)
+//                               out = relu(bn3(att W3^T) + x)                                        (linear3, bn3, residual, ReLU)
+//                    CHAIN:     qkv' = K1 of the NEXT block on the out tile                          (its linear1 / q|k|v)
+// A workgroup owns a tile of 16 points.  Everything between the gathered q|k|v rows and the block output stays in LDS: the
+// n x c tensors y1 = relu(bn1(linear1 x)) and att never exist in HBM (4 of the 7 n x c round trips of a block), and a level with b
+// blocks takes 1 + b launches instead of 4 b.  The 16-row GEMMs run on the fp32 matrix cores with the weight rows streamed from L2
+// (c x c floats per 16 points), wave w owning the output column tiles w, w + 4, ...
+// ------------------------------------------------------------------------------------------------
+struct PtBlockTail {
+    const float* W3l; const float* s3; const float* t3;      // linear3 [c][c], bn3 folded
+    const float* xres; long ldx;                              // block input (residual)
+    float* out; long ldo;
+    // CHAIN: the next block's K1
+    const float* W1n; const float* s1n; const float* t1n;     // linear1 [c][c], bn1 folded
+    const float* Wqkvn; const float* bqkvn;                   // [3c][c], [3c]
+    float* qkvn; long ldqn;
+};
+
+// D[16][O] = A[16][K] . W[O][K]^T; A in LDS (row stride lda), W row-major in global memory.  epi(col, acc): acc[r] = D[4 fg + r][col].
+template <int K, int NB, class Epi>
+__device__ __forceinline__ void pt_tile_gemm(const float* As, int lda, const float* __restrict__ W, int O, int wave, int fr, int fg, Epi epi) {
+    const int nct = O >> 4;
+    for (int c0 = wave; c0 < nct; c0 += 4 * NB) {
+        pf32x4 acc[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = (pf32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int t = 0; t < K / 16; ++t) {
+            const float4 af = *reinterpret_cast<const float4*>(As + fr * lda + t * 16 + fg * 4);
+            float4 wf[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int ct = c0 + 4 * b;
+                wf[b] = ct < nct ? *reinterpret_cast<const float4*>(W + (size_t)(ct * 16 + fr) * K + t * 16 + fg * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, wf[b].x, acc[b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, wf[b].y, acc[b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, wf[b].z, acc[b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, wf[b].w, acc[b], 0, 0, 0);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            if (c0 + 4 * b < nct) epi((c0 + 4 * b) * 16 + fr, acc[b]);
+    }
+}
+
+// K1 on one 16-row tile: Xt (LDS, [16][C + 4]) -> Yt = relu(bn1(Xt W1^T)) (LDS) -> qkv rows (global).  Barriers inside.
+template <int C>
+__device__ __forceinline__ void pt_tile_k1(const float* Xt, float* Yt, const float* __restrict__ W1, const float* __restrict__ s1,
+                                           const float* __restrict__ t1, const float* __restrict__ Wqkv, const float* __restrict__ bqkv,
+                                           float* __restrict__ qkv, long ldq, long row0, int n, int wave, int fr, int fg) {
+    constexpr int LD = C + 4;
+    pt_tile_gemm<C, (C >= 128 ? 2 : 1)>(Xt, LD, W1, C, wave, fr, fg, [&](int col, const pf32x4& acc) {
+        const float sc = s1[col], sh = t1[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Yt[(4 * fg + r) * LD + col] = fmaxf(acc[r] * sc + sh, 0.f);
+    });
+    __syncthreads();
+    pt_tile_gemm<C, (C >= 128 ? 4 : 3)>(Yt, LD, Wqkv, 3 * C, wave, fr, fg, [&](int col, const pf32x4& acc) {
+        const float bs = bqkv[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long row = row0 + 4 * fg + r;
+            if (row < n) qkv[row * ldq + col] = acc[r] + bs;
+        }
+    });
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) pt_block_k1_kernel(int n, const float* __restrict__ x, long ldx, const float* __restrict__ W1,
+                                                          const float* __restrict__ s1, const float* __restrict__ t1,
+                                                          const float* __restrict__ Wqkv, const float* __restrict__ bqkv,
+                                                          float* __restrict__ qkv, long ldq) {
+    constexpr int LD = C + 4;
+    extern __shared__ __attribute__((aligned(16))) float cst[];
+    float* Xt = cst;                 // [16][LD]
+    float* Yt = cst + 16 * LD;       // [16][LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const long ntiles = ((long)n + 15) >> 4;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row0 = tile * 16;
+        for (int e = tid; e < 16 * (C / 4); e += 256) {
+            const int r = e / (C / 4), c4 = e - r * (C / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + r < n) v = *reinterpret_cast<const float4*>(x + (row0 + r) * ldx + c4 * 4);
+            *reinterpret_cast<float4*>(&Xt[r * LD + c4 * 4]) = v;
+        }
+        __syncthreads();
+        pt_tile_k1<C>(Xt, Yt, W1, s1, t1, Wqkv, bqkv, qkv, ldq, row0, n, wave, fr, fg);
+        __syncthreads();
+    }
+}
+
+template <int C, int NS, bool CHAIN>
+__global__ void __launch_bounds__(256, 2) pt_block_k2_kernel(PtAttnParams a, const float* __restrict__ W2, PtBlockTail tl, long ntiles) {
+    constexpr int CS = C / 8;
+    constexpr int MT = CS <= 16 ? 1 : CS / 16;
+    constexpr int KT = C / 16;
+    constexpr int PPW = 16 / NS;                   // points per wave and pass
+    constexpr int NPASS = 16 / (4 * PPW);          // passes of the 4 waves over the tile's 16 points
+    constexpr bool W2_LDS = C <= 256;
+    constexpr int LDW = C + 4;
+    constexpr int LD = C + 4;                      // tile row stride
+    extern __shared__ __attribute__((aligned(16))) float cst[];
+    float* W3s = cst;                              // [C][3]   linear_p[3]
+    float* b3s = W3s + 3 * C;
+    float* scs = b3s + C;
+    float* shs = scs + C;
+    float* sos = shs + C;
+    float* tos = sos + C;
+    float* b2s = tos + C;
+    float* s3s = b2s + CS;
+    float* t3s = s3s + CS;
+    float* b5s = t3s + CS;
+    float* W5s = b5s + CS;                         // [CS][CS]
+    float* W2s = W5s + CS * CS;                    // [CS][LDW]  (W2_LDS only)
+    float* At = W2s + (W2_LDS ? CS * LDW : 0);     // [16][LD]  attention output tile (after bn2 + ReLU); CHAIN: y1 of the next block
+    float* Ot = At + 16 * LD;                      // [16][LD]  block output tile (CHAIN only)
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 3 * C; e += 256) W3s[e] = a.W3[e];
+    for (int e = tid; e < C; e += 256) {
+        b3s[e] = a.b3[e]; scs[e] = a.s_w0[e]; shs[e] = a.t_w0[e];
+        sos[e] = a.s_out[e]; tos[e] = a.t_out[e];
+    }
+    for (int e = tid; e < CS; e += 256) { b2s[e] = a.b2[e]; s3s[e] = a.s_w3[e]; t3s[e] = a.t_w3[e]; b5s[e] = a.b5[e]; }
+    for (int e = tid; e < CS * CS; e += 256) W5s[e] = a.W5[e];
+    if (W2_LDS)
+        for (int e = tid; e < CS * C / 4; e += 256) {
+            const int row = e / (C / 4), c4 = e - row * (C / 4);
+            *reinterpret_cast<float4*>(&W2s[row * LDW + c4 * 4]) = *reinterpret_cast<const float4*>(W2 + (size_t)row * C + c4 * 4);
+        }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int pw = fr / NS, jn = fr % NS;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row0 = tile * 16;
+#pragma unroll 1
+        for (int pass = 0; pass < NPASS; ++pass) {
+            asm volatile("" ::: "memory");
+            const int lrow = (pass * 4 + wave) * PPW + pw;            // row of the tile this lane's point owns
+            const long gi = row0 + lrow;
+            const bool valid = gi < a.n;
+            const int i = valid ? (int)gi : a.n - 1;
+            const int j = a.idx[(size_t)i * NS + jn];
+            float h[3];
+            pt_rel_hidden(a, i, j, h);
+            const float* kr = a.xk + (size_t)j * a.ldq;
+            const float* qr = a.xq + (size_t)i * a.ldq;
+            const float* vr = a.xv + (size_t)j * a.ldq;
+            pf32x4 acc[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = (pf32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int t = 0; t < KT; ++t) {
+                const int ch0 = t * 16 + fg * 4;
+                const float4 k4 = *reinterpret_cast<const float4*>(kr + ch0), q4 = *reinterpret_cast<const float4*>(qr + ch0);
+                const float4 wa = *reinterpret_cast<const float4*>(W3s + ch0 * 3), wb = *reinterpret_cast<const float4*>(W3s + ch0 * 3 + 4),
+                             wc = *reinterpret_cast<const float4*>(W3s + ch0 * 3 + 8);
+                const float4 b3 = *reinterpret_cast<const float4*>(b3s + ch0), sc = *reinterpret_cast<const float4*>(scs + ch0),
+                             sh = *reinterpret_cast<const float4*>(shs + ch0);
+                float w[4];
+                w[0] = fmaxf((k4.x - q4.x + (wa.x * h[0] + wa.y * h[1] + wa.z * h[2] + b3.x)) * sc.x + sh.x, 0.f);
+                w[1] = fmaxf((k4.y - q4.y + (wa.w * h[0] + wb.x * h[1] + wb.y * h[2] + b3.y)) * sc.y + sh.y, 0.f);
+                w[2] = fmaxf((k4.z - q4.z + (wb.z * h[0] + wb.w * h[1] + wc.x * h[2] + b3.z)) * sc.z + sh.z, 0.f);
+                w[3] = fmaxf((k4.w - q4.w + (wc.y * h[0] + wc.z * h[1] + wc.w * h[2] + b3.w)) * sc.w + sh.w, 0.f);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int row = mt * 16 + fr;
+                    float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (row < CS) f = W2_LDS ? *reinterpret_cast<const float4*>(W2s + row * LDW + ch0) : *reinterpret_cast<const float4*>(W2 + (size_t)row * C + ch0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.x, w[0], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.y, w[1], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.z, w[2], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w, w[3], acc[mt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int u = mt * 16 + fg * 4 + r;
+                    float v = 0.f;
+                    if (u < CS) v = fmaxf((acc[mt][r] + b2s[u]) * s3s[u] + t3s[u], 0.f);
+                    acc[mt][r] = v;
+                }
+            pf32x4 sm[MT];
+#pragma unroll
+            for (int mo = 0; mo < MT; ++mo) {
+                pf32x4 lg = {0.f, 0.f, 0.f, 0.f};
+                const int row = mo * 16 + fr;
+#pragma unroll
+                for (int mu = 0; mu < MT; ++mu) {
+                    const int u0 = mu * 16 + fg * 4;
+                    float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (row < CS && u0 < CS) f = *reinterpret_cast<const float4*>(W5s + row * CS + u0);
+                    lg = __builtin_amdgcn_mfma_f32_16x16x4f32(f.x, acc[mu][0], lg, 0, 0, 0);
+                    lg = __builtin_amdgcn_mfma_f32_16x16x4f32(f.y, acc[mu][1], lg, 0, 0, 0);
+                    lg = __builtin_amdgcn_mfma_f32_16x16x4f32(f.z, acc[mu][2], lg, 0, 0, 0);
+                    lg = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w, acc[mu][3], lg, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int tt = mo * 16 + fg * 4 + r;
+                    const float l = lg[r] + (tt < CS ? b5s[tt] : 0.f);
+                    const float m = pt_group_max<NS>(l);
+                    const float e = __expf(l - m);
+                    sm[mo][r] = e / pt_group_sum<NS>(e);
+                }
+            }
+            float* arow = At + lrow * LD;
+#pragma unroll
+            for (int mo = 0; mo < MT; ++mo) {
+                if (mo * 16 + fg * 4 < CS) {
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        const int ch0 = m * CS + mo * 16 + fg * 4;
+                        const float4 v4 = *reinterpret_cast<const float4*>(vr + ch0);
+                        const float4 wa = *reinterpret_cast<const float4*>(W3s + ch0 * 3), wb = *reinterpret_cast<const float4*>(W3s + ch0 * 3 + 4),
+                                     wc = *reinterpret_cast<const float4*>(W3s + ch0 * 3 + 8);
+                        const float4 b3 = *reinterpret_cast<const float4*>(b3s + ch0);
+                        float o0 = (v4.x + (wa.x * h[0] + wa.y * h[1] + wa.z * h[2] + b3.x)) * sm[mo][0];
+                        float o1 = (v4.y + (wa.w * h[0] + wb.x * h[1] + wb.y * h[2] + b3.y)) * sm[mo][1];
+                        float o2 = (v4.z + (wb.z * h[0] + wb.w * h[1] + wc.x * h[2] + b3.z)) * sm[mo][2];
+                        float o3 = (v4.w + (wc.y * h[0] + wc.z * h[1] + wc.w * h[2] + b3.w)) * sm[mo][3];
+                        o0 = pt_group_sum<NS>(o0); o1 = pt_group_sum<NS>(o1); o2 = pt_group_sum<NS>(o2); o3 = pt_group_sum<NS>(o3);
+                        if (jn == 0) {
+                            const float4 so = *reinterpret_cast<const float4*>(sos + ch0), to = *reinterpret_cast<const float4*>(tos + ch0);
+                            float4 o = make_float4(fmaxf(o0 * so.x + to.x, 0.f), fmaxf(o1 * so.y + to.y, 0.f), fmaxf(o2 * so.z + to.z, 0.f),
+                                                   fmaxf(o3 * so.w + to.w, 0.f));
+                            if (!valid) o = make_float4(0.f, 0.f, 0.f, 0.f);
+                            *reinterpret_cast<float4*>(arow + ch0) = o;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- out = relu(bn3(att W3^T) + x)
+        pt_tile_gemm<C, (C >= 128 ? 2 : 1)>(At, LD, tl.W3l, C, wave, fr, fg, [&](int col, const pf32x4& acc) {
+            const float sc = tl.s3[col], sh = tl.t3[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long row = row0 + 4 * fg + r;
+                float v = 0.f;
+                if (row < a.n) {
+                    v = fmaxf(acc[r] * sc + sh + tl.xres[row * tl.ldx + col], 0.f);
+                    tl.out[row * tl.ldo + col] = v;
+                }
+                if (CHAIN) Ot[(4 * fg + r) * LD + col] = v;
+            }
+        });
+        __syncthreads();
+        if (CHAIN) {
+            pt_tile_k1<C>(Ot, At, tl.W1n, tl.s1n, tl.t1n, tl.Wqkvn, tl.bqkvn, tl.qkvn, tl.ldqn, row0, a.n, wave, fr, fg);
+            __syncthreads();
+        }
+    }
+}
+
+template <int C_>
+static int launch_pt_k1(int n, const float* x, long ldx, const float* W1, const float* s1, const float* t1, const float* Wqkv, const float* bqkv,
+                        float* qkv, long ldq, hipStream_t st) {
+    const long ntiles = ((long)n + 15) >> 4;
+    const size_t lds = (size_t)2 * 16 * (C_ + 4) * sizeof(float);
+    auto kern = pt_block_k1_kernel<C_>;
+    static bool ready = false;
+    if (!ready) {
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ETCH_EUNSUPPORTED;
+        ready = true;
+    }
+    long blocks = (long)etch_cu_count() * 4;
+    if (blocks > ntiles) blocks = ntiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, n, x, ldx, W1, s1, t1, Wqkv, bqkv, qkv, ldq);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+template <int C_, int NS_, bool CHAIN>
+static int launch_pt_k2(const PtAttnParams& a, const float* W2, const PtBlockTail& tl, hipStream_t st) {
+    constexpr int CS = C_ / 8;
+    const size_t lds = (size_t)(8 * C_ + 4 * CS + CS * CS + (C_ <= 256 ? CS * (C_ + 4) : 0) + (CHAIN ? 2 : 1) * 16 * (C_ + 4)) * sizeof(float);
+    auto kern = pt_block_k2_kernel<C_, NS_, CHAIN>;
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ETCH_EUNSUPPORTED;
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, lds) != hipSuccess || nb < 1) nb = 1;
+        per_cu = nb > 4 ? 4 : nb;
+    }
+    const long ntiles = ((long)a.n + 15) >> 4;
+    long blocks = (long)etch_cu_count() * per_cu;
+    if (blocks > ntiles) blocks = ntiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, a, W2, tl, ntiles);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+extern "C" int etch_pt_block_k1(int n, int c, const float* x, long ldx, const float* W1, const float* s1, const float* t1, const float* Wqkv,
+                                const float* bqkv, float* qkv, long ldq, void* stream) {
+    if (n <= 0) return ETCH_OK;
+    if ((ldx & 3) || (ldq & 3) || !x || !W1 || !s1 || !t1 || !Wqkv || !bqkv || !qkv) return ETCH_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    switch (c) {
+        case 64: return launch_pt_k1<64>(n, x, ldx, W1, s1, t1, Wqkv, bqkv, qkv, ldq, st);
+        case 128: return launch_pt_k1<128>(n, x, ldx, W1, s1, t1, Wqkv, bqkv, qkv, ldq, st);
+        case 256: return launch_pt_k1<256>(n, x, ldx, W1, s1, t1, Wqkv, bqkv, qkv, ldq, st);
+        case 512: return launch_pt_k1<512>(n, x, ldx, W1, s1, t1, Wqkv, bqkv, qkv, ldq, st);
+    }
+    return ETCH_EUNSUPPORTED;
+}
+
+// tail = {W3l, s3, t3, xres, W1n, s1n, t1n, Wqkvn, bqkvn} (the last five NULL: no chained K1); params as etch_pt_attention (16 entries,
+// [14], [15] = bn2 folded, required)
+extern "C" int etch_pt_block_k2(int n, int c, int ns, const float* p, const float* xq, const float* xk, const float* xv, long ldq,
+                                const int* idx, const float* const* params, const float* W2, const float* const* tail, long ldx,
+                                float* out, long ldo, float* qkv_next, long ldqn, void* stream) {
+    if (n <= 0) return ETCH_OK;
+    if ((ldq & 3) || (ldo & 3) || (ldx & 3) || !W2 || !params || !tail || !params[14] || !params[15] || !out) return ETCH_EINVAL;
+    for (int k = 0; k < 4; ++k) if (!tail[k]) return ETCH_EINVAL;
+    const bool chain = tail[4] != nullptr;
+    if (chain && (!tail[5] || !tail[6] || !tail[7] || !tail[8] || !qkv_next || (ldqn & 3))) return ETCH_EINVAL;
+    PtAttnParams a;
+    fill_pt_params(a, n, c, ns, p, xq, xk, xv, ldq, idx, params, nullptr, 0);
+    PtBlockTail tl;
+    tl.W3l = tail[0]; tl.s3 = tail[1]; tl.t3 = tail[2]; tl.xres = tail[3]; tl.ldx = ldx; tl.out = out; tl.ldo = ldo;
+    tl.W1n = tail[4]; tl.s1n = tail[5]; tl.t1n = tail[6]; tl.Wqkvn = tail[7]; tl.bqkvn = tail[8]; tl.qkvn = qkv_next; tl.ldqn = ldqn;
+    hipStream_t st = (hipStream_t)stream;
+#define PT_K2_CASE(C_, NS_) \
+    if (c == C_ && ns == NS_) return chain ? launch_pt_k2<C_, NS_, true>(a, W2, tl, st) : launch_pt_k2<C_, NS_, false>(a, W2, tl, st);
+    PT_K2_CASE(64, 8) PT_K2_CASE(128, 8) PT_K2_CASE(128, 16) PT_K2_CASE(256, 16) PT_K2_CASE(512, 16)
+#undef PT_K2_CASE
+    return ETCH_EUNSUPPORTED;
+}

@@ -182,6 +182,16 @@ class PointTransformerBlock(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self._d = _Derived()
 
+    fused = True    # run_blocks: K1 / K2 fused kernels (2 launches per block, blocks of a level chained); False: 4 kernels per block
+
+    def _fused_params(self):
+        """Argument sets of the fused block kernels (etch_pt_block_k1 / _k2), rebuilt when a parameter changes."""
+        bns = (self.bn1, self.bn2, self.bn3)
+        f = self._d.get([t for m in bns for t in (m.weight, m.bias, m.running_mean, m.running_var)], lambda: [fold_bn(m) for m in bns])
+        wqkv, bqkv, params, mlp = self.transformer2._derived()
+        return dict(k1=(self.linear1.weight.detach(), f[0][0], f[0][1], wqkv, bqkv), attn=params + [f[1][0], f[1][1]], w2=mlp[0],
+                    w3=self.linear3.weight.detach(), s3=f[2][0], t3=f[2][1])
+
     def forward(self, pxo):
         p, x, o = pxo
         bns = (self.bn1, self.bn2, self.bn3)
@@ -190,6 +200,30 @@ class PointTransformerBlock(nn.Module):
         y = self.transformer2([p, y, o], out_bn=f[1])                                     # bn2 + relu fused into the kernel tail
         y = ops.linear(y, self.linear3.weight.detach(), scale=f[2][0], shift=f[2][1], res=x, res_mode=1, act="relu")
         return [p, y, o]
+
+
+def run_blocks(blocks, pxo):
+    """A run of consecutive PointTransformerBlocks of one level (pointtransformer_seg.py:101-122 each) with the fused block kernels:
+    1 + len(blocks) launches (K1 of the first block; K2 of every block, carrying the next block's K1) instead of 4 per block.  Falls back
+    to the blocks' own forward for shapes the fused kernels are not built for."""
+    blocks = list(blocks)
+    p, x, o = pxo
+    if not blocks:
+        return [p, x, o]
+    b0 = blocks[0]
+    c, ns = b0.transformer2.out_planes, b0.transformer2.nsample
+    if not (PointTransformerBlock.fused and x.is_cuda and (c, ns) in ops.PT_BLOCK_SHAPES and x.shape[1] == c and
+            all(b.transformer2.out_planes == c and b.transformer2.nsample == ns for b in blocks)):
+        for b in blocks:
+            p, x, o = b([p, x, o])
+        return [p, x, o]
+    idx = pointops.knnquery(ns, p, p, o, o)[0]
+    der = [b._fused_params() for b in blocks]
+    qkv = ops.pt_block_k1(x, *der[0]["k1"])
+    for i, d in enumerate(der):
+        nxt = der[i + 1]["k1"] if i + 1 < len(der) else None
+        x, qkv = ops.pt_block_k2(p, qkv, c, idx, d["attn"], ns, d["w2"], d["w3"], d["s3"], d["t3"], x, next_k1=nxt)
+    return [p, x, o]
 
 
 class _PointTransformerBase(nn.Module):
@@ -225,16 +259,17 @@ class _PointTransformerBase(nn.Module):
             x0 = torch.cat((p0, x0) + ((x0.new_zeros((x0.shape[0], pad)),) if pad else ()), 1)
         else:
             x0 = p0
-        p1, x1, o1 = self.enc1([p0, x0, o0])
-        p2, x2, o2 = self.enc2([p1, x1, o1])
-        p3, x3, o3 = self.enc3([p2, x2, o2])
-        p4, x4, o4 = self.enc4([p3, x3, o3])
-        p5, x5, o5 = self.enc5([p4, x4, o4])
-        x5 = self.dec5[1:]([p5, self.dec5[0]([p5, x5, o5]), o5])[1]
-        x4 = self.dec4[1:]([p4, self.dec4[0]([p4, x4, o4], [p5, x5, o5]), o4])[1]
-        x3 = self.dec3[1:]([p3, self.dec3[0]([p3, x3, o3], [p4, x4, o4]), o3])[1]
-        x2 = self.dec2[1:]([p2, self.dec2[0]([p2, x2, o2], [p3, x3, o3]), o2])[1]
-        x1 = self.dec1[1:]([p1, self.dec1[0]([p1, x1, o1], [p2, x2, o2]), o1])[1]
+        enc = lambda m, pxo_: run_blocks(m[1:], m[0](pxo_))            # TransitionDown, then the level's blocks (fused kernels)
+        p1, x1, o1 = enc(self.enc1, [p0, x0, o0])
+        p2, x2, o2 = enc(self.enc2, [p1, x1, o1])
+        p3, x3, o3 = enc(self.enc3, [p2, x2, o2])
+        p4, x4, o4 = enc(self.enc4, [p3, x3, o3])
+        p5, x5, o5 = enc(self.enc5, [p4, x4, o4])
+        x5 = run_blocks(self.dec5[1:], [p5, self.dec5[0]([p5, x5, o5]), o5])[1]
+        x4 = run_blocks(self.dec4[1:], [p4, self.dec4[0]([p4, x4, o4], [p5, x5, o5]), o4])[1]
+        x3 = run_blocks(self.dec3[1:], [p3, self.dec3[0]([p3, x3, o3], [p4, x4, o4]), o3])[1]
+        x2 = run_blocks(self.dec2[1:], [p2, self.dec2[0]([p2, x2, o2], [p3, x3, o3]), o2])[1]
+        x1 = run_blocks(self.dec1[1:], [p1, self.dec1[0]([p1, x1, o1], [p2, x2, o2]), o1])[1]
         return x1
 
 

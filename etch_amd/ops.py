@@ -370,6 +370,37 @@ def pt_attention_mfma(p, qkv, c, idx, params, ns, w2):
     return out
 
 
+def pt_block_k1(x, w1, s1, t1, wqkv, bqkv):
+    """First half of a PointTransformerBlock: qkv (n, 3c) = relu(bn1(x W1^T)) Wqkv^T + bqkv (pointtransformer_seg.py:112-113, 27)."""
+    n, c = x.shape
+    assert x.stride(1) == 1 and w1.shape == (c, c) and wqkv.shape == (3 * c, c)
+    qkv = torch.empty((n, 3 * c), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().etch_pt_block_k1(n, c, _ptr(x), _c_long(x.stride(0)), _ptr(w1), _ptr(s1), _ptr(t1), _ptr(wqkv), _ptr(bqkv), _ptr(qkv),
+                                           _c_long(3 * c), _stream()), "etch_pt_block_k1")
+    return qkv
+
+
+PT_BLOCK_SHAPES = {(64, 8), (128, 8), (128, 16), (256, 16), (512, 16)}     # (c, nsample) the fused block kernels are instantiated for
+
+
+def pt_block_k2(p, qkv, c, idx, params, ns, w2, w3, s3, t3, x_res, next_k1=None):
+    """Second half of a PointTransformerBlock: vector attention -> bn2 -> ReLU -> linear3 -> bn3 -> + x -> ReLU (pointtransformer_seg.py:
+    114-121), the attention output kept on chip.  next_k1 = (w1, s1, t1, wqkv, bqkv) of the NEXT block: its first half runs on the output
+    tile, and its qkv is returned as well."""
+    n = p.shape[0]
+    out = torch.empty((n, c), dtype=torch.float32, device=p.device)
+    arr = (ctypes.c_void_p * 16)(*[(0 if t is None else t.data_ptr()) for t in params])
+    tail = [w3, s3, t3, x_res] + (list(next_k1) if next_k1 is not None else [None] * 5)
+    tarr = (ctypes.c_void_p * 9)(*[(0 if t is None else t.data_ptr()) for t in tail])
+    qn = torch.empty((n, 3 * c), dtype=torch.float32, device=p.device) if next_k1 is not None else None
+    base = qkv.data_ptr()
+    assert x_res.stride(1) == 1
+    _lib.check(_lib.lib().etch_pt_block_k2(n, c, ns, _ptr(p), _vp(base), _vp(base + 4 * c), _vp(base + 8 * c), _c_long(qkv.stride(0)), _ptr(idx), arr,
+                                           _ptr(w2), tarr, _c_long(x_res.stride(0)), _ptr(out), _c_long(c), _optptr(qn), _c_long(3 * c), _stream()),
+               "etch_pt_block_k2")
+    return out, qn
+
+
 def pt_attention_split(p, qkv, c, idx, params, ns, w2, b2, s3, t3, w5, b5):
     """Same result as pt_attention with the two Linear layers of linear_w on the matrix cores (etch_linear)."""
     n = p.shape[0]

@@ -224,6 +224,19 @@ int etch_pt_attn_aggregate(int n, int c, int ns, const float* p, const float* xv
 int etch_pt_attention_mfma(int n, int c, int ns, const float* p, const float* xq, const float* xk, const float* xv, long ldq,
                            const int* idx, const float* const* params, const float* W2, float* out, long ldo, void* stream);
 
+/* PointTransformerBlock (src/models/pointtransformer_seg.py:101-122) in two kernels, consecutive blocks of a level chained:
+ * K1: qkv (n,3c) = relu(bn1(x W1^T)) Wqkv^T + bqkv   -- linear1 (no bias) -> bn1 (folded s1,t1) -> ReLU -> linear_q|k|v of transformer2.
+ * c in {64,128,256,512}. */
+int etch_pt_block_k1(int n, int c, const float* x, long ldx, const float* W1, const float* s1, const float* t1, const float* Wqkv,
+                     const float* bqkv, float* qkv, long ldq, void* stream);
+/* K2: out (n,c) = relu(bn3(relu(bn2(vector attention(q|k|v, idx))) W3^T) + x)  -- transformer2's attention core (as
+ * etch_pt_attention_mfma; params[14], params[15] = bn2 folded, required), bn2, ReLU, linear3, bn3, residual, ReLU; the attention output
+ * stays in LDS.  tail = {W3 (c,c), s3, t3, x (residual, row stride ldx), W1', s1', t1', Wqkv', bqkv'}: when tail[4] != NULL the K1 of the
+ * NEXT block runs on the output tile and fills qkv_next (n,3c).  (c, ns) in {(64,8),(128,8),(128,16),(256,16),(512,16)}. */
+int etch_pt_block_k2(int n, int c, int ns, const float* p, const float* xq, const float* xk, const float* xv, long ldq, const int* idx,
+                     const float* const* params, const float* W2, const float* const* tail, long ldx, float* out, long ldo,
+                     float* qkv_next, long ldqn, void* stream);
+
 /* queryandgroup(use_xyz=True) rows for TransitionDown (pointtransformer_seg.py:61, pointops.py:90-98):
  * out[(i*ns+j)] = [p[idx[i,j]] - new_p[i] | x[idx[i,j]] | 0...], row stride ldo >= 3+c (padding columns zeroed). */
 int etch_pt_group(int m, int ns, int c, const float* p, const float* new_p, const float* x, long ldx, const int* idx,

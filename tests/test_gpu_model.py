@@ -156,3 +156,44 @@ def test_pt_attention_mfma_kernel_matches_split_and_valu(c, ns, n):
                 outs[impl] = layer([pnt, x, o], out_bn=out_bn).cpu().numpy()
         assert outs["mfma"].shape == (n, c) and np.isfinite(outs["mfma"]).all()
         assert rel_err(outs["mfma"], outs["split"]) < 5e-6 and rel_err(outs["mfma"], outs["valu"]) < 5e-6
+
+
+@pytest.mark.parametrize("c,ns,n,nblocks", [(64, 8, 1003, 1), (128, 8, 517, 2), (128, 16, 1001, 3), (256, 16, 333, 5), (512, 16, 97, 2), (256, 16, 16, 1)])
+def test_fused_block_kernels_match_the_four_kernel_blocks(c, ns, n, nblocks):
+    """run_blocks (etch_pt_block_k1 / _k2: linear1+bn1+ReLU+q|k|v, then attention+bn2+ReLU+linear3+bn3+residual+ReLU, consecutive blocks
+    chained) against the blocks' own four-kernel forward (which the reference golden pins at c = 32): every instantiated (c, nsample),
+    runs of 1-5 blocks, point counts that leave partial 16-point tiles, two segments."""
+    from etch_amd import ops
+    from etch_amd.models import pointops
+    from etch_amd.models import pointtransformer_seg as P
+    assert (c, ns) in ops.PT_BLOCK_SHAPES
+    blocks = [load_seeded(P.PointTransformerBlock(c, c, 8, ns), 20 + k).cuda().eval() for k in range(nblocks)]
+    g = torch.Generator().manual_seed(c + ns + n)
+    pnt = (torch.randn(n, 3, generator=g) * 0.3).cuda()
+    x = torch.randn(n, c, generator=g).cuda()
+    o = pointops.offsets_tensor([n // 2, n], "cuda")
+    with torch.no_grad(), pointops.knn_scope():
+        ref = [pnt, x, o]
+        for b in blocks:
+            ref = b(ref)
+        got = P.run_blocks(blocks, [pnt, x, o])
+        try:
+            P.PointTransformerBlock.fused = False
+            off = P.run_blocks(blocks, [pnt, x, o])
+        finally:
+            P.PointTransformerBlock.fused = True
+    assert got[1].shape == (n, c) and torch.isfinite(got[1]).all()
+    assert torch.equal(off[1], ref[1])
+    assert rel_err(got[1].cpu().numpy(), ref[1].cpu().numpy()) < 1e-5 * nblocks
+
+
+def test_fused_block_vs_reference_golden_falls_back_for_unbuilt_widths(golden):
+    """c = 32 (the reference golden's block) is not a width of the nets: run_blocks must take the blocks' own forward and still match."""
+    from etch_amd.models import pointtransformer_seg as P
+    g = golden("module_pt.npz")
+    seeds = json.loads(str(g["seeds"]))
+    d = lambda k: torch.from_numpy(g[k]).cuda()
+    block = load_seeded(P.PointTransformerBlock(32, 32, 8, 16), seeds["block"]).cuda().eval()
+    with torch.no_grad():
+        out = P.run_blocks([block], [d("p"), d("x"), d("o")])[1]
+    assert rel_err(out.cpu().numpy(), g["block_out"]) < RTOL
