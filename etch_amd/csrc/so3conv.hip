@@ -479,11 +479,13 @@ __global__ void __launch_bounds__(256) intra_so3conv_kernel(int npts_total, int 
     }
     // InstanceNorm statistics of the output, fused (stat_part != NULL; the host guarantees pts_per_batch % PTS == 0, so a workgroup's
     // points belong to one sample): per lane the sum / sum of squares of its 4 channels per tile over the workgroup's points
-    // (squares in fp64: formed in fp32 they lose (mean/std)^2 * 6e-8 of the variance when a channel's mean dominates its spread)
-    float4 ss[MT];
-    double sq[MT][4];
+    // (in fp64: a channel whose mean dominates its spread loses (mean/std)^2 * 6e-8 of its variance to fp32 squares, and 2 * mean * 6e-8 * mean
+    // to an fp32 sum)
+    double ss[MT][4], sq[MT][4];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) { ss[mt] = make_float4(0.f, 0.f, 0.f, 0.f); sq[mt][0] = sq[mt][1] = sq[mt][2] = sq[mt][3] = 0.0; }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ss[mt][q] = sq[mt][q] = 0.0;
     if (a < NA) {
 #pragma unroll
         for (int pi = 0; pi < PTS; ++pi) {
@@ -495,32 +497,31 @@ __global__ void __launch_bounds__(256) intra_so3conv_kernel(int npts_total, int 
                 const float4 bs = *reinterpret_cast<const float4*>(bias + o);
                 const float4 v = make_float4(acc[pi][mt][0] + bs.x, acc[pi][mt][1] + bs.y, acc[pi][mt][2] + bs.z, acc[pi][mt][3] + bs.w);
                 *reinterpret_cast<float4*>(Y + ((size_t)pt * NA + a) * COUT + o) = v;
-                ss[mt].x += v.x; ss[mt].y += v.y; ss[mt].z += v.z; ss[mt].w += v.w;
+                ss[mt][0] += (double)v.x; ss[mt][1] += (double)v.y; ss[mt][2] += (double)v.z; ss[mt][3] += (double)v.w;
                 sq[mt][0] += (double)v.x * v.x; sq[mt][1] += (double)v.y * v.y; sq[mt][2] += (double)v.z * v.z; sq[mt][3] += (double)v.w * v.w;
             }
         }
     }
-    constexpr int RS = 3 * COUT + 4;                        // per anchor slot: COUT float sums + COUT double sums of squares (+ pad, even)
+    constexpr int RS = 2 * COUT + 4;                        // per anchor slot: COUT doubles (+ pad)
     if constexpr (NA * RS <= PTS * NA * LD) if (stat_part) {
-        // [60 anchor slots][sum fp32 x COUT | sum of squares fp64 x COUT] through the (now free) input tile; then one thread per
-        // (statistic, channel) sums the 60 slots in order, in fp64 (the host only asks for it where the staging fits the input tile)
-        __syncthreads();
-        if (a < NA) {
-            float* red = Xs + a * RS;
-            double* redq = reinterpret_cast<double*>(red + COUT);
+        // [60 anchor slots][COUT fp64] through the (now free) input tile, once for the sums and once for the sums of squares; one thread per
+        // channel adds the 60 slots in order (the host only asks for it where the staging fits the input tile)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                *reinterpret_cast<float4*>(red + mt * 16 + fg * 4) = ss[mt];
+        for (int which = 0; which < 2; ++which) {
+            __syncthreads();
+            if (a < NA) {
+                double* red = reinterpret_cast<double*>(Xs + a * RS);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) redq[mt * 16 + fg * 4 + q] = sq[mt][q];
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) red[mt * 16 + fg * 4 + q] = which == 0 ? ss[mt][q] : sq[mt][q];
             }
-        }
-        __syncthreads();
-        if (tid < 2 * COUT) {
-            double t = 0.0;
-            if (tid < COUT) { for (int k = 0; k < NA; ++k) t += (double)Xs[k * RS + tid]; }
-            else { for (int k = 0; k < NA; ++k) t += reinterpret_cast<const double*>(Xs + k * RS + COUT)[tid - COUT]; }
-            stat_part[(size_t)blockIdx.x * 2 * COUT + tid] = t;
+            __syncthreads();
+            if (tid < COUT) {
+                double t = 0.0;
+                for (int k = 0; k < NA; ++k) t += reinterpret_cast<const double*>(Xs + k * RS)[tid];
+                stat_part[(size_t)blockIdx.x * 2 * COUT + which * COUT + tid] = t;
+            }
         }
     }
 }

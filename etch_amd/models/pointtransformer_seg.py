@@ -1,6 +1,8 @@
 """MI355X counterpart of /root/reference/src/models/pointtransformer_seg.py: identical module tree and
 state-dict keys; Linear(+BN+ReLU) layers run as one fp32-MFMA GEMM with a fused epilogue, the kNN
 vector-attention core is one kernel per layer, FPS / kNN are the HIP index kernels."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -182,7 +184,8 @@ class PointTransformerBlock(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self._d = _Derived()
 
-    fused = True    # run_blocks: K1 / K2 fused kernels (2 launches per block, blocks of a level chained); False: 4 kernels per block
+    # run_blocks: K1 / K2 fused kernels (2 launches per block, blocks of a level chained); False: 4 kernels per block (ETCH_PT_FUSED=0: A/B runs)
+    fused = os.environ.get("ETCH_PT_FUSED", "1") != "0"
 
     def _fused_params(self):
         """Argument sets of the fused block kernels (etch_pt_block_k1 / _k2), rebuilt when a parameter changes."""
