@@ -172,16 +172,18 @@ def test_fused_block_kernels_match_the_four_kernel_blocks(c, ns, n, nblocks):
     pnt = (torch.randn(n, 3, generator=g) * 0.3).cuda()
     x = torch.randn(n, c, generator=g).cuda()
     o = pointops.offsets_tensor([n // 2, n], "cuda")
+    was = P.PointTransformerBlock.fused
     with torch.no_grad(), pointops.knn_scope():
         ref = [pnt, x, o]
         for b in blocks:
             ref = b(ref)
-        got = P.run_blocks(blocks, [pnt, x, o])
         try:
+            P.PointTransformerBlock.fused = True
+            got = P.run_blocks(blocks, [pnt, x, o])
             P.PointTransformerBlock.fused = False
             off = P.run_blocks(blocks, [pnt, x, o])
         finally:
-            P.PointTransformerBlock.fused = True
+            P.PointTransformerBlock.fused = was
     assert got[1].shape == (n, c) and torch.isfinite(got[1]).all()
     assert torch.equal(off[1], ref[1])
     assert rel_err(got[1].cpu().numpy(), ref[1].cpu().numpy()) < 1e-5 * nblocks
