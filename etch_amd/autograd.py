@@ -257,3 +257,147 @@ def pt_vector_attention(p, xq, xk, xv, idx, W0, b0, s_p, t_p, W3, b3, s_w0, t_w0
     """p (n,3), xq / xk / xv (n,c), idx (n,ns) int32 kNN indices, linear_p = [W0 (3,3), b0, BN(s_p, t_p), ReLU, W3 (c,3), b3],
     linear_w = [BN(s_w0, t_w0), ReLU, W2 (c/8,c), b2, BN(s_w3, t_w3), ReLU, W5 (c/8,c/8), b5] -> (n,c)."""
     return PTVectorAttentionFunction.apply(p, xq, xk, xv, idx, W0, b0, s_p, t_p, W3, b3, s_w0, t_w0, W2, b2, s_w3, t_w3, W5, b5)
+
+
+# ------------------------------------------------------------------------------------------------ the rest of the encoder + direction head
+class LinearFunction(torch.autograd.Function):
+    """y = act(x W^T + b) on the fp32 matrix cores (etch_linear), differentiable in x, W, b.  act in (None, "relu")."""
+
+    @staticmethod
+    def forward(ctx, x2, W, bias, act):
+        x2, Wc = x2.contiguous(), W.detach().contiguous()
+        y = ops.linear(x2, Wc, bias=None if bias is None else bias.detach().contiguous(), act=act)
+        ctx.save_for_backward(x2, Wc, y if act == "relu" else None)
+        ctx.act, ctx.has_bias = act, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        if ctx.act == "relu":
+            dy = dy * (y > 0)
+        dx = ops.linear(dy, W.t().contiguous()) if ctx.needs_input_grad[0] else None
+        if x2.shape[1] == 1:                     # one input channel (the first skip conv): dW[o] = sum_r dy[r,o] x[r]
+            dW = colsum(dy * x2).view(-1, 1)
+        else:
+            dW = gemm_tn(dy, x2)
+        db = colsum(dy) if ctx.has_bias else None
+        return dx, dW, db, None
+
+
+def linear(x, W, bias=None, act=None):
+    """x (..., K) -> (..., O)."""
+    shp = x.shape
+    y = LinearFunction.apply(x.reshape(-1, shp[-1]), W, bias, act)
+    return y.view(*shp[:-1], W.shape[0])
+
+
+class GatherPointsFunction(torch.autograd.Function):
+    """x (b, p1, ...) -> x[b, idx[b, :]] (b, p2, ...) for per-sample index lists WITHOUT repeats (furthest-point samples, lazy prefixes):
+    the skip branch's sub-sampling (so3conv.py:178-180)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        b = x.shape[0]
+        ar = torch.arange(b, device=x.device).view(b, 1)
+        ctx.save_for_backward(idx)
+        ctx.shape = x.shape
+        return x[ar, idx.long()].contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        b = ctx.shape[0]
+        dx = torch.zeros(ctx.shape, dtype=dy.dtype, device=dy.device)
+        dx[torch.arange(b, device=dy.device).view(b, 1), idx.long()] = dy        # unique indices: a plain (deterministic) scatter
+        return dx, None
+
+
+class PropInterpFunction(torch.autograd.Function):
+    """3-NN feature propagation on channels-last features (pointnet2_utils.py:45-74): feats_cl (B,S,A,C), idx / w (B,N,3) -> (B,N,A,C).
+    No gradient into idx / w (functions of the coordinates)."""
+
+    @staticmethod
+    def forward(ctx, feats_cl, idx, w):
+        feats_cl = feats_cl.contiguous()
+        out, _ = ops.prop_interp(feats_cl, idx, w)
+        ctx.save_for_backward(idx, w)
+        ctx.shape = feats_cl.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        idx, w = ctx.saved_tensors
+        B, S, A, C = ctx.shape
+        N = idx.shape[1]
+        dout = dout.contiguous()
+        key = (idx.long() + (torch.arange(B, device=idx.device) * S).view(B, 1, 1)).reshape(-1)
+        skey, perm = torch.sort(key, stable=True)
+        seg = torch.searchsorted(skey, torch.arange(B * S + 1, device=key.device, dtype=torch.int64)).contiguous()
+        dfe = torch.empty((B * S, A * C), dtype=torch.float32, device=dout.device)
+        _check(_lib.lib().etch_weighted_segment_sum_rows(ctypes.c_long(B * S), A * C, 3, _ptr(dout), _ptr(w.contiguous()), _ptr(perm.contiguous()), _ptr(seg),
+                                                         _ptr(dfe), _stream()), "etch_weighted_segment_sum_rows")
+        return dfe.view(B, S, A, C), None, None
+
+
+def prop_interp(feats_cl, idx, w):
+    return PropInterpFunction.apply(feats_cl, idx, w)
+
+
+class MHSAHeadsFunction(torch.autograd.Function):
+    """The concatenated head outputs of one MultiHeadAttention layer (before head_combine): x (T,60,64) -> (T,60,64); forward = the fused
+    kernel in mode 2, backward as MHSALayerFunction without the combine."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv):
+        T = x.shape[0]
+        x2 = x.reshape(T * 60, 64).contiguous()
+        ws = [t.detach().contiguous() for t in (wq, wk, wv)]
+        y = ops.mhsa_layer(x2, ws[0], ws[1], ws[2], mode=2)
+        ctx.save_for_backward(x2, *ws)
+        ctx.xshape = x.shape
+        return y.view(T, 60, 64)
+
+    @staticmethod
+    def backward(ctx, dO):
+        x2, wq, wk, wv = ctx.saved_tensors
+        T = x2.shape[0] // 60
+        dO2 = dO.reshape(T * 60, 64).contiguous()
+        wqkv = torch.cat([wq, wk, wv], 0).contiguous()
+        qkv = ops.linear(x2, wqkv)
+        dqkv = torch.empty_like(qkv)
+        _check(_lib.lib().etch_mhsa_attention_backward(ctypes.c_long(T), _ptr(qkv), ctypes.c_long(192), 0, 64, 128, _ptr(dO2), ctypes.c_long(64),
+                                                       _ptr(dqkv), _stream()), "etch_mhsa_attention_backward")
+        dx = ops.linear(dqkv, wqkv.t().contiguous())
+        dwqkv = gemm_tn(dqkv, x2)
+        return dx.view(ctx.xshape), dwqkv[:64], dwqkv[64:128], dwqkv[128:]
+
+
+def mhsa_heads(x, wq, wk, wv):
+    return MHSAHeadsFunction.apply(x, wq, wk, wv)
+
+
+class SO3MeanDirFunction(torch.autograd.Function):
+    """w (T,60) -> R(sum_a w_a R_a) @ [0,0,1] (T,3): so3_mean (so3conv.py:186-225) followed by the rotation of the standard vector
+    (models_pointcloud.py:120-124); backward = etch_so3_mean_dir_backward (derivative of the polar factor)."""
+
+    @staticmethod
+    def forward(ctx, w, anchors):
+        w, anchors = w.contiguous(), anchors.contiguous()
+        d, _, _ = ops.so3_mean_dir(w, anchors)
+        ctx.save_for_backward(w, anchors)
+        return d
+
+    @staticmethod
+    def backward(ctx, dd):
+        w, anchors = ctx.saved_tensors
+        T, A = w.shape
+        dw = torch.empty_like(w)
+        _check(_lib.lib().etch_so3_mean_dir_backward(ctypes.c_long(T), A, _ptr(w), _ptr(anchors), _ptr(dd.contiguous()), _ptr(dw), _stream()),
+               "etch_so3_mean_dir_backward")
+        return dw, None
+
+
+def so3_mean_dir(w, anchors):
+    return SO3MeanDirFunction.apply(w, anchors)

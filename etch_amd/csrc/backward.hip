@@ -468,3 +468,41 @@ extern "C" int etch_mhsa_attention_backward(long T, const float* qkv, long ld, i
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the 3-NN feature propagation (src/models/pointnet2_utils.py:45-74; forward = prop_interp_kernel):
+//   out[n, :] = sum_k w[n,k] * feats[idx[n,k], :]      =>      dfeats[s, :] = sum over { (n,k) : idx[n,k] == s } of w[n,k] * dout[n, :]
+// Gather-side and in a FIXED order: `perm` is the stable sort of the flattened (n,k) list by coarse row, `seg` its segment offsets
+// (int64, as for etch_segment_sum_rows); one workgroup per coarse row adds its entries in that order -- no atomics, reproducible.
+// The interpolation weights and indices are functions of the coordinates only: no gradient flows into them (as in the reference, where
+// `dists.sort` / the reciprocal weights do carry autograd history to xyz, but xyz is an input without grad).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) weighted_segment_sum_rows_kernel(long nseg, int C, const float* __restrict__ src, const float* __restrict__ wgt,
+                                                                        int fan, const long long* __restrict__ perm,
+                                                                        const long long* __restrict__ seg, float* __restrict__ dst) {
+    const long q = blockIdx.x;
+    if (q >= nseg) return;
+    const int c4 = C >> 2;
+    const long long k0 = seg[q], k1 = seg[q + 1];
+    for (int ch = threadIdx.x; ch < c4; ch += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (long long k = k0; k < k1; ++k) {
+            const long long e = perm[k];                   // flat index into the (rows, fan) index / weight lists
+            const float w = wgt[e];
+            const float4 v = reinterpret_cast<const float4*>(src + (size_t)(e / fan) * C)[ch];
+            acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
+        }
+        reinterpret_cast<float4*>(dst + (size_t)q * C)[ch] = acc;
+    }
+}
+
+// dst (nseg, C)[q] = sum_{k in [seg[q], seg[q+1])} wgt[perm[k]] * src[perm[k] / fan]   (src (rows, C), wgt (rows * fan))
+extern "C" int etch_weighted_segment_sum_rows(long nseg, int C, int fan, const float* src, const float* wgt, const long long* perm, const long long* seg,
+                                              float* dst, void* stream) {
+    if (nseg <= 0) return ETCH_OK;
+    if (C <= 0 || (C & 3) || fan <= 0 || !src || !wgt || !perm || !seg || !dst) return ETCH_EINVAL;
+    if (nseg > 0x7fffffffL) return ETCH_EUNSUPPORTED;
+    hipLaunchKernelGGL(weighted_segment_sum_rows_kernel, dim3((unsigned)nseg), dim3(256), 0, (hipStream_t)stream, nseg, C, src, wgt, fan, perm, seg, dst);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}

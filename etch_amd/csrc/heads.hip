@@ -370,6 +370,61 @@ __global__ void __launch_bounds__(256) so3_mean_dir_kernel(long T, int A, const 
     if (sv) { sv[t * 3] = (float)S[0]; sv[t * 3 + 1] = (float)S[1]; sv[t * 3 + 2] = (float)S[2]; }
 }
 
+// Backward of so3_mean_dir (src/models/so3conv.py:186-225 followed by R @ [0,0,1], models_pointcloud.py:120-124): dL/dw[t,a] from dL/d dir[t].
+// R = polar factor of Ce = U diag(s) V^T, R = U D V^T, D = diag(1, 1, det(U V^T)).  With M = Ce = R S, S = V diag(sigma) V^T,
+// sigma = (s0, s1, det * s2):  dR = R X, X skew with  X S + S X = R^T dM - dM^T R  (a 3x3 Sylvester equation, diagonal in V's basis).
+// Adjoint:  dL/dM = U D Z V^T,  Z_ij = (A_ij - A_ji) / (sigma_i + sigma_j),  A = D U^T G V,  G = dL/dR (only its third column is
+// non-zero here).  fp64 per point like the forward; denominators are floored at 1e-12 * s0 (the projection is not differentiable where
+// sigma_i + sigma_j = 0; the reference's torch.svd backward is infinite there).
+__global__ void __launch_bounds__(256) so3_mean_dir_backward_kernel(long T, int A, const float* __restrict__ w, const float* __restrict__ anchors,
+                                                                    const float* __restrict__ ddir, float* __restrict__ dw) {
+    __shared__ float sa[60 * 9];
+    for (int e = threadIdx.x; e < A * 9; e += 256) sa[e] = anchors[e];
+    __syncthreads();
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    double Ce[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float* wr = w + t * A;
+    for (int a = 0; a < A; ++a) {
+        const double wa = (double)wr[a];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Ce[k] += wa * (double)sa[a * 9 + k];
+    }
+    double U[9], S[3], V[9];
+    jacobi_svd3(Ce, U, S, V);
+    const double detU = U[0] * (U[4] * U[8] - U[5] * U[7]) - U[1] * (U[3] * U[8] - U[5] * U[6]) + U[2] * (U[3] * U[7] - U[4] * U[6]);
+    const double detV = V[0] * (V[4] * V[8] - V[5] * V[7]) - V[1] * (V[3] * V[8] - V[5] * V[6]) + V[2] * (V[3] * V[7] - V[4] * V[6]);
+    const double d = detU * detV;
+    const double sig[3] = {S[0], S[1], d * S[2]};
+    const double Dg[3] = {1.0, 1.0, d};
+    const double g[3] = {(double)ddir[t * 3], (double)ddir[t * 3 + 1], (double)ddir[t * 3 + 2]};     // G[i][2] = g[i], other columns 0
+    // A = D U^T G V:  (U^T G)[i][j] = (sum_k U[k][i] g[k]) * [j == 2]  ->  A[i][j] = Dg[i] * ug[i] * V[2][j]
+    double ug[3], Am[9], Z[9];
+    for (int i = 0; i < 3; ++i) ug[i] = U[i] * g[0] + U[3 + i] * g[1] + U[6 + i] * g[2];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Am[i * 3 + j] = Dg[i] * ug[i] * V[2 * 3 + j];
+    const double floor_ = 1e-12 * (S[0] > 0 ? S[0] : 1.0);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double den = sig[i] + sig[j];
+            if (fabs(den) < floor_) den = den < 0 ? -floor_ : floor_;
+            Z[i * 3 + j] = i == j ? 0.0 : (Am[i * 3 + j] - Am[j * 3 + i]) / den;
+        }
+    // dCe = U D Z V^T
+    double UDZ[9], dCe[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) UDZ[i * 3 + j] = U[i * 3] * Dg[0] * Z[j] + U[i * 3 + 1] * Dg[1] * Z[3 + j] + U[i * 3 + 2] * Dg[2] * Z[6 + j];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) dCe[i * 3 + j] = UDZ[i * 3] * V[j * 3] + UDZ[i * 3 + 1] * V[j * 3 + 1] + UDZ[i * 3 + 2] * V[j * 3 + 2];
+    float* dwr = dw + t * A;
+    for (int a = 0; a < A; ++a) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc += dCe[k] * (double)sa[a * 9 + k];
+        dwr[a] = (float)acc;
+    }
+}
+
 // so3_mean with the reference's general signature (so3conv.py:186-225): Rs (T,A,3,3) per row (rs_stride = A*9) or one shared set
 // (rs_stride = 0), weights (T,A) or none (all ones) -> R (T,3,3).  Same fp64 accumulation / Jacobi SVD / det fix as above.
 __global__ void __launch_bounds__(256) so3_mean_general_kernel(long T, int A, const float* __restrict__ Rs, long rs_stride,
@@ -459,6 +514,14 @@ int etch_so3_mean_dir(long T, int A, const float* w, const float* anchors, float
     if (T <= 0) return ETCH_OK;
     if (A != 60) return ETCH_EUNSUPPORTED;
     hipLaunchKernelGGL(so3_mean_dir_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream, T, A, w, anchors, dir, R, sv);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_so3_mean_dir_backward(long T, int A, const float* w, const float* anchors, const float* ddir, float* dw, void* stream) {
+    if (T <= 0) return ETCH_OK;
+    if (A <= 0 || A > 60 || !w || !anchors || !ddir || !dw) return ETCH_EINVAL;
+    hipLaunchKernelGGL(so3_mean_dir_backward_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream, T, A, w, anchors, ddir, dw);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }

@@ -196,6 +196,14 @@ int etch_rowdot(long R, int K, const float* x, long ldx, const float* w, float b
 /* so3_mean (src/models/so3conv.py:186-225) + R @ [0,0,1] (models_pointcloud.py:120-124): w (T,60), anchors (60,3,3)
  * -> dir (T,3); optional R (T,3,3) and singular values sv (T,3) (NULL to skip). */
 int etch_so3_mean_dir(long T, int A, const float* w, const float* anchors, float* dir, float* R, float* sv, void* stream);
+/* Backward of etch_so3_mean_dir (autograd through so3conv.py:186-225 + models_pointcloud.py:120-124 in train.py:77-85): ddir (T,3) = dL/d dir
+ * -> dw (T,A) = dL/d w.  Derivative of the polar factor through the 3x3 Sylvester equation in V's basis, fp64 per point. */
+int etch_so3_mean_dir_backward(long T, int A, const float* w, const float* anchors, const float* ddir, float* dw, void* stream);
+/* Backward of the 3-NN propagation (pointnet2_utils.py:45-74; forward etch_prop_interp) and of any weighted row gather:
+ * dst (nseg,C)[q] = sum_{k in [seg[q], seg[q+1])} wgt[perm[k]] * src[perm[k] / fan], perm = stable sort of the flattened (rows, fan) index
+ * list by target row, seg its offsets (int64): scatter-add in a fixed order.  C % 4 == 0. */
+int etch_weighted_segment_sum_rows(long nseg, int C, int fan, const float* src, const float* wgt, const long long* perm, const long long* seg,
+                                   float* dst, void* stream);
 
 /* ---- Point-Transformer heads (src/models/pointtransformer_seg.py) ------------------------------------------ */
 
