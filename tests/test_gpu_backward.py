@@ -315,7 +315,7 @@ def test_direction_loss_gradients_of_every_encoder_and_head_parameter(tmp_path):
         old = torch.get_default_dtype()
         torch.set_default_dtype(dtype)
         try:
-            sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in seeded_state_dict(model, 1).items()}
+            sd = {k: (v.cpu().to(dtype) if v.is_floating_point() else v.cpu()) for k, v in seeded_state_dict(model, 1).items()}
             for k in names:
                 sd[k] = sd[k].clone().requires_grad_()
             x = torch.from_numpy(pts).to(dtype)
