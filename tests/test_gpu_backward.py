@@ -285,13 +285,19 @@ def test_propagation_backward_vs_autograd():
 
 
 def test_direction_loss_gradients_of_every_encoder_and_head_parameter(tmp_path):
-    """VERDICT r02 task 7: the gradient of train.py's cosine direction loss (train.py:80-85) with respect to EVERY parameter of the EPN
-    encoder and the direction head, through the model's own forward in grad mode (etch_amd.autograd: hand-written backward kernels for the
-    inter / intra SO(3) convs, InstanceNorm + LeakyReLU, the 3-NN propagation, both attention layers, the linear layers and so3_mean),
-    against autograd through the oracle's restatement in fp64 -- N = 256, B = 2.  With seeded random weights sum_a w_a R_a is nearly
-    singular at many points and the polar projection's derivative blows up there, so the loss is taken over the points whose
-    projection is well conditioned (the same mask on both sides; mean over the mask).  Bar: 1e-4 of the tensor's largest gradient entry, or
-    twice what the oracle's own fp32 autograd loses against fp64 (the entitled-error rule of the forward tests)."""
+    """VERDICT r02 task 7: gradients with respect to EVERY parameter of the EPN encoder and the direction head through the model's own
+    forward in grad mode (etch_amd.autograd: hand-written backward kernels for the inter / intra SO(3) convs, InstanceNorm + LeakyReLU, the
+    3-NN propagation, both attention layers, the linear layers and so3_mean) against autograd through the oracle's restatement in fp64;
+    N = 256, B = 2.  Two losses:
+      (a) a random linear functional of the anchor weights (the output of so3_reg, models_pointcloud.py:117): well conditioned -> 1e-4 of each
+          tensor's largest gradient entry;
+      (b) train.py's cosine direction loss (train.py:80-85).  With seeded random weights the anchor weights are nearly constant over the 60
+          anchors and sum_a R_a = 0, so the polar projection sees only their tiny variation: the ORACLE's own fp32 autograd
+          lands 1e-2 - 1e-1 from its fp64 run on this loss.  Measured, not argued: the bar per tensor is twice the oracle's fp32 deviation (or
+          1e-4), over the points whose projection has a spectral gap (same mask on both sides).  so3_mean's backward alone is held to 1e-4 on
+          well-conditioned inputs in test_so3_mean_dir_backward_vs_autograd_of_the_svd_form.
+    Parameters whose gradient is identically zero (biases in front of an InstanceNorm, the first skip conv on constant occupancy features)
+    must come out as numerical zeros."""
     import types
 
     import torch.nn.functional as F
@@ -308,10 +314,12 @@ def test_direction_loss_gradients_of_every_encoder_and_head_parameter(tmp_path):
     rng = np.random.default_rng(8)
     vec = rng.standard_normal((B, N, 3))
     vec /= np.linalg.norm(vec, axis=-1, keepdims=True)
+    Gaw = rng.standard_normal((B * N, 60))
     names = [k for k, _ in model.named_parameters() if k.startswith(("encoder.", "direction_encoder.", "direction_predictor.", "so3_reg."))]
+    assert len(names) == 40
     table = S1.build_layer_table()
 
-    def oracle_grads(dtype, mask=None):
+    def oracle_grads(dtype, which, mask=None):
         old = torch.get_default_dtype()
         torch.set_default_dtype(dtype)
         try:
@@ -321,55 +329,73 @@ def test_direction_loss_gradients_of_every_encoder_and_head_parameter(tmp_path):
             x = torch.from_numpy(pts).to(dtype)
             xyz, feats = S1.encoder_forward(sd, x, table)
             S_ = xyz.shape[-1]
-            pef = S1.feat_propagation(x.permute(0, 2, 1), xyz, feats.permute(0, 1, 3, 2).reshape(B, -1, S_)).reshape(B, N, -1, 60)
+            pef = S1.feat_propagation(x.permute(0, 2, 1), xyz.to(dtype), feats.permute(0, 1, 3, 2).reshape(B, -1, S_)).reshape(B, N, -1, 60)
             aw = S1.direction_anchor_weights(sd, pef)
-            R, Ce, sv = S1.so3_mean(sd["encoder.backbone.1.blocks.1.intra_conv.conv.anchors"], aw)
-            d = R[:, :, 2].reshape(B, N, 3)
-            if mask is None:
-                sig = torch.stack([sv[:, 0], sv[:, 1], torch.det(Ce).sign() * sv[:, 2]], 1)
-                gap = torch.stack([sig[:, 0] + sig[:, 1], sig[:, 0] + sig[:, 2], sig[:, 1] + sig[:, 2]], 1).min(1).values
-                mask = (gap > 0.25 * sv[:, 0]).reshape(B, N).detach()
-            m = mask.to(dtype)
-            loss = ((1 - F.cosine_similarity(torch.from_numpy(vec).to(dtype), d, dim=-1)) * m).sum() / m.sum()
+            if which == "aw":
+                loss = (aw * torch.from_numpy(Gaw).to(dtype)).sum()
+            else:
+                R, Ce, sv = S1.so3_mean(sd["encoder.backbone.1.blocks.1.intra_conv.conv.anchors"], aw)
+                d = R[:, :, 2].reshape(B, N, 3)
+                if mask is None:
+                    sig = torch.stack([sv[:, 0], sv[:, 1], torch.det(Ce.detach()).sign() * sv[:, 2]], 1).detach()
+                    gap = torch.stack([sig[:, 0] + sig[:, 1], sig[:, 0] + sig[:, 2], sig[:, 1] + sig[:, 2]], 1).min(1).values
+                    mask = (gap > 0.25 * sv[:, 0].detach()).reshape(B, N)
+                m = mask.to(dtype)
+                loss = ((1 - F.cosine_similarity(torch.from_numpy(vec).to(dtype), d, dim=-1)) * m).sum() / m.sum()
             loss.backward()
-            return {k: sd[k].grad.detach().double().numpy() for k in names}, mask, float(loss), aw.detach()
+            return {k: sd[k].grad.detach().double().numpy() for k in names}, mask, float(loss.detach()), aw.detach()
         finally:
             torch.set_default_dtype(old)
 
-    g64, mask, loss64, aw64 = oracle_grads(torch.float64)
-    assert 0.15 < float(mask.float().mean()) < 1.0
-    g32, _, _, _ = oracle_grads(torch.float32, mask)
-
-    def gpu_grads():
+    def gpu_grads(which, mask=None):
         model.zero_grad(set_to_none=True)
         res, sel = model(torch.from_numpy(pts).cuda(), ["direction"], "standard_vector")
         assert res["direction"].requires_grad and sel.shape == (B, N, 3)
-        m = mask.float().cuda()
-        loss = ((1 - F.cosine_similarity(torch.from_numpy(vec.astype(np.float32)).cuda(), res["direction"], dim=-1)) * m).sum() / m.sum()
+        if which == "aw":
+            loss = (model.last_anc_w.reshape(B * N, 60) * torch.from_numpy(Gaw.astype(np.float32)).cuda()).sum()
+        else:
+            m = mask.float().cuda()
+            loss = ((1 - F.cosine_similarity(torch.from_numpy(vec.astype(np.float32)).cuda(), res["direction"], dim=-1)) * m).sum() / m.sum()
         loss.backward()
-        return {k: p.grad.detach().clone() for k, p in model.named_parameters() if k in names}, float(loss)
+        return {k: p.grad.detach().clone() for k, p in model.named_parameters() if k in names}, float(loss.detach())
 
-    gg, loss_gpu = gpu_grads()
-    assert abs(loss_gpu - loss64) < 1e-4 * max(1.0, abs(loss64))
+    def compare(gg, g64, g32, tag):
+        top = max(np.abs(v).max() for v in g64.values())
+        worst = []
+        for k in names:
+            assert gg[k] is not None, k
+            mine = gg[k].cpu().double().numpy().reshape(g64[k].shape)
+            scale = np.abs(g64[k]).max()
+            if scale < 1e-6 * top:                                       # identically zero gradient: a numerical zero, not a ratio
+                assert np.abs(mine).max() < 1e-4 * top, (tag, k, np.abs(mine).max())
+                continue
+            e_gpu = np.abs(mine - g64[k]).max() / scale
+            e_ref = 0.0 if g32 is None else np.abs(g32[k] - g64[k]).max() / scale
+            worst.append((e_gpu, e_ref, k))
+            assert e_gpu <= max(1e-4, 2.0 * e_ref), (tag, k, e_gpu, e_ref)
+        worst.sort(reverse=True)
+        print(f"{tag}: {len(worst)} tensors with a gradient; largest deviations from the fp64 oracle (gpu / oracle fp32):",
+              [(k, "%.1e / %.1e" % (a_, b_)) for a_, b_, k in worst[:3]])
+        return len(worst)
+
+    # (a) linear functional of the anchor weights: strict
+    g64, _, l64, aw64 = oracle_grads(torch.float64, "aw")
+    gg, lg = gpu_grads("aw")
     assert rel_err(model.last_anc_w.detach().cpu().numpy().reshape(-1, 60), aw64.numpy()) < 1e-4
-    worst = {}
+    assert abs(lg - l64) < 1e-4 * max(1.0, np.abs(Gaw).sum() * float(aw64.abs().max()))
+    assert compare(gg, g64, None, "anchor-weight functional") >= 25
+    g2, _ = gpu_grads("aw")
     for k in names:
-        assert gg[k] is not None, k
-        scale = np.abs(g64[k]).max()
-        assert scale > 0, k
-        e_gpu = np.abs(gg[k].cpu().double().numpy().reshape(g64[k].shape) - g64[k]).max() / scale
-        e_ref = np.abs(g32[k] - g64[k]).max() / scale
-        worst[k] = (e_gpu, e_ref)
-        assert e_gpu <= max(1e-4, 2.0 * e_ref), (k, e_gpu, e_ref)
-    top = sorted(worst.items(), key=lambda kv: -kv[1][0])[:4]
-    print("direction-loss gradients, %d parameter tensors; largest deviations (gpu, oracle fp32) vs fp64:" % len(names),
-          [(k, "%.1e / %.1e" % v) for k, v in top])
-    # untouched heads get no gradient; a second pass reproduces every bit
+        assert torch.equal(g2[k], gg[k]), k                              # bitwise reproducible
+    # (b) the cosine direction loss over the well-gapped points: as close to fp64 as the oracle's own fp32 autograd (x2)
+    c64, mask, lc64, _ = oracle_grads(torch.float64, "cos")
+    assert 0.15 < float(mask.float().mean()) < 1.0
+    c32, _, _, _ = oracle_grads(torch.float32, "cos", mask)
+    cg, lcg = gpu_grads("cos", mask)
+    assert abs(lcg - lc64) < 2e-3
+    compare(cg, c64, c32, "cosine direction loss")
+    # untouched heads get no gradient; in no_grad mode the same call takes the fused inference path
     assert all(p.grad is None for k, p in model.named_parameters() if k.startswith(("confidence_encoder.", "magnitude_encoder.")))
-    g2, _ = gpu_grads()
-    for k in names:
-        assert torch.equal(g2[k], gg[k]), k
-    # in no_grad mode the same call takes the fused inference path and gives the same direction (to fp32 rounding of a different order)
     with torch.no_grad():
         res0, _ = model(torch.from_numpy(pts).cuda(), ["direction"], "standard_vector")
     assert not res0["direction"].requires_grad
