@@ -359,7 +359,7 @@ def test_direction_loss_gradients_of_every_encoder_and_head_parameter(tmp_path):
         loss.backward()
         return {k: p.grad.detach().clone() for k, p in model.named_parameters() if k in names}, float(loss.detach())
 
-    def compare(gg, g64, g32, tag):
+    def compare(gg, g64, g32, tag, tol=1e-4):
         top = max(np.abs(v).max() for v in g64.values())
         worst = []
         for k in names:
@@ -372,10 +372,11 @@ def test_direction_loss_gradients_of_every_encoder_and_head_parameter(tmp_path):
             e_gpu = np.abs(mine - g64[k]).max() / scale
             e_ref = 0.0 if g32 is None else np.abs(g32[k] - g64[k]).max() / scale
             worst.append((e_gpu, e_ref, k))
-            assert e_gpu <= max(1e-4, 2.0 * e_ref), (tag, k, e_gpu, e_ref)
         worst.sort(reverse=True)
         print(f"{tag}: {len(worst)} tensors with a gradient; largest deviations from the fp64 oracle (gpu / oracle fp32):",
-              [(k, "%.1e / %.1e" % (a_, b_)) for a_, b_, k in worst[:3]])
+              [(k, "%.1e / %.1e" % (a_, b_)) for a_, b_, k in worst[:12]])
+        for e_gpu, e_ref, k in worst:
+            assert e_gpu <= max(tol, 2.0 * e_ref), (tag, k, e_gpu, e_ref)
         return len(worst)
 
     # (a) linear functional of the anchor weights: strict
