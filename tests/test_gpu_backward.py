@@ -396,9 +396,10 @@ def test_direction_loss_gradients_of_every_encoder_and_head_parameter(tmp_path):
     # (b) the cosine direction loss over the well-gapped points: as close to fp64 as the oracle's own fp32 autograd (x2)
     c64, mask, lc64, _ = oracle_grads(torch.float64, "cos")
     assert 0.15 < float(mask.float().mean()) < 1.0
-    c32, _, _, _ = oracle_grads(torch.float32, "cos", mask)
+    c32, _, lc32, _ = oracle_grads(torch.float32, "cos", mask)
     cg, lcg = gpu_grads("cos", mask)
-    assert abs(lcg - lc64) < 2e-3
+    print("masked cosine loss: fp64 oracle %.6f, fp32 oracle %.6f, gpu %.6f" % (lc64, lc32, lcg))
+    assert abs(lcg - lc64) <= max(2e-3, 2.0 * abs(lc32 - lc64))
     compare(cg, c64, c32, "cosine direction loss", tol=TOL)
     # untouched heads get no gradient; in no_grad mode the same call takes the fused inference path
     assert all(p.grad is None for k, p in model.named_parameters() if k.startswith(("confidence_encoder.", "magnitude_encoder.")))
