@@ -371,7 +371,7 @@ def test_direction_loss_gradients_of_every_encoder_and_head_parameter(tmp_path):
             mine = gg[k].cpu().double().numpy().reshape(g64[k].shape)
             scale = np.abs(g64[k]).max()
             if scale < 1e-6 * top:                                       # identically zero gradient: a numerical zero, not a ratio
-                assert np.abs(mine).max() < 1e-4 * top, (tag, k, np.abs(mine).max())
+                assert np.abs(mine).max() <= max(1e-4 * top, 4.0 * np.abs(g32[k]).max()), (tag, k, np.abs(mine).max(), np.abs(g32[k]).max())
                 continue
             l2 = lambda a: float(np.linalg.norm((a - g64[k]).ravel()) / np.linalg.norm(g64[k].ravel()))
             rows.append((l2(mine), l2(g32[k]), float(np.abs(mine - g64[k]).max() / scale), float(np.abs(g32[k] - g64[k]).max() / scale), k))
