@@ -109,8 +109,9 @@ def main(argv=None):
         from .utils.body_model import SyntheticSMPL
         args.body_model = SyntheticSMPL(7)
     elif args.body_model:
-        from .utils.body_model import load_smpl_pkl
-        args.body_model = load_smpl_pkl(args.body_model)
+        from .utils.body_model import load_smpl_pkl, load_smplx
+        # an SMPL-X model file (SMPLX_*.npz / .pkl) selects the 55-joint, 20-coefficient fit; anything else is read as an SMPL pickle
+        args.body_model = load_smplx(args.body_model) if "smplx" in os.path.basename(args.body_model).lower() else load_smpl_pkl(args.body_model)
     else:
         args.body_model = None
     os.makedirs(args.output_folder, exist_ok=True)

@@ -94,3 +94,43 @@ def load_smpl_pkl(path, num_betas=10):
     parents[0] = -1
     return BodyModel(np.asarray(d["v_template"]), np.asarray(d["shapedirs"])[:, :, :num_betas], posedirs, Jr, np.asarray(d["weights"]),
                      parents, np.asarray(d["f"]))
+
+
+# vertex ids of the 21 tip / face / foot joints smplx's VertexJointSelector appends for SMPL-X (smplx/vertex_ids.py, 'smplx' table, in the
+# selector's order: nose, reye, leye, rear, lear, LBigToe, LSmallToe, LHeel, RBigToe, RSmallToe, RHeel, then thumb..pinky tips left, right)
+# [upstream smplx, public]
+SMPLX_EXTRA_JOINT_VIDS = np.array([9120, 9929, 9448, 616, 6, 5770, 5780, 8846, 8463, 8474, 8635,
+                                   5361, 4933, 5058, 5169, 5286, 8079, 7669, 7794, 7905, 8022], np.int32)
+
+
+def load_smplx(path, num_betas=10, num_expression_coeffs=10):
+    """A real SMPL-X model file as distributed by smpl-x.is.tue.mpg.de (SMPLX_{NEUTRAL,MALE,FEMALE}.npz or the chumpy-free .pkl): keys
+    v_template (10475,3), shapedirs (10475,3,400: 300 shape + 100 expression components), posedirs (10475,3,486), J_regressor (55,10475),
+    weights (10475,55), kintree_table (2,55), f.  BASELINE configs[4] names SMPL-X; the reference itself only loads SMPL
+    (src/models/fit_SMPL.py:92-101).  Returns a BodyModel whose coefficient vector is [betas[:num_betas] | expression[:num_expression_coeffs]]
+    (the LM kernel is instantiated for 55 joints x 20 coefficients: the defaults), pose = 54 x 3 (body 21, jaw, eyes 2, hands 2 x 15, full
+    axis-angle hands: no PCA), joints = 55 regressed + the 21 vertex-picked ones (the 51 + 17 face landmarks of smplx's full output are not
+    appended)."""
+    if str(path).endswith(".npz"):
+        d = dict(np.load(path, allow_pickle=True))
+    else:
+        with open(path, "rb") as f:
+            d = pickle.load(f, encoding="latin1")
+    sd = np.asarray(d["shapedirs"])
+    n_shape_total = 300 if sd.shape[2] >= 400 else sd.shape[2] - min(100, sd.shape[2] // 4)
+    shape = sd[:, :, :num_betas]
+    expr = sd[:, :, n_shape_total:n_shape_total + num_expression_coeffs]
+    if expr.shape[2] != num_expression_coeffs or shape.shape[2] != num_betas:
+        raise ValueError(f"{path}: shapedirs has {sd.shape[2]} components, cannot take {num_betas} shape + {num_expression_coeffs} expression")
+    Jr = d["J_regressor"]
+    Jr = np.asarray(Jr.todense()) if hasattr(Jr, "todense") else np.asarray(Jr)
+    posedirs = np.asarray(d["posedirs"])
+    V = posedirs.shape[0]
+    posedirs = posedirs.reshape(V * 3, -1).T                                   # smplx: (9 * 54, V * 3)
+    parents = np.asarray(d["kintree_table"])[0].astype(np.int64).copy()
+    parents[0] = -1
+    if len(parents) != 55 or not np.array_equal(parents[1:], SMPLX_PARENTS[1:]):
+        raise ValueError(f"{path}: not the 55-joint SMPL-X kinematic tree")
+    extra = SMPLX_EXTRA_JOINT_VIDS if V > int(SMPLX_EXTRA_JOINT_VIDS.max()) else SMPL_EXTRA_JOINT_VIDS
+    return BodyModel(np.asarray(d["v_template"]), np.concatenate([shape, expr], 2), posedirs, Jr, np.asarray(d["weights"]), parents,
+                     np.asarray(d["f"]), extra)

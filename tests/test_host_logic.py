@@ -230,3 +230,34 @@ def test_transition_down_offsets_and_too_small_scans():
     assert downsampled_offsets([7, 19], 4) == [1, 4]
     with pytest.raises(ValueError, match="at least 256 points"):
         downsampled_offsets([1250, 1253], 4)
+
+
+def test_load_smplx_reads_the_distributed_file_layout(tmp_path):
+    """load_smplx on files written in the layout of SMPLX_NEUTRAL.npz / .pkl (400 shape + expression components, 486 pose-basis columns,
+    55-joint kintree): the coefficient vector is [10 betas | 10 expression], arrays land in the smplx buffer layout, a wrong tree is refused."""
+    import pickle
+
+    import pytest
+
+    from etch_amd.utils import body_model as BM
+    rng = np.random.default_rng(0)
+    V = 10475
+    d = dict(v_template=rng.standard_normal((V, 3)), shapedirs=rng.standard_normal((V, 3, 400)).astype(np.float32),
+             posedirs=rng.standard_normal((V, 3, 486)).astype(np.float32), J_regressor=rng.random((55, V)).astype(np.float32),
+             weights=rng.random((V, 55)).astype(np.float32), kintree_table=np.stack([np.where(BM.SMPLX_PARENTS < 0, 2 ** 32 - 1, BM.SMPLX_PARENTS),
+                                                                                     np.arange(55)]).astype(np.uint32),
+             f=rng.integers(0, V, (20908, 3)).astype(np.uint32))
+    np.savez(tmp_path / "SMPLX_NEUTRAL.npz", **d)
+    with open(tmp_path / "SMPLX_NEUTRAL.pkl", "wb") as fh:
+        pickle.dump(d, fh)
+    for name in ("SMPLX_NEUTRAL.npz", "SMPLX_NEUTRAL.pkl"):
+        bm = BM.load_smplx(str(tmp_path / name))
+        assert (bm.num_joints, bm.num_betas, bm.num_verts) == (55, 20, V)
+        assert np.array_equal(bm.parents, BM.SMPLX_PARENTS)
+        assert np.array_equal(bm.shapedirs[:, :, :10], d["shapedirs"][:, :, :10]) and np.array_equal(bm.shapedirs[:, :, 10:], d["shapedirs"][:, :, 300:310])
+        assert bm.posedirs.shape == (486, V * 3) and bm.posedirs[7, 3 * 5 + 2] == d["posedirs"][5, 2, 7]
+        assert np.array_equal(bm.extra_vids, BM.SMPLX_EXTRA_JOINT_VIDS) and bm.extra_vids.max() < V
+    d["kintree_table"][0, 30] = 3
+    np.savez(tmp_path / "bad.npz", **d)
+    with pytest.raises(ValueError, match="kinematic tree"):
+        BM.load_smplx(str(tmp_path / "bad.npz"))
