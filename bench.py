@@ -202,17 +202,25 @@ def stage2_latency(args, device, iters, batch):
         verts, _ = ops.smpl_lbs(db.lbs_consts, torch.from_numpy(x).to(device), db.V, db.n_extra, nj=db.nj, nb=db.nb)
         tgt = verts[:, torch.from_numpy(mv).to(device).long()] + torch.from_numpy(rng.standard_normal((bsz, len(mv), 3)).astype(np.float32) * 0.002).to(device)
         valid = torch.ones((bsz, len(mv)), dtype=torch.float32, device=device)
-        best = None
-        for _ in range(3):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            _, _, tr = ops.smpl_lm_fit(db.lm_consts, tgt.contiguous(), valid, iters[0], 0.5, 0.01, iters[1], 0.2, 1e-3, True, nj=db.nj, nb=db.nb)
-            e.record()
-            torch.cuda.synchronize()
-            best = s.elapsed_time(e) if best is None else min(best, s.elapsed_time(e))
+        def timed(split):
+            best, tr = None, None
+            for _ in range(3):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                _, _, tr = ops.smpl_lm_fit(db.lm_consts, tgt.contiguous(), valid, iters[0], 0.5, 0.01, iters[1], 0.2, 1e-3, True, nj=db.nj, nb=db.nb,
+                                           split=split)
+                e.record()
+                torch.cuda.synchronize()
+                best = s.elapsed_time(e) if best is None else min(best, s.elapsed_time(e))
+            return best, tr
+        best, tr = timed(None)                     # the default: split over LM_SPLIT_WGS workgroups per scan for small batches
         frozen = float((tr[:, 1:] == tr[:, :-1]).sum(1).float().mean())
         out[f"batch_{bsz}"] = {"ms": round(best, 3), "us_per_iteration": round(best * 1e3 / (iters[0] + iters[1] + 2), 1),
-                               "iterations_skipped_by_the_convergence_freeze": frozen}
+                               "iterations_skipped_by_the_convergence_freeze": frozen,
+                               "workgroups_per_scan": ops.LM_SPLIT_WGS if bsz <= ops.LM_SPLIT_MAX_BATCH else 1}
+        if bsz <= ops.LM_SPLIT_MAX_BATCH:
+            one, _ = timed(1)
+            out[f"batch_{bsz}"]["ms_one_workgroup_per_scan"] = round(one, 3)
     out["schedule"] = f"{iters[0]}+{iters[1]} iterations, 86 valid markers with 2 mm noise"
     return out
 

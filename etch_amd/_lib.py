@@ -55,6 +55,7 @@ def lib():
         for name in declared_symbols():
             fn = getattr(cdll, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = ctypes.c_int
+        cdll.etch_smpl_lm_split_workspace_bytes.restype = ctypes.c_long
         for name in declared_launchers():
             getattr(cdll, name).restype = None
         _lib = _Proxy(cdll)

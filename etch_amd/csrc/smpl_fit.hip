@@ -211,12 +211,25 @@ __device__ void lm_setup(LmShared<BM>& s, const SmplConsts& C, int M, const floa
     __syncthreads();
 }
 
+// A scan's linearisation split over G workgroups (latency regime: B <= 8 scans leave most of the chip idle): workgroup g of a scan takes the
+// marker chunks g, g + G, ...; the partial tiles of [J | r]^T [J | r] meet in global memory once per linearisation and every workgroup adds
+// them in the SAME order (g = 0 .. G-1), so all G copies of the scan's state stay bit-identical and solve redundantly -- no second exchange.
+// ws: [2 parities][G][SLOTS = WAVES * TPW][64 lanes][4] fp64 (double-buffered by the linearisation count), ctr: arrival counter.
+struct LmSplit {
+    int g, G;
+    double* ws;
+    unsigned* ctr;
+    unsigned count;         // linearisations exchanged so far (uniform over the scan's workgroups)
+};
+
 // residual + normal equations at s.x.  nb = number of active betas (2 in stage 0, NB in stage 1).  On return s.A holds the packed
 // lower triangle of J^T J (no damping yet) with the right-hand side -J^T r as row DOF, s.resid / s.err the residual and 0.5 |r|^2.
 // jac_out (diagnostics): the marker rows of J (3M x DOF) are also written to global memory.  grad_only (first-order fitter): only the
 // tile row that holds -J^T r is accumulated; the J^T J entries of s.A are then undefined.
 template <class BM>
-__device__ __attribute__((noinline)) void lm_linearize(LmShared<BM>& s, const SmplConsts& C, int M, int nb, float* __restrict__ jac_out, bool grad_only = false) {
+__device__ __attribute__((noinline)) void lm_linearize(LmShared<BM>& s, const SmplConsts& C, int M, int nb, float* __restrict__ jac_out, bool grad_only = false,
+                                                       LmSplit* sp = nullptr) {
+    const int grp_g = sp ? sp->g : 0, grp_G = sp ? sp->G : 1;
     constexpr int NJ = BM::NJ, NB = BM::NB, NPOSE = BM::NPOSE, NPF = BM::NPF, DOF = BM::DOF, LDJ = BM::LDJ, LDJS = BM::LDJS;
     LmLin<BM>& L = s.lin;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile indices stay in SGPRs
@@ -429,10 +442,10 @@ __device__ __attribute__((noinline)) void lm_linearize(LmShared<BM>& s, const Sm
     const int nchunk = (M + MC - 1) / MC;
     constexpr int NU = NB + 1;                                     // (marker, u) items of pass C besides the joints
     float wnext = 0.f;                                             // skinning weight of this thread's (marker, joint) item of the NEXT chunk
-    if (tid < MC * NJ && tid / NJ < M) wnext = C.mk_W[(size_t)(tid / NJ) * NJ + tid % NJ];
-    for (int ch = 0; ch < nchunk; ++ch) {
+    if (tid < MC * NJ && grp_g * MC + tid / NJ < M) wnext = C.mk_W[(size_t)(grp_g * MC + tid / NJ) * NJ + tid % NJ];
+    for (int ch = grp_g, ci = 0; ch < nchunk; ch += grp_G, ++ci) {       // this workgroup's chunks (all of them when the scan is not split)
         const int v0 = ch * MC;
-        float* Jb = L.Jc[ch & 1];
+        float* Jb = L.Jc[ci & 1];
 #if LM_TIMERS
         if (tid == 0) tp = wall_clock64();
 #endif
@@ -443,7 +456,7 @@ __device__ __attribute__((noinline)) void lm_linearize(LmShared<BM>& s, const Sm
         if (tid < MC * NJ) {
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             const float wcur = wnext;
-            if (v0 + MC + jm < M) wnext = C.mk_W[(size_t)(v0 + MC + jm) * NJ + jj];
+            if (v0 + grp_G * MC + jm < M) wnext = C.mk_W[(size_t)(v0 + grp_G * MC + jm) * NJ + jj];
             if (jlive) {
                 const double wj = (double)wcur;
                 if (jj >= 1) {
@@ -577,6 +590,40 @@ __device__ __attribute__((noinline)) void lm_linearize(LmShared<BM>& s, const Sm
         if (lane == 0) s.err = 0.5 * (double)e;
     }
     __syncthreads();           // every read of the linearisation scratch is done: the packed matrix may overwrite it
+    if (sp && grp_G > 1) {
+        // exchange of the partial tiles: write mine, arrive, wait for the scan's other workgroups, add all G partials in the order g = 0..G-1
+        constexpr int SLOTS = BM::WAVES * BM::TPW;
+        double* base = sp->ws + (size_t)(sp->count & 1u) * grp_G * SLOTS * 256;
+#pragma unroll
+        for (int t = 0; t < BM::TPW; ++t) {
+            double* dst = base + ((size_t)grp_g * SLOTS + wave + BM::WAVES * t) * 256 + lane * 4;
+            dst[0] = acc[t][0]; dst[1] = acc[t][1]; dst[2] = acc[t][2]; dst[3] = acc[t][3];
+        }
+        __threadfence();                                           // release: my partial tiles are visible device-wide ...
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(sp->ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned want = (unsigned)grp_G * (sp->count + 1u);
+            unsigned spins = 0;
+            while (__hip_atomic_load(sp->ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 27)) break;                   // partner workgroups never showed up (> ~10 s): give up instead of hanging the GPU
+            }
+        }
+        __syncthreads();
+        __threadfence();                                           // ... acquire: the others' tiles are read from memory, not from a stale cache line
+#pragma unroll
+        for (int t = 0; t < BM::TPW; ++t) {
+            f64x4 tot = {0.0, 0.0, 0.0, 0.0};
+            for (int g2 = 0; g2 < grp_G; ++g2) {
+                const double* src = base + ((size_t)g2 * SLOTS + wave + BM::WAVES * t) * 256 + lane * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tot[q] += __hip_atomic_load(src + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            acc[t] = tot;
+        }
+        ++sp->count;
+    }
     {
         // v_mfma_f64_16x16x4_f64 result layout: D[row = (lane >> 4) + 4 q][col = lane & 15]
         const int fr = lane & 15, fg = lane >> 4;
@@ -886,11 +933,15 @@ template <class BM>
 __global__ void __launch_bounds__(BM::THREADS) smpl_lm_fit_kernel(SmplConsts C, int M, const float* __restrict__ markers,
                                                                 const float* __restrict__ valid, int it0, float step0, float damp0,
                                                                 int it1, float step1, float damp1, float* __restrict__ x_out,
-                                                                float* __restrict__ x_stage0, float* __restrict__ err_trace, long long* __restrict__ phase_out) {
+                                                                float* __restrict__ x_stage0, float* __restrict__ err_trace, long long* __restrict__ phase_out,
+                                                                int G, double* __restrict__ split_ws, unsigned* __restrict__ split_ctr) {
     constexpr int DOF = BM::DOF;
     extern __shared__ __attribute__((aligned(16))) unsigned char lm_smem[];
     LmShared<BM>& s = *reinterpret_cast<LmShared<BM>*>(lm_smem);
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x / G, tid = threadIdx.x;
+    const bool lead = blockIdx.x % G == 0;                      // the scan's workgroup that writes the results (all G hold the same state)
+    LmSplit split{(int)(blockIdx.x % G), G, split_ws + (size_t)b * 2 * G * BM::WAVES * BM::TPW * 256, split_ctr + (size_t)b * 64, 0u};
+    if (!lead) { x_stage0 = nullptr; err_trace = nullptr; phase_out = nullptr; }
     for (int i = tid; i < DOF; i += BM::THREADS) s.x[i] = 0.0;
     lm_setup(s, C, M, markers + (size_t)b * M * 3, valid + (size_t)b * M);
     int trace_pos = 0;
@@ -908,7 +959,7 @@ __global__ void __launch_bounds__(BM::THREADS) smpl_lm_fit_kernel(SmplConsts C, 
                     for (int i = tid; i < DOF; i += BM::THREADS) s.x[i] += step * s.delta[i];
                     __syncthreads();
                 }
-                lm_linearize(s, C, M, nb, nullptr);
+                lm_linearize(s, C, M, nb, nullptr, false, G > 1 ? &split : nullptr);
                 const float err = (float)s.err;
                 if (it >= 0) {
                     const float a = fabsf(last - err);
@@ -923,7 +974,8 @@ __global__ void __launch_bounds__(BM::THREADS) smpl_lm_fit_kernel(SmplConsts C, 
             for (int i = tid; i < DOF; i += BM::THREADS) x_stage0[(size_t)b * DOF + i] = (float)s.x[i];
         __syncthreads();
     }
-    for (int i = tid; i < DOF; i += BM::THREADS) x_out[(size_t)b * DOF + i] = (float)s.x[i];
+    if (lead)
+        for (int i = tid; i < DOF; i += BM::THREADS) x_out[(size_t)b * DOF + i] = (float)s.x[i];
     if (phase_out && tid < 8) phase_out[(size_t)b * 8 + tid] = s.phase[tid];
 }
 
@@ -1215,14 +1267,30 @@ static inline SmplConsts lm_consts(const void* const* consts) {
 }
 
 template <class BM>
+static size_t lm_split_bytes(int B, int G) {       // arrival counters (one 256-byte line per scan) + the double-buffered partial tiles
+    return (size_t)B * 256 + (size_t)B * 2 * G * BM::WAVES * BM::TPW * 256 * sizeof(double);
+}
+
+template <class BM>
 static int launch_lm_fit(int B, int M, const void* const* consts, const float* markers, const float* valid, int it0, float step0, float damp0,
-                         int it1, float step1, float damp1, float* x_out, float* x_stage0, float* err_trace, long long* phase_ticks, hipStream_t st) {
+                         int it1, float step1, float damp1, float* x_out, float* x_stage0, float* err_trace, long long* phase_ticks, int G,
+                         void* workspace, hipStream_t st) {
     const int lds = (int)sizeof(LmShared<BM>);
     static_assert(sizeof(LmShared<BM>) <= 160 * 1024, "LM state must fit the 160 KB LDS of a gfx950 CU");
     hipError_t e = hipFuncSetAttribute((const void*)smpl_lm_fit_kernel<BM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(smpl_lm_fit_kernel<BM>, dim3(B), dim3(BM::THREADS), lds, st, lm_consts(consts), M, markers, valid, it0, step0, damp0, it1,
-                       step1, damp1, x_out, x_stage0, err_trace, phase_ticks);
+    unsigned* ctr = nullptr;
+    double* ws = nullptr;
+    if (G > 1) {
+        // every workgroup of a scan must be resident at the same time (they wait for each other): one workgroup per CU (LDS), so B * G <= CUs
+        if (!workspace || (long)B * G > etch_cu_count()) return ETCH_EUNSUPPORTED;
+        ctr = reinterpret_cast<unsigned*>(workspace);
+        ws = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(workspace) + (size_t)B * 256);
+        e = hipMemsetAsync(workspace, 0, (size_t)B * 256, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(smpl_lm_fit_kernel<BM>, dim3(B * G), dim3(BM::THREADS), lds, st, lm_consts(consts), M, markers, valid, it0, step0, damp0, it1,
+                       step1, damp1, x_out, x_stage0, err_trace, phase_ticks, G, ws, reinterpret_cast<unsigned*>(ctr ? ctr : nullptr));
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }
@@ -1294,15 +1362,31 @@ int etch_smpl_lm_workspace_bytes(int nj, int nb) {
 }
 
 // consts: 7 device pointers {J0, Jd, parents, mk_vt, mk_S, mk_P, mk_W}
+int etch_smpl_lm_fit_split(int B, int M, int nj, int nb, const void* const* consts, const float* markers, const float* valid, int it0, float step0,
+                           float damp0, int it1, float step1, float damp1, float* x_out, float* x_stage0, float* err_trace, long long* phase_ticks,
+                           int G, void* workspace, void* stream) {
+    if (B <= 0) return ETCH_OK;
+    if (M <= 0 || M > LM_MAXM || G < 1 || G > 8) return ETCH_EUNSUPPORTED;
+    if (nj == 24 && nb == 10)
+        return launch_lm_fit<BodySMPL>(B, M, consts, markers, valid, it0, step0, damp0, it1, step1, damp1, x_out, x_stage0, err_trace, phase_ticks, G,
+                                       workspace, (hipStream_t)stream);
+    if (nj == 55 && nb == 20)
+        return launch_lm_fit<BodySMPLX>(B, M, consts, markers, valid, it0, step0, damp0, it1, step1, damp1, x_out, x_stage0, err_trace, phase_ticks, G,
+                                        workspace, (hipStream_t)stream);
+    return ETCH_EUNSUPPORTED;
+}
+
+long etch_smpl_lm_split_workspace_bytes(int B, int nj, int nb, int G) {
+    if (B <= 0 || G <= 1) return 0;
+    if (nj == 24 && nb == 10) return (long)lm_split_bytes<BodySMPL>(B, G);
+    if (nj == 55 && nb == 20) return (long)lm_split_bytes<BodySMPLX>(B, G);
+    return ETCH_EUNSUPPORTED;
+}
+
 int etch_smpl_lm_fit(int B, int M, int nj, int nb, const void* const* consts, const float* markers, const float* valid, int it0, float step0,
                      float damp0, int it1, float step1, float damp1, float* x_out, float* x_stage0, float* err_trace, long long* phase_ticks, void* stream) {
-    if (B <= 0) return ETCH_OK;
-    if (M <= 0 || M > LM_MAXM) return ETCH_EUNSUPPORTED;
-    if (nj == 24 && nb == 10)
-        return launch_lm_fit<BodySMPL>(B, M, consts, markers, valid, it0, step0, damp0, it1, step1, damp1, x_out, x_stage0, err_trace, phase_ticks, (hipStream_t)stream);
-    if (nj == 55 && nb == 20)
-        return launch_lm_fit<BodySMPLX>(B, M, consts, markers, valid, it0, step0, damp0, it1, step1, damp1, x_out, x_stage0, err_trace, phase_ticks, (hipStream_t)stream);
-    return ETCH_EUNSUPPORTED;
+    return etch_smpl_lm_fit_split(B, M, nj, nb, consts, markers, valid, it0, step0, damp0, it1, step1, damp1, x_out, x_stage0, err_trace, phase_ticks, 1,
+                                  nullptr, stream);
 }
 
 int etch_smpl_adam_fit(int B, int M, int nj, int nb, const void* const* consts, const float* markers, const float* valid, int it0, int it1,

@@ -535,17 +535,27 @@ def get_markers(points, labels, conf, num_markers):
     return markers, valid_f, valid_b
 
 
-def smpl_lm_fit(consts, markers, valid_f, it0, step0, damp0, it1, step1, damp1, want_trace=False, phase_ticks=None, nj=24, nb=10):
-    """x (B, 3 nj + nb + 3) = pose | betas | orient | transl.  (nj, nb) = (24, 10) SMPL or (55, 20) SMPL-X-sized."""
+LM_SPLIT_MAX_BATCH = 8     # scans per launch up to which a scan's linearisation is split over several workgroups (latency regime)
+LM_SPLIT_WGS = 3
+
+
+def smpl_lm_fit(consts, markers, valid_f, it0, step0, damp0, it1, step1, damp1, want_trace=False, phase_ticks=None, nj=24, nb=10, split=None):
+    """x (B, 3 nj + nb + 3) = pose | betas | orient | transl.  (nj, nb) = (24, 10) SMPL or (55, 20) SMPL-X-sized.
+    split = workgroups per scan (None: LM_SPLIT_WGS when B <= LM_SPLIT_MAX_BATCH, else 1: one persistent workgroup per scan)."""
     B, M = valid_f.shape
     dof = 3 * nj + nb + 3
     arr = (ctypes.c_void_p * 7)(*[t.data_ptr() for t in consts])
     x = torch.empty((B, dof), dtype=torch.float32, device=markers.device)
     x0 = torch.empty((B, dof), dtype=torch.float32, device=markers.device)
     tr = torch.zeros((B, it0 + it1 + 2), dtype=torch.float32, device=markers.device) if want_trace else None
-    _lib.check(_lib.lib().etch_smpl_lm_fit(B, M, int(nj), int(nb), arr, _ptr(markers), _ptr(valid_f), int(it0), _c_float(step0), _c_float(damp0),
-                                           int(it1), _c_float(step1), _c_float(damp1), _ptr(x), _ptr(x0), _optptr(tr), _optptr(phase_ticks),
-                                           _stream()), "etch_smpl_lm_fit")
+    G = int(split) if split is not None else (LM_SPLIT_WGS if B <= LM_SPLIT_MAX_BATCH else 1)
+    ws = None
+    if G > 1:
+        nbytes = _lib.lib().etch_smpl_lm_split_workspace_bytes(B, int(nj), int(nb), G)
+        ws = torch.empty((nbytes // 8 + 1,), dtype=torch.float64, device=markers.device)
+    _lib.check(_lib.lib().etch_smpl_lm_fit_split(B, M, int(nj), int(nb), arr, _ptr(markers), _ptr(valid_f), int(it0), _c_float(step0), _c_float(damp0),
+                                                 int(it1), _c_float(step1), _c_float(damp1), _ptr(x), _ptr(x0), _optptr(tr), _optptr(phase_ticks),
+                                                 G, _optptr(ws), _stream()), "etch_smpl_lm_fit_split")
     return x, x0, tr
 
 

@@ -394,6 +394,14 @@ int etch_marker_status(int B, int M, const float* markers, const float* valid_f,
 int etch_smpl_lm_fit(int B, int M, int nj, int nb, const void* const* consts, const float* markers, const float* valid, int it0, float step0,
                      float damp0, int it1, float step1, float damp1, float* x_out, float* x_stage0, float* err_trace, long long* phase_ticks,
                      void* stream);
+/* The same fit with every scan's linearisation split over G workgroups (latency regime: a handful of scans leave most of the chip idle):
+ * workgroup g takes the marker chunks g, g + G, ...; the partial tiles of [J | r]^T [J | r] are exchanged through `workspace` once per
+ * linearisation and added in a fixed order, all G copies of a scan's state stay bit-identical and solve redundantly.  Results may differ
+ * from G = 1 in the last bits of the fp64 normal matrix (a different, still fixed, summation order).  B * G must not exceed the CU count
+ * (the workgroups of a scan wait for each other); workspace: etch_smpl_lm_split_workspace_bytes(B, nj, nb, G) bytes, contents arbitrary. */
+int etch_smpl_lm_fit_split(int B, int M, int nj, int nb, const void* const* consts, const float* markers, const float* valid, int it0, float step0,
+                           float damp0, int it1, float step1, float damp1, float* x_out, float* x_stage0, float* err_trace, long long* phase_ticks,
+                           int G, void* workspace, void* stream);
 /* LDS bytes one scan's fit holds for its whole duration (one workgroup per scan); ETCH_EUNSUPPORTED for unknown (nj, nb). */
 int etch_smpl_lm_workspace_bytes(int nj, int nb);
 

@@ -333,3 +333,35 @@ def test_lm_fit_conditioning_stress_vs_fp64_yardstick(golden):
     assert np.abs(vg - v64).max() <= max(2.0 * np.abs(v32 - v64).max(), 1e-4)
     assert np.abs(joints.cpu().numpy() - g["joints_fp64"]).max() <= max(2.0 * np.abs(g["joints_fp32"] - g["joints_fp64"]).max(), 1e-4)
     assert np.abs(x0.cpu().numpy()[:, :69] - g["x_stage0_fp64"][:, :69]).max() <= max(2.0 * np.abs(g["x_stage0_fp32"] - g["x_stage0_fp64"])[:, :69].max(), 1e-4)
+
+
+@pytest.mark.parametrize("model,B,it", [("smpl", 1, (30, 50)), ("smpl", 5, (12, 20)), ("smplx", 2, (20, 25))])
+def test_lm_fit_split_over_workgroups_matches_one_workgroup_per_scan(model, B, it):
+    """etch_smpl_lm_fit_split: a scan's linearisation spread over G = 2 / 3 / 4 workgroups (marker chunks interleaved, partial normal-matrix
+    tiles exchanged through global memory once per iteration and added in a fixed order) against one persistent workgroup per scan: same
+    error trace and parameters up to the last bits of the fp64 normal matrix (a different summation order), reproducible run to run, and
+    the default picks the split for small batches only."""
+    from etch_amd import ops
+    from etch_amd.models.fit_SMPL import _device_body
+    bm, ms, mv, tgt, valid, _ = _problem(max(B, 2), seed=12, model=model)
+    tgt, valid = tgt[:B], valid[:B]
+    db = _device_body(bm, mv, torch.device("cuda"))
+    mk, vf = tgt.cuda().contiguous(), valid.float().cuda().contiguous()
+    run = lambda g: ops.smpl_lm_fit(db.lm_consts, mk, vf, it[0], 0.5, 0.01, it[1], 0.2, 1e-3, True, nj=db.nj, nb=db.nb, split=g)
+    x1, x01, tr1 = run(1)
+    scale = float(tr1.max())
+    for g in (2, 3, 4):
+        xg, x0g, trg = run(g)
+        assert torch.isfinite(xg).all()
+        assert float((trg - tr1).abs().max()) <= 1e-6 * scale, g
+        assert float((xg - x1).abs().max()) < 2e-6 and float((x0g - x01).abs().max()) < 2e-6, (g, float((xg - x1).abs().max()))
+        xg2, _, trg2 = run(g)
+        assert torch.equal(xg2, xg) and torch.equal(trg2, trg), g                 # fixed exchange order: bitwise reproducible
+    xd, _, _ = ops.smpl_lm_fit(db.lm_consts, mk, vf, it[0], 0.5, 0.01, it[1], 0.2, 1e-3, True, nj=db.nj, nb=db.nb)
+    assert torch.equal(xd, run(ops.LM_SPLIT_WGS if B <= ops.LM_SPLIT_MAX_BATCH else 1)[0])
+    big = torch.cat([mk] * 4)[:9].contiguous() if B >= 3 else None
+    if big is not None:                                                             # 9 scans > LM_SPLIT_MAX_BATCH: default = one workgroup per scan
+        vb = torch.cat([vf] * 4)[:9].contiguous()
+        a = ops.smpl_lm_fit(db.lm_consts, big, vb, 4, 0.5, 0.01, 4, 0.2, 1e-3, nj=db.nj, nb=db.nb)[0]
+        b_ = ops.smpl_lm_fit(db.lm_consts, big, vb, 4, 0.5, 0.01, 4, 0.2, 1e-3, nj=db.nj, nb=db.nb, split=1)[0]
+        assert torch.equal(a, b_)
