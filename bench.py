@@ -217,7 +217,7 @@ def stage2_latency(args, device, iters, batch):
         frozen = float((tr[:, 1:] == tr[:, :-1]).sum(1).float().mean())
         out[f"batch_{bsz}"] = {"ms": round(best, 3), "us_per_iteration": round(best * 1e3 / (iters[0] + iters[1] + 2), 1),
                                "iterations_skipped_by_the_convergence_freeze": frozen,
-                               "workgroups_per_scan": ops.LM_SPLIT_WGS if bsz <= ops.LM_SPLIT_MAX_BATCH else 1}
+                               "workgroups_per_scan": ops.lm_split_default(bsz, db.nj)}
         if bsz <= ops.LM_SPLIT_MAX_BATCH:
             one, _ = timed(1)
             out[f"batch_{bsz}"]["ms_one_workgroup_per_scan"] = round(one, 3)

@@ -536,19 +536,24 @@ def get_markers(points, labels, conf, num_markers):
 
 
 LM_SPLIT_MAX_BATCH = 8     # scans per launch up to which a scan's linearisation is split over several workgroups (latency regime)
-LM_SPLIT_WGS = 3
+LM_SPLIT_WGS = 3           # SMPL: 3 marker chunks of 32 -> 3 workgroups (measured: 6.4 -> 5.2 ms per 30+50 fit; 4+ only add exchange cost)
+LM_SPLIT_WGS_BY_JOINTS = {55: 4}      # SMPL-X-sized: 10 chunks of 9 markers; 58 -> 45.6 ms per 75+125 fit at B = 8 (G = 5: 42.5 ms at B = 1)
+
+
+def lm_split_default(B, nj):
+    return LM_SPLIT_WGS_BY_JOINTS.get(int(nj), LM_SPLIT_WGS) if B <= LM_SPLIT_MAX_BATCH else 1
 
 
 def smpl_lm_fit(consts, markers, valid_f, it0, step0, damp0, it1, step1, damp1, want_trace=False, phase_ticks=None, nj=24, nb=10, split=None):
     """x (B, 3 nj + nb + 3) = pose | betas | orient | transl.  (nj, nb) = (24, 10) SMPL or (55, 20) SMPL-X-sized.
-    split = workgroups per scan (None: LM_SPLIT_WGS when B <= LM_SPLIT_MAX_BATCH, else 1: one persistent workgroup per scan)."""
+    split = workgroups per scan (None: lm_split_default -- 3 / 4 when B <= LM_SPLIT_MAX_BATCH, else one persistent workgroup per scan)."""
     B, M = valid_f.shape
     dof = 3 * nj + nb + 3
     arr = (ctypes.c_void_p * 7)(*[t.data_ptr() for t in consts])
     x = torch.empty((B, dof), dtype=torch.float32, device=markers.device)
     x0 = torch.empty((B, dof), dtype=torch.float32, device=markers.device)
     tr = torch.zeros((B, it0 + it1 + 2), dtype=torch.float32, device=markers.device) if want_trace else None
-    G = int(split) if split is not None else (LM_SPLIT_WGS if B <= LM_SPLIT_MAX_BATCH else 1)
+    G = int(split) if split is not None else lm_split_default(B, nj)
     ws = None
     if G > 1:
         nbytes = _lib.lib().etch_smpl_lm_split_workspace_bytes(B, int(nj), int(nb), G)

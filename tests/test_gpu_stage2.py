@@ -358,7 +358,7 @@ def test_lm_fit_split_over_workgroups_matches_one_workgroup_per_scan(model, B, i
         xg2, _, trg2 = run(g)
         assert torch.equal(xg2, xg) and torch.equal(trg2, trg), g                 # fixed exchange order: bitwise reproducible
     xd, _, _ = ops.smpl_lm_fit(db.lm_consts, mk, vf, it[0], 0.5, 0.01, it[1], 0.2, 1e-3, True, nj=db.nj, nb=db.nb)
-    assert torch.equal(xd, run(ops.LM_SPLIT_WGS if B <= ops.LM_SPLIT_MAX_BATCH else 1)[0])
+    assert torch.equal(xd, run(ops.lm_split_default(B, db.nj))[0])
     big = torch.cat([mk] * 4)[:9].contiguous() if B >= 3 else None
     if big is not None:                                                             # 9 scans > LM_SPLIT_MAX_BATCH: default = one workgroup per scan
         vb = torch.cat([vf] * 4)[:9].contiguous()
