@@ -527,6 +527,123 @@ __global__ void __launch_bounds__(256) intra_so3conv_kernel(int npts_total, int 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same intra conv on v_mfma_f32_32x32x2_f32.  On this chip the 16x16x4 fp32 MFMA never issues faster than 0.85 of the matrix peak
+// (~37 cycles instead of 32), the 32x32x2 form runs at 0.986 of it (profiles/r03_mfma_issue_rate.txt).  Tile = 32 output channels x 32 anchors,
+// K = 2 per instruction: wave w owns anchor half h = w & 1 (anchors 32 h .. 32 h + 31; 60..63 are padding) and
+//   COUT = 64: output-channel tile mt = w >> 1 for BOTH points of the workgroup (each W fragment feeds two MFMAs),
+//   COUT = 32: the single channel tile for point w >> 1.
+// K order: step t covers kappa = 8 t .. 8 t + 7 of the tap-major contraction (tap = 8 t / C); lane half kk = lane >> 5 takes kappa = 8 t + 4 kk + s
+// in MFMA s (one 16-byte LDS read and one 16-byte weight load feed four MFMAs).  Wp32[t][mt][lane][s] = W2[32 mt + lane % 32][8 t + 4 (lane / 32) + s]
+// (ops.permute_weight_frag32).  D[i][j]: lane holds column j = lane % 32 (anchor), rows i = 8 (v / 4) + 4 (lane / 32) + v % 4 (channel) in v = 0..15.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int C, int COUT>
+__global__ void __launch_bounds__(256) intra_so3conv32_kernel(int npts_total, int pts_per_batch, const float* __restrict__ X,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const int* __restrict__ intra_idx, const float* __restrict__ Wp,
+                                                              const float* __restrict__ bias, float* __restrict__ Y,
+                                                              double* __restrict__ stat_part) {
+    constexpr int PTS = 2;
+    constexpr int MT = COUT / 32;
+    constexpr int WPP = MT == 1 ? 1 : 2;   // points per wave
+    constexpr int LD = C + 40;             // row stride (floats): LD / 4 = 10 (mod 16) as in the 16-wide kernel
+    constexpr int NT = 12 * C / 8;         // K steps of 8
+    static_assert(MT == 1 || MT == 2, "32 or 64 output channels");
+    __shared__ __attribute__((aligned(16))) float Xs[PTS * NA * LD];
+    __shared__ int iidx[NA * 12];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, kk = lane >> 5;
+    const int pt0 = blockIdx.x * PTS;
+    for (int e = tid; e < NA * 12; e += 256) iidx[e] = intra_idx[e];
+    for (int e = tid; e < PTS * NA * (C / 4); e += 256) {
+        const int c4 = e % (C / 4), row = e / (C / 4);          // row = pt*60 + a
+        const int pt = pt0 + row / NA;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pt < npts_total) {
+            v = *reinterpret_cast<const float4*>(X + ((size_t)pt0 * NA + row) * C + c4 * 4);
+            if (mean) {
+                const int bb = pt / pts_per_batch;
+                const float4 m = *reinterpret_cast<const float4*>(mean + (size_t)bb * C + c4 * 4);
+                const float4 r = *reinterpret_cast<const float4*>(rstd + (size_t)bb * C + c4 * 4);
+                v.x = (v.x - m.x) * r.x; v.y = (v.y - m.y) * r.y; v.z = (v.z - m.z) * r.z; v.w = (v.w - m.w) * r.w;
+                v.x = v.x > 0.f ? v.x : 0.01f * v.x; v.y = v.y > 0.f ? v.y : 0.01f * v.y;
+                v.z = v.z > 0.f ? v.z : 0.01f * v.z; v.w = v.w > 0.f ? v.w : 0.01f * v.w;
+            }
+        }
+        *reinterpret_cast<float4*>(&Xs[row * LD + c4 * 4]) = v;
+    }
+    __syncthreads();
+    const int h = wave & 1;
+    const int mt = MT == 1 ? 0 : (wave >> 1);
+    const int p_first = MT == 1 ? (wave >> 1) : 0;
+    const int a = 32 * h + j;
+    const int aa = a < NA ? a : 0;
+    f32x16 acc[WPP];
+#pragma unroll
+    for (int pi = 0; pi < WPP; ++pi)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[pi][v] = 0.f;
+#pragma unroll 2
+    for (int t = 0; t < NT; ++t) {
+        const int tap = (8 * t) / C, cb = 8 * t - tap * C;
+        const int src = iidx[aa * 12 + tap];
+        float4 bv[WPP];
+#pragma unroll
+        for (int pi = 0; pi < WPP; ++pi) bv[pi] = *reinterpret_cast<const float4*>(&Xs[((p_first + pi) * NA + src) * LD + cb + 4 * kk]);
+        const float4 av = *reinterpret_cast<const float4*>(&Wp[(((size_t)t * MT + mt) * 64 + lane) * 4]);
+#define I32_STEP(CMP) _Pragma("unroll") for (int pi = 0; pi < WPP; ++pi) acc[pi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.CMP, bv[pi].CMP, acc[pi], 0, 0, 0);
+        I32_STEP(x) I32_STEP(y) I32_STEP(z) I32_STEP(w)
+#undef I32_STEP
+    }
+    // epilogue: bias, stores (16 bytes = 4 consecutive channels per register group), statistics
+    double ss[16], sq[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) ss[v] = sq[v] = 0.0;
+    if (a < NA) {
+#pragma unroll
+        for (int pi = 0; pi < WPP; ++pi) {
+            const int pt = pt0 + p_first + pi;
+            if (pt >= npts_total) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int o = 32 * mt + 8 * g + 4 * kk;
+                const float4 bs = *reinterpret_cast<const float4*>(bias + o);
+                const float4 v = make_float4(acc[pi][4 * g] + bs.x, acc[pi][4 * g + 1] + bs.y, acc[pi][4 * g + 2] + bs.z, acc[pi][4 * g + 3] + bs.w);
+                *reinterpret_cast<float4*>(Y + ((size_t)pt * NA + a) * COUT + o) = v;
+                ss[4 * g] += (double)v.x; ss[4 * g + 1] += (double)v.y; ss[4 * g + 2] += (double)v.z; ss[4 * g + 3] += (double)v.w;
+                sq[4 * g] += (double)v.x * v.x; sq[4 * g + 1] += (double)v.y * v.y; sq[4 * g + 2] += (double)v.z * v.z; sq[4 * g + 3] += (double)v.w * v.w;
+            }
+        }
+    }
+    if (stat_part) {
+        // [slot][COUT fp64] through the (now free) input tile, once for the sums and once for the sums of squares; slot = anchor (COUT = 64: a lane
+        // already holds both points) or (point, anchor) (COUT = 32); one thread per channel adds the slots in order
+        constexpr int NSLOT = MT == 1 ? 2 * NA : NA;
+        constexpr int RS = 2 * COUT + 4;
+        static_assert(NSLOT * RS <= PTS * NA * LD, "statistics staging must fit the input tile");
+        const int slot = (MT == 1 ? p_first * NA : 0) + a;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            __syncthreads();
+            if (a < NA) {
+                double* red = reinterpret_cast<double*>(Xs + slot * RS);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) red[32 * mt + 8 * g + 4 * kk + q] = which == 0 ? ss[4 * g + q] : sq[4 * g + q];
+            }
+            __syncthreads();
+            if (tid < COUT) {
+                double t = 0.0;
+                for (int k = 0; k < NSLOT; ++k) t += reinterpret_cast<const double*>(Xs + k * RS)[tid];
+                stat_part[(size_t)blockIdx.x * 2 * COUT + which * COUT + tid] = t;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // InstanceNorm statistics over (p, a) per (b, c): deterministic two-level reduction in fp64.
 //   x [b][rows][C]  ->  mean[b][C], rstd[b][C] = 1/sqrt(var_biased + eps)
 // ------------------------------------------------------------------------------------------------
@@ -696,7 +813,28 @@ static int launch_intra(int npts, int ppb, const float* X, const float* mean, co
     return ETCH_OK;
 }
 
+template <int C, int COUT>
+static int launch_intra32(int npts, int ppb, const float* X, const float* mean, const float* rstd, const int* intra_idx,
+                          const float* Wp32, const float* bias, float* Y, double* stat_part, hipStream_t st) {
+    if (stat_part && (ppb % 2) != 0) return ETCH_EUNSUPPORTED;
+    hipLaunchKernelGGL((intra_so3conv32_kernel<C, COUT>), dim3((npts + 1) / 2), dim3(256), 0, st, npts, ppb, X, mean, rstd, intra_idx, Wp32, bias, Y,
+                       stat_part);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
 extern "C" {
+
+// The 32x32x2 form (c = cout in {32, 64}): Wp32 = ops.permute_weight_frag32 order.  Same result as etch_intra_so3conv_stats up to the order of the
+// fp32 sums inside an output (the contraction is split over the two lane halves differently).
+int etch_intra_so3conv32(int b, int c, int cout, int p, const float* X, const float* mean, const float* rstd, const int* intra_idx, const float* Wp32,
+                         const float* bias, float* Y, double* stat_part, void* stream) {
+    if (b <= 0 || p <= 0) return ETCH_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (c == 32 && cout == 32) return launch_intra32<32, 32>(b * p, p, X, mean, rstd, intra_idx, Wp32, bias, Y, stat_part, st);
+    if (c == 64 && cout == 64) return launch_intra32<64, 64>(b * p, p, X, mean, rstd, intra_idx, Wp32, bias, Y, stat_part, st);
+    return ETCH_EUNSUPPORTED;
+}
 
 // W layouts: `W` = reference layout [cout][cin*24] (index c*24+k); `Wp` = fragment order produced by
 // etch_permute_weight_frag (only the MFMA path, cin % 16 == 0, reads it).

@@ -5,6 +5,7 @@ hands raw device pointers to libetch_hip.so; there is no eager/CPU fallback -- a
 missing library raises.
 """
 import ctypes
+import os
 
 import torch
 
@@ -152,6 +153,13 @@ def permute_weight_frag(w2):
     return w2.reshape(O // 16, 16, K // 16, 4, 4).permute(2, 0, 3, 1, 4).contiguous().reshape(-1)
 
 
+def permute_weight_frag32(w2):
+    """[O, K] (O % 32 == 0, K % 8 == 0) -> 32x32x2 MFMA fragment order Wp[t][mt][lane][s] = W2[32mt + lane%32][8t + 4(lane//32) + s]."""
+    O, K = w2.shape
+    assert O % 32 == 0 and K % 8 == 0
+    return w2.reshape(O // 32, 32, K // 8, 2, 4).permute(2, 0, 3, 1, 4).contiguous().reshape(-1)
+
+
 def inter_weight_frag(W, cin, ks=24):
     """Fragment-ordered weight of the fused inter conv: the columns of W [cout, cin*ks] are first brought into the kernel's
     contraction order (csrc/so3conv.hip: channels are processed in passes of CCH = min(cin, 64); within a pass a lane gathers
@@ -207,7 +215,10 @@ def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, orde
     return out, (mean, rstd)
 
 
-def intra_so3conv(x_cl, intra_idx32, Wp, bias, cout, mean=None, rstd=None, want_stats=False):
+INTRA_MFMA32 = os.environ.get("ETCH_INTRA_MFMA32", "1") != "0"     # widths 32 / 64: the 32x32x2 MFMA form (ETCH_INTRA_MFMA32=0: the 16x16x4 kernel)
+
+
+def intra_so3conv(x_cl, intra_idx32, Wp, bias, cout, mean=None, rstd=None, want_stats=False, Wp32=None):
     """want_stats: also return the InstanceNorm (mean, rstd) of the output, accumulated in the conv's epilogue (even point counts;
     otherwise by the separate statistics pass)."""
     b, p, na, c = x_cl.shape
@@ -215,8 +226,12 @@ def intra_so3conv(x_cl, intra_idx32, Wp, bias, cout, mean=None, rstd=None, want_
     out = torch.empty((b, p, 60, cout), dtype=torch.float32, device=x_cl.device)
     fused = want_stats and p % 2 == 0 and c <= 64        # wider tiles (encoder depths 3 / 4) take the separate statistics pass
     part = torch.empty((b * (p // 2), 2, cout), dtype=torch.float64, device=x_cl.device) if fused else None
-    _lib.check(_lib.lib().etch_intra_so3conv_stats(b, c, cout, p, _ptr(x_cl), _optptr(mean), _optptr(rstd), _ptr(intra_idx32), _ptr(Wp),
-                                                   _ptr(bias), _ptr(out), _optptr(part), _stream()), "etch_intra_so3conv")
+    if Wp32 is not None and INTRA_MFMA32 and c == cout and c in (32, 64):
+        _lib.check(_lib.lib().etch_intra_so3conv32(b, c, cout, p, _ptr(x_cl), _optptr(mean), _optptr(rstd), _ptr(intra_idx32), _ptr(Wp32),
+                                                   _ptr(bias), _ptr(out), _optptr(part), _stream()), "etch_intra_so3conv32")
+    else:
+        _lib.check(_lib.lib().etch_intra_so3conv_stats(b, c, cout, p, _ptr(x_cl), _optptr(mean), _optptr(rstd), _ptr(intra_idx32), _ptr(Wp),
+                                                       _ptr(bias), _ptr(out), _optptr(part), _stream()), "etch_intra_so3conv")
     if not want_stats:
         return out
     if not fused:

@@ -195,18 +195,19 @@ class IntraSO3Conv(nn.Module):
             ks, c = self.kernel_size, self.dim_in
             # kernel K order is tap-major: W2[o, tap*c + ch] = W[o, ch*12 + tap]
             W2 = W.detach().view(self.dim_out, c, ks).permute(0, 2, 1).reshape(self.dim_out, ks * c).contiguous()
-            return ops.permute_weight_frag(W2), bias.detach().reshape(-1).contiguous(), self.intra_idx.to(torch.int32).contiguous()
+            Wp32 = ops.permute_weight_frag32(W2) if (c == self.dim_out and c in (32, 64)) else None       # the 32x32x2 kernel's fragment order
+            return ops.permute_weight_frag(W2), bias.detach().reshape(-1).contiguous(), self.intra_idx.to(torch.int32).contiguous(), Wp32
 
         return self._d.get((W, bias, self.intra_idx), build)
 
     def forward(self, x, mean=None, rstd=None, want_stats=False):
-        Wp, bias, idx32 = self._derived()
+        Wp, bias, idx32, Wp32 = self._derived()
         if want_stats:
-            y, stats = ops.intra_so3conv(x.feats_cl, idx32, Wp, bias, self.dim_out, mean, rstd, want_stats=True)
+            y, stats = ops.intra_so3conv(x.feats_cl, idx32, Wp, bias, self.dim_out, mean, rstd, want_stats=True, Wp32=Wp32)
             cloud = SphericalPointCloud(x.xyz, None, self.anchors, feats_cl=y)
             cloud.in_stats = stats      # InstanceNorm (mean, rstd) of the output, a by-product of the conv's epilogue
             return cloud
-        y = ops.intra_so3conv(x.feats_cl, idx32, Wp, bias, self.dim_out, mean, rstd)
+        y = ops.intra_so3conv(x.feats_cl, idx32, Wp, bias, self.dim_out, mean, rstd, Wp32=Wp32)
         return SphericalPointCloud(x.xyz, None, self.anchors, feats_cl=y)
 
 

@@ -137,6 +137,10 @@ int etch_intra_so3conv(int b, int c, int cout, int p, const float* X, const floa
  * the sum of squares per output channel; finish with etch_instnorm_from_partials(b, p/2, cout, 120, ...).  p must be even; NULL = plain. */
 int etch_intra_so3conv_stats(int b, int c, int cout, int p, const float* X, const float* mean, const float* rstd,
                              const int* intra_idx, const float* Wp, const float* bias, float* Y, double* stat_part, void* stream);
+/* The same convolution on the 32x32x2 fp32 MFMA (0.986 of the matrix peak on this chip against 0.85 for 16x16x4, profiles/r03_mfma_issue_rate.txt);
+ * c = cout in {32, 64}; Wp32[t][mt][lane][s] = W2[32 mt + lane % 32][8 t + 4 (lane / 32) + s] with W2 as above.  stat_part as above (p even) or NULL. */
+int etch_intra_so3conv32(int b, int c, int cout, int p, const float* X, const float* mean, const float* rstd, const int* intra_idx,
+                         const float* Wp32, const float* bias, float* Y, double* stat_part, void* stream);
 
 /* InstanceNorm2d(affine=False, eps=1e-5) statistics over (p,a) per (b,c) (src/models/so3conv.py:24,85,168).
  * x (b,rows,C) -> mean (b,C), rstd (b,C).  workspace: etch_instnorm_stats_workspace_bytes(b, C) bytes. */

@@ -212,12 +212,16 @@ def test_intra_conv_fused_instancenorm_statistics(c, p, normed):
     g = torch.Generator().manual_seed(c + p)
     b = 3
     conv = load_seeded(V.IntraSO3Conv(c, c), 5).cuda()
-    Wp, bias, idx32 = conv._derived()
+    Wp, bias, idx32, Wp32 = conv._derived()
     x = (torch.randn(b, p, 60, c, generator=g) * 2 + 0.5).cuda()
     m1, r1 = ops.instnorm_stats(x) if normed else (None, None)
-    ref = ops.intra_so3conv(x, idx32, Wp, bias, c, m1, r1)
-    out, (m, r) = ops.intra_so3conv(x, idx32, Wp, bias, c, m1, r1, want_stats=True)
+    ref = ops.intra_so3conv(x, idx32, Wp, bias, c, m1, r1, Wp32=Wp32)
+    out, (m, r) = ops.intra_so3conv(x, idx32, Wp, bias, c, m1, r1, want_stats=True, Wp32=Wp32)
     assert torch.equal(out, ref)
+    if Wp32 is not None:
+        # the 32x32x2 MFMA kernel against the 16x16x4 one: same function, a different split of the fp32 sums over the lane groups
+        old = ops.intra_so3conv(x, idx32, Wp, bias, c, m1, r1)
+        assert rel_err(out.cpu().numpy(), old.cpu().numpy()) < 2e-6
     x64 = ref.double().reshape(b, -1, c)
     assert rel_err(m.cpu().numpy(), x64.mean(1).cpu().numpy()) < 2e-6
     assert rel_err(r.cpu().numpy(), (1.0 / torch.sqrt(x64.var(1, unbiased=False) + 1e-5)).cpu().numpy()) < 2e-6
@@ -247,11 +251,11 @@ def test_fused_instancenorm_statistics_with_a_dominant_channel_mean(kind):
         c, p = 32, 64
         cout = c
         conv = load_seeded(V.IntraSO3Conv(c, c), 5).cuda()
-        Wp, bias, idx32 = conv._derived()
+        Wp, bias, idx32, Wp32 = conv._derived()
         bias = bias.clone()
         bias[::2] += 300.0
         x = torch.randn(b, p, 60, c, generator=g).cuda()
-        out, (m, r) = ops.intra_so3conv(x, idx32, Wp, bias, c, None, None, want_stats=True)
+        out, (m, r) = ops.intra_so3conv(x, idx32, Wp, bias, c, None, None, want_stats=True, Wp32=Wp32)
     x64 = out.double().reshape(b, -1, cout)
     std = x64.std(1, unbiased=False)
     assert float((x64.mean(1).abs() / std).max()) > 100
