@@ -67,9 +67,9 @@ def algorithmic_flops(name, a):
         b, cin, cout, p1, p2, nn = v[0:6]
         kern = "inter_so3conv_c1_kernel" if cin == 1 else f"inter_so3conv_kernel<{cin},{cout},{(nn + 15) // 16 if nn <= 32 else 4}>"
         return 2.0 * b * p2 * 60 * 24 * (cin * nn + cout * cin), kern
-    if name in ("etch_intra_so3conv", "etch_intra_so3conv_stats"):
+    if name in ("etch_intra_so3conv", "etch_intra_so3conv_stats", "etch_intra_so3conv32"):
         b, c, cout, p = v[0:4]
-        return 2.0 * b * p * 60 * 12 * c * cout, f"intra_so3conv_kernel<{c},{cout}>"
+        return 2.0 * b * p * 60 * 12 * c * cout, ("intra_so3conv32_kernel" if name.endswith("32") else "intra_so3conv_kernel") + f"<{c},{cout}>"
     if name == "etch_mhsa_layer":
         T, mode = v[0], v[7]
         return T * (2.0 * 60 * 64 * 192 + 8 * (2.0 * 60 * 60 * 8 * 2) + (2.0 * 60 * 64 * 64 if mode != 2 else 0.0)), "mhsa_layer_kernel"

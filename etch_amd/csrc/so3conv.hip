@@ -13,6 +13,7 @@
 //                        InstanceNorm2d(affine=False, eps=1e-5) + leaky_relu(0.01) (+ residual branch)
 //                        (/root/reference/src/models/so3conv.py:36-44,96-99,178-182).
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define NA 60
@@ -538,6 +539,20 @@ __global__ void __launch_bounds__(256) intra_so3conv_kernel(int npts_total, int 
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// The weight-fragment ring of the kernel below is built from inline-asm loads and waits: written as plain loads the compiler splits every
+// 16-byte load into dwords and sinks them in front of their MFMAs (global_load_dword + s_waitcnt vmcnt(0) per MFMA pair: 7.2 -> 8.9 ms), as volatile
+// loads it waits for vmcnt(0) at every step (7.5 ms).  Rules that keep this safe: (1) no load is issued whose result is not consumed inside the loop
+// (a load still in flight after the loop would land in registers the compiler has already reused); (2) the wait names the ring register as an in/out
+// operand, so the consuming MFMAs cannot be scheduled above it; (3) vmcnt counts the compiler's own loads too, and loads return in order, so the
+// compiler's waits can only become stricter, never too weak.
+__device__ __forceinline__ f32x4 intra32_wload(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void intra32_wwait(f32x4& v) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N)); }
+
 template <int C, int COUT>
 __global__ void __launch_bounds__(256) intra_so3conv32_kernel(int npts_total, int pts_per_batch, const float* __restrict__ X,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -584,18 +599,44 @@ __global__ void __launch_bounds__(256) intra_so3conv32_kernel(int npts_total, in
     for (int pi = 0; pi < WPP; ++pi)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[pi][v] = 0.f;
-#pragma unroll 2
-    for (int t = 0; t < NT; ++t) {
-        const int tap = (8 * t) / C, cb = 8 * t - tap * C;
-        const int src = iidx[aa * 12 + tap];
-        float4 bv[WPP];
+    // weight fragments travel through a register ring PF steps ahead of the matrix cores (L2 latency ~ 1 us against 0.25 us of MFMAs per step)
+    constexpr int PF = 4;
+    static_assert(NT % PF == 0, "ring slots must line up");
+    f32x4 avq[PF];
 #pragma unroll
-        for (int pi = 0; pi < WPP; ++pi) bv[pi] = *reinterpret_cast<const float4*>(&Xs[((p_first + pi) * NA + src) * LD + cb + 4 * kk]);
-        const float4 av = *reinterpret_cast<const float4*>(&Wp[(((size_t)t * MT + mt) * 64 + lane) * 4]);
+    for (int q = 0; q < PF - 1; ++q) avq[q] = intra32_wload(&Wp[(((size_t)q * MT + mt) * 64 + lane) * 4]);
+    constexpr int SPT = C / 8;             // K steps per tap
+    static_assert(SPT % PF == 0, "a tap's steps must fill whole ring turns");
+    // (the last tap is a separate instantiation: a load under a run-time condition would make the ring register a phi of the asm's output and
+    // its old value, and the copy that merges them reads the register before the load has landed)
+    auto do_tap = [&](int tap, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const int src = iidx[aa * 12 + tap];                    // one dependent LDS read per tap, not per step
+        const float* xrow = &Xs[src * LD + 4 * kk];
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) {
+            const int q = i % PF;
+            const int t = tap * SPT + i;
+            constexpr int dummy = 0; (void)dummy;
+            const bool tail = LAST && i + PF - 1 >= SPT;               // compile-time per unrolled step: the last PF - 1 steps issue no load
+            if (!tail) avq[(q + PF - 1) % PF] = intra32_wload(&Wp[(((size_t)(t + PF - 1) * MT + mt) * 64 + lane) * 4]);
+            float4 bv[WPP];
+#pragma unroll
+            for (int pi = 0; pi < WPP; ++pi) bv[pi] = *reinterpret_cast<const float4*>(xrow + (p_first + pi) * NA * LD + 8 * i);
+            // outstanding ring loads here: PF (this step's, the oldest, + PF - 1 younger ones), fewer in the tail
+            if (!tail) intra32_wwait<PF - 1>(avq[q]);
+            else if (SPT - 1 - i == 2) intra32_wwait<2>(avq[q]);
+            else if (SPT - 1 - i == 1) intra32_wwait<1>(avq[q]);
+            else intra32_wwait<0>(avq[q]);
+            const f32x4 av = avq[q];
 #define I32_STEP(CMP) _Pragma("unroll") for (int pi = 0; pi < WPP; ++pi) acc[pi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.CMP, bv[pi].CMP, acc[pi], 0, 0, 0);
-        I32_STEP(x) I32_STEP(y) I32_STEP(z) I32_STEP(w)
+            I32_STEP(x) I32_STEP(y) I32_STEP(z) I32_STEP(w)
 #undef I32_STEP
-    }
+        }
+    };
+#pragma unroll 1
+    for (int tap = 0; tap < 11; ++tap) do_tap(tap, std::false_type{});
+    do_tap(11, std::true_type{});
     // epilogue: bias, stores (16 bytes = 4 consecutive channels per register group), statistics
     double ss[16], sq[16];
 #pragma unroll
