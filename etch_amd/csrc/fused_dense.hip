@@ -125,139 +125,6 @@ __global__ void __launch_bounds__(512) linear_relu_dot_kernel(long R, int G, con
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// The same chain on v_mfma_f32_32x32x2_f32 (0.986 of the fp32 matrix peak on this chip against 0.85 for 16x16x4,
-// profiles/r03_mfma_issue_rate.txt).  Tile = 32 rows x 32 hidden columns; wave w of 8 owns hidden-column tile ct = w & 3 of the current
-// group's 128 and RPW = FD_ROWS / 64 row tiles (K = 128: 64 rows, one tile per wave; K = 64: 128 rows, two tiles sharing each weight
-// fragment).  K order: step t covers k = 8 t .. 8 t + 7, lane half kk = lane >> 5 takes k = 8 t + 4 kk + s in MFMA s;
-// Wp32[g][t][ct][lane][s] = W[g * 128 + 32 ct + lane % 32][8 t + 4 (lane / 32) + s] (ops.permute_weight_frag_grouped32).
-// D[i][j]: lane holds hidden column j = lane % 32 and rows i = 8 (v / 4) + 4 kk + v % 4 of its tile in v = 0..15.
-// ------------------------------------------------------------------------------------------------
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// sum over the 32 lanes of a half wave (the tile's 32 hidden columns); every lane of the half ends up with the total
-__device__ __forceinline__ float fd_half_sum32(float v) {
-    v = fd_row_sum16(v);
-    return v + __shfl_xor(v, 16, 64);
-}
-
-template <int K, int FD_ROWS>
-__global__ void __launch_bounds__(512) linear_relu_dot32_kernel(long R, int G, const float* __restrict__ X, long ldx,
-                                                                const float* __restrict__ Wp, const float* __restrict__ b1,
-                                                                const float* __restrict__ w2, const float* __restrict__ b2,
-                                                                float* __restrict__ out, long ldo) {
-    constexpr int S = K + FD_PAD, KT = K / 8;
-    constexpr int RPW = FD_ROWS / 64;        // row tiles per wave
-    static_assert(FD_ROWS % 64 == 0, "two wave rows of 32-row tiles");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Xs = lds;                         // [FD_ROWS][S]
-    float* red = lds + FD_ROWS * S;          // [2][4 column tiles][FD_ROWS]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, kk = lane >> 5;
-    const int ct = wave & 3, rt0 = (wave >> 2) * RPW;
-    constexpr int C4 = K / 4;
-    constexpr int XL = FD_ROWS * C4 / 512;
-    static_assert(FD_ROWS * C4 % 512 == 0, "tile / thread geometry");
-    const long ntiles = (R + FD_ROWS - 1) / FD_ROWS;
-    float4 xn[XL];
-    auto fetch = [&](long tile) {
-        const long rt = tile * FD_ROWS;
-#pragma unroll
-        for (int h = 0; h < XL; ++h) {
-            const int e = tid + 512 * h;
-            const int row = e / C4, c = (e - row * C4) * 4;
-            xn[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tile < ntiles && rt + row < R) xn[h] = *reinterpret_cast<const float4*>(X + (rt + row) * ldx + c);
-        }
-    };
-    auto wfrag = [&](int g, int t) -> float4 { return *reinterpret_cast<const float4*>(Wp + ((((long)g * KT + t) * 4 + ct) * 64 + lane) * 4); };
-    fetch(blockIdx.x);
-    int buf = 0;
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long r0 = tile * FD_ROWS;
-        __syncthreads();
-#pragma unroll
-        for (int h = 0; h < XL; ++h) {
-            const int e = tid + 512 * h;
-            const int row = e / C4, c = (e - row * C4) * 4;
-            *reinterpret_cast<float4*>(&Xs[row * S + c]) = xn[h];
-        }
-        float4 bn = wfrag(0, 0);
-        __syncthreads();
-        fetch(tile + gridDim.x);
-        for (int g = 0; g < G; ++g) {
-            f32x16 acc[RPW];
-#pragma unroll
-            for (int i = 0; i < RPW; ++i)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
-#pragma unroll
-            for (int t = 0; t < KT; ++t) {
-                const float4 b = bn;
-                if (t + 1 < KT) bn = wfrag(g, t + 1);
-                else bn = wfrag(g + 1 < G ? g + 1 : g, 0);
-                float4 a[RPW];
-#pragma unroll
-                for (int i = 0; i < RPW; ++i) a[i] = *reinterpret_cast<const float4*>(&Xs[((rt0 + i) * 32 + j) * S + t * 8 + kk * 4]);
-#define FD32_STEP(C) _Pragma("unroll") for (int i = 0; i < RPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].C, b.C, acc[i], 0, 0, 0);
-                FD32_STEP(x) FD32_STEP(y) FD32_STEP(z) FD32_STEP(w)
-#undef FD32_STEP
-            }
-            const int col = g * FD_J + ct * 32 + j;
-            const float bs = b1[col], ww = w2[col];
-            float* rp = red + (buf * 4 + ct) * FD_ROWS;
-#pragma unroll
-            for (int i = 0; i < RPW; ++i)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const float sm = fd_half_sum32(fmaxf(acc[i][v] + bs, 0.f) * ww);
-                    if (j == v) rp[(rt0 + i) * 32 + 8 * (v >> 2) + 4 * kk + (v & 3)] = sm;    // spread the stores over the half's lanes
-                }
-            __syncthreads();
-            if (tid < FD_ROWS && r0 + tid < R) {
-                const float* rr = red + buf * 4 * FD_ROWS + tid;
-                out[(r0 + tid) * ldo + g] = ((rr[0] + rr[FD_ROWS]) + (rr[2 * FD_ROWS] + rr[3 * FD_ROWS])) + b2[g];
-            }
-            buf ^= 1;
-        }
-    }
-}
-
-template <int K, int FD_ROWS>
-static int launch_lrd32(long R, int G, const float* X, long ldx, const float* Wp32, const float* b1, const float* w2, const float* b2, float* out,
-                        long ldo, hipStream_t st) {
-    const size_t lds = ((size_t)FD_ROWS * (K + FD_PAD) + 2 * 4 * FD_ROWS) * sizeof(float);
-    const long ntiles = (R + FD_ROWS - 1) / FD_ROWS;
-    auto kern = linear_relu_dot32_kernel<K, FD_ROWS>;
-    static int blocks_resident = 0;
-    if (blocks_resident == 0) {
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-        }
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 512, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-        blocks_resident = etch_cu_count() * per_cu;
-    }
-    long blocks = blocks_resident;
-    if (blocks > ntiles) blocks = ntiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, st, R, G, X, ldx, Wp32, b1, w2, b2, out, ldo);
-    ETCH_RETURN_IF_LAUNCH_FAILED();
-    return ETCH_OK;
-}
-
-extern "C" int etch_linear_relu_dot32(long R, int K, int G, int J, const float* X, long ldx, const float* Wp32, const float* b1, const float* w2,
-                                      const float* b2, float* out, long ldo, void* stream) {
-    if (R <= 0 || G <= 0) return ETCH_OK;
-    if (!X || !Wp32 || !b1 || !w2 || !b2 || !out) return ETCH_EINVAL;
-    if ((ldx & 3) || ((uintptr_t)X & 15) || ((uintptr_t)Wp32 & 15)) return ETCH_EINVAL;
-    if (J != FD_J) return ETCH_EUNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
-    if (K == 64) return launch_lrd32<64, 128>(R, G, X, ldx, Wp32, b1, w2, b2, out, ldo, st);
-    if (K == 128) return launch_lrd32<128, 64>(R, G, X, ldx, Wp32, b1, w2, b2, out, ldo, st);
-    return ETCH_EUNSUPPORTED;
-}
-
 template <int K, int FD_ROWS>
 static int launch_lrd(long R, int G, const float* X, long ldx, const float* W, long ldw, const float* Wp, const float* b1,
                       const float* w2, const float* b2, float* out, long ldo, hipStream_t st) {

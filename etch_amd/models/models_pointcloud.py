@@ -89,7 +89,7 @@ class GT_network_equiv(nn.Module):
             bf = (W1 @ bc + b1).float().contiguous().to(dev)
             v = (W2.t() @ wr).float().contiguous().to(dev)
             c = (b2 @ wr + br[0]).float().view(1).to(dev)
-            return Wf, bf, v, c, ops.permute_weight_frag_grouped(Wf), (ops.permute_weight_frag_grouped32(Wf) if Wf.shape[1] in (64, 128) else None)
+            return Wf, bf, v, c, ops.permute_weight_frag_grouped(Wf)
 
         if not hasattr(self, "_fold_cache"):
             from ..vgtk_so3conv import _Derived
@@ -126,10 +126,10 @@ class GT_network_equiv(nn.Module):
         for layer in layers[first:-1]:
             x = layer(x, x, x, residual=True)
         last = layers[-1]
-        Wf, bf, v, c, Wfp, Wfp32 = self._folded()
+        Wf, bf, v, c, Wfp = self._folded()
         att = last.heads(x.reshape(T * 60, last.embedding_dim))                       # concatenated heads; head_combine is folded into Wf
         # relu(att Wf^T + bf) . v + c in one kernel: the (T*60, 128) hidden layer stays on chip
-        return ops.linear_relu_dot(att, Wf, bf, v, c, 1, wp=Wfp, wp32=Wfp32).view(T, 60)
+        return ops.linear_relu_dot(att, Wf, bf, v, c, 1, wp=Wfp).view(T, 60)
 
     def decode_direction(self, equiv_feat, anchors, initial_vectors, tokens_cl=None, interp=None):
         """models_pointcloud.py:111-126.  equiv_feat [B, N, C, 60] (reference layout) or tokens_cl [B, N, 60, C], or `interp` (see

@@ -304,9 +304,8 @@ class PointTransformer_confidence(_PointTransformerBase):
         w2 = self.confi[2].weight.detach().view(self.k, -1).contiguous()
         b2 = self.confi[2].bias.detach()
         # confi: Conv1d(128, 128k) -> ReLU -> grouped Conv1d(128k, k) fused; the (B*N, 128k) hidden layer is never materialised
-        wp, wp32 = self._dw.get([self.confi[0].weight], lambda: (ops.permute_weight_frag_grouped(w0.contiguous(), w2.shape[1]),
-                                                                   ops.permute_weight_frag_grouped32(w0.contiguous(), w2.shape[1])))
-        conf_k = ops.linear_relu_dot(x1, w0, b0, w2.view(-1), b2, self.k, wp=wp, wp32=wp32)
+        wp = self._dw.get([self.confi[0].weight], lambda: ops.permute_weight_frag_grouped(w0.contiguous(), w2.shape[1]))
+        conf_k = ops.linear_relu_dot(x1, w0, b0, w2.view(-1), b2, self.k, wp=wp)
         conf = ops.softmax_dot(logits, conf_k)
         return logits.view(B, N, self.k), conf.view(B, N, 1)
 

@@ -504,16 +504,7 @@ def permute_weight_frag_grouped(w, J=128):
     return torch.cat([permute_weight_frag(w[g * J:(g + 1) * J].contiguous()) for g in range(GJ // J)])
 
 
-def permute_weight_frag_grouped32(w, J=128):
-    """[G*J, K] -> 32x32x2 fragment order [G][K/8][J/32][64][4] for etch_linear_relu_dot32."""
-    GJ, K = w.shape
-    return torch.cat([permute_weight_frag32(w[g * J:(g + 1) * J].contiguous()) for g in range(GJ // J)])
-
-
-LRD_MFMA32 = os.environ.get("ETCH_LRD_MFMA32", "1") != "0"     # K in {64, 128}: the 32x32x2 MFMA form when the caller supplies wp32
-
-
-def linear_relu_dot(x, w, b1, w2, b2, G, wp=None, out=None, wp32=None):
+def linear_relu_dot(x, w, b1, w2, b2, G, wp=None, out=None):
     """out[r,g] = b2[g] + sum_j relu(x[r] . w[g*J+j] + b1[g*J+j]) * w2[g*J+j]   (J = 128), hidden kept on chip."""
     for t, n in ((w, "w"), (b1, "b1"), (w2, "w2"), (b2, "b2")):
         _need(t, torch.float32, n)
@@ -524,11 +515,6 @@ def linear_relu_dot(x, w, b1, w2, b2, G, wp=None, out=None, wp32=None):
     assert x.stride(1) == 1 and w.shape == (G * J, K) and b1.numel() == G * J and w2.numel() == G * J and b2.numel() == G
     if out is None:
         out = torch.empty((R, G), dtype=torch.float32, device=x.device)
-    if wp32 is not None and LRD_MFMA32 and K in (64, 128) and J == 128:
-        _lib.check(_lib.lib().etch_linear_relu_dot32(_c_long(R), int(K), int(G), int(J), _ptr(x), _c_long(x.stride(0) if R > 1 else K), _ptr(wp32),
-                                                     _ptr(b1), _ptr(w2), _ptr(b2), _ptr(out), _c_long(out.stride(0) if R > 1 else G), _stream()),
-                   "etch_linear_relu_dot32")
-        return out
     _lib.check(_lib.lib().etch_linear_relu_dot(_c_long(R), int(K), int(G), int(J), _ptr(x), _c_long(x.stride(0) if R > 1 else K), _ptr(w),
                                                _c_long(w.stride(0)), _optptr(wp), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(out),
                                                _c_long(out.stride(0) if R > 1 else G), _stream()), "etch_linear_relu_dot")

@@ -287,10 +287,6 @@ int etch_grouped_dot(long R, int G, int J, const float* h, long ldh, const float
  * read directly); out (R,G) row stride ldo.  J must be 128, K 64 or 128; ldx % 4 == 0, 16-byte aligned pointers. */
 int etch_linear_relu_dot(long R, int K, int G, int J, const float* X, long ldx, const float* W, long ldw, const float* Wp,
                          const float* b1, const float* w2, const float* b2, float* out, long ldo, void* stream);
-/* The same chain on the 32x32x2 fp32 MFMA (profiles/r03_mfma_issue_rate.txt); K in {64, 128}, J = 128;
- * Wp32[g][t][ct][lane][s] = W[g * 128 + 32 ct + lane % 32][8 t + 4 (lane / 32) + s].  Same result up to the order of the fp32 sums. */
-int etch_linear_relu_dot32(long R, int K, int G, int J, const float* X, long ldx, const float* Wp32, const float* b1, const float* w2,
-                           const float* b2, float* out, long ldo, void* stream);
 
 /* confidence = sum_g softmax(logits)_g * v_g (pointtransformer_seg.py:183-189): (R,G),(R,G) -> (R). */
 int etch_softmax_dot(long R, int G, const float* logits, const float* v, float* out, void* stream);

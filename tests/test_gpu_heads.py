@@ -140,11 +140,6 @@ def test_linear_relu_dot_matches_unfused_chain(R, K, G, perm):
     wide[:, :K] = xc
     out2 = ops.linear_relu_dot(wide[:, :K], wc, b1c, w2c.view(-1), b2c, G, wp=wp)
     assert torch.equal(out, out2)
-    # the 32x32x2 MFMA form (what the model runs): same function, rows past R and strided input included
-    wp32 = ops.permute_weight_frag_grouped32(wc)
-    out3 = ops.linear_relu_dot(xc, wc, b1c, w2c.view(-1), b2c, G, wp=wp, wp32=wp32)
-    assert rel_err(out3.cpu().numpy(), ref.numpy()) < 2e-6
-    assert torch.equal(out3, ops.linear_relu_dot(wide[:, :K], wc, b1c, w2c.view(-1), b2c, G, wp32=wp32))
 
 
 def _mhsa_reference(x, wq, wk, wv, wc, bc, mode):
