@@ -176,6 +176,23 @@ def inter_weight_frag(W, cin, ks=24):
     return permute_weight_frag(W[:, cols].contiguous())
 
 
+def inter_weight_frag32(W, cin, ks=24):
+    """Fragment order of the 32x32x2 inter conv (csrc/so3conv32.hip): [slice = 3 h + g][mt][kp][u][lane][4] with
+    [lane][s] = W[32 mt + lane % 32][(32 h + c) * 24 + 8 g + 4 (lane / 32) + s], c = kp * NU + u -- h = 32-channel tile of the input,
+    g = group of 8 kernel points, the slice's 256 contraction entries split over NKP = 8 / MT waves of NU = 32 / NKP k-steps."""
+    cout = W.shape[0]
+    assert ks == 24 and cin % 32 == 0 and cout in (32, 64) and W.shape[1] == cin * ks
+    mt, ntil = cout // 32, cin // 32
+    nkp = 8 // mt
+    nu = 32 // nkp
+    w = W.reshape(mt, 32, ntil, nkp, nu, 3, 2, 4)          # [mt][j][h][kp][u][g][kk][s]
+    return w.permute(2, 5, 0, 3, 4, 6, 1, 7).contiguous().reshape(-1)
+
+
+INTER_MFMA32 = os.environ.get("ETCH_INTER_MFMA32", "1") != "0"     # (32|64) -> (32|64) channels: the 32x32x2 MFMA form, two points per workgroup
+INTER_MFMA32_SHAPES = ((32, 32), (32, 64), (64, 64))
+
+
 # ------------------------------------------------------------------ EPN encoder
 def spatial_order(xyz):
     """xyz (b,3,n) -> (b,n) int32 Morton order of each scan (scheduling hint for inter_so3conv / prop_interp: a permutation of
@@ -187,7 +204,7 @@ def spatial_order(xyz):
     return order
 
 
-def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, order=None, want_stats=False):
+def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, order=None, want_stats=False, Wp32=None):
     """feats_cl (b,p1,60,cin) channels-last -> (b,p2,60,cout) pre-norm.  order (b,p2) int32: processing order of the output points.
     want_stats: also return the InstanceNorm (mean, rstd) of the output, accumulated in the conv's epilogue."""
     b, p1, na, cin = feats_cl.shape
@@ -202,9 +219,15 @@ def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, orde
     out = torch.empty((b, p2, 60, cout), dtype=torch.float32, device=xyz.device)
     fused = want_stats and 256 % cout == 0 and (cin >= 16 or cin == 1)
     part = torch.empty((b, p2, 2, cout), dtype=torch.float64, device=xyz.device) if fused else None
-    _lib.check(_lib.lib().etch_inter_so3conv_ordered(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
-                                                     _ptr(feats_cl), _ptr(rk), _ptr(W), _optptr(Wp), _ptr(bias), _ptr(out), _optptr(order),
-                                                     _optptr(part), _stream()), "etch_inter_so3conv")
+    if Wp32 is not None and INTER_MFMA32 and (cin, cout) in INTER_MFMA32_SHAPES:
+        _need(Wp32, torch.float32, "Wp32")
+        _lib.check(_lib.lib().etch_inter_so3conv32(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
+                                                   _ptr(feats_cl), _ptr(rk), _ptr(Wp32), _ptr(bias), _ptr(out), _optptr(order),
+                                                   _optptr(part), _stream()), "etch_inter_so3conv32")
+    else:
+        _lib.check(_lib.lib().etch_inter_so3conv_ordered(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
+                                                         _ptr(feats_cl), _ptr(rk), _ptr(W), _optptr(Wp), _ptr(bias), _ptr(out), _optptr(order),
+                                                         _optptr(part), _stream()), "etch_inter_so3conv")
     if not want_stats:
         return out
     if not fused:

@@ -126,6 +126,7 @@ class InterSO3Conv(nn.Module):
         self.register_buffer("anchors", torch.from_numpy(K.get_anchors(kanchor)))
         self.register_buffer("kernels", torch.from_numpy(kernels))
         self._d = _Derived()
+        self._d32 = _Derived()
 
     def _derived(self):
         W, bias = self.basic_conv.W, self.basic_conv.bias
@@ -138,6 +139,13 @@ class InterSO3Conv(nn.Module):
             return rk.to(W.device), Wd, Wp, bias.detach().reshape(-1).contiguous()
 
         return self._d.get((W, bias, self.anchors, self.kernels), build)
+
+    def _wp32(self):
+        """Weight in the fragment order of the 32x32x2 kernel (csrc/so3conv32.hip), for the widths it covers; else None."""
+        if (self.dim_in, self.dim_out) not in ops.INTER_MFMA32_SHAPES or self.kernel_size != 24:
+            return None
+        W = self.basic_conv.W
+        return self._d32.get((W,), lambda: ops.inter_weight_frag32(W.detach().contiguous(), self.dim_in, self.kernel_size))
 
     def group(self, xyz):
         """functional.py:176-185 inter_spconv_grouping_ball (index part): -> ball_idx, sample_idx, new_xyz.
@@ -169,7 +177,7 @@ class InterSO3Conv(nn.Module):
         else:
             sample_idx, new_xyz = None, xyz
         rk, W, Wp, bias = self._derived()
-        y, stats = ops.inter_so3conv(xyz, new_xyz, inter_idx, x.feats_cl, rk, W, Wp, bias, self.sigma, order=self.order(new_xyz), want_stats=True)
+        y, stats = ops.inter_so3conv(xyz, new_xyz, inter_idx, x.feats_cl, rk, W, Wp, bias, self.sigma, order=self.order(new_xyz), want_stats=True, Wp32=self._wp32())
         cloud = SphericalPointCloud(new_xyz, None, self.anchors, feats_cl=y)
         cloud.in_stats = stats          # InstanceNorm (mean, rstd) of the output, a by-product of the conv's epilogue
         return inter_idx, None, sample_idx, cloud

@@ -118,6 +118,14 @@ int etch_inter_so3conv_ordered(int b, int cin, int cout, int p1, int p2, int nn,
                                const int* ball_idx, const float* feats, const float* rk, const float* W, const float* Wp,
                                const float* bias, float* out, const int* order, double* stat_part, void* stream);
 
+/* The same convolution on the 32x32x2 fp32 MFMA (0.986 of the matrix peak on this chip against 0.85 for 16x16x4,
+ * profiles/r03_mfma_issue_rate.txt), two output points per workgroup; (cin, cout) in {(32,32), (32,64), (64,64)}, nn <= 64.
+ * Wp32[slice = 3 h + g][mt][kp][u][lane][s] = W[32 mt + lane % 32][(32 h + kp * NU + u) * 24 + 8 g + 4 (lane / 32) + s] with
+ * NKP = 8 / (cout / 32) K-shares kp of NU = 32 / NKP steps u (etch_amd/ops.py inter_weight_frag32).  order / stat_part as above. */
+int etch_inter_so3conv32(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
+                         const int* ball_idx, const float* feats, const float* rk, const float* Wp32, const float* bias, float* out,
+                         const int* order, double* stat_part, void* stream);
+
 /* mean / rstd (b,C) of InstanceNorm2d(affine=False, eps 1e-5) from per-part partial sums: partial (b,nparts,2,C) fp64, each over `count`
  * values.  Same result as etch_instnorm_stats over the full tensor (fp64 accumulation, fixed order). */
 int etch_instnorm_from_partials(int b, int nparts, int C, int count, const double* partial, float* mean, float* rstd, void* stream);

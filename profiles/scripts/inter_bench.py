@@ -19,5 +19,5 @@ for rep in range(3):
     for k, v in agg.items():
         if "so3conv" in k:
             tot.setdefault(k, []).append(v["ms"])
-print(os.environ.get("ETCH_HIP_LIB", "default").split("libetch_")[-1], " ".join(f"{k.replace('_so3conv_kernel','')}={min(v):.3f}" for k, v in tot.items()),
-      "inter_sum=%.3f" % sum(min(v) for k, v in tot.items() if k.startswith("inter_so3conv_kernel<")))
+print(os.environ.get("ETCH_HIP_LIB", "default").split("libetch_")[-1], "mfma32=" + os.environ.get("ETCH_INTER_MFMA32", "1"), " ".join(f"{k.replace('_so3conv_kernel','')}={min(v):.3f}" for k, v in tot.items()),
+      "inter_sum=%.3f" % sum(min(v) for k, v in tot.items() if k.startswith("inter_so3conv")))
