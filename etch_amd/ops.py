@@ -189,7 +189,7 @@ def inter_weight_frag32(W, cin, ks=24):
     return w.permute(2, 5, 0, 3, 4, 6, 1, 7).contiguous().reshape(-1)
 
 
-INTER_MFMA32 = os.environ.get("ETCH_INTER_MFMA32", "1") != "0"     # (32|64) -> (32|64) channels: the 32x32x2 MFMA form, two points per workgroup
+INTER_MFMA32 = os.environ.get("ETCH_INTER_MFMA32", "0") == "1"     # (32|64) -> (32|64) channels: the 32x32x2 MFMA form, two points per workgroup
 INTER_MFMA32_SHAPES = ((32, 32), (32, 64), (64, 64))
 
 
