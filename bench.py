@@ -67,6 +67,9 @@ def algorithmic_flops(name, a):
         b, cin, cout, p1, p2, nn = v[0:6]
         kern = "inter_so3conv_c1_kernel" if cin == 1 else f"inter_so3conv_kernel<{cin},{cout},{(nn + 15) // 16 if nn <= 32 else 4}>"
         return 2.0 * b * p2 * 60 * 24 * (cin * nn + cout * cin), kern
+    if name == "etch_inter_so3conv32":
+        b, cin, cout, p1, p2, nn = v[0:6]
+        return 2.0 * b * p2 * 60 * 24 * (cin * nn + cout * cin), f"inter_so3conv32_kernel<{cin},{cout},{(nn + 7) // 8}>"
     if name in ("etch_intra_so3conv", "etch_intra_so3conv_stats", "etch_intra_so3conv32"):
         b, c, cout, p = v[0:4]
         return 2.0 * b * p * 60 * 12 * c * cout, ("intra_so3conv32_kernel" if name.endswith("32") else "intra_so3conv_kernel") + f"<{c},{cout}>"
