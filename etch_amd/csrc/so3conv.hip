@@ -30,8 +30,38 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // contraction index of step 2 follows that order: kappa' = (half h, cc = r*MTH + (mi - h*MTH), k); the host permutes the columns
 // of W accordingly before the fragment permutation (ops.inter_weight_frag) -- the result is the same sum in a different order.
 // ------------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int MAXT, int PD>     // MAXT = ceil(nn / 16) neighbour chunks held in registers (nn <= 16 * MAXT); PD = gather prefetch distance (chunk-steps)
-__global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
+// BX: step 2 on the bf16 matrix cores with fp32 operands split exactly into three bf16 values each (hi / mid / lo mantissa bytes) and the six
+// largest cross products accumulated in fp32 -- the same error against fp64 as the fp32 MFMA (profiles/r03_bf16x3_split.txt) at 2.3 x its rate, and
+// beside the VALU instead of on it.  W comes pre-split from the host (ops.inter_weight_split); X1 stays fp32 in LDS and is split by the wave that
+// consumes it (each X1 element is read by exactly one wave), in the shadow of that wave's bf16 MFMAs.  Step 1 stays on the fp32 MFMA: its
+// weights are generated per use, a split per use would cost more VALU work than the matrix cores save.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+// 8 consecutive fp32 values -> 3 planes x 8 bf16; exact: v = hi + mid + lo (truncation split)
+__device__ __forceinline__ void split3_pack8(const float4 v0, const float4 v1, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h[i] = __float_as_uint(v[i]);
+        const float r = v[i] - __uint_as_float(h[i] & 0xffff0000u);
+        m[i] = __float_as_uint(r);
+        l[i] = __float_as_uint(r - __uint_as_float(m[i] & 0xffff0000u));
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    // v_perm_b32: bytes 2, 3 of the even element below bytes 2, 3 of the odd one
+#define ETCH_PK(a) (u32x4){__builtin_amdgcn_perm(a[1], a[0], 0x07060302u), __builtin_amdgcn_perm(a[3], a[2], 0x07060302u), \
+                           __builtin_amdgcn_perm(a[5], a[4], 0x07060302u), __builtin_amdgcn_perm(a[7], a[6], 0x07060302u)}
+    const u32x4 ph = ETCH_PK(h), pm = ETCH_PK(m), pl = ETCH_PK(l);
+#undef ETCH_PK
+    hi = __builtin_bit_cast(bf16x8, ph); mid = __builtin_bit_cast(bf16x8, pm); lo = __builtin_bit_cast(bf16x8, pl);
+}
+
+// waves per SIMD the BX instantiations are compiled for: the 32 -> 32 channel kernel fits four workgroups per CU in LDS (5.30 -> 5.09 ms with 128 registers)
+#ifndef INTER_BX_WPE
+#define INTER_BX_WPE(CIN, COUT) ((CIN) <= 32 && (COUT) <= 32 ? 4 : 2)
+#endif
+template <int CIN, int COUT, int MAXT, int PD, bool BX>     // MAXT = ceil(nn / 16) neighbour chunks held in registers (nn <= 16 * MAXT); PD = gather prefetch distance (chunk-steps)
+__global__ void __launch_bounds__(256, BX ? INTER_BX_WPE(CIN, COUT) : 2) inter_so3conv_kernel(
     int p1, int p2, int nn, float inv_sigma, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
     const int* __restrict__ ball_idx, const float* __restrict__ feats, const float* __restrict__ rk,
     const float* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ out, const int* __restrict__ order,
@@ -208,6 +238,38 @@ __global__ void __launch_bounds__(256, 2) inter_so3conv_kernel(
                 }
             }
             __syncthreads();
+            if constexpr (BX) {
+                // ---------------- step 2 on the bf16 matrix cores: chunk t = 32 kappas, K split over the 4 waves; per chunk and o tile six
+                // v_mfma_f32_16x16x32_bf16 (smallest cross products first), term-major so that consecutive MFMAs are independent
+                const bf16x8* Wq = reinterpret_cast<const bf16x8*>(Wp);
+#pragma unroll 1
+                for (int t = wave; t < KH / 32; t += 4) {
+                    const float* xr = &X1s[fr * S + t * 32 + fg * 8];
+                    bf16x8 bq[3];
+                    split3_pack8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4), bq[0], bq[1], bq[2]);
+#ifdef BX_ABL_SAMEW
+                    const int tg = 0;       // timing experiment: every chunk reads the same fragments (L1 hits)
+#else
+                    const int tg = (cc * HALVES + h) * (KH / 32) + t;
+#endif
+                    constexpr int MB = MT2 > 2 ? 2 : MT2;       // o tiles at a time: 2 x 3 planes x 4 registers of W fragments
+#pragma unroll
+                    for (int m0 = 0; m0 < MT2; m0 += MB) {
+                        bf16x8 aq[MB][3];
+#pragma unroll
+                        for (int mt = 0; mt < MB; ++mt)
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl) aq[mt][pl] = Wq[(((size_t)tg * MT2 + m0 + mt) * 3 + pl) * 64 + lane];
+#ifdef BX_ABL_NOMFMA
+#define BX_TERM(PA, PB) _Pragma("unroll") for (int mt = 0; mt < MB; ++mt) asm volatile("" :: "v"(aq[mt][PA]), "v"(bq[PB]));
+#else
+#define BX_TERM(PA, PB) _Pragma("unroll") for (int mt = 0; mt < MB; ++mt) y[m0 + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[mt][PA], bq[PB], y[m0 + mt], 0, 0, 0);
+#endif
+                        BX_TERM(2, 0) BX_TERM(0, 2) BX_TERM(1, 1) BX_TERM(1, 0) BX_TERM(0, 1) BX_TERM(0, 0)
+#undef BX_TERM
+                    }
+                }
+            } else
             // ---------------- step 2: K split over the 4 waves (chunk t of 16 kappas -> wave t & 3).  (An explicitly double-buffered form of
             // this loop measured 5 % slower: profiles/r02_inter_conv_experiments.txt.)
             for (int t = wave; t < KH / 16; t += 4) {
@@ -807,14 +869,14 @@ __global__ void __launch_bounds__(256) instnorm_act_add_kernel(long n4, int rows
 // ------------------------------------------------------------------------------------------------ C ABI
 // gather prefetch distance in chunk-steps (PD + 1 must divide 4 * MAXT: 1 or 3; 3 measured 3-8 % slower: more registers, fewer waves)
 #define INTER_PD(CIN, MAXT) 1
-template <int CIN, int COUT, int MAXT>
+template <int CIN, int COUT, int MAXT, bool BX>
 static int launch_inter_t(int b, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz, const int* idx,
                           const float* feats, const float* rk, const float* Wp, const float* bias, float* out, const int* order,
                           double* stat_part, hipStream_t st) {
     constexpr int CCH = CIN > 64 ? 64 : CIN;
     const size_t lds = (size_t)(16 * (CCH * KS / (CCH >= 32 ? 2 : 1) + 40) + 4 * 16 * (COUT + 4) + 16 * MAXT * 5) * sizeof(float);
     constexpr int PD = INTER_PD(CIN, MAXT);
-    auto kern = inter_so3conv_kernel<CIN, COUT, MAXT, PD>;
+    auto kern = inter_so3conv_kernel<CIN, COUT, MAXT, PD, BX>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -826,13 +888,13 @@ static int launch_inter_t(int b, int p1, int p2, int nn, float sigma, const floa
     return ETCH_OK;
 }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool BX>
 static int launch_inter(int b, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz, const int* idx,
                         const float* feats, const float* rk, const float* Wp, const float* bias, float* out, const int* order,
                         double* stat_part, hipStream_t st) {
-    if (nn <= 16) return launch_inter_t<CIN, COUT, 1>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, order, stat_part, st);
-    if (nn <= 32) return launch_inter_t<CIN, COUT, 2>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, order, stat_part, st);
-    return launch_inter_t<CIN, COUT, 4>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, order, stat_part, st);
+    if (nn <= 16) return launch_inter_t<CIN, COUT, 1, BX>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, order, stat_part, st);
+    if (nn <= 32) return launch_inter_t<CIN, COUT, 2, BX>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, order, stat_part, st);
+    return launch_inter_t<CIN, COUT, 4, BX>(b, p1, p2, nn, sigma, xyz, new_xyz, idx, feats, rk, Wp, bias, out, order, stat_part, st);
 }
 
 template <int C, int COUT>
@@ -896,7 +958,7 @@ int etch_inter_so3conv_ordered(int b, int cin, int cout, int p1, int p2, int nn,
     if (nn <= 0 || nn > 64 || sigma <= 0.f) return ETCH_EINVAL;
     hipStream_t st = (hipStream_t)stream;
 #define INTER_CASE(CI, CO) \
-    if (cin == CI && cout == CO) return launch_inter<CI, CO>(b, p1, p2, nn, sigma, xyz, new_xyz, ball_idx, feats, rk, Wp, bias, out, order, stat_part, st);
+    if (cin == CI && cout == CO) return launch_inter<CI, CO, false>(b, p1, p2, nn, sigma, xyz, new_xyz, ball_idx, feats, rk, Wp, bias, out, order, stat_part, st);
     INTER_CASE(16, 16) INTER_CASE(16, 32) INTER_CASE(32, 32) INTER_CASE(32, 64) INTER_CASE(64, 64)
     INTER_CASE(64, 128) INTER_CASE(128, 128) INTER_CASE(128, 256) INTER_CASE(256, 256)       // encoder depths 3 / 4 (models_pointcloud.py:34-48)
 #undef INTER_CASE
@@ -917,6 +979,23 @@ int etch_inter_so3conv_ordered(int b, int cin, int cout, int p1, int p2, int nn,
         ETCH_RETURN_IF_LAUNCH_FAILED();
         return ETCH_OK;
     }
+    return ETCH_EUNSUPPORTED;
+}
+
+// The same convolution with step 2 on the bf16 matrix cores (split fp32 operands, see inter_so3conv_kernel BX).  Wq = ops.inter_weight_split:
+// [chunk of 32 kappas][o tile][plane hi / mid / lo][lane][8 bf16] in the kernel's contraction order.
+int etch_inter_so3conv_split(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
+                             const int* ball_idx, const float* feats, const float* rk, const void* Wq, const float* bias, float* out,
+                             const int* order, double* stat_part, void* stream) {
+    if (b <= 0 || p2 <= 0) return ETCH_OK;
+    if (nn <= 0 || nn > 64 || sigma <= 0.f || !Wq) return ETCH_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const float* Wp = reinterpret_cast<const float*>(Wq);
+#define INTER_CASE(CI, CO) \
+    if (cin == CI && cout == CO) return launch_inter<CI, CO, true>(b, p1, p2, nn, sigma, xyz, new_xyz, ball_idx, feats, rk, Wp, bias, out, order, stat_part, st);
+    INTER_CASE(16, 16) INTER_CASE(16, 32) INTER_CASE(32, 32) INTER_CASE(32, 64) INTER_CASE(64, 64)
+    INTER_CASE(64, 128) INTER_CASE(128, 128) INTER_CASE(128, 256) INTER_CASE(256, 256)
+#undef INTER_CASE
     return ETCH_EUNSUPPORTED;
 }
 

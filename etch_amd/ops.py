@@ -165,6 +165,11 @@ def inter_weight_frag(W, cin, ks=24):
     contraction order (csrc/so3conv.hip: channels are processed in passes of CCH = min(cin, 64); within a pass a lane gathers
     VEC = CCH/16 consecutive channels per load, so column r of c-tile mi is channel VEC*r + mi and sits at position 16*mi + r of its
     half; halves h of the X1 tile hold the tiles [h*MTH, (h+1)*MTH)), then permuted into MFMA fragment order."""
+    return permute_weight_frag(W[:, _inter_contraction_cols(cin, ks, W.device)].contiguous())
+
+
+def _inter_contraction_cols(cin, ks, device):
+    """Column permutation of W [cout, cin*ks] into the contraction order of inter_so3conv_kernel (see inter_weight_frag)."""
     cch = min(cin, 64)
     vec = cch // 16
     halves = 2 if cch >= 32 else 1
@@ -172,8 +177,30 @@ def inter_weight_frag(W, cin, ks=24):
     one = [vec * (cc % 16) + h * mth + cc // 16 for h in range(halves) for cc in range(cch // halves)]
     order = [p * cch + c for p in range(cin // cch) for c in one]
     assert sorted(order) == list(range(cin))
-    cols = torch.tensor([c * ks + k for c in order for k in range(ks)], dtype=torch.long, device=W.device)
-    return permute_weight_frag(W[:, cols].contiguous())
+    return torch.tensor([c * ks + k for c in order for k in range(ks)], dtype=torch.long, device=device)
+
+
+def split3_bf16(x):
+    """fp32 tensor -> (3, *x.shape) int16: the bf16 bit patterns of the exact split x = hi + mid + lo (8 + 8 + 8 mantissa bits, by truncation;
+    csrc/so3conv.hip split3_pack4 is the device-side twin)."""
+    x = x.contiguous()
+    hi = x.view(torch.int32) & -65536
+    r = x - hi.view(torch.float32)
+    mid = r.view(torch.int32) & -65536
+    lo = (r - mid.view(torch.float32)).view(torch.int32)
+    return torch.stack([(t >> 16).to(torch.int16) for t in (hi, mid, lo)])
+
+
+def inter_weight_split(W, cin, ks=24):
+    """Weight of the inter conv for the split-operand kernel (etch_inter_so3conv_split): columns in the kernel's contraction order (the one of
+    inter_weight_frag), split into three bf16 planes, in v_mfma_f32_16x16x32_bf16 A-fragment order:
+    [chunk of 32 kappas][o tile][plane][lane = 16 * (k / 8) + o % 16][8]."""
+    cout = W.shape[0]
+    assert cin % 16 == 0 and cout % 16 == 0 and W.shape[1] == cin * ks and ks == 24
+    planes = split3_bf16(W[:, _inter_contraction_cols(cin, ks, W.device)])     # [3][cout][K]
+    K = cin * ks
+    q = planes.reshape(3, cout // 16, 16, K // 32, 4, 8)                 # [pl][mt][ol][tg][kg][e]
+    return q.permute(3, 1, 0, 4, 2, 5).contiguous().reshape(-1)          # [tg][mt][pl][kg][ol][e]
 
 
 def inter_weight_frag32(W, cin, ks=24):
@@ -189,6 +216,7 @@ def inter_weight_frag32(W, cin, ks=24):
     return w.permute(2, 5, 0, 3, 4, 6, 1, 7).contiguous().reshape(-1)
 
 
+INTER_SPLIT = os.environ.get("ETCH_INTER_SPLIT", "1") != "0"      # step 2 of the inter conv on the bf16 matrix cores (split fp32 operands); 0: fp32 MFMA
 INTER_MFMA32 = os.environ.get("ETCH_INTER_MFMA32", "0") == "1"     # (32|64) -> (32|64) channels: the 32x32x2 MFMA form, two points per workgroup
 INTER_MFMA32_SHAPES = ((32, 32), (32, 64), (64, 64))
 
@@ -204,7 +232,7 @@ def spatial_order(xyz):
     return order
 
 
-def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, order=None, want_stats=False, Wp32=None):
+def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, order=None, want_stats=False, Wp32=None, Wq=None):
     """feats_cl (b,p1,60,cin) channels-last -> (b,p2,60,cout) pre-norm.  order (b,p2) int32: processing order of the output points.
     want_stats: also return the InstanceNorm (mean, rstd) of the output, accumulated in the conv's epilogue."""
     b, p1, na, cin = feats_cl.shape
@@ -224,6 +252,11 @@ def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, orde
         _lib.check(_lib.lib().etch_inter_so3conv32(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
                                                    _ptr(feats_cl), _ptr(rk), _ptr(Wp32), _ptr(bias), _ptr(out), _optptr(order),
                                                    _optptr(part), _stream()), "etch_inter_so3conv32")
+    elif Wq is not None and INTER_SPLIT and cin % 16 == 0:
+        _need(Wq, torch.int16, "Wq")
+        _lib.check(_lib.lib().etch_inter_so3conv_split(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
+                                                      _ptr(feats_cl), _ptr(rk), _ptr(Wq), _ptr(bias), _ptr(out), _optptr(order),
+                                                      _optptr(part), _stream()), "etch_inter_so3conv_split")
     else:
         _lib.check(_lib.lib().etch_inter_so3conv_ordered(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
                                                          _ptr(feats_cl), _ptr(rk), _ptr(W), _optptr(Wp), _ptr(bias), _ptr(out), _optptr(order),

@@ -127,6 +127,7 @@ class InterSO3Conv(nn.Module):
         self.register_buffer("kernels", torch.from_numpy(kernels))
         self._d = _Derived()
         self._d32 = _Derived()
+        self._dq = _Derived()
 
     def _derived(self):
         W, bias = self.basic_conv.W, self.basic_conv.bias
@@ -146,6 +147,13 @@ class InterSO3Conv(nn.Module):
             return None
         W = self.basic_conv.W
         return self._d32.get((W,), lambda: ops.inter_weight_frag32(W.detach().contiguous(), self.dim_in, self.kernel_size))
+
+    def _wq(self):
+        """Weight as three bf16 planes in the fragment order of the split-operand kernel (etch_inter_so3conv_split); None for cin < 16."""
+        if self.dim_in % 16 != 0 or self.dim_out % 16 != 0 or self.kernel_size != 24:
+            return None
+        W = self.basic_conv.W
+        return self._dq.get((W,), lambda: ops.inter_weight_split(W.detach().contiguous(), self.dim_in, self.kernel_size))
 
     def group(self, xyz):
         """functional.py:176-185 inter_spconv_grouping_ball (index part): -> ball_idx, sample_idx, new_xyz.
@@ -177,7 +185,7 @@ class InterSO3Conv(nn.Module):
         else:
             sample_idx, new_xyz = None, xyz
         rk, W, Wp, bias = self._derived()
-        y, stats = ops.inter_so3conv(xyz, new_xyz, inter_idx, x.feats_cl, rk, W, Wp, bias, self.sigma, order=self.order(new_xyz), want_stats=True, Wp32=self._wp32())
+        y, stats = ops.inter_so3conv(xyz, new_xyz, inter_idx, x.feats_cl, rk, W, Wp, bias, self.sigma, order=self.order(new_xyz), want_stats=True, Wp32=self._wp32(), Wq=self._wq())
         cloud = SphericalPointCloud(new_xyz, None, self.anchors, feats_cl=y)
         cloud.in_stats = stats          # InstanceNorm (mean, rstd) of the output, a by-product of the conv's epilogue
         return inter_idx, None, sample_idx, cloud

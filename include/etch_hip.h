@@ -126,6 +126,14 @@ int etch_inter_so3conv32(int b, int cin, int cout, int p1, int p2, int nn, float
                          const int* ball_idx, const float* feats, const float* rk, const float* Wp32, const float* bias, float* out,
                          const int* order, double* stat_part, void* stream);
 
+/* The same convolution with its second contraction (W x X1, 1/2 - 2/3 of the flops) on the bf16 matrix cores: every fp32 operand split exactly
+ * into three bf16 values (8 + 8 + 8 mantissa bits), the six largest cross products accumulated in fp32 -- the error against fp64 of the fp32
+ * MFMA (profiles/r03_bf16x3_split.txt) at 2.3 x its rate.  cin, cout multiples of 16.  Wq: 3 * cout * cin * 24 bf16 =
+ * [chunk of 32 kappas][o tile][plane hi / mid / lo][lane][8] in the kernel's contraction order (etch_amd/ops.py inter_weight_split). */
+int etch_inter_so3conv_split(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
+                             const int* ball_idx, const float* feats, const float* rk, const void* Wq, const float* bias, float* out,
+                             const int* order, double* stat_part, void* stream);
+
 /* mean / rstd (b,C) of InstanceNorm2d(affine=False, eps 1e-5) from per-part partial sums: partial (b,nparts,2,C) fp64, each over `count`
  * values.  Same result as etch_instnorm_stats over the full tensor (fp64 accumulation, fixed order). */
 int etch_instnorm_from_partials(int b, int nparts, int C, int count, const double* partial, float* mean, float* rstd, void* stream);
