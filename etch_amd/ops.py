@@ -203,6 +203,17 @@ def inter_weight_split(W, cin, ks=24):
     return q.permute(3, 1, 0, 4, 2, 5).contiguous().reshape(-1)          # [tg][mt][pl][kg][ol][e]
 
 
+def intra_weight_split(w2):
+    """W2 [C, 12 C] (tap-major K: W2[o, tap * C + ch]) -> the register-resident fragments of the weight-stationary intra conv
+    (csrc/so3conv_ws.hip): [mt][kq][K step][plane][lane = 32 * (k / 8) + o % 32][8] with k = 3 kq C + 16 ks + 8 (lane / 32) + e."""
+    C, K = w2.shape
+    assert K == 12 * C and C in (32, 64)
+    nks = 3 * C // 16
+    planes = split3_bf16(w2)                                             # [3][C][K]
+    q = planes.reshape(3, C // 32, 32, 4, nks, 2, 8)                     # [pl][mt][i][kq][ks][kg][e]
+    return q.permute(1, 3, 4, 0, 5, 2, 6).contiguous().reshape(-1)       # [mt][kq][ks][pl][kg][i][e]
+
+
 def inter_weight_frag32(W, cin, ks=24):
     """Fragment order of the 32x32x2 inter conv (csrc/so3conv32.hip): [slice = 3 h + g][mt][kp][u][lane][4] with
     [lane][s] = W[32 mt + lane % 32][(32 h + c) * 24 + 8 g + 4 (lane / 32) + s], c = kp * NU + u -- h = 32-channel tile of the input,
@@ -272,9 +283,10 @@ def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, orde
 
 
 INTRA_MFMA32 = os.environ.get("ETCH_INTRA_MFMA32", "1") != "0"     # widths 32 / 64: the 32x32x2 MFMA form (ETCH_INTRA_MFMA32=0: the 16x16x4 kernel)
+INTRA_SPLIT = os.environ.get("ETCH_INTRA_SPLIT", "1") != "0"       # widths 32 / 64: weight-stationary on the bf16 matrix cores, split fp32 operands
 
 
-def intra_so3conv(x_cl, intra_idx32, Wp, bias, cout, mean=None, rstd=None, want_stats=False, Wp32=None):
+def intra_so3conv(x_cl, intra_idx32, Wp, bias, cout, mean=None, rstd=None, want_stats=False, Wp32=None, Wq=None):
     """want_stats: also return the InstanceNorm (mean, rstd) of the output, accumulated in the conv's epilogue (even point counts;
     otherwise by the separate statistics pass)."""
     b, p, na, c = x_cl.shape
@@ -282,7 +294,11 @@ def intra_so3conv(x_cl, intra_idx32, Wp, bias, cout, mean=None, rstd=None, want_
     out = torch.empty((b, p, 60, cout), dtype=torch.float32, device=x_cl.device)
     fused = want_stats and p % 2 == 0 and c <= 64        # wider tiles (encoder depths 3 / 4) take the separate statistics pass
     part = torch.empty((b * (p // 2), 2, cout), dtype=torch.float64, device=x_cl.device) if fused else None
-    if Wp32 is not None and INTRA_MFMA32 and c == cout and c in (32, 64):
+    if Wq is not None and INTRA_SPLIT and c == cout and c in (32, 64) and (part is None or p % 2 == 0):
+        _need(Wq, torch.int16, "Wq")
+        _lib.check(_lib.lib().etch_intra_so3conv_split(b, c, cout, p, _ptr(x_cl), _optptr(mean), _optptr(rstd), _ptr(intra_idx32), _ptr(Wq),
+                                                      _ptr(bias), _ptr(out), _optptr(part), _stream()), "etch_intra_so3conv_split")
+    elif Wp32 is not None and INTRA_MFMA32 and c == cout and c in (32, 64):
         _lib.check(_lib.lib().etch_intra_so3conv32(b, c, cout, p, _ptr(x_cl), _optptr(mean), _optptr(rstd), _ptr(intra_idx32), _ptr(Wp32),
                                                    _ptr(bias), _ptr(out), _optptr(part), _stream()), "etch_intra_so3conv32")
     else:

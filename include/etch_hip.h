@@ -158,6 +158,13 @@ int etch_intra_so3conv_stats(int b, int c, int cout, int p, const float* X, cons
 int etch_intra_so3conv32(int b, int c, int cout, int p, const float* X, const float* mean, const float* rstd, const int* intra_idx,
                          const float* Wp32, const float* bias, float* Y, double* stat_part, void* stream);
 
+/* The same convolution, weight-stationary on the bf16 matrix cores (csrc/so3conv_ws.hip): fp32 operands split exactly into three bf16 values, six
+ * cross products accumulated in fp32 (the fp32 MFMA's error against fp64, profiles/r03_bf16x3_split.txt); W lives in registers for the whole launch,
+ * persistent workgroups walk point pairs.  c = cout in {32, 64}; Wq = etch_amd/ops.py intra_weight_split:
+ * [mt][kq][K step][plane hi / mid / lo][lane][8 bf16] of W2 above.  stat_part as etch_intra_so3conv_stats (p even) or NULL. */
+int etch_intra_so3conv_split(int b, int c, int cout, int p, const float* X, const float* mean, const float* rstd, const int* intra_idx,
+                             const void* Wq, const float* bias, float* Y, double* stat_part, void* stream);
+
 /* InstanceNorm2d(affine=False, eps=1e-5) statistics over (p,a) per (b,c) (src/models/so3conv.py:24,85,168).
  * x (b,rows,C) -> mean (b,C), rstd (b,C).  workspace: etch_instnorm_stats_workspace_bytes(b, C) bytes. */
 int etch_instnorm_stats(int b, int rows, int C, const float* x, double* workspace, float* mean, float* rstd, void* stream);
