@@ -66,33 +66,175 @@ __device__ __forceinline__ void ml_softmax(f32x4 (&s)[4], int fg) {
     for (int j = 0; j < 4; ++j) s[j] *= inv;
 }
 
+// ---- the four dense products of the layer (q / k / v transforms, head_combine: 57 % of its MFMAs) on the bf16 matrix cores with exactly split
+// fp32 operands: x = hi + mid + lo (8 + 8 + 8 mantissa bits, by truncation), the six largest cross products accumulated in fp32 by
+// v_mfma_f32_16x16x32_bf16 -- the error against fp64 of the fp32 MFMA (profiles/r03_bf16x3_split.txt) at 2.3 x its rate, and beside the VALU
+// instead of on its datapath.  Their C/D layout is that of v_mfma_f32_16x16x4_f32, so the attention phase -- whose operands ARE the
+// projections' accumulators -- is untouched (it stays on the fp32 MFMA: its operands are produced per use).  The weights are split once per
+// workgroup (registers), the token tile when it is staged in LDS, the attention output when it is stored for head_combine.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+#define ML_PL (64 * 64)      // bf16 elements of one plane of a 64 x 64 tile: rows of 128 bytes, 16-byte units XOR-swizzled with the row (no padding:
+                             // three planes of a tile take 24.6 KB against 26.6 KB of the padded fp32 tile, so three workgroups still share a CU)
+__device__ __forceinline__ int ml_sw(int row, int k) { return row * 64 + ((((k) >> 3) ^ (row & 7)) << 3) + (k & 7); }
+#define ML_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ void ml_split(const float v, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(v);
+    const float r = v - __uint_as_float(h & 0xffff0000u);
+    m = __float_as_uint(r);
+    l = __float_as_uint(r - __uint_as_float(m & 0xffff0000u));
+}
+// 8 consecutive fp32 values -> 3 planes x 8 bf16
+__device__ __forceinline__ void ml_split8(const float4 v0, const float4 v1, bf16x8 (&o)[3]) {
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ml_split(v[i], h[i], m[i], l[i]);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    // v_perm_b32: bytes 2, 3 of the even element below bytes 2, 3 of the odd one
+#define ML_PK(a) (u32x4){__builtin_amdgcn_perm(a[1], a[0], 0x07060302u), __builtin_amdgcn_perm(a[3], a[2], 0x07060302u), \
+                         __builtin_amdgcn_perm(a[5], a[4], 0x07060302u), __builtin_amdgcn_perm(a[7], a[6], 0x07060302u)}
+    const u32x4 ph = ML_PK(h), pm = ML_PK(m), pl = ML_PK(l);
+#undef ML_PK
+    o[0] = __builtin_bit_cast(bf16x8, ph); o[1] = __builtin_bit_cast(bf16x8, pm); o[2] = __builtin_bit_cast(bf16x8, pl);
+}
+// float4 number e (row e >> 4, channels 4 (e & 15) ..) of a token tile -> the three planes
+__device__ __forceinline__ void ml_stage4(unsigned short* P, int e, const float4 v4) {
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ml_split(v[i], h[i], m[i], l[i]);
+    unsigned short* d = P + ml_sw(e >> 4, (e & 15) * 4);
+    *reinterpret_cast<uint2*>(d) = make_uint2(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u));
+    *reinterpret_cast<uint2*>(d + ML_PL) = make_uint2(__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u));
+    *reinterpret_cast<uint2*>(d + 2 * ML_PL) = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
+}
+// six cross products of one K = 32 step, smallest first
+#define ML_BX6(ACC, A, B)                                                                                   \
+    ACC = ML_MFMA16(A[2], B[0], ACC); ACC = ML_MFMA16(A[0], B[2], ACC); ACC = ML_MFMA16(A[1], B[1], ACC);  \
+    ACC = ML_MFMA16(A[1], B[0], ACC); ACC = ML_MFMA16(A[0], B[1], ACC); ACC = ML_MFMA16(A[0], B[0], ACC);
+
+struct MlWeights {          // fragments of this wave's tiles, K step ks = channels 32 ks + 8 fg .. + 7 of row / column fr
+    bf16x8 q[2][3], k[2][3], v[2][3], c[2][3];
+};
+template <bool COMBINE>
+__device__ __forceinline__ void ml_load_weights(MlWeights& W, const float* __restrict__ Wq, const float* __restrict__ Wk, const float* __restrict__ Wv,
+                                                const float* __restrict__ Wc, int w, int fr, int fg) {
+    const int chq = 8 * (2 * w + ((fr & 3) >> 1)) + 2 * (fr >> 2) + (fr & 1);    // Q/K tile row fr -> original channel
+    const int chv = 16 * w + fr;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int o = ks * 32 + fg * 8;
+        ml_split8(*reinterpret_cast<const float4*>(Wq + chq * ML_C + o), *reinterpret_cast<const float4*>(Wq + chq * ML_C + o + 4), W.q[ks]);
+        ml_split8(*reinterpret_cast<const float4*>(Wk + chq * ML_C + o), *reinterpret_cast<const float4*>(Wk + chq * ML_C + o + 4), W.k[ks]);
+        ml_split8(*reinterpret_cast<const float4*>(Wv + chv * ML_C + o), *reinterpret_cast<const float4*>(Wv + chv * ML_C + o + 4), W.v[ks]);
+        if (COMBINE) ml_split8(*reinterpret_cast<const float4*>(Wc + chv * ML_C + o), *reinterpret_cast<const float4*>(Wc + chv * ML_C + o + 4), W.c[ks]);
+    }
+}
+// A: projections of this wave's two heads from the token planes
+__device__ __forceinline__ void ml_project(const unsigned short* Xp, const MlWeights& W, f32x4 (&Q)[4], f32x4 (&Kt)[4], f32x4 (&V)[4], int fr, int fg) {
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        f32x4 q = {0.f, 0.f, 0.f, 0.f}, k = q, v = q;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 x[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) x[pl] = *reinterpret_cast<const bf16x8*>(Xp + pl * ML_PL + ml_sw(tt * 16 + fr, ks * 32 + fg * 8));
+            // term-major over q / k / v: consecutive MFMAs are independent
+#define ML_T(PA, PB) q = ML_MFMA16(W.q[ks][PA], x[PB], q); k = ML_MFMA16(W.k[ks][PA], x[PB], k); v = ML_MFMA16(x[PB], W.v[ks][PA], v);
+            ML_T(2, 0) ML_T(0, 2) ML_T(1, 1) ML_T(1, 0) ML_T(0, 1) ML_T(0, 0)
+#undef ML_T
+        }
+        Q[tt] = q; Kt[tt] = k; V[tt] = v;
+    }
+}
+// B: attention of heads 2w (registers 0,1 / output columns 0-7) and 2w+1 (registers 2,3 / columns 8-15) on the fp32 MFMA; the output tile goes to
+// LDS as fp32 (As: the layer's output in MODE 2) or as the three planes of head_combine's operand (Ap)
+template <bool PLANES>
+__device__ __forceinline__ void ml_attention(const f32x4 (&Q)[4], const f32x4 (&Kt)[4], const f32x4 (&V)[4], float* As, unsigned short* Ap, int w, int fr, int fg) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        f32x4 sa[4], sb[4];
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const float pad = fg == 3 ? -1e30f : 0.f;                     // padded keys 60..63 (tile 3, lane group 3): exp2 -> 0
+        const f32x4 zpad = {pad, pad, pad, pad};
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            sa[jt] = ML_MFMA(Kt[jt][0], Q[it][0], jt == 3 ? zpad : z);
+            sb[jt] = ML_MFMA(Kt[jt][2], Q[it][2], jt == 3 ? zpad : z);
+        }
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            sa[jt] = ML_MFMA(Kt[jt][1], Q[it][1], sa[jt]);
+            sb[jt] = ML_MFMA(Kt[jt][3], Q[it][3], sb[jt]);
+        }
+        ml_softmax(sa, fg);
+        ml_softmax(sb, fg);
+        f32x4 oa = z, ob = z;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                oa = ML_MFMA(sa[jt][r], V[jt][r], oa);
+                ob = ML_MFMA(sb[jt][r], V[jt][r], ob);
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float o = fr < 8 ? oa[r] : ob[r];
+            const int row = it * 16 + fg * 4 + r, col = 16 * w + fr;
+            if (PLANES) {
+                unsigned h, m, l;
+                ml_split(o, h, m, l);
+                unsigned short* d = Ap + ml_sw(row, col);
+                d[0] = (unsigned short)(h >> 16); d[ML_PL] = (unsigned short)(m >> 16); d[2 * ML_PL] = (unsigned short)(l >> 16);
+            } else {
+                As[row * ML_S + col] = o;
+            }
+        }
+    }
+}
+// C: head_combine, transposed (rows = this wave's 16 output channels, columns = tokens)
+__device__ __forceinline__ void ml_combine(const unsigned short* Ap, const MlWeights& W, f32x4 (&y)[4], int fr, int fg) {
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) y[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 a[4][3];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[tt][pl] = *reinterpret_cast<const bf16x8*>(Ap + pl * ML_PL + ml_sw(tt * 16 + fr, ks * 32 + fg * 8));
+#define ML_T(PA, PB) _Pragma("unroll") for (int tt = 0; tt < 4; ++tt) y[tt] = ML_MFMA16(W.c[ks][PA], a[tt][PB], y[tt]);
+        ML_T(2, 0) ML_T(0, 2) ML_T(1, 1) ML_T(1, 0) ML_T(0, 1) ML_T(0, 0)
+#undef ML_T
+    }
+}
+
 // MODE 0: out = X + att Wc^T + bc (residual layer);  1: out = att Wc^T + bc;  2: out = att (head_combine folded downstream)
+// waves per SIMD the layer is compiled for: the split weight fragments (72 - 96 registers) no longer fit three (168 registers, 116 - 268 bytes
+// of scratch: mode 0 / mode 2 = 5.02 / 3.93 ms); two (no scratch): 4.13 / 3.68 ms
+#ifndef ML_LAYER_WPE
+#define ML_LAYER_WPE 2
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(256, MODE == 2 ? 3 : 2) mhsa_layer_kernel(long T, const float* __restrict__ X, const float* __restrict__ Wq,
+__global__ void __launch_bounds__(256, ML_LAYER_WPE) mhsa_layer_kernel(long T, const float* __restrict__ X, const float* __restrict__ Wq,
                                                             const float* __restrict__ Wk, const float* __restrict__ Wv,
                                                             const float* __restrict__ Wc, const float* __restrict__ bc,
                                                             float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float Xs[64 * ML_S];
-    __shared__ __attribute__((aligned(16))) float As[64 * ML_S];
+    __shared__ __attribute__((aligned(16))) unsigned short Xp[3 * ML_PL];                     // token tile, three planes
+    __shared__ __attribute__((aligned(16))) float Asm[MODE == 2 ? 64 * ML_S : 3 * ML_PL / 2];   // attention tile: fp32 (MODE 2) or three planes
+    float* As = Asm;
+    unsigned short* Ap = reinterpret_cast<unsigned short*>(Asm);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
 
-    // weight fragments (interleaved-K: lane group fg holds k = 16t + 4fg + s of its row), resident in registers
-    float4 wq[4], wk[4], wv[4], wc[4];
-    {
-        const int chq = 8 * (2 * w + ((fr & 3) >> 1)) + 2 * (fr >> 2) + (fr & 1);    // Q/K tile row fr -> original channel
-        const int chv = 16 * w + fr;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            wq[t] = *reinterpret_cast<const float4*>(Wq + chq * ML_C + t * 16 + fg * 4);
-            wk[t] = *reinterpret_cast<const float4*>(Wk + chq * ML_C + t * 16 + fg * 4);
-            wv[t] = *reinterpret_cast<const float4*>(Wv + chv * ML_C + t * 16 + fg * 4);
-            if (MODE != 2) wc[t] = *reinterpret_cast<const float4*>(Wc + chv * ML_C + t * 16 + fg * 4);
-        }
-    }
+    MlWeights W;
+    ml_load_weights<MODE != 2>(W, Wq, Wk, Wv, Wc, w, fr, fg);
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
     if (MODE != 2 && bc) bias = *reinterpret_cast<const float4*>(bc + 16 * w + 4 * fg);
-    Xs[(ML_TOK + (tid >> 6)) * ML_S + (tid & 63)] = 0.f;      // token rows 60..63 stay zero for the whole kernel
+    // token rows 60..63 stay zero for the whole kernel (all planes): 3 x 4 rows x 64 bf16 = 384 dwords
+    for (int e = tid; e < 384; e += 256) reinterpret_cast<unsigned*>(Xp + (e / 128) * ML_PL + ML_TOK * 64)[e % 128] = 0u;
 
     // next point's tokens: 960 float4 over 256 threads, four named registers (an indexed array captured by a lambda ended up
     // in scratch memory: +5 GB of HBM traffic per launch)
@@ -106,63 +248,14 @@ __global__ void __launch_bounds__(256, MODE == 2 ? 3 : 2) mhsa_layer_kernel(long
     long pt = blockIdx.x;
     if (pt < T) ML_GLOAD(pt)
     for (; pt < T; pt += gridDim.x) {
-        *reinterpret_cast<float4*>(&Xs[(tid >> 4) * ML_S + (tid & 15) * 4]) = x0;
-        *reinterpret_cast<float4*>(&Xs[((tid >> 4) + 16) * ML_S + (tid & 15) * 4]) = x1;
-        *reinterpret_cast<float4*>(&Xs[((tid >> 4) + 32) * ML_S + (tid & 15) * 4]) = x2;
-        if (tid < ML_TOK * ML_C / 4 - 768) *reinterpret_cast<float4*>(&Xs[((tid >> 4) + 48) * ML_S + (tid & 15) * 4]) = x3;
+        ml_stage4(Xp, tid, x0); ml_stage4(Xp, tid + 256, x1); ml_stage4(Xp, tid + 512, x2);
+        if (tid < ML_TOK * ML_C / 4 - 768) ml_stage4(Xp, tid + 768, x3);
         __syncthreads();
         if (pt + gridDim.x < T) ML_GLOAD(pt + gridDim.x)      // next point's tokens: in flight during the whole layer
 
-        // ---- A: projections of this wave's two heads
         f32x4 Q[4], Kt[4], V[4];
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            float4 xf[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) xf[t] = *reinterpret_cast<const float4*>(&Xs[(tt * 16 + fr) * ML_S + t * 16 + fg * 4]);
-            f32x4 q = {0.f, 0.f, 0.f, 0.f}, k = q, v = q;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-#define ML_STEP(C)                     \
-    q = ML_MFMA(wq[t].C, xf[t].C, q);  \
-    k = ML_MFMA(wk[t].C, xf[t].C, k);  \
-    v = ML_MFMA(xf[t].C, wv[t].C, v);
-                ML_STEP(x) ML_STEP(y) ML_STEP(z) ML_STEP(w)
-#undef ML_STEP
-            }
-            Q[tt] = q; Kt[tt] = k; V[tt] = v;
-        }
-
-        // ---- B: attention of heads 2w (registers 0,1 / output columns 0-7) and 2w+1 (registers 2,3 / columns 8-15)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            f32x4 sa[4], sb[4];
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const float pad = fg == 3 ? -1e30f : 0.f;                     // padded keys 60..63 (tile 3, lane group 3): exp2 -> 0
-            const f32x4 zpad = {pad, pad, pad, pad};
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                sa[jt] = ML_MFMA(Kt[jt][0], Q[it][0], jt == 3 ? zpad : z);
-                sb[jt] = ML_MFMA(Kt[jt][2], Q[it][2], jt == 3 ? zpad : z);
-            }
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                sa[jt] = ML_MFMA(Kt[jt][1], Q[it][1], sa[jt]);
-                sb[jt] = ML_MFMA(Kt[jt][3], Q[it][3], sb[jt]);
-            }
-            ml_softmax(sa, fg);
-            ml_softmax(sb, fg);
-            f32x4 oa = z, ob = z;
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    oa = ML_MFMA(sa[jt][r], V[jt][r], oa);
-                    ob = ML_MFMA(sb[jt][r], V[jt][r], ob);
-                }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) As[(it * 16 + fg * 4 + r) * ML_S + 16 * w + fr] = fr < 8 ? oa[r] : ob[r];
-        }
+        ml_project(Xp, W, Q, Kt, V, fr, fg);
+        ml_attention<MODE != 2>(Q, Kt, V, As, Ap, w, fr, fg);
         __syncthreads();
 
         float* dst = out + pt * (ML_TOK * ML_C);
@@ -174,33 +267,22 @@ __global__ void __launch_bounds__(256, MODE == 2 ? 3 : 2) mhsa_layer_kernel(long
                     reinterpret_cast<float4*>(dst)[e] = *reinterpret_cast<const float4*>(&As[(e >> 4) * ML_S + (e & 15) * 4]);
             }
         } else {
-            // ---- C: head_combine, transposed (rows = this wave's 16 output channels, columns = tokens) -> float4 stores
             f32x4 y[4];
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) y[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                float4 af[4];
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt) af[tt] = *reinterpret_cast<const float4*>(&As[(tt * 16 + fr) * ML_S + t * 16 + fg * 4]);
-#define ML_STEP(C) _Pragma("unroll") for (int tt = 0; tt < 4; ++tt) y[tt] = ML_MFMA(wc[t].C, af[tt].C, y[tt]);
-                ML_STEP(x) ML_STEP(y) ML_STEP(z) ML_STEP(w)
-#undef ML_STEP
-            }
+            ml_combine(Ap, W, y, fr, fg);
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 const int tok = tt * 16 + fr;
                 if (tok < ML_TOK) {
                     float4 o = make_float4(y[tt][0] + bias.x, y[tt][1] + bias.y, y[tt][2] + bias.z, y[tt][3] + bias.w);
-                    if (MODE == 0) {
-                        const float4 rx = *reinterpret_cast<const float4*>(&Xs[tok * ML_S + 16 * w + 4 * fg]);
+                    if (MODE == 0) {                       // the residual: the point's own rows again (L2: they were read a layer ago)
+                        const float4 rx = *reinterpret_cast<const float4*>(X + pt * (ML_TOK * ML_C) + tok * ML_C + 16 * w + 4 * fg);
                         o.x += rx.x; o.y += rx.y; o.z += rx.z; o.w += rx.w;
                     }
                     *reinterpret_cast<float4*>(dst + tok * ML_C + 16 * w + 4 * fg) = o;
                 }
             }
         }
-        __syncthreads();      // Xs / As are rewritten by the next point
+        __syncthreads();      // Xp / As are rewritten by the next point
     }
 }
 
@@ -242,31 +324,25 @@ __global__ void __launch_bounds__(256) interp_schedule_kernel(int B, int N, int 
 
 // out[b,n] = X + att Wc^T + bc with X = blend of three rows of F (B,S,60,64), sched from interp_schedule_kernel.  Grid = multiple of 8
 // workgroups.  Per scan point: its three coarse token rows were requested during the previous point (12 float4 in registers) and are
-// blended into LDS; the rows of the NEXT point are requested before the layer's three phases start.
+// blended into LDS (fp32 for the residual, three bf16 planes for the projections); the rows of the NEXT point are requested before the
+// layer's three phases start.  LDS: 26.6 + 24.6 + 24.6 KB (dynamic).
+#define ML_INTERP_LDS (64 * ML_S * 4 + 2 * 3 * ML_PL * 2)
 __global__ void __launch_bounds__(256, MHSA_INTERP_WGS) mhsa_interp_layer_kernel(int B, int N, int S, const float* __restrict__ F,
                                                                    const int* __restrict__ sched, const float* __restrict__ Wq,
                                                                    const float* __restrict__ Wk, const float* __restrict__ Wv,
                                                                    const float* __restrict__ Wc, const float* __restrict__ bc,
                                                                    float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float Xs[64 * ML_S];
-    __shared__ __attribute__((aligned(16))) float As[64 * ML_S];
+    extern __shared__ __attribute__((aligned(16))) float ml_dyn[];
+    float* Xs = ml_dyn;                                                            // [64][ML_S] fp32 token tile (residual)
+    unsigned short* Xp = reinterpret_cast<unsigned short*>(ml_dyn + 64 * ML_S);    // its three planes
+    unsigned short* Ap = Xp + 3 * ML_PL;                                           // attention tile, three planes
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    float4 wq[4], wk[4], wv[4], wc[4];
-    {
-        const int chq = 8 * (2 * w + ((fr & 3) >> 1)) + 2 * (fr >> 2) + (fr & 1);
-        const int chv = 16 * w + fr;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            wq[t] = *reinterpret_cast<const float4*>(Wq + chq * ML_C + t * 16 + fg * 4);
-            wk[t] = *reinterpret_cast<const float4*>(Wk + chq * ML_C + t * 16 + fg * 4);
-            wv[t] = *reinterpret_cast<const float4*>(Wv + chv * ML_C + t * 16 + fg * 4);
-            wc[t] = *reinterpret_cast<const float4*>(Wc + chv * ML_C + t * 16 + fg * 4);
-        }
-    }
+    MlWeights W;
+    ml_load_weights<true>(W, Wq, Wk, Wv, Wc, w, fr, fg);
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bc) bias = *reinterpret_cast<const float4*>(bc + 16 * w + 4 * fg);
-    Xs[(ML_TOK + (tid >> 6)) * ML_S + (tid & 63)] = 0.f;      // token rows 60..63 stay zero for the whole kernel
+    for (int e = tid; e < 384; e += 256) reinterpret_cast<unsigned*>(Xp + (e / 128) * ML_PL + ML_TOK * 64)[e % 128] = 0u;      // token rows 60..63: zero
 
     const long T = (long)B * N;
     const long share = (T + 7) >> 3;                    // contiguous slots of the spatial order per XCD
@@ -304,7 +380,9 @@ __global__ void __launch_bounds__(256, MHSA_INTERP_WGS) mhsa_interp_layer_kernel
             const int e = tid + 256 * h;
             if (h < 3 || e < ML_TOK * ML_C / 4) {
                 const f32x4 v = ml_blend(xa[h], xb[h], xc[h], a0, a1, a2);
-                *reinterpret_cast<float4*>(&Xs[(e >> 4) * ML_S + (e & 15) * 4]) = make_float4(v[0], v[1], v[2], v[3]);
+                const float4 v4 = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(&Xs[(e >> 4) * ML_S + (e & 15) * 4]) = v4;
+                ml_stage4(Xp, e, v4);
             }
         }
         // the next point's token rows: in flight during the whole layer
@@ -314,69 +392,13 @@ __global__ void __launch_bounds__(256, MHSA_INTERP_WGS) mhsa_interp_layer_kernel
         __syncthreads();
 
         f32x4 Q[4], Kt[4], V[4];
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            float4 xf[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) xf[t] = *reinterpret_cast<const float4*>(&Xs[(tt * 16 + fr) * ML_S + t * 16 + fg * 4]);
-            f32x4 k = {0.f, 0.f, 0.f, 0.f}, v = k, qq = k;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-#define ML_STEP(C)                      \
-    qq = ML_MFMA(wq[t].C, xf[t].C, qq); \
-    k = ML_MFMA(wk[t].C, xf[t].C, k);   \
-    v = ML_MFMA(xf[t].C, wv[t].C, v);
-                ML_STEP(x) ML_STEP(y) ML_STEP(z) ML_STEP(w)
-#undef ML_STEP
-            }
-            Kt[tt] = k; V[tt] = v; Q[tt] = qq;
-        }
-
-        // ---- B: attention of heads 2w / 2w+1 (as in mhsa_layer_kernel)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            f32x4 sa[4], sb[4];
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const float pad = fg == 3 ? -1e30f : 0.f;                     // padded keys 60..63 (tile 3, lane group 3): exp2 -> 0
-            const f32x4 zpad = {pad, pad, pad, pad};
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                sa[jt] = ML_MFMA(Kt[jt][0], Q[it][0], jt == 3 ? zpad : z);
-                sb[jt] = ML_MFMA(Kt[jt][2], Q[it][2], jt == 3 ? zpad : z);
-            }
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                sa[jt] = ML_MFMA(Kt[jt][1], Q[it][1], sa[jt]);
-                sb[jt] = ML_MFMA(Kt[jt][3], Q[it][3], sb[jt]);
-            }
-            ml_softmax(sa, fg);
-            ml_softmax(sb, fg);
-            f32x4 oa = z, ob = z;
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    oa = ML_MFMA(sa[jt][r], V[jt][r], oa);
-                    ob = ML_MFMA(sb[jt][r], V[jt][r], ob);
-                }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) As[(it * 16 + fg * 4 + r) * ML_S + 16 * w + fr] = fr < 8 ? oa[r] : ob[r];
-        }
+        ml_project(Xp, W, Q, Kt, V, fr, fg);
+        ml_attention<true>(Q, Kt, V, nullptr, Ap, w, fr, fg);
         __syncthreads();
 
         // ---- C: head_combine + bias + residual
         f32x4 y[4];
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) y[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float4 af[4];
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) af[tt] = *reinterpret_cast<const float4*>(&As[(tt * 16 + fr) * ML_S + t * 16 + fg * 4]);
-#define ML_STEP(C) _Pragma("unroll") for (int tt = 0; tt < 4; ++tt) y[tt] = ML_MFMA(wc[t].C, af[tt].C, y[tt]);
-            ML_STEP(x) ML_STEP(y) ML_STEP(z) ML_STEP(w)
-#undef ML_STEP
-        }
+        ml_combine(Ap, W, y, fr, fg);
         float* dst = out + cpt * (ML_TOK * ML_C);
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
@@ -387,7 +409,7 @@ __global__ void __launch_bounds__(256, MHSA_INTERP_WGS) mhsa_interp_layer_kernel
                     make_float4(y[tt][0] + bias.x + rx.x, y[tt][1] + bias.y + rx.y, y[tt][2] + bias.z + rx.z, y[tt][3] + bias.w + rx.w);
             }
         }
-        __syncthreads();      // Xs / As are rewritten by the next point
+        __syncthreads();      // Xs / Xp / Ap are rewritten by the next point
     }
 #undef ML_XLOAD
 }
@@ -458,14 +480,16 @@ extern "C" int etch_mhsa_interp_layer(int B, int N, int S, const float* F, const
         return ETCH_EINVAL;
     static int per_cu = 0;
     if (per_cu == 0) {
+        hipError_t e = hipFuncSetAttribute((const void*)mhsa_interp_layer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ML_INTERP_LDS);
+        if (e != hipSuccess) return (int)e;
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)mhsa_interp_layer_kernel, 256, 0) != hipSuccess || n < 1) n = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)mhsa_interp_layer_kernel, 256, ML_INTERP_LDS) != hipSuccess || n < 1) n = 2;
         per_cu = n;
     }
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(interp_schedule_kernel, dim3((unsigned)(((long)B * N + 255) / 256)), dim3(256), 0, st, B, N, S, idx, weight, order,
                        reinterpret_cast<int4*>(sched));
-    hipLaunchKernelGGL(mhsa_interp_layer_kernel, dim3((unsigned)(((etch_cu_count() + 7) / 8) * 8 * per_cu)), dim3(256), 0, st, B, N, S, F, sched, Wq, Wk, Wv, Wc, bc, out);
+    hipLaunchKernelGGL(mhsa_interp_layer_kernel, dim3((unsigned)(((etch_cu_count() + 7) / 8) * 8 * per_cu)), dim3(256), ML_INTERP_LDS, st, B, N, S, F, sched, Wq, Wk, Wv, Wc, bc, out);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }
