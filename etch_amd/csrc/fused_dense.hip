@@ -125,6 +125,163 @@ __global__ void __launch_bounds__(512) linear_relu_dot_kernel(long R, int G, con
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same chain on the bf16 matrix cores with exactly split fp32 operands (x = hi + mid + lo, 8 + 8 + 8 mantissa bits; six cross products
+// accumulated in fp32 by v_mfma_f32_16x16x32_bf16: the error against fp64 of the fp32 MFMA, profiles/r03_bf16x3_split.txt, at 2.3 x its rate and
+// beside the VALU -- the epilogue's bias / ReLU / w2 / DPP row sums now run in the matrix cores' shadow).  X is split once when a row tile is
+// staged in LDS (three bf16 planes), W comes pre-split from the host (ops.lrd_weight_split).  Wave w = (row half w >> 2, strip pair w & 3): every
+// X fragment read from LDS feeds two 16-column strips (with one strip per wave the planes' reads alone would saturate the LDS), every W fragment
+// is read by the two row halves (the second read hits in L1).  128-row tiles for every K: the weight stream per row is what bounds the
+// confidence head (G = 86: 8.4 MB of split weights per tile).
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void fd_split(const float v, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(v);
+    const float r = v - __uint_as_float(h & 0xffff0000u);
+    m = __float_as_uint(r);
+    l = __float_as_uint(r - __uint_as_float(m & 0xffff0000u));
+}
+template <int K, int FD_ROWS>
+__global__ void __launch_bounds__(512) linear_relu_dot_bx_kernel(long R, int G, const float* __restrict__ X, long ldx, const bf16x8* __restrict__ Wq,
+                                                                 const float* __restrict__ b1, const float* __restrict__ w2,
+                                                                 const float* __restrict__ b2, float* __restrict__ out, long ldo) {
+    constexpr int SB = K + 8, KT = K / 32;       // bf16 row stride of a plane (SB / 8 odd: conflict-free 16-byte fragment reads); K steps
+    constexpr int PLANE = FD_ROWS * SB;
+    constexpr int RT = FD_ROWS / 32;             // 16-row tiles per wave (its row half)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned short* Xp = reinterpret_cast<unsigned short*>(lds);            // [3][FD_ROWS][SB]
+    float* red = lds + 3 * PLANE / 2;                                        // [2][8 strips][FD_ROWS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int rh = wave >> 2, sp = wave & 3;     // row half, strip pair (strips 2 sp, 2 sp + 1)
+    constexpr int C4 = K / 4;
+    constexpr int XL = FD_ROWS * C4 / 512;       // float4 per thread and tile
+    static_assert(FD_ROWS * C4 % 512 == 0, "tile / thread geometry");
+    const long ntiles = (R + FD_ROWS - 1) / FD_ROWS;
+    float4 xn[XL];
+    auto fetch = [&](long tile) {
+        const long rt = tile * FD_ROWS;
+#pragma unroll
+        for (int h = 0; h < XL; ++h) {
+            const int e = tid + 512 * h;
+            const int row = e / C4, c = (e - row * C4) * 4;
+            xn[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tile < ntiles && rt + row < R) xn[h] = *reinterpret_cast<const float4*>(X + (rt + row) * ldx + c);   // rows past R are zero
+        }
+    };
+    // W fragments of (group g, K step t, strip s): [g][t][strip][plane][lane] x 16 bytes
+    auto wfrag = [&](int g, int t, int s, bf16x8 (&dst)[3]) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) dst[pl] = Wq[((((long)g * KT + t) * 8 + s) * 3 + pl) * 64 + lane];
+    };
+    fetch(blockIdx.x);
+    int buf = 0;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long r0 = tile * FD_ROWS;
+        __syncthreads();                         // the previous tile (and its last reduction table) is consumed
+#pragma unroll
+        for (int h = 0; h < XL; ++h) {
+            const int e = tid + 512 * h;
+            const int row = e / C4, c = (e - row * C4) * 4;
+            const float v[4] = {xn[h].x, xn[h].y, xn[h].z, xn[h].w};
+            unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fd_split(v[i], hh[i], mm[i], ll[i]);
+            unsigned short* d = Xp + row * SB + c;
+            *reinterpret_cast<uint2*>(d) = make_uint2(__builtin_amdgcn_perm(hh[1], hh[0], 0x07060302u), __builtin_amdgcn_perm(hh[3], hh[2], 0x07060302u));
+            *reinterpret_cast<uint2*>(d + PLANE) = make_uint2(__builtin_amdgcn_perm(mm[1], mm[0], 0x07060302u), __builtin_amdgcn_perm(mm[3], mm[2], 0x07060302u));
+            *reinterpret_cast<uint2*>(d + 2 * PLANE) = make_uint2(__builtin_amdgcn_perm(ll[1], ll[0], 0x07060302u), __builtin_amdgcn_perm(ll[3], ll[2], 0x07060302u));
+        }
+        __syncthreads();
+        fetch(tile + gridDim.x);                 // in flight during all G groups of this tile
+
+#pragma unroll 1
+        for (int g = 0; g < G; ++g) {
+            f32x4 acc[RT][2];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                bf16x8 b[2][3];
+                wfrag(g, t, 2 * sp, b[0]); wfrag(g, t, 2 * sp + 1, b[1]);
+                bf16x8 a[RT][3];
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) a[i][pl] = *reinterpret_cast<const bf16x8*>(Xp + pl * PLANE + (rh * (FD_ROWS / 2) + i * 16 + fr) * SB + t * 32 + fg * 8);
+                // smallest cross products first; term-major: consecutive MFMAs are independent
+#define FD_T(PA, PB) _Pragma("unroll") for (int i = 0; i < RT; ++i) { \
+        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][PA], b[0][PB], acc[i][0], 0, 0, 0); \
+        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][PA], b[1][PB], acc[i][1], 0, 0, 0); }
+                FD_T(2, 0) FD_T(0, 2) FD_T(1, 1) FD_T(1, 0) FD_T(0, 1) FD_T(0, 0)
+#undef FD_T
+            }
+            // epilogue: D[row = 16 i + 4 fg + q][col = fr] of strips 2 sp, 2 sp + 1
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int strip = 2 * sp + s2;
+                const int col = g * FD_J + strip * 16 + fr;
+                const float bs = b1[col], ww = w2[col];
+                float* rp = red + (buf * 8 + strip) * FD_ROWS + rh * (FD_ROWS / 2);
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float s = fd_row_sum16(fmaxf(acc[i][s2][q] + bs, 0.f) * ww);
+                        if (fr == ((i * 4 + q) & 15)) rp[i * 16 + fg * 4 + q] = s;    // spread the stores over the row's lanes
+                    }
+            }
+            __syncthreads();
+            if (tid < FD_ROWS && r0 + tid < R) {
+                const float* rr = red + buf * 8 * FD_ROWS + tid;
+                float s = rr[0];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) s += rr[w * FD_ROWS];
+                out[(r0 + tid) * ldo + g] = s + b2[g];
+            }
+            buf ^= 1;
+        }
+    }
+}
+
+template <int K>
+static int launch_lrd_bx(long R, int G, const float* X, long ldx, const void* Wq, const float* b1, const float* w2, const float* b2, float* out,
+                         long ldo, hipStream_t st) {
+    constexpr int FD_ROWS = K <= 128 ? 128 : 64;          // K = 256: 128 rows of planes (203 KB) do not fit the LDS
+    const size_t lds = (size_t)3 * FD_ROWS * (K + 8) * 2 + (size_t)2 * 8 * FD_ROWS * sizeof(float);
+    const long ntiles = (R + FD_ROWS - 1) / FD_ROWS;
+    auto kern = linear_relu_dot_bx_kernel<K, FD_ROWS>;
+    static int blocks_resident = 0;
+    if (blocks_resident == 0) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 512, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        blocks_resident = etch_cu_count() * per_cu;
+    }
+    long blocks = blocks_resident;
+    if (blocks > ntiles) blocks = ntiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, st, R, G, X, ldx, reinterpret_cast<const bf16x8*>(Wq), b1, w2, b2, out, ldo);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+// Wq = ops.lrd_weight_split: [g][K step of 32][strip of 16 hidden columns][plane hi / mid / lo][lane = 16 * (k / 8) + column][8 bf16]
+extern "C" int etch_linear_relu_dot_split(long R, int K, int G, int J, const float* X, long ldx, const void* Wq, const float* b1, const float* w2,
+                                          const float* b2, float* out, long ldo, void* stream) {
+    if (R <= 0 || G <= 0) return ETCH_OK;
+    if (!X || !Wq || !b1 || !w2 || !b2 || !out) return ETCH_EINVAL;
+    if ((ldx & 3) || ((uintptr_t)X & 15) || ((uintptr_t)Wq & 15)) return ETCH_EINVAL;
+    if (J != FD_J) return ETCH_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 32) return launch_lrd_bx<32>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);
+    if (K == 64) return launch_lrd_bx<64>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);
+    if (K == 128) return launch_lrd_bx<128>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);
+    if (K == 256) return launch_lrd_bx<256>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);
+    return ETCH_EUNSUPPORTED;
+}
+
 template <int K, int FD_ROWS>
 static int launch_lrd(long R, int G, const float* X, long ldx, const float* W, long ldw, const float* Wp, const float* b1,
                       const float* w2, const float* b2, float* out, long ldo, hipStream_t st) {

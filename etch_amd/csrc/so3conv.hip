@@ -868,7 +868,9 @@ __global__ void __launch_bounds__(256) instnorm_act_add_kernel(long n4, int rows
 
 // ------------------------------------------------------------------------------------------------ C ABI
 // gather prefetch distance in chunk-steps (PD + 1 must divide 4 * MAXT: 1 or 3; 3 measured 3-8 % slower: more registers, fewer waves)
+#ifndef INTER_PD
 #define INTER_PD(CIN, MAXT) 1
+#endif
 template <int CIN, int COUT, int MAXT, bool BX>
 static int launch_inter_t(int b, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz, const int* idx,
                           const float* feats, const float* rk, const float* Wp, const float* bias, float* out, const int* order,

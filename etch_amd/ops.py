@@ -570,9 +570,25 @@ def grouped_dot(h, w, bias, G, J, out=None):
     return out
 
 
-def permute_weight_frag_grouped(w, J=128):
-    """[G*J, K] -> fragment order [G][K/16][J/16][64][4] for etch_linear_relu_dot."""
+LRD_SPLIT = os.environ.get("ETCH_LRD_SPLIT", "1") != "0"       # linear_relu_dot on the bf16 matrix cores (split fp32 operands); 0: fp32 MFMA
+
+
+def lrd_weight_split(w, J=128):
+    """[G*J, K] -> int16 [G][K/32][J/16 strips][plane hi / mid / lo][lane = 16 * (k / 8) + column][8]: the exactly split weight of
+    etch_linear_relu_dot_split in v_mfma_f32_16x16x32_bf16 B-fragment order."""
     GJ, K = w.shape
+    assert GJ % J == 0 and J % 16 == 0 and K % 32 == 0
+    planes = split3_bf16(w)                                                   # [3][GJ][K]
+    q = planes.reshape(3, GJ // J, J // 16, 16, K // 32, 4, 8)               # [pl][g][strip][col][t][kg][e]
+    return q.permute(1, 4, 2, 0, 5, 3, 6).contiguous().reshape(-1)           # [g][t][strip][pl][kg][col][e]
+
+
+def permute_weight_frag_grouped(w, J=128):
+    """[G*J, K] -> the weight operand of linear_relu_dot: split bf16 planes (lrd_weight_split; int16) by default, else the fp32 fragment order
+    [G][K/16][J/16][64][4] of etch_linear_relu_dot."""
+    GJ, K = w.shape
+    if LRD_SPLIT and J == 128 and K in (32, 64, 128, 256):
+        return lrd_weight_split(w.contiguous(), J)
     return torch.cat([permute_weight_frag(w[g * J:(g + 1) * J].contiguous()) for g in range(GJ // J)])
 
 
@@ -587,6 +603,11 @@ def linear_relu_dot(x, w, b1, w2, b2, G, wp=None, out=None):
     assert x.stride(1) == 1 and w.shape == (G * J, K) and b1.numel() == G * J and w2.numel() == G * J and b2.numel() == G
     if out is None:
         out = torch.empty((R, G), dtype=torch.float32, device=x.device)
+    if wp is not None and wp.dtype == torch.int16:
+        _lib.check(_lib.lib().etch_linear_relu_dot_split(_c_long(R), int(K), int(G), int(J), _ptr(x), _c_long(x.stride(0) if R > 1 else K), _ptr(wp),
+                                                         _ptr(b1), _ptr(w2), _ptr(b2), _ptr(out), _c_long(out.stride(0) if R > 1 else G), _stream()),
+                   "etch_linear_relu_dot_split")
+        return out
     _lib.check(_lib.lib().etch_linear_relu_dot(_c_long(R), int(K), int(G), int(J), _ptr(x), _c_long(x.stride(0) if R > 1 else K), _ptr(w),
                                                _c_long(w.stride(0)), _optptr(wp), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(out),
                                                _c_long(out.stride(0) if R > 1 else G), _stream()), "etch_linear_relu_dot")

@@ -311,6 +311,12 @@ int etch_grouped_dot(long R, int G, int J, const float* h, long ldh, const float
 int etch_linear_relu_dot(long R, int K, int G, int J, const float* X, long ldx, const float* W, long ldw, const float* Wp,
                          const float* b1, const float* w2, const float* b2, float* out, long ldo, void* stream);
 
+/* The same chain on the bf16 matrix cores with exactly split fp32 operands (three bf16 values per fp32 value, six cross products accumulated in
+ * fp32: the fp32 MFMA's error against fp64, profiles/r03_bf16x3_split.txt).  K in {32, 64, 128, 256}, J = 128.  Wq = etch_amd/ops.py
+ * lrd_weight_split: [g][K/32][8 strips][plane hi / mid / lo][lane][8 bf16]. */
+int etch_linear_relu_dot_split(long R, int K, int G, int J, const float* X, long ldx, const void* Wq, const float* b1, const float* w2,
+                               const float* b2, float* out, long ldo, void* stream);
+
 /* confidence = sum_g softmax(logits)_g * v_g (pointtransformer_seg.py:183-189): (R,G),(R,G) -> (R). */
 int etch_softmax_dot(long R, int G, const float* logits, const float* v, float* out, void* stream);
 
