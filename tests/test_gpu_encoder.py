@@ -262,3 +262,104 @@ def test_fused_instancenorm_statistics_with_a_dominant_channel_mean(kind):
     assert rel_err(m.cpu().numpy(), x64.mean(1).cpu().numpy()) < 1e-6
     want = (1.0 / torch.sqrt(x64.var(1, unbiased=False) + 1e-5)).cpu().numpy()
     assert np.abs(r.cpu().numpy() / want - 1).max() < 1e-5
+
+
+def _inter_conv_fp64(xyz, new_xyz, ball, feats, rk, W, bias, sigma):
+    """The dense formula of functional.py:286-324 + modules.py:33-39 in fp64 on the device: w = relu(1 - |g - R kappa|^2 / sigma),
+    X1[a,k,c] = sum_n w[a,k,n] F[idx_n, a, c], Y = W X1 + bias."""
+    b, _, p2 = new_xyz.shape
+    nn_, cin = ball.shape[2], feats.shape[3]
+    idx = ball.long()
+    X = xyz.double().permute(0, 2, 1)                                                    # b, p1, 3
+    g = torch.gather(X[:, None].expand(-1, p2, -1, -1), 2, idx[..., None].expand(-1, -1, -1, 3)) - new_xyz.double().permute(0, 2, 1)[:, :, None]
+    d2 = ((g[:, :, None, None] - rk.double()[None, None, :, :, None]) ** 2).sum(-1)      # b, p2, 60, 24, nn
+    w = torch.clamp(1.0 - d2 / sigma, min=0.0)
+    F = torch.gather(feats.double()[:, None].expand(-1, p2, -1, -1, -1), 2, idx[..., None, None].expand(-1, -1, -1, 60, cin))   # b, p2, nn, 60, c
+    X1 = torch.einsum("bpakn,bpnac->bpack", w, F).reshape(b, p2, 60, cin * 24)
+    return X1 @ W.double().t() + bias.double()
+
+
+@pytest.mark.parametrize("cin,cout,nn,p1,p2", [(32, 32, 32, 301, 149), (32, 64, 64, 211, 60), (64, 64, 20, 211, 101), (16, 32, 9, 100, 1),
+                                                (128, 128, 32, 150, 33)])
+def test_inter_conv_split_operands_match_the_fp32_kernel_and_fp64(cin, cout, nn, p1, p2):
+    """etch_inter_so3conv_split (step 2 on the bf16 matrix cores, fp32 operands split exactly into three bf16 values, six cross products) against
+    the fp32-MFMA kernel (same sums in a different order: <= 2e-6 of the output's scale) and against the fp64 formula: it may not be further
+    from fp64 than twice the fp32 kernel is (the entitled-error rule of the parity tests); bitwise reproducible, schedule-independent."""
+    from etch_amd import ops
+    from etch_amd import vgtk_so3conv as V
+    g = torch.Generator().manual_seed(cin + nn)
+    b = 2
+    xyz = (torch.randn(b, 3, p1, generator=g) * 0.2).cuda()
+    new_xyz = xyz[:, :, :p2].contiguous()
+    ball = ops.ball_query(new_xyz, xyz, 0.25, nn)
+    conv = load_seeded(V.InterSO3Conv(cin, cout, 1, 2, 0.25, 0.03, nn), 3).cuda()
+    rk, W, Wp, bias = conv._derived()
+    Wq = conv._wq()
+    feats = torch.randn(b, p1, 60, cin, generator=g).cuda()
+    f32, (m0, r0) = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, want_stats=True)
+    new, (m1, r1) = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, want_stats=True, Wq=Wq, order=ops.spatial_order(new_xyz))
+    again = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, Wq=Wq)
+    assert torch.equal(new, again)
+    scale = float(f32.abs().max())
+    assert float((new - f32).abs().max()) < 2e-6 * scale
+    assert rel_err(m1.cpu().numpy(), m0.cpu().numpy()) < 2e-6 and rel_err(r1.cpu().numpy(), r0.cpu().numpy()) < 2e-6
+    ref = _inter_conv_fp64(xyz, new_xyz, ball, feats, rk, W, bias, conv.sigma)
+    e_new, e_f32 = float((new.double() - ref).abs().max()), float((f32.double() - ref).abs().max())
+    assert e_f32 < 3e-6 * scale and e_new <= 2.0 * e_f32 + 1e-7 * scale, (e_new, e_f32)
+
+
+@pytest.mark.parametrize("c,p,b,normed", [(64, 256, 2, True), (32, 512, 2, False), (64, 57, 3, True), (32, 1, 1, True), (64, 2, 1, False)])
+def test_intra_conv_weight_stationary_split_matches_the_fp32_kernel_and_fp64(c, p, b, normed):
+    """etch_intra_so3conv_split (weight-stationary, bf16 matrix cores, exactly split fp32 operands) against the fp32 kernels and the fp64
+    formula (functional.py:331-378 + modules.py:150-153, InstanceNorm + LeakyReLU on load as so3conv.py:96-99); odd point counts, one point."""
+    from etch_amd import ops
+    from etch_amd import vgtk_so3conv as V
+    g = torch.Generator().manual_seed(c + p)
+    conv = load_seeded(V.IntraSO3Conv(c, c), 5).cuda()
+    Wp, bias, idx32, Wp32 = conv._derived()
+    x = (torch.randn(b, p, 60, c, generator=g) * 2 + 0.5).cuda()
+    mm, rr = ops.instnorm_stats(x) if normed else (None, None)
+    ws = p % 2 == 0
+    new = ops.intra_so3conv(x, idx32, Wp, bias, c, mm, rr, Wp32=Wp32, Wq=conv._wq, want_stats=ws)
+    f32 = ops.intra_so3conv(x, idx32, Wp, bias, c, mm, rr, want_stats=ws)
+    if ws:
+        (new, (m1, r1)), (f32, (m0, r0)) = new, f32
+        assert rel_err(m1.cpu().numpy(), m0.cpu().numpy()) < 2e-6 and rel_err(r1.cpu().numpy(), r0.cpu().numpy()) < 2e-6
+    assert torch.equal(new, ops.intra_so3conv(x, idx32, Wp, bias, c, mm, rr, Wq=conv._wq))
+    scale = float(f32.abs().max())
+    assert float((new - f32).abs().max()) < 3e-6 * scale
+    xd = x.double()
+    if normed:
+        xd = (xd - mm.double()[:, None, None]) * rr.double()[:, None, None]
+        xd = torch.where(xd > 0, xd, 0.01 * xd)
+    gathered = xd[:, :, conv.intra_idx.cuda()]                                           # b, p, 60, 12, c
+    W3 = conv.basic_conv.W.detach().double().view(c, c, 12)                              # [o][ch][tap]
+    ref = torch.einsum("bpatc,oct->bpao", gathered, W3) + bias.double()
+    e_new, e_f32 = float((new.double() - ref).abs().max()), float((f32.double() - ref).abs().max())
+    assert e_f32 < 3e-6 * scale and e_new <= 2.0 * e_f32 + 1e-7 * scale, (e_new, e_f32)
+
+
+@pytest.mark.parametrize("cin,cout,nn", [(32, 32, 32), (32, 64, 64), (64, 64, 20)])
+def test_inter_conv_32x32x2_variant_matches(cin, cout, nn):
+    """The opt-in two-points-per-workgroup kernel on v_mfma_f32_32x32x2_f32 (etch_inter_so3conv32, ETCH_INTER_MFMA32=1;
+    profiles/r03_inter_conv32_and_valu_overlap.txt) computes the same convolution; odd point counts leave its second point empty."""
+    from etch_amd import ops
+    from etch_amd import vgtk_so3conv as V
+    g = torch.Generator().manual_seed(cin + nn)
+    b, p1, p2 = 2, 211, 101
+    xyz = (torch.randn(b, 3, p1, generator=g) * 0.2).cuda()
+    new_xyz = xyz[:, :, :p2].contiguous()
+    ball = ops.ball_query(new_xyz, xyz, 0.25, nn)
+    conv = load_seeded(V.InterSO3Conv(cin, cout, 1, 2, 0.25, 0.03, nn), 3).cuda()
+    rk, W, Wp, bias = conv._derived()
+    feats = torch.randn(b, p1, 60, cin, generator=g).cuda()
+    ref, (m0, r0) = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, want_stats=True)
+    saved = ops.INTER_MFMA32
+    ops.INTER_MFMA32 = True
+    try:
+        out, (m, r) = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, want_stats=True, Wp32=conv._wp32(), order=ops.spatial_order(new_xyz))
+        assert torch.equal(out, ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, Wp32=conv._wp32()))
+    finally:
+        ops.INTER_MFMA32 = saved
+    assert float((out - ref).abs().max()) < 2e-6 * float(ref.abs().max())
+    assert rel_err(m.cpu().numpy(), m0.cpu().numpy()) < 2e-6 and rel_err(r.cpu().numpy(), r0.cpu().numpy()) < 2e-6

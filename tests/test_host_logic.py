@@ -261,3 +261,58 @@ def test_load_smplx_reads_the_distributed_file_layout(tmp_path):
     np.savez(tmp_path / "bad.npz", **d)
     with pytest.raises(ValueError, match="kinematic tree"):
         BM.load_smplx(str(tmp_path / "bad.npz"))
+
+
+def _bf16_to_f64(p):
+    import torch
+    return (p.to(torch.int32) << 16).view(torch.float32).double()
+
+
+def test_split3_bf16_is_exact():
+    """ops.split3_bf16: x = hi + mid + lo exactly, every part a bf16 bit pattern (the operand split of the *_split kernels; the device-side
+    twins are split3_pack8 / ws_split3_pack4 / ml_split / fd_split in csrc/)."""
+    import torch
+    from etch_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(20000, generator=g) * torch.exp(torch.randn(20000, generator=g) * 6)
+    x = torch.cat([x, torch.tensor([0.0, -0.0, 1.0, -1.0, 1e-30, -3e38, 2.0 ** -126, 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24])])
+    pl = ops.split3_bf16(x)
+    assert pl.dtype == torch.int16 and tuple(pl.shape) == (3,) + tuple(x.shape)
+    assert torch.equal(sum(_bf16_to_f64(p) for p in pl), x.double())
+    hi, mid, lo = (_bf16_to_f64(p).abs() for p in pl)
+    nz = x != 0
+    assert bool((mid[nz] <= hi[nz] * 2.0 ** -7).all()) and bool((lo[nz] <= hi[nz] * 2.0 ** -15).all())      # 8 bits each
+
+
+def test_split_weight_layouts_address_the_right_elements():
+    """inter_weight_split / intra_weight_split / lrd_weight_split: element (fragment indices) of the device layout = the plane of the weight
+    the kernels' index formulas name (csrc/so3conv.hip BX step 2, csrc/so3conv_ws.hip, csrc/fused_dense.hip)."""
+    import torch
+    from etch_amd import ops
+    g = torch.Generator().manual_seed(1)
+    rng = np.random.default_rng(0)
+    # inter: [tg][mt][pl][lane = 16 kg + ol][8] of W[:, cols] with the contraction order of inter_weight_frag
+    for cin, cout in ((32, 32), (64, 64), (128, 32)):
+        W = torch.randn(cout, cin * 24, generator=g)
+        q = ops.inter_weight_split(W, cin).view(cin * 24 // 32, cout // 16, 3, 64, 8)
+        Wk = ops.split3_bf16(W[:, ops._inter_contraction_cols(cin, 24, W.device)])
+        for _ in range(50):
+            tg, mt, pl, lane, e = (int(rng.integers(n)) for n in q.shape)
+            assert q[tg, mt, pl, lane, e] == Wk[pl, 16 * mt + lane % 16, 32 * tg + 8 * (lane // 16) + e]
+    # intra: [mt][kq][ks][pl][lane = 32 kg + i][8] of W2[32 mt + i][3 kq C + 16 ks + 8 kg + e]
+    for C in (32, 64):
+        W2 = torch.randn(C, 12 * C, generator=g)
+        nks = 3 * C // 16
+        q = ops.intra_weight_split(W2).view(C // 32, 4, nks, 3, 64, 8)
+        P = ops.split3_bf16(W2)
+        for _ in range(50):
+            mt, kq, ks, pl, lane, e = (int(rng.integers(n)) for n in q.shape)
+            assert q[mt, kq, ks, pl, lane, e] == P[pl, 32 * mt + lane % 32, 3 * kq * C + 16 * ks + 8 * (lane // 32) + e]
+    # linear_relu_dot: [g][t][strip][pl][lane = 16 kg + col][8] of w[g J + 16 strip + col][32 t + 8 kg + e]
+    for G, K in ((3, 64), (2, 128)):
+        w = torch.randn(G * 128, K, generator=g)
+        q = ops.lrd_weight_split(w).view(G, K // 32, 8, 3, 64, 8)
+        P = ops.split3_bf16(w)
+        for _ in range(50):
+            gi, t, strip, pl, lane, e = (int(rng.integers(n)) for n in q.shape)
+            assert q[gi, t, strip, pl, lane, e] == P[pl, gi * 128 + 16 * strip + lane % 16, 32 * t + 8 * (lane // 16) + e]
