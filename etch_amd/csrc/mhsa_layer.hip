@@ -195,17 +195,21 @@ __device__ __forceinline__ void ml_attention(const f32x4 (&Q)[4], const f32x4 (&
     }
 }
 // C: head_combine, transposed (rows = this wave's 16 output channels, columns = tokens)
-__device__ __forceinline__ void ml_combine(const unsigned short* Ap, const MlWeights& W, f32x4 (&y)[4], int fr, int fg) {
+// wc: the wave's head_combine fragments [ks][plane] -- registers (W.c) or, where registers are short, its 6 x 1 KB slice of an LDS copy
+template <class WC>
+__device__ __forceinline__ void ml_combine(const unsigned short* Ap, WC wc, f32x4 (&y)[4], int fr, int fg) {
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) y[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 a[4][3];
+        bf16x8 a[4][3], c[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) c[pl] = wc(ks, pl);
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) a[tt][pl] = *reinterpret_cast<const bf16x8*>(Ap + pl * ML_PL + ml_sw(tt * 16 + fr, ks * 32 + fg * 8));
-#define ML_T(PA, PB) _Pragma("unroll") for (int tt = 0; tt < 4; ++tt) y[tt] = ML_MFMA16(W.c[ks][PA], a[tt][PB], y[tt]);
+#define ML_T(PA, PB) _Pragma("unroll") for (int tt = 0; tt < 4; ++tt) y[tt] = ML_MFMA16(c[PA], a[tt][PB], y[tt]);
         ML_T(2, 0) ML_T(0, 2) ML_T(1, 1) ML_T(1, 0) ML_T(0, 1) ML_T(0, 0)
 #undef ML_T
     }
@@ -268,7 +272,7 @@ __global__ void __launch_bounds__(256, ML_LAYER_WPE) mhsa_layer_kernel(long T, c
             }
         } else {
             f32x4 y[4];
-            ml_combine(Ap, W, y, fr, fg);
+            ml_combine(Ap, [&](int ks, int pl) { return W.c[ks][pl]; }, y, fr, fg);
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 const int tok = tt * 16 + fr;
@@ -325,21 +329,30 @@ __global__ void __launch_bounds__(256) interp_schedule_kernel(int B, int N, int 
 // out[b,n] = X + att Wc^T + bc with X = blend of three rows of F (B,S,60,64), sched from interp_schedule_kernel.  Grid = multiple of 8
 // workgroups.  Per scan point: its three coarse token rows were requested during the previous point (12 float4 in registers) and are
 // blended into LDS (fp32 for the residual, three bf16 planes for the projections); the rows of the NEXT point are requested before the
-// layer's three phases start.  LDS: 26.6 + 24.6 + 24.6 KB (dynamic).
-#define ML_INTERP_LDS (64 * ML_S * 4 + 2 * 3 * ML_PL * 2)
+// layer's three phases start.  LDS: 24.6 + 24.6 + 24.6 KB (dynamic).
+#define ML_INTERP_LDS (2 * 3 * ML_PL * 2 + 4 * 2 * 3 * 64 * 16)
 __global__ void __launch_bounds__(256, MHSA_INTERP_WGS) mhsa_interp_layer_kernel(int B, int N, int S, const float* __restrict__ F,
                                                                    const int* __restrict__ sched, const float* __restrict__ Wq,
                                                                    const float* __restrict__ Wk, const float* __restrict__ Wv,
                                                                    const float* __restrict__ Wc, const float* __restrict__ bc,
                                                                    float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float ml_dyn[];
-    float* Xs = ml_dyn;                                                            // [64][ML_S] fp32 token tile (residual)
-    unsigned short* Xp = reinterpret_cast<unsigned short*>(ml_dyn + 64 * ML_S);    // its three planes
+    unsigned short* Xp = reinterpret_cast<unsigned short*>(ml_dyn);                // token tile, three planes (the residual is rebuilt from them: exact)
     unsigned short* Ap = Xp + 3 * ML_PL;                                           // attention tile, three planes
+    bf16x8* Wcl = reinterpret_cast<bf16x8*>(Ap + 3 * ML_PL);                       // head_combine fragments [wave][ks][plane][lane]: 24 registers the
+                                                                                   // prefetched coarse rows (48) leave no room for
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     MlWeights W;
-    ml_load_weights<true>(W, Wq, Wk, Wv, Wc, w, fr, fg);
+    ml_load_weights<false>(W, Wq, Wk, Wv, Wc, w, fr, fg);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 c[3];
+        const float* p = Wc + (16 * w + fr) * ML_C + ks * 32 + fg * 8;
+        ml_split8(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4), c);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) Wcl[((w * 2 + ks) * 3 + pl) * 64 + lane] = c[pl];
+    }
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bc) bias = *reinterpret_cast<const float4*>(bc + 16 * w + 4 * fg);
     for (int e = tid; e < 384; e += 256) reinterpret_cast<unsigned*>(Xp + (e / 128) * ML_PL + ML_TOK * 64)[e % 128] = 0u;      // token rows 60..63: zero
@@ -380,9 +393,7 @@ __global__ void __launch_bounds__(256, MHSA_INTERP_WGS) mhsa_interp_layer_kernel
             const int e = tid + 256 * h;
             if (h < 3 || e < ML_TOK * ML_C / 4) {
                 const f32x4 v = ml_blend(xa[h], xb[h], xc[h], a0, a1, a2);
-                const float4 v4 = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4*>(&Xs[(e >> 4) * ML_S + (e & 15) * 4]) = v4;
-                ml_stage4(Xp, e, v4);
+                ml_stage4(Xp, e, make_float4(v[0], v[1], v[2], v[3]));
             }
         }
         // the next point's token rows: in flight during the whole layer
@@ -398,18 +409,26 @@ __global__ void __launch_bounds__(256, MHSA_INTERP_WGS) mhsa_interp_layer_kernel
 
         // ---- C: head_combine + bias + residual
         f32x4 y[4];
-        ml_combine(Ap, W, y, fr, fg);
+        ml_combine(Ap, [&](int ks, int pl) { return Wcl[((w * 2 + ks) * 3 + pl) * 64 + lane]; }, y, fr, fg);
         float* dst = out + cpt * (ML_TOK * ML_C);
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
             const int tok = tt * 16 + fr;
             if (tok < ML_TOK) {
-                const float4 rx = *reinterpret_cast<const float4*>(&Xs[tok * ML_S + 16 * w + 4 * fg]);
+                // the residual X[tok][16 w + 4 fg ..] = hi + mid + lo of the planes: (hi + mid) + lo is exact in fp32
+                const unsigned short* xp = Xp + ml_sw(tok, 16 * w + 4 * fg);
+                const uint2 ph = *reinterpret_cast<const uint2*>(xp), pm = *reinterpret_cast<const uint2*>(xp + ML_PL), pl = *reinterpret_cast<const uint2*>(xp + 2 * ML_PL);
+#define ML_LO(u) __uint_as_float((u) << 16)
+#define ML_HI(u) __uint_as_float((u) & 0xffff0000u)
+                const float4 rx = make_float4((ML_LO(ph.x) + ML_LO(pm.x)) + ML_LO(pl.x), (ML_HI(ph.x) + ML_HI(pm.x)) + ML_HI(pl.x),
+                                              (ML_LO(ph.y) + ML_LO(pm.y)) + ML_LO(pl.y), (ML_HI(ph.y) + ML_HI(pm.y)) + ML_HI(pl.y));
+#undef ML_LO
+#undef ML_HI
                 *reinterpret_cast<float4*>(dst + tok * ML_C + 16 * w + 4 * fg) =
                     make_float4(y[tt][0] + bias.x + rx.x, y[tt][1] + bias.y + rx.y, y[tt][2] + bias.z + rx.z, y[tt][3] + bias.w + rx.w);
             }
         }
-        __syncthreads();      // Xs / Xp / Ap are rewritten by the next point
+        __syncthreads();      // Xp / Ap are rewritten by the next point
     }
 #undef ML_XLOAD
 }
