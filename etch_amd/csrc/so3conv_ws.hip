@@ -47,12 +47,22 @@ struct WsShape {
     static constexpr int NKS = 3 * C / 16;        // K steps of 16 per wave
     static constexpr int LDB = C + 8;             // bf16 row stride of a plane: LDB / 8 odd -> the 16-byte B reads of consecutive rows spread over the banks
     static constexpr int PS = C + 4;              // partial-tile row stride (floats)
-    static constexpr int PLANE = 2 * NA * LDB;    // bf16 elements of one plane (2 points)
-    static constexpr int NPRE = (2 * NA * (C / 4) + NT - 1) / NT;      // float4 loads per thread and pair
-    static constexpr size_t lds_bytes = (size_t)3 * PLANE * 2 + (size_t)2 * KQ * 32 * PS * 4 + NA * 12 * 4 + (size_t)2 * NT * 8;
+    static constexpr int PLANE = NA * LDB;        // bf16 elements of one plane of one point
+    static constexpr int NPRE = (NA * (C / 4) + NT - 1) / NT;          // float4 loads per thread and point
+    // [2 points][3 planes] + [2 buffers][KQ][32 cols][PS] partial tiles + anchor table + statistics staging
+    static constexpr size_t lds_bytes = (size_t)2 * 3 * PLANE * 2 + (size_t)2 * KQ * 32 * PS * 4 + NA * 12 * 4 + (size_t)2 * NT * 8;
 };
 
-template <int C>
+// The kernel is a pipeline of PHASES (point, anchor half).  In phase (pt, half) a wave
+//   * multiplies: its 3 taps x the point's planes -> partial tile, written to part[half] at the end of the phase (one barrier per phase);
+//   * and, in the same straight-line block -- independent work the scheduler interleaves with the (dependent) MFMA chain, and which the bf16
+//     matrix cores do not compete with --
+//       - sums and stores the PREVIOUS phase's partial tiles (bias, output, statistics),
+//       - half 0: normalises / splits the next point's rows (registers) into the other plane buffer,
+//       - half 1: requests the rows of the point after that.
+// Nothing in a phase is conditional (rows and stores of points past the end go through zero-sized buffer resources: loads return 0, stores
+// are dropped; anchors 60..63 of a tile fall outside the point's 60 x C records), so a phase is ONE basic block.
+template <int C, bool NORM, bool STATS>     // NORM: mean / rstd given (InstanceNorm + LeakyReLU on load); STATS: stat_part given
 __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total, int pts_per_batch, const float* __restrict__ X,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const int* __restrict__ intra_idx, const bf16x8* __restrict__ Wq,
@@ -61,9 +71,10 @@ __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total,
     using S = WsShape<C>;
     constexpr int NT = S::NT, MT = S::MT, KQ = S::KQ, NKS = S::NKS, LDB = S::LDB, PS = S::PS, PLANE = S::PLANE, NPRE = S::NPRE;
     constexpr int SPT = C / 16;                   // K steps per tap
+    constexpr int PBYTES = NA * C * 4;            // bytes of one point's rows
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned short* planes = reinterpret_cast<unsigned short*>(smem_raw);                    // [3][2 * 60][LDB]
-    float* part = reinterpret_cast<float*>(planes + 3 * PLANE);                              // [2 buffers][KQ][32 cols][PS]
+    unsigned short* planes = reinterpret_cast<unsigned short*>(smem_raw);                    // [2 points][3][60][LDB]
+    float* part = reinterpret_cast<float*>(planes + 2 * 3 * PLANE);                          // [2 buffers][KQ][32 cols][PS]
     int* iidx = reinterpret_cast<int*>(part + 2 * KQ * 32 * PS);                              // [60][12]
     double* dred = reinterpret_cast<double*>(iidx + NA * 12);                                 // [2][NT]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -90,28 +101,24 @@ __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total,
         for (int tl = 0; tl < 3; ++tl) srow[half][tl] = iidx[(a < NA ? a : 0) * 12 + 3 * kq + tl] * LDB;
     }
 
-    // ---- staging: rows of a pair -> registers (raw) -> normalise, LeakyReLU, split -> three bf16 planes
+    // ---- staging: rows of a point -> registers (raw) -> normalise, LeakyReLU, split -> three bf16 planes
     float4 pre[NPRE];
-    auto prefetch = [&](int pp) {
+    int pre_pt = 0;                               // the point `pre` holds (for its sample's statistics)
+    auto prefetch = [&](int pt) {
+        pre_pt = pt;
+        const bool ok = pt < npts_total;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X) + (size_t)(ok ? pt : 0) * (NA * C), 0, ok ? PBYTES : 0, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < NPRE; ++i) {
-            const int e = tid + i * NT;
-            const int row = e / (C / 4), c4 = e % (C / 4);
-            const int pt = 2 * pp + row / NA;
-            pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < 2 * NA * (C / 4) && pt < npts_total) pre[i] = *reinterpret_cast<const float4*>(X + ((size_t)2 * pp * NA + row) * C + c4 * 4);
-        }
+        for (int i = 0; i < NPRE; ++i) pre[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + i * NT) * 16, 0, 0));     // past the point's rows: 0
     };
-    auto stage = [&](int pp) {
+    auto stage = [&](unsigned short* P) {
+        const unsigned bb = (unsigned)(pre_pt < npts_total ? pre_pt : 0) / (unsigned)pts_per_batch;      // (32-bit: a 64-bit division brings branches)
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) {
             const int e = tid + i * NT;
-            if (e >= 2 * NA * (C / 4)) continue;
             const int row = e / (C / 4), c4 = e % (C / 4);
-            const int pt = 2 * pp + row / NA;
             float4 v = pre[i];
-            if (mean && pt < npts_total) {
-                const int bb = pt / pts_per_batch;
+            if (NORM) {
                 const float4 m = *reinterpret_cast<const float4*>(mean + (size_t)bb * C + c4 * 4);
                 const float4 r = *reinterpret_cast<const float4*>(rstd + (size_t)bb * C + c4 * 4);
                 v.x = (v.x - m.x) * r.x; v.y = (v.y - m.y) * r.y; v.z = (v.z - m.z) * r.z; v.w = (v.w - m.w) * r.w;
@@ -120,97 +127,131 @@ __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total,
             }
             uint2 ph, pm, pl;
             ws_split3_pack4(v, ph, pm, pl);
-            unsigned short* dst = planes + row * LDB + c4 * 4;
+            // (threads past the 60 rows write into the 8-element row padding region of row 59 .. never read: clamp instead of a branch)
+            unsigned short* dst = P + (e < NA * (C / 4) ? row * LDB + c4 * 4 : (NA - 1) * LDB + C);
             *reinterpret_cast<uint2*>(dst) = ph; *reinterpret_cast<uint2*>(dst + PLANE) = pm; *reinterpret_cast<uint2*>(dst + 2 * PLANE) = pl;
         }
     };
-
-    int pp = blockIdx.x;
-    if (pp < npairs) prefetch(pp);
-    if (pp < npairs) stage(pp);
-    __syncthreads();
-#pragma unroll 1
-    while (pp < npairs) {
-        const int next = pp + gridDim.x;
-        if (next < npairs) prefetch(next);        // in flight during the four phases below
-        double st_s = 0.0, st_q = 0.0;            // InstanceNorm partial sums of this pair, channel o_out
+    // ---- one phase's matrix work: planes P of the point, anchor half -> partial tile into pb
+    auto multiply = [&](const unsigned short* P, int half, float* pb) {
+        f32x16 acc;
 #pragma unroll
-        for (int ph = 0; ph < 4; ++ph) {
-            const int pt = ph >> 1, half = ph & 1;
-            f32x16 acc;
+        for (int v = 0; v < 16; ++v) acc[v] = 0.f;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+        for (int tl = 0; tl < 3; ++tl) {
+            const unsigned short* xrow = P + srow[half][tl] + 8 * kk;
 #pragma unroll
-            for (int tl = 0; tl < 3; ++tl) {
-                const unsigned short* xrow = planes + pt * NA * LDB + srow[half][tl] + 8 * kk;
+            for (int s_ = 0; s_ < SPT; ++s_) {
+                const int ks = tl * SPT + s_;
+                bf16x8 bq[3];
 #pragma unroll
-                for (int s = 0; s < SPT; ++s) {
-                    const int ks = tl * SPT + s;
-                    bf16x8 bq[3];
-#if WS_ABL & 2
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) bq[pl] = aq[ks][pl];
-#else
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) bq[pl] = *reinterpret_cast<const bf16x8*>(xrow + pl * PLANE + 16 * s);
-#endif
-#if WS_ABL & 1
-                    asm volatile("" :: "v"(bq[0]), "v"(bq[1]), "v"(bq[2]));
-#else
-                    // smallest cross products first
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks][2], bq[0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks][0], bq[2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks][1], bq[1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks][1], bq[0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks][0], bq[1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks][0], bq[0], acc, 0, 0, 0);
-#endif
-                }
+                for (int pl = 0; pl < 3; ++pl) bq[pl] = *reinterpret_cast<const bf16x8*>(xrow + pl * PLANE + 16 * s_);
+                // smallest cross products first
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks][2], bq[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks][0], bq[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks][1], bq[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks][1], bq[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks][0], bq[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks][0], bq[0], acc, 0, 0, 0);
             }
-            // acc[v] = partial Y[o = 32 mt + 8 (v / 4) + 4 kk + v % 4][anchor 32 half + j]
-            float* pb = part + (ph & 1) * KQ * 32 * PS;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<f32x4*>(&pb[(kq * 32 + j) * PS + 32 * mt + 8 * g + 4 * kk]) = (f32x4){acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-            __syncthreads();
-            const int ptg = 2 * pp + pt;
-            if (ptg < npts_total && !(WS_ABL & 4)) {
-#pragma unroll
-                for (int it = 0; it < 32 * C / NT; ++it) {
-                    const int col = (tid + it * NT) / C;
-                    const int a = 32 * half + col;
-                    if (a < NA) {
-                        float v = pb[col * PS + o_out];
-#pragma unroll
-                        for (int q = 1; q < KQ; ++q) v += pb[(q * 32 + col) * PS + o_out];
-                        v += bo;
-                        Y[((size_t)ptg * NA + a) * C + o_out] = v;
-                        st_s += (double)v; st_q += (double)v * (double)v;
-                    }
-                }
-            }
-            // (the buffer this phase read is rewritten two phases on, behind the next phase's barrier)
         }
-        // the planes are free (every wave passed the last phase's barrier behind its MFMAs): the next pair goes in
-        if (stat_part) { dred[tid] = st_s; dred[NT + tid] = st_q; }
-        if (next < npairs && !(WS_ABL & 8)) stage(next);
-        __syncthreads();
-        if (stat_part && tid < C) {
+        // acc[v] = partial Y[o = 32 mt + 8 (v / 4) + 4 kk + v % 4][anchor 32 half + j]
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(&pb[(kq * 32 + j) * PS + 32 * mt + 8 * g + 4 * kk]) = (f32x4){acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    };
+    // ---- the previous phase's partial tiles -> bias, output (point ptg, anchor half), statistics
+    double st_s = 0.0, st_q = 0.0;                // InstanceNorm partial sums of the pair being written, channel o_out
+    auto emit = [&](const float* pb, int ptg, int half) {
+        const bool ok = ptg >= 0 && ptg < npts_total;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Y + (size_t)(ok ? ptg : 0) * (NA * C), 0, ok ? PBYTES : 0, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < 32 * C / NT; ++it) {
+            const int col = (tid + it * NT) / C;
+            const int a = 32 * half + col;
+            float v = pb[col * PS + o_out];
+#pragma unroll
+            for (int q = 1; q < KQ; ++q) v += pb[(q * 32 + col) * PS + o_out];
+            v += bo;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (a * C + o_out) * 4, 0, 0);      // anchors 60..63 / points past the end: dropped
+            const double dv = (ok && a < NA) ? (double)v : 0.0;
+            st_s += dv; st_q += dv * dv;
+        }
+    };
+    auto finish_stats = [&](int pp) {               // after the barrier that follows the dred writes
+        if (STATS && pp >= 0 && tid < C) {
             double a0 = 0.0, a1 = 0.0;
 #pragma unroll
             for (int k = 0; k < NT / C; ++k) { a0 += dred[k * C + tid]; a1 += dred[NT + k * C + tid]; }
             stat_part[(size_t)pp * 2 * C + tid] = a0; stat_part[(size_t)pp * 2 * C + C + tid] = a1;
         }
-        pp = next;
+    };
+
+    // the matrix-core chain of a phase is dependent (one accumulator): between two MFMAs the wave has ~32 idle cycles -- the scheduler is told
+    // to put the phase's other instructions there (one LDS access, a few VALU ops, now and then a global access per MFMA)
+    auto interleave = [&]() {
+#pragma unroll
+        for (int i = 0; i < 6 * NKS; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);      // 1 LDS access
+            __builtin_amdgcn_sched_group_barrier(0x002, C == 32 ? 5 : 3, 0);      // VALU
+            if (i % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);    // 1 global access
+        }
+    };
+    unsigned short* P0 = planes;
+    unsigned short* P1 = planes + 3 * PLANE;
+    float* part0 = part;
+    float* part1 = part + KQ * 32 * PS;
+    int pp = blockIdx.x;
+    if (pp >= npairs) return;
+    prefetch(2 * pp); stage(P0);
+    prefetch(2 * pp + 1);
+    __syncthreads();
+    int prev_pp = -1;                             // the pair whose last phase is still to be written (-1: none -- its stores are dropped)
+#pragma unroll 1
+    for (; pp < npairs; pp += gridDim.x) {
+        const int next = pp + (int)gridDim.x < npairs ? pp + (int)gridDim.x : npairs;      // (past the end: zero-sized resources)
+        // phase (point 0, half 0): previous pair's last phase goes out; point 1 of this pair is staged
+        emit(part1, 2 * prev_pp + 1, 1);
+        if (STATS) { dred[tid] = st_s; dred[NT + tid] = st_q; }
+        st_s = 0.0; st_q = 0.0;
+        stage(P1);
+        multiply(P0, 0, part0);
+        interleave();
+        __syncthreads();
+        // phase (0, 1)
+        finish_stats(prev_pp);
+        emit(part0, 2 * pp, 0);
+        prefetch(2 * next);
+        multiply(P0, 1, part1);
+        interleave();
+        __syncthreads();
+        // phase (1, 0): the next pair's point 0 is staged (its rows were requested a phase ago)
+        emit(part1, 2 * pp, 1);
+        stage(P0);
+        multiply(P1, 0, part0);
+        interleave();
+        __syncthreads();
+        // phase (1, 1)
+        emit(part0, 2 * pp + 1, 0);
+        prefetch(2 * next + 1);
+        multiply(P1, 1, part1);
+        interleave();
+        __syncthreads();
+        prev_pp = pp;
     }
+    // drain: the last phase's tiles, the last pair's statistics
+    emit(part1, 2 * prev_pp + 1, 1);
+    if (STATS) { dred[tid] = st_s; dred[NT + tid] = st_q; }
+    __syncthreads();
+    finish_stats(prev_pp);
 }
 
-template <int C>
-static int launch_intra_ws(int npts, int ppb, const float* X, const float* mean, const float* rstd, const int* intra_idx, const void* Wq,
-                           const float* bias, float* Y, double* stat_part, hipStream_t st) {
+template <int C, bool NORM, bool STATS>
+static int launch_intra_ws_t(int npts, int ppb, const float* X, const float* mean, const float* rstd, const int* intra_idx, const void* Wq,
+                             const float* bias, float* Y, double* stat_part, hipStream_t st) {
     using S = WsShape<C>;
-    if (stat_part && (ppb % 2) != 0) return ETCH_EUNSUPPORTED;          // a pair's points must belong to one sample
-    auto kern = intra_so3conv_ws_kernel<C>;
+    auto kern = intra_so3conv_ws_kernel<C, NORM, STATS>;
     static bool ready = false;
     if (!ready) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::lds_bytes);
@@ -225,6 +266,17 @@ static int launch_intra_ws(int npts, int ppb, const float* X, const float* mean,
                        stat_part);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
+}
+template <int C>
+static int launch_intra_ws(int npts, int ppb, const float* X, const float* mean, const float* rstd, const int* intra_idx, const void* Wq,
+                           const float* bias, float* Y, double* stat_part, hipStream_t st) {
+    if (stat_part && (ppb % 2) != 0) return ETCH_EUNSUPPORTED;          // a pair's points must belong to one sample
+    if ((mean == nullptr) != (rstd == nullptr)) return ETCH_EINVAL;
+#define WS_GO(N, S_) return launch_intra_ws_t<C, N, S_>(npts, ppb, X, mean, rstd, intra_idx, Wq, bias, Y, stat_part, st)
+    if (mean) { if (stat_part) WS_GO(true, true); WS_GO(true, false); }
+    if (stat_part) WS_GO(false, true);
+    WS_GO(false, false);
+#undef WS_GO
 }
 
 // Wq = ops.intra_weight_split: [mt][kq][K step][plane hi / mid / lo][lane][8 bf16],
