@@ -175,6 +175,9 @@ __global__ void __launch_bounds__(512) linear_relu_dot_bx_kernel(long R, int G, 
     };
     fetch(blockIdx.x);
     int buf = 0;
+    bf16x8 bn[2][3];                             // the NEXT K step's W fragments (one step of register look-ahead, across groups and tiles:
+                                                 // the L2 latency of the weight stream is what an 8-wave workgroup cannot hide otherwise)
+    wfrag(0, 0, 2 * sp, bn[0]); wfrag(0, 0, 2 * sp + 1, bn[1]);
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long r0 = tile * FD_ROWS;
         __syncthreads();                         // the previous tile (and its last reduction table) is consumed
@@ -202,16 +205,25 @@ __global__ void __launch_bounds__(512) linear_relu_dot_bx_kernel(long R, int G, 
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
                 bf16x8 b[2][3];
-                wfrag(g, t, 2 * sp, b[0]); wfrag(g, t, 2 * sp + 1, b[1]);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) { b[0][pl] = bn[0][pl]; b[1][pl] = bn[1][pl]; }
+                {   // next step: (g, t + 1), or the first of the next group (after the last group: group 0 again, for the next tile)
+                    const int gn = t + 1 < KT ? g : (g + 1 < G ? g + 1 : 0), tn = t + 1 < KT ? t + 1 : 0;
+                    wfrag(gn, tn, 2 * sp, bn[0]); wfrag(gn, tn, 2 * sp + 1, bn[1]);
+                }
                 bf16x8 a[RT][3];
 #pragma unroll
                 for (int i = 0; i < RT; ++i)
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) a[i][pl] = *reinterpret_cast<const bf16x8*>(Xp + pl * PLANE + (rh * (FD_ROWS / 2) + i * 16 + fr) * SB + t * 32 + fg * 8);
                 // smallest cross products first; term-major: consecutive MFMAs are independent
+#if defined(LRD_ABL) && (LRD_ABL & 1)
+#define FD_T(PA, PB) _Pragma("unroll") for (int i = 0; i < RT; ++i) asm volatile("" :: "v"(a[i][PA]), "v"(b[0][PB]), "v"(b[1][PB]));
+#else
 #define FD_T(PA, PB) _Pragma("unroll") for (int i = 0; i < RT; ++i) { \
         acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][PA], b[0][PB], acc[i][0], 0, 0, 0); \
         acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][PA], b[1][PB], acc[i][1], 0, 0, 0); }
+#endif
                 FD_T(2, 0) FD_T(0, 2) FD_T(1, 1) FD_T(1, 0) FD_T(0, 1) FD_T(0, 0)
 #undef FD_T
             }
@@ -226,7 +238,11 @@ __global__ void __launch_bounds__(512) linear_relu_dot_bx_kernel(long R, int G, 
                 for (int i = 0; i < RT; ++i)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
+#if defined(LRD_ABL) && (LRD_ABL & 2)
+                        const float s = acc[i][s2][q] + bs + ww;       // timing experiment: no row sums
+#else
                         const float s = fd_row_sum16(fmaxf(acc[i][s2][q] + bs, 0.f) * ww);
+#endif
                         if (fr == ((i * 4 + q) & 15)) rp[i * 16 + fg * 4 + q] = s;    // spread the stores over the row's lanes
                     }
             }

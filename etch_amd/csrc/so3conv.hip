@@ -141,7 +141,11 @@ __global__ void __launch_bounds__(256, BX ? INTER_BX_WPE(CIN, COUT) : 2) inter_s
         a = a < NA ? a : NA - 1;
         const float* Fa = Fb + (size_t)a * CIN + (it_ % NCC) * CCH;         // wave-uniform base + 32-bit lane offset
 #pragma unroll
+#ifdef BX_ABL_NOGATHER
+        for (int s = 0; s < 4; ++s) dst[s] = *reinterpret_cast<const VecT*>(Fa + (unsigned)(VEC * fr) + 0 * noff[16 * t + 4 * fg + s]);      // timing experiment: every gather hits one row
+#else
         for (int s = 0; s < 4; ++s) dst[s] = *reinterpret_cast<const VecT*>(Fa + (noff[16 * t + 4 * fg + s] + (unsigned)(VEC * fr)));
+#endif
     };
     auto issue_rk = [&](int a) {
         a = a < NA ? a : NA - 1;
@@ -196,8 +200,12 @@ __global__ void __launch_bounds__(256, BX ? INTER_BX_WPE(CIN, COUT) : 2) inter_s
 #pragma unroll
                     for (int mi = 0; mi < MT1; ++mi) {
                         const float av = cur[s][mi];
+#ifdef BX_ABL_NOS1MFMA
+                        asm volatile("" :: "v"(w0), "v"(w1), "v"(av));      // timing experiment: step 1 without its MFMAs
+#else
                         acc[mi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, av, acc[mi][0], 0, 0, 0);      // D[k][c]: weights as the row operand
                         acc[mi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, av, acc[mi][1], 0, 0, 0);
+#endif
                     }
                 }
             }
