@@ -283,6 +283,152 @@ static int launch_lrd_bx(long R, int G, const float* X, long ldx, const void* Wq
     return ETCH_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Many groups (the confidence head: G = 86): weight-stationary.  The bx kernel above streams all 8.4 MB of split weights from L2 for every
+// 128-row tile (10.5 GB per launch: 1.3 ms of L2 time that its 8 waves do not overlap with 1.2 ms of matrix work).  Here a workgroup owns a
+// COLUMN BLOCK of two groups (256 hidden columns) and a row block: wave w keeps the fragments of strips 2 w, 2 w + 1 of the block (16 strips)
+// in registers for the whole launch (K = 128: 96 VGPRs) and walks its row block's 128-row tiles; X (82 MB, re-read by the 43 column blocks
+// out of L2 / MALL) is split into LDS planes per tile as before.  The product is formed TRANSPOSED (hidden units as accumulator rows, the
+// tile's rows as columns): a lane holds 4 hidden values of ONE row, so bias / ReLU / w2 and the sum over the strip's hidden units are in-lane
+// adds plus two lane-group swaps per row tile instead of four DPP reductions per accumulator register.
+template <int K>
+__global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, long rows_per_block, const float* __restrict__ X, long ldx,
+                                                                 const bf16x8* __restrict__ Wq, const float* __restrict__ b1,
+                                                                 const float* __restrict__ w2, const float* __restrict__ b2,
+                                                                 float* __restrict__ out, long ldo) {
+    constexpr int FD_ROWS = 128, SB = K + 8, KT = K / 32, PLANE = FD_ROWS * SB, RT = FD_ROWS / 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned short* Xp = reinterpret_cast<unsigned short*>(lds);            // [3][FD_ROWS][SB]
+    float* red = lds + 3 * PLANE / 2;                                        // [8 waves][FD_ROWS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int cb = blockIdx.x, rb = blockIdx.y;
+    // this wave's strips: 2 w, 2 w + 1 of the column block = strips (2 w) % 8, + 1 of group 2 cb + w / 4 (clamped: an odd G leaves the last
+    // block's second group empty -- its waves recompute the last group and never store)
+    const int gq = 2 * cb + (wave >> 2);
+    const bool gvalid = gq < G;
+    const int g = gvalid ? gq : G - 1;
+    const int s0 = (2 * wave) & 7;
+    bf16x8 wf[KT][2][3];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wf[t][s2][pl] = Wq[((((long)g * KT + t) * 8 + s0 + s2) * 3 + pl) * 64 + lane];
+    // hidden units of this lane: strip s0 + s2, rows 4 fg .. 4 fg + 3
+    float4 bs[2], ww[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        bs[s2] = *reinterpret_cast<const float4*>(b1 + g * FD_J + (s0 + s2) * 16 + 4 * fg);
+        ww[s2] = *reinterpret_cast<const float4*>(w2 + g * FD_J + (s0 + s2) * 16 + 4 * fg);
+    }
+    const float b2a = b2[2 * cb < G ? 2 * cb : G - 1], b2b = b2[2 * cb + 1 < G ? 2 * cb + 1 : G - 1];
+
+    constexpr int C4 = K / 4;
+    constexpr int XL = FD_ROWS * C4 / 512;
+    const long row_lo = rb * rows_per_block, row_hi = row_lo + rows_per_block < R ? row_lo + rows_per_block : R;
+    float4 xn[XL];
+    auto fetch = [&](long r0) {
+#pragma unroll
+        for (int h = 0; h < XL; ++h) {
+            const int e = tid + 512 * h;
+            const int row = e / C4, c = (e - row * C4) * 4;
+            xn[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r0 + row < row_hi) xn[h] = *reinterpret_cast<const float4*>(X + (r0 + row) * ldx + c);   // rows past the block are zero
+        }
+    };
+    fetch(row_lo);
+    for (long r0 = row_lo; r0 < row_hi; r0 += FD_ROWS) {
+        __syncthreads();                         // the previous tile (and its reduction table) is consumed
+#pragma unroll
+        for (int h = 0; h < XL; ++h) {
+            const int e = tid + 512 * h;
+            const int row = e / C4, c = (e - row * C4) * 4;
+            const float v[4] = {xn[h].x, xn[h].y, xn[h].z, xn[h].w};
+            unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fd_split(v[i], hh[i], mm[i], ll[i]);
+            unsigned short* d = Xp + row * SB + c;
+            *reinterpret_cast<uint2*>(d) = make_uint2(__builtin_amdgcn_perm(hh[1], hh[0], 0x07060302u), __builtin_amdgcn_perm(hh[3], hh[2], 0x07060302u));
+            *reinterpret_cast<uint2*>(d + PLANE) = make_uint2(__builtin_amdgcn_perm(mm[1], mm[0], 0x07060302u), __builtin_amdgcn_perm(mm[3], mm[2], 0x07060302u));
+            *reinterpret_cast<uint2*>(d + 2 * PLANE) = make_uint2(__builtin_amdgcn_perm(ll[1], ll[0], 0x07060302u), __builtin_amdgcn_perm(ll[3], ll[2], 0x07060302u));
+        }
+        __syncthreads();
+        fetch(r0 + FD_ROWS);                     // in flight during this tile's products
+
+        // row tiles two at a time: D[hidden 4 fg + q of strip s2][row 16 i + fr]
+#pragma unroll
+        for (int i0 = 0; i0 < RT; i0 += 2) {
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                bf16x8 x[2][3];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) x[i][pl] = *reinterpret_cast<const bf16x8*>(Xp + pl * PLANE + ((i0 + i) * 16 + fr) * SB + t * 32 + fg * 8);
+#define FD_T(PA, PB) _Pragma("unroll") for (int i = 0; i < 2; ++i) { \
+        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][0][PA], x[i][PB], acc[i][0], 0, 0, 0); \
+        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][1][PA], x[i][PB], acc[i][1], 0, 0, 0); }
+                FD_T(2, 0) FD_T(0, 2) FD_T(1, 1) FD_T(1, 0) FD_T(0, 1) FD_T(0, 0)
+#undef FD_T
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float tsum = 0.f;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    tsum += fmaxf(acc[i][s2][0] + bs[s2].x, 0.f) * ww[s2].x; tsum += fmaxf(acc[i][s2][1] + bs[s2].y, 0.f) * ww[s2].y;
+                    tsum += fmaxf(acc[i][s2][2] + bs[s2].z, 0.f) * ww[s2].z; tsum += fmaxf(acc[i][s2][3] + bs[s2].w, 0.f) * ww[s2].w;
+                }
+                // sum over the 4 lane groups (the other hidden rows of the two strips): v_permlane16_swap / v_permlane32_swap
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(tsum), __float_as_uint(tsum), false, false);
+                tsum = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                r = __builtin_amdgcn_permlane32_swap(__float_as_uint(tsum), __float_as_uint(tsum), false, false);
+                tsum = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                if (fg == 0) red[wave * FD_ROWS + (i0 + i) * 16 + fr] = tsum;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * FD_ROWS) {                 // thread = (group of the block, row): the four waves of a group in wave order
+            const int gi = tid >> 7, row = tid & (FD_ROWS - 1);
+            if (2 * cb + gi < G && r0 + row < row_hi) {
+                const float* rr = red + gi * 4 * FD_ROWS + row;
+                out[(r0 + row) * ldo + 2 * cb + gi] = ((rr[0] + rr[FD_ROWS]) + rr[2 * FD_ROWS]) + rr[3 * FD_ROWS] + (gi == 0 ? b2a : b2b);
+            }
+        }
+    }
+}
+
+template <int K>
+static int launch_lrd_ws(long R, int G, const float* X, long ldx, const void* Wq, const float* b1, const float* w2, const float* b2, float* out,
+                         long ldo, hipStream_t st) {
+    constexpr int FD_ROWS = 128;
+    const size_t lds = (size_t)3 * FD_ROWS * (K + 8) * 2 + (size_t)8 * FD_ROWS * sizeof(float);
+    auto kern = linear_relu_dot_ws_kernel<K>;
+    static bool ready = false;
+    if (!ready) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        ready = true;
+    }
+    const int ncb = (G + 1) / 2;
+    int nrb = etch_cu_count() / ncb;             // one workgroup per CU: row blocks per column block
+    if (nrb < 1) nrb = 1;
+    long rpb = (R + nrb - 1) / nrb;
+    rpb = (rpb + FD_ROWS - 1) / FD_ROWS * FD_ROWS;
+    nrb = (int)((R + rpb - 1) / rpb);
+    hipLaunchKernelGGL(kern, dim3((unsigned)ncb, (unsigned)nrb), dim3(512), lds, st, R, G, rpb, X, ldx, reinterpret_cast<const bf16x8*>(Wq), b1, w2, b2, out, ldo);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
 // Wq = ops.lrd_weight_split: [g][K step of 32][strip of 16 hidden columns][plane hi / mid / lo][lane = 16 * (k / 8) + column][8 bf16]
 extern "C" int etch_linear_relu_dot_split(long R, int K, int G, int J, const float* X, long ldx, const void* Wq, const float* b1, const float* w2,
                                           const float* b2, float* out, long ldo, void* stream) {
@@ -291,6 +437,14 @@ extern "C" int etch_linear_relu_dot_split(long R, int K, int G, int J, const flo
     if ((ldx & 3) || ((uintptr_t)X & 15) || ((uintptr_t)Wq & 15)) return ETCH_EINVAL;
     if (J != FD_J) return ETCH_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+#ifndef LRD_WS_MIN_G
+#define LRD_WS_MIN_G 8        // from this many groups on (and enough rows to fill the chip) the weight-stationary kernel
+#endif
+    if (G >= LRD_WS_MIN_G && K <= 128 && R >= 128L * 64) {
+        if (K == 32) return launch_lrd_ws<32>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);
+        if (K == 64) return launch_lrd_ws<64>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);
+        if (K == 128) return launch_lrd_ws<128>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);
+    }
     if (K == 32) return launch_lrd_bx<32>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);
     if (K == 64) return launch_lrd_bx<64>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);
     if (K == 128) return launch_lrd_bx<128>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);
