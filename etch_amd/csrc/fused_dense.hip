@@ -291,39 +291,42 @@ static int launch_lrd_bx(long R, int G, const float* X, long ldx, const void* Wq
 // out of L2 / MALL) is split into LDS planes per tile as before.  The product is formed TRANSPOSED (hidden units as accumulator rows, the
 // tile's rows as columns): a lane holds 4 hidden values of ONE row, so bias / ReLU / w2 and the sum over the strip's hidden units are in-lane
 // adds plus two lane-group swaps per row tile instead of four DPP reductions per accumulator register.
-template <int K>
+// SPW = strips per wave: 2 (a column block = two groups, 16 strips over the 8 waves) or 1 (a column block = one group: G = 1, the direction
+// head's tail, whose 49 KB of weights stream from L2 for nothing otherwise and whose 9.6 M rows make the epilogue the larger half of the work).
+template <int K, int SPW>
 __global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, long rows_per_block, const float* __restrict__ X, long ldx,
                                                                  const bf16x8* __restrict__ Wq, const float* __restrict__ b1,
                                                                  const float* __restrict__ w2, const float* __restrict__ b2,
                                                                  float* __restrict__ out, long ldo) {
     constexpr int FD_ROWS = 128, SB = K + 8, KT = K / 32, PLANE = FD_ROWS * SB, RT = FD_ROWS / 16;
+    constexpr int GPB = SPW;                      // groups per column block
+    constexpr int WPG = 8 / GPB;                  // waves per group
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned short* Xp = reinterpret_cast<unsigned short*>(lds);            // [3][FD_ROWS][SB]
     float* red = lds + 3 * PLANE / 2;                                        // [8 waves][FD_ROWS]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
     const int cb = blockIdx.x, rb = blockIdx.y;
-    // this wave's strips: 2 w, 2 w + 1 of the column block = strips (2 w) % 8, + 1 of group 2 cb + w / 4 (clamped: an odd G leaves the last
+    // this wave's strips: SPW w .. of the column block = strips (SPW w) % 8 .. of group GPB cb + w / WPG (clamped: an odd G leaves the last
     // block's second group empty -- its waves recompute the last group and never store)
-    const int gq = 2 * cb + (wave >> 2);
-    const bool gvalid = gq < G;
-    const int g = gvalid ? gq : G - 1;
-    const int s0 = (2 * wave) & 7;
-    bf16x8 wf[KT][2][3];
+    const int gq = GPB * cb + wave / WPG;
+    const int g = gq < G ? gq : G - 1;
+    const int s0 = (SPW * wave) & 7;
+    bf16x8 wf[KT][SPW][3];
 #pragma unroll
     for (int t = 0; t < KT; ++t)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+        for (int s2 = 0; s2 < SPW; ++s2)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) wf[t][s2][pl] = Wq[((((long)g * KT + t) * 8 + s0 + s2) * 3 + pl) * 64 + lane];
     // hidden units of this lane: strip s0 + s2, rows 4 fg .. 4 fg + 3
-    float4 bs[2], ww[2];
+    float4 bs[SPW], ww[SPW];
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
+    for (int s2 = 0; s2 < SPW; ++s2) {
         bs[s2] = *reinterpret_cast<const float4*>(b1 + g * FD_J + (s0 + s2) * 16 + 4 * fg);
         ww[s2] = *reinterpret_cast<const float4*>(w2 + g * FD_J + (s0 + s2) * 16 + 4 * fg);
     }
-    const float b2a = b2[2 * cb < G ? 2 * cb : G - 1], b2b = b2[2 * cb + 1 < G ? 2 * cb + 1 : G - 1];
+    const float b2a = b2[GPB * cb < G ? GPB * cb : G - 1], b2b = b2[GPB * cb + 1 < G ? GPB * cb + 1 : G - 1];
 
     constexpr int C4 = K / 4;
     constexpr int XL = FD_ROWS * C4 / 512;
@@ -360,9 +363,11 @@ __global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, 
         // row tiles two at a time: D[hidden 4 fg + q of strip s2][row 16 i + fr]
 #pragma unroll
         for (int i0 = 0; i0 < RT; i0 += 2) {
-            f32x4 acc[2][2];
+            f32x4 acc[2][SPW];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int s2 = 0; s2 < SPW; ++s2) acc[i][s2] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < KT; ++t) {
                 bf16x8 x[2][3];
@@ -370,9 +375,8 @@ __global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, 
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) x[i][pl] = *reinterpret_cast<const bf16x8*>(Xp + pl * PLANE + ((i0 + i) * 16 + fr) * SB + t * 32 + fg * 8);
-#define FD_T(PA, PB) _Pragma("unroll") for (int i = 0; i < 2; ++i) { \
-        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][0][PA], x[i][PB], acc[i][0], 0, 0, 0); \
-        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][1][PA], x[i][PB], acc[i][1], 0, 0, 0); }
+#define FD_T(PA, PB) _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int s2 = 0; s2 < SPW; ++s2) \
+        acc[i][s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][s2][PA], x[i][PB], acc[i][s2], 0, 0, 0);
                 FD_T(2, 0) FD_T(0, 2) FD_T(1, 1) FD_T(1, 0) FD_T(0, 1) FD_T(0, 0)
 #undef FD_T
             }
@@ -380,11 +384,11 @@ __global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, 
             for (int i = 0; i < 2; ++i) {
                 float tsum = 0.f;
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
+                for (int s2 = 0; s2 < SPW; ++s2) {
                     tsum += fmaxf(acc[i][s2][0] + bs[s2].x, 0.f) * ww[s2].x; tsum += fmaxf(acc[i][s2][1] + bs[s2].y, 0.f) * ww[s2].y;
                     tsum += fmaxf(acc[i][s2][2] + bs[s2].z, 0.f) * ww[s2].z; tsum += fmaxf(acc[i][s2][3] + bs[s2].w, 0.f) * ww[s2].w;
                 }
-                // sum over the 4 lane groups (the other hidden rows of the two strips): v_permlane16_swap / v_permlane32_swap
+                // sum over the 4 lane groups (the other hidden rows of the strips): v_permlane16_swap / v_permlane32_swap
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                 u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(tsum), __float_as_uint(tsum), false, false);
                 tsum = __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -394,32 +398,37 @@ __global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, 
             }
         }
         __syncthreads();
-        if (tid < 2 * FD_ROWS) {                 // thread = (group of the block, row): the four waves of a group in wave order
+        if (tid < GPB * FD_ROWS) {               // thread = (group of the block, row): the group's waves in wave order
             const int gi = tid >> 7, row = tid & (FD_ROWS - 1);
-            if (2 * cb + gi < G && r0 + row < row_hi) {
-                const float* rr = red + gi * 4 * FD_ROWS + row;
-                out[(r0 + row) * ldo + 2 * cb + gi] = ((rr[0] + rr[FD_ROWS]) + rr[2 * FD_ROWS]) + rr[3 * FD_ROWS] + (gi == 0 ? b2a : b2b);
+            if (GPB * cb + gi < G && r0 + row < row_hi) {
+                const float* rr = red + gi * WPG * FD_ROWS + row;
+                float s_ = rr[0];
+#pragma unroll
+                for (int w = 1; w < WPG; ++w) s_ += rr[w * FD_ROWS];
+                out[(r0 + row) * ldo + GPB * cb + gi] = s_ + (gi == 0 ? b2a : b2b);
             }
         }
     }
 }
 
-template <int K>
+template <int K, int SPW>
 static int launch_lrd_ws(long R, int G, const float* X, long ldx, const void* Wq, const float* b1, const float* w2, const float* b2, float* out,
                          long ldo, hipStream_t st) {
     constexpr int FD_ROWS = 128;
     const size_t lds = (size_t)3 * FD_ROWS * (K + 8) * 2 + (size_t)8 * FD_ROWS * sizeof(float);
-    auto kern = linear_relu_dot_ws_kernel<K>;
-    static bool ready = false;
-    if (!ready) {
+    auto kern = linear_relu_dot_ws_kernel<K, SPW>;
+    static int per_cu = 0;
+    if (per_cu == 0) {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
         }
-        ready = true;
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)kern, 512, lds) != hipSuccess || n < 1) n = 1;
+        per_cu = n;
     }
-    const int ncb = (G + 1) / 2;
-    int nrb = etch_cu_count() / ncb;             // one workgroup per CU: row blocks per column block
+    const int ncb = (G + SPW - 1) / SPW;
+    int nrb = etch_cu_count() * per_cu / ncb;    // resident workgroups: row blocks per column block
     if (nrb < 1) nrb = 1;
     long rpb = (R + nrb - 1) / nrb;
     rpb = (rpb + FD_ROWS - 1) / FD_ROWS * FD_ROWS;
@@ -438,12 +447,19 @@ extern "C" int etch_linear_relu_dot_split(long R, int K, int G, int J, const flo
     if (J != FD_J) return ETCH_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
 #ifndef LRD_WS_MIN_G
-#define LRD_WS_MIN_G 8        // from this many groups on (and enough rows to fill the chip) the weight-stationary kernel
+#define LRD_WS_MIN_G 8        // from this many groups on (and enough rows to fill the chip) the weight-stationary kernel with two groups per workgroup
 #endif
-    if (G >= LRD_WS_MIN_G && K <= 128 && R >= 128L * 64) {
-        if (K == 32) return launch_lrd_ws<32>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);
-        if (K == 64) return launch_lrd_ws<64>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);
-        if (K == 128) return launch_lrd_ws<128>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);
+    if (K <= 128 && R >= 128L * 64) {
+        if (G >= LRD_WS_MIN_G) {
+            if (K == 32) return launch_lrd_ws<32, 2>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);
+            if (K == 64) return launch_lrd_ws<64, 2>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);
+            if (K == 128) return launch_lrd_ws<128, 2>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);
+        }
+        if (G == 1) {
+            if (K == 32) return launch_lrd_ws<32, 1>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);
+            if (K == 64) return launch_lrd_ws<64, 1>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);
+            if (K == 128) return launch_lrd_ws<128, 1>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);
+        }
     }
     if (K == 32) return launch_lrd_bx<32>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);
     if (K == 64) return launch_lrd_bx<64>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);

@@ -117,7 +117,7 @@ def test_folded_direction_head_equals_unfolded(tmp_path):
 
 
 @pytest.mark.parametrize("R,K,G,perm", [(1000, 128, 5, False), (1000, 128, 5, True), (333, 64, 1, True), (130, 64, 2, False), (1, 128, 86, True),
-                                        (9001, 128, 9, True), (8200, 64, 86, True), (20000, 32, 8, True)])
+                                        (9001, 128, 9, True), (8200, 64, 86, True), (20000, 32, 8, True), (8193, 64, 1, True), (10000, 128, 1, True)])
 def test_linear_relu_dot_matches_unfused_chain(R, K, G, perm):
     """etch_linear_relu_dot == Conv1d(K, G*128) -> ReLU -> grouped Conv1d (pointtransformer_seg.py:145): fp64 reference and the
     unfused etch_linear + etch_grouped_dot chain; ragged row counts (partial 128-row tiles).  perm = the weight operand of the model path
