@@ -298,12 +298,14 @@ __global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, 
                                                                  const bf16x8* __restrict__ Wq, const float* __restrict__ b1,
                                                                  const float* __restrict__ w2, const float* __restrict__ b2,
                                                                  float* __restrict__ out, long ldo) {
-    constexpr int FD_ROWS = 128, SB = K + 8, KT = K / 32, PLANE = FD_ROWS * SB, RT = FD_ROWS / 16;
+    // 64-row tiles, planes and reduction table double-buffered: ONE barrier per tile, and the next tile's split + LDS stores sit between the two
+    // halves of this tile's MFMA stream (VALU work beside the bf16 matrix cores is free; beside a barrier it is not)
+    constexpr int FD_ROWS = 64, SB = K + 8, KT = K / 32, PLANE = FD_ROWS * SB, RT = FD_ROWS / 16;
     constexpr int GPB = SPW;                      // groups per column block
     constexpr int WPG = 8 / GPB;                  // waves per group
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    unsigned short* Xp = reinterpret_cast<unsigned short*>(lds);            // [3][FD_ROWS][SB]
-    float* red = lds + 3 * PLANE / 2;                                        // [8 waves][FD_ROWS]
+    unsigned short* Xp = reinterpret_cast<unsigned short*>(lds);            // [2 buffers][3][FD_ROWS][SB]
+    float* red = lds + 2 * 3 * PLANE / 2;                                    // [2 buffers][8 waves][FD_ROWS]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
     const int cb = blockIdx.x, rb = blockIdx.y;
@@ -329,7 +331,7 @@ __global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, 
     const float b2a = b2[GPB * cb < G ? GPB * cb : G - 1], b2b = b2[GPB * cb + 1 < G ? GPB * cb + 1 : G - 1];
 
     constexpr int C4 = K / 4;
-    constexpr int XL = FD_ROWS * C4 / 512;
+    constexpr int XL = (FD_ROWS * C4 + 511) / 512;
     const long row_lo = rb * rows_per_block, row_hi = row_lo + rows_per_block < R ? row_lo + rows_per_block : R;
     float4 xn[XL];
     auto fetch = [&](long r0) {
@@ -338,84 +340,93 @@ __global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, 
             const int e = tid + 512 * h;
             const int row = e / C4, c = (e - row * C4) * 4;
             xn[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r0 + row < row_hi) xn[h] = *reinterpret_cast<const float4*>(X + (r0 + row) * ldx + c);   // rows past the block are zero
+            if (e < FD_ROWS * C4 && r0 + row < row_hi) xn[h] = *reinterpret_cast<const float4*>(X + (r0 + row) * ldx + c);   // rows past the block are zero
         }
     };
-    fetch(row_lo);
-    for (long r0 = row_lo; r0 < row_hi; r0 += FD_ROWS) {
-        __syncthreads();                         // the previous tile (and its reduction table) is consumed
+    auto stage = [&](unsigned short* P) {
 #pragma unroll
         for (int h = 0; h < XL; ++h) {
             const int e = tid + 512 * h;
+            if (e >= FD_ROWS * C4) continue;
             const int row = e / C4, c = (e - row * C4) * 4;
             const float v[4] = {xn[h].x, xn[h].y, xn[h].z, xn[h].w};
             unsigned hh[4], mm[4], ll[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) fd_split(v[i], hh[i], mm[i], ll[i]);
-            unsigned short* d = Xp + row * SB + c;
+            unsigned short* d = P + row * SB + c;
             *reinterpret_cast<uint2*>(d) = make_uint2(__builtin_amdgcn_perm(hh[1], hh[0], 0x07060302u), __builtin_amdgcn_perm(hh[3], hh[2], 0x07060302u));
             *reinterpret_cast<uint2*>(d + PLANE) = make_uint2(__builtin_amdgcn_perm(mm[1], mm[0], 0x07060302u), __builtin_amdgcn_perm(mm[3], mm[2], 0x07060302u));
             *reinterpret_cast<uint2*>(d + 2 * PLANE) = make_uint2(__builtin_amdgcn_perm(ll[1], ll[0], 0x07060302u), __builtin_amdgcn_perm(ll[3], ll[2], 0x07060302u));
         }
-        __syncthreads();
-        fetch(r0 + FD_ROWS);                     // in flight during this tile's products
-
-        // row tiles two at a time: D[hidden 4 fg + q of strip s2][row 16 i + fr]
+    };
+    // two row tiles: D[hidden 4 fg + q of strip s2][row 16 i + fr] -> sums over the wave's hidden units into rt[]
+    auto half_tile = [&](const unsigned short* P, int i0, float* rt) {
+        f32x4 acc[2][SPW];
 #pragma unroll
-        for (int i0 = 0; i0 < RT; i0 += 2) {
-            f32x4 acc[2][SPW];
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int s2 = 0; s2 < SPW; ++s2) acc[i][s2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            bf16x8 x[2][3];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int s2 = 0; s2 < SPW; ++s2) acc[i][s2] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < KT; ++t) {
-                bf16x8 x[2][3];
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) x[i][pl] = *reinterpret_cast<const bf16x8*>(Xp + pl * PLANE + ((i0 + i) * 16 + fr) * SB + t * 32 + fg * 8);
+                for (int pl = 0; pl < 3; ++pl) x[i][pl] = *reinterpret_cast<const bf16x8*>(P + pl * PLANE + ((i0 + i) * 16 + fr) * SB + t * 32 + fg * 8);
 #define FD_T(PA, PB) _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int s2 = 0; s2 < SPW; ++s2) \
         acc[i][s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][s2][PA], x[i][PB], acc[i][s2], 0, 0, 0);
-                FD_T(2, 0) FD_T(0, 2) FD_T(1, 1) FD_T(1, 0) FD_T(0, 1) FD_T(0, 0)
+            FD_T(2, 0) FD_T(0, 2) FD_T(1, 1) FD_T(1, 0) FD_T(0, 1) FD_T(0, 0)
 #undef FD_T
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                float tsum = 0.f;
-#pragma unroll
-                for (int s2 = 0; s2 < SPW; ++s2) {
-                    tsum += fmaxf(acc[i][s2][0] + bs[s2].x, 0.f) * ww[s2].x; tsum += fmaxf(acc[i][s2][1] + bs[s2].y, 0.f) * ww[s2].y;
-                    tsum += fmaxf(acc[i][s2][2] + bs[s2].z, 0.f) * ww[s2].z; tsum += fmaxf(acc[i][s2][3] + bs[s2].w, 0.f) * ww[s2].w;
-                }
-                // sum over the 4 lane groups (the other hidden rows of the strips): v_permlane16_swap / v_permlane32_swap
-                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(tsum), __float_as_uint(tsum), false, false);
-                tsum = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-                r = __builtin_amdgcn_permlane32_swap(__float_as_uint(tsum), __float_as_uint(tsum), false, false);
-                tsum = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-                if (fg == 0) red[wave * FD_ROWS + (i0 + i) * 16 + fr] = tsum;
-            }
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float tsum = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < SPW; ++s2) {
+                tsum += fmaxf(acc[i][s2][0] + bs[s2].x, 0.f) * ww[s2].x; tsum += fmaxf(acc[i][s2][1] + bs[s2].y, 0.f) * ww[s2].y;
+                tsum += fmaxf(acc[i][s2][2] + bs[s2].z, 0.f) * ww[s2].z; tsum += fmaxf(acc[i][s2][3] + bs[s2].w, 0.f) * ww[s2].w;
+            }
+            // sum over the 4 lane groups (the other hidden rows of the strips): v_permlane16_swap / v_permlane32_swap
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(tsum), __float_as_uint(tsum), false, false);
+            tsum = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            r = __builtin_amdgcn_permlane32_swap(__float_as_uint(tsum), __float_as_uint(tsum), false, false);
+            tsum = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            if (fg == 0) rt[(i0 + i) * 16 + fr] = tsum;
+        }
+    };
+    fetch(row_lo);
+    stage(Xp);
+    fetch(row_lo + FD_ROWS);
+    __syncthreads();
+    int buf = 0;
+    for (long r0 = row_lo; r0 < row_hi; r0 += FD_ROWS, buf ^= 1) {
+        const unsigned short* P = Xp + buf * 3 * PLANE;
+        float* rtab = red + buf * 8 * FD_ROWS;
+        half_tile(P, 0, rtab + wave * FD_ROWS);
+        stage(Xp + (buf ^ 1) * 3 * PLANE);       // tile r0 + 64 (its last readers finished before the previous barrier)
+        fetch(r0 + 2 * FD_ROWS);
+        half_tile(P, 2, rtab + wave * FD_ROWS);
         __syncthreads();
         if (tid < GPB * FD_ROWS) {               // thread = (group of the block, row): the group's waves in wave order
-            const int gi = tid >> 7, row = tid & (FD_ROWS - 1);
+            const int gi = tid / FD_ROWS, row = tid % FD_ROWS;
             if (GPB * cb + gi < G && r0 + row < row_hi) {
-                const float* rr = red + gi * WPG * FD_ROWS + row;
+                const float* rr = rtab + gi * WPG * FD_ROWS + row;
                 float s_ = rr[0];
 #pragma unroll
                 for (int w = 1; w < WPG; ++w) s_ += rr[w * FD_ROWS];
                 out[(r0 + row) * ldo + GPB * cb + gi] = s_ + (gi == 0 ? b2a : b2b);
             }
         }
+        // (the table read here is rewritten two tiles on, behind the next tile's barrier)
     }
 }
 
 template <int K, int SPW>
 static int launch_lrd_ws(long R, int G, const float* X, long ldx, const void* Wq, const float* b1, const float* w2, const float* b2, float* out,
                          long ldo, hipStream_t st) {
-    constexpr int FD_ROWS = 128;
-    const size_t lds = (size_t)3 * FD_ROWS * (K + 8) * 2 + (size_t)8 * FD_ROWS * sizeof(float);
+    constexpr int FD_ROWS = 64;
+    const size_t lds = (size_t)2 * 3 * FD_ROWS * (K + 8) * 2 + (size_t)2 * 8 * FD_ROWS * sizeof(float);
     auto kern = linear_relu_dot_ws_kernel<K, SPW>;
     static int per_cu = 0;
     if (per_cu == 0) {
