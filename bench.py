@@ -62,7 +62,7 @@ def algorithmic_flops(name, a):
         return 2.0 * R * K * O, f"gemm_nt_kernel"
     if name in ("etch_linear_relu_dot", "etch_linear_relu_dot_split"):
         R, K, G, J = v[0], v[1], v[2], v[3]
-        ws = name.endswith("split") and K <= 128 and R >= 128 * 64 and (G >= 8 or G == 1)          # the dispatch of etch_linear_relu_dot_split
+        ws = name.endswith("split") and K <= 128 and (G >= 8 or G == 1)          # the dispatch of etch_linear_relu_dot_split
         return 2.0 * R * G * J * (K + 1), ("linear_relu_dot_ws_kernel" if ws else "linear_relu_dot_bx_kernel") if name.endswith("split") else "linear_relu_dot_kernel"
     if name in ("etch_inter_so3conv", "etch_inter_so3conv_ordered", "etch_inter_so3conv_split"):
         b, cin, cout, p1, p2, nn = v[0:6]

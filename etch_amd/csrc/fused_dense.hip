@@ -458,9 +458,10 @@ extern "C" int etch_linear_relu_dot_split(long R, int K, int G, int J, const flo
     if (J != FD_J) return ETCH_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
 #ifndef LRD_WS_MIN_G
-#define LRD_WS_MIN_G 8        // from this many groups on (and enough rows to fill the chip) the weight-stationary kernel with two groups per workgroup
+#define LRD_WS_MIN_G 8        // from this many groups on the weight-stationary kernel with two groups per workgroup
 #endif
-    if (K <= 128 && R >= 128L * 64) {
+    // (the choice depends on the layer's shape only, never on the row count: a scan's result may not depend on its batch neighbours, bit for bit)
+    if (K <= 128) {
         if (G >= LRD_WS_MIN_G) {
             if (K == 32) return launch_lrd_ws<32, 2>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);
             if (K == 64) return launch_lrd_ws<64, 2>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);

@@ -121,7 +121,8 @@ def test_folded_direction_head_equals_unfolded(tmp_path):
 def test_linear_relu_dot_matches_unfused_chain(R, K, G, perm):
     """etch_linear_relu_dot == Conv1d(K, G*128) -> ReLU -> grouped Conv1d (pointtransformer_seg.py:145): fp64 reference and the
     unfused etch_linear + etch_grouped_dot chain; ragged row counts (partial 128-row tiles).  perm = the weight operand of the model path
-    (split bf16 planes: the streaming kernel, or from 8 groups and 8 192 rows on the weight-stationary one -- odd group counts, ragged row blocks)."""
+    (split bf16 planes: the streaming kernel for 2 - 7 groups, the weight-stationary one for a single group and from 8 groups on -- odd group
+    counts, ragged row blocks, a single row)."""
     from etch_amd import ops
     g = torch.Generator().manual_seed(R + K + G)
     x = torch.randn(R, K, generator=g)
