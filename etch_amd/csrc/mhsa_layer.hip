@@ -149,10 +149,18 @@ __device__ __forceinline__ void ml_project(const unsigned short* Xp, const MlWei
         Q[tt] = q; Kt[tt] = k; V[tt] = v;
     }
 }
-// B: attention of heads 2w (registers 0,1 / output columns 0-7) and 2w+1 (registers 2,3 / columns 8-15) on the fp32 MFMA; the output tile goes to
+// B: attention of heads 2w (registers 0,1 / output columns 0-7) and 2w+1 (registers 2,3 / columns 8-15): scores on the fp32 MFMA (their operands are the
+// projections' accumulators as they stand; 8-dim heads fill only a quarter of a bf16 K step) and so does P V (see ML_PV_BF16); the output tile goes to
 // LDS as fp32 (As: the layer's output in MODE 2) or as the three planes of head_combine's operand (Ap)
 template <bool PLANES>
 __device__ __forceinline__ void ml_attention(const f32x4 (&Q)[4], const f32x4 (&Kt)[4], const f32x4 (&V)[4], float* As, unsigned short* Ap, int w, int fr, int fg) {
+#ifdef ML_PV_BF16
+    bf16x8 Vq[2][3];                                                   // the V accumulators as split operands, once per point
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+        ml_split8(make_float4(V[2 * ks][0], V[2 * ks][1], V[2 * ks][2], V[2 * ks][3]),
+                  make_float4(V[2 * ks + 1][0], V[2 * ks + 1][1], V[2 * ks + 1][2], V[2 * ks + 1][3]), Vq[ks]);
+#endif
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         f32x4 sa[4], sb[4];
@@ -171,6 +179,24 @@ __device__ __forceinline__ void ml_attention(const f32x4 (&Q)[4], const f32x4 (&
         }
         ml_softmax(sa, fg);
         ml_softmax(sb, fg);
+#ifdef ML_PV_BF16      // measured SLOWER (interp layer 4.54 -> 4.77 ms, mode 2 3.68 -> 3.76): splitting 32 probabilities per lane and query tile costs more
+                       // VALU time than the 32 -> 24 cheaper MFMAs give back; kept as the record of the experiment (tests pass with it)
+        // P V on the bf16 matrix cores.  A lane's 16 probabilities and its 16 V accumulators belong to the SAME keys (16 jt + 4 fg + r), so they
+        // are the lane's slices of the 16x16x32 operands as they stand: K step ks = key tiles 2 ks, 2 ks + 1, element e = 4 (jt - 2 ks) + r.
+        f32x4 o4[2][2] = {{z, z}, {z, z}};                             // [head][ks]: four independent chains
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 pa[3], pb[3];
+            ml_split8(make_float4(sa[2 * ks][0], sa[2 * ks][1], sa[2 * ks][2], sa[2 * ks][3]),
+                      make_float4(sa[2 * ks + 1][0], sa[2 * ks + 1][1], sa[2 * ks + 1][2], sa[2 * ks + 1][3]), pa);
+            ml_split8(make_float4(sb[2 * ks][0], sb[2 * ks][1], sb[2 * ks][2], sb[2 * ks][3]),
+                      make_float4(sb[2 * ks + 1][0], sb[2 * ks + 1][1], sb[2 * ks + 1][2], sb[2 * ks + 1][3]), pb);
+#define ML_T(PA, PB) o4[0][ks] = ML_MFMA16(pa[PA], Vq[ks][PB], o4[0][ks]); o4[1][ks] = ML_MFMA16(pb[PA], Vq[ks][PB], o4[1][ks]);
+            ML_T(2, 0) ML_T(0, 2) ML_T(1, 1) ML_T(1, 0) ML_T(0, 1) ML_T(0, 0)
+#undef ML_T
+        }
+        const f32x4 oa = o4[0][0] + o4[0][1], ob = o4[1][0] + o4[1][1];
+#else
         f32x4 oa = z, ob = z;
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
@@ -179,6 +205,7 @@ __device__ __forceinline__ void ml_attention(const f32x4 (&Q)[4], const f32x4 (&
                 oa = ML_MFMA(sa[jt][r], V[jt][r], oa);
                 ob = ML_MFMA(sb[jt][r], V[jt][r], ob);
             }
+#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float o = fr < 8 ? oa[r] : ob[r];
