@@ -304,6 +304,163 @@ __global__ void __launch_bounds__(256) linear_k1_kernel(GemmArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight-stationary GEMM on the bf16 matrix cores for the layers with a small weight matrix and many rows (the Point-Transformer nets' linear
+// layers at the two large levels, the encoder's skip convs): fp32 operands split EXACTLY into three bf16 values (8 + 8 + 8 mantissa bits), six
+// cross products accumulated in fp32 by v_mfma_f32_16x16x32_bf16 -- the fp32 MFMA's error against fp64 (profiles/r03_bf16x3_split.txt).  The
+// tiled kernel above reads X once per 64-column output tile and spends 37 - 50 % of the fp32 matrix rate on these shapes; here a workgroup
+// keeps ALL of W in registers (split once per workgroup: wave = (strip group, row part), SPW strips of 16 output channels each), streams
+// 64-row tiles of X through double-buffered LDS planes (split at staging, one barrier per tile) and writes Y once: X and Y cross HBM once.
+// The product is formed transposed (output channels as accumulator rows): a lane holds 4 consecutive channels of one row = one 16-byte store.
+// ------------------------------------------------------------------------------------------------
+typedef short g_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void g_split(const float v, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(v);
+    const float r = v - __uint_as_float(h & 0xffff0000u);
+    m = __float_as_uint(r);
+    l = __float_as_uint(r - __uint_as_float(m & 0xffff0000u));
+}
+__device__ __forceinline__ void g_split8(const float4 v0, const float4 v1, g_bf16x8 (&o)[3]) {
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g_split(v[i], h[i], m[i], l[i]);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define G_PK(a) (u32x4){__builtin_amdgcn_perm(a[1], a[0], 0x07060302u), __builtin_amdgcn_perm(a[3], a[2], 0x07060302u), \
+                        __builtin_amdgcn_perm(a[5], a[4], 0x07060302u), __builtin_amdgcn_perm(a[7], a[6], 0x07060302u)}
+    const u32x4 ph = G_PK(h), pm = G_PK(m), pl = G_PK(l);
+#undef G_PK
+    o[0] = __builtin_bit_cast(g_bf16x8, ph); o[1] = __builtin_bit_cast(g_bf16x8, pm); o[2] = __builtin_bit_cast(g_bf16x8, pl);
+}
+
+// O = 16 * SPW * (8 / RP) output channels; RP row parts (the 4 row tiles of a 64-row tile divided among them)
+template <int K, int SPW, int RP>
+__global__ void __launch_bounds__(512) gemm_ws_split_kernel(GemmArgs a, long rows_per_block) {
+    constexpr int FD_ROWS = 64, SB = K + 8, KT = K / 32, PLANE = FD_ROWS * SB;
+    constexpr int SG = 8 / RP;                    // strip groups (waves along the output channels)
+    constexpr int RTW = (FD_ROWS / 16) / RP;      // row tiles per wave
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned short* Xp = reinterpret_cast<unsigned short*>(lds);            // [2 buffers][3][FD_ROWS][SB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int sg = wave % SG, rp = wave / SG;
+    // this wave's weight fragments: strips SPW sg .. + SPW - 1, rows (output channels) 16 strip + fr, k = 32 t + 8 fg + e
+    g_bf16x8 wf[KT][SPW][3];
+    float4 bs[SPW], sc[SPW], sh[SPW];
+#pragma unroll
+    for (int s2 = 0; s2 < SPW; ++s2) {
+        const int o = 16 * (SPW * sg + s2);
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            const float* p = a.W + (long)(o + fr) * a.ldw + 32 * t + 8 * fg;
+            g_split8(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4), wf[t][s2]);
+        }
+        // epilogue constants of the lane's 4 channels o + 4 fg .. + 3
+        bs[s2] = a.bias ? make_float4(a.bias[o + 4 * fg], a.bias[o + 4 * fg + 1], a.bias[o + 4 * fg + 2], a.bias[o + 4 * fg + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sc[s2] = a.scale ? make_float4(a.scale[o + 4 * fg], a.scale[o + 4 * fg + 1], a.scale[o + 4 * fg + 2], a.scale[o + 4 * fg + 3]) : make_float4(1.f, 1.f, 1.f, 1.f);
+        sh[s2] = a.shift ? make_float4(a.shift[o + 4 * fg], a.shift[o + 4 * fg + 1], a.shift[o + 4 * fg + 2], a.shift[o + 4 * fg + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    constexpr int C4 = K / 4;
+    constexpr int XL = (FD_ROWS * C4 + 511) / 512;
+    const long row_lo = (long)blockIdx.x * rows_per_block, row_hi = row_lo + rows_per_block < a.R ? row_lo + rows_per_block : a.R;
+    float4 xn[XL];
+    auto fetch = [&](long r0) {
+#pragma unroll
+        for (int h = 0; h < XL; ++h) {
+            const int e = tid + 512 * h;
+            const int row = e / C4, c = (e - row * C4) * 4;
+            xn[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < FD_ROWS * C4 && r0 + row < row_hi) xn[h] = *reinterpret_cast<const float4*>(a.X + (r0 + row) * a.ldx + c);
+        }
+    };
+    auto stage = [&](unsigned short* P) {
+#pragma unroll
+        for (int h = 0; h < XL; ++h) {
+            const int e = tid + 512 * h;
+            if (e >= FD_ROWS * C4) continue;
+            const int row = e / C4, c = (e - row * C4) * 4;
+            const float v[4] = {xn[h].x, xn[h].y, xn[h].z, xn[h].w};
+            unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g_split(v[i], hh[i], mm[i], ll[i]);
+            unsigned short* d = P + row * SB + c;
+            *reinterpret_cast<uint2*>(d) = make_uint2(__builtin_amdgcn_perm(hh[1], hh[0], 0x07060302u), __builtin_amdgcn_perm(hh[3], hh[2], 0x07060302u));
+            *reinterpret_cast<uint2*>(d + PLANE) = make_uint2(__builtin_amdgcn_perm(mm[1], mm[0], 0x07060302u), __builtin_amdgcn_perm(mm[3], mm[2], 0x07060302u));
+            *reinterpret_cast<uint2*>(d + 2 * PLANE) = make_uint2(__builtin_amdgcn_perm(ll[1], ll[0], 0x07060302u), __builtin_amdgcn_perm(ll[3], ll[2], 0x07060302u));
+        }
+    };
+    // row tile i of the 64-row tile at r0: D[channel 4 fg + q of strip s2][row 16 i + fr] -> epilogue -> Y
+    auto row_tile = [&](const unsigned short* P, int i, long r0) {
+        f32x4 acc[SPW];
+#pragma unroll
+        for (int s2 = 0; s2 < SPW; ++s2) acc[s2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            g_bf16x8 x[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) x[pl] = *reinterpret_cast<const g_bf16x8*>(P + pl * PLANE + (i * 16 + fr) * SB + t * 32 + fg * 8);
+#define G_T(PA, PB) _Pragma("unroll") for (int s2 = 0; s2 < SPW; ++s2) acc[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][s2][PA], x[PB], acc[s2], 0, 0, 0);
+            G_T(2, 0) G_T(0, 2) G_T(1, 1) G_T(1, 0) G_T(0, 1) G_T(0, 0)
+#undef G_T
+        }
+        const long r = r0 + i * 16 + fr;
+        if (r < row_hi) {
+#pragma unroll
+            for (int s2 = 0; s2 < SPW; ++s2) {
+                const int o = 16 * (SPW * sg + s2) + 4 * fg;
+                float4 v = make_float4(acc[s2][0] + bs[s2].x, acc[s2][1] + bs[s2].y, acc[s2][2] + bs[s2].z, acc[s2][3] + bs[s2].w);
+                if (a.scale) { v.x = v.x * sc[s2].x + sh[s2].x; v.y = v.y * sc[s2].y + sh[s2].y; v.z = v.z * sc[s2].z + sh[s2].z; v.w = v.w * sc[s2].w + sh[s2].w; }
+                float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.res_mode != 0) rs = *reinterpret_cast<const float4*>(a.res + r * a.ldr + o);
+                if (a.res_mode == 1) { v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w; }
+                if (a.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                else if (a.act == 2) { v.x = v.x > 0.f ? v.x : 0.01f * v.x; v.y = v.y > 0.f ? v.y : 0.01f * v.y; v.z = v.z > 0.f ? v.z : 0.01f * v.z; v.w = v.w > 0.f ? v.w : 0.01f * v.w; }
+                if (a.res_mode == 2) { v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w; }
+                *reinterpret_cast<float4*>(a.Y + r * a.ldy + o) = v;
+            }
+        }
+    };
+    if (row_lo >= row_hi) return;
+    fetch(row_lo);
+    stage(Xp);
+    fetch(row_lo + FD_ROWS);
+    __syncthreads();
+    int buf = 0;
+    for (long r0 = row_lo; r0 < row_hi; r0 += FD_ROWS, buf ^= 1) {
+        const unsigned short* P = Xp + buf * 3 * PLANE;
+        row_tile(P, rp * RTW, r0);
+        stage(Xp + (buf ^ 1) * 3 * PLANE);       // the next tile (its buffer's last readers finished before the previous barrier)
+        fetch(r0 + 2 * FD_ROWS);
+#pragma unroll
+        for (int i = 1; i < RTW; ++i) row_tile(P, rp * RTW + i, r0);
+        __syncthreads();
+    }
+}
+
+template <int K, int SPW, int RP>
+static int launch_ws_split(const GemmArgs& a, hipStream_t st) {
+    constexpr int FD_ROWS = 64;
+    const size_t lds = (size_t)2 * 3 * FD_ROWS * (K + 8) * 2;
+    auto kern = gemm_ws_split_kernel<K, SPW, RP>;
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)kern, 512, lds) != hipSuccess || n < 1) n = 1;
+        per_cu = n;
+    }
+    long nb = (long)etch_cu_count() * per_cu;
+    long rpb = (a.R + nb - 1) / nb;
+    rpb = (rpb + FD_ROWS - 1) / FD_ROWS * FD_ROWS;
+    nb = (a.R + rpb - 1) / rpb;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(512), lds, st, a, rpb);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
 extern "C" int etch_linear(int R, int K, int O, const float* X, long ldx, const int* row_idx, int grp, int p_in, int p_out,
                            const float* W, long ldw, const float* bias, const float* scale, const float* shift, int act,
                            const float* res, long ldr, int res_mode, float* Y, long ldy, void* stream) {
@@ -322,6 +479,16 @@ extern "C" int etch_linear(int R, int K, int O, const float* X, long ldx, const 
         hipLaunchKernelGGL(linear_k1_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
         ETCH_RETURN_IF_LAUNCH_FAILED();
         return ETCH_OK;
+    }
+    // weight-stationary split kernel: chosen by the layer's shape only (never by R: a scan's result may not depend on its batch neighbours)
+    static const bool no_split = getenv("ETCH_LINEAR_SPLIT") != nullptr && !strcmp(getenv("ETCH_LINEAR_SPLIT"), "0");
+    const bool al = vx && vw && !row_idx && !(ldy & 3) && !((uintptr_t)Y & 15) && (!res || (!(ldr & 3) && !((uintptr_t)res & 15)));
+    if (!no_split && al) {
+#define WS_CASE(KK, OO, SPW, RP) if (K == KK && O == OO) return launch_ws_split<KK, SPW, RP>(a, st);
+        WS_CASE(32, 32, 1, 4) WS_CASE(32, 64, 1, 2) WS_CASE(32, 128, 1, 1)
+        WS_CASE(64, 64, 1, 2) WS_CASE(64, 128, 1, 1) WS_CASE(64, 192, 3, 2) WS_CASE(64, 256, 2, 1)
+        WS_CASE(128, 128, 1, 1) WS_CASE(128, 256, 2, 1) WS_CASE(128, 384, 3, 1)
+#undef WS_CASE
     }
     static const bool no_wres = getenv("ETCH_GEMM_NO_WRES") != nullptr;   // diagnostics: force the tiled kernel
     if (!no_wres && vx && vw && R >= 8192 && O <= 16) {   // weight-resident streaming kernel: narrow outputs only (measured)

@@ -17,7 +17,10 @@ def rel_err(a, b):
 
 
 @pytest.mark.parametrize("R,K,O", [(1000, 64, 64), (777, 128, 86), (64, 32, 16), (5000, 131, 128), (300, 3, 35), (129, 67, 128),
-                                   (2048, 512, 512), (100, 1, 32)])
+                                   (2048, 512, 512), (100, 1, 32),
+                                   # the weight-stationary split kernel's shapes (gemm_ws_split_kernel): ragged row blocks, one row, every (SPW, RP)
+                                   (3000, 128, 128), (500, 128, 384), (777, 32, 32), (1000, 64, 192), (130, 32, 64), (4097, 64, 256), (900, 128, 256),
+                                   (1, 64, 128), (20000, 32, 128)])
 def test_linear_epilogues(R, K, O):
     from etch_amd import ops
     rng = np.random.default_rng(R + K)
