@@ -595,7 +595,7 @@ def main():
                        "algorithmic_gflop_per_launch": round(d["flops"] / d["calls"] / 1e9, 3),
                        "share_of_step": round(d["ms"] / tot_ms, 3),
                        "arithmetic": "fp32 throughout, priced against the fp32 matrix peak; dense products whose operands are reused (inter conv step 2, intra conv, "
-                                     "q/k/v + head_combine, linear_relu_dot) run as exact 3 x bf16 operand splits with six fp32-accumulated cross products on the "
+                                     "q/k/v + head_combine, linear_relu_dot, small-weight Linear layers) run as exact 3 x bf16 operand splits with six fp32-accumulated cross products on the "
                                      "bf16 matrix cores -- the fp32 MFMA's error against fp64 (profiles/r03_bf16x3_split.txt); ETCH_*_SPLIT=0 selects the fp32 MFMA"}
     if longest != kern:
         out["roofline"]["longest_kernel"] = {"kernel": longest, "ms": round(fam[longest]["ms"], 3), "note": "one workgroup per scan: latency-bound"}
