@@ -286,7 +286,8 @@ class GT_network_equiv(nn.Module):
         if not hasattr(self, "_head_streams"):
             # the nets are long chains of small kernels (the critical path of this phase), the direction head on the current
             # stream is a few chip-wide kernels: high-priority queues let the chains go first whenever they have work
-            self._head_streams = (torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=-1))
+            prio = int(os.environ.get("ETCH_HEAD_STREAM_PRIORITY", "-1"))
+            self._head_streams = (torch.cuda.Stream(priority=prio), torch.cuda.Stream(priority=prio))
         return self._head_streams
 
     def _forward(self, hitpts, pred_items, direction_mode, B, N):
