@@ -57,6 +57,21 @@ __device__ __forceinline__ void split3_pack8(const float4 v0, const float4 v1, b
 }
 
 // waves per SIMD the BX instantiations are compiled for: the 32 -> 32 channel kernel fits four workgroups per CU in LDS (5.30 -> 5.09 ms with 128 registers)
+// W-fragment look-ahead of the BX step 2 (output widths >= 64: an even number of o-tile batches per chunk): the next batch's six fragments are
+// requested before the current batch is multiplied, through inline-asm loads + counted waits (plain loads are sunk in front of their MFMAs; fully
+// unrolled forms cost 100+ registers).  Two register sets alternate (even / odd batch); the chunk loop stays rolled and issues unconditionally
+// (the last chunk re-requests its own first batch: a conditional asm load would turn a set into a phi of the asm's output and its old value, and
+// the merging copy reads the register before the load lands), the one set still in flight after the loop is drained with the set as operand.
+// Step 2 issues no other vector-memory instruction, so the counts are exact; older loads in flight only make a wait stricter.
+__device__ __forceinline__ void bx_wload(f32x4& dst, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p)); }
+template <int N> __device__ __forceinline__ void bx_wwait6(f32x4 (&v)[2][3]) {
+    asm volatile("s_waitcnt vmcnt(%6)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[1][2]) : "n"(N));
+}
+// on for the 64-channel-and-wider inputs (6.55 -> 6.22 ms at 64 -> 64: the look-ahead's 48 registers fit beside two workgroups per CU); off at 32 input
+// channels (4.90 -> 5.32 ms at 32 -> 64: the third workgroup per CU it costs was hiding more latency than the look-ahead does)
+#ifndef INTER_BX_RING
+#define INTER_BX_RING(CIN, COUT) ((CIN) >= 64)
+#endif
 #ifndef INTER_BX_WPE
 #define INTER_BX_WPE(CIN, COUT) ((CIN) <= 32 && (COUT) <= 32 ? 4 : 2)
 #endif
@@ -250,6 +265,38 @@ __global__ void __launch_bounds__(256, BX ? INTER_BX_WPE(CIN, COUT) : 2) inter_s
                 // ---------------- step 2 on the bf16 matrix cores: chunk t = 32 kappas, K split over the 4 waves; per chunk and o tile six
                 // v_mfma_f32_16x16x32_bf16 (smallest cross products first), term-major so that consecutive MFMAs are independent
                 const bf16x8* Wq = reinterpret_cast<const bf16x8*>(Wp);
+                if constexpr (INTER_BX_RING(CIN, COUT) && MT2 >= 4 && (MT2 / 2) % 2 == 0) {
+                    constexpr int NM = MT2 / 2;                  // o-tile batches (of two tiles) per chunk: even
+                    constexpr int NTW = KH / 32 / 4;             // chunks per wave
+                    f32x4 ra[2][2][3];                           // [set][o tile of the batch][plane]
+                    const int tg0 = (cc * HALVES + h) * (KH / 32) + wave;
+                    auto issue_w = [&](int c, int m, f32x4 (&dst)[2][3]) {
+                        const size_t base = ((size_t)(tg0 + 4 * c) * MT2 + 2 * m) * 3 * 64 + lane;
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl) bx_wload(dst[mt][pl], Wq + base + (mt * 3 + pl) * 64);
+                    };
+                    issue_w(0, 0, ra[0]);
+#pragma unroll 1
+                    for (int c = 0; c < NTW; ++c) {
+                        const float* xr = &X1s[fr * S + (wave + 4 * c) * 32 + fg * 8];
+                        bf16x8 bq[3];
+                        split3_pack8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4), bq[0], bq[1], bq[2]);
+#pragma unroll
+                        for (int m = 0; m < NM; ++m) {
+                            // next batch: (c, m + 1), or the first of the next chunk (after the last chunk: its own first again)
+                            if (m + 1 < NM) issue_w(c, m + 1, ra[(m + 1) & 1]);
+                            else issue_w(c + 1 < NTW ? c + 1 : c, 0, ra[0]);
+                            bx_wwait6<6>(ra[m & 1]);             // behind this batch's six loads: the six just requested
+                            f32x4 (&ac)[2][3] = ra[m & 1];
+#define BX_TERM(PA, PB) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) y[2 * m + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ac[mt][PA]), bq[PB], y[2 * m + mt], 0, 0, 0);
+                            BX_TERM(2, 0) BX_TERM(0, 2) BX_TERM(1, 1) BX_TERM(1, 0) BX_TERM(0, 1) BX_TERM(0, 0)
+#undef BX_TERM
+                        }
+                    }
+                    bx_wwait6<0>(ra[0]);                         // the redundant last request
+                } else
 #pragma unroll 1
                 for (int t = wave; t < KH / 32; t += 4) {
                     const float* xr = &X1s[fr * S + t * 32 + fg * 8];
