@@ -454,6 +454,10 @@ static int launch_ws_split(const GemmArgs& a, hipStream_t st) {
     }
     long nb = (long)etch_cu_count() * per_cu;
     long rpb = (a.R + nb - 1) / nb;
+#ifndef GEMM_WS_MIN_TILES
+#define GEMM_WS_MIN_TILES 4       // a workgroup pays for splitting W once: at least this many 64-row tiles each
+#endif
+    if (rpb < GEMM_WS_MIN_TILES * FD_ROWS) rpb = GEMM_WS_MIN_TILES * FD_ROWS;
     rpb = (rpb + FD_ROWS - 1) / FD_ROWS * FD_ROWS;
     nb = (a.R + rpb - 1) / rpb;
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(512), lds, st, a, rpb);
