@@ -199,3 +199,24 @@ def test_fused_block_vs_reference_golden_falls_back_for_unbuilt_widths(golden):
     with torch.no_grad():
         out = P.run_blocks([block], [d("p"), d("x"), d("o")])[1]
     assert rel_err(out.cpu().numpy(), g["block_out"]) < RTOL
+
+
+def test_whole_model_on_the_fp32_mfma_kernels_vs_reference_golden(tmp_path, golden, monkeypatch):
+    """The switches of the split-operand kernels (ETCH_INTER_SPLIT / ETCH_INTRA_SPLIT / ETCH_LRD_SPLIT = 0, here through the module flags they set):
+    the model built and run on the fp32-MFMA kernels meets the same fixture of the reference's Python, and the two arithmetic paths agree with
+    each other far inside the parity tolerance (they are the same fp32 sums in different orders)."""
+    from etch_amd import ops
+    g = golden("model_n1024.npz")
+    pts = torch.from_numpy(g["points"]).cuda()
+    items = ["confidence", "direction", "magnitude"]
+    with torch.no_grad():
+        split, _ = build_model(tmp_path, int(g["seed"]))(pts, items, "standard_vector")
+    for flag in ("INTER_SPLIT", "INTRA_SPLIT", "LRD_SPLIT"):
+        monkeypatch.setattr(ops, flag, False)
+    m = build_model(tmp_path, int(g["seed"]))             # a fresh model: the weight operands are cached per parameter version
+    with torch.no_grad():
+        f32, _ = m(pts, items, "standard_vector")
+    for k in ("part_labels", "confidences", "magnitude"):
+        assert rel_err(f32[k].cpu().numpy(), g[k]) < RTOL, k
+        assert rel_err(f32[k].cpu().numpy(), split[k].cpu().numpy()) < 2e-5, k
+    assert rel_err(m.last_anc_w.cpu().numpy(), g["anc_w"]) < RTOL
