@@ -128,7 +128,6 @@ __global__ void __launch_bounds__(THREADS) fps_kernel(int lds_xyz, const float* 
             else { x1 = src[old * ps]; y1 = src[cs + old * ps]; z1 = src[2 * cs + old * ps]; }
         }
         unsigned long long best = 0ull;
-        float bx = 0.f, by = 0.f, bz = 0.f;
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             if (valid & (1u << i)) {
@@ -149,19 +148,30 @@ __global__ void __launch_bounds__(THREADS) fps_kernel(int lds_xyz, const float* 
                 const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | t;
                 const bool gt = key > best;
                 best = gt ? key : best;
-                if (CARRY) { bx = gt ? x : bx; by = gt ? y : by; bz = gt ? z : bz; }
             }
         }
         const unsigned long long wbest = etch_wave_max_u64_dpp(best);
         // one barrier per round: partial maxima are double-buffered and every wave reduces them redundantly
         Cand* rb = red + (j & 1) * (THREADS / 64);
         if (CARRY) {
-            // keys are unique per point, so exactly one lane holds the wave's best (or none when the wave has no candidate)
+            // keys are unique per point, so exactly one lane holds the wave's best (or none when the wave has no candidate).  Its coordinates are
+            // fetched from that lane's registers AFTER the scan: the key names the point (k = slot * THREADS + thread), the slot is wave-uniform,
+            // so one scalar-selected v_readlane per coordinate replaces three selects per point and round (60 of ~300 VALU ops per lane at 20 000 points)
             const unsigned long long hit = __ballot(best == wbest && wbest != 0ull);
             const int srcl = hit ? (int)__builtin_ctzll(hit) : 0;
-            const float wx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bx), srcl));
-            const float wy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, by), srcl));
-            const float wz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bz), srcl));
+            float wx = 0.f, wy = 0.f, wz = 0.f;
+            if (REGS && hit) {                                 // wave-uniform
+                const unsigned t = 0xFFFFFFFFu - (unsigned)(wbest & 0xFFFFFFFFull);
+                const unsigned kl = bs_bits ? (__brev(t >> 16) >> (32 - bs_bits)) : 0u;
+                const int slot = (int)((t & 0xFFFFu) * (unsigned)bs + kl) / THREADS;
+#pragma unroll
+                for (int i = 0; i < PPT; ++i)
+                    if (slot == i) {                           // wave-uniform: a scalar branch
+                        wx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, px[i]), srcl));
+                        wy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, py[i]), srcl));
+                        wz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pz[i]), srcl));
+                    }
+            }
             if (lane == 0) { rb[wave].key = wbest; rb[wave].x = wx; rb[wave].y = wy; rb[wave].z = wz; }
         } else if (lane == 0) rb[wave].key = wbest;
         __syncthreads();
