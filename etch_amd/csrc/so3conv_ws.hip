@@ -36,9 +36,6 @@ __device__ __forceinline__ void ws_split3_pack4(const float4 v4, uint2& hi, uint
     lo = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
 }
 
-#ifndef WS_ABL
-#define WS_ABL 0       // timing experiments only (wrong results): 1 no MFMAs, 2 no LDS operand reads, 4 no output loop, 8 no staging of the next pair
-#endif
 template <int C>
 struct WsShape {
     static constexpr int NT = C * 8;              // threads: 4 (C = 32) or 8 (C = 64) waves
