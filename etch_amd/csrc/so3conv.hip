@@ -13,6 +13,7 @@
 //                        InstanceNorm2d(affine=False, eps=1e-5) + leaky_relu(0.01) (+ residual branch)
 //                        (/root/reference/src/models/so3conv.py:36-44,96-99,178-182).
 #include "common.h"
+#include "split_bf16.h"
 #include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -35,27 +36,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // beside the VALU instead of on it.  W comes pre-split from the host (ops.inter_weight_split); X1 stays fp32 in LDS and is split by the wave that
 // consumes it (each X1 element is read by exactly one wave), in the shadow of that wave's bf16 MFMAs.  Step 1 stays on the fp32 MFMA: its
 // weights are generated per use, a split per use would cost more VALU work than the matrix cores save.
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-// 8 consecutive fp32 values -> 3 planes x 8 bf16; exact: v = hi + mid + lo (truncation split)
-__device__ __forceinline__ void split3_pack8(const float4 v0, const float4 v1, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    unsigned h[8], m[8], l[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        h[i] = __float_as_uint(v[i]);
-        const float r = v[i] - __uint_as_float(h[i] & 0xffff0000u);
-        m[i] = __float_as_uint(r);
-        l[i] = __float_as_uint(r - __uint_as_float(m[i] & 0xffff0000u));
-    }
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    // v_perm_b32: bytes 2, 3 of the even element below bytes 2, 3 of the odd one
-#define ETCH_PK(a) (u32x4){__builtin_amdgcn_perm(a[1], a[0], 0x07060302u), __builtin_amdgcn_perm(a[3], a[2], 0x07060302u), \
-                           __builtin_amdgcn_perm(a[5], a[4], 0x07060302u), __builtin_amdgcn_perm(a[7], a[6], 0x07060302u)}
-    const u32x4 ph = ETCH_PK(h), pm = ETCH_PK(m), pl = ETCH_PK(l);
-#undef ETCH_PK
-    hi = __builtin_bit_cast(bf16x8, ph); mid = __builtin_bit_cast(bf16x8, pm); lo = __builtin_bit_cast(bf16x8, pl);
-}
-
 // waves per SIMD the BX instantiations are compiled for: the 32 -> 32 channel kernel fits four workgroups per CU in LDS (5.30 -> 5.09 ms with 128 registers)
 // W-fragment look-ahead of the BX step 2 (output widths >= 64: an even number of o-tile batches per chunk): the next batch's six fragments are
 // requested before the current batch is multiplied, through inline-asm loads + counted waits (plain loads are sunk in front of their MFMAs; fully
@@ -898,7 +878,8 @@ __global__ void __launch_bounds__(1024) instnorm_from_partials_kernel(int nparts
 __global__ void __launch_bounds__(256) instnorm_act_add_kernel(long n4, int rows, int C, const float* __restrict__ x1,
                                                                const float* __restrict__ m1, const float* __restrict__ r1,
                                                                const float* __restrict__ x2, const float* __restrict__ m2,
-                                                               const float* __restrict__ r2, float* __restrict__ out) {
+                                                               const float* __restrict__ r2, float* __restrict__ out,
+                                                               unsigned short* __restrict__ planes) {
     const long per_batch4 = (long)rows * C / 4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int b = (int)(i / per_batch4);
@@ -918,6 +899,14 @@ __global__ void __launch_bounds__(256) instnorm_act_add_kernel(long n4, int rows
             for (int k = 0; k < 4; ++k) o[k] += o2[k] > 0.f ? o2[k] : 0.01f * o2[k];
         }
         reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+        if (planes) {
+            // the same values as three bf16 planes [row][plane][C] (exact split): the operand format of etch_inter_so3conv_planes, written by the
+            // producer once instead of being split by every gather of the row
+            uint2 hi, mid, lo;
+            split3_pack4(make_float4(o[0], o[1], o[2], o[3]), hi, mid, lo);
+            unsigned short* pr = planes + (size_t)((i * 4) / C) * 3 * C + c;
+            *reinterpret_cast<uint2*>(pr) = hi; *reinterpret_cast<uint2*>(pr + C) = mid; *reinterpret_cast<uint2*>(pr + 2 * C) = lo;
+        }
     }
 }
 
@@ -1094,17 +1083,22 @@ int etch_instnorm_from_partials(int b, int nparts, int C, int count, const doubl
 
 int etch_instnorm_stats_workspace_bytes(int b, int C) { return (int)((size_t)IN_CHUNKS * b * 2 * C * sizeof(double)); }
 
-int etch_instnorm_act_add(int b, int rows, int C, const float* x1, const float* m1, const float* r1, const float* x2,
-                          const float* m2, const float* r2, float* out, void* stream) {
+int etch_instnorm_act_add_planes(int b, int rows, int C, const float* x1, const float* m1, const float* r1, const float* x2,
+                                 const float* m2, const float* r2, float* out, void* planes, void* stream) {
     if (b <= 0 || rows <= 0) return ETCH_OK;
-    if (C & 3) return ETCH_EUNSUPPORTED;
+    if ((C & 3) || ((uintptr_t)planes & 7)) return ETCH_EUNSUPPORTED;
     const long n4 = (long)b * rows * C / 4;
     long blocks = (n4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(instnorm_act_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n4, rows, C, x1, m1, r1, x2,
-                       m2, r2, out);
+                       m2, r2, out, reinterpret_cast<unsigned short*>(planes));
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
+}
+
+int etch_instnorm_act_add(int b, int rows, int C, const float* x1, const float* m1, const float* r1, const float* x2,
+                          const float* m2, const float* r2, float* out, void* stream) {
+    return etch_instnorm_act_add_planes(b, rows, C, x1, m1, r1, x2, m2, r2, out, nullptr, stream);
 }
 
 }  // extern "C"

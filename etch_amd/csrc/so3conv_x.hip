@@ -1,0 +1,489 @@
+// Inter SO(3) conv with BOTH contractions on the bf16 matrix cores (round 4).
+//
+//   etch_inter_so3conv_planes   replaces inter_so3conv_grouping_anchor + inter_so3conv_feat_grouping + BasicSO3Conv
+//                               (/root/reference/external/vgtk/vgtk/so3conv/functional.py:286-324, :61-67, modules.py:33-39)
+//   etch_split3_planes          fp32 rows -> the three bf16 planes the kernel gathers (the encoder's producers emit them directly:
+//                               etch_instnorm_act_add_planes in so3conv.hip)
+//
+// inter_so3conv_kernel (so3conv.hip) runs step 1, X1[k, c] = sum_n w[a, k, n] F[idx_n, a, c], on the fp32 MFMA: that instruction shares the fp32
+// vector datapath with the VALU, so the five VALU operations that generate every kernel weight are paid on top of the matrix work, and it issues at
+// 1/16 of the bf16 rate.  Here every fp32 operand is split EXACTLY into three bf16 values (hi / mid / lo mantissa bytes) and the six largest cross
+// products are accumulated in fp32 on v_mfma_f32_16x16x32_bf16 -- the arithmetic of the round-3 step 2, now for step 1 as well:
+//   * the gathered rows F are REUSED (every source row is a neighbour of ~nn output points): their producer writes the three planes once
+//     ([b][q][a][plane][c] bf16, 1.5 x the fp32 bytes), so no split work for F is left in this kernel;
+//   * the rows of one (anchor, 32-neighbour chunk) go global -> LDS by direct loads (global_load_lds_dwordx4: each lane fetches 16 bytes of a
+//     neighbour's row, no register round trip), one 1-KiB tile [32 rows][16 channels] per instruction and (plane, channel tile), laid out so that
+//     ds_read_b64_tr_b16 returns MFMA B fragments (K = neighbour) conflict-free: rows 4g .. 4g+3 and 16+4g .. 16+4g+3 to lane group g;
+//   * the kernel weights w = relu(a_n + b_k + G_n . r_k) are generated per use (5 VALU operations) and split (5.5): 10.5 VALU operations per
+//     weight, amortised over the CIN / 16 channel tiles x 6 terms they feed -- 7 (CIN = 32) / 3.5 (CIN = 64) VALU instructions per MFMA, beside
+//     the matrix pipe instead of on it.
+// Step 2 (Y = W X1 on the bf16 cores), the epilogue and the InstanceNorm partial sums are those of inter_so3conv_kernel<.., BX = true>.
+// Channel order: column r of channel tile ct is channel 16 ct + r, so the contraction of step 2 runs in W's natural column order
+// (ops.inter_weight_split(natural=True)).
+#include "common.h"
+#include "split_bf16.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define NA 60
+#define KS 24
+
+typedef const void __attribute__((address_space(1)))* x_gptr;
+typedef void __attribute__((address_space(3)))* x_lptr;
+
+__device__ __forceinline__ bf16x4 x_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3)))*)p);
+}
+__device__ __forceinline__ void x_wload(f32x4& dst, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p)); }
+// the same with a wave-uniform base (SGPR pair) + 32-bit lane offset + k KiB immediate
+__device__ __forceinline__ void x_wload_s(f32x4& dst, unsigned voff, const void* sbase, int k) {
+    if (k == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase));
+    else if (k == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(dst) : "v"(voff), "s"(sbase));
+    else asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(dst) : "v"(voff), "s"(sbase));
+}
+template <int N> __device__ __forceinline__ void x_wwait6(f32x4 (&v)[2][3]) {
+    asm volatile("s_waitcnt vmcnt(%6)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[1][2]) : "n"(N));
+}
+
+// step 2, Y[o, col] += sum_kappa W[o, kappa] X1[col][kappa], for the two channel halves of the X1 tile: chunk of 32 kappas -> wave (chunk & 3); six bf16
+// MFMAs per (chunk, o tile), smallest cross products first, term-major so that consecutive MFMAs are independent (so3conv.hip, BX step 2).  The W
+// fragments (L2) travel one batch (two o tiles x three planes) ahead of the matrix cores through inline-asm loads + counted waits, across chunks AND
+// across the two halves; everything is unrolled, so the two register sets are static.  vmcnt counts in order for loads; older stores / LDS-direct
+// loads still in flight only make a wait stricter.  `between()` = what the workgroup does between the halves (barrier, parked half -> LDS, barrier);
+// the first batch is requested by the caller BEFORE the barrier that opens step 2 (x_step2_first), so its latency hides behind the barrier.
+template <int CIN, int COUT, int NCT>       // NCT column tiles of 16 anchors each
+struct XStep2 {
+    static constexpr int MT2 = COUT / 16, KH = CIN * KS / 2, S = KH + 40;
+    static constexpr int MB = (CIN >= 64 && NCT == 1) ? 2 : 1;    // o tiles per batch (registers: 2 sets x MB x 3 planes x 4)
+    static constexpr int NM = MT2 / MB;             // batches per chunk
+    static constexpr int NTW = KH / 32 / 4;         // chunks per wave and half
+    static constexpr int NBH = NTW * NM;            // batches per half
+    f32x4 ra[2][MB][3];
+    // addresses: wave-uniform batch base in SGPRs + lane * 16 + immediate (fully unrolled 64-bit vector addresses would all be hoisted out of the
+    // group loop: 12 registers per batch)
+    __device__ __forceinline__ void issue(int i, const bf16x8* __restrict__ Wq, int wave, int lane) {
+        const int h = i / NBH, r = i % NBH, c = r / NM, m = r % NM;
+        const char* b0 = reinterpret_cast<const char*>(Wq) + ((size_t)(h * (KH / 32) + wave + 4 * c) * MT2 + MB * m) * 3 * 1024;
+        const unsigned vo = (unsigned)lane * 16u;
+#pragma unroll
+        for (int mt = 0; mt < MB; ++mt)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) x_wload_s(ra[i & 1][mt][pl], vo, b0 + mt * 3 * 1024, pl);
+    }
+    template <int N> __device__ __forceinline__ void wait(f32x4 (&v)[MB][3]) {
+        if constexpr (MB == 2) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[1][2]) : "n"(N));
+        else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]) : "n"(N));
+    }
+    template <int H>
+    __device__ __forceinline__ void half(f32x4 (&y)[NCT][COUT / 16], const float* X1s, const bf16x8* __restrict__ Wq, int wave, int lane) {
+        const int fr = lane & 15, fg = lane >> 4;
+        bf16x8 bq[NCT][3];
+#pragma unroll
+        for (int r = 0; r < NBH; ++r) {
+            const int i = H * NBH + r, c = r / NM, m = r % NM;
+            if (m == 0) {
+                asm volatile("" ::: "memory");             // keeps the X1 reads (and their splits) of later chunks from being hoisted: 12 registers per chunk
+#pragma unroll
+                for (int nc = 0; nc < NCT; ++nc) {
+                    const float* xr = &X1s[(16 * nc + fr) * S + (wave + 4 * c) * 32 + fg * 8];
+                    split3_pack8p(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4), bq[nc][0], bq[nc][1], bq[nc][2]);
+                }
+            }
+            if (i + 1 < 2 * NBH) { issue(i + 1, Wq, wave, lane); wait<3 * MB>(ra[i & 1]); }
+            else wait<0>(ra[i & 1]);
+            f32x4 (&ac)[MB][3] = ra[i & 1];
+#define X_TERM(PA, PB) _Pragma("unroll") for (int nc = 0; nc < NCT; ++nc) _Pragma("unroll") for (int mt = 0; mt < MB; ++mt) \
+    y[nc][MB * m + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ac[mt][PA]), bq[nc][PB], y[nc][MB * m + mt], 0, 0, 0);
+            X_TERM(2, 0) X_TERM(0, 2) X_TERM(1, 1) X_TERM(1, 0) X_TERM(0, 1) X_TERM(0, 0)
+#undef X_TERM
+        }
+    }
+};
+
+// AG = anchors per step-2 pass (16 or 32): every W fragment streamed from L2 feeds AG / 16 column tiles, so the L2 -> CU weight stream -- the
+// largest consumer of the CU's vector-memory path in this kernel -- is 64 / AG passes x |W| per output point.  The four K shares of a pass meet
+// in an LDS table that ALIASES the X1 tile (dead by then): LDS = X1 tile + staging, which is what decides the workgroups per CU.
+#ifndef INTER_X_AG
+#define INTER_X_AG(CIN, COUT) 32
+#endif
+#ifndef INTER_X_NBUF
+#define INTER_X_NBUF(CIN, COUT) 1
+#endif
+#ifndef INTER_X_WPE
+#define INTER_X_WPE(CIN) ((CIN) <= 32 ? 2 : 1)
+#endif
+// NBUF = staging tiles per wave: 1 = the rows of step s + 1 are requested once the fragments of step s are in registers; 2 = those of step s + 2
+// (same tile, two steps ahead: a counted wait leaves the NDI LDS-direct loads of step s + 1 in flight -- they complete in order among themselves,
+// and plain loads / stores in between can only make the wait stricter)
+template <int CIN, int COUT, int NCH, int AG, int NBUF>       // NCH = nn / 32 neighbour chunks
+__global__ void __launch_bounds__(256, INTER_X_WPE(CIN)) inter_so3conv_x_kernel(
+    int p1, int p2, float inv_sigma, const float* __restrict__ xyz, const float* __restrict__ new_xyz, const int* __restrict__ ball_idx,
+    const unsigned short* __restrict__ Fq, const float* __restrict__ rk, const bf16x8* __restrict__ Wq, const float* __restrict__ bias,
+    float* __restrict__ out, const int* __restrict__ order, double* __restrict__ stat_part) {
+    constexpr int NN = 32 * NCH;
+    constexpr int NJ = AG / 4;             // anchors per wave and pass
+    constexpr int NG = 64 / AG;            // passes per output point
+    constexpr int NCT = AG / 16;           // column tiles of step 2
+    constexpr int MT1 = CIN / 16;          // channel tiles of step 1
+    constexpr int MT2 = COUT / 16;         // output tiles of step 2
+    constexpr int MTH = MT1 / 2;           // channel tiles per X1 half (the second half waits in registers)
+    constexpr int KH = CIN * KS / 2;       // contraction length of step 2 per half
+    constexpr int S = KH + 40;             // X1s row stride (floats): S/4 = 10 (mod 16) keeps the ds_read_b128 B-fragment reads conflict-free
+    constexpr int PS = COUT + 4;
+    static_assert(4 * PS <= S, "the partial table must fit the X1 tile it aliases");
+    constexpr int ROWB = 3 * CIN * 2;      // bytes of one (q, a) row: three planes of CIN bf16
+    constexpr int PPR = CIN / 8;           // 16-byte pieces per plane row (a row of one plane = CIN bf16)
+    constexpr int RPI = 64 / PPR;          // rows one LDS-direct load instruction covers: its lanes = RPI rows x PPR pieces, row-contiguous in memory
+    constexpr int NRB = 32 / RPI;          // row blocks per chunk
+    constexpr int PLB = 32 * CIN * 2;      // bytes of one plane of a chunk in LDS: [32 rows][CIN bf16], row-major, tile segments swizzled (below)
+    constexpr int STG = 3 * PLB;           // bytes of one staging tile
+    constexpr int NDI = 3 * NRB;           // LDS-direct load instructions per chunk-step
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X1s = smem;                     // [AG][S]
+    float* part = smem;                    // [4 waves][AG cols][PS]: aliases X1s between the last product of a pass and the next pass
+    float4* nbt = reinterpret_cast<float4*>(smem + AG * S);            // [NN]  (2 g / sigma, 1 - |g|^2 / sigma)
+    unsigned* noffs = reinterpret_cast<unsigned*>(nbt + NN);            // [NN]  byte offset of the neighbour's anchor-0 row
+    char* stage = reinterpret_cast<char*>(noffs + NN);                  // [4 waves][NBUF][STG]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int b = blockIdx.y;
+    int p = blockIdx.x;
+    if (order) {
+        // spatially ordered schedule (see inter_so3conv_kernel): XCD x walks the x-th contiguous eighth of the scan's space-filling curve
+        const int per = gridDim.x >> 3;
+        const int slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (slot >= p2) return;
+        p = order[(size_t)b * p2 + slot];
+    }
+    if (tid < NN) {
+        const int n = tid;
+        int q = ball_idx[((size_t)b * p2 + p) * NN + n];
+        const int qq = q < 0 ? 0 : q;
+        const float* X = xyz + (size_t)b * 3 * p1;
+        const float x = X[qq] - new_xyz[((size_t)b * 3 + 0) * p2 + p], y = X[p1 + qq] - new_xyz[((size_t)b * 3 + 1) * p2 + p],
+                    z = X[2 * p1 + qq] - new_xyz[((size_t)b * 3 + 2) * p2 + p];
+        nbt[n] = make_float4(2.0f * inv_sigma * x, 2.0f * inv_sigma * y, 2.0f * inv_sigma * z,
+                             q < 0 ? -1e30f : 1.0f - (x * x + y * y + z * z) * inv_sigma);
+        noffs[n] = (unsigned)qq * (unsigned)(NA * ROWB);
+    }
+    __syncthreads();
+    // Staging image of one plane of a chunk: row r (neighbour) at r * CIN * 2, its 32-byte segment of channel tile ct at slot (ct + sh(r)) mod MT1 with
+    // sh(r) = (r >> 2) & 1 (CIN = 32) / (r >> 1) & 3 (CIN = 64): the eight rows two lane groups of a ds_read_b64_tr_b16 touch together (4g .. 4g+3 for
+    // g = 0, 1) then cover all 64 banks once.  The load side: lane -> (row rl = lane / PPR of its row block, slot s = lane % PPR); the lanes of a row
+    // fetch the row's pieces in swizzled order -- still one contiguous CIN * 2 bytes of memory per PPR consecutive lanes.
+    const int rl = lane / PPR, sl = lane % PPR;
+    const int shl = CIN == 32 ? (rl >> 2) & 1 : (rl >> 1) & 3;
+    const unsigned pieceoff = (unsigned)((2 * (((sl >> 1) - shl) & (MT1 - 1)) + (sl & 1)) * 16);
+    unsigned roff[NCH][NRB];
+#pragma unroll
+    for (int t = 0; t < NCH; ++t)
+#pragma unroll
+#ifdef X_ABL_SAMEROW
+        for (int rb = 0; rb < NRB; ++rb) roff[t][rb] = 0 * noffs[32 * t + RPI * rb + rl] + pieceoff;     // timing experiment: every gather hits one row (L1)
+#elif defined(X_ABL_SEQROW)
+        for (int rb = 0; rb < NRB; ++rb) roff[t][rb] = (unsigned)((32 * t + RPI * rb + rl) * NA * ROWB) + ((unsigned)p & 1023u) * 8u * NA * ROWB + pieceoff + 0 * noffs[0];  // rows p*8 .. : L2-resident, distinct per workgroup
+#else
+        for (int rb = 0; rb < NRB; ++rb) roff[t][rb] = noffs[32 * t + RPI * rb + rl] + pieceoff;
+#endif
+    const char* Fb = reinterpret_cast<const char*>(Fq) + (size_t)b * p1 * NA * ROWB;
+    char* stg0 = stage + wave * NBUF * STG;
+    // the read side: lane (fr, fg) supplies the address of row 4 fg + (fr >> 2) (second read: + 16 rows), 8-byte piece fr & 3 of the tile segment
+    unsigned toff[MT1];
+    {
+        const int r1 = 4 * fg + (fr >> 2);
+        const int shr = CIN == 32 ? (r1 >> 2) & 1 : (r1 >> 1) & 3;
+#pragma unroll
+        for (int ct = 0; ct < MT1; ++ct) toff[ct] = (unsigned)(r1 * CIN * 2 + 32 * ((ct + shr) & (MT1 - 1)) + 8 * (fr & 3));
+    }
+    float* outp = out + ((size_t)b * p2 + p) * NA * COUT;
+    const bool k1ok = fr < 8;
+    const int k1 = k1ok ? 16 + fr : 0;
+
+    // The kernel weights of chunk-step s + 1 are generated (VALU) in the same basic block as the matrix products of step s: they depend only on the
+    // neighbour table and the anchor's kernel points, not on the gathered rows, so one wave keeps both pipes busy.  Two static sets of everything
+    // that crosses a step: weight fragments (step parity), kernel points (anchor parity; requested two anchors ahead).
+    float rkn[2][6];
+    auto issue_rk = [&](int a, float (&dst)[6]) {
+        a = a < NA ? a : NA - 1;
+        const float* rka = rk + (size_t)a * KS * 3;
+        dst[0] = rka[fr * 3]; dst[1] = rka[fr * 3 + 1]; dst[2] = rka[fr * 3 + 2];
+        dst[3] = rka[k1 * 3]; dst[4] = rka[k1 * 3 + 1]; dst[5] = rka[k1 * 3 + 2];
+    };
+    auto issue_rows = [&](int a, int t, char* stg) {   // the three planes of chunk t of anchor a: global -> LDS, 16 bytes per lane and instruction
+        a = a < NA ? a : NA - 1;
+        const char* src = Fb + (size_t)a * ROWB;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#ifdef X_ABL_NODMA
+                asm volatile("" :: "v"(src + roff[t][rb]));
+#else
+                __builtin_amdgcn_global_load_lds((x_gptr)(src + roff[t][rb] + pl * CIN * 2), (x_lptr)(stg + pl * PLB + rb * 1024), 16, 0, 0);
+#endif
+    };
+    // Two weights per instruction: the pair (kernel point fr, kernel point 16 + fr) of one neighbour -- v_pk_fma_f32 with the neighbour's term
+    // broadcast by op_sel; the last FMA carries the clamp modifier: relu for free (the upper bound 1 is the weight's mathematical maximum,
+    // 1 - |g - r|^2 / sigma <= 1: it only removes rounding excess of the expanded form).  2 instead of 5 VALU instructions per weight.
+    // This lane's 8 neighbours of chunk t: K positions 8 fg + e <-> rows 4 fg + e (e < 4), 16 + 4 fg + e - 4.
+    // The generation is cut into 12 phases -- 8 x (one neighbour's pair of weights), 4 x (split + pack of two neighbours into one dword of each of
+    // the six fragments) -- which the step below lays BETWEEN its matrix instructions in program order (the compiler keeps that order; left to
+    // itself it emits all of the VALU work and then all of the MFMAs).
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    struct WGen { f32x2 rx, ry, rz, rb; f32x2 w[8]; float4 g[8]; };
+    constexpr int GLA = 2;                              // neighbour-table reads run GLA phases ahead of their use (LDS latency off the dependent chain)
+    auto gen_read = [&](WGen& G, int t, int e) { G.g[e] = nbt[32 * t + 4 * fg + (e < 4 ? e : 12 + e)]; };
+    auto gen_begin = [&](const float (&rv)[6], WGen& G) {
+        G.rx = (f32x2){rv[0], rv[3]}; G.ry = (f32x2){rv[1], rv[4]}; G.rz = (f32x2){rv[2], rv[5]};
+        G.rb = -(G.rx * G.rx + G.ry * G.ry + G.rz * G.rz) * inv_sigma;
+        G.rb.y = k1ok ? G.rb.y : -1e30f;                             // k >= 24: weight 0
+    };
+    auto gen_weight = [&](WGen& G, int t, int e) {
+        if (e + GLA < 8) gen_read(G, t, e + GLA);
+        const float4 g = G.g[e];
+        f32x2 s = (f32x2){g.w, g.w} + G.rb;
+        s = __builtin_elementwise_fma((f32x2){g.x, g.x}, G.rx, s);
+        s = __builtin_elementwise_fma((f32x2){g.y, g.y}, G.ry, s);
+        const f32x2 gzw = {g.z, g.w};
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] clamp" : "=v"(G.w[e]) : "v"(gzw), "v"(G.rz), "v"(s));
+    };
+    auto gen_pack = [&](const WGen& G, int i, u32x4 (&aw)[2][3]) {       // neighbours 2i, 2i+1 -> dword i of the six fragments (exact split, split_bf16.h)
+        unsigned h[2][2], m[2][2], l[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const f32x2 v = G.w[2 * i + u];
+            h[0][u] = __float_as_uint(v.x); h[1][u] = __float_as_uint(v.y);
+            const f32x2 r = v - (f32x2){__uint_as_float(h[0][u] & 0xffff0000u), __uint_as_float(h[1][u] & 0xffff0000u)};
+            m[0][u] = __float_as_uint(r.x); m[1][u] = __float_as_uint(r.y);
+            const f32x2 q = r - (f32x2){__uint_as_float(m[0][u] & 0xffff0000u), __uint_as_float(m[1][u] & 0xffff0000u)};
+            l[0][u] = __float_as_uint(q.x); l[1][u] = __float_as_uint(q.y);
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            aw[kt][0][i] = __builtin_amdgcn_perm(h[kt][1], h[kt][0], 0x07060302u);
+            aw[kt][1][i] = __builtin_amdgcn_perm(m[kt][1], m[kt][0], 0x07060302u);
+            aw[kt][2][i] = __builtin_amdgcn_perm(l[kt][1], l[kt][0], 0x07060302u);
+        }
+    };
+    auto gen_phase = [&](WGen& G, int t, int ph, u32x4 (&aw)[2][3]) { if (ph < 8) gen_weight(G, t, ph); else gen_pack(G, ph - 8, aw); };
+    // this wave's anchor sequence: q -> anchor (q / NJ) * AG + wave * NJ + q % NJ, q = 0 .. NG * NJ - 1 (values >= 60 are clamped by the loaders)
+    auto anchor_of = [&](int q) { return (q / NJ) * AG + wave * NJ + (q % NJ); };
+    issue_rk(anchor_of(0), rkn[0]);
+    issue_rk(anchor_of(1), rkn[1]);
+    issue_rows(anchor_of(0), 0, stg0);
+    if (NBUF > 1) issue_rows(anchor_of(1 / NCH), 1 % NCH, stg0 + STG);
+    u32x4 aws[2][2][3];                             // [step parity][kernel-point tile][plane]
+    {
+        WGen G;
+        gen_begin(rkn[0], G);
+#pragma unroll
+        for (int e = 0; e < GLA; ++e) gen_read(G, 0, e);
+#pragma unroll
+        for (int ph = 0; ph < 12; ++ph) gen_phase(G, 0, ph, aws[0]);
+    }
+
+    double st_s = 0.0, st_q = 0.0;
+    f32x4 y[NCT][MT2];
+#pragma unroll 1
+    for (int ag = 0; ag < NG; ++ag) {
+        f32x4 keep[NJ][MTH][2];                     // second channel half of the wave's NJ anchors
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int col = wave * NJ + j;
+            const int q = ag * NJ + j;
+            const int a = ag * AG + col;
+            const int a_next = anchor_of(q + 1);                         // this wave's next anchor (>= NA past the end)
+            f32x4 acc[MT1][2];
+#pragma unroll
+            for (int t = 0; t < NCH; ++t) {
+                const int sp = (j * NCH + t) & 1;                        // step parity (NJ NCH steps per pass: consistent across passes)
+                char* stg = stg0 + (NBUF > 1 ? sp * STG : 0);
+                if (NBUF > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDI) : "memory");       // this chunk's rows have landed in LDS (the next step's may be in flight)
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                bf16x8 bf[MT1][3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int ct = 0; ct < MT1; ++ct) {
+                        const bf16x4 lo4 = x_tr16(stg + pl * PLB + toff[ct]), hi4 = x_tr16(stg + pl * PLB + toff[ct] + 16 * CIN * 2);
+                        bf[ct][pl] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                WGen G;                                                  // next step's weights: first neighbour-table reads ride on the same wait
+                const int tn = t + 1 < NCH ? t + 1 : 0;
+#pragma unroll
+                for (int e = 0; e < GLA; ++e) gen_read(G, tn, e);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers: the staging tile may be overwritten
+                // next chunk-step's rows (this wave's next anchor / chunk; across passes too)
+                if (NBUF > 1) {                                          // (past the last anchor: a harmless reload of anchor 59 -- the wait counts stay exact)
+                    const int s2 = q * NCH + t + 2;
+                    issue_rows(anchor_of(s2 / NCH), s2 % NCH, stg);
+                } else if (t + 1 < NCH) issue_rows(a, t + 1, stg);
+                else if (a_next < 64) issue_rows(a_next, 0, stg);
+                // this anchor's kernel points were last used a step ago (the weights of its last chunk): request the anchor after next into their set
+                if (t == NCH - 1) issue_rk(anchor_of(q + 2), rkn[j & 1]);
+                // This step's matrix products with the next step's weights (other parity) generated between them: NMF MFMAs (six terms, smallest first,
+                // term-major: 2 MT1 independent accumulators between dependent ones), 12 generation phases.  Unconditional: the slots 60 .. 63 of the last
+                // wave compute on anchor 59's (clamped) operands and their columns are dropped at the output -- one basic block per step.
+                {
+                    u32x4 (&aw)[2][3] = aws[sp];
+                    u32x4 (&awn)[2][3] = aws[sp ^ 1];
+                    gen_begin(t + 1 < NCH ? rkn[j & 1] : rkn[(j + 1) & 1], G);
+                    constexpr int NMF = 12 * MT1, MPP = NMF / 12;
+                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                    for (int ph = 0; ph < 12; ++ph) {
+                        gen_phase(G, tn, ph, awn);
+#pragma unroll
+                        for (int u = 0; u < MPP; ++u) {
+                            const int mi = ph * MPP + u, term = mi / (2 * MT1), ct = (mi / 2) % MT1, kt = mi % 2;
+#ifndef X_ABL_NOMFMA1
+                            acc[ct][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aw[kt][PA[term]]), bf[ct][PB[term]],
+                                                                                  (t == 0 && term == 0) ? (f32x4){0, 0, 0, 0} : acc[ct][kt], 0, 0, 0);
+#else
+                            asm volatile("" :: "v"(aw[kt][PA[term]]), "v"(bf[ct][PB[term]]));
+                            if (t == 0 && term == 0) acc[ct][kt] = (f32x4){0, 0, 0, 0};
+#endif
+                        }
+                    }
+                }
+            }
+            // anchor end: a lane's 4 accumulator registers are 4 consecutive kernel points of one channel -> one 16-byte LDS store per tile
+            float* xcol = X1s + col * S;
+#pragma unroll
+            for (int mi = 0; mi < MTH; ++mi) {
+                float* xr = xcol + (mi * 16 + fr) * KS + 4 * fg;
+                *reinterpret_cast<float4*>(xr) = make_float4(acc[mi][0][0], acc[mi][0][1], acc[mi][0][2], acc[mi][0][3]);
+                if (fg < 2) *reinterpret_cast<float4*>(xr + 16) = make_float4(acc[mi][1][0], acc[mi][1][1], acc[mi][1][2], acc[mi][1][3]);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MTH; ++mi) { keep[j][mi][0] = acc[MTH + mi][0]; keep[j][mi][1] = acc[MTH + mi][1]; }
+        }
+#pragma unroll
+        for (int nc = 0; nc < NCT; ++nc)
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) y[nc][mt] = (f32x4){0, 0, 0, 0};
+#ifndef X_ABL_NOSTEP2
+        XStep2<CIN, COUT, NCT> s2;
+        const bf16x8* Wq_g = Wq;
+        asm volatile("" : "+s"(Wq_g));                  // opaque per pass: the unrolled batch addresses are recomputed (scalar adds), not hoisted out of the loop
+        s2.issue(0, Wq_g, wave, lane);                  // first W batch: in flight across the barrier
+        __syncthreads();                                // every wave's first X1 half is in LDS
+        s2.template half<0>(y, X1s, Wq_g, wave, lane);
+#endif
+        __syncthreads();                                // every wave finished reading the first half
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float* xcol = X1s + (wave * NJ + j) * S;
+#pragma unroll
+            for (int mi = 0; mi < MTH; ++mi) {
+                float* xr = xcol + (mi * 16 + fr) * KS + 4 * fg;
+                *reinterpret_cast<float4*>(xr) = make_float4(keep[j][mi][0][0], keep[j][mi][0][1], keep[j][mi][0][2], keep[j][mi][0][3]);
+                if (fg < 2) *reinterpret_cast<float4*>(xr + 16) = make_float4(keep[j][mi][1][0], keep[j][mi][1][1], keep[j][mi][1][2], keep[j][mi][1][3]);
+            }
+        }
+        __syncthreads();
+#ifndef X_ABL_NOSTEP2
+        s2.template half<1>(y, X1s, Wq_g, wave, lane);
+#endif
+        __syncthreads();                                // every wave finished reading X1s: the partial table may overwrite it
+        // y[nc][mt][q] = Y[o = 16 mt + 4 fg + q][col = 16 nc + fr]: the four K shares meet in LDS
+#pragma unroll
+        for (int nc = 0; nc < NCT; ++nc)
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt)
+                *reinterpret_cast<float4*>(&part[((wave * AG) + 16 * nc + fr) * PS + mt * 16 + fg * 4]) = make_float4(y[nc][mt][0], y[nc][mt][1], y[nc][mt][2], y[nc][mt][3]);
+        __syncthreads();
+        for (int e = tid; e < AG * COUT; e += 256) {
+            const int col = e / COUT, o = e - col * COUT;
+            const int a = ag * AG + col;
+            if (a < NA) {
+                float v = part[(0 * AG + col) * PS + o] + part[(1 * AG + col) * PS + o];
+                v += part[(2 * AG + col) * PS + o] + part[(3 * AG + col) * PS + o];
+                v += bias[o];
+                outp[(size_t)a * COUT + o] = v;
+                st_s += (double)v; st_q += (double)v * (double)v;
+            }
+        }
+        __syncthreads();                                // the table is read: the next pass may write X1s
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-direct load may outlive the workgroup's LDS allocation
+    if (stat_part) {
+        static_assert(256 % COUT == 0, "a thread must keep one output channel");
+        double* dred = reinterpret_cast<double*>(part);      // 512 doubles <= the X1 tile
+        dred[tid] = st_s; dred[256 + tid] = st_q;
+        __syncthreads();
+        if (tid < COUT) {
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 256 / COUT; ++k) { a0 += dred[k * COUT + tid]; a1 += dred[256 + k * COUT + tid]; }
+            double* sp = stat_part + ((size_t)b * p2 + p) * 2 * COUT;
+            sp[tid] = a0; sp[COUT + tid] = a1;
+        }
+    }
+}
+
+// x [rows][C] fp32 -> planes [rows][3][C] bf16 (exact split); thread = 4 consecutive channels
+__global__ void __launch_bounds__(256) split3_planes_kernel(long n4, int C, const float* __restrict__ x, unsigned short* __restrict__ planes) {
+    const int c4 = C >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / c4;
+        const int c = (int)(i - row * c4) * 4;
+        uint2 hi, mid, lo;
+        split3_pack4(reinterpret_cast<const float4*>(x)[i], hi, mid, lo);
+        unsigned short* pr = planes + (size_t)row * 3 * C + c;
+        *reinterpret_cast<uint2*>(pr) = hi; *reinterpret_cast<uint2*>(pr + C) = mid; *reinterpret_cast<uint2*>(pr + 2 * C) = lo;
+    }
+}
+
+template <int CIN, int COUT, int NCH>
+static int launch_x(int b, int p1, int p2, float sigma, const float* xyz, const float* new_xyz, const int* idx, const void* Fq, const float* rk,
+                    const void* Wq, const float* bias, float* out, const int* order, double* stat_part, hipStream_t st) {
+    constexpr int NN = 32 * NCH;
+    constexpr int AG = INTER_X_AG(CIN, COUT);
+    constexpr int NBUF = INTER_X_NBUF(CIN, COUT);
+    const size_t lds = (size_t)(AG * (CIN * KS / 2 + 40) + 5 * NN) * sizeof(float) + (size_t)4 * NBUF * 3 * (CIN / 16) * 1024;
+    auto kern = inter_so3conv_x_kernel<CIN, COUT, NCH, AG, NBUF>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    const unsigned gx = order ? 8u * (unsigned)((p2 + 7) / 8) : (unsigned)p2;
+    hipLaunchKernelGGL(kern, dim3(gx, b), dim3(256), lds, st, p1, p2, 1.0f / sigma, xyz, new_xyz, idx, reinterpret_cast<const unsigned short*>(Fq), rk,
+                       reinterpret_cast<const bf16x8*>(Wq), bias, out, order, stat_part);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+extern "C" {
+
+int etch_split3_planes(long rows, int C, const float* x, void* planes, void* stream) {
+    if (rows <= 0) return ETCH_OK;
+    if (C <= 0 || (C & 3) || ((uintptr_t)x & 15) || ((uintptr_t)planes & 7)) return ETCH_EUNSUPPORTED;
+    const long n4 = rows * (C / 4);
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(split3_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n4, C, x, reinterpret_cast<unsigned short*>(planes));
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+// 1 if etch_inter_so3conv_planes has an instantiation for the shape (the callers' routing test), else 0
+int etch_inter_so3conv_planes_supported(int cin, int cout, int nn) {
+    return ((cin == 32 && (cout == 32 || cout == 64)) || (cin == 64 && cout == 64)) && (nn == 32 || nn == 64);
+}
+
+int etch_inter_so3conv_planes(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
+                              const int* ball_idx, const void* feats_planes, const float* rk, const void* Wq, const float* bias, float* out,
+                              const int* order, double* stat_part, void* stream) {
+    if (b <= 0 || p2 <= 0) return ETCH_OK;
+    if (sigma <= 0.f || !Wq || !feats_planes) return ETCH_EINVAL;
+    if (((uintptr_t)feats_planes & 15) || ((uintptr_t)Wq & 15)) return ETCH_EINVAL;
+    if ((size_t)p1 * NA * 3 * cin * 2 >= ((size_t)1 << 32)) return ETCH_EUNSUPPORTED;      // 32-bit byte offsets inside a scan
+    hipStream_t st = (hipStream_t)stream;
+#define X_CASE(CI, CO, NC) \
+    if (cin == CI && cout == CO && nn == 32 * NC) return launch_x<CI, CO, NC>(b, p1, p2, sigma, xyz, new_xyz, ball_idx, feats_planes, rk, Wq, bias, out, order, stat_part, st);
+    X_CASE(32, 32, 1) X_CASE(32, 32, 2) X_CASE(32, 64, 1) X_CASE(32, 64, 2) X_CASE(64, 64, 1) X_CASE(64, 64, 2)
+#undef X_CASE
+    return ETCH_EUNSUPPORTED;
+}
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+// Exact split of fp32 values into three bf16 values (hi / mid / lo = the top, middle and bottom 8 mantissa bits, by truncation: v = hi + mid + lo
+// with no rounding anywhere) -- the operand format of the "fp32 products on the bf16 matrix cores" kernels.  Shared by
+// so3conv.hip (step 2 of the inter conv) and so3conv_x.hip (both steps).
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+// 8 consecutive fp32 values -> 3 planes x 8 bf16
+__device__ __forceinline__ void split3_pack8(const float4 v0, const float4 v1, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h[i] = __float_as_uint(v[i]);
+        const float r = v[i] - __uint_as_float(h[i] & 0xffff0000u);
+        m[i] = __float_as_uint(r);
+        l[i] = __float_as_uint(r - __uint_as_float(m[i] & 0xffff0000u));
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    // v_perm_b32: bytes 2, 3 of the even element below bytes 2, 3 of the odd one
+#define ETCH_PK(a) (u32x4){__builtin_amdgcn_perm(a[1], a[0], 0x07060302u), __builtin_amdgcn_perm(a[3], a[2], 0x07060302u), \
+                           __builtin_amdgcn_perm(a[5], a[4], 0x07060302u), __builtin_amdgcn_perm(a[7], a[6], 0x07060302u)}
+    const u32x4 ph = ETCH_PK(h), pm = ETCH_PK(m), pl = ETCH_PK(l);
+#undef ETCH_PK
+    hi = __builtin_bit_cast(bf16x8, ph); mid = __builtin_bit_cast(bf16x8, pm); lo = __builtin_bit_cast(bf16x8, pl);
+}
+
+// 4 consecutive fp32 values -> 3 planes x 4 bf16 (8 bytes each)
+__device__ __forceinline__ void split3_pack4(const float4 v4, uint2& hi, uint2& mid, uint2& lo) {
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = __float_as_uint(v[i]);
+        const float r = v[i] - __uint_as_float(h[i] & 0xffff0000u);
+        m[i] = __float_as_uint(r);
+        l[i] = __float_as_uint(r - __uint_as_float(m[i] & 0xffff0000u));
+    }
+    hi = make_uint2(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u));
+    mid = make_uint2(__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u));
+    lo = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
+}
+
+// The same split with the two residual subtractions of a PAIR of values as one packed instruction (v_pk_add_f32 with negated second operand): 4.5
+// instead of 5.5 VALU instructions per value.  pairs[i] = (a_i, b_i): the a's and the b's are split into their own fragments (two 8-element
+// fragments at once, e.g. the two kernel-point tiles of a weight chunk).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_pack8_pairs(const f32x2 (&v)[8], bf16x8 (&a)[3], bf16x8 (&b)[3]) {
+    unsigned ha[8], ma[8], la[8], hb[8], mb[8], lb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        ha[i] = __float_as_uint(v[i].x); hb[i] = __float_as_uint(v[i].y);
+        const f32x2 r = v[i] - (f32x2){__uint_as_float(ha[i] & 0xffff0000u), __uint_as_float(hb[i] & 0xffff0000u)};
+        ma[i] = __float_as_uint(r.x); mb[i] = __float_as_uint(r.y);
+        const f32x2 q = r - (f32x2){__uint_as_float(ma[i] & 0xffff0000u), __uint_as_float(mb[i] & 0xffff0000u)};
+        la[i] = __float_as_uint(q.x); lb[i] = __float_as_uint(q.y);
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define ETCH_PK(x) (u32x4){__builtin_amdgcn_perm(x[1], x[0], 0x07060302u), __builtin_amdgcn_perm(x[3], x[2], 0x07060302u), \
+                           __builtin_amdgcn_perm(x[5], x[4], 0x07060302u), __builtin_amdgcn_perm(x[7], x[6], 0x07060302u)}
+    a[0] = __builtin_bit_cast(bf16x8, ETCH_PK(ha)); a[1] = __builtin_bit_cast(bf16x8, ETCH_PK(ma)); a[2] = __builtin_bit_cast(bf16x8, ETCH_PK(la));
+    b[0] = __builtin_bit_cast(bf16x8, ETCH_PK(hb)); b[1] = __builtin_bit_cast(bf16x8, ETCH_PK(mb)); b[2] = __builtin_bit_cast(bf16x8, ETCH_PK(lb));
+#undef ETCH_PK
+}
+// 8 consecutive values of one row, residuals of neighbouring values paired
+__device__ __forceinline__ void split3_pack8p(const float4 v0, const float4 v1, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+    const f32x2 v[4] = {{v0.x, v0.y}, {v0.z, v0.w}, {v1.x, v1.y}, {v1.z, v1.w}};
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[2 * i] = __float_as_uint(v[i].x); h[2 * i + 1] = __float_as_uint(v[i].y);
+        const f32x2 r = v[i] - (f32x2){__uint_as_float(h[2 * i] & 0xffff0000u), __uint_as_float(h[2 * i + 1] & 0xffff0000u)};
+        m[2 * i] = __float_as_uint(r.x); m[2 * i + 1] = __float_as_uint(r.y);
+        const f32x2 q = r - (f32x2){__uint_as_float(m[2 * i] & 0xffff0000u), __uint_as_float(m[2 * i + 1] & 0xffff0000u)};
+        l[2 * i] = __float_as_uint(q.x); l[2 * i + 1] = __float_as_uint(q.y);
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define ETCH_PK(x) (u32x4){__builtin_amdgcn_perm(x[1], x[0], 0x07060302u), __builtin_amdgcn_perm(x[3], x[2], 0x07060302u), \
+                           __builtin_amdgcn_perm(x[5], x[4], 0x07060302u), __builtin_amdgcn_perm(x[7], x[6], 0x07060302u)}
+    hi = __builtin_bit_cast(bf16x8, ETCH_PK(h)); mid = __builtin_bit_cast(bf16x8, ETCH_PK(m)); lo = __builtin_bit_cast(bf16x8, ETCH_PK(l));
+#undef ETCH_PK
+}

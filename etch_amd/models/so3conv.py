@@ -95,6 +95,7 @@ class SeparableSO3ConvBlock(nn.Module):
         self.stride = params["stride"]
         self.skip_conv = nn.Conv2d(dim_in, dim_out, 1)
         self.norm = nn.InstanceNorm2d(dim_out, affine=False)
+        self.emit_planes = False
 
     def forward(self, x, inter_idx, inter_w):
         conv = self.inter_conv.conv
@@ -114,9 +115,17 @@ class SeparableSO3ConvBlock(nn.Module):
             s = ops.linear(fin.view(-1, cin), w, bias=bias)
         s = s.view(b, p2, na, -1)
         m3, r3 = ops.instnorm_stats(s)
-        out = ops.instnorm_act_add(z.feats_cl, m2, r2, s, m3, r3)
+        # emit_planes (set by BasicSO3ConvBlock when the NEXT conv gathers bf16 planes): the output is also written split, once, by this pass
+        planes = None
+        if self.emit_planes:
+            out, planes = ops.instnorm_act_add(z.feats_cl, m2, r2, s, m3, r3, want_planes=True)
+        else:
+            out = ops.instnorm_act_add(z.feats_cl, m2, r2, s, m3, r3)
         # x.anchors after the intra conv = the INTRA conv's anchors buffer (vgtk modules.py:153; so3conv.py:182 passes it on)
-        return inter_idx, None, sample_idx, sptk.SphericalPointCloud(y.xyz, None, z.anchors, feats_cl=out)
+        cloud = sptk.SphericalPointCloud(y.xyz, None, z.anchors, feats_cl=out)
+        if planes is not None:
+            cloud.feats_planes = planes
+        return inter_idx, None, sample_idx, cloud
 
 
 class BasicSO3ConvBlock(nn.Module):

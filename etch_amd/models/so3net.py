@@ -84,6 +84,11 @@ class EquivBackbone(nn.Module):
         self.na_in = params["na"]
         self.config = config
         self.anchors = torch.from_numpy(L.get_anchors(60))   # plain attribute like the reference (:21): not in the state dict
+        # a separable block whose successor gathers bf16 planes (etch_inter_so3conv_planes) writes its output split as well
+        convs = [c for blk in self.backbone for c in blk.blocks]
+        for cur, nxt in zip(convs[:-1], convs[1:]):
+            if isinstance(cur, M.SeparableSO3ConvBlock) and isinstance(nxt, M.SeparableSO3ConvBlock):
+                cur.emit_planes = nxt.inter_conv.conv.wants_planes()
 
     def _apply(self, fn, *a, **k):
         super()._apply(fn, *a, **k)

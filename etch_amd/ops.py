@@ -191,13 +191,13 @@ def split3_bf16(x):
     return torch.stack([(t >> 16).to(torch.int16) for t in (hi, mid, lo)])
 
 
-def inter_weight_split(W, cin, ks=24):
-    """Weight of the inter conv for the split-operand kernel (etch_inter_so3conv_split): columns in the kernel's contraction order (the one of
-    inter_weight_frag), split into three bf16 planes, in v_mfma_f32_16x16x32_bf16 A-fragment order:
-    [chunk of 32 kappas][o tile][plane][lane = 16 * (k / 8) + o % 16][8]."""
+def inter_weight_split(W, cin, ks=24, natural=False):
+    """Weight of the inter conv for the split-operand kernels: columns in the kernel's contraction order (etch_inter_so3conv_split: the one of
+    inter_weight_frag; natural=True, etch_inter_so3conv_planes: W's own column order c * 24 + k), split into three bf16 planes, in
+    v_mfma_f32_16x16x32_bf16 A-fragment order: [chunk of 32 kappas][o tile][plane][lane = 16 * (k / 8) + o % 16][8]."""
     cout = W.shape[0]
     assert cin % 16 == 0 and cout % 16 == 0 and W.shape[1] == cin * ks and ks == 24
-    planes = split3_bf16(W[:, _inter_contraction_cols(cin, ks, W.device)])     # [3][cout][K]
+    planes = split3_bf16(W if natural else W[:, _inter_contraction_cols(cin, ks, W.device)])     # [3][cout][K]
     K = cin * ks
     q = planes.reshape(3, cout // 16, 16, K // 32, 4, 8)                 # [pl][mt][ol][tg][kg][e]
     return q.permute(3, 1, 0, 4, 2, 5).contiguous().reshape(-1)          # [tg][mt][pl][kg][ol][e]
@@ -230,6 +230,22 @@ def inter_weight_frag32(W, cin, ks=24):
 INTER_SPLIT = os.environ.get("ETCH_INTER_SPLIT", "1") != "0"      # step 2 of the inter conv on the bf16 matrix cores (split fp32 operands); 0: fp32 MFMA
 INTER_MFMA32 = os.environ.get("ETCH_INTER_MFMA32", "0") == "1"     # (32|64) -> (32|64) channels: the 32x32x2 MFMA form, two points per workgroup
 INTER_MFMA32_SHAPES = ((32, 32), (32, 64), (64, 64))
+INTER_X = os.environ.get("ETCH_INTER_X", "1") != "0"             # both contractions of the inter conv on the bf16 matrix cores, gathered rows as bf16 planes (csrc/so3conv_x.hip)
+
+
+def inter_planes_supported(cin, cout, nn):
+    """Shapes etch_inter_so3conv_planes covers (the three convs of the released encoder depth)."""
+    return INTER_X and (cin, cout) in ((32, 32), (32, 64), (64, 64)) and nn in (32, 64)      # = etch_inter_so3conv_planes_supported
+
+
+def split3_planes(x_cl):
+    """x (..., C) fp32 -> (..., 3, C) int16: the bf16 bit patterns of the exact split x = hi + mid + lo, the layout etch_inter_so3conv_planes
+    gathers (the encoder's own producer, instnorm_act_add(want_planes=True), writes it directly)."""
+    _need(x_cl, torch.float32, "x")
+    C = x_cl.shape[-1]
+    planes = torch.empty(tuple(x_cl.shape[:-1]) + (3, C), dtype=torch.int16, device=x_cl.device)
+    _lib.check(_lib.lib().etch_split3_planes(_c_long(x_cl.numel() // C), int(C), _ptr(x_cl), _ptr(planes), _stream()), "etch_split3_planes")
+    return planes
 
 
 # ------------------------------------------------------------------ EPN encoder
@@ -243,9 +259,12 @@ def spatial_order(xyz):
     return order
 
 
-def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, order=None, want_stats=False, Wp32=None, Wq=None):
+def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, order=None, want_stats=False, Wp32=None, Wq=None, Wqn=None,
+                  feats_planes=None):
     """feats_cl (b,p1,60,cin) channels-last -> (b,p2,60,cout) pre-norm.  order (b,p2) int32: processing order of the output points.
-    want_stats: also return the InstanceNorm (mean, rstd) of the output, accumulated in the conv's epilogue."""
+    want_stats: also return the InstanceNorm (mean, rstd) of the output, accumulated in the conv's epilogue.
+    Wqn (inter_weight_split(natural=True)): both contractions on the bf16 matrix cores where the shape is covered; feats_planes
+    (b,p1,60,3,cin) int16 = the producer's split of feats_cl (made here when absent)."""
     b, p1, na, cin = feats_cl.shape
     p2, nn = ball_idx.shape[1], ball_idx.shape[2]
     cout = W.shape[0]
@@ -258,7 +277,16 @@ def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, orde
     out = torch.empty((b, p2, 60, cout), dtype=torch.float32, device=xyz.device)
     fused = want_stats and 256 % cout == 0 and (cin >= 16 or cin == 1)
     part = torch.empty((b, p2, 2, cout), dtype=torch.float64, device=xyz.device) if fused else None
-    if Wp32 is not None and INTER_MFMA32 and (cin, cout) in INTER_MFMA32_SHAPES:
+    if Wqn is not None and inter_planes_supported(cin, cout, nn):
+        _need(Wqn, torch.int16, "Wqn")
+        if feats_planes is None:
+            feats_planes = split3_planes(feats_cl)
+        _need(feats_planes, torch.int16, "feats_planes")
+        assert tuple(feats_planes.shape) == (b, p1, na, 3, cin)
+        _lib.check(_lib.lib().etch_inter_so3conv_planes(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
+                                                       _ptr(feats_planes), _ptr(rk), _ptr(Wqn), _ptr(bias), _ptr(out), _optptr(order),
+                                                       _optptr(part), _stream()), "etch_inter_so3conv_planes")
+    elif Wp32 is not None and INTER_MFMA32 and (cin, cout) in INTER_MFMA32_SHAPES:
         _need(Wp32, torch.float32, "Wp32")
         _lib.check(_lib.lib().etch_inter_so3conv32(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
                                                    _ptr(feats_cl), _ptr(rk), _ptr(Wp32), _ptr(bias), _ptr(out), _optptr(order),
@@ -326,14 +354,16 @@ def instnorm_stats(x_cl):
     return mean, rstd
 
 
-def instnorm_act_add(x1, m1, r1, x2=None, m2=None, r2=None):
+def instnorm_act_add(x1, m1, r1, x2=None, m2=None, r2=None, want_planes=False):
+    """want_planes: also return the result as three bf16 planes (..., 3, C) int16 (the gather format of etch_inter_so3conv_planes)."""
     _need(x1, torch.float32, "x1")
     b, C = x1.shape[0], x1.shape[-1]
     rows = x1.numel() // (b * C)
     out = torch.empty_like(x1)
-    _lib.check(_lib.lib().etch_instnorm_act_add(b, rows, C, _ptr(x1), _ptr(m1), _ptr(r1), _optptr(x2), _optptr(m2), _optptr(r2),
-                                                _ptr(out), _stream()), "etch_instnorm_act_add")
-    return out
+    planes = torch.empty(tuple(x1.shape[:-1]) + (3, C), dtype=torch.int16, device=x1.device) if want_planes else None
+    _lib.check(_lib.lib().etch_instnorm_act_add_planes(b, rows, C, _ptr(x1), _ptr(m1), _ptr(r1), _optptr(x2), _optptr(m2), _optptr(r2),
+                                                       _ptr(out), _optptr(planes), _stream()), "etch_instnorm_act_add")
+    return (out, planes) if want_planes else out
 
 
 # ------------------------------------------------------------------ propagation + direction head

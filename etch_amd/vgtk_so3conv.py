@@ -128,6 +128,7 @@ class InterSO3Conv(nn.Module):
         self._d = _Derived()
         self._d32 = _Derived()
         self._dq = _Derived()
+        self._dqn = _Derived()
 
     def _derived(self):
         W, bias = self.basic_conv.W, self.basic_conv.bias
@@ -154,6 +155,18 @@ class InterSO3Conv(nn.Module):
             return None
         W = self.basic_conv.W
         return self._dq.get((W,), lambda: ops.inter_weight_split(W.detach().contiguous(), self.dim_in, self.kernel_size))
+
+    def _wqn(self):
+        """The same planes in W's natural column order: etch_inter_so3conv_planes (both contractions on the bf16 matrix cores); None where
+        that kernel has no instantiation."""
+        if not ops.inter_planes_supported(self.dim_in, self.dim_out, self.n_neighbor) or self.kernel_size != 24:
+            return None
+        W = self.basic_conv.W
+        return self._dqn.get((W,), lambda: ops.inter_weight_split(W.detach().contiguous(), self.dim_in, self.kernel_size, natural=True))
+
+    def wants_planes(self):
+        """True if this conv gathers its input as bf16 planes (its producer should emit them: SeparableSO3ConvBlock.emit_planes)."""
+        return ops.inter_planes_supported(self.dim_in, self.dim_out, self.n_neighbor) and self.kernel_size == 24
 
     def group(self, xyz):
         """functional.py:176-185 inter_spconv_grouping_ball (index part): -> ball_idx, sample_idx, new_xyz.
@@ -185,7 +198,8 @@ class InterSO3Conv(nn.Module):
         else:
             sample_idx, new_xyz = None, xyz
         rk, W, Wp, bias = self._derived()
-        y, stats = ops.inter_so3conv(xyz, new_xyz, inter_idx, x.feats_cl, rk, W, Wp, bias, self.sigma, order=self.order(new_xyz), want_stats=True, Wp32=self._wp32(), Wq=self._wq())
+        y, stats = ops.inter_so3conv(xyz, new_xyz, inter_idx, x.feats_cl, rk, W, Wp, bias, self.sigma, order=self.order(new_xyz), want_stats=True, Wp32=self._wp32(), Wq=self._wq(),
+                                     Wqn=self._wqn(), feats_planes=getattr(x, "feats_planes", None))
         cloud = SphericalPointCloud(new_xyz, None, self.anchors, feats_cl=y)
         cloud.in_stats = stats          # InstanceNorm (mean, rstd) of the output, a by-product of the conv's epilogue
         return inter_idx, None, sample_idx, cloud

@@ -134,6 +134,22 @@ int etch_inter_so3conv_split(int b, int cin, int cout, int p1, int p2, int nn, f
                              const int* ball_idx, const float* feats, const float* rk, const void* Wq, const float* bias, float* out,
                              const int* order, double* stat_part, void* stream);
 
+/* The same convolution with BOTH contractions on the bf16 matrix cores (round 4, etch_amd/csrc/so3conv_x.hip): the neighbour contraction
+ * X1[k, c] = sum_n w[a, k, n] F[idx_n, a, c] (functional.py:61-67 with the weights of :286-324 generated in registers) runs as split-operand
+ * products too.  The gathered rows come as three bf16 planes written once by their producer: feats_planes (b, p1, 60, 3, cin) bf16 =
+ * hi / mid / lo of the fp32 features (exact: hi + mid + lo == value; etch_split3_planes or etch_instnorm_act_add_planes write them), loaded
+ * global -> LDS directly and read back as matrix-core fragments with the transposing LDS read.  (cin, cout) in {(32,32), (32,64), (64,64)},
+ * nn in {32, 64} (etch_inter_so3conv_planes_supported).  Wq as for etch_inter_so3conv_split but in W's NATURAL column order
+ * (etch_amd/ops.py inter_weight_split(natural=True)).  order / stat_part as above.  Same result as the fp32 kernels up to the order of the
+ * fp32 sums. */
+int etch_inter_so3conv_planes(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
+                              const int* ball_idx, const void* feats_planes, const float* rk, const void* Wq, const float* bias, float* out,
+                              const int* order, double* stat_part, void* stream);
+int etch_inter_so3conv_planes_supported(int cin, int cout, int nn);
+
+/* x (rows, C) fp32 -> planes (rows, 3, C) bf16: the exact split x = hi + mid + lo (8 + 8 + 8 mantissa bits, by truncation). */
+int etch_split3_planes(long rows, int C, const float* x, void* planes, void* stream);
+
 /* mean / rstd (b,C) of InstanceNorm2d(affine=False, eps 1e-5) from per-part partial sums: partial (b,nparts,2,C) fp64, each over `count`
  * values.  Same result as etch_instnorm_stats over the full tensor (fp64 accumulation, fixed order). */
 int etch_instnorm_from_partials(int b, int nparts, int C, int count, const double* partial, float* mean, float* rstd, void* stream);
@@ -174,6 +190,9 @@ int etch_instnorm_stats_workspace_bytes(int b, int C);
  * SeparableSO3ConvBlock.forward (src/models/so3conv.py:178-182).  x2 may be NULL. */
 int etch_instnorm_act_add(int b, int rows, int C, const float* x1, const float* m1, const float* r1, const float* x2,
                           const float* m2, const float* r2, float* out, void* stream);
+/* The same, additionally writing the result as three bf16 planes (b, rows, 3, C) for etch_inter_so3conv_planes (planes may be NULL). */
+int etch_instnorm_act_add_planes(int b, int rows, int C, const float* x1, const float* m1, const float* r1, const float* x2,
+                                 const float* m2, const float* r2, float* out, void* planes, void* stream);
 
 /* ---- feature propagation + direction head --------------------------------------------------------------- */
 

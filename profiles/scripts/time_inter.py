@@ -1,0 +1,41 @@
+"""Times the three inter convs of the released encoder depth at the bench batch (32 x 5 000 points): round-3 kernel (step 1 on the fp32 MFMA)
+against etch_inter_so3conv_planes.  python profiles/scripts/time_inter.py [reps]"""
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from etch_amd import ops  # noqa: E402
+from etch_amd import vgtk_so3conv as V  # noqa: E402
+from etch_amd.utils.weights import load_seeded  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+B = 32
+g = torch.Generator().manual_seed(0)
+pts = (torch.randn(B, 5000, 3, generator=g) * torch.tensor([0.14, 0.31, 0.085])).cuda()
+xyz0 = pts.permute(0, 2, 1).contiguous()
+fps = ops.furthest_point_sampling(xyz0, 2500)
+xyz1 = ops.gather_points_forward(xyz0, fps)
+shapes = [("b0c1", 32, 32, 32, 0.113137, 0.0064, xyz1, 2500), ("b1c0", 32, 64, 64, 0.16, 0.0128, xyz1, 1250), ("b1c1", 64, 64, 32, 0.16, 0.0128, xyz1[:, :, :1250].contiguous(), 1250)]
+for name, cin, cout, nn, radius, sigma, xyz, p2 in shapes:
+    new_xyz = xyz[:, :, :p2].contiguous()
+    ball = ops.ball_query(new_xyz, xyz, radius, nn)
+    conv = load_seeded(V.InterSO3Conv(cin, cout, 1, 1, radius, sigma, nn), 3).cuda()
+    rk, W, Wp, bias = conv._derived()
+    feats = torch.randn(B, xyz.shape[2], 60, cin, generator=g).cuda()
+    planes = ops.split3_planes(feats)
+    order = ops.spatial_order(new_xyz)
+    res = {}
+    for label, kw in (("r03 split", dict(Wq=conv._wq())), ("planes", dict(Wqn=conv._wqn(), feats_planes=planes))):
+        f = lambda: ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, sigma, order=order, want_stats=True, **kw)
+        y = f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        res[label] = (e0.elapsed_time(e1) / reps, y[0])
+    d = float((res["planes"][1] - res["r03 split"][1]).abs().max()) / float(res["r03 split"][1].abs().max())
+    print(f"{name} {cin}->{cout} nn={nn} p2={p2}: r03 {res['r03 split'][0]:.3f} ms, planes {res['planes'][0]:.3f} ms, max diff / scale {d:.2e}", flush=True)

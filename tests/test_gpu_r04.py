@@ -1,0 +1,88 @@
+"""Round-4 GPU tests: the inter conv with both contractions on the bf16 matrix cores (csrc/so3conv_x.hip), the bf16-plane producers."""
+import numpy as np
+import pytest
+import torch
+
+from etch_amd.utils.weights import load_seeded
+from tests.test_gpu_encoder import _inter_conv_fp64, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_split3_planes_are_exact_and_match_the_host_split():
+    """etch_split3_planes / instnorm_act_add(want_planes=True): the three bf16 planes sum to the fp32 value exactly and equal ops.split3_bf16."""
+    from etch_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(2, 37, 60, 32, generator=g) * torch.logspace(-6, 6, 32)).cuda()
+    planes = ops.split3_planes(x)
+    assert planes.shape == (2, 37, 60, 3, 32) and planes.dtype == torch.int16
+    host = ops.split3_bf16(x)                                   # [3][...]
+    assert torch.equal(planes, host.permute(1, 2, 3, 0, 4))
+    back = sum((planes[..., k, :].to(torch.int32) << 16).view(torch.float32).double() for k in range(3))
+    assert torch.equal(back.float(), x) and torch.equal(back, x.double())
+    m, r = ops.instnorm_stats(x)
+    x2 = torch.randn(2, 37, 60, 32, generator=g).cuda()
+    m2, r2 = ops.instnorm_stats(x2)
+    out = ops.instnorm_act_add(x, m, r, x2, m2, r2)
+    out_p, pl = ops.instnorm_act_add(x, m, r, x2, m2, r2, want_planes=True)
+    assert torch.equal(out, out_p) and torch.equal(pl, ops.split3_planes(out))
+
+
+@pytest.mark.parametrize("cin,cout,nn,p1,p2", [(32, 32, 32, 301, 149), (32, 64, 64, 211, 60), (64, 64, 32, 211, 101), (32, 32, 64, 130, 1),
+                                                (32, 64, 32, 97, 97), (64, 64, 64, 150, 33)])
+def test_inter_conv_planes_matches_the_fp32_kernel_and_fp64(cin, cout, nn, p1, p2):
+    """etch_inter_so3conv_planes (BOTH contractions on the bf16 matrix cores: fp32 operands split exactly into three bf16 values, six cross
+    products each; gathered rows as producer-written planes through LDS-direct loads + transposing LDS reads) against the fp32-MFMA kernel
+    (the same sums in another order) and the fp64 formula under the entitled-error rule; bitwise reproducible, schedule-independent;
+    padded neighbourhoods (radius smaller than the cloud: cyclic padding) included."""
+    from etch_amd import ops
+    from etch_amd import vgtk_so3conv as V
+    assert ops.inter_planes_supported(cin, cout, nn)
+    g = torch.Generator().manual_seed(cin + nn + p2)
+    b = 2
+    xyz = (torch.randn(b, 3, p1, generator=g) * 0.2).cuda()
+    new_xyz = xyz[:, :, :p2].contiguous()
+    ball = ops.ball_query(new_xyz, xyz, 0.25, nn)
+    conv = load_seeded(V.InterSO3Conv(cin, cout, 1, 2, 0.25, 0.03, nn), 3).cuda()
+    rk, W, Wp, bias = conv._derived()
+    Wqn = conv._wqn()
+    assert Wqn is not None
+    feats = torch.randn(b, p1, 60, cin, generator=g).cuda()
+    planes = ops.split3_planes(feats)
+    f32, (m0, r0) = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, want_stats=True)
+    new, (m1, r1) = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, want_stats=True, Wqn=Wqn, feats_planes=planes,
+                                      order=ops.spatial_order(new_xyz))
+    again = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, Wqn=Wqn)        # planes made on the fly, plain order
+    assert torch.equal(new, again)
+    scale = float(f32.abs().max())
+    assert float((new - f32).abs().max()) < 2e-6 * scale, float((new - f32).abs().max()) / scale
+    assert rel_err(m1.cpu().numpy(), m0.cpu().numpy()) < 2e-6 and rel_err(r1.cpu().numpy(), r0.cpu().numpy()) < 2e-6
+    ref = _inter_conv_fp64(xyz, new_xyz, ball, feats, rk, W, bias, conv.sigma)
+    e_new, e_f32 = float((new.double() - ref).abs().max()), float((f32.double() - ref).abs().max())
+    assert e_f32 < 3e-6 * scale and e_new <= 2.0 * e_f32 + 1e-7 * scale, (e_new, e_f32)
+
+
+def test_encoder_with_plane_producers_equals_encoder_without(monkeypatch):
+    """The encoder with its blocks emitting planes for the next conv == the encoder that splits inside ops.inter_so3conv (bitwise), and both
+    within the split kernels' bound of the round-3 path (ETCH_INTER_X=0: step 1 on the fp32 MFMA)."""
+    import types
+
+    from etch_amd import constants as K
+    from etch_amd import ops
+    from etch_amd.models.models_pointcloud import GT_network_equiv
+    args = types.SimpleNamespace(output_folder="/tmp/etch_r04", EPN_input_radius=0.4, EPN_layer_num=2, device=torch.device("cuda"),
+                                 markerset=K.default_markerset())
+    model = load_seeded(GT_network_equiv(option=args), 1).cuda().eval()
+    emit = [c.emit_planes for blk in model.encoder.backbone for c in blk.blocks]
+    assert emit == [True, True, True, False], emit
+    pts = torch.from_numpy((np.random.default_rng(5).standard_normal((2, 1500, 3)) * np.array([0.14, 0.31, 0.085])).astype(np.float32)).cuda()
+    with torch.no_grad():
+        a = model.encoder(pts)[0].feats_cl
+        for blk in model.encoder.backbone:
+            for c in blk.blocks:
+                c.emit_planes = False
+        bb = model.encoder(pts)[0].feats_cl
+        assert torch.equal(a, bb)
+        monkeypatch.setattr(ops, "INTER_X", False)
+        c3 = model.encoder(pts)[0].feats_cl
+    assert float((a - c3).abs().max()) < 2e-5 * float(c3.abs().max())
