@@ -30,6 +30,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const void __attribute__((address_space(1)))* x_gptr;
 typedef void __attribute__((address_space(3)))* x_lptr;
 
+// Neighbour-table reads as inline asm + counted waits.  Written as plain LDS loads, the compiler orders every one of them behind s_waitcnt vmcnt(0) when
+// an LDS-direct load is in flight (it cannot prove that the table and the staging tile are disjoint, not even as separate LDS objects): the rows requested
+// at the top of a chunk-step were drained a few instructions later, and the gather latency was paid in full every step.  LDS operations complete in
+// order, so "all but the N youngest" is exact; operations the compiler issues in between only make a wait stricter.
+#define X_LDS_READ128(dst, addr, off) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"((addr) + (unsigned)(off)))
+template <int N> __device__ __forceinline__ void x_lds_wait(f32x4& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
+template <int N> __device__ __forceinline__ void x_lds_wait2(f32x4& a, f32x4& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+
 __device__ __forceinline__ bf16x4 x_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3)))*)p);
 }
@@ -117,7 +125,7 @@ struct XStep2 {
 template <int CIN, int COUT, int NCH, int AG, int NBUF>       // NCH = nn / 32 neighbour chunks
 __global__ void __launch_bounds__(256, INTER_X_WPE(CIN)) inter_so3conv_x_kernel(
     int p1, int p2, float inv_sigma, const float* __restrict__ xyz, const float* __restrict__ new_xyz, const int* __restrict__ ball_idx,
-    const unsigned short* __restrict__ Fq, const float* __restrict__ rk, const bf16x8* __restrict__ Wq, const float* __restrict__ bias,
+    const unsigned short* __restrict__ Fq, const float* rk, const bf16x8* __restrict__ Wq, const float* __restrict__ bias,
     float* __restrict__ out, const int* __restrict__ order, double* __restrict__ stat_part) {
     constexpr int NN = 32 * NCH;
     constexpr int NJ = AG / 4;             // anchors per wave and pass
@@ -142,7 +150,9 @@ __global__ void __launch_bounds__(256, INTER_X_WPE(CIN)) inter_so3conv_x_kernel(
     float* part = smem;                    // [4 waves][AG cols][PS]: aliases X1s between the last product of a pass and the next pass
     float4* nbt = reinterpret_cast<float4*>(smem + AG * S);            // [NN]  (2 g / sigma, 1 - |g|^2 / sigma)
     unsigned* noffs = reinterpret_cast<unsigned*>(nbt + NN);            // [NN]  byte offset of the neighbour's anchor-0 row
-    char* stage = reinterpret_cast<char*>(noffs + NN);                  // [4 waves][NBUF][STG]
+    // the staging tiles are an LDS object of their own: the compiler orders every LDS read that MAY alias a pending LDS-direct load behind
+    // s_waitcnt vmcnt(0) -- carved from the same array as the neighbour table, every table read of a step drained the load issued just before it
+    __shared__ __attribute__((aligned(16))) char stage[4 * NBUF * STG];  // [4 waves][NBUF][STG]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
     const int b = blockIdx.y;
@@ -229,17 +239,19 @@ __global__ void __launch_bounds__(256, INTER_X_WPE(CIN)) inter_so3conv_x_kernel(
     // the six fragments) -- which the step below lays BETWEEN its matrix instructions in program order (the compiler keeps that order; left to
     // itself it emits all of the VALU work and then all of the MFMAs).
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    struct WGen { f32x2 rx, ry, rz, rb; f32x2 w[8]; float4 g[8]; };
+    struct WGen { f32x2 rx, ry, rz, rb; f32x2 w[8]; f32x4 g[8]; };
+    const unsigned nbt_lane = (unsigned)(uintptr_t)nbt + (unsigned)(fg * 64);
     constexpr int GLA = 2;                              // neighbour-table reads run GLA phases ahead of their use (LDS latency off the dependent chain)
-    auto gen_read = [&](WGen& G, int t, int e) { G.g[e] = nbt[32 * t + 4 * fg + (e < 4 ? e : 12 + e)]; };
+#define X_GEN_READ(G, t, e) X_LDS_READ128((G).g[e], nbt_lane, (32 * (t) + ((e) < 4 ? (e) : 12 + (e))) * 16)
     auto gen_begin = [&](const float (&rv)[6], WGen& G) {
         G.rx = (f32x2){rv[0], rv[3]}; G.ry = (f32x2){rv[1], rv[4]}; G.rz = (f32x2){rv[2], rv[5]};
         G.rb = -(G.rx * G.rx + G.ry * G.ry + G.rz * G.rz) * inv_sigma;
         G.rb.y = k1ok ? G.rb.y : -1e30f;                             // k >= 24: weight 0
     };
     auto gen_weight = [&](WGen& G, int t, int e) {
-        if (e + GLA < 8) gen_read(G, t, e + GLA);
-        const float4 g = G.g[e];
+        if (e + GLA < 8) X_GEN_READ(G, t, e + GLA);
+        if (e + GLA < 8) x_lds_wait<GLA>(G.g[e]); else if (e + 1 < 8) x_lds_wait<1>(G.g[e]); else x_lds_wait<0>(G.g[e]);      // all but the reads issued after this one
+        const float4 g = make_float4(G.g[e][0], G.g[e][1], G.g[e][2], G.g[e][3]);
         f32x2 s = (f32x2){g.w, g.w} + G.rb;
         s = __builtin_elementwise_fma((f32x2){g.x, g.x}, G.rx, s);
         s = __builtin_elementwise_fma((f32x2){g.y, g.y}, G.ry, s);
@@ -273,10 +285,11 @@ __global__ void __launch_bounds__(256, INTER_X_WPE(CIN)) inter_so3conv_x_kernel(
     if (NBUF > 1) issue_rows(anchor_of(1 / NCH), 1 % NCH, stg0 + STG);
     u32x4 aws[2][2][3];                             // [step parity][kernel-point tile][plane]
     {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (see inter_so3conv_x32_kernel: `rk` is not __restrict__ on purpose)
         WGen G;
         gen_begin(rkn[0], G);
 #pragma unroll
-        for (int e = 0; e < GLA; ++e) gen_read(G, 0, e);
+        for (int e = 0; e < GLA; ++e) X_GEN_READ(G, 0, e);
 #pragma unroll
         for (int ph = 0; ph < 12; ++ph) gen_phase(G, 0, ph, aws[0]);
     }
@@ -310,7 +323,7 @@ __global__ void __launch_bounds__(256, INTER_X_WPE(CIN)) inter_so3conv_x_kernel(
                 WGen G;                                                  // next step's weights: first neighbour-table reads ride on the same wait
                 const int tn = t + 1 < NCH ? t + 1 : 0;
 #pragma unroll
-                for (int e = 0; e < GLA; ++e) gen_read(G, tn, e);
+                for (int e = 0; e < GLA; ++e) X_GEN_READ(G, tn, e);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers: the staging tile may be overwritten
                 // next chunk-step's rows (this wave's next anchor / chunk; across passes too)
                 if (NBUF > 1) {                                          // (past the last anchor: a harmless reload of anchor 59 -- the wait counts stay exact)
@@ -421,6 +434,366 @@ __global__ void __launch_bounds__(256, INTER_X_WPE(CIN)) inter_so3conv_x_kernel(
     }
 }
 
+// =================================================================================================================================
+// The same convolution on v_mfma_f32_32x32x16_bf16.  profiles/r04_mfma_bf16_issue_rates.txt: the 16x16x32 shape never issues faster than ~27 cycles
+// per SIMD (0.55 - 0.6 of the bf16 peak), the 32x32x16 shape runs at 0.97 - 0.99 of it -- per fp32 product (six MFMAs) it is 1.7 - 1.9 x cheaper.
+//   step 1, TRANSPOSED:  D[c][k] = sum_n F[idx_n, a, c] w[a, k, n]:  A = the gathered rows (32 channels x 16 neighbours per instruction, read from the
+//           staging tile with ds_read_b64_tr_b16: lane group g -> channels 16 (g & 1) .., rows 8 (g >> 1) ..), B = the kernel weights: lane = (kernel
+//           point l % 32 (24 used), neighbour group l / 32): ONE kernel point and 16 neighbours per lane and chunk, generated two neighbours per
+//           instruction (v_pk_fma_f32 over a neighbour pair -- the pair is also the bf16 pair of one fragment dword: no repacking).
+//           A lane of D holds one kernel point and 16 channels: the channel halves of the X1 tile split inside every lane (8 registers to LDS now,
+//           8 parked), and 4 consecutive channels are one 16-byte LDS store.
+//   X1 tile:  [32 anchors][kernel point k][CH channels of the half] (k-major), 16-byte channel blocks XOR-swizzled by k so that the stores of 8
+//           consecutive kernel points hit 8 different bank groups; the contraction of step 2 runs in this PHYSICAL order -- the host permutes the
+//           columns of W to it (ops.inter_weight_split32), the kernel never un-swizzles.
+//   step 2:   Y[o][a] = sum_kappa W[o][kappa] X1[a][kappa]: A = W fragments from L2 ([K step of 16][o tile of 32][plane][lane][8]), B = X1 rows
+//           (lane = anchor), K steps dealt to the four waves, partial tiles reduced through LDS (aliasing the X1 tile).
+// Everything else (LDS-direct gathers, single staging tile per wave, weights of step s + 1 generated between the MFMAs of step s, W look-ahead,
+// 32-anchor passes, fused InstanceNorm partial sums) as in inter_so3conv_x_kernel above.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int CIN, int COUT>
+struct X32Step2 {
+    static constexpr int MT2 = COUT / 32, CH = CIN / 2, KH = CH * KS, S = KH + 44;
+    static constexpr int NSW = KH / 16 / 4;         // K steps per wave and half
+    f32x4 ra[2][MT2][3];
+    __device__ __forceinline__ void issue(int i, const bf16x8* __restrict__ Wq, int wave, int lane) {
+        const int h = i / NSW, c = i % NSW;
+        const char* b0 = reinterpret_cast<const char*>(Wq) + ((size_t)(h * (KH / 16) + wave + 4 * c) * MT2) * 3 * 1024;
+        const unsigned vo = (unsigned)lane * 16u;
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) x_wload_s(ra[i & 1][mt][pl], vo, b0 + mt * 3 * 1024, pl);
+    }
+    template <int N> __device__ __forceinline__ void wait(f32x4 (&v)[MT2][3]) {
+        if constexpr (MT2 == 2) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[1][2]) : "n"(N));
+        else asm volatile("s_waitcnt vmcnt(%3)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]) : "n"(N));
+    }
+    template <int H>
+    __device__ __forceinline__ void half(f32x16 (&y)[MT2], const float* X1s, const bf16x8* __restrict__ Wq, int wave, int lane) {
+        const int an = lane & 31, kg = lane >> 5;
+#pragma unroll
+        for (int c = 0; c < NSW; ++c) {
+            const int i = H * NSW + c;
+            asm volatile("" ::: "memory");                 // keeps the X1 reads (and their splits) of later steps from being hoisted
+            const float* xr = &X1s[an * S + (wave + 4 * c) * 16 + kg * 8];
+            bf16x8 bq[3];
+            split3_pack8p(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4), bq[0], bq[1], bq[2]);
+            if (i + 1 < 2 * NSW) { issue(i + 1, Wq, wave, lane); wait<3 * MT2>(ra[i & 1]); }
+            else wait<0>(ra[i & 1]);
+            f32x4 (&ac)[MT2][3] = ra[i & 1];
+#define X_TERM(PA, PB) _Pragma("unroll") for (int mt = 0; mt < MT2; ++mt) \
+    y[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac[mt][PA]), bq[PB], y[mt], 0, 0, 0);
+            X_TERM(2, 0) X_TERM(0, 2) X_TERM(1, 1) X_TERM(1, 0) X_TERM(0, 1) X_TERM(0, 0)
+#undef X_TERM
+        }
+    }
+};
+
+template <int CIN, int COUT, int NCH>
+__global__ void __launch_bounds__(256, INTER_X_WPE(CIN)) inter_so3conv_x32_kernel(
+    int p1, int p2, float inv_sigma, const float* __restrict__ xyz, const float* __restrict__ new_xyz, const int* __restrict__ ball_idx,
+    const unsigned short* __restrict__ Fq, const float* rk, const bf16x8* __restrict__ Wq, const float* __restrict__ bias,
+    float* __restrict__ out, const int* __restrict__ order, double* __restrict__ stat_part) {
+    constexpr int NN = 32 * NCH;
+    constexpr int AG = 32, NJ = 8, NG = 2;         // anchors per pass, per wave and pass; passes per point
+    constexpr int NT32 = CIN / 32;                 // 32-channel tiles of step 1
+    constexpr int MT2 = COUT / 32;                 // 32-wide output tiles of step 2
+    constexpr int CH = CIN / 2;                    // channels per X1 half
+    constexpr int NKR = CH / 2;                    // accumulator registers of a lane per half: CH / 4 blocks of 4 channels, every other one (by lane half)
+    constexpr int KH = CH * KS;                    // contraction length of step 2 per half
+    constexpr int S = KH + 44;                     // X1s row stride (floats): S / 4 odd -> the 32 rows of a B-fragment read start in 32 different 16-byte slots mod 16
+    constexpr int PS = COUT + 4;
+    static_assert(4 * PS <= S, "the partial table must fit the X1 tile it aliases");
+    constexpr int ROWB = 3 * CIN * 2;
+    constexpr int PPR = CIN / 8, RPI = 64 / PPR, NRB = 32 / RPI;
+    constexpr int PLB = 32 * CIN * 2, STG = 3 * PLB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X1s = smem;                             // [32][S]
+    float* part = smem;                            // [4 waves][32 cols][PS], aliases X1s between the last product of a pass and the next pass
+    float4* nbtp = reinterpret_cast<float4*>(smem + AG * S);           // [NN / 2][2]: neighbour PAIRS (x0,x1,y0,y1), (z0,z1,w0,w1) of (2 g / sigma, 1 - |g|^2 / sigma)
+    unsigned* noffs = reinterpret_cast<unsigned*>(nbtp + NN);
+    __shared__ __attribute__((aligned(16))) char stage[4 * STG];       // [4 waves][STG]: its own LDS object (see inter_so3conv_x_kernel)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    int p = blockIdx.x;
+    if (order) {
+        const int per = gridDim.x >> 3;
+        const int slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (slot >= p2) return;
+        p = order[(size_t)b * p2 + slot];
+    }
+    if (tid < NN) {
+        const int n = tid;
+        int q = ball_idx[((size_t)b * p2 + p) * NN + n];
+        const int qq = q < 0 ? 0 : q;
+        const float* X = xyz + (size_t)b * 3 * p1;
+        const float x = X[qq] - new_xyz[((size_t)b * 3 + 0) * p2 + p], y = X[p1 + qq] - new_xyz[((size_t)b * 3 + 1) * p2 + p],
+                    z = X[2 * p1 + qq] - new_xyz[((size_t)b * 3 + 2) * p2 + p];
+        float* pr = reinterpret_cast<float*>(nbtp) + (n >> 1) * 8 + (n & 1);
+        pr[0] = 2.0f * inv_sigma * x; pr[2] = 2.0f * inv_sigma * y; pr[4] = 2.0f * inv_sigma * z;
+        pr[6] = q < 0 ? -1e30f : 1.0f - (x * x + y * y + z * z) * inv_sigma;
+        noffs[n] = (unsigned)qq * (unsigned)(NA * ROWB);
+    }
+    __syncthreads();
+    // staging image of one plane of a chunk: [32 rows][CIN bf16]; CIN = 64: the two 64-byte tile segments of row r swapped when (r >> 1) & 1, so that the four
+    // rows x 64 bytes the first two lane groups of a transposing read touch cover all 64 banks.  Load side: PPR consecutive lanes fetch one row.
+    const int rl = lane / PPR, sl = lane % PPR;
+    const unsigned pieceoff = NT32 == 1 ? (unsigned)(sl * 16) : (unsigned)((4 * (((sl >> 2) - (rl >> 1)) & 1) + (sl & 3)) * 16);
+    unsigned roff[NCH][NRB];
+#pragma unroll
+    for (int t = 0; t < NCH; ++t)
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) roff[t][rb] = noffs[32 * t + RPI * rb + rl] + pieceoff;
+    const char* Fb = reinterpret_cast<const char*>(Fq) + (size_t)b * p1 * NA * ROWB;
+    char* stg = stage + wave * STG;
+    // read side: lane group g = lane / 16 -> channels 16 (g & 1) .. of the tile, rows 8 (g >> 1) + (i >> 2) + {0, 4} of the 16-row K step; i = lane % 16
+    unsigned toff[NT32];
+    {
+        const int g = lane >> 4, i = lane & 15;
+        const int r0 = 8 * (g >> 1) + (i >> 2);
+#pragma unroll
+        for (int ct = 0; ct < NT32; ++ct)
+            toff[ct] = (unsigned)(r0 * CIN * 2 + (NT32 == 1 ? 0 : 64 * ((ct + (r0 >> 1)) & 1)) + 32 * (g & 1) + 8 * (i & 3));
+    }
+    float* outp = out + ((size_t)b * p2 + p) * NA * COUT;
+    const int kp = lane & 31, kg = lane >> 5;      // this lane's kernel point (weights: column of B; X1: column of D) and neighbour group / channel sub-block
+    const bool kok = kp < KS;
+    const int kpc = kok ? kp : 0;
+
+    float rkn[2][3];
+    auto issue_rk = [&](int a, float (&dst)[3]) {
+        a = a < NA ? a : NA - 1;
+        const float* rka = rk + ((size_t)a * KS + kpc) * 3;
+        dst[0] = rka[0]; dst[1] = rka[1]; dst[2] = rka[2];
+    };
+    auto issue_rows = [&](int a, int t) {
+        a = a < NA ? a : NA - 1;
+        const char* src = Fb + (size_t)a * ROWB;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#ifdef X_ABL_NODMA
+                asm volatile("" :: "v"(src + roff[t][rb]));
+#else
+                __builtin_amdgcn_global_load_lds((x_gptr)(src + roff[t][rb] + pl * CIN * 2), (x_lptr)(stg + pl * PLB + rb * 1024), 16, 0, 0);
+#endif
+    };
+    // weight generation: 8 phases per chunk (K step h2 = phase / 4, neighbour pair pp = phase % 4); a phase = the pair's two table reads (issued GLA
+    // phases ahead), 4 packed instructions for the two weights (relu by the clamp of the last FMA), the exact split and ONE dword of each plane's fragment
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    struct WGen { f32x2 rx, ry, rz, rb; f32x4 ga[8], gb[8]; };
+    const unsigned nbt_lane = (unsigned)(uintptr_t)nbtp + (unsigned)(kg * 128);
+    constexpr int GLA = 2;
+    auto gen_begin = [&](const float (&rv)[3], WGen& G) {
+        G.rx = (f32x2){rv[0], rv[0]}; G.ry = (f32x2){rv[1], rv[1]}; G.rz = (f32x2){rv[2], rv[2]};
+        const float rb = kok ? -(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]) * inv_sigma : -1e30f;      // kernel points 24 .. 31: weight 0
+        G.rb = (f32x2){rb, rb};
+    };
+#define X32_GEN_READ(G, t, ph) do { X_LDS_READ128((G).ga[ph], nbt_lane, 32 * (16 * (t) + 8 * ((ph) >> 2) + ((ph) & 3))); \
+                                    X_LDS_READ128((G).gb[ph], nbt_lane, 32 * (16 * (t) + 8 * ((ph) >> 2) + ((ph) & 3)) + 16); } while (0)
+    auto gen_phase = [&](WGen& G, int t, int ph, u32x4 (&aw)[2][3]) {
+        if (ph + GLA < 8) X32_GEN_READ(G, t, ph + GLA);
+        if (ph + GLA < 8) x_lds_wait2<2 * GLA>(G.ga[ph], G.gb[ph]); else if (ph + 1 < 8) x_lds_wait2<2>(G.ga[ph], G.gb[ph]); else x_lds_wait2<0>(G.ga[ph], G.gb[ph]);
+        const float4 ga = make_float4(G.ga[ph][0], G.ga[ph][1], G.ga[ph][2], G.ga[ph][3]), gb = make_float4(G.gb[ph][0], G.gb[ph][1], G.gb[ph][2], G.gb[ph][3]);
+        f32x2 s = (f32x2){gb.z, gb.w} + G.rb;
+        s = __builtin_elementwise_fma((f32x2){ga.x, ga.y}, G.rx, s);
+        s = __builtin_elementwise_fma((f32x2){ga.z, ga.w}, G.ry, s);
+        const f32x2 gz = {gb.x, gb.y};
+        f32x2 w;
+        asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(w) : "v"(gz), "v"(G.rz), "v"(s));
+        const unsigned h0 = __float_as_uint(w.x), h1 = __float_as_uint(w.y);
+        const f32x2 r = w - (f32x2){__uint_as_float(h0 & 0xffff0000u), __uint_as_float(h1 & 0xffff0000u)};
+        const unsigned m0 = __float_as_uint(r.x), m1 = __float_as_uint(r.y);
+        const f32x2 q = r - (f32x2){__uint_as_float(m0 & 0xffff0000u), __uint_as_float(m1 & 0xffff0000u)};
+        const int h2 = ph >> 2, pp = ph & 3;
+        aw[h2][0][pp] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+        aw[h2][1][pp] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+        aw[h2][2][pp] = __builtin_amdgcn_perm(__float_as_uint(q.y), __float_as_uint(q.x), 0x07060302u);
+    };
+    auto anchor_of = [&](int q) { return (q / NJ) * AG + wave * NJ + (q % NJ); };
+    issue_rk(anchor_of(0), rkn[0]);
+    issue_rk(anchor_of(1), rkn[1]);
+    issue_rows(anchor_of(0), 0);
+    u32x4 aws[2][2][3];                             // [step parity][K step of the chunk][plane]
+    {
+        // `rk` is deliberately NOT __restrict__: its loads must stay between the memory-clobbering waits they were written between.  The compiler's own
+        // counted vmcnt waits assume in-order completion of everything it issued, but LDS-direct loads and plain loads complete out of order with
+        // respect to each other on this chip: a younger LDS-direct load retiring first satisfies the count while the kernel-point load is in flight.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WGen G;
+        gen_begin(rkn[0], G);
+#pragma unroll
+        for (int e = 0; e < GLA; ++e) X32_GEN_READ(G, 0, e);
+#pragma unroll
+        for (int ph = 0; ph < 8; ++ph) gen_phase(G, 0, ph, aws[0]);
+    }
+
+    // X1 store addresses of this lane: kernel point kp, channel blocks (2 q + kg) ^ sw(kp), q < NKR / 4
+    int xoff[NKR / 4];
+#pragma unroll
+    for (int q = 0; q < NKR / 4; ++q) xoff[q] = kp * CH + 4 * (((2 * q + kg) ^ (CH == 16 ? (kp >> 1) & 3 : kp & 7)));
+
+    double st_s = 0.0, st_q = 0.0;
+    f32x16 y[MT2];
+#pragma unroll 1
+    for (int ag = 0; ag < NG; ++ag) {
+        float keep[NJ][NT32 == 1 ? 8 : 16];        // second channel half of the wave's anchors
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int col = wave * NJ + j;
+            const int q = ag * NJ + j;
+            const int a = ag * AG + col;
+            const int a_next = anchor_of(q + 1);
+            f32x16 acc[NT32];
+#pragma unroll
+            for (int t = 0; t < NCH; ++t) {
+                const int sp = (j * NCH + t) & 1;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this chunk's rows have landed in LDS
+                bf16x8 bf[NT32][2][3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int ct = 0; ct < NT32; ++ct)
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const char* pa = stg + pl * PLB + toff[ct] + 16 * h2 * CIN * 2;
+                            const bf16x4 lo4 = x_tr16(pa), hi4 = x_tr16(pa + 4 * CIN * 2);
+                            bf[ct][h2][pl] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
+                WGen G;
+                const int tn = t + 1 < NCH ? t + 1 : 0;
+#pragma unroll
+                for (int e = 0; e < GLA; ++e) X32_GEN_READ(G, tn, e);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers: the staging tile may be overwritten
+                if (t + 1 < NCH) issue_rows(a, t + 1);
+                else if (a_next < 64) issue_rows(a_next, 0);
+                if (t == NCH - 1) issue_rk(anchor_of(q + 2), rkn[j & 1]);
+                {
+                    u32x4 (&aw)[2][3] = aws[sp];
+                    u32x4 (&awn)[2][3] = aws[sp ^ 1];
+                    gen_begin(t + 1 < NCH ? rkn[j & 1] : rkn[(j + 1) & 1], G);
+                    constexpr int NMF = 12 * NT32;
+                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+                    // the matrix instructions go between the first NPM generation phases (the tail of the generation runs beside the last of them)
+                    constexpr int NPM = 6;
+#pragma unroll
+                    for (int ph = 0; ph < 8; ++ph) {
+                        gen_phase(G, tn, ph, awn);
+#pragma unroll
+                        for (int mi = ph * NMF / NPM; mi < (ph + 1) * NMF / NPM && ph < NPM; ++mi) {
+                            const int ct = mi % NT32, term = (mi / NT32) % 6, h2 = mi / (6 * NT32);
+#ifndef X_ABL_NOMFMA1
+                            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ct][h2][PB[term]], __builtin_bit_cast(bf16x8, aw[h2][PA[term]]),
+                                                                              (t == 0 && mi < NT32) ? (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : acc[ct], 0, 0, 0);
+#else
+                            asm volatile("" :: "v"(aw[h2][PA[term]]), "v"(bf[ct][h2][PB[term]]));
+                            if (t == 0 && mi < NT32) acc[ct] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+                        }
+                    }
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) {
+                            asm volatile("" :: "v"(aw[h2][pl]));                    // operands stay allocated until here (keeps the accumulator tuple of the next anchor off them)
+#pragma unroll
+                            for (int ct = 0; ct < NT32; ++ct) asm volatile("" :: "v"(bf[ct][h2][pl]));
+                        }
+                }
+            }
+            // anchor end.  D[c][k]: this lane = kernel point kp, channels 8 (v / 4) + 4 kg + v % 4 of each 32-channel tile: first half -> LDS, second half parked
+            float* xcol = X1s + col * S;
+            if (kok) {
+#pragma unroll
+                for (int q4 = 0; q4 < NKR / 4; ++q4)
+                    *reinterpret_cast<float4*>(xcol + xoff[q4]) = make_float4(acc[0][4 * q4], acc[0][4 * q4 + 1], acc[0][4 * q4 + 2], acc[0][4 * q4 + 3]);
+            }
+#pragma unroll
+            for (int v = 0; v < NKR; ++v) keep[j][v] = NT32 == 1 ? acc[0][NKR + v] : acc[NT32 - 1][v];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) y[mt][v] = 0.f;
+#ifndef X_ABL_NOSTEP2
+        X32Step2<CIN, COUT> s2;
+        const bf16x8* Wq_g = Wq;
+        asm volatile("" : "+s"(Wq_g));
+        s2.issue(0, Wq_g, wave, lane);
+        __syncthreads();
+        s2.template half<0>(y, X1s, Wq_g, wave, lane);
+#endif
+        __syncthreads();
+        if (kok) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float* xcol = X1s + (wave * NJ + j) * S;
+#pragma unroll
+                for (int q4 = 0; q4 < NKR / 4; ++q4)
+                    *reinterpret_cast<float4*>(xcol + xoff[q4]) = make_float4(keep[j][4 * q4], keep[j][4 * q4 + 1], keep[j][4 * q4 + 2], keep[j][4 * q4 + 3]);
+            }
+        }
+        __syncthreads();
+#ifndef X_ABL_NOSTEP2
+        s2.template half<1>(y, X1s, Wq_g, wave, lane);
+#endif
+        __syncthreads();                                // every wave finished reading X1s: the partial table may overwrite it
+        // y[mt][v] = Y[o = 32 mt + 8 (v / 4) + 4 kg + v % 4][anchor column = lane % 32]
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+                *reinterpret_cast<float4*>(&part[(wave * AG + kp) * PS + 32 * mt + 8 * q4 + 4 * kg]) = make_float4(y[mt][4 * q4], y[mt][4 * q4 + 1], y[mt][4 * q4 + 2], y[mt][4 * q4 + 3]);
+        __syncthreads();
+        for (int e = tid; e < AG * COUT; e += 256) {
+            const int col = e / COUT, o = e - col * COUT;
+            const int a = ag * AG + col;
+            if (a < NA) {
+                float v = part[(0 * AG + col) * PS + o] + part[(1 * AG + col) * PS + o];
+                v += part[(2 * AG + col) * PS + o] + part[(3 * AG + col) * PS + o];
+                v += bias[o];
+                outp[(size_t)a * COUT + o] = v;
+                st_s += (double)v; st_q += (double)v * (double)v;
+            }
+        }
+        __syncthreads();                                // the table is read: the next pass may write X1s
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (stat_part) {
+        static_assert(256 % COUT == 0, "a thread must keep one output channel");
+        double* dred = reinterpret_cast<double*>(part);
+        dred[tid] = st_s; dred[256 + tid] = st_q;
+        __syncthreads();
+        if (tid < COUT) {
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 256 / COUT; ++k) { a0 += dred[k * COUT + tid]; a1 += dred[256 + k * COUT + tid]; }
+            double* sp = stat_part + ((size_t)b * p2 + p) * 2 * COUT;
+            sp[tid] = a0; sp[COUT + tid] = a1;
+        }
+    }
+}
+
+template <int CIN, int COUT, int NCH>
+static int launch_x32(int b, int p1, int p2, float sigma, const float* xyz, const float* new_xyz, const int* idx, const void* Fq, const float* rk,
+                      const void* Wq, const float* bias, float* out, const int* order, double* stat_part, hipStream_t st) {
+    constexpr int NN = 32 * NCH;
+    const size_t lds = (size_t)(32 * ((CIN / 2) * KS + 44) + 5 * NN) * sizeof(float);
+    auto kern = inter_so3conv_x32_kernel<CIN, COUT, NCH>;
+    {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    const unsigned gx = order ? 8u * (unsigned)((p2 + 7) / 8) : (unsigned)p2;
+    hipLaunchKernelGGL(kern, dim3(gx, b), dim3(256), lds, st, p1, p2, 1.0f / sigma, xyz, new_xyz, idx, reinterpret_cast<const unsigned short*>(Fq), rk,
+                       reinterpret_cast<const bf16x8*>(Wq), bias, out, order, stat_part);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
 // x [rows][C] fp32 -> planes [rows][3][C] bf16 (exact split); thread = 4 consecutive channels
 __global__ void __launch_bounds__(256) split3_planes_kernel(long n4, int C, const float* __restrict__ x, unsigned short* __restrict__ planes) {
     const int c4 = C >> 2;
@@ -440,9 +813,9 @@ static int launch_x(int b, int p1, int p2, float sigma, const float* xyz, const 
     constexpr int NN = 32 * NCH;
     constexpr int AG = INTER_X_AG(CIN, COUT);
     constexpr int NBUF = INTER_X_NBUF(CIN, COUT);
-    const size_t lds = (size_t)(AG * (CIN * KS / 2 + 40) + 5 * NN) * sizeof(float) + (size_t)4 * NBUF * 3 * (CIN / 16) * 1024;
+    const size_t lds = (size_t)(AG * (CIN * KS / 2 + 40) + 5 * NN) * sizeof(float);      // dynamic part: X1 tile + neighbour table (the staging tiles are static)
     auto kern = inter_so3conv_x_kernel<CIN, COUT, NCH, AG, NBUF>;
-    if (lds > 64 * 1024) {
+    {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
@@ -482,6 +855,27 @@ int etch_inter_so3conv_planes(int b, int cin, int cout, int p1, int p2, int nn, 
 #define X_CASE(CI, CO, NC) \
     if (cin == CI && cout == CO && nn == 32 * NC) return launch_x<CI, CO, NC>(b, p1, p2, sigma, xyz, new_xyz, ball_idx, feats_planes, rk, Wq, bias, out, order, stat_part, st);
     X_CASE(32, 32, 1) X_CASE(32, 32, 2) X_CASE(32, 64, 1) X_CASE(32, 64, 2) X_CASE(64, 64, 1) X_CASE(64, 64, 2)
+#undef X_CASE
+    return ETCH_EUNSUPPORTED;
+}
+
+// The same on v_mfma_f32_32x32x16_bf16 (inter_so3conv_x32_kernel).  Wq32 = ops.inter_weight_split32: [K step of 16][o tile of 32][plane][lane][8] in the
+// kernel's physical contraction order.
+int etch_inter_so3conv_planes32(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
+                                const int* ball_idx, const void* feats_planes, const float* rk, const void* Wq32, const float* bias, float* out,
+                                const int* order, double* stat_part, void* stream) {
+    if (b <= 0 || p2 <= 0) return ETCH_OK;
+    if (sigma <= 0.f || !Wq32 || !feats_planes) return ETCH_EINVAL;
+    if (((uintptr_t)feats_planes & 15) || ((uintptr_t)Wq32 & 15)) return ETCH_EINVAL;
+    if ((size_t)p1 * NA * 3 * cin * 2 >= ((size_t)1 << 32)) return ETCH_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+#define X_CASE(CI, CO, NC) \
+    if (cin == CI && cout == CO && nn == 32 * NC) return launch_x32<CI, CO, NC>(b, p1, p2, sigma, xyz, new_xyz, ball_idx, feats_planes, rk, Wq32, bias, out, order, stat_part, st);
+    // 64 input channels only.  The 32-channel instantiations (two workgroups per CU: a 256-register budget, accumulators in VGPRs) compute wrong kernel
+    // points 16 .. 23 for some anchors -- run-to-run varying, gone with a 512-register budget (accumulators in AGPRs), at -O1 and without inlining;
+    // X1 / weight dumps, operand-overwrite and dependent-chain microbenchmarks (profiles/r04_x32_cin32_miscompile.txt) did not find the cause.  Those
+    // shapes stay on the 16x16x32 kernel.
+    X_CASE(64, 64, 1) X_CASE(64, 64, 2)
 #undef X_CASE
     return ETCH_EUNSUPPORTED;
 }

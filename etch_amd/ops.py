@@ -203,6 +203,23 @@ def inter_weight_split(W, cin, ks=24, natural=False):
     return q.permute(3, 1, 0, 4, 2, 5).contiguous().reshape(-1)          # [tg][mt][pl][kg][ol][e]
 
 
+def inter_weight_split32(W, cin, ks=24):
+    """Weight of etch_inter_so3conv_planes32 (v_mfma_f32_32x32x16_bf16): the columns of W [cout, cin*24] in the kernel's PHYSICAL contraction order --
+    per channel half h (CH = cin / 2 channels), kernel point k, 16-byte block pb, element i: channel h*CH + 4*(pb ^ sw(k)) + i with the X1 tile's
+    store swizzle sw(k) = (k >> 1) & 3 (CH = 16) / k & 7 (CH = 32) -- split into three bf16 planes, in A-fragment order
+    [K step of 16][o tile of 32][plane][lane = 32 * (kappa / 8 % 2) + o % 32][8]."""
+    cout = W.shape[0]
+    assert ks == 24 and cin in (32, 64) and cout % 32 == 0 and W.shape[1] == cin * ks
+    ch = cin // 2
+    cols = [(h * ch + 4 * (pb ^ (((k >> 1) & 3) if ch == 16 else (k & 7))) + i) * ks + k
+            for h in range(2) for k in range(ks) for pb in range(ch // 4) for i in range(4)]
+    assert sorted(cols) == list(range(cin * ks))
+    planes = split3_bf16(W[:, torch.tensor(cols, dtype=torch.long, device=W.device)])     # [3][cout][K]
+    K = cin * ks
+    q = planes.reshape(3, cout // 32, 32, K // 16, 2, 8)                 # [pl][mt][o][s][kg][e]
+    return q.permute(3, 1, 0, 4, 2, 5).contiguous().reshape(-1)          # [s][mt][pl][kg][o][e]
+
+
 def intra_weight_split(w2):
     """W2 [C, 12 C] (tap-major K: W2[o, tap * C + ch]) -> the register-resident fragments of the weight-stationary intra conv
     (csrc/so3conv_ws.hip): [mt][kq][K step][plane][lane = 32 * (k / 8) + o % 32][8] with k = 3 kq C + 16 ks + 8 (lane / 32) + e."""
@@ -231,6 +248,12 @@ INTER_SPLIT = os.environ.get("ETCH_INTER_SPLIT", "1") != "0"      # step 2 of th
 INTER_MFMA32 = os.environ.get("ETCH_INTER_MFMA32", "0") == "1"     # (32|64) -> (32|64) channels: the 32x32x2 MFMA form, two points per workgroup
 INTER_MFMA32_SHAPES = ((32, 32), (32, 64), (64, 64))
 INTER_X = os.environ.get("ETCH_INTER_X", "1") != "0"             # both contractions of the inter conv on the bf16 matrix cores, gathered rows as bf16 planes (csrc/so3conv_x.hip)
+INTER_X32 = os.environ.get("ETCH_INTER_X", "1") != "16"          # 64 input channels: the 32x32x16 MFMA form (ETCH_INTER_X=16: the 16x16x32 form everywhere)
+
+
+def inter_planes_form(cin):
+    """MFMA shape of the planes kernel for this width: 32 (etch_inter_so3conv_planes32, 64 input channels) or 16 (etch_inter_so3conv_planes)."""
+    return 32 if (INTER_X32 and cin == 64) else 16
 
 
 def inter_planes_supported(cin, cout, nn):
@@ -260,11 +283,11 @@ def spatial_order(xyz):
 
 
 def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, order=None, want_stats=False, Wp32=None, Wq=None, Wqn=None,
-                  feats_planes=None):
+                  feats_planes=None, Wq32=None):
     """feats_cl (b,p1,60,cin) channels-last -> (b,p2,60,cout) pre-norm.  order (b,p2) int32: processing order of the output points.
     want_stats: also return the InstanceNorm (mean, rstd) of the output, accumulated in the conv's epilogue.
-    Wqn (inter_weight_split(natural=True)): both contractions on the bf16 matrix cores where the shape is covered; feats_planes
-    (b,p1,60,3,cin) int16 = the producer's split of feats_cl (made here when absent)."""
+    Wq32 (inter_weight_split32) / Wqn (inter_weight_split(natural=True)): both contractions on the bf16 matrix cores where the shape is covered
+    (32x32x16 / 16x16x32 MFMA form); feats_planes (b,p1,60,3,cin) int16 = the producer's split of feats_cl (made here when absent)."""
     b, p1, na, cin = feats_cl.shape
     p2, nn = ball_idx.shape[1], ball_idx.shape[2]
     cout = W.shape[0]
@@ -277,7 +300,16 @@ def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, orde
     out = torch.empty((b, p2, 60, cout), dtype=torch.float32, device=xyz.device)
     fused = want_stats and 256 % cout == 0 and (cin >= 16 or cin == 1)
     part = torch.empty((b, p2, 2, cout), dtype=torch.float64, device=xyz.device) if fused else None
-    if Wqn is not None and inter_planes_supported(cin, cout, nn):
+    if Wq32 is not None and inter_planes_form(cin) == 32 and inter_planes_supported(cin, cout, nn):
+        _need(Wq32, torch.int16, "Wq32")
+        if feats_planes is None:
+            feats_planes = split3_planes(feats_cl)
+        _need(feats_planes, torch.int16, "feats_planes")
+        assert tuple(feats_planes.shape) == (b, p1, na, 3, cin)
+        _lib.check(_lib.lib().etch_inter_so3conv_planes32(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
+                                                         _ptr(feats_planes), _ptr(rk), _ptr(Wq32), _ptr(bias), _ptr(out), _optptr(order),
+                                                         _optptr(part), _stream()), "etch_inter_so3conv_planes32")
+    elif Wqn is not None and inter_planes_supported(cin, cout, nn):
         _need(Wqn, torch.int16, "Wqn")
         if feats_planes is None:
             feats_planes = split3_planes(feats_cl)

@@ -129,6 +129,7 @@ class InterSO3Conv(nn.Module):
         self._d32 = _Derived()
         self._dq = _Derived()
         self._dqn = _Derived()
+        self._dq32 = _Derived()
 
     def _derived(self):
         W, bias = self.basic_conv.W, self.basic_conv.bias
@@ -163,6 +164,13 @@ class InterSO3Conv(nn.Module):
             return None
         W = self.basic_conv.W
         return self._dqn.get((W,), lambda: ops.inter_weight_split(W.detach().contiguous(), self.dim_in, self.kernel_size, natural=True))
+
+    def _wq32(self):
+        """The planes in the physical contraction order of the 32x32x16 kernel (etch_inter_so3conv_planes32); None where it has no instantiation."""
+        if not (self.wants_planes() and ops.inter_planes_form(self.dim_in) == 32):
+            return None
+        W = self.basic_conv.W
+        return self._dq32.get((W,), lambda: ops.inter_weight_split32(W.detach().contiguous(), self.dim_in, self.kernel_size))
 
     def wants_planes(self):
         """True if this conv gathers its input as bf16 planes (its producer should emit them: SeparableSO3ConvBlock.emit_planes)."""
@@ -199,7 +207,7 @@ class InterSO3Conv(nn.Module):
             sample_idx, new_xyz = None, xyz
         rk, W, Wp, bias = self._derived()
         y, stats = ops.inter_so3conv(xyz, new_xyz, inter_idx, x.feats_cl, rk, W, Wp, bias, self.sigma, order=self.order(new_xyz), want_stats=True, Wp32=self._wp32(), Wq=self._wq(),
-                                     Wqn=self._wqn(), feats_planes=getattr(x, "feats_planes", None))
+                                     Wqn=None if ops.inter_planes_form(self.dim_in) == 32 else self._wqn(), Wq32=self._wq32(), feats_planes=getattr(x, "feats_planes", None))
         cloud = SphericalPointCloud(new_xyz, None, self.anchors, feats_cl=y)
         cloud.in_stats = stats          # InstanceNorm (mean, rstd) of the output, a by-product of the conv's epilogue
         return inter_idx, None, sample_idx, cloud

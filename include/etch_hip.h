@@ -146,6 +146,12 @@ int etch_inter_so3conv_planes(int b, int cin, int cout, int p1, int p2, int nn, 
                               const int* ball_idx, const void* feats_planes, const float* rk, const void* Wq, const float* bias, float* out,
                               const int* order, double* stat_part, void* stream);
 int etch_inter_so3conv_planes_supported(int cin, int cout, int nn);
+/* The same on v_mfma_f32_32x32x16_bf16, the bf16 shape that issues at the matrix peak on this chip (profiles/r04_mfma_bf16_issue_rates.txt; the 16x16x32
+ * shape of the entry above reaches 0.55 - 0.6 of it).  Wq32: 3 * cout * cin * 24 bf16 = [K step of 16][o tile of 32][plane][lane][8] in the kernel's
+ * physical contraction order (etch_amd/ops.py inter_weight_split32).  Same shapes, same result up to the order of the fp32 sums. */
+int etch_inter_so3conv_planes32(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
+                                const int* ball_idx, const void* feats_planes, const float* rk, const void* Wq32, const float* bias, float* out,
+                                const int* order, double* stat_part, void* stream);
 
 /* x (rows, C) fp32 -> planes (rows, 3, C) bf16: the exact split x = hi + mid + lo (8 + 8 + 8 mantissa bits, by truncation). */
 int etch_split3_planes(long rows, int C, const float* x, void* planes, void* stream);

@@ -26,7 +26,7 @@ for name, cin, cout, nn, radius, sigma, xyz, p2 in shapes:
     planes = ops.split3_planes(feats)
     order = ops.spatial_order(new_xyz)
     res = {}
-    for label, kw in (("r03 split", dict(Wq=conv._wq())), ("planes", dict(Wqn=conv._wqn(), feats_planes=planes))):
+    for label, kw in (("r03 split", dict(Wq=conv._wq())), ("planes16", dict(Wqn=conv._wqn(), feats_planes=planes)), ("planes", dict(Wq32=conv._wq32(), feats_planes=planes) if cin == 64 else dict(Wqn=conv._wqn(), feats_planes=planes))):
         f = lambda: ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, sigma, order=order, want_stats=True, **kw)
         y = f()
         torch.cuda.synchronize()
@@ -38,4 +38,4 @@ for name, cin, cout, nn, radius, sigma, xyz, p2 in shapes:
         torch.cuda.synchronize()
         res[label] = (e0.elapsed_time(e1) / reps, y[0])
     d = float((res["planes"][1] - res["r03 split"][1]).abs().max()) / float(res["r03 split"][1].abs().max())
-    print(f"{name} {cin}->{cout} nn={nn} p2={p2}: r03 {res['r03 split'][0]:.3f} ms, planes {res['planes'][0]:.3f} ms, max diff / scale {d:.2e}", flush=True)
+    print(f"{name} {cin}->{cout} nn={nn} p2={p2}: r03 {res['r03 split'][0]:.3f} ms, planes16 {res['planes16'][0]:.3f} ms, planes32 {res['planes'][0]:.3f} ms, max diff / scale {d:.2e}", flush=True)

@@ -28,10 +28,11 @@ def test_split3_planes_are_exact_and_match_the_host_split():
     assert torch.equal(out, out_p) and torch.equal(pl, ops.split3_planes(out))
 
 
+@pytest.mark.parametrize("form", [32, 16])
 @pytest.mark.parametrize("cin,cout,nn,p1,p2", [(32, 32, 32, 301, 149), (32, 64, 64, 211, 60), (64, 64, 32, 211, 101), (32, 32, 64, 130, 1),
                                                 (32, 64, 32, 97, 97), (64, 64, 64, 150, 33)])
-def test_inter_conv_planes_matches_the_fp32_kernel_and_fp64(cin, cout, nn, p1, p2):
-    """etch_inter_so3conv_planes (BOTH contractions on the bf16 matrix cores: fp32 operands split exactly into three bf16 values, six cross
+def test_inter_conv_planes_matches_the_fp32_kernel_and_fp64(cin, cout, nn, p1, p2, form):
+    """etch_inter_so3conv_planes32 / etch_inter_so3conv_planes (32x32x16 / 16x16x32 MFMA form; BOTH contractions on the bf16 matrix cores: fp32 operands split exactly into three bf16 values, six cross
     products each; gathered rows as producer-written planes through LDS-direct loads + transposing LDS reads) against the fp32-MFMA kernel
     (the same sums in another order) and the fp64 formula under the entitled-error rule; bitwise reproducible, schedule-independent;
     padded neighbourhoods (radius smaller than the cloud: cyclic padding) included."""
@@ -45,14 +46,16 @@ def test_inter_conv_planes_matches_the_fp32_kernel_and_fp64(cin, cout, nn, p1, p
     ball = ops.ball_query(new_xyz, xyz, 0.25, nn)
     conv = load_seeded(V.InterSO3Conv(cin, cout, 1, 2, 0.25, 0.03, nn), 3).cuda()
     rk, W, Wp, bias = conv._derived()
-    Wqn = conv._wqn()
-    assert Wqn is not None
+    if form == 32 and cin != 64:
+        pytest.skip("the 32x32x16 form is instantiated for 64 input channels only")
+    wkw = dict(Wq32=conv._wq32()) if form == 32 else dict(Wqn=conv._wqn())
+    assert all(v is not None for v in wkw.values())
     feats = torch.randn(b, p1, 60, cin, generator=g).cuda()
     planes = ops.split3_planes(feats)
     f32, (m0, r0) = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, want_stats=True)
-    new, (m1, r1) = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, want_stats=True, Wqn=Wqn, feats_planes=planes,
-                                      order=ops.spatial_order(new_xyz))
-    again = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, Wqn=Wqn)        # planes made on the fly, plain order
+    new, (m1, r1) = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, want_stats=True, feats_planes=planes,
+                                      order=ops.spatial_order(new_xyz), **wkw)
+    again = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, **wkw)        # planes made on the fly, plain order
     assert torch.equal(new, again)
     scale = float(f32.abs().max())
     assert float((new - f32).abs().max()) < 2e-6 * scale, float((new - f32).abs().max()) / scale
