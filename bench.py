@@ -54,6 +54,9 @@ def build(device, seed=1, body="smpl"):
 
 
 # ------------------------------------------------------------------------------------------------ roofline
+SPLIT_RATE_TFLOPS = 403.0     # fp32 products per second on the bf16 matrix cores as six-term splits: 2418 TFLOP/s measured for v_mfma_f32_32x32x16_bf16 / 6 (profiles/r04_mfma_bf16_issue_rates.txt)
+
+
 def algorithmic_flops(name, a):
     """Algorithmic FLOPs of one C-ABI call from its integer arguments (DESIGN.md 'work per launch')."""
     v = [x.value if hasattr(x, "value") else x for x in a]
@@ -67,6 +70,10 @@ def algorithmic_flops(name, a):
     if name in ("etch_inter_so3conv", "etch_inter_so3conv_ordered", "etch_inter_so3conv_split"):
         b, cin, cout, p1, p2, nn = v[0:6]
         kern = "inter_so3conv_c1_kernel" if cin == 1 else f"inter_so3conv_kernel<{cin},{cout},{(nn + 15) // 16 if nn <= 32 else 4}{',split' if name.endswith('split') else ''}>"
+        return 2.0 * b * p2 * 60 * 24 * (cin * nn + cout * cin), kern
+    if name in ("etch_inter_so3conv_planes", "etch_inter_so3conv_planes32"):     # both contractions on the bf16 matrix cores (csrc/so3conv_x.hip)
+        b, cin, cout, p1, p2, nn = v[0:6]
+        kern = f"inter_so3conv_x32_kernel<{cin},{cout},{nn // 32}>" if name.endswith("32") else f"inter_so3conv_x_kernel<{cin},{cout},{nn // 32}>"
         return 2.0 * b * p2 * 60 * 24 * (cin * nn + cout * cin), kern
     if name == "etch_inter_so3conv32":
         b, cin, cout, p1, p2, nn = v[0:6]
@@ -117,7 +124,7 @@ def profile_pass(run_step):
         d["calls"] += 1
         d["ms"] += s.elapsed_time(e)
         d["flops"] += fl
-    return agg
+    return agg, rec
 
 
 def single_scan_latency(args, model, device, n_points, reps=15):
@@ -334,6 +341,36 @@ def launch_ranks(n, argv):
     return 0
 
 
+def preflight(a):
+    """`bench.py --gpus N --preflight`: one JSON line describing the N-rank job (no GPU call, no process group, no child process)."""
+    from etch_amd import parallel as P
+    cfg = {"batch": 8, "points": 20000} if a.config == 4 else {"batch": 32, "points": 5000}
+    B, N, world = a.batch or cfg["batch"], a.points or cfg["points"], a.gpus
+    ranks = []
+    for r in range(world):
+        s0, s1 = P.shard_range(B * world, r, world)
+        try:
+            cpus = sorted(P.local_cpu_set(r, world)) if world > 1 and not a.no_pin else None
+            cpu_note = None
+        except Exception as e:                       # unreadable topology: the run itself would go on unpinned and say so
+            cpus, cpu_note = None, f"{type(e).__name__}: {e}"
+        ranks.append({"rank": r, "local_rank": r, "device": f"cuda:{r}", "scans": [s0, s1], "scan_seeds": [1000 + s0, 1000 + s1 - 1],
+                      "cpu_set": None if cpus is None else f"{len(cpus)} cpus: {cpus[0]}..{cpus[-1]}", "cpu_pinning_error": cpu_note})
+    env_keys = ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "NCCL_SOCKET_IFNAME", "NCCL_IB_DISABLE", "RCCL_MSCCL_ENABLE", "HIP_VISIBLE_DEVICES",
+                "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_MAX_HW_QUEUES", "MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE", "RANK", "LOCAL_RANK",
+                "ETCH_DIST_BACKEND", "ETCH_FORCE_DIST")
+    out = {"preflight": True, "n_gpus": world, "config": a.config, "scans_per_gpu": B, "points": N, "global_batch": B * world, "scaling": "weak",
+           "launcher": "torchrun/env" if "TORCHELASTIC_RUN_ID" in os.environ else ("self: bench.py starts its own ranks" if world > 1 else "single process"),
+           "rendezvous": {"addr": os.environ.get("MASTER_ADDR", "127.0.0.1"), "port": os.environ.get("MASTER_PORT", "chosen at launch")},
+           "collective": {"backend": os.environ.get("ETCH_DIST_BACKEND", "nccl (= RCCL)") if world > 1 else None,
+                          "calls": "1 barrier + 1 all_reduce(MAX) of the timing + 1 all_gather of 7 floats per scan at the end of the job; none on the data path"},
+           "child_env_overrides": {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "MASTER_ADDR": "127.0.0.1"} if world > 1 and "RANK" not in os.environ else {},
+           "env": {k: os.environ[k] for k in env_keys if k in os.environ},
+           "host": {"cpus_online": os.cpu_count(), "torch": torch.__version__, "hip": getattr(torch.version, "hip", None), "gpus_visible": torch.cuda.device_count()},
+           "ranks": ranks}
+    print(json.dumps(out), flush=True)
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -361,9 +398,15 @@ def main():
     ap.add_argument("--stage1-streams", type=int, default=1, help="stage-1 streams the pipeline alternates over (batches in flight = this + 1)")
     ap.add_argument("--concurrent-heads", type=int, default=1, help="1: confidence / magnitude nets on their own streams next to the direction head")
     ap.add_argument("--graph-latency-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--preflight", action="store_true", help="print, WITHOUT touching a GPU, what each of the --gpus N ranks would do: its shard of the "
+                    "global batch, the CPU set it would pin itself to, the rendezvous and the RCCL-relevant environment -- so that a failed scaling run "
+                    "can be diagnosed from its log")
     a = ap.parse_args()
     if a.graph_latency_child:
         graph_latency_child(a.points or 5000)
+        return
+    if a.preflight:
+        preflight(a)
         return
     if a.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(a.gpus, sys.argv[1:]))          # parent: no GPU call before or after this point
@@ -390,10 +433,13 @@ def main():
         # single-scan latency as ONE HIP graph, measured in a child process that owns the GPU alone: started (and finished) BEFORE this
         # process makes its first GPU call, so neither side shares hardware queues with the other
         import subprocess
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--graph-latency-child", "--points", str(a.points or 5000)],
-                           capture_output=True, text=True, timeout=900)
-        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        latency_child = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": (r.stderr or "no output")[-400:]}
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--graph-latency-child", "--points", str(a.points or 5000)],
+                               capture_output=True, text=True, timeout=900)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            latency_child = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": (r.stderr or "no output")[-400:]}
+        except (subprocess.TimeoutExpired, OSError, ValueError) as e:     # a hung or unstartable child must not abort the bench: the error is reported
+            latency_child = {"error": f"{type(e).__name__}: {str(e)[-300:]}"}
     dry = bool(os.environ.get("ETCH_BENCH_DRY"))                # control-flow test of the N > 1 path without a GPU (tests/test_parallel_gloo.py)
     if dry and os.environ.get("ETCH_BENCH_DRY_FAIL_RANK") == str(rank):
         sys.exit(3)                                             # failure injection for the launcher test
@@ -561,17 +607,20 @@ def main():
     with torch.no_grad():
         step()
         torch.cuda.synchronize()
-        agg = profile_pass(step)
+        agg, agg_calls = profile_pass(step)
         model.concurrent_heads, model.overlap_index_ops = saved
         stage1_only()
     tot_ms = sum(d["ms"] for d in agg.values())
     # dominant kernel = the kernel FUNCTION with the largest share of the step (template instantiations of one kernel are
     # one kernel: the three inter_so3conv_kernel<CIN,COUT,MAXT> launches of a step are priced together)
+    def family(k):      # the inter conv of a step is ONE kernel family: its 16x16x32 (32 input channels) and 32x32x16 (64 input channels) instantiations are priced together
+        return "inter_so3conv_x_kernel" if k.startswith("inter_so3conv_x32_kernel") else k.split("<")[0]
     fam = collections.OrderedDict()
     for k, v in agg.items():
-        f = fam.setdefault(k.split("<")[0], dict(calls=0, ms=0.0, flops=0.0))
+        f = fam.setdefault(family(k), dict(calls=0, ms=0.0, flops=0.0, members=[]))
         for key in ("calls", "ms", "flops"):
             f[key] += v[key]
+        f["members"].append(k)
     # ... among the chip-wide kernels: the LM fit and FPS run one workgroup per scan (8 - 32 of 256 CUs) and are bound by their
     # dependent iterations, not by a chip-level roofline; when one of them is the longest launch (the 8-scan dense shard of configs[4])
     # it is named in `longest_kernel` and the roofline stays with the widest arithmetic kernel
@@ -584,19 +633,47 @@ def main():
     import glob
     for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):     # newest round / pass first
         tab = json.load(open(pmc))
-        ents = [v for k, v in tab.items() if k == kern or k.startswith(kern + "<")]     # template variants of the kernel: launch-weighted mean
+        ents = [v for k, v in tab.items() if family(k.replace(" ", "")) == kern]     # template variants of the kernel: launch-weighted mean
         if ents:
             n = sum(e["launches_profiled"] for e in ents)
             traffic = round(sum(e["bytes_per_launch"] * e["launches_profiled"] for e in ents) / n)
             break
-    out["roofline"] = {"bound": "mfma", "kernel": kern, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                       "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+    # algorithmic HBM bytes per launch of the dominant kernel (unique input + output): the gathered rows once (three bf16 planes = 6 bytes per
+    # element for the planes kernels, 4 otherwise), the output once; and the matrix-pipe busy share of its instantiations from the newest committed counter pass
+    alg_bytes = None
+    if kern.startswith("inter_so3conv"):
+        tot_b, n_b = 0.0, 0
+        for name_, args_, _, _ in agg_calls:
+            if name_.startswith("etch_inter_so3conv"):
+                v_ = [x.value if hasattr(x, "value") else x for x in args_]
+                b_, cin_, cout_, p1_, p2_, nn_ = v_[0:6]
+                if cin_ > 1:
+                    tot_b += b_ * p1_ * 60.0 * cin_ * (6 if "planes" in name_ else 4) + b_ * p2_ * 60.0 * cout_ * 4 + b_ * p2_ * nn_ * 4.0
+                    n_b += 1
+        alg_bytes = round(tot_b / n_b) if n_b else None
+    pipe_busy = None
+    for f_ in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma.txt")), reverse=True):
+        got = {}
+        for ln in open(f_):
+            if "matrix pipe busy" in ln and not ln.startswith("#"):
+                nm = ln.split(" launches")[0].replace("void ", "").strip()
+                if family(nm.replace(" ", "")) == kern:
+                    got[nm] = float(ln.split("matrix pipe busy")[1].split()[0])
+        if got:
+            pipe_busy = {"source": os.path.basename(f_), "per_instantiation": got}
+            break
+    out["roofline"] = {"bound": "mfma", "kernel": kern, "instantiations": d["members"], "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                       "traffic_over_algorithmic": round(traffic / alg_bytes, 2) if traffic and alg_bytes else None,
+                       "matrix_pipe_busy": pipe_busy,
                        "launches_per_step": d["calls"], "avg_launch_ms": round(d["ms"] / d["calls"], 4),
                        "algorithmic_gflop_per_launch": round(d["flops"] / d["calls"] / 1e9, 3),
                        "share_of_step": round(d["ms"] / tot_ms, 3),
-                       "arithmetic": "fp32 throughout, priced against the fp32 matrix peak; dense products whose operands are reused (inter conv step 2, intra conv, "
-                                     "q/k/v + head_combine, linear_relu_dot, small-weight Linear layers) run as exact 3 x bf16 operand splits with six fp32-accumulated cross products on the "
-                                     "bf16 matrix cores -- the fp32 MFMA's error against fp64 (profiles/r03_bf16x3_split.txt); ETCH_*_SPLIT=0 selects the fp32 MFMA"}
+                       "arithmetic": "fp32 throughout, priced against the fp32 matrix peak (157.3: `frac` can exceed what the fp32 MFMA could ever reach); both contractions of the "
+                                     "inter conv, the intra conv, q/k/v + head_combine, linear_relu_dot and the small-weight Linear layers run as exact 3 x bf16 operand splits with six "
+                                     "fp32-accumulated cross products on the bf16 matrix cores -- the fp32 MFMA's error against fp64 (profiles/r03_bf16x3_split.txt); the pipe the kernel "
+                                     "actually runs on is priced in `frac_of_split_rate` (measured v_mfma_f32_32x32x16_bf16 issue rate / 6 terms, profiles/r04_mfma_bf16_issue_rates.txt)",
+                       "split_rate_tflops": SPLIT_RATE_TFLOPS, "frac_of_split_rate": round(achieved / SPLIT_RATE_TFLOPS, 4)}
     if longest != kern:
         out["roofline"]["longest_kernel"] = {"kernel": longest, "ms": round(fam[longest]["ms"], 3), "note": "one workgroup per scan: latency-bound"}
     out["kernel_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]}
@@ -626,7 +703,13 @@ def main():
     if N == 5000 and not a.forward_only:
         # 152.4 GFLOP matmul / conv + 5.2 GFLOP kernel-weight generation per 5 000-point scan -> 1.0 ms at the fp32-MFMA
         # peak, HBM-side 0.05 ms: ceiling ~ 1 030 scans/s per GPU for the whole path
-        out["path_roofline"] = {"ceiling_scans_per_s_per_gpu": 1030, "frac": round(value / world / 1030.0, 4)}
+        # ceiling_mixed: the products that run split (everything but the attention scores / P V, the first conv's VALU work and the kernel-weight generation:
+        # 140.7 of the 152.4 GFLOP) at the measured split rate, the rest (11.7 + 5.2 GFLOP) at the fp32 peak
+        t_mixed = 140.7e9 / (SPLIT_RATE_TFLOPS * 1e12) + (11.7e9 + 5.2e9) / (FP32_MFMA_PEAK_TFLOPS * 1e12)
+        out["path_roofline"] = {"ceiling_scans_per_s_per_gpu": 1030, "frac": round(value / world / 1030.0, 4),
+                                "ceiling_mixed": round(1.0 / t_mixed), "frac_mixed": round(value / world * t_mixed, 4),
+                                "note": "ceiling = 152.4 GFLOP + 5.2 GFLOP weight generation per scan at the fp32 matrix peak (SURVEY 8d); ceiling_mixed prices the split-operand "
+                                        "products at the measured bf16-MFMA rate / 6"}
 
     if world == 1 and not a.no_cpu_baseline:
         def refit(run):          # the GPU fit of batch 0 with a shortened schedule (parity partner of the bounded oracle run)

@@ -461,7 +461,10 @@ extern "C" int etch_linear_relu_dot_split(long R, int K, int G, int J, const flo
 #define LRD_WS_MIN_G 8        // from this many groups on the weight-stationary kernel with two groups per workgroup
 #endif
     // (the choice depends on the layer's shape only, never on the row count: a scan's result may not depend on its batch neighbours, bit for bit)
-    if (K <= 128) {
+    // the weight-stationary kernel reads b1 and w2 with 16-byte loads: a bias / w2 VIEW at an offset that is not a multiple of 16 bytes goes to the
+    // streaming kernel below (scalar reads) instead of faulting
+    const bool ws_aligned = (((uintptr_t)b1 | (uintptr_t)w2) & 15) == 0;
+    if (K <= 128 && ws_aligned) {
         if (G >= LRD_WS_MIN_G) {
             if (K == 32) return launch_lrd_ws<32, 2>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);
             if (K == 64) return launch_lrd_ws<64, 2>(R, G, X, ldx, Wq, b1, w2, b2, out, ldo, st);

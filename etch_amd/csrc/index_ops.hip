@@ -539,18 +539,26 @@ int etch_knnquery(int b, int m_max, int m_total, int nsample, const float* xyz, 
 
 // Segment lookup on the device (knnquery_cuda_kernel.cu:52-62 get_bt_idx: the scan over new_offset ends because q < m = new_offset[b-1]):
 // the caller needs neither the number of segments nor the largest one -- no host read of the offsets.
-int etch_knnquery_dev(int m, int nsample, const float* xyz, const float* new_xyz, const int* offset, const int* new_offset, int* idx,
-                      float* dist, int write_sqrt, void* stream) {
+// nseg = number of segments (entries of offset / new_offset) when the caller knows it -- a tensor's element count, no device read: the segment
+// scan of a query is then clamped to it, so a query index past new_offset[nseg - 1] (m larger than the offsets cover) cannot run off the arrays.
+int etch_knnquery_dev_bounded(int m, int nsample, int nseg, const float* xyz, const float* new_xyz, const int* offset, const int* new_offset,
+                              int* idx, float* dist, int write_sqrt, void* stream) {
     if (m <= 0) return ETCH_OK;
-    if (nsample <= 0) return ETCH_EINVAL;
+    if (nsample <= 0 || nseg <= 0) return ETCH_EINVAL;
     if (nsample > 100) return ETCH_EUNSUPPORTED;          // the reference's best_dist[100] (knnquery_cuda_kernel.cu:86-87)
     const size_t lds = (size_t)(KNNW_WAVES * 2 * nsample + KNNW_WAVES * 128) * 4;
     long blocks = ((long)m + KNNW_WAVES - 1) / KNNW_WAVES;
     if (blocks > 256 * 64) blocks = 256 * 64;
-    hipLaunchKernelGGL(knn_wave_kernel, dim3((unsigned)blocks), dim3(KNNW_WAVES * 64), lds, (hipStream_t)stream, nsample, 0x7fffffff, xyz,
+    hipLaunchKernelGGL(knn_wave_kernel, dim3((unsigned)blocks), dim3(KNNW_WAVES * 64), lds, (hipStream_t)stream, nsample, nseg, xyz,
                        new_xyz, offset, new_offset, m, idx, dist, write_sqrt);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
+}
+
+// The reference launcher's contract (no segment count in its signature): the scan ends because q < m = new_offset[b - 1].
+int etch_knnquery_dev(int m, int nsample, const float* xyz, const float* new_xyz, const int* offset, const int* new_offset, int* idx,
+                      float* dist, int write_sqrt, void* stream) {
+    return etch_knnquery_dev_bounded(m, nsample, 0x7fffffff, xyz, new_xyz, offset, new_offset, idx, dist, write_sqrt, stream);
 }
 
 // ---- the reference's launchers under their own names and signatures (null stream, void, errors printed like grouping_cuda_kernel.cu:486-488)

@@ -28,6 +28,7 @@
 // SMPL, 144 KB for the 188-DoF model) ALIASES the linearisation scratch: it is written from the accumulators after the last
 // chunk and consumed by the Cholesky solve before the next linearisation.
 #include "common.h"
+#include <cstdlib>
 
 #ifndef LM_ELIM_COLS
 #define LM_ELIM_COLS 3    // pivots eliminated per barrier in the 85-DoF solve (2: the two-column form, kept for A/B)
@@ -154,6 +155,7 @@ struct LmShared {
     unsigned long long sub[BM::NJ];   // bit j of sub[k]: joint j lies in the subtree of joint k
     int lorder[BM::NJ], lstart[BM::NJ + 2], nlev;   // joints sorted by depth in the kinematic tree: level l = lorder[lstart[l] .. lstart[l+1])
     long long phase[8];               // s_memtime cycles per phase (thread 0), optional diagnostics
+    int split_failed;                 // a partner workgroup of a split fit never arrived (or had given up): this scan's fit is abandoned, its results are NaN
 };
 
 __device__ inline double& Apk(double* A, int i, int j) { return A[i * (i + 1) / 2 + j]; }   // i >= j
@@ -218,8 +220,9 @@ __device__ void lm_setup(LmShared<BM>& s, const SmplConsts& C, int M, const floa
 struct LmSplit {
     int g, G;
     double* ws;
-    unsigned* ctr;
+    unsigned* ctr;          // ctr[0]: arrivals; ctr[1]: the scan's give-up flag (set by the first workgroup that timed out, read by all at every exchange)
     unsigned count;         // linearisations exchanged so far (uniform over the scan's workgroups)
+    unsigned spin_limit;    // polls before a workgroup gives up waiting for its partners
 };
 
 // residual + normal equations at s.x.  nb = number of active betas (2 in stage 0, NB in stage 1).  On return s.A holds the packed
@@ -606,13 +609,19 @@ __device__ __attribute__((noinline)) void lm_linearize(LmShared<BM>& s, const Sm
             __hip_atomic_fetch_add(sp->ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned want = (unsigned)grp_G * (sp->count + 1u);
             unsigned spins = 0;
+            bool gave_up = false;
             while (__hip_atomic_load(sp->ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 27)) break;                   // partner workgroups never showed up (> ~10 s): give up instead of hanging the GPU
+                // partner workgroups never showed up (not co-resident: a concurrent kernel or a CU partition took their CUs): give up instead of
+                // hanging the GPU -- and NEVER go on with tiles that were not written: the scan is flagged, every workgroup of it abandons the fit
+                if (++spins > sp->spin_limit) { gave_up = true; break; }
             }
+            if (gave_up) __hip_atomic_store(sp->ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gave_up || __hip_atomic_load(sp->ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) s.split_failed = 1;
             __threadfence();                                       // ... acquire: the others' tiles are read from memory, not from a stale cache line
         }
         __syncthreads();
+        if (s.split_failed) return;                                // uniform over the workgroup (LDS flag behind the barrier)
 #pragma unroll
         for (int t = 0; t < BM::TPW; ++t) {
             f64x4 tot = {0.0, 0.0, 0.0, 0.0};
@@ -936,13 +945,16 @@ __global__ void __launch_bounds__(BM::THREADS) smpl_lm_fit_kernel(SmplConsts C, 
                                                                 const float* __restrict__ valid, int it0, float step0, float damp0,
                                                                 int it1, float step1, float damp1, float* __restrict__ x_out,
                                                                 float* __restrict__ x_stage0, float* __restrict__ err_trace, long long* __restrict__ phase_out,
-                                                                int G, double* __restrict__ split_ws, unsigned* __restrict__ split_ctr) {
+                                                                int G, double* __restrict__ split_ws, unsigned* __restrict__ split_ctr,
+                                                                unsigned spin_limit, int drop_group) {
     constexpr int DOF = BM::DOF;
     extern __shared__ __attribute__((aligned(16))) unsigned char lm_smem[];
     LmShared<BM>& s = *reinterpret_cast<LmShared<BM>*>(lm_smem);
     const int b = blockIdx.x / G, tid = threadIdx.x;
     const bool lead = blockIdx.x % G == 0;                      // the scan's workgroup that writes the results (all G hold the same state)
-    LmSplit split{(int)(blockIdx.x % G), G, split_ws + (size_t)b * 2 * G * BM::WAVES * BM::TPW * 256, split_ctr + (size_t)b * 64, 0u};
+    if (G > 1 && (int)(blockIdx.x % G) == drop_group) return;   // test hook (etch_smpl_lm_debug): a partner that never becomes resident
+    LmSplit split{(int)(blockIdx.x % G), G, split_ws + (size_t)b * 2 * G * BM::WAVES * BM::TPW * 256, split_ctr + (size_t)b * 64, 0u, spin_limit};
+    if (tid == 0) s.split_failed = 0;
     if (!lead) { x_stage0 = nullptr; err_trace = nullptr; phase_out = nullptr; }
     for (int i = tid; i < DOF; i += BM::THREADS) s.x[i] = 0.0;
     lm_setup(s, C, M, markers + (size_t)b * M * 3, valid + (size_t)b * M);
@@ -962,6 +974,7 @@ __global__ void __launch_bounds__(BM::THREADS) smpl_lm_fit_kernel(SmplConsts C, 
                     __syncthreads();
                 }
                 lm_linearize(s, C, M, nb, nullptr, false, G > 1 ? &split : nullptr);
+                if (G > 1 && s.split_failed) break;            // abandoned (uniform): fall through to the NaN write-out
                 const float err = (float)s.err;
                 if (it >= 0) {
                     const float a = fabsf(last - err);
@@ -972,9 +985,20 @@ __global__ void __launch_bounds__(BM::THREADS) smpl_lm_fit_kernel(SmplConsts C, 
             if (err_trace && tid == 0) err_trace[(size_t)b * (it0 + it1 + 2) + trace_pos] = last;
             ++trace_pos;
         }
+        if (G > 1 && s.split_failed) break;
         if (stage == 0 && x_stage0)
             for (int i = tid; i < DOF; i += BM::THREADS) x_stage0[(size_t)b * DOF + i] = (float)s.x[i];
         __syncthreads();
+    }
+    if (G > 1 && s.split_failed) {
+        // loud failure: the scan's parameters (and its error trace) are NaN, never a fit of partial sums; the flag word stays set in the workspace
+        // (etch_smpl_lm_split_failed reads it).  Every workgroup of the scan ends up here: a late one sees the flag at its first exchange.
+        const float qnan = __uint_as_float(0x7fc00000u);
+        if (lead) {
+            for (int i = tid; i < DOF; i += BM::THREADS) { x_out[(size_t)b * DOF + i] = qnan; if (x_stage0) x_stage0[(size_t)b * DOF + i] = qnan; }
+            if (err_trace) for (int i = tid; i < it0 + it1 + 2; i += BM::THREADS) err_trace[(size_t)b * (it0 + it1 + 2) + i] = qnan;
+        }
+        return;
     }
     if (lead)
         for (int i = tid; i < DOF; i += BM::THREADS) x_out[(size_t)b * DOF + i] = (float)s.x[i];
@@ -1273,6 +1297,9 @@ static size_t lm_split_bytes(int B, int G) {       // arrival counters (one 256-
     return (size_t)B * 256 + (size_t)B * 2 * G * BM::WAVES * BM::TPW * 256 * sizeof(double);
 }
 
+static unsigned g_lm_spin_limit = 1u << 27;      // polls (s_sleep 2 each) before a split workgroup gives up: ~10 s
+static int g_lm_drop_group = -1;                 // test hook: this group index of every scan returns at once (its partners must time out)
+
 template <class BM>
 static int launch_lm_fit(int B, int M, const void* const* consts, const float* markers, const float* valid, int it0, float step0, float damp0,
                          int it1, float step1, float damp1, float* x_out, float* x_stage0, float* err_trace, long long* phase_ticks, int G,
@@ -1292,7 +1319,8 @@ static int launch_lm_fit(int B, int M, const void* const* consts, const float* m
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(smpl_lm_fit_kernel<BM>, dim3(B * G), dim3(BM::THREADS), lds, st, lm_consts(consts), M, markers, valid, it0, step0, damp0, it1,
-                       step1, damp1, x_out, x_stage0, err_trace, phase_ticks, G, ws, reinterpret_cast<unsigned*>(ctr ? ctr : nullptr));
+                       step1, damp1, x_out, x_stage0, err_trace, phase_ticks, G, ws, reinterpret_cast<unsigned*>(ctr ? ctr : nullptr), g_lm_spin_limit,
+                       g_lm_drop_group);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }
@@ -1376,6 +1404,30 @@ int etch_smpl_lm_fit_split(int B, int M, int nj, int nb, const void* const* cons
         return launch_lm_fit<BodySMPLX>(B, M, consts, markers, valid, it0, step0, damp0, it1, step1, damp1, x_out, x_stage0, err_trace, phase_ticks, G,
                                         workspace, (hipStream_t)stream);
     return ETCH_EUNSUPPORTED;
+}
+
+// Test hook of the split fit's failure path: spin_limit = polls before a workgroup gives up (0: the default, ~10 s); drop_group >= 0: that
+// workgroup of every scan returns at launch, so its partners time out, flag the scan and return NaN parameters.  Process-wide; call with
+// (0, -1) to restore the defaults.
+int etch_smpl_lm_debug(unsigned spin_limit, int drop_group) {
+    g_lm_spin_limit = spin_limit ? spin_limit : (1u << 27);
+    g_lm_drop_group = drop_group;
+    return ETCH_OK;
+}
+
+// Number of scans whose split fit was abandoned (their x_out rows are NaN); synchronises the stream.  workspace = the one handed to the fit.
+int etch_smpl_lm_split_failed(int B, const void* workspace, int* n_failed, void* stream) {
+    if (!n_failed) return ETCH_EINVAL;
+    *n_failed = 0;
+    if (B <= 0 || !workspace) return ETCH_OK;
+    unsigned char* host = (unsigned char*)malloc((size_t)B * 256);
+    if (!host) return ETCH_EINVAL;
+    hipError_t e = hipMemcpyAsync(host, workspace, (size_t)B * 256, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e == hipSuccess)
+        for (int b = 0; b < B; ++b) *n_failed += reinterpret_cast<const unsigned*>(host + (size_t)b * 256)[1] != 0u;
+    free(host);
+    return e == hipSuccess ? ETCH_OK : (int)e;
 }
 
 long etch_smpl_lm_split_workspace_bytes(int B, int nj, int nb, int G) {

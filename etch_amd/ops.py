@@ -298,7 +298,7 @@ def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, orde
         _need(order, torch.int32, "order")
         assert tuple(order.shape) == (b, p2)
     out = torch.empty((b, p2, 60, cout), dtype=torch.float32, device=xyz.device)
-    fused = want_stats and 256 % cout == 0 and (cin >= 16 or cin == 1)
+    fused = want_stats and 256 % cout == 0 and (cin >= 16 or (cin == 1 and cout <= 64 and nn * 60 >= 1026))      # the c1 kernel's own precondition (so3conv.hip)
     part = torch.empty((b, p2, 2, cout), dtype=torch.float64, device=xyz.device) if fused else None
     if Wq32 is not None and inter_planes_form(cin) == 32 and inter_planes_supported(cin, cout, nn):
         _need(Wq32, torch.int16, "Wq32")
@@ -724,6 +724,8 @@ def smpl_lm_fit(consts, markers, valid_f, it0, step0, damp0, it1, step1, damp1, 
     x0 = torch.empty((B, dof), dtype=torch.float32, device=markers.device)
     tr = torch.zeros((B, it0 + it1 + 2), dtype=torch.float32, device=markers.device) if want_trace else None
     G = int(split) if split is not None else lm_split_default(B, nj)
+    if G > 1 and B * G > torch.cuda.get_device_properties(markers.device).multi_processor_count:
+        G = 1           # the workgroups of a scan wait for each other: on a small part / CU partition one persistent workgroup per scan (same results up to summation order)
     ws = None
     if G > 1:
         nbytes = _lib.lib().etch_smpl_lm_split_workspace_bytes(B, int(nj), int(nb), G)
@@ -731,7 +733,19 @@ def smpl_lm_fit(consts, markers, valid_f, it0, step0, damp0, it1, step1, damp1, 
     _lib.check(_lib.lib().etch_smpl_lm_fit_split(B, M, int(nj), int(nb), arr, _ptr(markers), _ptr(valid_f), int(it0), _c_float(step0), _c_float(damp0),
                                                  int(it1), _c_float(step1), _c_float(damp1), _ptr(x), _ptr(x0), _optptr(tr), _optptr(phase_ticks),
                                                  G, _optptr(ws), _stream()), "etch_smpl_lm_fit_split")
+    x._etch_split_ws = ws       # the split fit's workspace carries the per-scan give-up flags (smpl_lm_split_failed); None for one workgroup per scan
     return x, x0, tr
+
+
+def smpl_lm_split_failed(x):
+    """Number of scans of a split LM fit that were abandoned because a partner workgroup never arrived (their rows of `x` are NaN).  `x` = the
+    first tensor smpl_lm_fit returned.  Synchronises the current stream."""
+    ws = getattr(x, "_etch_split_ws", None)
+    if ws is None:
+        return 0
+    n = ctypes.c_int(0)
+    _lib.check(_lib.lib().etch_smpl_lm_split_failed(int(x.shape[0]), _ptr(ws), ctypes.byref(n), _stream()), "etch_smpl_lm_split_failed")
+    return int(n.value)
 
 
 def smpl_adam_fit(consts, markers, valid_f, it0, it1, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-8, want_trace=False, nj=24, nb=10):

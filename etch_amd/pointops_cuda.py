@@ -11,8 +11,9 @@ from .ops import _ptr, _stream
 def knnquery_cuda(m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2):
     """Fills idx (m,nsample) int32 and dist2 (m,nsample) with SQUARED distances (knnquery_cuda.cpp:9-19)."""
     # segments are found on the device like knnquery_cuda_kernel.cu:52-62,74-80: no host read of the offsets
-    _lib.check(_lib.lib().etch_knnquery_dev(int(m), int(nsample), _ptr(xyz), _ptr(new_xyz), _ptr(offset), _ptr(new_offset), _ptr(idx), _ptr(dist2), 0,
-                                            _stream()), "etch_knnquery_dev")
+    # (the number of segments is the offsets tensor's element count -- known here without a sync: the kernel's segment scan is clamped to it)
+    _lib.check(_lib.lib().etch_knnquery_dev_bounded(int(m), int(nsample), int(new_offset.numel()), _ptr(xyz), _ptr(new_xyz), _ptr(offset), _ptr(new_offset),
+                                                    _ptr(idx), _ptr(dist2), 0, _stream()), "etch_knnquery_dev_bounded")
 
 
 def furthestsampling_cuda(b, n_max, xyz, offset, new_offset, tmp, idx):

@@ -62,6 +62,10 @@ int etch_furthestsampling(int b, int n_max, const float* xyz, const int* offset,
  * etch_knnquery; this is the form a binding calls when the offsets only exist on the device (no .tolist() / .item() sync). */
 int etch_knnquery_dev(int m, int nsample, const float* xyz, const float* new_xyz, const int* offset, const int* new_offset, int* idx,
                       float* dist, int write_sqrt, void* stream);
+/* The same with the number of segments given (entries of offset / new_offset: known on the host without a device read): the per-query segment
+ * scan is clamped to it.  etch_knnquery_dev keeps the reference launcher's contract (m == new_offset[nseg - 1]). */
+int etch_knnquery_dev_bounded(int m, int nsample, int nseg, const float* xyz, const float* new_xyz, const int* offset, const int* new_offset,
+                              int* idx, float* dist, int write_sqrt, void* stream);
 
 /* ---- the reference's own launcher symbols --------------------------------------------------------------
  * Exactly the names and signatures the reference's host wrappers link against, so knnquery_cuda.cpp / sampling_cuda.cpp (and a
@@ -460,6 +464,12 @@ int etch_smpl_lm_fit(int B, int M, int nj, int nb, const void* const* consts, co
 int etch_smpl_lm_fit_split(int B, int M, int nj, int nb, const void* const* consts, const float* markers, const float* valid, int it0, float step0,
                            float damp0, int it1, float step1, float damp1, float* x_out, float* x_stage0, float* err_trace, long long* phase_ticks,
                            int G, void* workspace, void* stream);
+/* Failure path of the split fit.  A workgroup that waits longer than its spin limit for its partners (they were not co-resident: another kernel, a CU
+ * partition) flags the scan and every workgroup of the scan abandons the fit: the scan's x_out / x_stage0 / err_trace rows are NaN -- never a fit of
+ * partial sums -- and the flag stays set in the workspace.  etch_smpl_lm_split_failed counts the flagged scans (synchronises the stream).
+ * etch_smpl_lm_debug is the test hook: spin limit in polls (0 = default, ~10 s) and a group index that returns at launch (-1 = none). */
+int etch_smpl_lm_split_failed(int B, const void* workspace, int* n_failed, void* stream);
+int etch_smpl_lm_debug(unsigned spin_limit, int drop_group);
 /* LDS bytes one scan's fit holds for its whole duration (one workgroup per scan); ETCH_EUNSUPPORTED for unknown (nj, nb). */
 int etch_smpl_lm_workspace_bytes(int nj, int nb);
 

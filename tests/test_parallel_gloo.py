@@ -125,3 +125,20 @@ def test_core_pinning_from_kfd_topology(tmp_path):
     # unreadable topology -> even split of the affinity mask
     got = P.local_cpu_set(1, 2, str(tmp_path / "none"), nodes)
     assert got and set(got) <= set(avail) and (len(avail) < 2 or not set(got) & set(P.local_cpu_set(0, 2, str(tmp_path / "none"), nodes)))
+
+
+def test_bench_preflight_describes_the_8_rank_job_without_a_gpu():
+    """`bench.py --gpus 8 --preflight`: one JSON line with every rank's shard, CPU set and the collective plan; no GPU, no child processes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--preflight"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-500:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["preflight"] and d["n_gpus"] == 8 and d["global_batch"] == 256 and d["scaling"] == "weak"
+    assert [x["scans"] for x in d["ranks"]] == [[32 * k, 32 * k + 32] for k in range(8)]
+    assert all(x["device"] == f"cuda:{k}" for k, x in enumerate(d["ranks"])) and "all_gather" in d["collective"]["calls"]
+    r4 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--config", "4", "--preflight"], capture_output=True, text=True, timeout=300)
+    d4 = json.loads([l for l in r4.stdout.splitlines() if l.startswith("{")][-1])
+    assert d4["global_batch"] == 64 and d4["points"] == 20000
