@@ -14,9 +14,17 @@ class EtchHipError(RuntimeError):
     pass
 
 
-def declared_symbols():
-    """Every function declared in include/etch_hip.h."""
+def has_experiments():
+    """True if the loaded library was built with ETCH_BUILD_EXPERIMENTS=1 (the opt-in kernels measured slower than the default path:
+    etch_inter_so3conv32, etch_pt_block_k1 / _k2)."""
+    return hasattr(lib()._cdll, "etch_pt_block_k1")
+
+
+def declared_symbols(experiments=False):
+    """Every function declared in include/etch_hip.h; the `#ifdef ETCH_BUILD_EXPERIMENTS` sections only on request."""
     txt = open(HEADER).read()
+    if not experiments:
+        txt = re.sub(r"#ifdef ETCH_BUILD_EXPERIMENTS.*?#endif", "", txt, flags=re.S)
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\bint\s+(etch_\w+)\s*\(", txt)))
 
@@ -52,7 +60,7 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -m etch_amd.build` (hipcc, gfx950). "
                 "etch_amd has no CPU fallback.")
         cdll = ctypes.CDLL(LIB_PATH)
-        for name in declared_symbols():
+        for name in declared_symbols(experiments=hasattr(cdll, "etch_pt_block_k1")):
             fn = getattr(cdll, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = ctypes.c_int
         cdll.etch_smpl_lm_split_workspace_bytes.restype = ctypes.c_long

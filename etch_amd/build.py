@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-OBJDIR = os.path.join(LIBDIR, "obj")
+OBJDIR = os.path.join(LIBDIR, "obj_exp" if os.environ.get("ETCH_BUILD_EXPERIMENTS", "0") == "1" else "obj")
 LIB = os.path.join(LIBDIR, "libetch_hip.so")
 ARCH = "gfx950"
 BASE = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I", CSRC,
@@ -28,8 +28,12 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
+EXPERIMENTS = os.environ.get("ETCH_BUILD_EXPERIMENTS", "0") == "1"
+EXPERIMENT_SOURCES = {"so3conv32.hip"}         # opt-in kernels measured slower than the default path (+ the `#ifdef ETCH_BUILD_EXPERIMENTS` parts of pt.hip)
+
+
 def sources():
-    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") and (EXPERIMENTS or f not in EXPERIMENT_SOURCES))
 
 
 def _stale(target, deps):
@@ -49,7 +53,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [os.path.join(CSRC, src)] + headers + [os.path.abspath(__file__)]):
-            jobs.append([cc] + BASE + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj])
+            jobs.append([cc] + BASE + (["-DETCH_BUILD_EXPERIMENTS"] if EXPERIMENTS else []) + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -886,6 +886,7 @@ extern "C" int etch_pt_down_gather_max(int m, int ns, int co, const float* ux, l
     return ETCH_OK;
 }
 
+#ifdef ETCH_BUILD_EXPERIMENTS      // measured 1.0 - 3.4 x slower than the four-kernel block (profiles/r03_pt_block_fusion.txt): a lab record, built only on request
 // ------------------------------------------------------------------------------------------------
 // PointTransformerBlock (pointtransformer_seg.py:101-122) in TWO kernels instead of four, and consecutive blocks of a level chained:
 //   K1  pt_block_k1_kernel      qkv = (relu(bn1(x W1^T))) Wqkv^T + bqkv                              (linear1 -> bn1 -> ReLU -> linear_q|k|v)
@@ -1227,3 +1228,4 @@ extern "C" int etch_pt_block_k2(int n, int c, int ns, const float* p, const floa
 #undef PT_K2_CASE
     return ETCH_EUNSUPPORTED;
 }
+#endif  // ETCH_BUILD_EXPERIMENTS

@@ -187,7 +187,7 @@ class PointTransformerBlock(nn.Module):
     # run_blocks: True = the K1 / K2 fused kernels (2 launches per block, blocks of a level chained: 1 + b launches per level); False = 4
     # kernels per block.  Default OFF: measured on the bench workload the fused form is 1.0 - 3.4x SLOWER per level (a 16-point tile
     # re-streams every c x c weight from L2 and its GEMM chain is latency-bound; profiles/r03_pt_block_fusion.txt).  ETCH_PT_FUSED=1 enables it.
-    fused = os.environ.get("ETCH_PT_FUSED", "0") == "1"
+    fused = os.environ.get("ETCH_PT_FUSED", "0") == "1"       # (needs a library built with ETCH_BUILD_EXPERIMENTS=1: ops.pt_block_k1 raises otherwise)
 
     def _fused_params(self):
         """Argument sets of the fused block kernels (etch_pt_block_k1 / _k2), rebuilt when a parameter changes."""

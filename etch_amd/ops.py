@@ -318,7 +318,7 @@ def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, orde
         _lib.check(_lib.lib().etch_inter_so3conv_planes(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
                                                        _ptr(feats_planes), _ptr(rk), _ptr(Wqn), _ptr(bias), _ptr(out), _optptr(order),
                                                        _optptr(part), _stream()), "etch_inter_so3conv_planes")
-    elif Wp32 is not None and INTER_MFMA32 and (cin, cout) in INTER_MFMA32_SHAPES:
+    elif Wp32 is not None and INTER_MFMA32 and (cin, cout) in INTER_MFMA32_SHAPES and _lib.has_experiments():
         _need(Wp32, torch.float32, "Wp32")
         _lib.check(_lib.lib().etch_inter_so3conv32(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
                                                    _ptr(feats_cl), _ptr(rk), _ptr(Wp32), _ptr(bias), _ptr(out), _optptr(order),
@@ -519,7 +519,13 @@ def pt_attention_mfma(p, qkv, c, idx, params, ns, w2):
     return out
 
 
+def _need_experiments(what):
+    if not _lib.has_experiments():
+        raise _lib.EtchHipError(f"{what} is an opt-in experiment: rebuild with ETCH_BUILD_EXPERIMENTS=1 python -m etch_amd.build")
+
+
 def pt_block_k1(x, w1, s1, t1, wqkv, bqkv):
+    _need_experiments("etch_pt_block_k1")
     """First half of a PointTransformerBlock: qkv (n, 3c) = relu(bn1(x W1^T)) Wqkv^T + bqkv (pointtransformer_seg.py:112-113, 27)."""
     n, c = x.shape
     assert x.stride(1) == 1 and w1.shape == (c, c) and wqkv.shape == (3 * c, c)

@@ -122,6 +122,7 @@ int etch_inter_so3conv_ordered(int b, int cin, int cout, int p1, int p2, int nn,
                                const int* ball_idx, const float* feats, const float* rk, const float* W, const float* Wp,
                                const float* bias, float* out, const int* order, double* stat_part, void* stream);
 
+#ifdef ETCH_BUILD_EXPERIMENTS
 /* The same convolution on the 32x32x2 fp32 MFMA (0.986 of the matrix peak on this chip against 0.85 for 16x16x4,
  * profiles/r03_mfma_issue_rate.txt), two output points per workgroup; (cin, cout) in {(32,32), (32,64), (64,64)}, nn <= 64.
  * Wp32[slice = 3 h + g][mt][kp][u][lane][s] = W[32 mt + lane % 32][(32 h + kp * NU + u) * 24 + 8 g + 4 (lane / 32) + s] with
@@ -129,6 +130,7 @@ int etch_inter_so3conv_ordered(int b, int cin, int cout, int p1, int p2, int nn,
 int etch_inter_so3conv32(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
                          const int* ball_idx, const float* feats, const float* rk, const float* Wp32, const float* bias, float* out,
                          const int* order, double* stat_part, void* stream);
+#endif
 
 /* The same convolution with its second contraction (W x X1, 1/2 - 2/3 of the flops) on the bf16 matrix cores: every fp32 operand split exactly
  * into three bf16 values (8 + 8 + 8 mantissa bits), the six largest cross products accumulated in fp32 -- the error against fp64 of the fp32
@@ -288,6 +290,7 @@ int etch_pt_attn_aggregate(int n, int c, int ns, const float* p, const float* xv
 int etch_pt_attention_mfma(int n, int c, int ns, const float* p, const float* xq, const float* xk, const float* xv, long ldq,
                            const int* idx, const float* const* params, const float* W2, float* out, long ldo, void* stream);
 
+#ifdef ETCH_BUILD_EXPERIMENTS      /* lab records, measured slower than the default path; built only with ETCH_BUILD_EXPERIMENTS=1 (etch_amd/build.py) */
 /* PointTransformerBlock (src/models/pointtransformer_seg.py:101-122) in two kernels, consecutive blocks of a level chained:
  * K1: qkv (n,3c) = relu(bn1(x W1^T)) Wqkv^T + bqkv   -- linear1 (no bias) -> bn1 (folded s1,t1) -> ReLU -> linear_q|k|v of transformer2.
  * c in {64,128,256,512}. */
@@ -300,6 +303,7 @@ int etch_pt_block_k1(int n, int c, const float* x, long ldx, const float* W1, co
 int etch_pt_block_k2(int n, int c, int ns, const float* p, const float* xq, const float* xk, const float* xv, long ldq, const int* idx,
                      const float* const* params, const float* W2, const float* const* tail, long ldx, float* out, long ldo,
                      float* qkv_next, long ldqn, void* stream);
+#endif
 
 /* queryandgroup(use_xyz=True) rows for TransitionDown (pointtransformer_seg.py:61, pointops.py:90-98):
  * out[(i*ns+j)] = [p[idx[i,j]] - new_p[i] | x[idx[i,j]] | 0...], row stride ldo >= 3+c (padding columns zeroed). */

@@ -346,6 +346,9 @@ def test_intra_conv_weight_stationary_split_matches_the_fp32_kernel_and_fp64(c, 
 def test_inter_conv_32x32x2_variant_matches(cin, cout, nn):
     """The opt-in two-points-per-workgroup kernel on v_mfma_f32_32x32x2_f32 (etch_inter_so3conv32, ETCH_INTER_MFMA32=1;
     profiles/r03_inter_conv32_and_valu_overlap.txt) computes the same convolution; odd point counts leave its second point empty."""
+    from etch_amd import _lib
+    if not _lib.has_experiments():
+        pytest.skip("opt-in experiment kernel: built only with ETCH_BUILD_EXPERIMENTS=1 (measured slower than the default path)")
     from etch_amd import ops
     from etch_amd import vgtk_so3conv as V
     g = torch.Generator().manual_seed(cin + nn)

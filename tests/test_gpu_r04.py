@@ -184,3 +184,28 @@ def test_config4_whole_8gpu_batch_64x20000_smplx_on_one_gpu(tmp_path):
     peak = _full_vs_shards(tmp_path, 64, 8, 20000, SyntheticSMPLX(7), (75, 125))
     print(f"configs[4] on one GPU: peak HBM {peak:.1f} GiB")
     assert peak < 200
+
+
+def test_selfcheck_compares_a_dump_section_by_section(tmp_path):
+    """etch_amd.selfcheck (pinning the CUDA index kernels from a dump made on a CUDA box): here the dump is written by the CPU
+    oracle, so every section must match; a corrupted entry must be reported as a mismatch."""
+    from etch_amd import selfcheck
+    from oracle import ops as O
+    rng = np.random.default_rng(3)
+    xyz = (rng.standard_normal((2, 3, 700)) * 0.2).astype(np.float32)
+    new_xyz = xyz[:, :, :200].copy()
+    pk = (rng.standard_normal((900, 3)) * 0.3).astype(np.float32)
+    off, noff = np.array([400, 900], np.int32), np.array([100, 225], np.int32)
+    fidx = O.furthestsampling(pk, off, noff)
+    kidx, kd2 = O.knnquery(16, pk, pk[fidx], off, noff)
+    dump = dict(fps_xyz=xyz, fps_m=350, fps_idx=O.furthest_point_sampling(xyz, 350), bq_new_xyz=new_xyz, bq_xyz=xyz, bq_radius=0.15, bq_nsample=32,
+                bq_idx=O.ball_query(new_xyz, xyz, 0.15, 32), pfps_xyz=pk, pfps_offset=off, pfps_new_offset=noff, pfps_idx=fidx,
+                knn_xyz=pk, knn_new_xyz=pk[fidx], knn_offset=off, knn_new_offset=noff, knn_nsample=16, knn_idx=kidx, knn_dist=np.sqrt(kd2))
+    path = tmp_path / "dump.npz"
+    np.savez(path, **dump)
+    rep = selfcheck.check(dict(np.load(path)))
+    assert set(rep) == {"vgtk_fps", "ball_query", "pointops_fps", "pointops_knn_idx", "pointops_knn_dist"} and all(v["match"] for v in rep.values()), rep
+    dump["bq_idx"] = dump["bq_idx"].copy()
+    dump["bq_idx"][1, 7, 3] += 1
+    rep = selfcheck.check(dump)
+    assert rep["ball_query"]["match"] is False and rep["ball_query"]["differing"] == 1 and rep["vgtk_fps"]["match"]
