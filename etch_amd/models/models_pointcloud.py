@@ -149,8 +149,24 @@ class GT_network_equiv(nn.Module):
         return d.view(B, N, 3)
 
     # ------------------------------------------------------------------------------------------------ differentiable path
+    # Which path forward() takes:
+    #   differentiable = None  (default)  the path with autograd history (etch_amd.autograd / autograd_pt: hand-written backward kernels, un-fused,
+    #                                     several times slower and far more memory than inference) ONLY in train() mode with gradients enabled --
+    #                                     what train.py:61,77 does; eval() mode always takes the fused inference path (results without history),
+    #                                     also when the caller forgot torch.no_grad()
+    #   differentiable = True             always (eval() mode: BatchNorm on its running statistics)
+    #   differentiable = False            never
+    differentiable = None
+    _warned_switch = False
+
     def wants_grad(self):
-        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if self.differentiable is not None:
+            return bool(self.differentiable) and torch.is_grad_enabled()
+        return self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
+    def differentiable_supported(self):
+        """The differentiable direction head is built for the released width (EPN_layer_num = 2: 64-dim tokens)."""
+        return all(l.embedding_dim == 64 for l in self.direction_encoder.self_attention_layers)
 
     def encode_differentiable(self, hitpts):
         """The EPN encoder through etch_amd.autograd (hand-written backward kernels): what train.py:77-101 back-propagates through
@@ -175,16 +191,12 @@ class GT_network_equiv(nn.Module):
                 feats, xyz, anchors = z + s, new_xyz, itc.anchors
         return xyz, feats, anchors
 
-    def direction_differentiable(self, hitpts, xyz, feats_cl, anchors):
-        """3-NN propagation -> direction_encoder -> direction_predictor -> so3_reg -> so3_mean -> R @ [0,0,1] (models_pointcloud.py:111-126,
-        181-183) with autograd history; un-fused (no folded linear chains: every parameter receives its own gradient)."""
+    def direction_differentiable(self, tokens, anchors, B, N):
+        """direction_encoder -> direction_predictor -> so3_reg -> so3_mean -> R @ [0,0,1] (models_pointcloud.py:111-126) on the propagated
+        tokens (B*N, 60, 64), with autograd history; un-fused (no folded linear chains: every parameter receives its own gradient)."""
         from .. import autograd as A
-        B, N, _ = hitpts.shape
-        idx3, w3 = ops.prop3nn(hitpts, xyz)
-        x = A.prop_interp(feats_cl, idx3, w3).view(B * N, 60, feats_cl.shape[-1])
+        x = tokens
         layers = list(self.direction_encoder.self_attention_layers)
-        if any(l.embedding_dim != 64 for l in layers):
-            raise NotImplementedError("the differentiable direction head is built for the released width (EPN_layer_num = 2: 64-dim tokens)")
         for l in layers[:-1]:
             x = A.mhsa_layer(x, l.query_transform.weight, l.key_transform.weight, l.value_transform.weight, l.head_combine.weight,
                              l.head_combine.bias, residual=True)
@@ -198,32 +210,48 @@ class GT_network_equiv(nn.Module):
         return A.so3_mean_dir(aw, anchors).view(B, N, 3)
 
     def forward_differentiable(self, hitpts, pred_items, direction_mode):
-        """forward() with autograd history for the encoder and the direction head (VERDICT r02 task 7; train.py:77-85).  The two
-        Point-Transformer heads are evaluated WITHOUT history (their TransitionDown / TransitionUp backward and train-mode BatchNorm are not
-        built): `confidences`, `part_labels`, `magnitude` come back detached."""
+        """forward() with autograd history for every parameter (train.py:77-101): the encoder and the direction head through etch_amd.autograd,
+        the two Point-Transformer nets through etch_amd.autograd_pt (train-mode BatchNorm on batch statistics when self.training).  The encoder
+        and the 3-NN propagation run once and feed all three heads."""
+        from .. import autograd as A
+        from .. import autograd_pt as P
         if direction_mode != "standard_vector":
             raise AssertionError("Not implemented")
         B, N, _ = hitpts.shape
         xyz, feats_cl, anchors = self.encode_differentiable(hitpts)
+        idx3, w3 = ops.prop3nn(hitpts, xyz)
+        tokens = A.prop_interp(feats_cl, idx3, w3)                                 # (B,N,60,C): models_pointcloud.py:181-183
         results = {}
+        if "confidence" in pred_items or "magnitude" in pred_items:
+            inv = tokens.mean(2)                                                    # the anchor mean (:184)
+            pxo = self.preprocess_data(hitpts, inv)
+            if "confidence" in pred_items:
+                results["part_labels"], results["confidences"] = P.confidence_forward(self.confidence_encoder, pxo)
+            if "magnitude" in pred_items:
+                results["magnitude"] = P.magnitude_forward(self.magnitude_encoder, pxo)
         if "direction" in pred_items:
-            results["direction"] = self.direction_differentiable(hitpts, xyz, feats_cl, anchors)
-        rest = [it for it in pred_items if it != "direction"]
-        if rest:
-            with torch.no_grad():
-                other, _ = self._forward(hitpts, rest, direction_mode, B, N)
-            results.update(other)
+            results["direction"] = self.direction_differentiable(tokens.view(B * N, 60, feats_cl.shape[-1]), anchors, B, N)
         selected_indexs = torch.arange(0, N, device=hitpts.device).repeat(B, 1).unsqueeze(-1).expand(-1, -1, 3)
         return results, selected_indexs
 
     def forward(self, hitpts, pred_items=["direction", "magnitude"], direction_mode="standard_vector"):
-        """models_pointcloud.py:146-221.  With gradients enabled and trainable parameters the encoder and the direction head run through
-        etch_amd.autograd (forward_differentiable); otherwise the fused inference path."""
+        """models_pointcloud.py:146-221.  See `differentiable` above for when the path with autograd history is taken."""
         B, N, _ = hitpts.size()
         hitpts = hitpts.contiguous()
         if self.wants_grad():
-            with pointops.knn_scope():
-                return self.forward_differentiable(hitpts, pred_items, direction_mode)
+            if self.differentiable_supported():
+                if self.differentiable is None and not GT_network_equiv._warned_switch:
+                    GT_network_equiv._warned_switch = True
+                    import warnings
+                    warnings.warn("GT_network_equiv: train() mode with gradients enabled -> the differentiable (un-fused, slower) path; "
+                                  "call model.eval() or set model.differentiable = False for inference", stacklevel=2)
+                with pointops.knn_scope():
+                    return self.forward_differentiable(hitpts, pred_items, direction_mode)
+            if self.differentiable:
+                raise NotImplementedError("the differentiable direction head is built for the released width (EPN_layer_num = 2: 64-dim tokens)")
+            import warnings
+            warnings.warn("GT_network_equiv: no differentiable path for this token width; running the inference path (results carry no "
+                          "autograd history)", stacklevel=2)
         with pointops.knn_scope():
             return self._forward(hitpts, pred_items, direction_mode, B, N)
 

@@ -415,6 +415,24 @@ int etch_pt_attention_backward(int n, int c, int ns, const float* p, const float
  * segment offsets, int64): the reproducible form of scatter-add.  C % 4 == 0. */
 int etch_segment_sum_rows(long nseg, int C, const float* src, const long long* perm, const long long* seg, float* dst, void* stream);
 
+/* ---- training-side kernels of the Point-Transformer nets (train.py:77-101 through pointtransformer_seg.py in train() mode; etch_amd/autograd_pt.py) */
+/* BatchNorm1d batch statistics of the rows of x (R,C; leading dimension ldx): mean[c], biased var[c], summed in fp64 in a fixed order.
+ * workspace: 64 * 2 * C doubles. */
+int etch_bn_stats(long R, int C, const float* x, long ldx, double* workspace, float* mean, float* var, void* stream);
+/* y (R,C) = act((x - mean[c]) * scale[c] + beta[c]) with scale = gamma / sqrt(var + eps); act = ReLU if relu != 0. */
+int etch_bn_apply(long R, int C, const float* x, long ldx, const float* mean, const float* scale, const float* beta, int relu, float* y, void* stream);
+/* Backward of y = act(gamma * (x - mean) * rstd + beta): dgamma, dbeta and (dx != NULL) dx.  train != 0: mean / rstd are the batch
+ * statistics of x (torch.nn.BatchNorm1d in train() mode); train == 0: constants (running statistics).  y is read only when relu != 0.
+ * workspace: 64 * 2 * C doubles. */
+int etch_bn_backward(long R, int C, const float* x, long ldx, const float* y, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                     int relu, int train, double* workspace, float* dx, float* dgamma, float* dbeta, void* stream);
+/* Backward of etch_rows_maxpool (nn.MaxPool1d(nsample), pointtransformer_seg.py:66): dy (m*ns,c) = dout at the first maximum of each group. */
+int etch_rows_maxpool_backward(long m, int ns, int c, const float* y, const float* dout, float* dy, void* stream);
+/* The tail of PointTransformerLayer.forward (pointtransformer_seg.py:34-36): softmax over the ns neighbours of logit (n*ns, cs), then
+ * out[i, s*cs + j] = sum_k sm[i,k,j] v[i,k,s*cs + j] for v (n*ns, c); sm (n*ns, cs) is kept for the backward. */
+int etch_pt_softmax_agg(long n, int ns, int c, int cs, const float* logit, const float* v, float* sm, float* out, void* stream);
+int etch_pt_softmax_agg_backward(long n, int ns, int c, int cs, const float* sm, const float* v, const float* dout, float* dlogit, float* dv, void* stream);
+
 /* Backward of the 8-head dot-product attention over a point's 60 tokens (direction_backbones.py:102-129; autograd through it in
  * train.py:77-101): qkv rows [T*60][ld] with q / k / v at column offsets qoff / koff / voff (the layout of etch_mhsa_attention), dO rows
  * [T*60][ldo] = gradient of the concatenated head outputs -> dqkv rows [T*60][ld] at the same offsets.  Fixed summation order. */

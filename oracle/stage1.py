@@ -226,8 +226,13 @@ def so3_mean(anchors, weights):
 
 
 # ----------------------------------------------------------------------------- point transformer
+BN_TRAINING = False     # True: BatchNorm1d on batch statistics (model.train(), train.py:61) -- the running statistics are not touched here
+
+
 def _bn(sd, pre, x):
-    """eval-mode BatchNorm1d on channel dim 1 of [n,c] or [n,c,l]."""
+    """BatchNorm1d on channel dim 1 of [n,c] or [n,c,l]: eval mode (running statistics) or, with BN_TRAINING, train mode (batch statistics)."""
+    if BN_TRAINING:
+        return F.batch_norm(x, None, None, sd[pre + "weight"], sd[pre + "bias"], True, 0.0, 1e-5)
     return F.batch_norm(x, sd[pre + "running_mean"], sd[pre + "running_var"], sd[pre + "weight"], sd[pre + "bias"], False, 0.0, 1e-5)
 
 

@@ -314,6 +314,7 @@ def test_direction_loss_gradients_of_every_encoder_and_head_parameter(tmp_path):
     args = types.SimpleNamespace(output_folder=str(tmp_path), EPN_input_radius=0.4, EPN_layer_num=2, device=torch.device("cuda"),
                                  markerset=K.default_markerset())
     model = load_seeded(GT_network_equiv(option=args), 1).cuda().eval()
+    model.differentiable = True              # eval() mode takes the inference path unless asked (train() mode switches by itself)
     pts = np.stack([scan(80 + b, N) for b in range(B)])
     rng = np.random.default_rng(8)
     vec = rng.standard_normal((B, N, 3))
@@ -410,4 +411,7 @@ def test_direction_loss_gradients_of_every_encoder_and_head_parameter(tmp_path):
     with torch.no_grad():
         res0, _ = model(torch.from_numpy(pts).cuda(), ["direction"], "standard_vector")
     assert not res0["direction"].requires_grad
+    model.differentiable = None              # default: eval() mode -> inference path even with gradients enabled (a forgotten no_grad)
+    res1, _ = model(torch.from_numpy(pts).cuda(), ["direction"], "standard_vector")
+    assert not res1["direction"].requires_grad and torch.equal(res1["direction"], res0["direction"])
     assert rel_err(model.last_anc_w.cpu().numpy().reshape(-1, 60), aw64.numpy()) < 1e-4
