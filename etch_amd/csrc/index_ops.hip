@@ -65,7 +65,12 @@ __global__ void __launch_bounds__(WAVES * 64) ball_query_kernel(int n, int m, fl
 // Addressing: coordinate c of local point k is src[c * cs + k * ps].
 // CARRY: the candidate's coordinates travel with its key through the reduction (scans too large for an LDS copy of the coordinates:
 // saves the dependent global read of the winner, 16 -> 2.7 us per round at 20 000 points); otherwise the winner is read from the LDS copy.
-template <int THREADS, int PPT, bool REGS, bool CARRY>   // lds_xyz = capacity (points) of the dynamic-LDS coordinate copy, 0 = none
+// FAST (REGS kernels whose tie-key block size equals THREADS, i.e. every scan of >= 1024 points): a thread's slots share the bit-reversed part of
+// the tie key and differ by the slot number only, so the thread's winner is tracked as (distance, slot) with a strict '>' over ascending slots
+// -- the same order as the 64-bit keys -- and the key is composed once per round; invalid slots carry distance -2 (< the initial -1) instead of an
+// exec-mask branch per slot.  10 instead of 13 VALU instructions + a branch per slot: 2.29 -> 2.18 us per round at 20 000 points; slower where
+// few of a thread's slots are occupied (5 000 points: 1.11 -> 1.24), so only the large-scan (CARRY) variants use it (profiles/r04_fps_split.txt).
+template <int THREADS, int PPT, bool REGS, bool CARRY, bool FAST = false>   // lds_xyz = capacity (points) of the dynamic-LDS coordinate copy, 0 = none
 __global__ void __launch_bounds__(THREADS) fps_kernel(int lds_xyz, const float* __restrict__ xyz, long cs, long ps,
                                                       long batch_stride, int n_fixed, int m_fixed,
                                                       const int* __restrict__ offset, const int* __restrict__ new_offset,
@@ -117,6 +122,11 @@ __global__ void __launch_bounds__(THREADS) fps_kernel(int lds_xyz, const float* 
             if (ok) valid |= 1u << i;
         }
     }
+    if (FAST) {
+#pragma unroll
+        for (int i = 0; i < PPT; ++i)
+            if (!(valid & (1u << i))) temp[i] = -2.0f;    // never a candidate: below the initial best of -1
+    }
     if (tid == 0 && m > 0) idx[start_m] = start_n;
     if (!CARRY && lds_xyz) __syncthreads();
     int old = 0;  // local index of the last selected point
@@ -128,6 +138,22 @@ __global__ void __launch_bounds__(THREADS) fps_kernel(int lds_xyz, const float* 
             else { x1 = src[old * ps]; y1 = src[cs + old * ps]; z1 = src[2 * cs + old * ps]; }
         }
         unsigned long long best = 0ull;
+        if constexpr (FAST) {
+            float bestd = -1.0f;
+            int besti = -1;
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                const float d = etch_sqdist(px[i], py[i], pz[i], x1, y1, z1);
+                float d2;                                  // v_min_f32 as it stands (the builtin adds a canonicalising v_max per operand); no NaNs here
+                asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(temp[i]));
+                temp[i] = d2;
+                const bool gt = d2 > bestd;
+                bestd = gt ? d2 : bestd;
+                besti = gt ? i : besti;
+            }
+            // tie[i] = tie[0] - i: the slots of a thread are THREADS = bs points apart
+            if (besti >= 0) best = ((unsigned long long)__float_as_uint(bestd) << 32) | (tie[0] - (unsigned)besti);
+        } else
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             if (valid & (1u << i)) {
@@ -190,6 +216,175 @@ __global__ void __launch_bounds__(THREADS) fps_kernel(int lds_xyz, const float* 
         } else if (CARRY && n > 0) { x1 = src[0]; y1 = src[cs]; z1 = src[2 * cs]; }
         if (tid == 0) idx[start_m + j] = start_n + w;
         old = w;
+    }
+}
+
+// ------------------------------------------------------------------------------------ FPS, one scan split over G workgroups
+// Large scans (>= ~10 000 points) spend their round in the per-point distance update of ONE compute unit (2.7 us per round at 20 000 points:
+// 20 points per thread).  Here G workgroups (on G compute units) own interleaved 1024-point chunks of the scan in registers; every round each
+// publishes its best candidate -- the 64-bit key and the winner's coordinates as five data-tagged 8-byte granules {tag = round, value}, one
+// 64-byte record per workgroup -- and ONE wave sweeps the G records of the round (double-buffered by round parity: a workgroup can only be
+// one round ahead of the slowest, which has then finished reading the other parity).  Keys are unique per point, so the maximum over the G
+// candidates is the maximum over all points whatever the order: the picks are bit-identical to fps_kernel's (same key, same tie-breaking).
+// Price of the seam, measured (profiles/scripts/xwg_exchange.hip): 0.75 us per round for one scan, 1.2 us with 32 - 64 scans in flight.
+// Every spin is bounded: on a timeout (a workgroup of the scan not resident, e.g. more workgroups than the device holds) the fail word of the
+// workspace is set, the scan's remaining indices are poisoned with INT_MIN and every workgroup of the scan gives up.
+typedef __attribute__((address_space(1))) unsigned long long fps_gu64;
+template <int PPT>
+__global__ void __launch_bounds__(1024) fps_split_kernel(int G, const float* __restrict__ xyz, long cs, long ps, long batch_stride, int n_fixed,
+                                                         int m_fixed, const int* __restrict__ offset, const int* __restrict__ new_offset, int bs,
+                                                         int bs_bits, int skip_origin, unsigned spin_limit, int drop_group,
+                                                         unsigned long long* ws, int* __restrict__ idx) {
+    constexpr int THREADS = 1024, NW = THREADS / 64;
+    struct Cand { unsigned long long key; float x, y, z, pad; };
+    __shared__ Cand red[NW];
+    __shared__ float res[4];
+    __shared__ int res_w[2];                              // winner's local index, failure flag
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seg = blockIdx.x / G, g = blockIdx.x - seg * G;
+    if (g == drop_group) return;                          // test hook: a workgroup that never arrives
+    int start_n, n, start_m, m;
+    const float* src;
+    if (offset == nullptr) {
+        start_n = 0; n = n_fixed; start_m = seg * m_fixed; m = m_fixed;
+        src = xyz + (size_t)seg * batch_stride;
+    } else {
+        start_n = seg == 0 ? 0 : offset[seg - 1];
+        n = offset[seg] - start_n;
+        start_m = seg == 0 ? 0 : new_offset[seg - 1];
+        m = new_offset[seg] - start_m;
+        src = xyz + (size_t)start_n * ps;
+    }
+    fps_gu64* slots = (fps_gu64*)(ws + 8) + (size_t)seg * 2 * G * 8;       // [parity][G] records of 8 granules (5 used)
+    float px[PPT], py[PPT], pz[PPT], temp[PPT];
+    unsigned tie[PPT];
+    unsigned valid = 0u;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int k = (i * G + g) * THREADS + tid;        // chunk i*G + g of the scan
+        temp[i] = 1e10f;
+        px[i] = py[i] = pz[i] = 0.f;
+        const unsigned kl = (unsigned)k & (unsigned)(bs - 1);
+        const unsigned rev = bs_bits ? (__brev(kl) >> (32 - bs_bits)) : 0u;
+        tie[i] = 0xFFFFFFFFu - ((rev << 16) | ((unsigned)k / (unsigned)bs));
+        if (k < n) {
+            const float x = src[k * ps], y = src[cs + k * ps], z = src[2 * cs + k * ps];
+            px[i] = x; py[i] = y; pz[i] = z;
+            bool ok = true;
+            if (skip_origin) {
+#pragma clang fp contract(off)
+                float mag = ((x * x) + (y * y)) + (z * z);
+                ok = !((double)mag <= 1e-3);
+            }
+            if (ok) valid |= 1u << i;
+        }
+    }
+    if (g == 0 && tid == 0 && m > 0) idx[start_m] = start_n;
+    if (tid == 0) res_w[1] = 0;
+    float x1 = 0.f, y1 = 0.f, z1 = 0.f;
+    if (n > 0) { x1 = src[0]; y1 = src[cs]; z1 = src[2 * cs]; }
+    __syncthreads();
+    for (int j = 1; j < m; ++j) {
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            if (valid & (1u << i)) {
+                const float d = etch_sqdist(px[i], py[i], pz[i], x1, y1, z1);
+                const float d2 = d < temp[i] ? d : temp[i];
+                temp[i] = d2;
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | tie[i];
+                best = key > best ? key : best;
+            }
+        }
+        const unsigned long long wbest = etch_wave_max_u64_dpp(best);
+        {
+            const unsigned long long hit = __ballot(best == wbest && wbest != 0ull);
+            const int srcl = hit ? (int)__builtin_ctzll(hit) : 0;
+            float wx = 0.f, wy = 0.f, wz = 0.f;
+            if (hit) {                                     // wave-uniform
+                const unsigned t = 0xFFFFFFFFu - (unsigned)(wbest & 0xFFFFFFFFull);
+                const unsigned kl = bs_bits ? (__brev(t >> 16) >> (32 - bs_bits)) : 0u;
+                const int slot = (int)((t & 0xFFFFu) * (unsigned)bs + kl) / THREADS / G;
+#pragma unroll
+                for (int i = 0; i < PPT; ++i)
+                    if (slot == i) {
+                        wx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, px[i]), srcl));
+                        wy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, py[i]), srcl));
+                        wz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pz[i]), srcl));
+                    }
+            }
+            if (lane == 0) { red[wave].key = wbest; red[wave].x = wx; red[wave].y = wy; red[wave].z = wz; }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // this workgroup's candidate
+            const unsigned long long mine = lane < NW ? red[lane].key : 0ull;
+            const unsigned long long v = etch_wave_max_u64_dpp(mine);
+            const int wl = v != 0ull ? (int)__builtin_ctzll(__ballot(mine == v)) : 0;
+            fps_gu64* buf = slots + (size_t)(j & 1) * G * 8;
+            if (lane < 5) {
+                unsigned val;
+                if (lane == 0) val = (unsigned)(v & 0xFFFFFFFFull);
+                else if (lane == 1) val = (unsigned)(v >> 32);
+                else val = __float_as_uint(lane == 2 ? red[wl].x : (lane == 3 ? red[wl].y : red[wl].z));
+                __hip_atomic_store(buf + g * 8 + lane, ((unsigned long long)(unsigned)j << 32) | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // all G candidates of the round
+            unsigned val = 0u;
+            bool failed = false;
+            const int rec = lane / 5, fld = lane - rec * 5;
+            for (unsigned spins = 0;;) {
+                bool ok = true;
+                if (lane < 5 * G) {
+                    const unsigned long long x = __hip_atomic_load(buf + rec * 8 + fld, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    val = (unsigned)x;
+                    ok = (unsigned)(x >> 32) == (unsigned)j;
+                }
+                if (__all(ok)) break;
+                if (++spins > spin_limit || __hip_atomic_load((__attribute__((address_space(1))) unsigned*)ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    failed = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (failed) {
+                if (lane == 0) {
+                    __hip_atomic_store((__attribute__((address_space(1))) unsigned*)ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    res_w[1] = 1;
+                }
+            } else {
+                unsigned long long bk = 0ull;
+                int bg = 0;
+                for (int gg = 0; gg < G; ++gg) {
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)val, gg * 5), hi = (unsigned)__builtin_amdgcn_readlane((int)val, gg * 5 + 1);
+                    const unsigned long long key = ((unsigned long long)hi << 32) | lo;
+                    if (key > bk) { bk = key; bg = gg; }
+                }
+                int w = 0;
+                float wx, wy, wz;
+                if (bk != 0ull) {
+                    const unsigned t = 0xFFFFFFFFu - (unsigned)(bk & 0xFFFFFFFFull);
+                    const unsigned kl = bs_bits ? (__brev(t >> 16) >> (32 - bs_bits)) : 0u;
+                    w = (int)((t & 0xFFFFu) * (unsigned)bs + kl);
+                    wx = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)val, bg * 5 + 2));
+                    wy = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)val, bg * 5 + 3));
+                    wz = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)val, bg * 5 + 4));
+                } else {                                   // no candidate at all -> local index 0 (reference: besti default)
+                    wx = n > 0 ? src[0] : 0.f; wy = n > 0 ? src[cs] : 0.f; wz = n > 0 ? src[2 * cs] : 0.f;
+                }
+                if (lane == 0) { res[0] = wx; res[1] = wy; res[2] = wz; res_w[0] = w; }
+            }
+        }
+        __syncthreads();
+        if (res_w[1]) {                                    // give up: poison what is left of this scan
+            if (g == 0)
+                for (int t = j + tid; t < m; t += THREADS) idx[start_m + t] = (int)0x80000000;
+            return;
+        }
+        x1 = res[0]; y1 = res[1]; z1 = res[2];
+        if (g == 0 && tid == 0) idx[start_m + j] = start_n + res_w[0];
+        // no third barrier: `red` is rewritten by waves that passed the barrier above (wave 0 read it before), `res` by wave 0 after the NEXT
+        // round's first barrier (every thread has read it by then)
     }
 }
 
@@ -447,6 +642,8 @@ static int opt_n_threads_host(int work_size) {
     return v;
 }
 
+static int g_fps_fast = 1;     // etch_fps_split_debug's third knob: 0 = the 64-bit-key form everywhere (A/B timing, tests)
+
 static int launch_fps(int nseg, int n_max, const float* xyz, long cs, long ps, long bstride, int n_fixed, int m_fixed,
                       const int* offset, const int* new_offset, int skip_origin, int* idx, hipStream_t st) {
     const int bs = opt_n_threads_host(n_max);
@@ -455,8 +652,12 @@ static int launch_fps(int nseg, int n_max, const float* xyz, long cs, long ps, l
 #define FPS_CASE(T, P, R, C, COND)                                                                                     \
     if (n_max <= T * P && (COND)) {                                                                                    \
         const int use_lds = !C && fits_lds ? n_max : 0;                                                                \
-        hipLaunchKernelGGL((fps_kernel<T, P, R, C>), dim3(nseg), dim3(T), (size_t)3 * use_lds * sizeof(float), st,     \
-                           use_lds, xyz, cs, ps, bstride, n_fixed, m_fixed, offset, new_offset, bs, bits, skip_origin, idx);   \
+        if (R && C && T == 1024 && bs == T && g_fps_fast)     /* large scans only: at <= 8 slots the branchy loop skips the empty ones */ \
+            hipLaunchKernelGGL((fps_kernel<T, P, R, C, (R && C && T == 1024)>), dim3(nseg), dim3(T), (size_t)3 * use_lds * sizeof(float), st,   \
+                               use_lds, xyz, cs, ps, bstride, n_fixed, m_fixed, offset, new_offset, bs, bits, skip_origin, idx);   \
+        else                                                                                                           \
+            hipLaunchKernelGGL((fps_kernel<T, P, R, C>), dim3(nseg), dim3(T), (size_t)3 * use_lds * sizeof(float), st, \
+                               use_lds, xyz, cs, ps, bstride, n_fixed, m_fixed, offset, new_offset, bs, bits, skip_origin, idx);   \
         ETCH_RETURN_IF_LAUNCH_FAILED();                                                                                \
         return ETCH_OK;                                                                                                \
     }
@@ -467,7 +668,67 @@ static int launch_fps(int nseg, int n_max, const float* xyz, long cs, long ps, l
     return ETCH_EUNSUPPORTED;  // more than 32768 points per segment
 }
 
+static unsigned g_fps_spin_limit = 1u << 22;
+static int g_fps_drop_group = -1;
+
+static int launch_fps_split(int nseg, int n_max, int G, const float* xyz, long cs, long ps, long bstride, int n_fixed, int m_fixed, const int* offset,
+                            const int* new_offset, int skip_origin, int* idx, void* workspace, hipStream_t st) {
+    if (G < 2 || G > 8 || !workspace) return ETCH_EINVAL;
+    const int bs = opt_n_threads_host(n_max);
+    const int bits = ilog2_floor_host(bs);
+    const int chunks = (n_max + 1023) / 1024, need = (chunks + G - 1) / G;
+    const size_t bytes = 64 + (size_t)nseg * 2 * G * 64;
+    hipError_t e = hipMemsetAsync(workspace, 0, bytes, st);                    // tags and the fail word: zero before EVERY launch
+    if (e != hipSuccess) return (int)e;
+#define FPS_SPLIT_CASE(P)                                                                                                                  \
+    if (need <= P) {                                                                                                                       \
+        hipLaunchKernelGGL((fps_split_kernel<P>), dim3(nseg * G), dim3(1024), 0, st, G, xyz, cs, ps, bstride, n_fixed, m_fixed, offset,    \
+                           new_offset, bs, bits, skip_origin, g_fps_spin_limit, g_fps_drop_group, (unsigned long long*)workspace, idx);    \
+        ETCH_RETURN_IF_LAUNCH_FAILED();                                                                                                    \
+        return ETCH_OK;                                                                                                                    \
+    }
+    FPS_SPLIT_CASE(2) FPS_SPLIT_CASE(3) FPS_SPLIT_CASE(4) FPS_SPLIT_CASE(5) FPS_SPLIT_CASE(6) FPS_SPLIT_CASE(8)
+#undef FPS_SPLIT_CASE
+    return ETCH_EUNSUPPORTED;      // more than 8 x 1024 x G points per segment
+}
+
 extern "C" {
+
+int etch_fps_split_workspace_bytes(int nseg, int G) { return nseg > 0 && G > 0 ? 64 + nseg * 2 * G * 64 : 64; }
+
+int etch_furthest_point_sampling_split(int b, int n, int m, const float* xyz, int* idx, int G, void* workspace, void* stream) {
+    if (b <= 0 || m <= 0) return ETCH_OK;
+    if (n <= 0) return ETCH_EINVAL;
+    return launch_fps_split(b, n, G, xyz, (long)n, 1, (long)3 * n, n, m, nullptr, nullptr, 1, idx, workspace, (hipStream_t)stream);
+}
+
+int etch_furthestsampling_split(int b, int n_max, const float* xyz, const int* offset, const int* new_offset, int* idx, int G, void* workspace,
+                                void* stream) {
+    if (b <= 0) return ETCH_OK;
+    if (n_max <= 0) return ETCH_EINVAL;
+    return launch_fps_split(b, n_max, G, xyz, 1, 3, 0, 0, 0, offset, new_offset, 0, idx, workspace, (hipStream_t)stream);
+}
+
+int etch_fps_split_failed(const void* workspace, int* failed, void* stream) {
+    if (!workspace || !failed) return ETCH_EINVAL;
+    unsigned v = 0;
+    hipError_t e = hipMemcpyAsync(&v, workspace, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    *failed = v != 0;
+    return ETCH_OK;
+}
+
+int etch_fps_split_debug(unsigned spin_limit, int drop_group) {
+    g_fps_spin_limit = spin_limit ? spin_limit : (1u << 22);
+    g_fps_drop_group = drop_group;
+    return ETCH_OK;
+}
+
+int etch_fps_fast(int enable) {
+    g_fps_fast = enable != 0;
+    return ETCH_OK;
+}
 
 int etch_ball_query(int b, int n, int m, float radius, int nsample, const float* new_xyz, const float* xyz, int* idx,
                     void* stream) {

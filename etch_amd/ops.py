@@ -44,11 +44,54 @@ def ball_query(new_xyz, xyz, radius, nsample):
     return idx
 
 
-def furthest_point_sampling(xyz, m):
-    """epn_grouping.furthest_point_sampling (grouping_cuda.cpp:158-173): (b,3,n) -> (b,m) int32."""
+FPS_SPLIT_FORCE = None      # tests: an int G forces the split kernels (2..8) or disables them (0 / 1); None = fps_split_default
+
+
+def fps_split_default(nseg, n_max, device=None):
+    """Workgroups per scan for the FPS kernels.  Measured (profiles/r04_fps_split.txt): the per-round exchange between the workgroups of a
+    split scan costs 0.75 us (one scan) to 1.2 us (32 - 64 scans in flight) on top of a fixed 0.8 us per round, against 1.1 us for the WHOLE
+    one-workgroup round at 5 000 points and 2.3 us at 20 000 -- the split is slower at every size the path runs (2.7 us at 20 000 points with
+    G = 4), so the default is one workgroup per scan.  The split kernels stay available (bit-identical picks): split=G, FPS_SPLIT_FORCE or
+    ETCH_FPS_SPLIT=G; they need nseg * G co-resident workgroups (one per compute unit)."""
+    if FPS_SPLIT_FORCE is not None:
+        return int(FPS_SPLIT_FORCE) if int(FPS_SPLIT_FORCE) >= 2 else 1
+    env = os.environ.get("ETCH_FPS_SPLIT")
+    if env is not None and int(env) >= 2:
+        cus = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).multi_processor_count
+        g = min(8, int(env))
+        while g >= 2 and (nseg * g > cus or n_max > 8192 * g):
+            g = g // 2 if nseg * g > cus else 0
+        return g if g >= 2 else 1
+    return 1
+
+
+def _fps_split_ws(nseg, G, device):
+    ws = torch.empty((_lib.lib().etch_fps_split_workspace_bytes(nseg, G),), dtype=torch.uint8, device=device)
+    return ws
+
+
+def fps_split_failed(idx):
+    """True if the split FPS launch that produced `idx` gave up (a workgroup of a scan never arrived); synchronises the current stream."""
+    ws = getattr(idx, "_etch_split_ws", None)
+    if ws is None:
+        return False
+    out = ctypes.c_int(0)
+    _lib.check(_lib.lib().etch_fps_split_failed(_ptr(ws), ctypes.byref(out), _stream()), "etch_fps_split_failed")
+    return bool(out.value)
+
+
+def furthest_point_sampling(xyz, m, split=None):
+    """epn_grouping.furthest_point_sampling (grouping_cuda.cpp:158-173): (b,3,n) -> (b,m) int32.  split = workgroups per scan (None: auto)."""
     _need(xyz, torch.float32, "xyz")
     b, _, n = xyz.shape
     idx = torch.zeros((b, m), dtype=torch.int32, device=xyz.device)
+    G = fps_split_default(b, n, xyz.device) if split is None else int(split)
+    if G >= 2:
+        ws = _fps_split_ws(b, G, xyz.device)
+        _lib.check(_lib.lib().etch_furthest_point_sampling_split(b, n, int(m), _ptr(xyz), _ptr(idx), G, _ptr(ws), _stream()),
+                   "etch_furthest_point_sampling_split")
+        idx._etch_split_ws = ws
+        return idx
     _lib.check(_lib.lib().etch_furthest_point_sampling(b, n, int(m), _ptr(xyz), _ptr(idx), _stream()), "etch_furthest_point_sampling")
     return idx
 
@@ -102,7 +145,7 @@ def knnquery(nsample, xyz, new_xyz, offset, new_offset, new_offset_host=None, sq
     return idx, dist
 
 
-def furthestsampling(xyz, offset, new_offset, offset_host=None, new_offset_host=None):
+def furthestsampling(xyz, offset, new_offset, offset_host=None, new_offset_host=None, split=None):
     """pointops.furthestsampling (pointops.py:10-28): packed (n,3) + offsets -> idx (m) int32."""
     _need(xyz, torch.float32, "xyz"), _need(offset, torch.int32, "offset"), _need(new_offset, torch.int32, "new_offset")
     if offset_host is None:
@@ -110,8 +153,15 @@ def furthestsampling(xyz, offset, new_offset, offset_host=None, new_offset_host=
     if new_offset_host is None:
         new_offset_host = new_offset.tolist()
     idx = torch.zeros((int(new_offset_host[-1]),), dtype=torch.int32, device=xyz.device)
-    _lib.check(_lib.lib().etch_furthestsampling(len(offset_host), _seg_max(offset_host), _ptr(xyz), _ptr(offset), _ptr(new_offset),
-                                                _ptr(idx), _stream()), "etch_furthestsampling")
+    nseg, n_max = len(offset_host), _seg_max(offset_host)
+    G = fps_split_default(nseg, n_max, xyz.device) if split is None else int(split)
+    if G >= 2:
+        ws = _fps_split_ws(nseg, G, xyz.device)
+        _lib.check(_lib.lib().etch_furthestsampling_split(nseg, n_max, _ptr(xyz), _ptr(offset), _ptr(new_offset), _ptr(idx), G, _ptr(ws), _stream()),
+                   "etch_furthestsampling_split")
+        idx._etch_split_ws = ws
+        return idx
+    _lib.check(_lib.lib().etch_furthestsampling(nseg, n_max, _ptr(xyz), _ptr(offset), _ptr(new_offset), _ptr(idx), _stream()), "etch_furthestsampling")
     return idx
 
 

@@ -30,6 +30,21 @@ int etch_ball_query(int b, int n, int m, float radius, int nsample, const float*
  * Start index 0, points with |p|^2 <= 1e-3 never selected, reference tie-breaking reproduced exactly. */
 int etch_furthest_point_sampling(int b, int n, int m, const float* xyz, int* idx, void* stream);
 
+/* The same samplers with every scan split over G workgroups (2 <= G <= 8; large scans: one compute unit's distance update bounds the
+ * round): bit-identical picks (unique 64-bit keys, grouping_cuda_kernel.cu:352-466 / sampling_cuda_kernel.cu:15-129 tie-breaking).  The
+ * G workgroups of a scan exchange one candidate per round through `workspace` (etch_fps_split_workspace_bytes(nseg, G) bytes, zeroed by the
+ * call) and must be co-resident: callers keep nseg * G at or below the number of compute units.  A workgroup that waits longer than the
+ * spin limit sets the fail word (etch_fps_split_failed, synchronises the stream) and the scan's remaining indices become INT_MIN.
+ * etch_fps_split_debug(spin_limit, drop_group): test hook (0 / -1 = defaults). */
+int etch_fps_split_workspace_bytes(int nseg, int G);
+int etch_furthest_point_sampling_split(int b, int n, int m, const float* xyz, int* idx, int G, void* workspace, void* stream);
+int etch_furthestsampling_split(int b, int n_max, const float* xyz, const int* offset, const int* new_offset, int* idx, int G, void* workspace,
+                                void* stream);
+int etch_fps_split_failed(const void* workspace, int* failed, void* stream);
+int etch_fps_split_debug(unsigned spin_limit, int drop_group);
+/* A/B switch of the one-workgroup kernels' branch-free slot loop (default 1; 0 = the 64-bit-key loop everywhere): same picks either way. */
+int etch_fps_fast(int enable);
+
 /* Replaces epn_gathering.gather_points_forward: gathering_cuda.cpp:29-46 -> gathering_cuda_kernel.cu:43-68.
  * points (b,c,n) f32, idx (b,m) i32 -> out (b,c,m) f32. */
 int etch_gather_points(int b, int c, int n, int m, const float* points, const int* idx, float* out, void* stream);

@@ -20,22 +20,30 @@ def dev(a):
                                        (160, 80, (0.14, 0.31, 0.085)), (37, 20, (0.5, 0.5, 0.5)), (9000, 300, (0.14, 0.31, 0.085)),
                                        (20000, 200, (0.14, 0.31, 0.085)), (12000, 700, (0.14, 0.31, 0.085)), (20000, 10000, (0.14, 0.31, 0.085)),
                                        (24000, 150, (0.14, 0.31, 0.085))])
-def test_fps_vgtk(n, m, sigma):
+@pytest.mark.parametrize("split", [None, 2, 4, 8])        # None: the dispatch's own choice; G: every scan forced over G workgroups
+def test_fps_vgtk(n, m, sigma, split):
     from etch_amd import ops
+    if split is not None and n > 8 * 1024 * split:
+        pytest.skip("more than 8 chunks of 1024 points per workgroup: not a split shape")
     x = np.stack([scan(1000 + b, n, sigma).T for b in range(3)])
-    got = ops.furthest_point_sampling(dev(x), m).cpu().numpy()
+    idx = ops.furthest_point_sampling(dev(x), m, split=split)
+    got = idx.cpu().numpy()
     assert np.array_equal(got, O.furthest_point_sampling(x, m))
+    assert not ops.fps_split_failed(idx)
 
 
-def test_fps_vgtk_ties_and_origin_skip():
+@pytest.mark.parametrize("split", [None, 2, 4, 8])
+def test_fps_vgtk_ties_and_origin_skip(split):
     from etch_amd import ops
     rng = np.random.default_rng(3)
     for n in (37, 64, 200, 1500, 2600, 4100, 9000, 17000):
+        if split is not None and n > 8 * 1024 * split:
+            continue
         pts = rng.integers(-3, 4, (2, n, 3)).astype(np.float32) * 0.25 + 0.125
         pts[:, 5] = 0.0      # origin point: never a candidate
         pts[:, 7] = 0.01
         x = np.ascontiguousarray(pts.transpose(0, 2, 1))
-        got = ops.furthest_point_sampling(dev(x), n // 2).cpu().numpy()
+        got = ops.furthest_point_sampling(dev(x), n // 2, split=split).cpu().numpy()
         assert np.array_equal(got, O.furthest_point_sampling(x, n // 2)), n
 
 
@@ -103,13 +111,39 @@ def test_knn_exact_ties_follow_heap_order():
 
 @pytest.mark.parametrize("segs,stride", [([5000, 5000, 5000], 4), ([1250, 1250], 4), ([312, 312], 4), ([78, 78, 78], 4), ([19, 19], 4),
                                          ([150, 90], 4), ([4999, 130, 2047], 3), ([20000, 20000], 4), ([11000, 300, 20480], 4)])
-def test_fps_pointops(segs, stride):
+@pytest.mark.parametrize("split", [None, 2, 4, 8])
+def test_fps_pointops(segs, stride, split):
     from etch_amd import ops
+    if split is not None and max(segs) > 8 * 1024 * split:
+        pytest.skip("more than 8 chunks of 1024 points per workgroup: not a split shape")
     p = np.concatenate([scan(5000 + i, n) for i, n in enumerate(segs)])
     o = np.cumsum(segs).astype(np.int32)
     no = np.cumsum([n // stride for n in segs]).astype(np.int32)
-    got = ops.furthestsampling(dev(p), dev(o), dev(no)).cpu().numpy()
+    got = ops.furthestsampling(dev(p), dev(o), dev(no), split=split).cpu().numpy()
     assert np.array_equal(got, O.furthestsampling(p, o, no))
+
+
+def test_fps_split_dispatch_and_failure_is_loud():
+    """The dispatch never splits by itself (measured slower at every size the path runs, profiles/r04_fps_split.txt); forced, a workgroup that
+    never arrives makes every workgroup of its scan give up within the spin bound: the fail word is set and the scan's remaining indices are
+    INT_MIN (a later gather with them faults instead of silently sampling garbage)."""
+    import ctypes
+
+    from etch_amd import _lib, ops
+    assert ops.fps_split_default(32, 5000) == 1 and ops.fps_split_default(64, 20000) == 1 and ops.fps_split_default(1, 20000) == 1
+    x = np.stack([scan(1000 + b, 12000).T for b in range(2)])
+    ref = O.furthest_point_sampling(x, 600)
+    lib = _lib.lib()
+    try:
+        _lib.check(lib.etch_fps_split_debug(ctypes.c_uint(2000), 1), "etch_fps_split_debug")      # workgroup 1 of every scan returns at once
+        idx = ops.furthest_point_sampling(dev(x), 600, split=4)
+        assert ops.fps_split_failed(idx)
+        got = idx.cpu().numpy()
+        assert (got[:, 0] == 0).all() and (got[:, 1:] == np.iinfo(np.int32).min).all()
+    finally:
+        _lib.check(lib.etch_fps_split_debug(ctypes.c_uint(0), -1), "etch_fps_split_debug")
+    idx = ops.furthest_point_sampling(dev(x), 600, split=4)
+    assert not ops.fps_split_failed(idx) and np.array_equal(idx.cpu().numpy(), ref)
 
 
 def test_pybind_module_mirrors():
