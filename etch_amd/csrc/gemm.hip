@@ -346,7 +346,15 @@ __global__ void __launch_bounds__(512) gemm_ws_split_kernel(GemmArgs a, long row
     const int sg = wave % SG, rp = wave / SG;
     // this wave's weight fragments: strips SPW sg .. + SPW - 1, rows (output channels) 16 strip + fr, k = 32 t + 8 fg + e
     g_bf16x8 wf[KT][SPW][3];
-    float4 bs[SPW], sc[SPW], sh[SPW];
+    // epilogue constants: resident next to the weight fragments where both fit the 256-register budget of 2 waves/SIMD, re-read per row tile
+    // (36 of them, L1 hits) where the fragments alone take 144 (K = 128, 3 strips: 22 spilled registers otherwise)
+    constexpr bool EPI_REGS = KT * SPW * 12 <= 96;
+    float4 bs[EPI_REGS ? SPW : 1], sc[EPI_REGS ? SPW : 1], sh[EPI_REGS ? SPW : 1];
+    auto epi_load = [&](int o, float4& b_, float4& s_, float4& h_) {
+        b_ = a.bias ? make_float4(a.bias[o + 4 * fg], a.bias[o + 4 * fg + 1], a.bias[o + 4 * fg + 2], a.bias[o + 4 * fg + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s_ = a.scale ? make_float4(a.scale[o + 4 * fg], a.scale[o + 4 * fg + 1], a.scale[o + 4 * fg + 2], a.scale[o + 4 * fg + 3]) : make_float4(1.f, 1.f, 1.f, 1.f);
+        h_ = a.shift ? make_float4(a.shift[o + 4 * fg], a.shift[o + 4 * fg + 1], a.shift[o + 4 * fg + 2], a.shift[o + 4 * fg + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
 #pragma unroll
     for (int s2 = 0; s2 < SPW; ++s2) {
         const int o = 16 * (SPW * sg + s2);
@@ -356,34 +364,34 @@ __global__ void __launch_bounds__(512) gemm_ws_split_kernel(GemmArgs a, long row
             g_split8(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4), wf[t][s2]);
         }
         // epilogue constants of the lane's 4 channels o + 4 fg .. + 3
-        bs[s2] = a.bias ? make_float4(a.bias[o + 4 * fg], a.bias[o + 4 * fg + 1], a.bias[o + 4 * fg + 2], a.bias[o + 4 * fg + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        sc[s2] = a.scale ? make_float4(a.scale[o + 4 * fg], a.scale[o + 4 * fg + 1], a.scale[o + 4 * fg + 2], a.scale[o + 4 * fg + 3]) : make_float4(1.f, 1.f, 1.f, 1.f);
-        sh[s2] = a.shift ? make_float4(a.shift[o + 4 * fg], a.shift[o + 4 * fg + 1], a.shift[o + 4 * fg + 2], a.shift[o + 4 * fg + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (EPI_REGS) epi_load(o, bs[s2], sc[s2], sh[s2]);
     }
     constexpr int C4 = K / 4;
     constexpr int XL = (FD_ROWS * C4 + 511) / 512;
     const long row_lo = (long)blockIdx.x * rows_per_block, row_hi = row_lo + rows_per_block < a.R ? row_lo + rows_per_block : a.R;
     float4 xn[XL];
+    // element e = tid + 512 h of a tile: 512 is a multiple of C4 (K = 32 / 64 / 128), so h only moves the row -- one address per thread, h as an
+    // immediate offset (the generic e / C4 per h cost an address register per h, one of them spilled at K = 128)
+    static_assert(512 % C4 == 0 && (FD_ROWS * C4) % 512 == 0, "tile staging assumes whole 512-element passes");
+    constexpr int RSTEP = 512 / C4;
+    const int row0 = tid / C4, c0 = (tid % C4) * 4;
     auto fetch = [&](long r0) {
+        const float* src = a.X + (r0 + row0) * a.ldx + c0;
 #pragma unroll
         for (int h = 0; h < XL; ++h) {
-            const int e = tid + 512 * h;
-            const int row = e / C4, c = (e - row * C4) * 4;
             xn[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < FD_ROWS * C4 && r0 + row < row_hi) xn[h] = *reinterpret_cast<const float4*>(a.X + (r0 + row) * a.ldx + c);
+            if (r0 + row0 + h * RSTEP < row_hi) xn[h] = *reinterpret_cast<const float4*>(src + (long)(h * RSTEP) * a.ldx);
         }
     };
     auto stage = [&](unsigned short* P) {
+        unsigned short* d0 = P + row0 * SB + c0;
 #pragma unroll
         for (int h = 0; h < XL; ++h) {
-            const int e = tid + 512 * h;
-            if (e >= FD_ROWS * C4) continue;
-            const int row = e / C4, c = (e - row * C4) * 4;
             const float v[4] = {xn[h].x, xn[h].y, xn[h].z, xn[h].w};
             unsigned hh[4], mm[4], ll[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) g_split(v[i], hh[i], mm[i], ll[i]);
-            unsigned short* d = P + row * SB + c;
+            unsigned short* d = d0 + h * RSTEP * SB;
             *reinterpret_cast<uint2*>(d) = make_uint2(__builtin_amdgcn_perm(hh[1], hh[0], 0x07060302u), __builtin_amdgcn_perm(hh[3], hh[2], 0x07060302u));
             *reinterpret_cast<uint2*>(d + PLANE) = make_uint2(__builtin_amdgcn_perm(mm[1], mm[0], 0x07060302u), __builtin_amdgcn_perm(mm[3], mm[2], 0x07060302u));
             *reinterpret_cast<uint2*>(d + 2 * PLANE) = make_uint2(__builtin_amdgcn_perm(ll[1], ll[0], 0x07060302u), __builtin_amdgcn_perm(ll[3], ll[2], 0x07060302u));
@@ -408,8 +416,11 @@ __global__ void __launch_bounds__(512) gemm_ws_split_kernel(GemmArgs a, long row
 #pragma unroll
             for (int s2 = 0; s2 < SPW; ++s2) {
                 const int o = 16 * (SPW * sg + s2) + 4 * fg;
-                float4 v = make_float4(acc[s2][0] + bs[s2].x, acc[s2][1] + bs[s2].y, acc[s2][2] + bs[s2].z, acc[s2][3] + bs[s2].w);
-                if (a.scale) { v.x = v.x * sc[s2].x + sh[s2].x; v.y = v.y * sc[s2].y + sh[s2].y; v.z = v.z * sc[s2].z + sh[s2].z; v.w = v.w * sc[s2].w + sh[s2].w; }
+                float4 b_, s_, h_;
+                if constexpr (EPI_REGS) { b_ = bs[s2]; s_ = sc[s2]; h_ = sh[s2]; }
+                else epi_load(o - 4 * fg, b_, s_, h_);
+                float4 v = make_float4(acc[s2][0] + b_.x, acc[s2][1] + b_.y, acc[s2][2] + b_.z, acc[s2][3] + b_.w);
+                if (a.scale) { v.x = v.x * s_.x + h_.x; v.y = v.y * s_.y + h_.y; v.z = v.z * s_.z + h_.z; v.w = v.w * s_.w + h_.w; }
                 float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (a.res_mode != 0) rs = *reinterpret_cast<const float4*>(a.res + r * a.ldr + o);
                 if (a.res_mode == 1) { v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w; }
@@ -430,9 +441,10 @@ __global__ void __launch_bounds__(512) gemm_ws_split_kernel(GemmArgs a, long row
         const unsigned short* P = Xp + buf * 3 * PLANE;
         row_tile(P, rp * RTW, r0);
         stage(Xp + (buf ^ 1) * 3 * PLANE);       // the next tile (its buffer's last readers finished before the previous barrier)
-        fetch(r0 + 2 * FD_ROWS);
+        if constexpr (EPI_REGS) fetch(r0 + 2 * FD_ROWS);
 #pragma unroll
         for (int i = 1; i < RTW; ++i) row_tile(P, rp * RTW + i, r0);
+        if constexpr (!EPI_REGS) fetch(r0 + 2 * FD_ROWS);      // register-bound shape: the prefetch registers are not live across the row tiles
         __syncthreads();
     }
 }

@@ -61,6 +61,12 @@ struct Body {
     static constexpr int EPU = EPP <= 32 ? (EPP + 1) / 2 : 16;   // posedirs rows loaded back to back per wait (3 floats each)
 };
 
+// lm_linearize / lm_solve are out-of-line functions on purpose.  Their call frames -- ~40 callee-saved registers saved / restored ONCE per call,
+// i.e. once per LM iteration -- are the 172 - 252 bytes of scratch the fit kernels report; inlined (-DLM_PHASE_INLINE=always_inline) the register
+// allocator spills 104 (SMPL) / 42 (SMPL-X) registers INSIDE the phases instead, and the file takes 3.5 minutes to compile.
+#ifndef LM_PHASE_INLINE
+#define LM_PHASE_INLINE noinline
+#endif
 struct SmplConsts {
     const float* J0;      // [NJ][3]      J_regressor @ v_template
     const float* Jd;      // [NJ][3][NB]  J_regressor @ shapedirs
@@ -139,6 +145,18 @@ struct LmLin {                        // linearisation scratch (dead during the 
     float Jc[2][BM::CHUNK_ROWS * BM::LDJS];   // double-buffered Jacobian chunk: 3 rows per marker, column DOF = residual
 };
 
+// A scan's linearisation split over G workgroups (latency regime: B <= 8 scans leave most of the chip idle): workgroup g of a scan takes the
+// marker chunks g, g + G, ...; the partial tiles of [J | r]^T [J | r] meet in global memory once per linearisation and every workgroup adds
+// them in the SAME order (g = 0 .. G-1), so all G copies of the scan's state stay bit-identical and solve redundantly -- no second exchange.
+// ws: [2 parities][G][SLOTS = WAVES * TPW][64 lanes][4] fp64 (double-buffered by the linearisation count), ctr: arrival counter.
+struct LmSplit {
+    int g, G;
+    double* ws;
+    unsigned* ctr;          // ctr[0]: arrivals; ctr[1]: the scan's give-up flag (set by the first workgroup that timed out, read by all at every exchange)
+    unsigned count;         // linearisations exchanged so far (uniform over the scan's workgroups)
+    unsigned spin_limit;    // polls before a workgroup gives up waiting for its partners
+};
+
 template <class BM>
 struct LmShared {
     union {
@@ -155,6 +173,8 @@ struct LmShared {
     unsigned long long sub[BM::NJ];   // bit j of sub[k]: joint j lies in the subtree of joint k
     int lorder[BM::NJ], lstart[BM::NJ + 2], nlev;   // joints sorted by depth in the kinematic tree: level l = lorder[lstart[l] .. lstart[l+1])
     long long phase[8];               // s_memtime cycles per phase (thread 0), optional diagnostics
+    SmplConsts consts;                // the kernel's table pointers and the split state live HERE, not in a by-reference struct of the noinline
+    LmSplit split;                    // phases' caller (that is a private-memory copy: 88 + 32 bytes of scratch per thread)
     int split_failed;                 // a partner workgroup of a split fit never arrived (or had given up): this scan's fit is abandoned, its results are NaN
 };
 
@@ -186,6 +206,7 @@ __device__ void lm_setup(LmShared<BM>& s, const SmplConsts& C, int M, const floa
     constexpr int NJ = BM::NJ;
     const int tid = threadIdx.x;
     if (tid < 8) s.phase[tid] = 0;
+    if (tid == 0) s.consts = C;                // what the noinline phases read (see LmShared::consts)
     if (tid < NJ) s.parents[tid] = C.parents[tid];
     if (tid < M * 3) s.target[tid] = target[tid];
     if (tid < M) s.mask[tid] = mask[tid];
@@ -200,7 +221,8 @@ __device__ void lm_setup(LmShared<BM>& s, const SmplConsts& C, int M, const floa
         s.sub[tid] = m;
     }
     if (tid == 0) {                            // kinematic levels (parents precede their children: depth by one pass)
-        int depth[NJ], cnt[NJ + 2];
+        int* depth = reinterpret_cast<int*>(s.A);      // scratch of this one-thread pass in the (still unused) matrix area: dynamically indexed
+        int* cnt = depth + NJ;                          // private arrays would be scratch memory
         int maxd = 0;
         for (int j = 0; j < NJ; ++j) { depth[j] = j == 0 ? 0 : depth[s.parents[j]] + 1; maxd = depth[j] > maxd ? depth[j] : maxd; }
         for (int l = 0; l <= maxd + 1; ++l) cnt[l] = 0;
@@ -213,25 +235,15 @@ __device__ void lm_setup(LmShared<BM>& s, const SmplConsts& C, int M, const floa
     __syncthreads();
 }
 
-// A scan's linearisation split over G workgroups (latency regime: B <= 8 scans leave most of the chip idle): workgroup g of a scan takes the
-// marker chunks g, g + G, ...; the partial tiles of [J | r]^T [J | r] meet in global memory once per linearisation and every workgroup adds
-// them in the SAME order (g = 0 .. G-1), so all G copies of the scan's state stay bit-identical and solve redundantly -- no second exchange.
-// ws: [2 parities][G][SLOTS = WAVES * TPW][64 lanes][4] fp64 (double-buffered by the linearisation count), ctr: arrival counter.
-struct LmSplit {
-    int g, G;
-    double* ws;
-    unsigned* ctr;          // ctr[0]: arrivals; ctr[1]: the scan's give-up flag (set by the first workgroup that timed out, read by all at every exchange)
-    unsigned count;         // linearisations exchanged so far (uniform over the scan's workgroups)
-    unsigned spin_limit;    // polls before a workgroup gives up waiting for its partners
-};
-
 // residual + normal equations at s.x.  nb = number of active betas (2 in stage 0, NB in stage 1).  On return s.A holds the packed
 // lower triangle of J^T J (no damping yet) with the right-hand side -J^T r as row DOF, s.resid / s.err the residual and 0.5 |r|^2.
 // jac_out (diagnostics): the marker rows of J (3M x DOF) are also written to global memory.  grad_only (first-order fitter): only the
 // tile row that holds -J^T r is accumulated; the J^T J entries of s.A are then undefined.
 template <class BM>
-__device__ __attribute__((noinline)) void lm_linearize(LmShared<BM>& s, const SmplConsts& C, int M, int nb, float* __restrict__ jac_out, bool grad_only = false,
-                                                       LmSplit* sp = nullptr) {
+__device__ __attribute__((LM_PHASE_INLINE)) void lm_linearize(LmShared<BM>& s, int M, int nb, float* __restrict__ jac_out, bool grad_only = false,
+                                                       bool use_split = false) {
+    const SmplConsts& C = s.consts;
+    LmSplit* sp = use_split ? &s.split : nullptr;
     const int grp_g = sp ? sp->g : 0, grp_G = sp ? sp->G : 1;
     constexpr int NJ = BM::NJ, NB = BM::NB, NPOSE = BM::NPOSE, NPF = BM::NPF, DOF = BM::DOF, LDJ = BM::LDJ, LDJS = BM::LDJS;
     LmLin<BM>& L = s.lin;
@@ -633,7 +645,7 @@ __device__ __attribute__((noinline)) void lm_linearize(LmShared<BM>& s, const Sm
             }
             acc[t] = tot;
         }
-        ++sp->count;
+        if (tid == 0) ++sp->count;         // (LDS: read again only by the next linearisation, many barriers from here)
     }
     {
         // v_mfma_f64_16x16x4_f64 result layout: D[row = (lane >> 4) + 4 q][col = lane & 15]
@@ -675,7 +687,7 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 // (3) the trailing matrix takes the rank-16 update on the fp64 matrix cores, one 16 x 16 tile per wave at a time.  3 barriers per
 // block (18 for SMPL, 36 for the 188-DoF model) instead of one per column (85 / 188).
 template <class BM>
-__device__ __attribute__((noinline)) void lm_solve(LmShared<BM>& s, double lambda) {
+__device__ __attribute__((LM_PHASE_INLINE)) void lm_solve(LmShared<BM>& s, double lambda) {
     constexpr int DOF = BM::DOF, N = BM::DOF, NPACK = BM::NPACK;
     constexpr int NBLK = (N + 15) / 16;                 // pivot blocks
     constexpr int NRT = (N + 1 + 15) / 16;              // row tiles of the (N + 1)-row matrix
@@ -953,8 +965,10 @@ __global__ void __launch_bounds__(BM::THREADS) smpl_lm_fit_kernel(SmplConsts C, 
     const int b = blockIdx.x / G, tid = threadIdx.x;
     const bool lead = blockIdx.x % G == 0;                      // the scan's workgroup that writes the results (all G hold the same state)
     if (G > 1 && (int)(blockIdx.x % G) == drop_group) return;   // test hook (etch_smpl_lm_debug): a partner that never becomes resident
-    LmSplit split{(int)(blockIdx.x % G), G, split_ws + (size_t)b * 2 * G * BM::WAVES * BM::TPW * 256, split_ctr + (size_t)b * 64, 0u, spin_limit};
-    if (tid == 0) s.split_failed = 0;
+    if (tid == 0) {
+        s.split = LmSplit{(int)(blockIdx.x % G), G, split_ws + (size_t)b * 2 * G * BM::WAVES * BM::TPW * 256, split_ctr + (size_t)b * 64, 0u, spin_limit};
+        s.split_failed = 0;
+    }
     if (!lead) { x_stage0 = nullptr; err_trace = nullptr; phase_out = nullptr; }
     for (int i = tid; i < DOF; i += BM::THREADS) s.x[i] = 0.0;
     lm_setup(s, C, M, markers + (size_t)b * M * 3, valid + (size_t)b * M);
@@ -973,7 +987,7 @@ __global__ void __launch_bounds__(BM::THREADS) smpl_lm_fit_kernel(SmplConsts C, 
                     for (int i = tid; i < DOF; i += BM::THREADS) s.x[i] += step * s.delta[i];
                     __syncthreads();
                 }
-                lm_linearize(s, C, M, nb, nullptr, false, G > 1 ? &split : nullptr);
+                lm_linearize(s, M, nb, nullptr, false, G > 1);
                 if (G > 1 && s.split_failed) break;            // abandoned (uniform): fall through to the NaN write-out
                 const float err = (float)s.err;
                 if (it >= 0) {
@@ -1052,7 +1066,7 @@ __global__ void __launch_bounds__(BM::THREADS) smpl_adam_fit_kernel(SmplConsts C
             // the last stage-0 iteration (the reference's `verts` then still hold that forward, fit_SMPL_Adam.py:221-225)
             if (x_last && it == iters - 1 && (stage == 1 || it1 == 0))
                 for (int i = tid; i < DOF; i += BM::THREADS) x_last[(size_t)b * DOF + i] = (float)s.x[i];
-            lm_linearize(s, C, M, nb, nullptr, true);
+            lm_linearize(s, M, nb, nullptr, true);
             if (loss_trace && tid == 0) loss_trace[(size_t)b * (it0 + it1) + trace_pos] = (float)(2.0 * s.err * ninv);   // this scan's share of L
             ++trace_pos;
             b1t *= (double)beta1; b2t *= (double)beta2;
@@ -1086,7 +1100,7 @@ __global__ void __launch_bounds__(BM::THREADS) smpl_lm_linearize_kernel(SmplCons
     const int b = blockIdx.x, tid = threadIdx.x;
     for (int i = tid; i < DOF; i += BM::THREADS) s.x[i] = (double)x_in[(size_t)b * DOF + i];
     lm_setup(s, C, M, markers + (size_t)b * M * 3, valid + (size_t)b * M);
-    lm_linearize(s, C, M, nb, jac + (size_t)b * M * 3 * DOF);
+    lm_linearize(s, M, nb, jac + (size_t)b * M * 3 * DOF);
     for (int i = tid; i < M * 3; i += BM::THREADS) resid[(size_t)b * M * 3 + i] = s.resid[i];
     if (normal)                 // (DOF+1) x (DOF+1) lower triangle, row DOF = -J^T r
         for (int e = tid; e < (DOF + 1) * (DOF + 1); e += BM::THREADS) {

@@ -59,6 +59,7 @@ struct WsShape {
 //       - half 1: requests the rows of the point after that.
 // Nothing in a phase is conditional (rows and stores of points past the end go through zero-sized buffer resources: loads return 0, stores
 // are dropped; anchors 60..63 of a tile fall outside the point's 60 x C records), so a phase is ONE basic block.
+#define SROW_REGS_C(C) ((C) <= 32)
 template <int C, bool NORM, bool STATS>     // NORM: mean / rstd given (InstanceNorm + LeakyReLU on load); STATS: stat_part given
 __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total, int pts_per_batch, const float* __restrict__ X,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -90,13 +91,20 @@ __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total,
     const float bo = bias[o_out];
     __syncthreads();
     // source rows of this lane's anchors (both halves) for the wave's three taps
-    int srow[2][3];
+    // (C = 64: 144 registers of weight fragments leave no room for the six offsets -- 8 spilled registers -- so they are re-read from the LDS
+    // table per phase: three ds_read_b32 beside 72 MFMAs)
+    constexpr bool SROW_REGS = SROW_REGS_C(C);
+    int srow[SROW_REGS ? 2 : 1][3];
+    if constexpr (SROW_REGS) {
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int a = 32 * half + j;
+        for (int half = 0; half < 2; ++half) {
+            const int a = 32 * half + j;
 #pragma unroll
-        for (int tl = 0; tl < 3; ++tl) srow[half][tl] = iidx[(a < NA ? a : 0) * 12 + 3 * kq + tl] * LDB;
+            for (int tl = 0; tl < 3; ++tl) srow[half][tl] = iidx[(a < NA ? a : 0) * 12 + 3 * kq + tl] * LDB;
+        }
     }
+    const int* irow_lo = iidx + j * 12 + 3 * kq;                          // anchor j
+    const int* irow_hi = iidx + (32 + j < NA ? 32 + j : 0) * 12 + 3 * kq;  // anchor 32 + j (60..63: anchor 0, results dropped)
 
     // ---- staging: rows of a point -> registers (raw) -> normalise, LeakyReLU, split -> three bf16 planes
     float4 pre[NPRE];
@@ -136,7 +144,7 @@ __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total,
         for (int v = 0; v < 16; ++v) acc[v] = 0.f;
 #pragma unroll
         for (int tl = 0; tl < 3; ++tl) {
-            const unsigned short* xrow = P + srow[half][tl] + 8 * kk;
+            const unsigned short* xrow = P + (SROW_REGS ? srow[SROW_REGS ? half : 0][tl] : (half ? irow_hi : irow_lo)[tl] * LDB) + 8 * kk;
 #pragma unroll
             for (int s_ = 0; s_ < SPT; ++s_) {
                 const int ks = tl * SPT + s_;
@@ -177,10 +185,12 @@ __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total,
     };
     auto finish_stats = [&](int pp) {               // after the barrier that follows the dred writes
         if (STATS && pp >= 0 && tid < C) {
+            int t2 = tid;
+            asm volatile("" : "+v"(t2));            // the store address is formed here, not hoisted out of the point loop as a 64-bit register pair (spilled at C = 64)
             double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-            for (int k = 0; k < NT / C; ++k) { a0 += dred[k * C + tid]; a1 += dred[NT + k * C + tid]; }
-            stat_part[(size_t)pp * 2 * C + tid] = a0; stat_part[(size_t)pp * 2 * C + C + tid] = a1;
+            for (int k = 0; k < NT / C; ++k) { a0 += dred[k * C + t2]; a1 += dred[NT + k * C + t2]; }
+            stat_part[(size_t)pp * 2 * C + t2] = a0; stat_part[(size_t)pp * 2 * C + C + t2] = a1;
         }
     };
 
