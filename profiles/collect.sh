@@ -18,6 +18,8 @@ grep '^{' $O/trace_default.log | tail -1 > $O/${tag}_bench_line_under_rocprof.js
 db=$(find $O/prof_default -name '*_results.db' | head -1)
 python3 profiles/summarize_rocpd.py $db > $O/${tag}_kernel_stats.txt
 python3 profiles/timeline_rocpd.py $db > $O/${tag}_stream_timeline.txt 2>&1
+echo "# --- inside two steady-state steps (profiles/scripts/gap_rocpd.py)" >> $O/${tag}_stream_timeline.txt
+python3 profiles/scripts/gap_rocpd.py $db >> $O/${tag}_stream_timeline.txt 2>&1
 rm -rf $O/prof_default
 run trace_serial --kernel-trace --stats -d $O/prof_serial -o serial -- python3 $R/bench.py --serial --steps 16 --warmup 3 --no-cpu-baseline --no-extras
 db=$(find $O/prof_serial -name '*_results.db' | head -1)

@@ -60,6 +60,24 @@ def main(path):
     print(f"busiest stream: idle between its kernels {tot_gap / nsteps / 1e6:.2f} ms/step; largest gaps (us, after -> before):")
     for g in gaps[:8]:
         print(f"  {g[0] / 1e3:9.1f}  {g[1]} -> {g[2]}")
+    # the step boundary of the stage-1 stream (last kernel of step i -> first conv of step i+1) IN TIME ORDER: the window above spans the
+    # warm-up steps, the barrier + device synchronisation in front of the timed region, the timed steps and the drain, so the few large
+    # gaps sit at those seams; the steady state is the run of consecutive boundaries in between
+    bnd = [(rs[i + 1][1] - rs[i][2], rs[i][2] - t0) for i in range(len(rs) - 1) if "inter_so3conv_c1" in rs[i + 1][0]]
+    print("step boundaries of the busiest stream in time order (ms after the window start: gap in us):")
+    print("   " + "  ".join(f"{at / 1e6:.0f}: {g / 1e3:.0f}" for g, at in bnd))
+    best, cur = [], []
+    for g, at in bnd:
+        if g < 2e6:
+            cur.append(g)
+            if len(cur) > len(best):
+                best = list(cur)
+        else:
+            cur = []
+    if best:
+        b2 = sorted(best)
+        print(f"steady state = the longest run of boundaries without a seam: {len(best)} boundaries, gap median {b2[len(b2) // 2] / 1e3:.0f} us, "
+              f"max {b2[-1] / 1e3:.0f} us")
 
 
 if __name__ == "__main__":
