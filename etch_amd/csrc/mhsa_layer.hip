@@ -15,6 +15,7 @@
 //   C  head_combine (+ bias + residual) from the attention tile in LDS, float4 stores.
 // Keys 60..63 (tile padding) are masked to -inf; rows 60..63 are never stored.
 #include "common.h"
+#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -252,7 +253,8 @@ template <int MODE>
 __global__ void __launch_bounds__(256, ML_LAYER_WPE) mhsa_layer_kernel(long T, const float* __restrict__ X, const float* __restrict__ Wq,
                                                             const float* __restrict__ Wk, const float* __restrict__ Wv,
                                                             const float* __restrict__ Wc, const float* __restrict__ bc,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, unsigned* __restrict__ ctr) {
+    __shared__ unsigned s_grab;
     __shared__ __attribute__((aligned(16))) unsigned short Xp[3 * ML_PL];                     // token tile, three planes
     __shared__ __attribute__((aligned(16))) float Asm[MODE == 2 ? 64 * ML_S : 3 * ML_PL / 2];   // attention tile: fp32 (MODE 2) or three planes
     float* As = Asm;
@@ -276,13 +278,19 @@ __global__ void __launch_bounds__(256, ML_LAYER_WPE) mhsa_layer_kernel(long T, c
         x0 = src_[tid]; x1 = src_[tid + 256]; x2 = src_[tid + 512];                          \
         if (tid < ML_TOK * ML_C / 4 - 768) x3 = src_[tid + 768];                             \
     }
-    long pt = blockIdx.x;
+    // Work distribution.  The workgroups are persistent; under the 2-deep pipeline other streams' kernels share the compute units unevenly, and a
+    // static round-robin makes the whole launch wait for the workgroups that were slowed down.  With `ctr` (zeroed by the launcher) the first two
+    // points of a workgroup are static and every further one is taken from a device-wide counter: thread 0 asks for the point after next while the
+    // current one computes (the atomic's latency disappears behind the layer), the answer crosses LDS behind the loop's last barrier.
+    long pt = blockIdx.x, nxt = (long)blockIdx.x + gridDim.x;
     if (pt < T) ML_GLOAD(pt)
-    for (; pt < T; pt += gridDim.x) {
+    for (; pt < T;) {
         ml_stage4(Xp, tid, x0); ml_stage4(Xp, tid + 256, x1); ml_stage4(Xp, tid + 512, x2);
         if (tid < ML_TOK * ML_C / 4 - 768) ml_stage4(Xp, tid + 768, x3);
         __syncthreads();
-        if (pt + gridDim.x < T) ML_GLOAD(pt + gridDim.x)      // next point's tokens: in flight during the whole layer
+        if (nxt < T) ML_GLOAD(nxt)                            // next point's tokens: in flight during the whole layer
+        unsigned grabbed = 0u;
+        if (ctr && tid == 0) grabbed = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
         f32x4 Q[4], Kt[4], V[4];
         ml_project(Xp, W, Q, Kt, V, fr, fg);
@@ -313,7 +321,10 @@ __global__ void __launch_bounds__(256, ML_LAYER_WPE) mhsa_layer_kernel(long T, c
                 }
             }
         }
+        if (ctr && tid == 0) s_grab = grabbed;
         __syncthreads();      // Xp / As are rewritten by the next point
+        pt = nxt;
+        nxt = ctr ? 2L * gridDim.x + s_grab : nxt + gridDim.x;
     }
 }
 
@@ -362,7 +373,8 @@ __global__ void __launch_bounds__(256, MHSA_INTERP_WGS) mhsa_interp_layer_kernel
                                                                    const int* __restrict__ sched, const float* __restrict__ Wq,
                                                                    const float* __restrict__ Wk, const float* __restrict__ Wv,
                                                                    const float* __restrict__ Wc, const float* __restrict__ bc,
-                                                                   float* __restrict__ out) {
+                                                                   float* __restrict__ out, unsigned* __restrict__ ctr) {
+    __shared__ unsigned s_grab;
     extern __shared__ __attribute__((aligned(16))) float ml_dyn[];
     unsigned short* Xp = reinterpret_cast<unsigned short*>(ml_dyn);                // token tile, three planes (the residual is rebuilt from them: exact)
     unsigned short* Ap = Xp + 3 * ML_PL;                                           // attention tile, three planes
@@ -388,14 +400,16 @@ __global__ void __launch_bounds__(256, MHSA_INTERP_WGS) mhsa_interp_layer_kernel
     const long share = (T + 7) >> 3;                    // contiguous slots of the spatial order per XCD
     const int per = gridDim.x >> 3, xcd = blockIdx.x & 7;
     const long lim = share < T - xcd * share ? share : T - xcd * share;
-    long q = blockIdx.x >> 3;
+    // positions in the XCD's share of the spatial order: the first three of a workgroup are static, every further one comes from the XCD's counter
+    // (see mhsa_layer_kernel; per-XCD counters keep the coarse rows of neighbouring points in that XCD's L2)
+    long q = blockIdx.x >> 3, q1 = q + (gridDim.x >> 3), q2 = q1 + (gridDim.x >> 3);
     // Scalar state of a point = one 32-byte record of `sched` (output row, three coarse rows, three weights), read two points ahead:
     // the record of point k+2 is requested while point k computes, so that the token rows of k+1 can be requested at the top of k
     // without waiting for a scalar load (order -> idx -> rows would be three dependent latencies per point).
     const int4* rec = reinterpret_cast<const int4*>(sched) + 2 * (xcd * share);
     int4 c_i = make_int4(0, 0, 0, 0), c_w = c_i, n_i = c_i, n_w = c_i;
     if (q < lim) { c_i = rec[2 * q]; c_w = rec[2 * q + 1]; }
-    if (q + per < lim) { n_i = rec[2 * (q + per)]; n_w = rec[2 * (q + per) + 1]; }
+    if (q1 < lim) { n_i = rec[2 * q1]; n_w = rec[2 * q1 + 1]; }
     // raw token rows of a point: element e = tid + 256 h of each of its three coarse rows
     float4 xa[4], xb[4], xc[4];
 #define ML_XLOAD(R)                                                                        \
@@ -411,7 +425,7 @@ __global__ void __launch_bounds__(256, MHSA_INTERP_WGS) mhsa_interp_layer_kernel
 #pragma unroll
     for (int h = 0; h < 4; ++h) xa[h] = xb[h] = xc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (q < lim) ML_XLOAD(c_i)
-    for (; q < lim; q += per) {
+    for (; q < lim;) {
         const long cpt = c_i.x;
         const float a0 = __int_as_float(c_w.x), a1 = __int_as_float(c_w.y), a2 = __int_as_float(c_w.z);
         // the token tile itself (projections, residual)
@@ -424,9 +438,11 @@ __global__ void __launch_bounds__(256, MHSA_INTERP_WGS) mhsa_interp_layer_kernel
             }
         }
         // the next point's token rows: in flight during the whole layer
-        if (q + per < lim) ML_XLOAD(n_i)
+        if (q1 < lim) ML_XLOAD(n_i)
         c_i = n_i; c_w = n_w;
-        if (q + 2 * per < lim) { n_i = rec[2 * (q + 2 * per)]; n_w = rec[2 * (q + 2 * per) + 1]; }
+        if (q2 < lim) { n_i = rec[2 * q2]; n_w = rec[2 * q2 + 1]; }
+        unsigned grabbed = 0u;
+        if (ctr && tid == 0) grabbed = __hip_atomic_fetch_add(ctr + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
 
         f32x4 Q[4], Kt[4], V[4];
@@ -455,7 +471,10 @@ __global__ void __launch_bounds__(256, MHSA_INTERP_WGS) mhsa_interp_layer_kernel
                     make_float4(y[tt][0] + bias.x + rx.x, y[tt][1] + bias.y + rx.y, y[tt][2] + bias.z + rx.z, y[tt][3] + bias.w + rx.w);
             }
         }
+        if (ctr && tid == 0) s_grab = grabbed;
         __syncthreads();      // Xp / Ap are rewritten by the next point
+        q = q1; q1 = q2;
+        q2 = ctr ? 3L * per + s_grab : q2 + per;
     }
 #undef ML_XLOAD
 }
@@ -487,6 +506,33 @@ __global__ void __launch_bounds__(256) token_mean_kernel(long T, int A, int C, c
     }
 }
 
+__global__ void mhsa_zero_counters_kernel(unsigned* slot) {
+    if (threadIdx.x < 8) slot[threadIdx.x] = 0u;
+}
+
+// Work counters of the persistent layer kernels: a ring of zero-initialised words in device memory, one slot (8 words: one per XCD for the interp
+// layer) per launch, re-zeroed on the launch's stream in front of the kernel.  Allocated on first use outside a
+// capture; if that is not possible the kernels get no counter and fall back to the static round-robin.  ETCH_MHSA_DYNAMIC=0 does the same.
+static unsigned* mhsa_counter_slot(hipStream_t st) {
+    static unsigned* ring = nullptr;
+    static int state = 0, next = 0;            // state: 0 untried, 1 ready, -1 unavailable
+    constexpr int SLOTS = 512;
+    if (state == 0) {
+        const char* env = getenv("ETCH_MHSA_DYNAMIC");
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (env && env[0] == '0') state = -1;
+        else if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;      // try again on a later call
+        else state = hipMalloc((void**)&ring, SLOTS * 8 * sizeof(unsigned)) == hipSuccess ? 1 : -1;
+    }
+    if (state != 1) return nullptr;
+    unsigned* slot = ring + (size_t)(next++ % SLOTS) * 8;
+    // zeroed by a one-wave kernel on the same queue, not by hipMemsetAsync: a memset goes through the runtime's blit / copy path, which under the
+    // multi-stream pipeline occasionally stalled a step (one bench run in eleven at 605 instead of 720 scans/s; none with the kernel)
+    hipLaunchKernelGGL(mhsa_zero_counters_kernel, dim3(1), dim3(64), 0, st, slot);
+    if (hipGetLastError() != hipSuccess) return nullptr;
+    return slot;
+}
+
 template <int MODE>
 static int launch_layer(long T, const float* X, const float* Wq, const float* Wk, const float* Wv, const float* Wc, const float* bc,
                         float* out, hipStream_t st) {
@@ -499,7 +545,7 @@ static int launch_layer(long T, const float* X, const float* Wq, const float* Wk
     }
     long blocks = (long)etch_cu_count() * per_cu;
     if (blocks > T) blocks = T;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, T, X, Wq, Wk, Wv, Wc, bc, out);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, T, X, Wq, Wk, Wv, Wc, bc, out, mhsa_counter_slot(st));
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }
@@ -535,7 +581,7 @@ extern "C" int etch_mhsa_interp_layer(int B, int N, int S, const float* F, const
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(interp_schedule_kernel, dim3((unsigned)(((long)B * N + 255) / 256)), dim3(256), 0, st, B, N, S, idx, weight, order,
                        reinterpret_cast<int4*>(sched));
-    hipLaunchKernelGGL(mhsa_interp_layer_kernel, dim3((unsigned)(((etch_cu_count() + 7) / 8) * 8 * per_cu)), dim3(256), ML_INTERP_LDS, st, B, N, S, F, sched, Wq, Wk, Wv, Wc, bc, out);
+    hipLaunchKernelGGL(mhsa_interp_layer_kernel, dim3((unsigned)(((etch_cu_count() + 7) / 8) * 8 * per_cu)), dim3(256), ML_INTERP_LDS, st, B, N, S, F, sched, Wq, Wk, Wv, Wc, bc, out, mhsa_counter_slot(st));
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }
