@@ -506,33 +506,6 @@ __global__ void __launch_bounds__(256) token_mean_kernel(long T, int A, int C, c
     }
 }
 
-__global__ void mhsa_zero_counters_kernel(unsigned* slot) {
-    if (threadIdx.x < 8) slot[threadIdx.x] = 0u;
-}
-
-// Work counters of the persistent layer kernels: a ring of zero-initialised words in device memory, one slot (8 words: one per XCD for the interp
-// layer) per launch, re-zeroed on the launch's stream in front of the kernel.  Allocated on first use outside a
-// capture; if that is not possible the kernels get no counter and fall back to the static round-robin.  ETCH_MHSA_DYNAMIC=0 does the same.
-static unsigned* mhsa_counter_slot(hipStream_t st) {
-    static unsigned* ring = nullptr;
-    static int state = 0, next = 0;            // state: 0 untried, 1 ready, -1 unavailable
-    constexpr int SLOTS = 512;
-    if (state == 0) {
-        const char* env = getenv("ETCH_MHSA_DYNAMIC");
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (env && env[0] == '0') state = -1;
-        else if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;      // try again on a later call
-        else state = hipMalloc((void**)&ring, SLOTS * 8 * sizeof(unsigned)) == hipSuccess ? 1 : -1;
-    }
-    if (state != 1) return nullptr;
-    unsigned* slot = ring + (size_t)(next++ % SLOTS) * 8;
-    // zeroed by a one-wave kernel on the same queue, not by hipMemsetAsync: a memset goes through the runtime's blit / copy path, which under the
-    // multi-stream pipeline occasionally stalled a step (one bench run in eleven at 605 instead of 720 scans/s; none with the kernel)
-    hipLaunchKernelGGL(mhsa_zero_counters_kernel, dim3(1), dim3(64), 0, st, slot);
-    if (hipGetLastError() != hipSuccess) return nullptr;
-    return slot;
-}
-
 template <int MODE>
 static int launch_layer(long T, const float* X, const float* Wq, const float* Wk, const float* Wv, const float* Wc, const float* bc,
                         float* out, hipStream_t st) {
@@ -545,7 +518,7 @@ static int launch_layer(long T, const float* X, const float* Wq, const float* Wk
     }
     long blocks = (long)etch_cu_count() * per_cu;
     if (blocks > T) blocks = T;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, T, X, Wq, Wk, Wv, Wc, bc, out, mhsa_counter_slot(st));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, T, X, Wq, Wk, Wv, Wc, bc, out, etch_work_counter_slot(st));
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }
@@ -581,7 +554,7 @@ extern "C" int etch_mhsa_interp_layer(int B, int N, int S, const float* F, const
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(interp_schedule_kernel, dim3((unsigned)(((long)B * N + 255) / 256)), dim3(256), 0, st, B, N, S, idx, weight, order,
                        reinterpret_cast<int4*>(sched));
-    hipLaunchKernelGGL(mhsa_interp_layer_kernel, dim3((unsigned)(((etch_cu_count() + 7) / 8) * 8 * per_cu)), dim3(256), ML_INTERP_LDS, st, B, N, S, F, sched, Wq, Wk, Wv, Wc, bc, out, mhsa_counter_slot(st));
+    hipLaunchKernelGGL(mhsa_interp_layer_kernel, dim3((unsigned)(((etch_cu_count() + 7) / 8) * 8 * per_cu)), dim3(256), ML_INTERP_LDS, st, B, N, S, F, sched, Wq, Wk, Wv, Wc, bc, out, etch_work_counter_slot(st));
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }

@@ -65,7 +65,8 @@ __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const int* __restrict__ intra_idx, const bf16x8* __restrict__ Wq,
                                                                  const float* __restrict__ bias, float* __restrict__ Y,
-                                                                 double* __restrict__ stat_part) {
+                                                                 double* __restrict__ stat_part, unsigned* __restrict__ ctr) {
+    __shared__ unsigned s_grab;
     using S = WsShape<C>;
     constexpr int NT = S::NT, MT = S::MT, KQ = S::KQ, NKS = S::NKS, LDB = S::LDB, PS = S::PS, PLANE = S::PLANE, NPRE = S::NPRE;
     constexpr int SPT = C / 16;                   // K steps per tap
@@ -75,7 +76,8 @@ __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total,
     float* part = reinterpret_cast<float*>(planes + 2 * 3 * PLANE);                          // [2 buffers][KQ][32 cols][PS]
     int* iidx = reinterpret_cast<int*>(part + 2 * KQ * 32 * PS);                              // [60][12]
     double* dred = reinterpret_cast<double*>(iidx + NA * 12);                                 // [2][NT]
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, kk = lane >> 5;
     const int mt = wave % MT, kq = wave / MT;
     const int npairs = (npts_total + 1) >> 1;
@@ -87,7 +89,7 @@ __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total,
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) aq[ks][pl] = Wq[((((size_t)mt * KQ + kq) * NKS + ks) * 3 + pl) * 64 + lane];
     for (int e = tid; e < NA * 12; e += NT) iidx[e] = intra_idx[e];
-    const int o_out = tid % C;                    // the output channel this thread writes in every phase (NT % C == 0)
+    int o_out = tid % C;                          // the output channel this thread writes in every phase (NT % C == 0)
     const float bo = bias[o_out];
     __syncthreads();
     // source rows of this lane's anchors (both halves) for the wave's three taps
@@ -215,9 +217,13 @@ __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total,
     prefetch(2 * pp + 1);
     __syncthreads();
     int prev_pp = -1;                             // the pair whose last phase is still to be written (-1: none -- its stores are dropped)
+    // pairs: the first two of a workgroup are static, every further one comes from the launch's work counter (common.h: etch_work_counter_slot),
+    // asked for by thread 0 at the top of a pair and handed over through LDS behind the pair's last barrier
+    int nxt = pp + (int)gridDim.x;
 #pragma unroll 1
-    for (; pp < npairs; pp += gridDim.x) {
-        const int next = pp + (int)gridDim.x < npairs ? pp + (int)gridDim.x : npairs;      // (past the end: zero-sized resources)
+    for (; pp < npairs;) {
+        const int next = nxt < npairs ? nxt : npairs;      // (past the end: zero-sized resources)
+
         // phase (point 0, half 0): previous pair's last phase goes out; point 1 of this pair is staged
         emit(part1, 2 * prev_pp + 1, 1);
         if (STATS) { dred[tid] = st_s; dred[NT + tid] = st_q; }
@@ -239,15 +245,22 @@ __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total,
         multiply(P1, 0, part0);
         interleave();
         __syncthreads();
-        // phase (1, 1)
+        // phase (1, 1)  (+ the request for the pair after next: its answer has this phase's 72 MFMAs to arrive)
+        unsigned grabbed = 0u;
+        if (ctr && tid == 0) grabbed = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         emit(part0, 2 * pp + 1, 0);
         prefetch(2 * next + 1);
         multiply(P1, 1, part1);
         interleave();
+        if (ctr && tid == 0) s_grab = grabbed;
         __syncthreads();
         prev_pp = pp;
+        pp = next;
+        nxt = ctr ? 2 * (int)gridDim.x + __builtin_amdgcn_readfirstlane((int)s_grab) : nxt + (int)gridDim.x;      // wave-uniform: scalar registers
     }
-    // drain: the last phase's tiles, the last pair's statistics
+    // drain: the last phase's tiles, the last pair's statistics.  (The laundering keeps the drain's address arithmetic out of the registers the
+    // loop needs: values derived from tid / o_out for use down here were spilled across the whole loop at C = 64.)
+    asm volatile("" : "+v"(tid), "+v"(o_out));
     emit(part1, 2 * prev_pp + 1, 1);
     if (STATS) { dred[tid] = st_s; dred[NT + tid] = st_q; }
     __syncthreads();
@@ -270,7 +283,7 @@ static int launch_intra_ws_t(int npts, int ppb, const float* X, const float* mea
     int grid = etch_cu_count() * wgs_per_cu;
     if (grid > npairs) grid = npairs;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(S::NT), S::lds_bytes, st, npts, ppb, X, mean, rstd, intra_idx, reinterpret_cast<const bf16x8*>(Wq), bias, Y,
-                       stat_part);
+                       stat_part, etch_work_counter_slot(st));
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }
