@@ -81,14 +81,14 @@ __device__ __forceinline__ float etch_wave_max_f32(float v) {
 
 // ---- work counters of the persistent kernels (mhsa layers, intra conv).  Under the 2-deep pipeline other streams' kernels share the compute units
 // unevenly; a static round-robin over persistent workgroups then makes a launch wait for the workgroups that were slowed down.  The kernels take
-// their first items statically and every further one from a device counter.  A counter = one slot (8 words: one per XCD where a kernel keeps
-// per-XCD lists) of a ring in device memory, allocated on first use outside a graph capture and re-zeroed on the launch's stream in front of the
+// their first items statically and every further one from a device counter.  A counter = one slot (64 words: one per XCD where a kernel keeps
+// per-XCD lists, one per column block of the fused dense head) of a ring in device memory, allocated on first use outside a graph capture and re-zeroed on the launch's stream in front of the
 // kernel by a one-wave kernel -- not by hipMemsetAsync: a memset goes through the runtime's blit / copy path, which under the multi-stream pipeline
 // occasionally stalled a step (one bench run in eleven at 605 instead of 720 scans/s; none in 14 with the kernel).  No counter (allocation not
 // possible, ETCH_DYNAMIC_WORK=0 / ETCH_MHSA_DYNAMIC=0) = the static round-robin.  One ring per translation unit.
 #include <cstdlib>
 static __global__ void etch_zero_counters_kernel(unsigned* slot) {
-    if (threadIdx.x < 8) slot[threadIdx.x] = 0u;
+    slot[threadIdx.x] = 0u;
 }
 static inline unsigned* etch_work_counter_slot(hipStream_t st) {
     static unsigned* ring = nullptr;
@@ -100,10 +100,10 @@ static inline unsigned* etch_work_counter_slot(hipStream_t st) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if ((e1 && e1[0] == '0') || (e2 && e2[0] == '0')) state = -1;
         else if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;      // try again on a later call
-        else state = hipMalloc((void**)&ring, SLOTS * 8 * sizeof(unsigned)) == hipSuccess ? 1 : -1;
+        else state = hipMalloc((void**)&ring, SLOTS * 64 * sizeof(unsigned)) == hipSuccess ? 1 : -1;
     }
     if (state != 1) return nullptr;
-    unsigned* slot = ring + (size_t)(next++ % SLOTS) * 8;
+    unsigned* slot = ring + (size_t)(next++ % SLOTS) * 64;
     hipLaunchKernelGGL(etch_zero_counters_kernel, dim3(1), dim3(64), 0, st, slot);
     if (hipGetLastError() != hipSuccess) return nullptr;
     return slot;

@@ -294,10 +294,11 @@ static int launch_lrd_bx(long R, int G, const float* X, long ldx, const void* Wq
 // SPW = strips per wave: 2 (a column block = two groups, 16 strips over the 8 waves) or 1 (a column block = one group: G = 1, the direction
 // head's tail, whose 49 KB of weights stream from L2 for nothing otherwise and whose 9.6 M rows make the epilogue the larger half of the work).
 template <int K, int SPW>
-__global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, long rows_per_block, const float* __restrict__ X, long ldx,
+__global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, const float* __restrict__ X, long ldx,
                                                                  const bf16x8* __restrict__ Wq, const float* __restrict__ b1,
                                                                  const float* __restrict__ w2, const float* __restrict__ b2,
-                                                                 float* __restrict__ out, long ldo) {
+                                                                 float* __restrict__ out, long ldo, unsigned* __restrict__ ctr) {
+    __shared__ unsigned s_grab[2];
     // 64-row tiles, planes and reduction table double-buffered: ONE barrier per tile, and the next tile's split + LDS stores sit between the two
     // halves of this tile's MFMA stream (VALU work beside the bf16 matrix cores is free; beside a barrier it is not)
     constexpr int FD_ROWS = 64, SB = K + 8, KT = K / 32, PLANE = FD_ROWS * SB, RT = FD_ROWS / 16;
@@ -332,7 +333,12 @@ __global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, 
 
     constexpr int C4 = K / 4;
     constexpr int XL = (FD_ROWS * C4 + 511) / 512;
-    const long row_lo = rb * rows_per_block, row_hi = row_lo + rows_per_block < R ? row_lo + rows_per_block : R;
+    // row tiles of the column block: the first three of a workgroup are static (rb, rb + nrb, rb + 2 nrb), every further one comes from the column
+    // block's work counter (common.h: etch_work_counter_slot) -- asked for two tiles ahead, handed over through LDS (double-buffered: the loop has one
+    // barrier per tile); without a counter the round-robin continues
+    const long row_hi = R, ntiles = (R + FD_ROWS - 1) / FD_ROWS;
+    const int nrb = gridDim.y;
+    long t0 = rb, t1 = t0 + nrb, t2 = t1 + nrb;
     float4 xn[XL];
     auto fetch = [&](long r0) {
 #pragma unroll
@@ -395,19 +401,26 @@ __global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, 
             if (fg == 0) rt[(i0 + i) * 16 + fr] = tsum;
         }
     };
-    fetch(row_lo);
+    if (t0 >= ntiles) return;
+    fetch(t0 * FD_ROWS);
     stage(Xp);
-    fetch(row_lo + FD_ROWS);
+    fetch(t1 * FD_ROWS);                          // (tiles past the end: rows >= R are fetched as zeros)
     __syncthreads();
     int buf = 0;
-    for (long r0 = row_lo; r0 < row_hi; r0 += FD_ROWS, buf ^= 1) {
+    for (; t0 < ntiles; buf ^= 1) {
+        const long r0 = t0 * FD_ROWS;
         const unsigned short* P = Xp + buf * 3 * PLANE;
         float* rtab = red + buf * 8 * FD_ROWS;
+        unsigned grabbed = 0u;
+        if (ctr && tid == 0) grabbed = __hip_atomic_fetch_add(ctr + (cb & 63), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         half_tile(P, 0, rtab + wave * FD_ROWS);
-        stage(Xp + (buf ^ 1) * 3 * PLANE);       // tile r0 + 64 (its last readers finished before the previous barrier)
-        fetch(r0 + 2 * FD_ROWS);
+        stage(Xp + (buf ^ 1) * 3 * PLANE);       // the next tile (its buffer's last readers finished before the previous barrier)
+        fetch(t2 * FD_ROWS);
         half_tile(P, 2, rtab + wave * FD_ROWS);
+        if (ctr && tid == 0) s_grab[buf] = grabbed;
         __syncthreads();
+        t0 = t1; t1 = t2;
+        t2 = ctr ? 3L * nrb + __builtin_amdgcn_readfirstlane((int)s_grab[buf]) : t2 + nrb;
         if (tid < GPB * FD_ROWS) {               // thread = (group of the block, row): the group's waves in wave order
             const int gi = tid / FD_ROWS, row = tid % FD_ROWS;
             if (GPB * cb + gi < G && r0 + row < row_hi) {
@@ -441,10 +454,13 @@ static int launch_lrd_ws(long R, int G, const float* X, long ldx, const void* Wq
     const int ncb = (G + SPW - 1) / SPW;
     int nrb = etch_cu_count() * per_cu / ncb;    // resident workgroups: row blocks per column block
     if (nrb < 1) nrb = 1;
-    long rpb = (R + nrb - 1) / nrb;
-    rpb = (rpb + FD_ROWS - 1) / FD_ROWS * FD_ROWS;
-    nrb = (int)((R + rpb - 1) / rpb);
-    hipLaunchKernelGGL(kern, dim3((unsigned)ncb, (unsigned)nrb), dim3(512), lds, st, R, G, rpb, X, ldx, reinterpret_cast<const bf16x8*>(Wq), b1, w2, b2, out, ldo);
+    const long ntiles = (R + FD_ROWS - 1) / FD_ROWS;
+    if (nrb > ntiles) nrb = (int)ntiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)ncb, (unsigned)nrb), dim3(512), lds, st, R, G, X, ldx, reinterpret_cast<const bf16x8*>(Wq), b1, w2, b2, out, ldo,
+                       // one column block only (the direction tail).  With many column blocks (the confidence head: 43) the workgroups of a row position
+                       // walk the same X tiles in lock-step and share them through L2; per-block counters let them drift apart (measured: 706 against
+                       // 744 scans/s, and unstable) -- those launches keep the static round-robin
+                       ncb == 1 ? etch_work_counter_slot(st) : nullptr);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }
