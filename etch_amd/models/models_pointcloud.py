@@ -268,7 +268,9 @@ class GT_network_equiv(nn.Module):
         from .so3conv import input_xyz
         main = torch.cuda.current_stream()
         if not hasattr(self, "_side_stream"):
-            self._side_stream = torch.cuda.Stream()
+            # the index ops of batch i+1 (two dependent FPS chains on 32 workgroups, ball queries, kNN) are what the first conv of batch i+1 waits for:
+            # a high-priority queue lets their few workgroups start as soon as a compute unit has room instead of behind the chip-wide kernels
+            self._side_stream = torch.cuda.Stream(priority=int(os.environ.get("ETCH_INDEX_STREAM_PRIORITY", "-1")))
         side = self._side_stream
         side.wait_stream(self.input_producer if self.input_producer is not None else main)
         made = []
@@ -289,6 +291,8 @@ class GT_network_equiv(nn.Module):
                         made.append(od)
             epn_ready = torch.cuda.Event()
             epn_ready.record(side)
+            # (the Point-Transformer nets' FPS / kNN chain stays on this stream behind the EPN part: a stream of its own -- so that the next batch's first
+            # FPS does not queue behind this batch's kNN queries -- measured no better, 6 streams on 4 hardware queues)
             if want_pt:
                 oh = [N * (i + 1) for i in range(B)]
                 o = pointops.offsets_tensor(oh, hitpts.device)
