@@ -494,7 +494,7 @@ def main():
                         frozen=(tr[:, 1:] == tr[:, :-1]).sum(1))
 
         step = stage1_only if a.forward_only else full_step
-        pipe = HotPathPipeline(args, model, "neutral", max_in_flight=a.stage1_streams + 1, stage1_streams=a.stage1_streams, want_trace=True, **fit_kw)
+        pipe = HotPathPipeline(args, model, "neutral", max_in_flight=int(os.environ.get("ETCH_MAX_IN_FLIGHT", a.stage1_streams + 1)), stage1_streams=a.stage1_streams, want_trace=True, **fit_kw)
 
         def run_steps(bs):
             """One step per batch of `bs`; with the pipeline, stage 2 of step i overlaps stage 1 of step i+1 (all finish inside the call)."""
