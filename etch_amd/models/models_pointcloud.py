@@ -268,9 +268,8 @@ class GT_network_equiv(nn.Module):
         from .so3conv import input_xyz
         main = torch.cuda.current_stream()
         if not hasattr(self, "_side_stream"):
-            # the index ops of batch i+1 (two dependent FPS chains on 32 workgroups, ball queries, kNN) are what the first conv of batch i+1 waits for:
-            # a high-priority queue lets their few workgroups start as soon as a compute unit has room instead of behind the chip-wide kernels
-            self._side_stream = torch.cuda.Stream(priority=int(os.environ.get("ETCH_INDEX_STREAM_PRIORITY", "-1")))
+            # (normal priority: as a high-priority queue it starves the stage-2 fit, see pipeline.py)
+            self._side_stream = torch.cuda.Stream(priority=int(os.environ.get("ETCH_INDEX_STREAM_PRIORITY", "0")))
         side = self._side_stream
         side.wait_stream(self.input_producer if self.input_producer is not None else main)
         made = []
