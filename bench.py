@@ -510,11 +510,24 @@ def main():
     run_steps([pts] * min(2, a.warmup))
     P.barrier()
     sync()
+    import gc
+    if os.environ.get("ETCH_BENCH_GC", "1") == "0":
+        gc.collect(); gc.disable()
+    seg0 = torch.cuda.memory_stats().get("segment.all.allocated", 0) if device.type == "cuda" else 0
+    gc0 = [g["collections"] for g in gc.get_stats()]
     t0 = time.perf_counter()
     run_steps(timed)
     sync()
     P.barrier()
     dt = P.max_over_ranks(time.perf_counter() - t0, device)
+    if os.environ.get("ETCH_PIPE_TIMING") == "1" and device.type == "cuda":
+        print("timed region: allocator segments allocated %d, gc collections per generation %s" % (
+            torch.cuda.memory_stats().get("segment.all.allocated", 0) - seg0, [g["collections"] - c for g, c in zip(gc.get_stats(), gc0)]), file=sys.stderr)
+    gc.enable()
+    if a.pipeline and getattr(pipe, "host_times", None):
+        ht = np.array(pipe.host_times[-a.steps:])
+        print("host ms per submit (wait for the oldest ticket / finalize it / enqueue the batch): median %s, max %s; enqueue ms per step: %s"
+              % (np.round(np.median(ht, 0), 2), np.round(ht.max(0), 2), " ".join("%.0f" % v for v in ht[:, 2])), file=sys.stderr)
     # the same K steps without the cross-step overlap (untimed here; reported next to the headline for transparency)
     sync()
     ts = time.perf_counter()

@@ -30,15 +30,21 @@ class HotPathPipeline:
         self.in_flight = []
         self._pinned = [None] * (max_in_flight + 1)     # ring of pinned host buffers, one set per batch in flight (+1 being read)
         self._n = 0
+        self.host_times = [] if os.environ.get("ETCH_PIPE_TIMING") == "1" else None
 
     def submit(self, points):
         """Enqueue one batch (B,N,3) resident on the device; returns a Ticket.  Does not block on the GPU unless
         `max_in_flight` batches are already outstanding: the pinned host buffers are a ring of max_in_flight + 1 slots, so the
         oldest ticket is then retired first (host waits for it; its result is kept on the ticket for result())."""
+        import time
+        t0 = time.perf_counter()
+        t1 = t0
         while len(self.in_flight) >= self.max_in_flight:
             oldest = self.in_flight.pop(0)
             oldest.done.synchronize()
+            t1 = time.perf_counter()
             oldest.finalized = fit_smpl_finalize(oldest.fit)
+        t2 = time.perf_counter()
         caller = torch.cuda.current_stream()
         s1 = self.s1s[self._n % len(self.s1s)]
         s1.wait_stream(caller)
@@ -75,6 +81,8 @@ class HotPathPipeline:
                 done.record(self.s2)
         t = Ticket(done, results, fit)
         self.in_flight.append(t)
+        if self.host_times is not None:      # (wait for the oldest ticket, finalize it, enqueue this batch) in ms: diagnostics
+            self.host_times.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (time.perf_counter() - t2) * 1e3))
         return t
 
     def result(self, ticket):
