@@ -391,17 +391,21 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads of the cpu_baseline leg (0: min(32, cores))")
     ap.add_argument("--no-pin", action="store_true", help="do not pin ranks to the cores of their GPU's NUMA node (N > 1 only)")
     ap.add_argument("--sync", action="store_true", help="synchronous steps (stage 2 of a batch finishes before stage 1 of the next starts). Default: the "
-                    "2-deep stream pipeline of etch_amd.pipeline -- stage 2 of step i (32 persistent workgroups, 1/8 of the chip) runs on a second "
+                    "stream pipeline of etch_amd.pipeline (3 batches in flight) -- stage 2 of step i (32 persistent workgroups, 1/8 of the chip) runs on a second "
                     "HIP stream next to stage 1 of step i+1; every one of the K steps still completes inside the timed region")
     ap.add_argument("--serial", action="store_true", help="profiling schedule: synchronous steps and every kernel on one stream")
     ap.add_argument("--unfused-interp", action="store_true", help="A/B: separate 3-NN interpolation kernel in front of the direction head")
-    ap.add_argument("--stage1-streams", type=int, default=1, help="stage-1 streams the pipeline alternates over (batches in flight = this + 1)")
+    ap.add_argument("--stage1-streams", type=int, default=1, help="stage-1 streams the pipeline alternates over (batches in flight = this + 2; ETCH_MAX_IN_FLIGHT overrides)")
     ap.add_argument("--concurrent-heads", type=int, default=1, help="1: confidence / magnitude nets on their own streams next to the direction head")
     ap.add_argument("--graph-latency-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--preflight", action="store_true", help="print, WITHOUT touching a GPU, what each of the --gpus N ranks would do: its shard of the "
                     "global batch, the CPU set it would pin itself to, the rendezvous and the RCCL-relevant environment -- so that a failed scaling run "
                     "can be diagnosed from its log")
     a = ap.parse_args()
+    # batches in flight: with 2 the host submits batch i+1 only after batch i-1 has finished stage 2 -- whose start waits for that batch's Point-Transformer
+    # nets, which trail into the next batch's encoder -- so that every other step's index ops were enqueued late and its first conv idled 3.5 ms on them
+    # (profiles/r04_stream_timeline.txt); with 3 the step boundary is a steady 0.3 ms
+    in_flight = int(os.environ.get("ETCH_MAX_IN_FLIGHT", a.stage1_streams + 2))
     if a.graph_latency_child:
         graph_latency_child(a.points or 5000)
         return
@@ -494,7 +498,7 @@ def main():
                         frozen=(tr[:, 1:] == tr[:, :-1]).sum(1))
 
         step = stage1_only if a.forward_only else full_step
-        pipe = HotPathPipeline(args, model, "neutral", max_in_flight=int(os.environ.get("ETCH_MAX_IN_FLIGHT", a.stage1_streams + 1)), stage1_streams=a.stage1_streams, want_trace=True, **fit_kw)
+        pipe = HotPathPipeline(args, model, "neutral", max_in_flight=in_flight, stage1_streams=a.stage1_streams, want_trace=True, **fit_kw)
 
         def run_steps(bs):
             """One step per batch of `bs`; with the pipeline, stage 2 of step i overlaps stage 1 of step i+1 (all finish inside the call)."""
@@ -524,7 +528,7 @@ def main():
         print("timed region: allocator segments allocated %d, gc collections per generation %s" % (
             torch.cuda.memory_stats().get("segment.all.allocated", 0) - seg0, [g["collections"] - c for g, c in zip(gc.get_stats(), gc0)]), file=sys.stderr)
     gc.enable()
-    if a.pipeline and getattr(pipe, "host_times", None):
+    if a.pipeline and not dry and getattr(pipe, "host_times", None):
         ht = np.array(pipe.host_times[-a.steps:])
         print("host ms per submit (wait for the oldest ticket / finalize it / enqueue the batch): median %s, max %s; enqueue ms per step: %s"
               % (np.round(np.median(ht, 0), 2), np.round(ht.max(0), 2), " ".join("%.0f" % v for v in ht[:, 2])), file=sys.stderr)
@@ -543,7 +547,7 @@ def main():
     wp = None
     if not dry and not a.forward_only and not a.no_extras:
         mk_wp = well_posed_markers(args, device, B)
-        pipe_wp = HotPathPipeline(args, model, "neutral", max_in_flight=a.stage1_streams + 1, stage1_streams=a.stage1_streams, want_trace=True,
+        pipe_wp = HotPathPipeline(args, model, "neutral", max_in_flight=in_flight, stage1_streams=a.stage1_streams, want_trace=True,
                                   markers_override=mk_wp[:3], **fit_kw)
         for r_ in pipe_wp.run(iter([pts] * 2)):
             pass
@@ -589,7 +593,7 @@ def main():
                 f"configs[2]: batch={B}/GPU synthetic {N}-pt Gaussian-blob scans, full pipeline (eq-net + 30+50-iter LM SMPL fit), "
                 "seeded random weights, seeded SMPL-shaped body model, 86-marker superset")
     sched = ("serial: synchronous steps, one stream" if a.serial else "synchronous steps") if not a.pipeline else \
-        "2-deep stream pipeline: stage 2 of step i overlaps stage 1 of step i+1"
+        f"stream pipeline, {in_flight} batches in flight: stage 2 of step i overlaps stage 1 of step i+1, the host enqueues two steps ahead"
     metric = "scans/s (5k pts, eq-net forward only)" if a.forward_only else "scans/s (5k pts, eq-net + 50-iter SMPL fit)"
     if a.config == 4:
         metric = "scans/s (20k pts, eq-net + 200-iter SMPL-X-sized fit)"

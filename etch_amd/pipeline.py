@@ -16,7 +16,7 @@ class Ticket:
 
 
 class HotPathPipeline:
-    def __init__(self, args, model, gender="neutral", max_in_flight=2, stage1_streams=1, **fit_kwargs):
+    def __init__(self, args, model, gender="neutral", max_in_flight=3, stage1_streams=1, **fit_kwargs):
         self.args, self.model, self.gender, self.fit_kwargs = args, model, gender, fit_kwargs
         # stage 1 of consecutive batches alternates over `stage1_streams` streams: with 2, the low-occupancy kernels of one
         # batch (deep Point-Transformer levels: a few dozen workgroups) fill behind the chip-wide kernels of the other
