@@ -1,0 +1,404 @@
+// Inter SO(3) conv, round 5: the kernel weights come off the MATRIX pipe.
+//
+//   etch_inter_so3conv_planes_kq   replaces inter_so3conv_grouping_anchor + inter_so3conv_feat_grouping + BasicSO3Conv
+//                                  (/root/reference/external/vgtk/vgtk/so3conv/functional.py:286-324, :61-67, modules.py:33-39)
+//   etch_inter_kpoint_operand      rotated kernel points (functional.py:296) -> the B operand of the pre-activation product
+//
+// inter_so3conv_x32_kernel (so3conv_x.hip) generates every kernel weight w[a, k, n] = relu(1 - |g_n - R_a kappa_k|^2 / sigma) on the VALU: four
+// packed fp32 instructions per weight pair behind two LDS table reads, as a dependent chain per pair, laid between the matrix instructions in
+// program order -- profiles/r04_inter_x_counters_and_ablations.txt: with the gathers, step 1's MFMAs and step 2 compiled out the kernels still take
+// 2.2 / 1.5 / 2.2 ms, i.e. ~1 800 cycles per (anchor, chunk) step for ~150 instructions; packed fp32 instructions never hide behind an MFMA
+// (profiles/r04_mfma_bf16_issue_rates.txt).  Here the pre-activation
+//         P[n, k] = a_n + b_k + G_n . r_ak,    a_n = 1 - |g_n|^2 / sigma,  G_n = 2 g_n / sigma,  b_k = -|r_ak|^2 / sigma,  r_ak = R_a kappa_k
+// is a rank-5 bilinear form [a_n, 1, G_n] . [1, b_k, r_ak]; both factors are split exactly into three bf16 planes and the six largest cross terms
+// of the five products fill 30 of the 32 K slots of ONE pair of v_mfma_f32_32x32x16_bf16 per (anchor, 32-neighbour chunk): rows = neighbours,
+// columns = kernel points, so a lane's 16 accumulators are one kernel point x 16 neighbours -- exactly the B operand of step 1.  What is left on
+// the VALU per weight is the clamp and the exact split (v_med3, 2 and, 2 sub, 1.5 perm: plain instructions that hide beside MFMAs), written as
+// 16 independent chains per lane and interleaved with the step's matrix instructions by sched_group_barrier.
+//   * neighbour factor: built once per output point into an LDS table [nn][32 slots] bf16 and held in registers (8 VGPRs per chunk);
+//   * kernel-point factor: a table of the layer, [60 anchors][2][64 lanes][8] bf16 (122 880 bytes, L2-resident), two 16-byte loads per anchor;
+//   * the neighbour order of the product's rows is the staging tile's row order with bits 2 and 3 swapped, which makes the accumulator layout
+//     (rows 8 (v / 4) + 4 (lane / 32) + v % 4) land on the K slots 8 (lane / 32) + e of the two K steps of step 1.
+// Step 1 (transposed product on the gathered bf16 planes), the X1 tile, step 2 and the epilogue are those of inter_so3conv_x32_kernel.
+// No inline-asm LDS reads are left in the loop (see etch_amd/isa_lint.py for why that matters); the W stream of step 2 keeps its asm ring.
+#include "so3conv_x.h"
+
+#ifndef INTER_Y_WPE
+#define INTER_Y_WPE(CIN) ((CIN) <= 32 ? 2 : 1)
+#endif
+#ifndef INTER_Y_VPM
+#define INTER_Y_VPM(CIN) ((CIN) <= 32 ? 9 : 5)      // VALU instructions the scheduler is asked to place behind each step-1 MFMA
+#endif
+
+typedef unsigned y_u32x4 __attribute__((ext_vector_type(4)));
+
+// scheduling request for one step: N x (1 MFMA, then V VALU instructions) -- the arguments of the builtin must be literal constants
+template <int N, int V> __device__ __forceinline__ void y_sched_pattern() {
+    if constexpr (N > 0) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, V, 0);      // V VALU
+        y_sched_pattern<N - 1, V>();
+    }
+}
+
+// K slot s of the pre-activation product: term t = s / 5 (s < 30), component c = s % 5.  Planes (0 hi, 1 mid, 2 lo) of the two factors per term:
+//   term            0        1         2         3        4        5
+//   neighbour side  hi       hi        mid       hi       lo       mid
+//   kernel side     hi       mid       hi        lo       hi       mid
+__host__ __device__ constexpr int y_geo_plane(int t) { return t == 2 || t == 5 ? 1 : (t == 4 ? 2 : 0); }
+__host__ __device__ constexpr int y_kp_plane(int t) { return t == 1 || t == 5 ? 1 : (t == 3 ? 2 : 0); }
+
+struct Y3 { unsigned h, m, l; };          // bf16 bit patterns (in the low 16 bits) of the exact split of one fp32 value
+__device__ __forceinline__ Y3 y_split3(float v) {
+    const unsigned h = __float_as_uint(v);
+    const float r = v - __uint_as_float(h & 0xffff0000u);
+    const unsigned m = __float_as_uint(r);
+    const float q = r - __uint_as_float(m & 0xffff0000u);
+    return {h >> 16, m >> 16, __float_as_uint(q) >> 16};
+}
+__device__ __forceinline__ constexpr unsigned y_pick(const Y3& s, int plane) { return plane == 0 ? s.h : (plane == 1 ? s.m : s.l); }
+
+// [60][24][3] rotated kernel points -> kq [60][2 K steps][64 lanes][8] bf16: lane = 32 kg + k holds the slots 16 j + 8 kg + i of kernel point k
+// (components [1, b_k, r_x, r_y, r_z]; k >= 24: b = -1e30, r = 0: weight 0)
+__global__ void __launch_bounds__(128) inter_kpoint_operand_kernel(float inv_sigma, const float* __restrict__ rk, unsigned short* __restrict__ kq) {
+    const int a = blockIdx.x, j = threadIdx.x >> 6, lane = threadIdx.x & 63, k = lane & 31, kg = lane >> 5;
+    float comp[5] = {1.0f, -1e30f, 0.f, 0.f, 0.f};
+    if (k < KS) {
+        const float* r = rk + ((size_t)a * KS + k) * 3;
+        comp[1] = -(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * inv_sigma;
+        comp[2] = r[0]; comp[3] = r[1]; comp[4] = r[2];
+    }
+    const Y3 sp[5] = {y_split3(comp[0]), y_split3(comp[1]), y_split3(comp[2]), y_split3(comp[3]), y_split3(comp[4])};
+    unsigned short* dst = kq + (((size_t)a * 2 + j) * 64 + lane) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int s = 16 * j + 8 * kg + i;
+        dst[i] = (unsigned short)(s < 30 ? y_pick(sp[s % 5], y_kp_plane(s / 5)) : 0u);
+    }
+}
+
+template <int CIN, int COUT, int NCH>
+__global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
+    int p1, int p2, float inv_sigma, const float* __restrict__ xyz, const float* __restrict__ new_xyz, const int* __restrict__ ball_idx,
+    const unsigned short* __restrict__ Fq, const bf16x8* kq, const bf16x8* __restrict__ Wq, const float* __restrict__ bias,
+    float* __restrict__ out, const int* __restrict__ order, double* __restrict__ stat_part) {
+    constexpr int NN = 32 * NCH;
+    constexpr int AG = 32, NJ = 8, NG = 2;         // anchors per pass, per wave and pass; passes per point
+    constexpr int NT32 = CIN / 32;                 // 32-channel tiles of step 1
+    constexpr int MT2 = COUT / 32;                 // 32-wide output tiles of step 2
+    constexpr int CH = CIN / 2;                    // channels per X1 half
+    constexpr int NKR = CH / 2;                    // accumulator registers of a lane per half
+    constexpr int KH = CH * KS;                    // contraction length of step 2 per half
+    constexpr int S = KH + 44;                     // X1s row stride (floats), see inter_so3conv_x32_kernel
+    constexpr int PS = COUT + 4;
+    static_assert(4 * PS <= S, "the partial table must fit the X1 tile it aliases");
+    constexpr int ROWB = 3 * CIN * 2;
+    constexpr int PPR = CIN / 8, RPI = 64 / PPR, NRB = 32 / RPI;
+    constexpr int PLB = 32 * CIN * 2, STG = 3 * PLB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X1s = smem;                             // [32][S]
+    float* part = smem;                            // [4 waves][32 cols][PS], aliases X1s between the last product of a pass and the next pass
+    unsigned* geo = reinterpret_cast<unsigned*>(smem + AG * S);        // [NN][16 dwords]: the neighbour factor, 32 bf16 slots per neighbour
+    unsigned* noffs = geo + NN * 16;                                    // [NN] byte offset of the neighbour's anchor-0 row
+    float* dump = reinterpret_cast<float*>(noffs + NN);                 // [64 lanes][4]: where the lanes of the unused kernel points 24 .. 31 store
+    __shared__ __attribute__((aligned(16))) char stage[4 * STG];       // [4 waves][STG]: its own LDS object (see inter_so3conv_x_kernel)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    int p = blockIdx.x;
+    if (order) {
+        const int per = gridDim.x >> 3;
+        const int slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (slot >= p2) return;
+        p = order[(size_t)b * p2 + slot];
+    }
+    if (tid < NN) {
+        const int n = tid;
+        int q = ball_idx[((size_t)b * p2 + p) * NN + n];
+        const int qq = q < 0 ? 0 : q;
+        const float* X = xyz + (size_t)b * 3 * p1;
+        const float x = X[qq] - new_xyz[((size_t)b * 3 + 0) * p2 + p], y = X[p1 + qq] - new_xyz[((size_t)b * 3 + 1) * p2 + p],
+                    z = X[2 * p1 + qq] - new_xyz[((size_t)b * 3 + 2) * p2 + p];
+        // slot s = 5 t + c: plane y_geo_plane(t) of component c of [a_n, 1, G_x, G_y, G_z]
+        const Y3 s0 = y_split3(q < 0 ? -1e30f : 1.0f - (x * x + y * y + z * z) * inv_sigma), s1 = {0x3f80u, 0u, 0u},
+                 s2 = y_split3(2.0f * inv_sigma * x), s3 = y_split3(2.0f * inv_sigma * y), s4 = y_split3(2.0f * inv_sigma * z);
+#define Y_SLOT(s) ((s) >= 30 ? 0u : y_pick((s) % 5 == 0 ? s0 : (s) % 5 == 1 ? s1 : (s) % 5 == 2 ? s2 : (s) % 5 == 3 ? s3 : s4, y_geo_plane((s) / 5)))
+#define Y_DW(d) (Y_SLOT(2 * (d)) | (Y_SLOT(2 * (d) + 1) << 16))
+        const unsigned dw[16] = {Y_DW(0), Y_DW(1), Y_DW(2), Y_DW(3), Y_DW(4), Y_DW(5), Y_DW(6), Y_DW(7), Y_DW(8), Y_DW(9), Y_DW(10), Y_DW(11), Y_DW(12), Y_DW(13), Y_DW(14), Y_DW(15)};
+#undef Y_DW
+#undef Y_SLOT
+        y_u32x4* gr = reinterpret_cast<y_u32x4*>(geo + n * 16);
+#pragma unroll
+        for (int d4 = 0; d4 < 4; ++d4) gr[d4] = (y_u32x4){dw[4 * d4], dw[4 * d4 + 1], dw[4 * d4 + 2], dw[4 * d4 + 3]};
+        noffs[n] = (unsigned)qq * (unsigned)(NA * ROWB);
+    }
+    __syncthreads();
+    const int kp = lane & 31, kg = lane >> 5;      // this lane's kernel point (weights: column of B; X1: column of D) and neighbour group / channel sub-block
+    const bool kok = kp < KS;
+    // the neighbour factor of this lane: row m = lane % 32 of the pre-activation product = the neighbour in staging row swap23(m)
+    bf16x8 geo_r[NCH][2];
+    {
+        const int m = kp;
+        const int nloc = (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1);
+#pragma unroll
+        for (int t = 0; t < NCH; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                geo_r[t][j] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(geo) + (32 * t + nloc) * 64 + 32 * j + 16 * kg);
+    }
+    // staging image of one plane of a chunk (see inter_so3conv_x32_kernel): load side
+    const int rl = lane / PPR, sl = lane % PPR;
+    const unsigned pieceoff = NT32 == 1 ? (unsigned)(sl * 16) : (unsigned)((4 * (((sl >> 2) - (rl >> 1)) & 1) + (sl & 3)) * 16);
+    unsigned roff[NCH][NRB];
+#pragma unroll
+    for (int t = 0; t < NCH; ++t)
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) roff[t][rb] = noffs[32 * t + RPI * rb + rl] + pieceoff;
+    const char* Fb = reinterpret_cast<const char*>(Fq) + (size_t)b * p1 * NA * ROWB;
+    char* stg = stage + wave * STG;
+    // read side: lane group g = lane / 16 -> channels 16 (g & 1) .. of the tile, rows 8 (g >> 1) + (i >> 2) + {0, 4} of the 16-row K step; i = lane % 16
+    unsigned toff[NT32];
+    {
+        const int g = lane >> 4, i = lane & 15;
+        const int r0 = 8 * (g >> 1) + (i >> 2);
+#pragma unroll
+        for (int ct = 0; ct < NT32; ++ct)
+            toff[ct] = (unsigned)(r0 * CIN * 2 + (NT32 == 1 ? 0 : 64 * ((ct + (r0 >> 1)) & 1)) + 32 * (g & 1) + 8 * (i & 3));
+    }
+    float* outp = out + ((size_t)b * p2 + p) * NA * COUT;
+
+    bf16x8 kpn[2][2];                               // kernel-point factor of this wave's current / next anchor: [anchor parity][K step]
+    // `kq` is deliberately NOT __restrict__: its loads must stay between the memory-clobbering waits they are written between (plain loads and
+    // LDS-direct loads retire out of order with respect to each other: a compiler-counted vmcnt wait with LDS-direct loads younger than the plain
+    // load it waits for is not sound; every use below sits behind a full `s_waitcnt vmcnt(0)`)
+    auto issue_kp = [&](int a, bf16x8 (&dst)[2]) {
+        a = a < NA ? a : NA - 1;
+        const bf16x8* src = kq + (size_t)a * 128 + lane;
+        dst[0] = src[0]; dst[1] = src[64];
+    };
+    auto issue_rows = [&](int a, int t) {
+        a = a < NA ? a : NA - 1;
+        const char* src = Fb + (size_t)a * ROWB;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#ifdef Y_ABL_NODMA
+                asm volatile("" :: "v"(src + roff[t][rb]));
+#else
+                __builtin_amdgcn_global_load_lds((x_gptr)(src + roff[t][rb] + pl * CIN * 2), (x_lptr)(stg + pl * PLB + rb * 1024), 16, 0, 0);
+#endif
+    };
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // pre-activations of one (anchor, chunk): P[v] = row 8 (v / 4) + 4 kg + v % 4 of column kp
+    auto gen_pre = [&](int t, const bf16x8 (&kpa)[2]) {
+        f32x16 P = __builtin_amdgcn_mfma_f32_32x32x16_bf16(geo_r[t][0], kpa[0], zero16, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(geo_r[t][1], kpa[1], P, 0, 0, 0);
+    };
+    // clamp to [0, 1] (the weight's mathematical range: relu below, rounding excess of the expanded form above) + exact split + pack:
+    // K step h2 of step 1 takes v = 8 h2 .. 8 h2 + 7 as its slots e = 0 .. 7; dword d of a fragment = slots (2 d, 2 d + 1)
+    auto gen_split = [&](const f32x16& P, y_u32x4 (&aw)[2][3]) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                unsigned h[2], m[2], l[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float w = __builtin_amdgcn_fmed3f(P[8 * h2 + 2 * d + u], 0.0f, 1.0f);
+                    h[u] = __float_as_uint(w);
+                    const float r = w - __uint_as_float(h[u] & 0xffff0000u);
+                    m[u] = __float_as_uint(r);
+                    l[u] = __float_as_uint(r - __uint_as_float(m[u] & 0xffff0000u));
+                }
+                aw[h2][0][d] = __builtin_amdgcn_perm(h[1], h[0], 0x07060302u);
+                aw[h2][1][d] = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u);
+                aw[h2][2][d] = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u);
+            }
+    };
+    auto anchor_of = [&](int q) { return (q / NJ) * AG + wave * NJ + (q % NJ); };
+    issue_kp(anchor_of(0), kpn[0]);
+    issue_kp(anchor_of(1), kpn[1]);
+    issue_rows(anchor_of(0), 0);
+    y_u32x4 aws[2][2][3];                           // [step parity][K step of the chunk][plane]
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const f32x16 P = gen_pre(0, kpn[0]);
+        gen_split(P, aws[0]);
+    }
+
+    // X1 store addresses of this lane: kernel point kp, channel blocks (2 q + kg) ^ sw(kp), q < NKR / 4
+    int xoff[NKR / 4];
+#pragma unroll
+    for (int q = 0; q < NKR / 4; ++q) xoff[q] = kok ? kp * CH + 4 * (((2 * q + kg) ^ (CH == 16 ? (kp >> 1) & 3 : kp & 7))) : (int)(dump - X1s) + 4 * lane;
+
+    double st_s = 0.0, st_q = 0.0;
+    f32x16 y[MT2];
+#pragma unroll 1
+    for (int ag = 0; ag < NG; ++ag) {
+        float keep[NJ][NT32 == 1 ? 8 : 16];        // second channel half of the wave's anchors
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int col = wave * NJ + j;
+            const int q = ag * NJ + j;
+            const int a = ag * AG + col;
+            const int a_next = anchor_of(q + 1);
+            f32x16 acc[NT32];
+#pragma unroll
+            for (int t = 0; t < NCH; ++t) {
+                const int sp = (j * NCH + t) & 1;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this chunk's rows have landed in LDS (and the kernel-point factor requested a step ago)
+                bf16x8 bf[NT32][2][3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int ct = 0; ct < NT32; ++ct)
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const char* pa = stg + pl * PLB + toff[ct] + 16 * h2 * CIN * 2;
+                            const bf16x4 lo4 = x_tr16(pa), hi4 = x_tr16(pa + 4 * CIN * 2);
+                            bf[ct][h2][pl] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
+                // the next step's pre-activations: they need neither the rows nor the LDS, so they run while the fragment reads return
+                const int tn = t + 1 < NCH ? t + 1 : 0;
+                const f32x16 P = gen_pre(tn, t + 1 < NCH ? kpn[j & 1] : kpn[(j + 1) & 1]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers: the staging tile may be overwritten
+                // the next chunk-step's rows (past this wave's last anchor: a harmless reload of anchor 59 -- no branch, the pass stays one basic block)
+                if (t + 1 < NCH) issue_rows(a, t + 1);
+                else issue_rows(a_next, 0);
+                // this anchor's kernel-point factor was last used just above (the pre-activations of its last chunk): request the anchor after next into its set
+                if (t == NCH - 1) issue_kp(anchor_of(q + 2), kpn[j & 1]);
+                {
+                    y_u32x4 (&aw)[2][3] = aws[sp];
+                    constexpr int NMF = 12 * NT32;
+                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                    for (int mi = 0; mi < NMF; ++mi) {
+                        const int ct = mi % NT32, term = (mi / NT32) % 6, h2 = mi / (6 * NT32);
+#ifndef Y_ABL_NOMFMA1
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ct][h2][PB[term]], __builtin_bit_cast(bf16x8, aw[h2][PA[term]]),
+                                                                          (t == 0 && mi < NT32) ? zero16 : acc[ct], 0, 0, 0);
+#else
+                        asm volatile("" :: "v"(aw[h2][PA[term]]), "v"(bf[ct][h2][PB[term]]));
+                        if (t == 0 && mi < NT32) acc[ct] = zero16;
+#endif
+                    }
+                    gen_split(P, aws[sp ^ 1]);
+#ifndef Y_NO_SCHED
+                    // the split's 16 independent chains go between the step's matrix instructions
+                    y_sched_pattern<NMF, INTER_Y_VPM(CIN)>();
+#endif
+                }
+            }
+            // anchor end.  D[c][k]: this lane = kernel point kp, channels 8 (v / 4) + 4 kg + v % 4 of each 32-channel tile: first half -> LDS, second half parked
+            float* xcol = X1s + (kok ? col * S : 0);         // lanes of the kernel points 24 .. 31 write their zeros into the dump slot (xoff): no branch
+#pragma unroll
+            for (int q4 = 0; q4 < NKR / 4; ++q4)
+                *reinterpret_cast<float4*>(xcol + xoff[q4]) = make_float4(acc[0][4 * q4], acc[0][4 * q4 + 1], acc[0][4 * q4 + 2], acc[0][4 * q4 + 3]);
+#pragma unroll
+            for (int v = 0; v < NKR; ++v) keep[j][v] = NT32 == 1 ? acc[0][NKR + v] : acc[NT32 - 1][v];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) y[mt][v] = 0.f;
+#ifndef Y_ABL_NOSTEP2
+        X32Step2<CIN, COUT> s2;
+        const bf16x8* Wq_g = Wq;
+        asm volatile("" : "+s"(Wq_g));
+        s2.issue(0, Wq_g, wave, lane);
+        __syncthreads();
+        s2.template half<0>(y, X1s, Wq_g, wave, lane);
+#endif
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float* xcol = X1s + (kok ? (wave * NJ + j) * S : 0);
+#pragma unroll
+            for (int q4 = 0; q4 < NKR / 4; ++q4)
+                *reinterpret_cast<float4*>(xcol + xoff[q4]) = make_float4(keep[j][4 * q4], keep[j][4 * q4 + 1], keep[j][4 * q4 + 2], keep[j][4 * q4 + 3]);
+        }
+        __syncthreads();
+#ifndef Y_ABL_NOSTEP2
+        s2.template half<1>(y, X1s, Wq_g, wave, lane);
+#endif
+        __syncthreads();                                // every wave finished reading X1s: the partial table may overwrite it
+        // y[mt][v] = Y[o = 32 mt + 8 (v / 4) + 4 kg + v % 4][anchor column = lane % 32]
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+                *reinterpret_cast<float4*>(&part[(wave * AG + kp) * PS + 32 * mt + 8 * q4 + 4 * kg]) = make_float4(y[mt][4 * q4], y[mt][4 * q4 + 1], y[mt][4 * q4 + 2], y[mt][4 * q4 + 3]);
+        __syncthreads();
+        for (int e = tid; e < AG * COUT; e += 256) {
+            const int col = e / COUT, o = e - col * COUT;
+            const int a = ag * AG + col;
+            if (a < NA) {
+                float v = part[(0 * AG + col) * PS + o] + part[(1 * AG + col) * PS + o];
+                v += part[(2 * AG + col) * PS + o] + part[(3 * AG + col) * PS + o];
+                v += bias[o];
+                outp[(size_t)a * COUT + o] = v;
+                st_s += (double)v; st_q += (double)v * (double)v;
+            }
+        }
+        __syncthreads();                                // the table is read: the next pass may write X1s
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no LDS-direct load may outlive the workgroup's LDS allocation
+    if (stat_part) {
+        static_assert(256 % COUT == 0, "a thread must keep one output channel");
+        double* dred = reinterpret_cast<double*>(part);
+        dred[tid] = st_s; dred[256 + tid] = st_q;
+        __syncthreads();
+        if (tid < COUT) {
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 256 / COUT; ++k) { a0 += dred[k * COUT + tid]; a1 += dred[256 + k * COUT + tid]; }
+            double* sp = stat_part + ((size_t)b * p2 + p) * 2 * COUT;
+            sp[tid] = a0; sp[COUT + tid] = a1;
+        }
+    }
+}
+
+template <int CIN, int COUT, int NCH>
+static int launch_y(int b, int p1, int p2, float sigma, const float* xyz, const float* new_xyz, const int* idx, const void* Fq, const void* kq,
+                    const void* Wq, const float* bias, float* out, const int* order, double* stat_part, hipStream_t st) {
+    constexpr int NN = 32 * NCH;
+    const size_t lds = (size_t)(32 * ((CIN / 2) * KS + 44) + 17 * NN + 256) * sizeof(float);
+    auto kern = inter_so3conv_y_kernel<CIN, COUT, NCH>;
+    {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    const unsigned gx = order ? 8u * (unsigned)((p2 + 7) / 8) : (unsigned)p2;
+    hipLaunchKernelGGL(kern, dim3(gx, b), dim3(256), lds, st, p1, p2, 1.0f / sigma, xyz, new_xyz, idx, reinterpret_cast<const unsigned short*>(Fq),
+                       reinterpret_cast<const bf16x8*>(kq), reinterpret_cast<const bf16x8*>(Wq), bias, out, order, stat_part);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+extern "C" {
+
+// rk [60][24][3] fp32 (anchors @ kernel points, functional.py:296) + sigma -> kq [60][2][64][8] bf16 (122 880 bytes), once per layer
+int etch_inter_kpoint_operand(float sigma, const float* rk, void* kq, void* stream) {
+    if (sigma <= 0.f || !rk || !kq || ((uintptr_t)kq & 15)) return ETCH_EINVAL;
+    hipLaunchKernelGGL(inter_kpoint_operand_kernel, dim3(NA), dim3(128), 0, (hipStream_t)stream, 1.0f / sigma, rk, reinterpret_cast<unsigned short*>(kq));
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+// etch_inter_so3conv_planes32 with the kernel weights formed on the matrix cores.  kq = etch_inter_kpoint_operand(sigma, rk); Wq32 and feats_planes as there.
+int etch_inter_so3conv_planes_kq(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
+                                 const int* ball_idx, const void* feats_planes, const void* kq, const void* Wq32, const float* bias, float* out,
+                                 const int* order, double* stat_part, void* stream) {
+    if (b <= 0 || p2 <= 0) return ETCH_OK;
+    if (sigma <= 0.f || !Wq32 || !feats_planes || !kq) return ETCH_EINVAL;
+    if (((uintptr_t)feats_planes & 15) || ((uintptr_t)Wq32 & 15) || ((uintptr_t)kq & 15)) return ETCH_EINVAL;
+    if ((size_t)p1 * NA * 3 * cin * 2 >= ((size_t)1 << 32)) return ETCH_EUNSUPPORTED;      // 32-bit byte offsets inside a scan
+    hipStream_t st = (hipStream_t)stream;
+#define Y_CASE(CI, CO, NC) \
+    if (cin == CI && cout == CO && nn == 32 * NC) return launch_y<CI, CO, NC>(b, p1, p2, sigma, xyz, new_xyz, ball_idx, feats_planes, kq, Wq32, bias, out, order, stat_part, st);
+    Y_CASE(32, 32, 1) Y_CASE(32, 32, 2) Y_CASE(32, 64, 1) Y_CASE(32, 64, 2) Y_CASE(64, 64, 1) Y_CASE(64, 64, 2)
+#undef Y_CASE
+    return ETCH_EUNSUPPORTED;
+}
+
+}  // extern "C"

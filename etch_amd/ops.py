@@ -301,9 +301,22 @@ INTER_X = os.environ.get("ETCH_INTER_X", "1") != "0"             # both contract
 INTER_X32 = os.environ.get("ETCH_INTER_X", "1") != "16"          # 64 input channels: the 32x32x16 MFMA form (ETCH_INTER_X=16: the 16x16x32 form everywhere)
 
 
+INTER_KQ = os.environ.get("ETCH_INTER_KQ", "1") != "0"          # kernel weights formed on the matrix cores (csrc/so3conv_y.hip); 0: the round-4 kernels
+
+
 def inter_planes_form(cin):
-    """MFMA shape of the planes kernel for this width: 32 (etch_inter_so3conv_planes32, 64 input channels) or 16 (etch_inter_so3conv_planes)."""
-    return 32 if (INTER_X32 and cin == 64) else 16
+    """MFMA shape of the planes kernel for this width: 32 (etch_inter_so3conv_planes_kq / _planes32) or 16 (etch_inter_so3conv_planes)."""
+    return 32 if (INTER_KQ and INTER_X) or (INTER_X32 and cin == 64) else 16
+
+
+def inter_kpoint_operand(rk, sigma):
+    """rk (60,24,3) fp32 rotated kernel points -> (60,2,64,8) int16: the kernel-point factor of the weights' pre-activation as matrix-core B
+    fragments (etch_inter_so3conv_planes_kq)."""
+    _need(rk, torch.float32, "rk")
+    assert tuple(rk.shape) == (60, 24, 3)
+    kq = torch.empty((60, 2, 64, 8), dtype=torch.int16, device=rk.device)
+    _lib.check(_lib.lib().etch_inter_kpoint_operand(_c_float(sigma), _ptr(rk), _ptr(kq), _stream()), "etch_inter_kpoint_operand")
+    return kq
 
 
 def inter_planes_supported(cin, cout, nn):
@@ -333,11 +346,12 @@ def spatial_order(xyz):
 
 
 def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, order=None, want_stats=False, Wp32=None, Wq=None, Wqn=None,
-                  feats_planes=None, Wq32=None):
+                  feats_planes=None, Wq32=None, kq=None):
     """feats_cl (b,p1,60,cin) channels-last -> (b,p2,60,cout) pre-norm.  order (b,p2) int32: processing order of the output points.
     want_stats: also return the InstanceNorm (mean, rstd) of the output, accumulated in the conv's epilogue.
+    kq (inter_kpoint_operand) + Wq32: the round-5 kernel (weights' pre-activation on the matrix cores, every covered shape).
     Wq32 (inter_weight_split32) / Wqn (inter_weight_split(natural=True)): both contractions on the bf16 matrix cores where the shape is covered
-    (32x32x16 / 16x16x32 MFMA form); feats_planes (b,p1,60,3,cin) int16 = the producer's split of feats_cl (made here when absent)."""
+    (32x32x16 for 64 input channels / 16x16x32 MFMA form); feats_planes (b,p1,60,3,cin) int16 = the producer's split of feats_cl (made here when absent)."""
     b, p1, na, cin = feats_cl.shape
     p2, nn = ball_idx.shape[1], ball_idx.shape[2]
     cout = W.shape[0]
@@ -350,7 +364,16 @@ def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, orde
     out = torch.empty((b, p2, 60, cout), dtype=torch.float32, device=xyz.device)
     fused = want_stats and 256 % cout == 0 and (cin >= 16 or (cin == 1 and cout <= 64 and nn * 60 >= 1026))      # the c1 kernel's own precondition (so3conv.hip)
     part = torch.empty((b, p2, 2, cout), dtype=torch.float64, device=xyz.device) if fused else None
-    if Wq32 is not None and inter_planes_form(cin) == 32 and inter_planes_supported(cin, cout, nn):
+    if kq is not None and Wq32 is not None and INTER_KQ and inter_planes_supported(cin, cout, nn):
+        _need(Wq32, torch.int16, "Wq32"), _need(kq, torch.int16, "kq")
+        if feats_planes is None:
+            feats_planes = split3_planes(feats_cl)
+        _need(feats_planes, torch.int16, "feats_planes")
+        assert tuple(feats_planes.shape) == (b, p1, na, 3, cin) and kq.numel() == 60 * 2 * 64 * 8
+        _lib.check(_lib.lib().etch_inter_so3conv_planes_kq(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
+                                                          _ptr(feats_planes), _ptr(kq), _ptr(Wq32), _ptr(bias), _ptr(out), _optptr(order),
+                                                          _optptr(part), _stream()), "etch_inter_so3conv_planes_kq")
+    elif Wq32 is not None and cin == 64 and inter_planes_form(cin) == 32 and inter_planes_supported(cin, cout, nn):
         _need(Wq32, torch.int16, "Wq32")
         if feats_planes is None:
             feats_planes = split3_planes(feats_cl)

@@ -130,6 +130,7 @@ class InterSO3Conv(nn.Module):
         self._dq = _Derived()
         self._dqn = _Derived()
         self._dq32 = _Derived()
+        self._dkq = _Derived()
 
     def _derived(self):
         W, bias = self.basic_conv.W, self.basic_conv.bias
@@ -172,6 +173,13 @@ class InterSO3Conv(nn.Module):
         W = self.basic_conv.W
         return self._dq32.get((W,), lambda: ops.inter_weight_split32(W.detach().contiguous(), self.dim_in, self.kernel_size))
 
+    def _kq(self):
+        """Kernel-point factor of the weights' pre-activation (etch_inter_so3conv_planes_kq); None where that kernel is not used."""
+        if not (ops.INTER_KQ and self.wants_planes()):
+            return None
+        rk = self._derived()[0]
+        return self._dkq.get((self.anchors, self.kernels), lambda: ops.inter_kpoint_operand(rk, self.sigma))
+
     def wants_planes(self):
         """True if this conv gathers its input as bf16 planes (its producer should emit them: SeparableSO3ConvBlock.emit_planes)."""
         return ops.inter_planes_supported(self.dim_in, self.dim_out, self.n_neighbor) and self.kernel_size == 24
@@ -207,7 +215,7 @@ class InterSO3Conv(nn.Module):
             sample_idx, new_xyz = None, xyz
         rk, W, Wp, bias = self._derived()
         y, stats = ops.inter_so3conv(xyz, new_xyz, inter_idx, x.feats_cl, rk, W, Wp, bias, self.sigma, order=self.order(new_xyz), want_stats=True, Wp32=self._wp32(), Wq=self._wq(),
-                                     Wqn=None if ops.inter_planes_form(self.dim_in) == 32 else self._wqn(), Wq32=self._wq32(), feats_planes=getattr(x, "feats_planes", None))
+                                     Wqn=None if ops.inter_planes_form(self.dim_in) == 32 else self._wqn(), Wq32=self._wq32(), kq=self._kq(), feats_planes=getattr(x, "feats_planes", None))
         cloud = SphericalPointCloud(new_xyz, None, self.anchors, feats_cl=y)
         cloud.in_stats = stats          # InstanceNorm (mean, rstd) of the output, a by-product of the conv's epilogue
         return inter_idx, None, sample_idx, cloud

@@ -174,6 +174,18 @@ int etch_inter_so3conv_planes32(int b, int cin, int cout, int p1, int p2, int nn
                                 const int* ball_idx, const void* feats_planes, const float* rk, const void* Wq32, const float* bias, float* out,
                                 const int* order, double* stat_part, void* stream);
 
+/* Round 5 (etch_amd/csrc/so3conv_y.hip): etch_inter_so3conv_planes32 with the kernel weights of functional.py:286-324 formed on the MATRIX cores:
+ * the pre-activation 1 - |g_n - R_a kappa_k|^2 / sigma = [a_n, 1, G_n] . [1, b_k, r_ak] is a rank-5 bilinear form whose six largest exactly-split
+ * cross terms fill one pair of v_mfma_f32_32x32x16_bf16 per (anchor, 32 neighbours); the VALU keeps the clamp and the exact split of the result.
+ * kq = etch_inter_kpoint_operand(sigma, rk): [60 anchors][2 K steps][64 lanes][8] bf16 (122 880 bytes), the kernel-point factor in B-fragment
+ * order, built once per layer from rk [60][24][3] = anchors @ kernel points (functional.py:296).  Covers every shape of
+ * etch_inter_so3conv_planes_supported (32 AND 64 input channels); Wq32 / feats_planes / order / stat_part as for etch_inter_so3conv_planes32.
+ * Same result as the fp32 kernels up to the rounding of the weights' pre-activation (<= 4e-7 absolute on weights in [0, 1]) and the order of the sums. */
+int etch_inter_kpoint_operand(float sigma, const float* rk, void* kq, void* stream);
+int etch_inter_so3conv_planes_kq(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
+                                 const int* ball_idx, const void* feats_planes, const void* kq, const void* Wq32, const float* bias, float* out,
+                                 const int* order, double* stat_part, void* stream);
+
 /* x (rows, C) fp32 -> planes (rows, 3, C) bf16: the exact split x = hi + mid + lo (8 + 8 + 8 mantissa bits, by truncation). */
 int etch_split3_planes(long rows, int C, const float* x, void* planes, void* stream);
 

@@ -1,0 +1,128 @@
+"""Round-5 GPU tests: the inter conv whose kernel weights come off the matrix cores (csrc/so3conv_y.hip, etch_inter_so3conv_planes_kq)."""
+import numpy as np
+import pytest
+import torch
+
+from etch_amd.utils.weights import load_seeded
+from tests.test_gpu_encoder import _inter_conv_fp64, rel_err
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(32, 32, 32, 301, 149), (32, 64, 64, 211, 60), (64, 64, 32, 211, 101), (32, 32, 64, 130, 1), (32, 64, 32, 97, 97), (64, 64, 64, 150, 33)]
+
+
+def _bf16_to_f64(x_i16):
+    return (x_i16.to(torch.int32) << 16).view(torch.float32).double()
+
+
+def test_kpoint_operand_is_the_exact_split_of_the_kernel_point_factor():
+    """etch_inter_kpoint_operand: slot s = 5 t + c of kernel point k holds plane kp_plane(t) of component c of [1, -|r|^2 / sigma, r_x, r_y, r_z]
+    (csrc/so3conv_y.hip); the three planes of a component sum to its fp32 value exactly; kernel points 24 .. 31 carry b = -1e30, r = 0."""
+    from etch_amd import ops
+    from etch_amd import vgtk_so3conv as V
+    conv = V.InterSO3Conv(32, 32, 1, 1, 0.2, 0.0128, 32).cuda()
+    rk = conv._derived()[0]
+    sigma = conv.sigma
+    kq = ops.inter_kpoint_operand(rk, sigma).cpu()                    # [60][2][64][8]
+    assert kq.shape == (60, 2, 64, 8) and kq.dtype == torch.int16
+    # [a][slot][k]: lane = 32 kg + k holds slots 16 j + 8 kg + i
+    slots = kq.reshape(60, 2, 2, 32, 8).permute(0, 1, 2, 4, 3).reshape(60, 32, 32)
+    val = _bf16_to_f64(slots)
+    assert float(val[:, 30:].abs().max()) == 0.0
+    kp_plane = [0, 1, 0, 2, 0, 1]
+    # hi + mid + lo of every component (terms 0, 1, 3 carry the kernel side's hi, mid, lo) = the component in fp32, exactly
+    comp = (val[:, 0:5] + val[:, 5:10] + val[:, 15:20]).permute(0, 2, 1)          # [60][32 k][5]
+    assert torch.equal(comp.float().double(), comp)
+    comp = comp.float()
+    planes = ops.split3_bf16(comp)                                      # [3][60][32][5] int16
+    for t in range(6):
+        for c in range(5):
+            assert torch.equal(slots[:, 5 * t + c, :], planes[kp_plane[t], :, :, c]), (t, c)
+    rkc = rk.cpu()
+    assert torch.equal(comp[:, :, 0], torch.ones(60, 32)) and torch.equal(comp[:, :24, 2:], rkc) and float(comp[:, 24:, 2:].abs().max()) == 0.0
+    assert torch.equal(comp[:, 24:, 1], torch.full((60, 8), -1e30))
+    bk = -(rkc.double() ** 2).sum(-1) / sigma
+    assert float((comp[:, :24, 1].double() - bk).abs().max()) < 1e-6 * float(bk.abs().max())
+
+
+@pytest.mark.parametrize("cin,cout,nn,p1,p2", SHAPES)
+def test_inter_conv_kq_matches_the_fp32_kernel_and_fp64(cin, cout, nn, p1, p2):
+    """etch_inter_so3conv_planes_kq (v_mfma_f32_32x32x16_bf16 for BOTH contractions AND for the weights' pre-activation, every covered shape incl.
+    32 input channels) against the fp32-MFMA kernel and the fp64 formula under the entitled-error rule; bitwise reproducible,
+    schedule-independent; padded neighbourhoods included."""
+    from etch_amd import ops
+    from etch_amd import vgtk_so3conv as V
+    assert ops.inter_planes_supported(cin, cout, nn)
+    g = torch.Generator().manual_seed(cin + nn + p2)
+    b = 2
+    xyz = (torch.randn(b, 3, p1, generator=g) * 0.2).cuda()
+    new_xyz = xyz[:, :, :p2].contiguous()
+    ball = ops.ball_query(new_xyz, xyz, 0.25, nn)
+    conv = load_seeded(V.InterSO3Conv(cin, cout, 1, 2, 0.25, 0.03, nn), 3).cuda()
+    rk, W, Wp, bias = conv._derived()
+    kq, wq32 = conv._kq(), conv._wq32()
+    assert kq is not None and wq32 is not None
+    feats = torch.randn(b, p1, 60, cin, generator=g).cuda()
+    planes = ops.split3_planes(feats)
+    f32, (m0, r0) = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, want_stats=True)
+    new, (m1, r1) = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, want_stats=True, feats_planes=planes,
+                                      order=ops.spatial_order(new_xyz), Wq32=wq32, kq=kq)
+    again = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, Wq32=wq32, kq=kq)        # planes made on the fly, plain order
+    assert torch.equal(new, again)
+    scale = float(f32.abs().max())
+    assert float((new - f32).abs().max()) < 2e-6 * scale, float((new - f32).abs().max()) / scale
+    assert rel_err(m1.cpu().numpy(), m0.cpu().numpy()) < 2e-6 and rel_err(r1.cpu().numpy(), r0.cpu().numpy()) < 2e-6
+    ref = _inter_conv_fp64(xyz, new_xyz, ball, feats, rk, W, bias, conv.sigma)
+    e_new, e_f32 = float((new.double() - ref).abs().max()), float((f32.double() - ref).abs().max())
+    assert e_f32 < 3e-6 * scale and e_new <= 2.0 * e_f32 + 1e-7 * scale, (e_new, e_f32)
+
+
+@pytest.mark.parametrize("cin,cout,nn,p2", [(32, 32, 32, 2500), (32, 64, 64, 1250), (64, 64, 32, 1250)])
+def test_inter_conv_kq_soak_under_contention(cin, cout, nn, p2):
+    """VERDICT r04 item 2 / ADVICE r04: the planes kernels at the bench's own shapes (8 scans x 5 000 points' worth of rows), launched repeatedly
+    while two other streams keep the chip busy with the pipeline's other persistent kernels (mhsa layer, weight-stationary GEMM, FPS): every
+    output bitwise equal to the first one and within 2e-6 of the fp32-MFMA kernel.  REPS from ETCH_SOAK_REPS (default 200 per shape)."""
+    import os
+
+    from etch_amd import ops
+    from etch_amd import vgtk_so3conv as V
+    reps = int(os.environ.get("ETCH_SOAK_REPS", "200"))
+    g = torch.Generator().manual_seed(7)
+    b, p1 = 8, (2500 if cin == 32 else 1250)
+    pts = (torch.randn(b, 5000, 3, generator=g) * torch.tensor([0.14, 0.31, 0.085])).cuda()
+    xyz0 = pts.permute(0, 2, 1).contiguous()
+    fps = ops.furthest_point_sampling(xyz0, 2500)
+    xyz = ops.gather_points_forward(xyz0, fps)[:, :, :p1].contiguous()
+    new_xyz = xyz[:, :, :p2].contiguous()
+    radius, sigma = (0.113137, 0.0064) if (cin, cout) == (32, 32) else (0.16, 0.0128)
+    ball = ops.ball_query(new_xyz, xyz, radius, nn)
+    conv = load_seeded(V.InterSO3Conv(cin, cout, 1, 1, radius, sigma, nn), 3).cuda()
+    rk, W, Wp, bias = conv._derived()
+    kq, wq32 = conv._kq(), conv._wq32()
+    feats = torch.randn(b, p1, 60, cin, generator=g).cuda()
+    planes = ops.split3_planes(feats)
+    order = ops.spatial_order(new_xyz)
+    f32 = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, sigma)
+    run = lambda: ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, sigma, order=order, Wq32=wq32, kq=kq, feats_planes=planes)
+    first = run()
+    scale = float(f32.abs().max())
+    assert float((first - f32).abs().max()) < 2e-6 * scale
+    # the contention: an attention layer and a GEMM on a second stream, FPS on a third, re-enqueued as long as the soak runs
+    T = 60 * 20000
+    tok = torch.randn(T // 60, 60, 64, generator=g).cuda()
+    wq, wk, wv = (torch.randn(64, 64, generator=g).cuda() * 0.1 for _ in range(3))
+    xg = torch.randn(160000, 128, generator=g).cuda()
+    wg = torch.randn(128, 128, generator=g).cuda() * 0.05
+    s2, s3 = torch.cuda.Stream(), torch.cuda.Stream()
+    bad = 0
+    for i in range(reps):
+        if i % 4 == 0:
+            with torch.cuda.stream(s2):
+                ops.mhsa_layer(tok.view(-1, 64), wq, wk, wv, mode=2)
+                ops.linear(xg, wg)
+            with torch.cuda.stream(s3):
+                ops.furthest_point_sampling(xyz0, 2500)
+        out = run()
+        bad += int(not torch.equal(out, first))
+    torch.cuda.synchronize()
+    assert bad == 0, f"{bad} of {reps} launches differ from the first"
