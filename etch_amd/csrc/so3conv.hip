@@ -875,6 +875,7 @@ __global__ void __launch_bounds__(1024) instnorm_from_partials_kernel(int nparts
 }
 
 // out = lrelu((x1 - m1) * r1) [+ lrelu((x2 - m2) * r2)]     (elementwise, channels-last, float4)
+template <bool F16>
 __global__ void __launch_bounds__(256) instnorm_act_add_kernel(long n4, int rows, int C, const float* __restrict__ x1,
                                                                const float* __restrict__ m1, const float* __restrict__ r1,
                                                                const float* __restrict__ x2, const float* __restrict__ m2,
@@ -902,10 +903,17 @@ __global__ void __launch_bounds__(256) instnorm_act_add_kernel(long n4, int rows
         if (planes) {
             // the same values as three bf16 planes [row][plane][C] (exact split): the operand format of etch_inter_so3conv_planes, written by the
             // producer once instead of being split by every gather of the row
-            uint2 hi, mid, lo;
-            split3_pack4(make_float4(o[0], o[1], o[2], o[3]), hi, mid, lo);
-            unsigned short* pr = planes + (size_t)((i * 4) / C) * 3 * C + c;
-            *reinterpret_cast<uint2*>(pr) = hi; *reinterpret_cast<uint2*>(pr + C) = mid; *reinterpret_cast<uint2*>(pr + 2 * C) = lo;
+            if constexpr (F16) {          // two fp16 planes [row][2][C] (split_bf16.h: split2h): the operand format of etch_inter_so3conv_planes_kq
+                uint2 h, l;
+                split2h_pack4(make_float4(o[0], o[1], o[2], o[3]), h, l);
+                unsigned short* pr = planes + (size_t)((i * 4) / C) * 2 * C + c;
+                *reinterpret_cast<uint2*>(pr) = h; *reinterpret_cast<uint2*>(pr + C) = l;
+            } else {
+                uint2 hi, mid, lo;
+                split3_pack4(make_float4(o[0], o[1], o[2], o[3]), hi, mid, lo);
+                unsigned short* pr = planes + (size_t)((i * 4) / C) * 3 * C + c;
+                *reinterpret_cast<uint2*>(pr) = hi; *reinterpret_cast<uint2*>(pr + C) = mid; *reinterpret_cast<uint2*>(pr + 2 * C) = lo;
+            }
         }
     }
 }
@@ -1083,17 +1091,29 @@ int etch_instnorm_from_partials(int b, int nparts, int C, int count, const doubl
 
 int etch_instnorm_stats_workspace_bytes(int b, int C) { return (int)((size_t)IN_CHUNKS * b * 2 * C * sizeof(double)); }
 
-int etch_instnorm_act_add_planes(int b, int rows, int C, const float* x1, const float* m1, const float* r1, const float* x2,
-                                 const float* m2, const float* r2, float* out, void* planes, void* stream) {
+static int instnorm_act_add_launch(bool f16, int b, int rows, int C, const float* x1, const float* m1, const float* r1, const float* x2,
+                                   const float* m2, const float* r2, float* out, void* planes, void* stream) {
     if (b <= 0 || rows <= 0) return ETCH_OK;
     if ((C & 3) || ((uintptr_t)planes & 7)) return ETCH_EUNSUPPORTED;
     const long n4 = (long)b * rows * C / 4;
     long blocks = (n4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(instnorm_act_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n4, rows, C, x1, m1, r1, x2,
-                       m2, r2, out, reinterpret_cast<unsigned short*>(planes));
+    if (f16) hipLaunchKernelGGL(instnorm_act_add_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n4, rows, C, x1, m1, r1, x2,
+                                m2, r2, out, reinterpret_cast<unsigned short*>(planes));
+    else hipLaunchKernelGGL(instnorm_act_add_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n4, rows, C, x1, m1, r1, x2,
+                            m2, r2, out, reinterpret_cast<unsigned short*>(planes));
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
+}
+
+int etch_instnorm_act_add_planes(int b, int rows, int C, const float* x1, const float* m1, const float* r1, const float* x2,
+                                 const float* m2, const float* r2, float* out, void* planes, void* stream) {
+    return instnorm_act_add_launch(false, b, rows, C, x1, m1, r1, x2, m2, r2, out, planes, stream);
+}
+
+int etch_instnorm_act_add_planes_f16(int b, int rows, int C, const float* x1, const float* m1, const float* r1, const float* x2,
+                                     const float* m2, const float* r2, float* out, void* planes, void* stream) {
+    return instnorm_act_add_launch(true, b, rows, C, x1, m1, r1, x2, m2, r2, out, planes, stream);
 }
 
 int etch_instnorm_act_add(int b, int rows, int C, const float* x1, const float* m1, const float* r1, const float* x2,

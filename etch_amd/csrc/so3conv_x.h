@@ -34,9 +34,9 @@ template <int N> __device__ __forceinline__ void x_wwait6(f32x4 (&v)[2][3]) {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, int PAD = 44>      // PAD: (KH + PAD) / 4 must be odd (the 32 rows of a B-fragment read start in different 16-byte slots)
 struct X32Step2 {
-    static constexpr int MT2 = COUT / 32, CH = CIN / 2, KH = CH * KS, S = KH + 44;
+    static constexpr int MT2 = COUT / 32, CH = CIN / 2, KH = CH * KS, S = KH + PAD;
     static constexpr int NSW = KH / 16 / 4;         // K steps per wave and half
     f32x4 ra[2][MT2][3];
     __device__ __forceinline__ void issue(int i, const bf16x8* __restrict__ Wq, int wave, int lane) {

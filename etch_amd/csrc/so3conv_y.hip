@@ -26,20 +26,8 @@
 #ifndef INTER_Y_WPE
 #define INTER_Y_WPE(CIN) ((CIN) <= 32 ? 2 : 1)
 #endif
-#ifndef INTER_Y_VPM
-#define INTER_Y_VPM(CIN) ((CIN) <= 32 ? 9 : 5)      // VALU instructions the scheduler is asked to place behind each step-1 MFMA
-#endif
-
+#define Y_PAD(CIN) ((CIN) <= 32 ? 12 : 44)
 typedef unsigned y_u32x4 __attribute__((ext_vector_type(4)));
-
-// scheduling request for one step: N x (1 MFMA, then V VALU instructions) -- the arguments of the builtin must be literal constants
-template <int N, int V> __device__ __forceinline__ void y_sched_pattern() {
-    if constexpr (N > 0) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, V, 0);      // V VALU
-        y_sched_pattern<N - 1, V>();
-    }
-}
 
 // K slot s of the pre-activation product: term t = s / 5 (s < 30), component c = s % 5.  Planes (0 hi, 1 mid, 2 lo) of the two factors per term:
 //   term            0        1         2         3        4        5
@@ -77,10 +65,52 @@ __global__ void __launch_bounds__(128) inter_kpoint_operand_kernel(float inv_sig
     }
 }
 
-template <int CIN, int COUT, int NCH>
+// step 2 of the 32x32x16 kernels on the fp16 matrix cores: Y[o][a] += sum_kappa W[o][kappa] X1[a][kappa] with both operands as two fp16 planes (W pre-split
+// and scaled by 2^6 on the host, ops.inter_weight_split32_f16; the X1 row split by the wave that reads it) and the three largest cross products.
+// W fragments: [K step of 16][o tile of 32][plane][lane][8], streamed from L2 one batch ahead (inline-asm loads + counted waits, see X32Step2).
+template <int CIN, int COUT, int PAD>
+struct H32Step2 {
+    static constexpr int MT2 = COUT / 32, CH = CIN / 2, KH = CH * KS, S = KH + PAD;
+    static constexpr int NSW = KH / 16 / 4;         // K steps per wave and half
+    f32x4 ra[2][MT2][2];
+    __device__ __forceinline__ void issue(int i, const bf16x8* __restrict__ Wq, int wave, int lane) {
+        const int h = i / NSW, c = i % NSW;
+        const char* b0 = reinterpret_cast<const char*>(Wq) + ((size_t)(h * (KH / 16) + wave + 4 * c) * MT2) * 2 * 1024;
+        const unsigned vo = (unsigned)lane * 16u;
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) x_wload_s(ra[i & 1][mt][pl], vo, b0 + mt * 2 * 1024, pl);
+    }
+    template <int N> __device__ __forceinline__ void wait(f32x4 (&v)[MT2][2]) {
+        if constexpr (MT2 == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[1][0]), "+v"(v[1][1]) : "n"(N));
+        else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(v[0][0]), "+v"(v[0][1]) : "n"(N));
+    }
+    template <int H>
+    __device__ __forceinline__ void half(f32x16 (&y)[MT2], const float* X1s, const bf16x8* __restrict__ Wq, int wave, int lane) {
+        const int an = lane & 31, kg = lane >> 5;
+#pragma unroll
+        for (int c = 0; c < NSW; ++c) {
+            const int i = H * NSW + c;
+            asm volatile("" ::: "memory");                 // keeps the X1 reads (and their splits) of later steps from being hoisted
+            const float* xr = &X1s[an * S + (wave + 4 * c) * 16 + kg * 8];
+            f16x8 bq[2];
+            split2h_pack8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4), bq[0], bq[1]);
+            if (i + 1 < 2 * NSW) { issue(i + 1, Wq, wave, lane); wait<2 * MT2>(ra[i & 1]); }
+            else wait<0>(ra[i & 1]);
+            f32x4 (&ac)[MT2][2] = ra[i & 1];
+#define H_TERM(PA, PB) _Pragma("unroll") for (int mt = 0; mt < MT2; ++mt) \
+    y[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ac[mt][PA]), bq[PB], y[mt], 0, 0, 0);
+            H_TERM(1, 0) H_TERM(0, 1) H_TERM(0, 0)
+#undef H_TERM
+        }
+    }
+};
+
+template <int CIN, int COUT, int NCH, int D>
 __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
     int p1, int p2, float inv_sigma, const float* __restrict__ xyz, const float* __restrict__ new_xyz, const int* __restrict__ ball_idx,
-    const unsigned short* __restrict__ Fq, const bf16x8* kq, const bf16x8* __restrict__ Wq, const float* __restrict__ bias,
+    const unsigned short* __restrict__ Fq, const bf16x8* __restrict__ kq, const bf16x8* __restrict__ Wq, const float* __restrict__ bias,
     float* __restrict__ out, const int* __restrict__ order, double* __restrict__ stat_part) {
     constexpr int NN = 32 * NCH;
     constexpr int AG = 32, NJ = 8, NG = 2;         // anchors per pass, per wave and pass; passes per point
@@ -89,18 +119,21 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
     constexpr int CH = CIN / 2;                    // channels per X1 half
     constexpr int NKR = CH / 2;                    // accumulator registers of a lane per half
     constexpr int KH = CH * KS;                    // contraction length of step 2 per half
-    constexpr int S = KH + 44;                     // X1s row stride (floats), see inter_so3conv_x32_kernel
+    constexpr int S = KH + Y_PAD(CIN);             // X1s row stride (floats), S / 4 odd (see inter_so3conv_x32_kernel); 32 input channels: the tile,
+                                                   // the tables and the staging tiles of TWO workgroups must fit the 160 KB of a compute unit
+    static_assert((S / 4) % 2 == 1, "row stride");
     constexpr int PS = COUT + 4;
     static_assert(4 * PS <= S, "the partial table must fit the X1 tile it aliases");
-    constexpr int ROWB = 3 * CIN * 2;
+    constexpr int ROWB = 2 * CIN * 2;              // bytes of one (q, a) row: two planes of CIN fp16
     constexpr int PPR = CIN / 8, RPI = 64 / PPR, NRB = 32 / RPI;
-    constexpr int PLB = 32 * CIN * 2, STG = 3 * PLB;
+    constexpr int PLB = 32 * CIN * 2, STG = 2 * PLB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X1s = smem;                             // [32][S]
     float* part = smem;                            // [4 waves][32 cols][PS], aliases X1s between the last product of a pass and the next pass
     unsigned* geo = reinterpret_cast<unsigned*>(smem + AG * S);        // [NN][16 dwords]: the neighbour factor, 32 bf16 slots per neighbour
     unsigned* noffs = geo + NN * 16;                                    // [NN] byte offset of the neighbour's anchor-0 row
-    float* dump = reinterpret_cast<float*>(noffs + NN);                 // [64 lanes][4]: where the lanes of the unused kernel points 24 .. 31 store
+    float* dump = reinterpret_cast<float*>(geo);                        // [64 lanes][4]: where the lanes of the unused kernel points 24 .. 31 store (aliases the
+                                                                        // neighbour factor, which lives in registers once the second barrier below is passed)
     __shared__ __attribute__((aligned(16))) char stage[4 * STG];       // [4 waves][STG]: its own LDS object (see inter_so3conv_x_kernel)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
@@ -145,16 +178,22 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
             for (int j = 0; j < 2; ++j)
                 geo_r[t][j] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(geo) + (32 * t + nloc) * 64 + 32 * j + 16 * kg);
     }
-    // staging image of one plane of a chunk (see inter_so3conv_x32_kernel): load side
+    // staging image of one plane of a chunk (see inter_so3conv_x32_kernel): load side -- lane = (row rl of the row block, 16-byte piece sl)
     const int rl = lane / PPR, sl = lane % PPR;
     const unsigned pieceoff = NT32 == 1 ? (unsigned)(sl * 16) : (unsigned)((4 * (((sl >> 2) - (rl >> 1)) & 1) + (sl & 3)) * 16);
     unsigned roff[NCH][NRB];
 #pragma unroll
     for (int t = 0; t < NCH; ++t)
 #pragma unroll
+#ifdef Y_ABL_SAMEROW
+        for (int rb = 0; rb < NRB; ++rb) roff[t][rb] = 0 * noffs[32 * t + RPI * rb + rl] + pieceoff;     // timing experiment: every gather hits one row (cache-resident)
+#else
         for (int rb = 0; rb < NRB; ++rb) roff[t][rb] = noffs[32 * t + RPI * rb + rl] + pieceoff;
+#endif
+    __syncthreads();                               // every wave holds its part of the tables in registers: the table region may be reused (dump slot)
     const char* Fb = reinterpret_cast<const char*>(Fq) + (size_t)b * p1 * NA * ROWB;
     char* stg = stage + wave * STG;
+    char* stg_w = stg + lane * 16;                 // write side: the lane's 16-byte piece of every 1-KiB row block
     // read side: lane group g = lane / 16 -> channels 16 (g & 1) .. of the tile, rows 8 (g >> 1) + (i >> 2) + {0, 4} of the 16-row K step; i = lane % 16
     unsigned toff[NT32];
     {
@@ -166,143 +205,174 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
     }
     float* outp = out + ((size_t)b * p2 + p) * NA * COUT;
 
-    bf16x8 kpn[2][2];                               // kernel-point factor of this wave's current / next anchor: [anchor parity][K step]
-    // `kq` is deliberately NOT __restrict__: its loads must stay between the memory-clobbering waits they are written between (plain loads and
-    // LDS-direct loads retire out of order with respect to each other: a compiler-counted vmcnt wait with LDS-direct loads younger than the plain
-    // load it waits for is not sound; every use below sits behind a full `s_waitcnt vmcnt(0)`)
-    auto issue_kp = [&](int a, bf16x8 (&dst)[2]) {
-        a = a < NA ? a : NA - 1;
-        const bf16x8* src = kq + (size_t)a * 128 + lane;
+    // ---- the software pipeline of one wave.  Global step G = 0 .. 2 NSTEP - 1 of a point: anchor sequence index G / NCH, chunk G % NCH.
+    //   gathered rows   global -> registers (ring of D chunks, plain loads: in order, tracked by the compiler) -> staging tile (ds_write) -> fragments
+    //   during step g   the MFMAs of step g (fragments and split weights prepared during step g - 1) are interleaved, slot by slot, with
+    //                   * the ring's chunk g + 1 going to the staging tile, the loads of chunk g + 1 + D into the freed registers,
+    //                   * the fragment reads of chunk g + 1 into the other fragment set,
+    //                   * the clamp / split of the weights of step g + 1 (their pre-activation MFMAs open the step).
+    //   Every slot ends with sched_barrier(0): the order below IS the schedule (left alone, the scheduler clusters the VALU work; asked with
+    //   sched_group_barrier over a whole pass, its solver takes minutes).  No LDS-direct loads: with one staging tile per wave they bound a step
+    //   from below by the memory round trip (profiles/r05_inter_conv_latency_bound.txt), and any LDS access behind one is drained by the compiler.
+    constexpr int NSTEP = NJ * NCH;                // steps per pass and wave
+    static_assert(NSTEP % D == 0 && NSTEP % 2 == 0 && D <= NSTEP, "ring depth");
+    constexpr int NMF = 6 * NT32;                  // step-1 MFMAs (= slots) per step: 2 K steps x 3 cross terms x channel tiles
+    constexpr int NF = 4 * NT32;                   // operand fragments of the gathered rows per step (K step, plane, channel tile; two transposing reads each)
+    constexpr int NL = 2 * NRB;                    // 16-byte loads per lane and chunk
+    constexpr int NW = NL / 2;                     // slots that stage two pieces each
+    static_assert(NW + NL <= NMF && NW + NF <= NMF, "slot plan");
+    f32x4 ring[D][NL];
+    f16x8 bf[2][NT32][2][2] = {};                   // [step parity][channel tile][K step][plane]
+    y_u32x4 aws[2][2][2] = {};                      // [step parity][K step of the chunk][plane]
+    bf16x8 kpn[2][2] = {};                          // kernel-point factor of this wave's current / next anchor: [anchor parity][K step]
+    f32x16 acc[NT32];
+    // anchor of sequence index q (>= 16: past the end -> clamped by the loaders: harmless repeats of anchor 59, the pipeline stays branch-free)
+    auto anchor_of = [&](int q) { const int a = (q / NJ) * AG + wave * NJ + (q % NJ); return a < NA ? a : NA - 1; };
+    auto issue_kp = [&](int q, bf16x8 (&dst)[2]) {
+#ifdef Y_ABL_NOPRE
+        return;
+#endif
+        const bf16x8* src = kq + (size_t)anchor_of(q) * 128 + lane;
         dst[0] = src[0]; dst[1] = src[64];
     };
-    auto issue_rows = [&](int a, int t) {
-        a = a < NA ? a : NA - 1;
-        const char* src = Fb + (size_t)a * ROWB;
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb)
-#ifdef Y_ABL_NODMA
-                asm volatile("" :: "v"(src + roff[t][rb]));
+    auto load_piece = [&](int G, int k, f32x4& dst) {          // piece k = (plane, row block) of the chunk of global step G
+        const char* src = Fb + (size_t)anchor_of(G / NCH) * ROWB + roff[G % NCH][k % NRB] + (k / NRB) * CIN * 2;
+#ifdef Y_ABL_NOLOAD
+        asm volatile("" : "=v"(dst) : "v"(src));
 #else
-                __builtin_amdgcn_global_load_lds((x_gptr)(src + roff[t][rb] + pl * CIN * 2), (x_lptr)(stg + pl * PLB + rb * 1024), 16, 0, 0);
+        dst = *reinterpret_cast<const f32x4*>(src);
 #endif
     };
+    auto stage_piece = [&](int k, const f32x4& v) { *reinterpret_cast<f32x4*>(stg_w + (k / NRB) * PLB + (k % NRB) * 1024) = v; };
+    auto read_frag = [&](int r, f16x8 (&dst)[NT32][2][2]) {      // fragment r = (K step h2, plane, channel tile), in the order the MFMAs want them
+        const int ct = r % NT32, pl = (r / NT32) % 2, h2 = r / (2 * NT32);
+        const char* pa = stg + pl * PLB + toff[ct] + 16 * h2 * CIN * 2;
+        const bf16x4 lo4 = x_tr16(pa), hi4 = x_tr16(pa + 4 * CIN * 2);
+        dst[ct][h2][pl] = __builtin_bit_cast(f16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    // pre-activations of one (anchor, chunk): P[v] = row 8 (v / 4) + 4 kg + v % 4 of column kp
-    auto gen_pre = [&](int t, const bf16x8 (&kpa)[2]) {
+    auto gen_pre = [&](int t, const bf16x8 (&kpa)[2]) {          // pre-activations of one (anchor, chunk): P[v] = row 8 (v / 4) + 4 kg + v % 4 of column kp
+#ifdef Y_ABL_NOPRE
+        f32x16 P = zero16;
+        asm volatile("" : "+v"(P) : "v"(kpa[0]));
+        return P;
+#else
         f32x16 P = __builtin_amdgcn_mfma_f32_32x32x16_bf16(geo_r[t][0], kpa[0], zero16, 0, 0, 0);
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(geo_r[t][1], kpa[1], P, 0, 0, 0);
+#endif
     };
-    // clamp to [0, 1] (the weight's mathematical range: relu below, rounding excess of the expanded form above) + exact split + pack:
-    // K step h2 of step 1 takes v = 8 h2 .. 8 h2 + 7 as its slots e = 0 .. 7; dword d of a fragment = slots (2 d, 2 d + 1)
-    auto gen_split = [&](const f32x16& P, y_u32x4 (&aw)[2][3]) {
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                unsigned h[2], m[2], l[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const float w = __builtin_amdgcn_fmed3f(P[8 * h2 + 2 * d + u], 0.0f, 1.0f);
-                    h[u] = __float_as_uint(w);
-                    const float r = w - __uint_as_float(h[u] & 0xffff0000u);
-                    m[u] = __float_as_uint(r);
-                    l[u] = __float_as_uint(r - __uint_as_float(m[u] & 0xffff0000u));
-                }
-                aw[h2][0][d] = __builtin_amdgcn_perm(h[1], h[0], 0x07060302u);
-                aw[h2][1][d] = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u);
-                aw[h2][2][d] = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u);
-            }
+    // clamp to [0, 1] (the weight's mathematical range) + two-plane fp16 split of the pair k = (P[2 k], P[2 k + 1]), cut into time steps:
+    // A(k): clamp, h = fp16 pair (truncation); B(k - 1): l = fp16 pair of the residuals.  K step h2 = k / 4 of step 1, dword d = k % 4 of its fragment.
+    struct Split { float w[16]; unsigned h[8]; };
+    constexpr int NTICK = 9;
+    auto split_tick = [&](int k, const f32x16& P, Split& S_, y_u32x4 (&aw)[2][2]) {
+#ifdef Y_ABL_NOSPLIT
+        if (k == 0) asm volatile("" :: "v"(P));
+        return;
+#endif
+        if (k < 8) {
+            S_.w[2 * k] = __builtin_amdgcn_fmed3f(P[2 * k], 0.0f, 1.0f);
+            S_.w[2 * k + 1] = __builtin_amdgcn_fmed3f(P[2 * k + 1], 0.0f, 1.0f);
+            S_.h[k] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(S_.w[2 * k], S_.w[2 * k + 1]));
+            aw[k / 4][0][k % 4] = S_.h[k];
+        }
+        if (k >= 1) {
+            const int pr = k - 1;
+            const f16x2 h = __builtin_bit_cast(f16x2, S_.h[pr]);      // (read back as an element of aw[..][0], the compiler took dword 0 for every pair of a K step)
+            aw[pr / 4][1][pr % 4] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(S_.w[2 * pr] - (float)h[0], S_.w[2 * pr + 1] - (float)h[1]));
+        }
     };
-    auto anchor_of = [&](int q) { return (q / NJ) * AG + wave * NJ + (q % NJ); };
-    issue_kp(anchor_of(0), kpn[0]);
-    issue_kp(anchor_of(1), kpn[1]);
-    issue_rows(anchor_of(0), 0);
-    y_u32x4 aws[2][2][3];                           // [step parity][K step of the chunk][plane]
-    {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const f32x16 P = gen_pre(0, kpn[0]);
-        gen_split(P, aws[0]);
-    }
-
-    // X1 store addresses of this lane: kernel point kp, channel blocks (2 q + kg) ^ sw(kp), q < NKR / 4
+    // X1 store addresses of this lane: kernel point kp, channel blocks (2 q + kg) ^ sw(kp), q < NKR / 4; kernel points 24 .. 31: the dump slot
     int xoff[NKR / 4];
 #pragma unroll
     for (int q = 0; q < NKR / 4; ++q) xoff[q] = kok ? kp * CH + 4 * (((2 * q + kg) ^ (CH == 16 ? (kp >> 1) & 3 : kp & 7))) : (int)(dump - X1s) + 4 * lane;
 
+    // prologue: the first D chunks requested, chunk 0 staged and read, the weights of step 0
+    issue_kp(0, kpn[0]);
+    issue_kp(1, kpn[1]);
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int k = 0; k < NL; ++k) load_piece(d, k, ring[d][k]);
+#pragma unroll
+    for (int k = 0; k < NL; ++k) stage_piece(k, ring[0][k]);
+#pragma unroll
+    for (int k = 0; k < NL; ++k) load_piece(D, k, ring[0][k]);
+#pragma unroll
+    for (int r = 0; r < NF; ++r) read_frag(r, bf[0]);
+    {
+        const f32x16 P = gen_pre(0, kpn[0]);
+        Split S_;
+#pragma unroll
+        for (int k = 0; k < NTICK; ++k) split_tick(k, P, S_, aws[0]);
+    }
+
     double st_s = 0.0, st_q = 0.0;
     f32x16 y[MT2];
+    float keep[NJ][NT32 == 1 ? 8 : 16];            // second channel half of the wave's anchors of a pass
 #pragma unroll 1
     for (int ag = 0; ag < NG; ++ag) {
-        float keep[NJ][NT32 == 1 ? 8 : 16];        // second channel half of the wave's anchors
+        const int G0 = ag * NSTEP;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int col = wave * NJ + j;
             const int q = ag * NJ + j;
-            const int a = ag * AG + col;
-            const int a_next = anchor_of(q + 1);
-            f32x16 acc[NT32];
 #pragma unroll
             for (int t = 0; t < NCH; ++t) {
-                const int sp = (j * NCH + t) & 1;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this chunk's rows have landed in LDS (and the kernel-point factor requested a step ago)
-                bf16x8 bf[NT32][2][3];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                    for (int ct = 0; ct < NT32; ++ct)
-#pragma unroll
-                        for (int h2 = 0; h2 < 2; ++h2) {
-                            const char* pa = stg + pl * PLB + toff[ct] + 16 * h2 * CIN * 2;
-                            const bf16x4 lo4 = x_tr16(pa), hi4 = x_tr16(pa + 4 * CIN * 2);
-                            bf[ct][h2][pl] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
-                        }
-                // the next step's pre-activations: they need neither the rows nor the LDS, so they run while the fragment reads return
+                const int g = j * NCH + t, sp = g & 1;                 // local step and its parity (fragment set, weight set)
                 const int tn = t + 1 < NCH ? t + 1 : 0;
+                const int rs = (g + 1) % D;                             // ring entry of chunk g + 1
+                // the next step's pre-activations open the step (they need registers only)
                 const f32x16 P = gen_pre(tn, t + 1 < NCH ? kpn[j & 1] : kpn[(j + 1) & 1]);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers: the staging tile may be overwritten
-                // the next chunk-step's rows (past this wave's last anchor: a harmless reload of anchor 59 -- no branch, the pass stays one basic block)
-                if (t + 1 < NCH) issue_rows(a, t + 1);
-                else issue_rows(a_next, 0);
-                // this anchor's kernel-point factor was last used just above (the pre-activations of its last chunk): request the anchor after next into its set
-                if (t == NCH - 1) issue_kp(anchor_of(q + 2), kpn[j & 1]);
-                {
-                    y_u32x4 (&aw)[2][3] = aws[sp];
-                    constexpr int NMF = 12 * NT32;
-                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+                // this anchor's kernel-point factor was last used just above: the anchor after next goes into its set
+                if (t == NCH - 1) issue_kp(q + 2, kpn[j & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                Split S_;
+                constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};     // (weight plane, feature plane): l * h, h * l, h * h
 #pragma unroll
-                    for (int mi = 0; mi < NMF; ++mi) {
-                        const int ct = mi % NT32, term = (mi / NT32) % 6, h2 = mi / (6 * NT32);
+                for (int i = 0; i < NMF; ++i) {
+                    {
+                        const int ct = i % NT32, term = (i / NT32) % 3, h2 = i / (3 * NT32);
 #ifndef Y_ABL_NOMFMA1
-                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ct][h2][PB[term]], __builtin_bit_cast(bf16x8, aw[h2][PA[term]]),
-                                                                          (t == 0 && mi < NT32) ? zero16 : acc[ct], 0, 0, 0);
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[sp][ct][h2][PB[term]], __builtin_bit_cast(f16x8, aws[sp][h2][PA[term]]),
+                                                                         (t == 0 && i < NT32) ? zero16 : acc[ct], 0, 0, 0);
 #else
-                        asm volatile("" :: "v"(aw[h2][PA[term]]), "v"(bf[ct][h2][PB[term]]));
-                        if (t == 0 && mi < NT32) acc[ct] = zero16;
+                        asm volatile("" :: "v"(aws[sp][h2][PA[term]]), "v"(bf[sp][ct][h2][PB[term]]));
+                        if (t == 0 && i < NT32) acc[ct] = zero16;
 #endif
                     }
-                    gen_split(P, aws[sp ^ 1]);
-#ifndef Y_NO_SCHED
-                    // the split's 16 independent chains go between the step's matrix instructions
-                    y_sched_pattern<NMF, INTER_Y_VPM(CIN)>();
+                    // chunk g + 1: ring -> staging tile (two pieces per slot), then its fragments (one per slot); the freed registers take chunk g + 1 + D
+#ifndef Y_ABL_NOSTAGE
+                    if (i < NW) { stage_piece(2 * i, ring[rs][2 * i]); stage_piece(2 * i + 1, ring[rs][2 * i + 1]); }
+#else
+                    if (i < NW) asm volatile("" :: "v"(ring[rs][2 * i]), "v"(ring[rs][2 * i + 1]));
 #endif
+                    if (i >= NW && i < NW + NL) load_piece(G0 + g + 1 + D, i - NW, ring[rs][i - NW]);
+#ifndef Y_ABL_NOFRAG
+                    if (i >= NW && i < NW + NF) read_frag(i - NW, bf[sp ^ 1]);
+#endif
+                    // the next step's weights
+                    if (NT32 == 2) { if (i >= 2 && i < 2 + NTICK) split_tick(i - 2, P, S_, aws[sp ^ 1]); }
+                    else if (i >= 1) { split_tick(2 * (i - 1), P, S_, aws[sp ^ 1]); if (2 * (i - 1) + 1 < NTICK) split_tick(2 * (i - 1) + 1, P, S_, aws[sp ^ 1]); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (t == NCH - 1) {
+                    // anchor end.  D[c][k]: this lane = kernel point kp, channels 8 (v / 4) + 4 kg + v % 4 of each 32-channel tile: first half -> X1 tile, second half parked
+                    float* xcol = X1s + (kok ? col * S : 0);
+#pragma unroll
+                    for (int q4 = 0; q4 < NKR / 4; ++q4)
+                        *reinterpret_cast<float4*>(xcol + xoff[q4]) = make_float4(acc[0][4 * q4], acc[0][4 * q4 + 1], acc[0][4 * q4 + 2], acc[0][4 * q4 + 3]);
+#pragma unroll
+                    for (int v = 0; v < NKR; ++v) keep[j][v] = NT32 == 1 ? acc[0][NKR + v] : acc[NT32 - 1][v];
                 }
             }
-            // anchor end.  D[c][k]: this lane = kernel point kp, channels 8 (v / 4) + 4 kg + v % 4 of each 32-channel tile: first half -> LDS, second half parked
-            float* xcol = X1s + (kok ? col * S : 0);         // lanes of the kernel points 24 .. 31 write their zeros into the dump slot (xoff): no branch
-#pragma unroll
-            for (int q4 = 0; q4 < NKR / 4; ++q4)
-                *reinterpret_cast<float4*>(xcol + xoff[q4]) = make_float4(acc[0][4 * q4], acc[0][4 * q4 + 1], acc[0][4 * q4 + 2], acc[0][4 * q4 + 3]);
-#pragma unroll
-            for (int v = 0; v < NKR; ++v) keep[j][v] = NT32 == 1 ? acc[0][NKR + v] : acc[NT32 - 1][v];
         }
 #pragma unroll
         for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
             for (int v = 0; v < 16; ++v) y[mt][v] = 0.f;
 #ifndef Y_ABL_NOSTEP2
-        X32Step2<CIN, COUT> s2;
+        H32Step2<CIN, COUT, Y_PAD(CIN)> s2;
         const bf16x8* Wq_g = Wq;
         asm volatile("" : "+s"(Wq_g));
         s2.issue(0, Wq_g, wave, lane);
@@ -322,7 +392,7 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
         s2.template half<1>(y, X1s, Wq_g, wave, lane);
 #endif
         __syncthreads();                                // every wave finished reading X1s: the partial table may overwrite it
-        // y[mt][v] = Y[o = 32 mt + 8 (v / 4) + 4 kg + v % 4][anchor column = lane % 32]
+        // y[mt][v] = 2^6 Y[o = 32 mt + 8 (v / 4) + 4 kg + v % 4][anchor column = lane % 32]
 #pragma unroll
         for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
@@ -335,14 +405,13 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
             if (a < NA) {
                 float v = part[(0 * AG + col) * PS + o] + part[(1 * AG + col) * PS + o];
                 v += part[(2 * AG + col) * PS + o] + part[(3 * AG + col) * PS + o];
-                v += bias[o];
+                v = v * 0.015625f + bias[o];            // the weight planes carry W * 2^6 (exact)
                 outp[(size_t)a * COUT + o] = v;
                 st_s += (double)v; st_q += (double)v * (double)v;
             }
         }
         __syncthreads();                                // the table is read: the next pass may write X1s
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no LDS-direct load may outlive the workgroup's LDS allocation
     if (stat_part) {
         static_assert(256 % COUT == 0, "a thread must keep one output channel");
         double* dred = reinterpret_cast<double*>(part);
@@ -358,12 +427,16 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
     }
 }
 
+#ifndef INTER_Y_DEPTH
+#define INTER_Y_DEPTH(CIN) 2
+#endif
+
 template <int CIN, int COUT, int NCH>
 static int launch_y(int b, int p1, int p2, float sigma, const float* xyz, const float* new_xyz, const int* idx, const void* Fq, const void* kq,
                     const void* Wq, const float* bias, float* out, const int* order, double* stat_part, hipStream_t st) {
     constexpr int NN = 32 * NCH;
-    const size_t lds = (size_t)(32 * ((CIN / 2) * KS + 44) + 17 * NN + 256) * sizeof(float);
-    auto kern = inter_so3conv_y_kernel<CIN, COUT, NCH>;
+    const size_t lds = (size_t)(32 * ((CIN / 2) * KS + Y_PAD(CIN)) + 17 * NN) * sizeof(float);
+    auto kern = inter_so3conv_y_kernel<CIN, COUT, NCH, INTER_Y_DEPTH(CIN)>;
     {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -375,7 +448,31 @@ static int launch_y(int b, int p1, int p2, float sigma, const float* xyz, const 
     return ETCH_OK;
 }
 
+// x [rows][C] fp32 -> planes [rows][2][C] fp16 (split2h); thread = 4 consecutive channels
+__global__ void __launch_bounds__(256) split2_planes_f16_kernel(long n4, int C, const float* __restrict__ x, unsigned short* __restrict__ planes) {
+    const int c4 = C >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / c4;
+        const int c = (int)(i - row * c4) * 4;
+        uint2 h, l;
+        split2h_pack4(reinterpret_cast<const float4*>(x)[i], h, l);
+        unsigned short* pr = planes + (size_t)row * 2 * C + c;
+        *reinterpret_cast<uint2*>(pr) = h; *reinterpret_cast<uint2*>(pr + C) = l;
+    }
+}
+
 extern "C" {
+
+int etch_split2_planes_f16(long rows, int C, const float* x, void* planes, void* stream) {
+    if (rows <= 0) return ETCH_OK;
+    if (C <= 0 || (C & 3) || ((uintptr_t)x & 15) || ((uintptr_t)planes & 7)) return ETCH_EUNSUPPORTED;
+    const long n4 = rows * (C / 4);
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(split2_planes_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n4, C, x, reinterpret_cast<unsigned short*>(planes));
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
 
 // rk [60][24][3] fp32 (anchors @ kernel points, functional.py:296) + sigma -> kq [60][2][64][8] bf16 (122 880 bytes), once per layer
 int etch_inter_kpoint_operand(float sigma, const float* rk, void* kq, void* stream) {
@@ -392,7 +489,7 @@ int etch_inter_so3conv_planes_kq(int b, int cin, int cout, int p1, int p2, int n
     if (b <= 0 || p2 <= 0) return ETCH_OK;
     if (sigma <= 0.f || !Wq32 || !feats_planes || !kq) return ETCH_EINVAL;
     if (((uintptr_t)feats_planes & 15) || ((uintptr_t)Wq32 & 15) || ((uintptr_t)kq & 15)) return ETCH_EINVAL;
-    if ((size_t)p1 * NA * 3 * cin * 2 >= ((size_t)1 << 32)) return ETCH_EUNSUPPORTED;      // 32-bit byte offsets inside a scan
+    if ((size_t)p1 * NA * 2 * cin * 2 >= ((size_t)1 << 32)) return ETCH_EUNSUPPORTED;      // 32-bit byte offsets inside a scan
     hipStream_t st = (hipStream_t)stream;
 #define Y_CASE(CI, CO, NC) \
     if (cin == CI && cout == CO && nn == 32 * NC) return launch_y<CI, CO, NC>(b, p1, p2, sigma, xyz, new_xyz, ball_idx, feats_planes, kq, Wq32, bias, out, order, stat_part, st);

@@ -82,3 +82,28 @@ __device__ __forceinline__ void split3_pack8p(const float4 v0, const float4 v1, 
     hi = __builtin_bit_cast(bf16x8, ETCH_PK(h)); mid = __builtin_bit_cast(bf16x8, ETCH_PK(m)); lo = __builtin_bit_cast(bf16x8, ETCH_PK(l));
 #undef ETCH_PK
 }
+
+// ---- two-plane fp16 split (round 5): x = h + l with h = fp16(x) by truncation and l = fp16(x - h), 22 significant bits above 2^-14 and an absolute
+// floor of 2^-24 below (fp16 subnormals, which the gfx950 matrix cores keep: profiles/r05_f16_two_plane_split.txt) -- for O(1) operands a product
+// (l*h + h*l + h*h, three v_mfma_f32_32x32x16_f16) carries the error of the fp32 MFMA, with half the matrix instructions, 4 instead of 6 bytes per
+// element and 4 instead of 6.5 VALU operations per split value of the exact three-plane bf16 split above.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2h_pair(float a, float b, unsigned& h, unsigned& l) {
+    const f16x2 hp = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
+    h = __builtin_bit_cast(unsigned, hp);
+    l = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - (float)hp[0], b - (float)hp[1]));
+}
+// 4 consecutive fp32 values -> 2 planes x 4 fp16 (8 bytes each)
+__device__ __forceinline__ void split2h_pack4(const float4 v, uint2& h, uint2& l) {
+    split2h_pair(v.x, v.y, h.x, l.x);
+    split2h_pair(v.z, v.w, h.y, l.y);
+}
+// 8 consecutive fp32 values -> 2 planes x 8 fp16
+__device__ __forceinline__ void split2h_pack8(const float4 v0, const float4 v1, f16x8& h, f16x8& l) {
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    unsigned hh[4], ll[4];
+    split2h_pair(v0.x, v0.y, hh[0], ll[0]); split2h_pair(v0.z, v0.w, hh[1], ll[1]);
+    split2h_pair(v1.x, v1.y, hh[2], ll[2]); split2h_pair(v1.z, v1.w, hh[3], ll[3]);
+    h = __builtin_bit_cast(f16x8, (u32x4_){hh[0], hh[1], hh[2], hh[3]}); l = __builtin_bit_cast(f16x8, (u32x4_){ll[0], ll[1], ll[2], ll[3]});
+}

@@ -115,10 +115,10 @@ class SeparableSO3ConvBlock(nn.Module):
             s = ops.linear(fin.view(-1, cin), w, bias=bias)
         s = s.view(b, p2, na, -1)
         m3, r3 = ops.instnorm_stats(s)
-        # emit_planes (set by BasicSO3ConvBlock when the NEXT conv gathers bf16 planes): the output is also written split, once, by this pass
+        # emit_planes (set by EquivBackbone when the NEXT conv gathers planes; True / "bf16" / "f16" = their format): the output is also written split, once, by this pass
         planes = None
         if self.emit_planes:
-            out, planes = ops.instnorm_act_add(z.feats_cl, m2, r2, s, m3, r3, want_planes=True)
+            out, planes = ops.instnorm_act_add(z.feats_cl, m2, r2, s, m3, r3, want_planes=self.emit_planes)
         else:
             out = ops.instnorm_act_add(z.feats_cl, m2, r2, s, m3, r3)
         # x.anchors after the intra conv = the INTRA conv's anchors buffer (vgtk modules.py:153; so3conv.py:182 passes it on)

@@ -305,8 +305,36 @@ INTER_KQ = os.environ.get("ETCH_INTER_KQ", "1") != "0"          # kernel weights
 
 
 def inter_planes_form(cin):
-    """MFMA shape of the planes kernel for this width: 32 (etch_inter_so3conv_planes_kq / _planes32) or 16 (etch_inter_so3conv_planes)."""
-    return 32 if (INTER_KQ and INTER_X) or (INTER_X32 and cin == 64) else 16
+    """MFMA shape of the round-4 planes kernel for this width: 32 (etch_inter_so3conv_planes32, 64 input channels) or 16 (etch_inter_so3conv_planes)."""
+    return 32 if (INTER_X32 and cin == 64) else 16
+
+
+def split2_planes_f16(x_cl):
+    """x (..., C) fp32 -> (..., 2, C) float16: h = fp16(x) by truncation, l = fp16(x - h), the layout etch_inter_so3conv_planes_kq gathers (the
+    encoder's own producer, instnorm_act_add(want_planes="f16"), writes it directly)."""
+    _need(x_cl, torch.float32, "x")
+    C = x_cl.shape[-1]
+    planes = torch.empty(tuple(x_cl.shape[:-1]) + (2, C), dtype=torch.float16, device=x_cl.device)
+    _lib.check(_lib.lib().etch_split2_planes_f16(_c_long(x_cl.numel() // C), int(C), _ptr(x_cl), _ptr(planes), _stream()), "etch_split2_planes_f16")
+    return planes
+
+
+def inter_weight_split32_f16(W, cin, ks=24):
+    """Weight of etch_inter_so3conv_planes_kq: the columns of W [cout, cin*24] in the physical contraction order of inter_weight_split32, scaled by
+    2^6 (exact; Xavier-sized weights then keep a normal fp16 residual plane, the kernel's epilogue multiplies by 2^-6), as two fp16 planes
+    h = fp16(64 W), l = fp16(64 W - h), in A-fragment order [K step of 16][o tile of 32][plane][lane = 32 * (kappa / 8 % 2) + o % 32][8]."""
+    cout = W.shape[0]
+    assert ks == 24 and cin in (32, 64) and cout % 32 == 0 and W.shape[1] == cin * ks
+    ch = cin // 2
+    cols = [(h * ch + 4 * (pb ^ (((k >> 1) & 3) if ch == 16 else (k & 7))) + i) * ks + k
+            for h in range(2) for k in range(ks) for pb in range(ch // 4) for i in range(4)]
+    assert sorted(cols) == list(range(cin * ks))
+    w64 = W[:, torch.tensor(cols, dtype=torch.long, device=W.device)] * 64.0
+    hi = w64.to(torch.float16)
+    planes = torch.stack([hi, (w64 - hi.float()).to(torch.float16)])                      # [2][cout][K]
+    K = cin * ks
+    q = planes.reshape(2, cout // 32, 32, K // 16, 2, 8)                 # [pl][mt][o][s][kg][e]
+    return q.permute(3, 1, 0, 4, 2, 5).contiguous().reshape(-1)          # [s][mt][pl][kg][o][e]
 
 
 def inter_kpoint_operand(rk, sigma):
@@ -346,10 +374,11 @@ def spatial_order(xyz):
 
 
 def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, order=None, want_stats=False, Wp32=None, Wq=None, Wqn=None,
-                  feats_planes=None, Wq32=None, kq=None):
+                  feats_planes=None, Wq32=None, kq=None, Wqh=None):
     """feats_cl (b,p1,60,cin) channels-last -> (b,p2,60,cout) pre-norm.  order (b,p2) int32: processing order of the output points.
     want_stats: also return the InstanceNorm (mean, rstd) of the output, accumulated in the conv's epilogue.
-    kq (inter_kpoint_operand) + Wq32: the round-5 kernel (weights' pre-activation on the matrix cores, every covered shape).
+    kq (inter_kpoint_operand) + Wqh (inter_weight_split32_f16): the round-5 kernel (weights' pre-activation on the matrix cores, two fp16 planes per
+    operand, every covered shape); feats_planes (b,p1,60,2,cin) float16 = split2_planes_f16 (made here when absent or in the bf16 format).
     Wq32 (inter_weight_split32) / Wqn (inter_weight_split(natural=True)): both contractions on the bf16 matrix cores where the shape is covered
     (32x32x16 for 64 input channels / 16x16x32 MFMA form); feats_planes (b,p1,60,3,cin) int16 = the producer's split of feats_cl (made here when absent)."""
     b, p1, na, cin = feats_cl.shape
@@ -364,18 +393,18 @@ def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, orde
     out = torch.empty((b, p2, 60, cout), dtype=torch.float32, device=xyz.device)
     fused = want_stats and 256 % cout == 0 and (cin >= 16 or (cin == 1 and cout <= 64 and nn * 60 >= 1026))      # the c1 kernel's own precondition (so3conv.hip)
     part = torch.empty((b, p2, 2, cout), dtype=torch.float64, device=xyz.device) if fused else None
-    if kq is not None and Wq32 is not None and INTER_KQ and inter_planes_supported(cin, cout, nn):
-        _need(Wq32, torch.int16, "Wq32"), _need(kq, torch.int16, "kq")
-        if feats_planes is None:
-            feats_planes = split3_planes(feats_cl)
-        _need(feats_planes, torch.int16, "feats_planes")
-        assert tuple(feats_planes.shape) == (b, p1, na, 3, cin) and kq.numel() == 60 * 2 * 64 * 8
+    if kq is not None and Wqh is not None and INTER_KQ and inter_planes_supported(cin, cout, nn):
+        _need(Wqh, torch.float16, "Wqh"), _need(kq, torch.int16, "kq")
+        if feats_planes is None or feats_planes.dtype != torch.float16:
+            feats_planes = split2_planes_f16(feats_cl)
+        _need(feats_planes, torch.float16, "feats_planes")
+        assert tuple(feats_planes.shape) == (b, p1, na, 2, cin) and kq.numel() == 60 * 2 * 64 * 8 and Wqh.numel() == 2 * cout * cin * 24
         _lib.check(_lib.lib().etch_inter_so3conv_planes_kq(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
-                                                          _ptr(feats_planes), _ptr(kq), _ptr(Wq32), _ptr(bias), _ptr(out), _optptr(order),
+                                                          _ptr(feats_planes), _ptr(kq), _ptr(Wqh), _ptr(bias), _ptr(out), _optptr(order),
                                                           _optptr(part), _stream()), "etch_inter_so3conv_planes_kq")
     elif Wq32 is not None and cin == 64 and inter_planes_form(cin) == 32 and inter_planes_supported(cin, cout, nn):
         _need(Wq32, torch.int16, "Wq32")
-        if feats_planes is None:
+        if feats_planes is None or feats_planes.dtype != torch.int16:
             feats_planes = split3_planes(feats_cl)
         _need(feats_planes, torch.int16, "feats_planes")
         assert tuple(feats_planes.shape) == (b, p1, na, 3, cin)
@@ -384,7 +413,7 @@ def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, orde
                                                          _optptr(part), _stream()), "etch_inter_so3conv_planes32")
     elif Wqn is not None and inter_planes_supported(cin, cout, nn):
         _need(Wqn, torch.int16, "Wqn")
-        if feats_planes is None:
+        if feats_planes is None or feats_planes.dtype != torch.int16:
             feats_planes = split3_planes(feats_cl)
         _need(feats_planes, torch.int16, "feats_planes")
         assert tuple(feats_planes.shape) == (b, p1, na, 3, cin)
@@ -460,14 +489,19 @@ def instnorm_stats(x_cl):
 
 
 def instnorm_act_add(x1, m1, r1, x2=None, m2=None, r2=None, want_planes=False):
-    """want_planes: also return the result as three bf16 planes (..., 3, C) int16 (the gather format of etch_inter_so3conv_planes)."""
+    """want_planes: also return the result split for the next conv's gathers -- True / "bf16": three bf16 planes (..., 3, C) int16
+    (etch_inter_so3conv_planes); "f16": two fp16 planes (..., 2, C) float16 (etch_inter_so3conv_planes_kq)."""
     _need(x1, torch.float32, "x1")
     b, C = x1.shape[0], x1.shape[-1]
     rows = x1.numel() // (b * C)
     out = torch.empty_like(x1)
-    planes = torch.empty(tuple(x1.shape[:-1]) + (3, C), dtype=torch.int16, device=x1.device) if want_planes else None
-    _lib.check(_lib.lib().etch_instnorm_act_add_planes(b, rows, C, _ptr(x1), _ptr(m1), _ptr(r1), _optptr(x2), _optptr(m2), _optptr(r2),
-                                                       _ptr(out), _optptr(planes), _stream()), "etch_instnorm_act_add")
+    f16 = want_planes == "f16"
+    planes = None
+    if want_planes:
+        planes = torch.empty(tuple(x1.shape[:-1]) + ((2, C) if f16 else (3, C)), dtype=torch.float16 if f16 else torch.int16, device=x1.device)
+    fn = _lib.lib().etch_instnorm_act_add_planes_f16 if f16 else _lib.lib().etch_instnorm_act_add_planes
+    _lib.check(fn(b, rows, C, _ptr(x1), _ptr(m1), _ptr(r1), _optptr(x2), _optptr(m2), _optptr(r2), _ptr(out), _optptr(planes), _stream()),
+               "etch_instnorm_act_add")
     return (out, planes) if want_planes else out
 
 

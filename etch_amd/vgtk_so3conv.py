@@ -131,6 +131,7 @@ class InterSO3Conv(nn.Module):
         self._dqn = _Derived()
         self._dq32 = _Derived()
         self._dkq = _Derived()
+        self._dqh = _Derived()
 
     def _derived(self):
         W, bias = self.basic_conv.W, self.basic_conv.bias
@@ -173,6 +174,13 @@ class InterSO3Conv(nn.Module):
         W = self.basic_conv.W
         return self._dq32.get((W,), lambda: ops.inter_weight_split32(W.detach().contiguous(), self.dim_in, self.kernel_size))
 
+    def _wqh(self):
+        """The two fp16 planes of 2^6 W in the physical contraction order of the 32x32x16 kernels (etch_inter_so3conv_planes_kq); None where unused."""
+        if not (ops.INTER_KQ and self.wants_planes()):
+            return None
+        W = self.basic_conv.W
+        return self._dqh.get((W,), lambda: ops.inter_weight_split32_f16(W.detach().contiguous(), self.dim_in, self.kernel_size))
+
     def _kq(self):
         """Kernel-point factor of the weights' pre-activation (etch_inter_so3conv_planes_kq); None where that kernel is not used."""
         if not (ops.INTER_KQ and self.wants_planes()):
@@ -181,8 +189,11 @@ class InterSO3Conv(nn.Module):
         return self._dkq.get((self.anchors, self.kernels), lambda: ops.inter_kpoint_operand(rk, self.sigma))
 
     def wants_planes(self):
-        """True if this conv gathers its input as bf16 planes (its producer should emit them: SeparableSO3ConvBlock.emit_planes)."""
-        return ops.inter_planes_supported(self.dim_in, self.dim_out, self.n_neighbor) and self.kernel_size == 24
+        """Falsy, or the plane format this conv gathers its input in (its producer should emit it: SeparableSO3ConvBlock.emit_planes):
+        "f16" (two fp16 planes, etch_inter_so3conv_planes_kq) / "bf16" (three bf16 planes, the round-4 kernels)."""
+        if not (ops.inter_planes_supported(self.dim_in, self.dim_out, self.n_neighbor) and self.kernel_size == 24):
+            return False
+        return "f16" if ops.INTER_KQ else "bf16"
 
     def group(self, xyz):
         """functional.py:176-185 inter_spconv_grouping_ball (index part): -> ball_idx, sample_idx, new_xyz.
@@ -215,7 +226,7 @@ class InterSO3Conv(nn.Module):
             sample_idx, new_xyz = None, xyz
         rk, W, Wp, bias = self._derived()
         y, stats = ops.inter_so3conv(xyz, new_xyz, inter_idx, x.feats_cl, rk, W, Wp, bias, self.sigma, order=self.order(new_xyz), want_stats=True, Wp32=self._wp32(), Wq=self._wq(),
-                                     Wqn=None if ops.inter_planes_form(self.dim_in) == 32 else self._wqn(), Wq32=self._wq32(), kq=self._kq(), feats_planes=getattr(x, "feats_planes", None))
+                                     Wqn=None if ops.inter_planes_form(self.dim_in) == 32 else self._wqn(), Wq32=self._wq32(), kq=self._kq(), Wqh=self._wqh(), feats_planes=getattr(x, "feats_planes", None))
         cloud = SphericalPointCloud(new_xyz, None, self.anchors, feats_cl=y)
         cloud.in_stats = stats          # InstanceNorm (mean, rstd) of the output, a by-product of the conv's epilogue
         return inter_idx, None, sample_idx, cloud

@@ -174,17 +174,27 @@ int etch_inter_so3conv_planes32(int b, int cin, int cout, int p1, int p2, int nn
                                 const int* ball_idx, const void* feats_planes, const float* rk, const void* Wq32, const float* bias, float* out,
                                 const int* order, double* stat_part, void* stream);
 
-/* Round 5 (etch_amd/csrc/so3conv_y.hip): etch_inter_so3conv_planes32 with the kernel weights of functional.py:286-324 formed on the MATRIX cores:
- * the pre-activation 1 - |g_n - R_a kappa_k|^2 / sigma = [a_n, 1, G_n] . [1, b_k, r_ak] is a rank-5 bilinear form whose six largest exactly-split
- * cross terms fill one pair of v_mfma_f32_32x32x16_bf16 per (anchor, 32 neighbours); the VALU keeps the clamp and the exact split of the result.
- * kq = etch_inter_kpoint_operand(sigma, rk): [60 anchors][2 K steps][64 lanes][8] bf16 (122 880 bytes), the kernel-point factor in B-fragment
- * order, built once per layer from rk [60][24][3] = anchors @ kernel points (functional.py:296).  Covers every shape of
- * etch_inter_so3conv_planes_supported (32 AND 64 input channels); Wq32 / feats_planes / order / stat_part as for etch_inter_so3conv_planes32.
- * Same result as the fp32 kernels up to the rounding of the weights' pre-activation (<= 4e-7 absolute on weights in [0, 1]) and the order of the sums. */
+/* Round 5 (etch_amd/csrc/so3conv_y.hip): the inter conv of functional.py:286-324, :61-67 + modules.py:33-39 rebuilt around three measurements of
+ * this round (profiles/r05_inter_conv_latency_bound.txt, r05_f16_two_plane_split.txt):
+ *   (1) kernel weights off the MATRIX cores: the pre-activation 1 - |g_n - R_a kappa_k|^2 / sigma = [a_n, 1, G_n] . [1, b_k, r_ak] is a rank-5
+ *       bilinear form whose six largest exactly-split bf16 cross terms fill one pair of v_mfma_f32_32x32x16_bf16 per (anchor, 32 neighbours);
+ *   (2) both contractions on v_mfma_f32_32x32x16_f16 with TWO fp16 planes per operand (x = h + l, h = fp16(x) by truncation, l = fp16(x - h):
+ *       22 significant bits, absolute floor 2^-24; three cross products): for the O(1) operands of this path the error of the fp32 MFMA, with half
+ *       the matrix instructions, 4 instead of 6 bytes per gathered element and 40 % of the split work of the three-plane bf16 split;
+ *   (3) gathered rows through a register ring (plain loads, several chunks in flight per wave) instead of LDS-direct loads.
+ * feats_planes (b, p1, 60, 2, cin) fp16 = etch_split2_planes_f16 / etch_instnorm_act_add_planes_f16 of the fp32 features; kq =
+ * etch_inter_kpoint_operand(sigma, rk): [60 anchors][2 K steps][64 lanes][8] bf16 (122 880 bytes), the kernel-point factor in B-fragment order, built
+ * once per layer from rk [60][24][3] = anchors @ kernel points (functional.py:296); Wq: 2 * cout * cin * 24 fp16 = the two planes of 2^6 W in the
+ * physical contraction order of etch_inter_so3conv_planes32, [K step of 16][o tile of 32][plane][lane][8] (etch_amd/ops.py inter_weight_split32_f16).
+ * Covers every shape of etch_inter_so3conv_planes_supported; order / stat_part as for etch_inter_so3conv.  Same result as the fp32 kernels to
+ * ~1e-6 of the output scale (tests/test_gpu_r05.py holds it to the fp32 kernel AND to fp64 under the entitled-error rule). */
 int etch_inter_kpoint_operand(float sigma, const float* rk, void* kq, void* stream);
 int etch_inter_so3conv_planes_kq(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
                                  const int* ball_idx, const void* feats_planes, const void* kq, const void* Wq32, const float* bias, float* out,
                                  const int* order, double* stat_part, void* stream);
+
+/* x (rows, C) fp32 -> planes (rows, 2, C) fp16: h = fp16(x) by truncation, l = fp16(x - h) (the gather format of etch_inter_so3conv_planes_kq). */
+int etch_split2_planes_f16(long rows, int C, const float* x, void* planes, void* stream);
 
 /* x (rows, C) fp32 -> planes (rows, 3, C) bf16: the exact split x = hi + mid + lo (8 + 8 + 8 mantissa bits, by truncation). */
 int etch_split3_planes(long rows, int C, const float* x, void* planes, void* stream);
@@ -232,6 +242,9 @@ int etch_instnorm_act_add(int b, int rows, int C, const float* x1, const float* 
 /* The same, additionally writing the result as three bf16 planes (b, rows, 3, C) for etch_inter_so3conv_planes (planes may be NULL). */
 int etch_instnorm_act_add_planes(int b, int rows, int C, const float* x1, const float* m1, const float* r1, const float* x2,
                                  const float* m2, const float* r2, float* out, void* planes, void* stream);
+/* The same with two fp16 planes (b, rows, 2, C) for etch_inter_so3conv_planes_kq. */
+int etch_instnorm_act_add_planes_f16(int b, int rows, int C, const float* x1, const float* m1, const float* r1, const float* x2,
+                                     const float* m2, const float* r2, float* out, void* planes, void* stream);
 
 /* ---- feature propagation + direction head --------------------------------------------------------------- */
 

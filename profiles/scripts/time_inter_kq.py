@@ -30,7 +30,7 @@ for name, cin, cout, nn, radius, sigma, xyz, p2 in shapes:
     planes = ops.split3_planes(feats)
     order = ops.spatial_order(new_xyz)
     wq32 = ops.inter_weight_split32(W, cin)
-    forms = [("kq", dict(Wq32=wq32, kq=ops.inter_kpoint_operand(rk, sigma), feats_planes=planes))]
+    forms = [("kq", dict(Wqh=ops.inter_weight_split32_f16(W, cin), kq=ops.inter_kpoint_operand(rk, sigma), feats_planes=ops.split2_planes_f16(feats)))]
     if not only_kq:
         forms = [("r03", dict(Wq=conv._wq())), ("r04", dict(Wq32=wq32, feats_planes=planes) if cin == 64 else dict(Wqn=ops.inter_weight_split(W, cin, natural=True), feats_planes=planes))] + forms
     res = {}

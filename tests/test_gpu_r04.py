@@ -77,7 +77,7 @@ def test_encoder_with_plane_producers_equals_encoder_without(monkeypatch):
                                  markerset=K.default_markerset())
     model = load_seeded(GT_network_equiv(option=args), 1).cuda().eval()
     emit = [c.emit_planes for blk in model.encoder.backbone for c in blk.blocks]
-    assert emit == [True, True, True, False], emit
+    assert [bool(e) for e in emit] == [True, True, True, False], emit
     pts = torch.from_numpy((np.random.default_rng(5).standard_normal((2, 1500, 3)) * np.array([0.14, 0.31, 0.085])).astype(np.float32)).cuda()
     with torch.no_grad():
         a = model.encoder(pts)[0].feats_cl

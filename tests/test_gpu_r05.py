@@ -27,6 +27,7 @@ def test_kpoint_operand_is_the_exact_split_of_the_kernel_point_factor():
     assert kq.shape == (60, 2, 64, 8) and kq.dtype == torch.int16
     # [a][slot][k]: lane = 32 kg + k holds slots 16 j + 8 kg + i
     slots = kq.reshape(60, 2, 2, 32, 8).permute(0, 1, 2, 4, 3).reshape(60, 32, 32)
+    slots = torch.where(slots == -32768, torch.zeros_like(slots), slots)          # -0.0 (b of the origin kernel point: -(0) / sigma) == +0.0
     val = _bf16_to_f64(slots)
     assert float(val[:, 30:].abs().max()) == 0.0
     kp_plane = [0, 1, 0, 2, 0, 1]
@@ -45,11 +46,33 @@ def test_kpoint_operand_is_the_exact_split_of_the_kernel_point_factor():
     assert float((comp[:, :24, 1].double() - bk).abs().max()) < 1e-6 * float(bk.abs().max())
 
 
+def test_split2_planes_f16_carry_22_bits_and_match_the_producer():
+    """etch_split2_planes_f16 / instnorm_act_add(want_planes="f16"): h = fp16(x) by truncation, l = fp16(x - h); h + l reproduces x to 2^-21
+    relative above 2^-14 and to 2^-24 absolute below (fp16 subnormals); the producer's planes are the split of its fp32 output bit for bit."""
+    from etch_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(2, 37, 60, 32, generator=g) * torch.logspace(-4, 2, 32)).cuda()
+    planes = ops.split2_planes_f16(x)
+    assert planes.shape == (2, 37, 60, 2, 32) and planes.dtype == torch.float16
+    h, l = planes[..., 0, :].double(), planes[..., 1, :].double()
+    xd = x.double()
+    assert bool((h.abs() <= xd.abs()).all())                                     # truncation
+    err = (h + l - xd).abs()
+    assert bool((err <= torch.maximum(xd.abs() * 2.0 ** -21, torch.full_like(xd, 2.0 ** -24))).all()), float((err / xd.abs().clamp_min(1e-30)).max())
+    m, r = ops.instnorm_stats(x)
+    x2 = torch.randn(2, 37, 60, 32, generator=g).cuda()
+    m2, r2 = ops.instnorm_stats(x2)
+    out = ops.instnorm_act_add(x, m, r, x2, m2, r2)
+    out_p, pl = ops.instnorm_act_add(x, m, r, x2, m2, r2, want_planes="f16")
+    assert torch.equal(out, out_p) and torch.equal(pl, ops.split2_planes_f16(out))
+
+
 @pytest.mark.parametrize("cin,cout,nn,p1,p2", SHAPES)
 def test_inter_conv_kq_matches_the_fp32_kernel_and_fp64(cin, cout, nn, p1, p2):
-    """etch_inter_so3conv_planes_kq (v_mfma_f32_32x32x16_bf16 for BOTH contractions AND for the weights' pre-activation, every covered shape incl.
-    32 input channels) against the fp32-MFMA kernel and the fp64 formula under the entitled-error rule; bitwise reproducible,
-    schedule-independent; padded neighbourhoods included."""
+    """etch_inter_so3conv_planes_kq (weights' pre-activation on v_mfma_f32_32x32x16_bf16 from exactly split factors, both contractions on
+    v_mfma_f32_32x32x16_f16 with two fp16 planes per operand, gathered rows through the register ring; every covered shape incl. 32 input channels)
+    against the fp32-MFMA kernel and the fp64 formula under the entitled-error rule; bitwise reproducible, schedule-independent; padded
+    neighbourhoods included."""
     from etch_amd import ops
     from etch_amd import vgtk_so3conv as V
     assert ops.inter_planes_supported(cin, cout, nn)
@@ -60,14 +83,14 @@ def test_inter_conv_kq_matches_the_fp32_kernel_and_fp64(cin, cout, nn, p1, p2):
     ball = ops.ball_query(new_xyz, xyz, 0.25, nn)
     conv = load_seeded(V.InterSO3Conv(cin, cout, 1, 2, 0.25, 0.03, nn), 3).cuda()
     rk, W, Wp, bias = conv._derived()
-    kq, wq32 = conv._kq(), conv._wq32()
-    assert kq is not None and wq32 is not None
+    kq, wqh = conv._kq(), conv._wqh()
+    assert kq is not None and wqh is not None
     feats = torch.randn(b, p1, 60, cin, generator=g).cuda()
-    planes = ops.split3_planes(feats)
+    planes = ops.split2_planes_f16(feats)
     f32, (m0, r0) = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, want_stats=True)
     new, (m1, r1) = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, want_stats=True, feats_planes=planes,
-                                      order=ops.spatial_order(new_xyz), Wq32=wq32, kq=kq)
-    again = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, Wq32=wq32, kq=kq)        # planes made on the fly, plain order
+                                      order=ops.spatial_order(new_xyz), Wqh=wqh, kq=kq)
+    again = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, Wqh=wqh, kq=kq)        # planes made on the fly, plain order
     assert torch.equal(new, again)
     scale = float(f32.abs().max())
     assert float((new - f32).abs().max()) < 2e-6 * scale, float((new - f32).abs().max()) / scale
@@ -98,12 +121,12 @@ def test_inter_conv_kq_soak_under_contention(cin, cout, nn, p2):
     ball = ops.ball_query(new_xyz, xyz, radius, nn)
     conv = load_seeded(V.InterSO3Conv(cin, cout, 1, 1, radius, sigma, nn), 3).cuda()
     rk, W, Wp, bias = conv._derived()
-    kq, wq32 = conv._kq(), conv._wq32()
+    kq, wqh = conv._kq(), conv._wqh()
     feats = torch.randn(b, p1, 60, cin, generator=g).cuda()
-    planes = ops.split3_planes(feats)
+    planes = ops.split2_planes_f16(feats)
     order = ops.spatial_order(new_xyz)
     f32 = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, sigma)
-    run = lambda: ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, sigma, order=order, Wq32=wq32, kq=kq, feats_planes=planes)
+    run = lambda: ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, sigma, order=order, Wqh=wqh, kq=kq, feats_planes=planes)
     first = run()
     scale = float(f32.abs().max())
     assert float((first - f32).abs().max()) < 2e-6 * scale
