@@ -72,37 +72,35 @@ template <int CIN, int COUT, int PAD>
 struct H32Step2 {
     static constexpr int MT2 = COUT / 32, CH = CIN / 2, KH = CH * KS, S = KH + PAD;
     static constexpr int NSW = KH / 16 / 4;         // K steps per wave and half
-    f32x4 ra[2][MT2][2];
+    static constexpr int NB = NSW * MT2;            // batches (one K step x one o tile: two planes) per half
+    f32x4 ra[2][2];
     __device__ __forceinline__ void issue(int i, const bf16x8* __restrict__ Wq, int wave, int lane) {
-        const int h = i / NSW, c = i % NSW;
-        const char* b0 = reinterpret_cast<const char*>(Wq) + ((size_t)(h * (KH / 16) + wave + 4 * c) * MT2) * 2 * 1024;
+        const int h = i / NB, c = (i % NB) / MT2, mt = i % MT2;
+        const char* b0 = reinterpret_cast<const char*>(Wq) + ((size_t)(h * (KH / 16) + wave + 4 * c) * MT2 + mt) * 2 * 1024;
         const unsigned vo = (unsigned)lane * 16u;
 #pragma unroll
-        for (int mt = 0; mt < MT2; ++mt)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) x_wload_s(ra[i & 1][mt][pl], vo, b0 + mt * 2 * 1024, pl);
+        for (int pl = 0; pl < 2; ++pl) x_wload_s(ra[i & 1][pl], vo, b0, pl);
     }
-    template <int N> __device__ __forceinline__ void wait(f32x4 (&v)[MT2][2]) {
-        if constexpr (MT2 == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[1][0]), "+v"(v[1][1]) : "n"(N));
-        else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(v[0][0]), "+v"(v[0][1]) : "n"(N));
-    }
+    template <int N> __device__ __forceinline__ void wait(f32x4 (&v)[2]) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(v[0]), "+v"(v[1]) : "n"(N)); }
     template <int H>
     __device__ __forceinline__ void half(f32x16 (&y)[MT2], const float* X1s, const bf16x8* __restrict__ Wq, int wave, int lane) {
         const int an = lane & 31, kg = lane >> 5;
+        f16x8 bq[2];
 #pragma unroll
-        for (int c = 0; c < NSW; ++c) {
-            const int i = H * NSW + c;
-            asm volatile("" ::: "memory");                 // keeps the X1 reads (and their splits) of later steps from being hoisted
-            const float* xr = &X1s[an * S + (wave + 4 * c) * 16 + kg * 8];
-            f16x8 bq[2];
-            split2h_pack8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4), bq[0], bq[1]);
-            if (i + 1 < 2 * NSW) { issue(i + 1, Wq, wave, lane); wait<2 * MT2>(ra[i & 1]); }
+        for (int r = 0; r < NB; ++r) {
+            const int i = H * NB + r, c = r / MT2, mt = r % MT2;
+            if (mt == 0) {
+                asm volatile("" ::: "memory");             // keeps the X1 reads (and their splits) of later steps from being hoisted
+                const float* xr = &X1s[an * S + (wave + 4 * c) * 16 + kg * 8];
+                split2h_pack8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4), bq[0], bq[1]);
+            }
+            if (i + 1 < 2 * NB) { issue(i + 1, Wq, wave, lane); wait<2>(ra[i & 1]); }
             else wait<0>(ra[i & 1]);
-            f32x4 (&ac)[MT2][2] = ra[i & 1];
-#define H_TERM(PA, PB) _Pragma("unroll") for (int mt = 0; mt < MT2; ++mt) \
-    y[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ac[mt][PA]), bq[PB], y[mt], 0, 0, 0);
-            H_TERM(1, 0) H_TERM(0, 1) H_TERM(0, 0)
-#undef H_TERM
+            f32x4 (&ac)[2] = ra[i & 1];
+            // smallest cross products first: l * h, h * l, h * h
+            y[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ac[1]), bq[0], y[mt], 0, 0, 0);
+            y[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ac[0]), bq[1], y[mt], 0, 0, 0);
+            y[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ac[0]), bq[0], y[mt], 0, 0, 0);
         }
     }
 };
@@ -210,7 +208,7 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
     //   during step g   the MFMAs of step g (fragments and split weights prepared during step g - 1) are interleaved, slot by slot, with
     //                   * the ring's chunk g + 1 going to the staging tile, the loads of chunk g + 1 + D into the freed registers,
     //                   * the fragment reads of chunk g + 1 into the other fragment set,
-    //                   * the clamp / split of the weights of step g + 1 (their pre-activation MFMAs open the step).
+    //                   * the clamp / split of the weights of step g + 1 (their pre-activation MFMAs close step g - 1).
     //   Every slot ends with sched_barrier(0): the order below IS the schedule (left alone, the scheduler clusters the VALU work; asked with
     //   sched_group_barrier over a whole pass, its solver takes minutes).  No LDS-direct loads: with one staging tile per wave they bound a step
     //   from below by the memory round trip (profiles/r05_inter_conv_latency_bound.txt), and any LDS access behind one is drained by the compiler.
@@ -282,10 +280,20 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
             aw[pr / 4][1][pr % 4] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(S_.w[2 * pr] - (float)h[0], S_.w[2 * pr + 1] - (float)h[1]));
         }
     };
-    // X1 store addresses of this lane: kernel point kp, channel blocks (2 q + kg) ^ sw(kp), q < NKR / 4; kernel points 24 .. 31: the dump slot
-    int xoff[NKR / 4];
+    // X1 store addresses of this lane (LDS byte addresses): column 0 of the wave, kernel point kp, channel blocks (2 q + kg) ^ sw(kp), q < NKR / 4;
+    // the lanes of the kernel points 24 .. 31 store into the dump slot (no branch).  Column j adds j * xmul -- formed per anchor from an opaque
+    // copy: left to itself the compiler precomputes all NJ * NKR / 4 addresses, spills them, and every reload waits for the whole load ring.
+    typedef __attribute__((address_space(3))) f32x4* x_lds_f4;
+    unsigned xaddr[NKR / 4];
 #pragma unroll
-    for (int q = 0; q < NKR / 4; ++q) xoff[q] = kok ? kp * CH + 4 * (((2 * q + kg) ^ (CH == 16 ? (kp >> 1) & 3 : kp & 7))) : (int)(dump - X1s) + 4 * lane;
+    for (int q = 0; q < NKR / 4; ++q)
+        xaddr[q] = kok ? (unsigned)(uintptr_t)(X1s + wave * NJ * S + kp * CH + 4 * (((2 * q + kg) ^ (CH == 16 ? (kp >> 1) & 3 : kp & 7)))) : (unsigned)(uintptr_t)(dump + 4 * lane);
+    const unsigned xmul = kok ? (unsigned)(S * 4) : 0u;
+    auto x1_store = [&](int j, int q4, float a0, float a1, float a2, float a3) {
+        unsigned m = xmul;
+        asm volatile("" : "+v"(m));
+        *(x_lds_f4)(uintptr_t)(xaddr[q4] + (unsigned)j * m) = (f32x4){a0, a1, a2, a3};
+    };
 
     // prologue: the first D chunks requested, chunk 0 staged and read, the weights of step 0
     issue_kp(0, kpn[0]);
@@ -300,11 +308,13 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
     for (int k = 0; k < NL; ++k) load_piece(D, k, ring[0][k]);
 #pragma unroll
     for (int r = 0; r < NF; ++r) read_frag(r, bf[0]);
+    f32x16 P;                                       // pre-activations of the step AFTER the current one (formed at the end of the step before it)
     {
-        const f32x16 P = gen_pre(0, kpn[0]);
+        P = gen_pre(0, kpn[0]);
         Split S_;
 #pragma unroll
         for (int k = 0; k < NTICK; ++k) split_tick(k, P, S_, aws[0]);
+        P = gen_pre(1 % NCH, kpn[(1 / NCH) & 1]);
     }
 
     double st_s = 0.0, st_q = 0.0;
@@ -315,17 +325,14 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
         const int G0 = ag * NSTEP;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int col = wave * NJ + j;
             const int q = ag * NJ + j;
 #pragma unroll
             for (int t = 0; t < NCH; ++t) {
                 const int g = j * NCH + t, sp = g & 1;                 // local step and its parity (fragment set, weight set)
-                const int tn = t + 1 < NCH ? t + 1 : 0;
                 const int rs = (g + 1) % D;                             // ring entry of chunk g + 1
-                // the next step's pre-activations open the step (they need registers only)
-                const f32x16 P = gen_pre(tn, t + 1 < NCH ? kpn[j & 1] : kpn[(j + 1) & 1]);
-                // this anchor's kernel-point factor was last used just above: the anchor after next goes into its set
-                if (t == NCH - 1) issue_kp(q + 2, kpn[j & 1]);
+                // this anchor's kernel-point factor was last used a step ago (the pre-activations of its last chunk, formed two steps ahead of their
+                // use): the anchor after next goes into its set
+                if (t == 0) issue_kp(q + 2, kpn[j & 1]);
                 __builtin_amdgcn_sched_barrier(0);
                 Split S_;
                 constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};     // (weight plane, feature plane): l * h, h * l, h * h
@@ -356,12 +363,12 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
                     else if (i >= 1) { split_tick(2 * (i - 1), P, S_, aws[sp ^ 1]); if (2 * (i - 1) + 1 < NTICK) split_tick(2 * (i - 1) + 1, P, S_, aws[sp ^ 1]); }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                // the pre-activations of step g + 2 (P is free: the last tick above consumed those of step g + 1); they complete across the step boundary
+                P = gen_pre((t + 2) % NCH, kpn[(j + (t + 2) / NCH) & 1]);
                 if (t == NCH - 1) {
                     // anchor end.  D[c][k]: this lane = kernel point kp, channels 8 (v / 4) + 4 kg + v % 4 of each 32-channel tile: first half -> X1 tile, second half parked
-                    float* xcol = X1s + (kok ? col * S : 0);
 #pragma unroll
-                    for (int q4 = 0; q4 < NKR / 4; ++q4)
-                        *reinterpret_cast<float4*>(xcol + xoff[q4]) = make_float4(acc[0][4 * q4], acc[0][4 * q4 + 1], acc[0][4 * q4 + 2], acc[0][4 * q4 + 3]);
+                    for (int q4 = 0; q4 < NKR / 4; ++q4) x1_store(j, q4, acc[0][4 * q4], acc[0][4 * q4 + 1], acc[0][4 * q4 + 2], acc[0][4 * q4 + 3]);
 #pragma unroll
                     for (int v = 0; v < NKR; ++v) keep[j][v] = NT32 == 1 ? acc[0][NKR + v] : acc[NT32 - 1][v];
                 }
@@ -382,10 +389,8 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            float* xcol = X1s + (kok ? (wave * NJ + j) * S : 0);
 #pragma unroll
-            for (int q4 = 0; q4 < NKR / 4; ++q4)
-                *reinterpret_cast<float4*>(xcol + xoff[q4]) = make_float4(keep[j][4 * q4], keep[j][4 * q4 + 1], keep[j][4 * q4 + 2], keep[j][4 * q4 + 3]);
+            for (int q4 = 0; q4 < NKR / 4; ++q4) x1_store(j, q4, keep[j][4 * q4], keep[j][4 * q4 + 1], keep[j][4 * q4 + 2], keep[j][4 * q4 + 3]);
         }
         __syncthreads();
 #ifndef Y_ABL_NOSTEP2
