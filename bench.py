@@ -54,6 +54,8 @@ def build(device, seed=1, body="smpl"):
 
 
 # ------------------------------------------------------------------------------------------------ roofline
+SOURCE_OF_KERNEL = {"inter_so3conv_y_kernel": "so3conv_y.hip", "inter_so3conv_x_kernel": "so3conv_x.hip", "inter_so3conv_kernel": "so3conv.hip", "gemm_nt_kernel": "gemm.hip",
+                    "mhsa_layer_kernel": "mhsa_layer.hip", "mhsa_interp_layer_kernel": "mhsa_layer.hip", "linear_relu_dot_ws_kernel": "fused_dense.hip"}
 SPLIT_RATE_TFLOPS = 403.0     # fp32 products per second on the bf16 matrix cores as six-term splits: 2418 TFLOP/s measured for v_mfma_f32_32x32x16_bf16 / 6 (profiles/r04_mfma_bf16_issue_rates.txt)
 
 
@@ -75,6 +77,9 @@ def algorithmic_flops(name, a):
         b, cin, cout, p1, p2, nn = v[0:6]
         kern = f"inter_so3conv_x32_kernel<{cin},{cout},{nn // 32}>" if name.endswith("32") else f"inter_so3conv_x_kernel<{cin},{cout},{nn // 32}>"
         return 2.0 * b * p2 * 60 * 24 * (cin * nn + cout * cin), kern
+    if name == "etch_inter_so3conv_planes_kq":     # round 5: two fp16 planes per operand, weights' pre-activation on the matrix cores (csrc/so3conv_y.hip)
+        b, cin, cout, p1, p2, nn = v[0:6]
+        return 2.0 * b * p2 * 60 * 24 * (cin * nn + cout * cin), f"inter_so3conv_y_kernel<{cin},{cout},{nn // 32}>"
     if name == "etch_inter_so3conv32":
         b, cin, cout, p1, p2, nn = v[0:6]
         return 2.0 * b * p2 * 60 * 24 * (cin * nn + cout * cin), f"inter_so3conv32_kernel<{cin},{cout},{(nn + 7) // 8}>"
@@ -93,7 +98,26 @@ def algorithmic_flops(name, a):
     if name == "etch_mhsa_attention":
         T = v[0]
         return T * 8 * (2.0 * 60 * 60 * 8 * 2), "mhsa_attention_kernel"
-    return 0.0, name.replace("etch_", "") + "_kernel"
+    return 0.0, KERNEL_OF_ENTRY.get(name, name.replace("etch_", "") + "_kernel")
+
+
+# C-ABI entry -> the kernel it launches (entries without a flop model; `kernel_breakdown_ms` names kernels, not entry points)
+KERNEL_OF_ENTRY = {
+    "etch_smpl_lm_fit": "smpl_lm_fit_kernel", "etch_smpl_lm_fit_split": "smpl_lm_fit_kernel (one workgroup per scan above 8 scans)", "etch_smpl_lbs": "smpl_lbs_kernel",
+    "etch_furthest_point_sampling": "fps_kernel", "etch_furthestsampling": "fps_kernel", "etch_ball_query": "ball_query_kernel", "etch_knnquery": "knn_wave_kernel",
+    "etch_instnorm_act_add_planes": "instnorm_act_add_kernel", "etch_instnorm_act_add_planes_f16": "instnorm_act_add_kernel", "etch_instnorm_stats": "instnorm_partial_kernel + instnorm_final_kernel",
+    "etch_instnorm_from_partials": "instnorm_from_partials_kernel", "etch_get_markers": "get_markers_kernel", "etch_so3_mean_dir": "so3_mean_dir_kernel",
+    "etch_prop3nn": "prop3nn_kernel", "etch_prop_interp": "prop_interp_kernel", "etch_token_mean": "token_mean_kernel", "etch_spatial_order": "spatial_order_kernel",
+    "etch_pt_down_gather_max": "pt_down_gather_max_kernel", "etch_pt_interp_add": "pt_interp_add_kernel", "etch_gather_points_forward": "gather_points_kernel",
+}
+
+
+def blob_hash(path):
+    """git's blob hash of a file (sha1 over 'blob <size>\\0' + content): the profile summaries under profiles/ record it for the kernel sources
+    they were collected from, bench.py marks a quoted counter `stale` when the source has changed since."""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
 def profile_pass(run_step):
@@ -631,7 +655,7 @@ def main():
     # dominant kernel = the kernel FUNCTION with the largest share of the step (template instantiations of one kernel are
     # one kernel: the three inter_so3conv_kernel<CIN,COUT,MAXT> launches of a step are priced together)
     def family(k):      # the inter conv of a step is ONE kernel family: its 16x16x32 (32 input channels) and 32x32x16 (64 input channels) instantiations are priced together
-        return "inter_so3conv_x_kernel" if k.startswith("inter_so3conv_x32_kernel") else k.split("<")[0]
+        return "inter_so3conv_x_kernel" if k.startswith("inter_so3conv_x32_kernel") else k.split("<")[0].split(" (")[0]
     fam = collections.OrderedDict()
     for k, v in agg.items():
         f = fam.setdefault(family(k), dict(calls=0, ms=0.0, flops=0.0, members=[]))
@@ -646,14 +670,27 @@ def main():
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
     # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # runs of this same command, corrected as profiles/pmc_traffic.py documents); counters cannot be read inside this process
-    traffic = None
+    traffic, counter_files = None, {}
     import glob
+
+    def stamp(path):      # which committed file a counter comes from, and whether the kernel source has changed since it was collected
+        src = os.path.join(ROOT, "etch_amd", "csrc", SOURCE_OF_KERNEL.get(kern, ""))
+        rec = {"file": os.path.basename(path), "file_blob": blob_hash(path)[:12]}
+        side = path + ".sources.json"
+        if os.path.isfile(src):
+            rec["kernel_source"] = os.path.basename(src)
+            rec["kernel_source_blob"] = blob_hash(src)[:12]
+            then = json.load(open(side)).get(os.path.basename(src)) if os.path.exists(side) else None
+            rec["stale"] = then is None or then[:12] != rec["kernel_source_blob"]
+        return rec
+
     for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):     # newest round / pass first
         tab = json.load(open(pmc))
         ents = [v for k, v in tab.items() if family(k.replace(" ", "")) == kern]     # template variants of the kernel: launch-weighted mean
         if ents:
             n = sum(e["launches_profiled"] for e in ents)
             traffic = round(sum(e["bytes_per_launch"] * e["launches_profiled"] for e in ents) / n)
+            counter_files["traffic"] = stamp(pmc)
             break
     # algorithmic HBM bytes per launch of the dominant kernel (unique input + output): the gathered rows once (three bf16 planes = 6 bytes per
     # element for the planes kernels, 4 otherwise), the output once; and the matrix-pipe busy share of its instantiations from the newest committed counter pass
@@ -665,7 +702,7 @@ def main():
                 v_ = [x.value if hasattr(x, "value") else x for x in args_]
                 b_, cin_, cout_, p1_, p2_, nn_ = v_[0:6]
                 if cin_ > 1:
-                    tot_b += b_ * p1_ * 60.0 * cin_ * (6 if "planes" in name_ else 4) + b_ * p2_ * 60.0 * cout_ * 4 + b_ * p2_ * nn_ * 4.0
+                    tot_b += b_ * p1_ * 60.0 * cin_ * (4 if name_.endswith("planes_kq") else 6 if "planes" in name_ else 4) + b_ * p2_ * 60.0 * cout_ * 4 + b_ * p2_ * nn_ * 4.0
                     n_b += 1
         alg_bytes = round(tot_b / n_b) if n_b else None
     pipe_busy = None
@@ -678,19 +715,25 @@ def main():
                     got[nm] = float(ln.split("matrix pipe busy")[1].split()[0])
         if got:
             pipe_busy = {"source": os.path.basename(f_), "per_instantiation": got}
+            counter_files["matrix_pipe_busy"] = stamp(f_)
             break
+    y_kernel = kern == "inter_so3conv_y_kernel"
+    split_rate = SPLIT_RATE_TFLOPS * (2.0 if y_kernel else 1.0)        # three cross terms instead of six on the same 32x32x16 issue rate
     out["roofline"] = {"bound": "mfma", "kernel": kern, "instantiations": d["members"], "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                        "traffic_over_algorithmic": round(traffic / alg_bytes, 2) if traffic and alg_bytes else None,
-                       "matrix_pipe_busy": pipe_busy,
+                       "matrix_pipe_busy": pipe_busy, "counter_files": counter_files,
                        "launches_per_step": d["calls"], "avg_launch_ms": round(d["ms"] / d["calls"], 4),
                        "algorithmic_gflop_per_launch": round(d["flops"] / d["calls"] / 1e9, 3),
                        "share_of_step": round(d["ms"] / tot_ms, 3),
-                       "arithmetic": "fp32 throughout, priced against the fp32 matrix peak (157.3: `frac` can exceed what the fp32 MFMA could ever reach); both contractions of the "
-                                     "inter conv, the intra conv, q/k/v + head_combine, linear_relu_dot and the small-weight Linear layers run as exact 3 x bf16 operand splits with six "
-                                     "fp32-accumulated cross products on the bf16 matrix cores -- the fp32 MFMA's error against fp64 (profiles/r03_bf16x3_split.txt); the pipe the kernel "
-                                     "actually runs on is priced in `frac_of_split_rate` (measured v_mfma_f32_32x32x16_bf16 issue rate / 6 terms, profiles/r04_mfma_bf16_issue_rates.txt)",
-                       "split_rate_tflops": SPLIT_RATE_TFLOPS, "frac_of_split_rate": round(achieved / SPLIT_RATE_TFLOPS, 4)}
+                       "arithmetic": "fp32 results throughout, priced against the fp32 matrix peak (157.3: `frac` can exceed what the fp32 MFMA could ever reach).  "
+                                     + ("The inter conv (round 5, csrc/so3conv_y.hip) runs both contractions on v_mfma_f32_32x32x16_f16 with TWO fp16 planes per operand (h = fp16(x) by "
+                                        "truncation, l = fp16(x - h); three cross products; the fp32 MFMA's error against fp64 for this path's O(1) operands, profiles/r05_f16_two_plane_split.txt) "
+                                        "and forms the kernel weights' pre-activation on v_mfma_f32_32x32x16_bf16 from exactly split factors; " if y_kernel else "")
+                                     + "the intra conv, q/k/v + head_combine, linear_relu_dot and the small-weight Linear layers run as exact 3 x bf16 operand splits with six "
+                                     "fp32-accumulated cross products on the bf16 matrix cores (profiles/r03_bf16x3_split.txt); the pipe the dominant kernel actually runs on is priced in "
+                                     "`frac_of_split_rate` (measured 32x32x16 issue rate, profiles/r04_mfma_bf16_issue_rates.txt, / cross terms per product: 3 for the two-plane fp16 split, 6 for the bf16 split)",
+                       "split_rate_tflops": split_rate, "frac_of_split_rate": round(achieved / split_rate, 4)}
     if longest != kern:
         out["roofline"]["longest_kernel"] = {"kernel": longest, "ms": round(fam[longest]["ms"], 3), "note": "one workgroup per scan: latency-bound"}
     out["kernel_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]}

@@ -52,6 +52,18 @@ rm -rf $O/pmc_busy
 # the bench lines read the newest profiles/r*_pmc_traffic.json for `roofline.traffic`: put THIS round's pass there first, so that every
 # committed line of the round quotes the same counter file
 cp $O/${tag}_pmc_traffic.json $R/profiles/${tag}_pmc_traffic.json
+# sidecars: git blob hashes of the kernel sources these counters were collected from (bench.py marks a quoted counter `stale` when its kernel's source changed since)
+python3 - $R $O/${tag}_pmc_traffic.json.sources.json $O/${tag}_pmc_mfma.txt.sources.json <<'PY'
+import glob, hashlib, json, os, sys
+root, outs = sys.argv[1], sys.argv[2:]
+h = {}
+for f in sorted(glob.glob(os.path.join(root, "etch_amd", "csrc", "*"))):
+    d = open(f, "rb").read()
+    h[os.path.basename(f)] = hashlib.sha1(b"blob %d\0" % len(d) + d).hexdigest()
+for o in outs:
+    json.dump(h, open(o, "w"), indent=1, sort_keys=True)
+PY
+cp $O/${tag}_pmc_traffic.json.sources.json $R/profiles/
 # the bench lines themselves (default run with the CPU baseline; forward only; the dense SMPL-X-sized config; two ranks on this one GPU)
 python3 $R/bench.py > $O/${tag}_bench_line_default_run.json 2> $O/bench_default.err
 python3 $R/bench.py --config 1 --steps 10 > $O/${tag}_bench_line_config1_forward_only.json 2> $O/bench_c1.err
