@@ -130,8 +130,7 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
     float* part = smem;                            // [4 waves][32 cols][PS], aliases X1s between the last product of a pass and the next pass
     unsigned* geo = reinterpret_cast<unsigned*>(smem + AG * S);        // [NN][16 dwords]: the neighbour factor, 32 bf16 slots per neighbour
     unsigned* noffs = geo + NN * 16;                                    // [NN] byte offset of the neighbour's anchor-0 row
-    float* dump = reinterpret_cast<float*>(geo);                        // [64 lanes][4]: where the lanes of the unused kernel points 24 .. 31 store (aliases the
-                                                                        // neighbour factor, which lives in registers once the second barrier below is passed)
+    float* dump = reinterpret_cast<float*>(noffs + NN);                 // [64 lanes][4]: where the lanes of the unused kernel points 24 .. 31 store
     __shared__ __attribute__((aligned(16))) char stage[4 * STG];       // [4 waves][STG]: its own LDS object (see inter_so3conv_x_kernel)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
@@ -142,40 +141,16 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
         if (slot >= p2) return;
         p = order[(size_t)b * p2 + slot];
     }
+    // setup, part 1: the neighbour list -> row offsets.  The first gathers of the point need nothing else: they are requested below, BEFORE the
+    // coordinates are fetched and the neighbour factor is built (the point's two dependent memory round trips overlap instead of adding up)
+    int q_nb = 0;
     if (tid < NN) {
-        const int n = tid;
-        int q = ball_idx[((size_t)b * p2 + p) * NN + n];
-        const int qq = q < 0 ? 0 : q;
-        const float* X = xyz + (size_t)b * 3 * p1;
-        const float x = X[qq] - new_xyz[((size_t)b * 3 + 0) * p2 + p], y = X[p1 + qq] - new_xyz[((size_t)b * 3 + 1) * p2 + p],
-                    z = X[2 * p1 + qq] - new_xyz[((size_t)b * 3 + 2) * p2 + p];
-        // slot s = 5 t + c: plane y_geo_plane(t) of component c of [a_n, 1, G_x, G_y, G_z]
-        const Y3 s0 = y_split3(q < 0 ? -1e30f : 1.0f - (x * x + y * y + z * z) * inv_sigma), s1 = {0x3f80u, 0u, 0u},
-                 s2 = y_split3(2.0f * inv_sigma * x), s3 = y_split3(2.0f * inv_sigma * y), s4 = y_split3(2.0f * inv_sigma * z);
-#define Y_SLOT(s) ((s) >= 30 ? 0u : y_pick((s) % 5 == 0 ? s0 : (s) % 5 == 1 ? s1 : (s) % 5 == 2 ? s2 : (s) % 5 == 3 ? s3 : s4, y_geo_plane((s) / 5)))
-#define Y_DW(d) (Y_SLOT(2 * (d)) | (Y_SLOT(2 * (d) + 1) << 16))
-        const unsigned dw[16] = {Y_DW(0), Y_DW(1), Y_DW(2), Y_DW(3), Y_DW(4), Y_DW(5), Y_DW(6), Y_DW(7), Y_DW(8), Y_DW(9), Y_DW(10), Y_DW(11), Y_DW(12), Y_DW(13), Y_DW(14), Y_DW(15)};
-#undef Y_DW
-#undef Y_SLOT
-        y_u32x4* gr = reinterpret_cast<y_u32x4*>(geo + n * 16);
-#pragma unroll
-        for (int d4 = 0; d4 < 4; ++d4) gr[d4] = (y_u32x4){dw[4 * d4], dw[4 * d4 + 1], dw[4 * d4 + 2], dw[4 * d4 + 3]};
-        noffs[n] = (unsigned)qq * (unsigned)(NA * ROWB);
+        q_nb = ball_idx[((size_t)b * p2 + p) * NN + tid];
+        noffs[tid] = (unsigned)(q_nb < 0 ? 0 : q_nb) * (unsigned)(NA * ROWB);
     }
     __syncthreads();
     const int kp = lane & 31, kg = lane >> 5;      // this lane's kernel point (weights: column of B; X1: column of D) and neighbour group / channel sub-block
     const bool kok = kp < KS;
-    // the neighbour factor of this lane: row m = lane % 32 of the pre-activation product = the neighbour in staging row swap23(m)
-    bf16x8 geo_r[NCH][2];
-    {
-        const int m = kp;
-        const int nloc = (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1);
-#pragma unroll
-        for (int t = 0; t < NCH; ++t)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                geo_r[t][j] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(geo) + (32 * t + nloc) * 64 + 32 * j + 16 * kg);
-    }
     // staging image of one plane of a chunk (see inter_so3conv_x32_kernel): load side -- lane = (row rl of the row block, 16-byte piece sl)
     const int rl = lane / PPR, sl = lane % PPR;
     const unsigned pieceoff = NT32 == 1 ? (unsigned)(sl * 16) : (unsigned)((4 * (((sl >> 2) - (rl >> 1)) & 1) + (sl & 3)) * 16);
@@ -188,7 +163,6 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
 #else
         for (int rb = 0; rb < NRB; ++rb) roff[t][rb] = noffs[32 * t + RPI * rb + rl] + pieceoff;
 #endif
-    __syncthreads();                               // every wave holds its part of the tables in registers: the table region may be reused (dump slot)
     const char* Fb = reinterpret_cast<const char*>(Fq) + (size_t)b * p1 * NA * ROWB;
     char* stg = stage + wave * STG;
     char* stg_w = stg + lane * 16;                 // write side: the lane's 16-byte piece of every 1-KiB row block
@@ -220,6 +194,7 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
     constexpr int NW = NL / 2;                     // slots that stage two pieces each
     static_assert(NW + NL <= NMF && NW + NF <= NMF, "slot plan");
     f32x4 ring[D][NL];
+    bf16x8 geo_r[NCH][2];                           // the neighbour factor of this lane (filled in setup part 2)
     f16x8 bf[2][NT32][2][2] = {};                   // [step parity][channel tile][K step][plane]
     y_u32x4 aws[2][2][2] = {};                      // [step parity][K step of the chunk][plane]
     bf16x8 kpn[2][2] = {};                          // kernel-point factor of this wave's current / next anchor: [anchor parity][K step]
@@ -259,10 +234,13 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(geo_r[t][1], kpa[1], P, 0, 0, 0);
 #endif
     };
-    // clamp to [0, 1] (the weight's mathematical range) + two-plane fp16 split of the pair k = (P[2 k], P[2 k + 1]), cut into time steps:
-    // A(k): clamp, h = fp16 pair (truncation); B(k - 1): l = fp16 pair of the residuals.  K step h2 = k / 4 of step 1, dword d = k % 4 of its fragment.
-    struct Split { float w[16]; unsigned h[8]; };
-    constexpr int NTICK = 9;
+    // clamp to [0, 1] (the weight's mathematical range) + two-plane fp16 split of the pair k = (P[2 k], P[2 k + 1]) as a software pipeline over the
+    // pairs: tick tau runs stage 1 of pair tau (clamp), stage 2 of pair tau - 1 (h = fp16 pair, truncation), stage 3 of pair tau - 2 (l = w - h:
+    // v_fma_mix_f32 reads the fp16 half directly), stage 4 of pair tau - 3 (l as fp16 pair) -- inside a tick nothing depends on anything (a VALU
+    // instruction that reads its predecessor's result issues ~4 cycles late, profiles/r05_valu_rates_f16.txt).  K step h2 = k / 4 of step 1,
+    // dword d = k % 4 of its fragment.
+    struct Split { float w[16]; unsigned h[8]; float l[16]; };
+    constexpr int NTICK = 11;
     auto split_tick = [&](int k, const f32x16& P, Split& S_, y_u32x4 (&aw)[2][2]) {
 #ifdef Y_ABL_NOSPLIT
         if (k == 0) asm volatile("" :: "v"(P));
@@ -271,13 +249,26 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
         if (k < 8) {
             S_.w[2 * k] = __builtin_amdgcn_fmed3f(P[2 * k], 0.0f, 1.0f);
             S_.w[2 * k + 1] = __builtin_amdgcn_fmed3f(P[2 * k + 1], 0.0f, 1.0f);
-            S_.h[k] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(S_.w[2 * k], S_.w[2 * k + 1]));
-            aw[k / 4][0][k % 4] = S_.h[k];
         }
-        if (k >= 1) {
+        if (k >= 1 && k < 9) {
             const int pr = k - 1;
-            const f16x2 h = __builtin_bit_cast(f16x2, S_.h[pr]);      // (read back as an element of aw[..][0], the compiler took dword 0 for every pair of a K step)
-            aw[pr / 4][1][pr % 4] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(S_.w[2 * pr] - (float)h[0], S_.w[2 * pr + 1] - (float)h[1]));
+            S_.h[pr] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(S_.w[2 * pr], S_.w[2 * pr + 1]));
+            aw[pr / 4][0][pr % 4] = S_.h[pr];
+        }
+        if (k >= 2 && k < 10) {
+            const int pr = k - 2;
+#ifdef Y_NO_FMA_MIX
+            const f16x2 h = __builtin_bit_cast(f16x2, S_.h[pr]);
+            S_.l[2 * pr] = S_.w[2 * pr] - (float)h[0]; S_.l[2 * pr + 1] = S_.w[2 * pr + 1] - (float)h[1];
+#else
+            // l = fp16-half * (-1) + w in one instruction (exact: w - h has at most 13 significant bits)
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(S_.l[2 * pr]) : "v"(S_.h[pr]), "v"(S_.w[2 * pr]));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(S_.l[2 * pr + 1]) : "v"(S_.h[pr]), "v"(S_.w[2 * pr + 1]));
+#endif
+        }
+        if (k >= 3) {
+            const int pr = k - 3;
+            aw[pr / 4][1][pr % 4] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(S_.l[2 * pr], S_.l[2 * pr + 1]));
         }
     };
     // X1 store addresses of this lane (LDS byte addresses): column 0 of the wave, kernel point kp, channel blocks (2 q + kg) ^ sw(kp), q < NKR / 4;
@@ -302,6 +293,36 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
     for (int d = 0; d < D; ++d)
 #pragma unroll
         for (int k = 0; k < NL; ++k) load_piece(d, k, ring[d][k]);
+    // setup, part 2 (the gathers above are in flight): neighbour coordinates -> the neighbour factor of the weights' pre-activation
+    if (tid < NN) {
+        const int n = tid, q = q_nb;
+        const int qq = q < 0 ? 0 : q;
+        const float* X = xyz + (size_t)b * 3 * p1;
+        const float x = X[qq] - new_xyz[((size_t)b * 3 + 0) * p2 + p], y = X[p1 + qq] - new_xyz[((size_t)b * 3 + 1) * p2 + p],
+                    z = X[2 * p1 + qq] - new_xyz[((size_t)b * 3 + 2) * p2 + p];
+        // slot s = 5 t + c: plane y_geo_plane(t) of component c of [a_n, 1, G_x, G_y, G_z]
+        const Y3 s0 = y_split3(q < 0 ? -1e30f : 1.0f - (x * x + y * y + z * z) * inv_sigma), s1 = {0x3f80u, 0u, 0u},
+                 s2 = y_split3(2.0f * inv_sigma * x), s3 = y_split3(2.0f * inv_sigma * y), s4 = y_split3(2.0f * inv_sigma * z);
+#define Y_SLOT(s) ((s) >= 30 ? 0u : y_pick((s) % 5 == 0 ? s0 : (s) % 5 == 1 ? s1 : (s) % 5 == 2 ? s2 : (s) % 5 == 3 ? s3 : s4, y_geo_plane((s) / 5)))
+#define Y_DW(d) (Y_SLOT(2 * (d)) | (Y_SLOT(2 * (d) + 1) << 16))
+        const unsigned dw[16] = {Y_DW(0), Y_DW(1), Y_DW(2), Y_DW(3), Y_DW(4), Y_DW(5), Y_DW(6), Y_DW(7), Y_DW(8), Y_DW(9), Y_DW(10), Y_DW(11), Y_DW(12), Y_DW(13), Y_DW(14), Y_DW(15)};
+#undef Y_DW
+#undef Y_SLOT
+        y_u32x4* gr = reinterpret_cast<y_u32x4*>(geo + n * 16);
+#pragma unroll
+        for (int d4 = 0; d4 < 4; ++d4) gr[d4] = (y_u32x4){dw[4 * d4], dw[4 * d4 + 1], dw[4 * d4 + 2], dw[4 * d4 + 3]};
+    }
+    __syncthreads();
+    // the neighbour factor of this lane: row m = lane % 32 of the pre-activation product = the neighbour in staging row swap23(m)
+    {
+        const int m = kp;
+        const int nloc = (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1);
+#pragma unroll
+        for (int t = 0; t < NCH; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                geo_r[t][j] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(geo) + (32 * t + nloc) * 64 + 32 * j + 16 * kg);
+    }
 #pragma unroll
     for (int k = 0; k < NL; ++k) stage_piece(k, ring[0][k]);
 #pragma unroll
@@ -359,8 +380,8 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
                     if (i >= NW && i < NW + NF) read_frag(i - NW, bf[sp ^ 1]);
 #endif
                     // the next step's weights
-                    if (NT32 == 2) { if (i >= 2 && i < 2 + NTICK) split_tick(i - 2, P, S_, aws[sp ^ 1]); }
-                    else if (i >= 1) { split_tick(2 * (i - 1), P, S_, aws[sp ^ 1]); if (2 * (i - 1) + 1 < NTICK) split_tick(2 * (i - 1) + 1, P, S_, aws[sp ^ 1]); }
+                    if (NT32 == 2) { if (i >= 1 && i < 1 + NTICK) split_tick(i - 1, P, S_, aws[sp ^ 1]); }
+                    else { split_tick(2 * i, P, S_, aws[sp ^ 1]); if (2 * i + 1 < NTICK) split_tick(2 * i + 1, P, S_, aws[sp ^ 1]); }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // the pre-activations of step g + 2 (P is free: the last tick above consumed those of step g + 1); they complete across the step boundary
@@ -440,7 +461,7 @@ template <int CIN, int COUT, int NCH>
 static int launch_y(int b, int p1, int p2, float sigma, const float* xyz, const float* new_xyz, const int* idx, const void* Fq, const void* kq,
                     const void* Wq, const float* bias, float* out, const int* order, double* stat_part, hipStream_t st) {
     constexpr int NN = 32 * NCH;
-    const size_t lds = (size_t)(32 * ((CIN / 2) * KS + Y_PAD(CIN)) + 17 * NN) * sizeof(float);
+    const size_t lds = (size_t)(32 * ((CIN / 2) * KS + Y_PAD(CIN)) + 17 * NN + 256) * sizeof(float);
     auto kern = inter_so3conv_y_kernel<CIN, COUT, NCH, INTER_Y_DEPTH(CIN)>;
     {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
