@@ -194,9 +194,12 @@ def compile_to_asm(src, defines=(), extra=()):
 
 
 def main(argv):
+    """python -m etch_amd.isa_lint FILE.hip|FILE.s [-Dflags] [--all]
+    default: only loads issued from inline asm (the ones whose waits are hand-written); --all also lists compiler-issued loads, for which the
+    linear walk through forward branches over-reports (the compiler's own waits sit on paths the walk does not follow)."""
     src = argv[0]
-    text = open(src).read() if src.endswith(".s") else compile_to_asm(os.path.abspath(src), [a for a in argv[1:] if a.startswith("-")])
-    f = lint_asm(text)
+    text = open(src).read() if src.endswith(".s") else compile_to_asm(os.path.abspath(src), [a for a in argv[1:] if a.startswith("-D")])
+    f = lint_asm(text, only_asm_loads="--all" not in argv)
     by_kernel = {}
     for x in f:
         by_kernel.setdefault(x["kernel"], []).append(x)
