@@ -79,31 +79,62 @@ __device__ __forceinline__ float etch_wave_max_f32(float v) {
     return v;
 }
 
-// ---- work counters of the persistent kernels (mhsa layers, intra conv).  Under the 2-deep pipeline other streams' kernels share the compute units
-// unevenly; a static round-robin over persistent workgroups then makes a launch wait for the workgroups that were slowed down.  The kernels take
-// their first items statically and every further one from a device counter.  A counter = one slot (64 words: one per XCD where a kernel keeps
-// per-XCD lists, one per column block of the fused dense head) of a ring in device memory, allocated on first use outside a graph capture and re-zeroed on the launch's stream in front of the
-// kernel by a one-wave kernel -- not by hipMemsetAsync: a memset goes through the runtime's blit / copy path, which under the multi-stream pipeline
-// occasionally stalled a step (one bench run in eleven at 605 instead of 720 scans/s; none in 14 with the kernel).  No counter (allocation not
-// possible, ETCH_DYNAMIC_WORK=0 / ETCH_MHSA_DYNAMIC=0) = the static round-robin.  One ring per translation unit.
+// ---- work counters of the persistent kernels (mhsa layers, intra conv, fused dense head).  Under the multi-stream pipeline other streams' kernels share
+// the compute units unevenly; a static round-robin over persistent workgroups then makes a launch wait for the workgroups that were slowed down.  The
+// kernels take their first items statically and every further one from a device counter.  A counter = one slot (64 words: one per XCD where a kernel keeps
+// per-XCD lists, one per column block of the fused dense head), re-zeroed on the launch's stream in front of the kernel by a one-wave kernel -- not by
+// hipMemsetAsync: a memset goes through the runtime's blit / copy path, which under the multi-stream pipeline occasionally stalled a step.
+//   * one pool PER DEVICE (keyed by hipGetDevice at the launch: a process that drives several GPUs never hands a kernel another device's memory),
+//     created under a mutex, slot numbers from atomics (ctypes releases the GIL: two host threads may launch at once);
+//   * eager launches rotate through a ring of RING slots: two launches share a slot only if RING counter-using launches of this translation unit are
+//     enqueued while the first is still running (a pipeline step holds ~90 in flight);
+//   * launches recorded into a HIP graph take their slot from a second region that is never reused (a replayed graph re-zeroes and uses the slot it
+//     was captured with, whenever it runs -- it must not be one that eager launches rotate through); when that region is used up, or the pool
+//     cannot be created while a capture is in progress, the launch gets no counter = the static round-robin (same results, no dynamic distribution).
+// No counter at all with ETCH_DYNAMIC_WORK=0 / ETCH_MHSA_DYNAMIC=0.  One pool set per translation unit.
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 static __global__ void etch_zero_counters_kernel(unsigned* slot) {
     slot[threadIdx.x] = 0u;
 }
 static inline unsigned* etch_work_counter_slot(hipStream_t st) {
-    static unsigned* ring = nullptr;
-    static int state = 0, next = 0;            // state: 0 untried, 1 ready, -1 unavailable
-    constexpr int SLOTS = 512;
-    if (state == 0) {
+    constexpr int RING = 2048, GRAPH = 2048, MAXDEV = 32;
+    struct Pool { unsigned* mem = nullptr; std::atomic<int> state{0}; std::atomic<unsigned> next{0}; std::atomic<unsigned> next_graph{0}; };      // state: 0 untried, 1 ready, -1 unavailable
+    static Pool pools[MAXDEV];
+    static std::mutex mu;
+    static std::atomic<int> disabled{0};                 // 0 unknown, 1 off (environment), 2 on
+    if (disabled.load(std::memory_order_acquire) == 0) {
         const char* e1 = getenv("ETCH_DYNAMIC_WORK");
         const char* e2 = getenv("ETCH_MHSA_DYNAMIC");
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if ((e1 && e1[0] == '0') || (e2 && e2[0] == '0')) state = -1;
-        else if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;      // try again on a later call
-        else state = hipMalloc((void**)&ring, SLOTS * 64 * sizeof(unsigned)) == hipSuccess ? 1 : -1;
+        disabled.store(((e1 && e1[0] == '0') || (e2 && e2[0] == '0')) ? 1 : 2, std::memory_order_release);
     }
-    if (state != 1) return nullptr;
-    unsigned* slot = ring + (size_t)(next++ % SLOTS) * 64;
+    if (disabled.load(std::memory_order_acquire) == 1) return nullptr;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+    Pool& P = pools[dev];
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+    if (P.state.load(std::memory_order_acquire) == 0) {
+        if (capturing) return nullptr;                   // no allocation inside a capture: this launch runs static, a later one creates the pool
+        std::lock_guard<std::mutex> lock(mu);
+        if (P.state.load(std::memory_order_relaxed) == 0) {
+            unsigned* m = nullptr;
+            const bool ok = hipMalloc((void**)&m, (size_t)(RING + GRAPH) * 64 * sizeof(unsigned)) == hipSuccess;
+            P.mem = ok ? m : nullptr;
+            P.state.store(ok ? 1 : -1, std::memory_order_release);
+        }
+    }
+    if (P.state.load(std::memory_order_acquire) != 1) return nullptr;
+    unsigned idx;
+    if (capturing) {
+        idx = P.next_graph.fetch_add(1u, std::memory_order_relaxed);
+        if (idx >= (unsigned)GRAPH) return nullptr;
+        idx += RING;
+    } else {
+        idx = P.next.fetch_add(1u, std::memory_order_relaxed) % (unsigned)RING;
+    }
+    unsigned* slot = P.mem + (size_t)idx * 64;
     hipLaunchKernelGGL(etch_zero_counters_kernel, dim3(1), dim3(64), 0, st, slot);
     if (hipGetLastError() != hipSuccess) return nullptr;
     return slot;

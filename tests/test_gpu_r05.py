@@ -149,3 +149,38 @@ def test_inter_conv_kq_soak_under_contention(cin, cout, nn, p2):
         bad += int(not torch.equal(out, first))
     torch.cuda.synchronize()
     assert bad == 0, f"{bad} of {reps} launches differ from the first"
+
+
+def test_work_counters_graph_replay_next_to_eager_launches():
+    """a launch recorded into a HIP graph keeps the work-counter slot it was captured with; eager launches must never rotate onto it (two
+    concurrent kernels on one counter skip work items silently: rows of the output are never written).  A graphed attention layer is replayed on one
+    stream while > 2 x the eager ring's worth of launches of the same kernel run on another: every result equals the reference bit for bit."""
+    from etch_amd import ops
+    g = torch.Generator().manual_seed(3)
+    T = 6000
+    x = torch.randn(T * 60, 64, generator=g).cuda()
+    wq, wk, wv = (torch.randn(64, 64, generator=g).cuda() * 0.1 for _ in range(3))
+    ref = ops.mhsa_layer(x, wq, wk, wv, mode=2)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s1):
+        ops.mhsa_layer(x, wq, wk, wv, mode=2)                       # warm-up on the capture stream (the pool exists before the capture starts)
+        s1.synchronize()
+        with torch.cuda.graph(graph, stream=s1):
+            out_g = ops.mhsa_layer(x, wq, wk, wv, mode=2)
+    bad_e = bad_g = 0
+    for i in range(4500):
+        if i % 6 == 0:
+            if i:
+                s1.synchronize()
+                bad_g += int(not torch.equal(out_g, ref))
+            with torch.cuda.stream(s1):
+                graph.replay()
+        with torch.cuda.stream(s2):
+            out_e = ops.mhsa_layer(x, wq, wk, wv, mode=2)
+        if i % 50 == 0:
+            s2.synchronize()
+            bad_e += int(not torch.equal(out_e, ref))
+    torch.cuda.synchronize()
+    assert bad_e == 0 and bad_g == 0 and torch.equal(out_g, ref), (bad_e, bad_g)
