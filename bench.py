@@ -319,6 +319,87 @@ def cpu_baseline(n_points, gpu_pts, gpu_results, gpu_fit_aux, args, seed=1, thre
 
 
 # ------------------------------------------------------------------------------------------------ launcher
+def train_bench(a):
+    """`bench.py --train`: what train.py:77-124 times per iteration -- forward of GT_network_equiv in train() mode (the differentiable path: hand-written
+    backward kernels behind torch.autograd, train-mode BatchNorm), the four losses of train.py:81-101, backward, one torch.optim.Adam step (lr 1e-4,
+    train.py:219) -- on synthetic scans at train.py's batch shape (batch_size x num_point, defaults 1 x 5000; --batch / --points override), next to the
+    oracle's CPU autograd step (oracle/train_step.py, ONE step, bounded).  SURVEY 8 f-3.  Prints one JSON line (not the driver's metric)."""
+    import types
+    from etch_amd import constants as K
+    from etch_amd.models.models_pointcloud import GT_network_equiv
+    from etch_amd.utils.weights import load_seeded, seeded_state_dict
+    device = torch.device("cuda:0")
+    B, N, depth = a.batch or 1, a.points or 5000, a.train_depth
+    args = types.SimpleNamespace(output_folder="/tmp/etch_bench_train", EPN_input_radius=0.4, EPN_layer_num=depth, device=device, markerset=K.default_markerset(),
+                                 scale_magnitude=10)
+    model = load_seeded(GT_network_equiv(option=args), 1).to(device).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    rng = np.random.default_rng(11)
+    pts_np = np.stack([synth_scan(b, N) for b in range(B)])
+    vec_np = (rng.standard_normal((B, N, 3)) * 0.05).astype(np.float32)
+    conf_np = rng.uniform(0.0, 1.0, (B, N, 1)).astype(np.float32)
+    lab_np = rng.integers(0, len(args.markerset), (B, N))
+    pts, vec, conf, labels = (torch.from_numpy(x).to(device) for x in (pts_np, vec_np, conf_np, lab_np))
+    items = ["confidence", "direction", "magnitude"]
+
+    def step():
+        res, _ = model(pts, items, "standard_vector")
+        cos = 1 - torch.nn.functional.cosine_similarity(vec, res["direction"], dim=-1)
+        loss = (cos.mean() + torch.nn.functional.mse_loss(torch.norm(vec, dim=-1, keepdim=True) * 10, res["magnitude"])
+                + torch.nn.functional.mse_loss(res["confidences"], conf)
+                + torch.nn.functional.cross_entropy(res["part_labels"].permute(0, 2, 1).contiguous(), labels))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(a.warmup):
+            step()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats(device)
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # the same step with the phases bracketed (one extra, untimed in `value`)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+        res, _ = model(pts, items, "standard_vector")
+        l2 = ((1 - torch.nn.functional.cosine_similarity(vec, res["direction"], dim=-1)).mean() + torch.nn.functional.mse_loss(torch.norm(vec, dim=-1, keepdim=True) * 10, res["magnitude"])
+              + torch.nn.functional.mse_loss(res["confidences"], conf) + torch.nn.functional.cross_entropy(res["part_labels"].permute(0, 2, 1).contiguous(), labels))
+        ev[1].record()
+        opt.zero_grad()
+        l2.backward()
+        ev[2].record()
+        opt.step()
+        ev[3].record()
+        torch.cuda.synchronize()
+    ms = dt / a.steps * 1e3
+    out = {"metric": "training steps/s (train.py:77-124: forward in train() mode + 4 losses + backward + Adam)", "value": round(a.steps / dt, 3), "unit": "steps/s",
+           "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"train.py batch shape: batch_size {B} x num_point {N}, EPN_layer_num {depth}, seeded random weights, Adam lr 1e-4, all four losses",
+                      "path": "etch_amd.autograd / autograd_pt (un-fused differentiable kernels, train-mode BatchNorm on batch statistics)"},
+           "scans_per_s": round(B * a.steps / dt, 3), "final_loss": round(float(loss.detach()), 6),
+           "phase_ms": {"forward + losses": round(ev[0].elapsed_time(ev[1]), 2), "backward": round(ev[1].elapsed_time(ev[2]), 2), "adam": round(ev[2].elapsed_time(ev[3]), 2)},
+           "peak_hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2), "vs_baseline": None}
+    if not a.no_cpu_baseline:
+        from oracle import train_step as OT
+        threads = a.cpu_threads or min(32, os.cpu_count() or 1)
+        torch.set_num_threads(threads)
+        sd = {k: v.cpu() for k, v in seeded_state_dict(model, 1).items()}
+        names = [k for k, _ in model.named_parameters()]
+        nb = 1                                               # bounded sample: ONE scan of the batch, one step
+        parts, tf, tb, ta = OT.train_step(sd, names, torch.from_numpy(pts_np[:nb]), torch.from_numpy(vec_np[:nb]), torch.from_numpy(conf_np[:nb]),
+                                          torch.from_numpy(lab_np[:nb]), depth=depth)
+        out["cpu_baseline"] = {"value": round(1.0 / (tf + tb + ta), 4), "unit": "steps/s", "cores": threads, "kind": "port",
+                               "sample": f"1 step of 1 x {N} points: oracle forward {tf:.1f} s + torch.autograd backward {tb:.1f} s + Adam {ta:.2f} s, torch CPU fp32"}
+    print(json.dumps(out), flush=True)
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -421,6 +502,9 @@ def main():
     ap.add_argument("--unfused-interp", action="store_true", help="A/B: separate 3-NN interpolation kernel in front of the direction head")
     ap.add_argument("--stage1-streams", type=int, default=1, help="stage-1 streams the pipeline alternates over (batches in flight = this + 2; ETCH_MAX_IN_FLIGHT overrides)")
     ap.add_argument("--concurrent-heads", type=int, default=1, help="1: confidence / magnitude nets on their own streams next to the direction head")
+    ap.add_argument("--train", action="store_true", help="time one training step (forward in train() mode + the four losses + backward + Adam, train.py:77-124) instead "
+                    "of the inference metric; --batch / --points = train.py's batch_size / num_point (defaults 1 x 5000)")
+    ap.add_argument("--train-depth", type=int, default=2, choices=[1, 2, 3, 4], help="EPN_layer_num of the --train model")
     ap.add_argument("--graph-latency-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--preflight", action="store_true", help="print, WITHOUT touching a GPU, what each of the --gpus N ranks would do: its shard of the "
                     "global batch, the CPU set it would pin itself to, the rendezvous and the RCCL-relevant environment -- so that a failed scaling run "
@@ -435,6 +519,9 @@ def main():
         return
     if a.preflight:
         preflight(a)
+        return
+    if a.train:
+        train_bench(a)
         return
     if a.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(a.gpus, sys.argv[1:]))          # parent: no GPU call before or after this point

@@ -160,41 +160,62 @@ def instnorm_leaky_relu(x_cl, slope=0.01):
     return InstanceNormLeakyReLUFunction.apply(x_cl, slope)
 
 
+def _mhsa_forward(x2, wq, wk, wv, wc, bc, mode):
+    """One MultiHeadAttention layer on tokens x2 (T*60, E): the fused inference kernel for E = 64 (etch_mhsa_layer), the un-fused chain
+    Linear -> etch_mhsa_attention_dim -> Linear for the other encoder depths (E = 32 / 128 / 256: models_pointcloud.py:34-48).
+    mode 0 residual, 1 plain, 2 concatenated heads only."""
+    E = x2.shape[1]
+    T = x2.shape[0] // 60
+    if E == 64:
+        return ops.mhsa_layer(x2, wq, wk, wv, wc, bc, mode=mode)
+    qkv = ops.linear(x2, torch.cat([wq, wk, wv], 0).contiguous())
+    att = ops.mhsa_attention(qkv, T, 0, E, 2 * E, embedding_dim=E)
+    if mode == 2:
+        return att
+    return ops.linear(att, wc, bias=bc, res=x2 if mode == 0 else None, res_mode=2 if mode == 0 else 0)
+
+
+def _mhsa_attention_backward(T, E, qkv, dO):
+    dqkv = torch.empty_like(qkv)
+    _check(_lib.lib().etch_mhsa_attention_backward_dim(ctypes.c_long(T), int(E), _ptr(qkv), ctypes.c_long(3 * E), 0, E, 2 * E, _ptr(dO), ctypes.c_long(E),
+                                                       _ptr(dqkv), _stream()), "etch_mhsa_attention_backward")
+    return dqkv
+
+
 class MHSALayerFunction(torch.autograd.Function):
     """One MultiHeadAttention layer of the direction head (direction_backbones.py:132-194, + the residual of :216-221): forward = the
-    fused inference kernel (etch_mhsa_layer); backward recomputes q|k|v and the head outputs with the un-fused kernels, runs the
-    attention core's hand-written backward (etch_mhsa_attention_backward) and closes the linear maps with the matrix-core GEMMs."""
+    fused inference kernel (etch_mhsa_layer; the un-fused chain for token widths other than 64); backward recomputes q|k|v and the head
+    outputs with the un-fused kernels, runs the attention core's hand-written backward (etch_mhsa_attention_backward_dim) and closes the
+    linear maps with the matrix-core GEMMs."""
 
     @staticmethod
     def forward(ctx, x, wq, wk, wv, wc, bc, residual):
-        T = x.shape[0]
-        x2 = x.reshape(T * 60, 64).contiguous()
+        T, E = x.shape[0], x.shape[-1]
+        x2 = x.reshape(T * 60, E).contiguous()
         ws = [t.detach().contiguous() for t in (wq, wk, wv, wc)]
-        y = ops.mhsa_layer(x2, ws[0], ws[1], ws[2], ws[3], bc.detach().contiguous(), mode=0 if residual else 1)
+        y = _mhsa_forward(x2, ws[0], ws[1], ws[2], ws[3], bc.detach().contiguous(), 0 if residual else 1)
         ctx.save_for_backward(x2, *ws)
         ctx.residual, ctx.xshape = bool(residual), x.shape
-        return y.view(T, 60, 64)
+        return y.view(T, 60, wc.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         x2, wq, wk, wv, wc = ctx.saved_tensors
-        T = x2.shape[0] // 60
-        dy2 = dy.reshape(T * 60, 64).contiguous()
-        wqkv = torch.cat([wq, wk, wv], 0).contiguous()                       # (192, 64)
+        T, E = x2.shape[0] // 60, x2.shape[1]
+        dy2 = dy.reshape(T * 60, wc.shape[0]).contiguous()
+        wqkv = torch.cat([wq, wk, wv], 0).contiguous()                       # (3E, E)
         qkv = ops.linear(x2, wqkv)                                           # recomputed, not kept from the forward
-        att = ops.mhsa_attention(qkv, T, 0, 64, 128)
+        att = ops.mhsa_attention(qkv, T, 0, E, 2 * E, embedding_dim=E)
         dO = ops.linear(dy2, wc.t().contiguous())                            # dY Wc
-        dqkv = torch.empty_like(qkv)
-        _check(_lib.lib().etch_mhsa_attention_backward(ctypes.c_long(T), _ptr(qkv), ctypes.c_long(192), 0, 64, 128, _ptr(dO), ctypes.c_long(64),
-                                                       _ptr(dqkv), _stream()), "etch_mhsa_attention_backward")
+        dqkv = _mhsa_attention_backward(T, E, qkv, dO)
         dx = ops.linear(dqkv, wqkv.t().contiguous(), res=dy2 if ctx.residual else None, res_mode=2 if ctx.residual else 0)
-        dwqkv = gemm_tn(dqkv, x2)                                            # (192, 64)
+        dwqkv = gemm_tn(dqkv, x2)                                            # (3E, E)
         dwc = gemm_tn(dy2, att)
-        return dx.view(ctx.xshape), dwqkv[:64], dwqkv[64:128], dwqkv[128:], dwc, colsum(dy2), None
+        return dx.view(ctx.xshape), dwqkv[:E], dwqkv[E:2 * E], dwqkv[2 * E:], dwc, colsum(dy2), None
 
 
 def mhsa_layer(x, wq, wk, wv, wc, bc, residual=True):
-    """x (T,60,64) -> (T,60,64), differentiable in x and all five parameters."""
+    """x (T,60,E) -> (T,60,E), differentiable in x and all five parameters; E in {32, 64, 128, 256}."""
     return MHSALayerFunction.apply(x, wq, wk, wv, wc, bc, residual)
 
 
@@ -346,32 +367,30 @@ def prop_interp(feats_cl, idx, w):
 
 
 class MHSAHeadsFunction(torch.autograd.Function):
-    """The concatenated head outputs of one MultiHeadAttention layer (before head_combine): x (T,60,64) -> (T,60,64); forward = the fused
-    kernel in mode 2, backward as MHSALayerFunction without the combine."""
+    """The concatenated head outputs of one MultiHeadAttention layer (before head_combine): x (T,60,E) -> (T,60,E); forward = the fused
+    kernel in mode 2 (E = 64) or the un-fused chain, backward as MHSALayerFunction without the combine."""
 
     @staticmethod
     def forward(ctx, x, wq, wk, wv):
-        T = x.shape[0]
-        x2 = x.reshape(T * 60, 64).contiguous()
+        T, E = x.shape[0], x.shape[-1]
+        x2 = x.reshape(T * 60, E).contiguous()
         ws = [t.detach().contiguous() for t in (wq, wk, wv)]
-        y = ops.mhsa_layer(x2, ws[0], ws[1], ws[2], mode=2)
+        y = _mhsa_forward(x2, ws[0], ws[1], ws[2], None, None, 2)
         ctx.save_for_backward(x2, *ws)
         ctx.xshape = x.shape
-        return y.view(T, 60, 64)
+        return y.view(T, 60, E)
 
     @staticmethod
     def backward(ctx, dO):
         x2, wq, wk, wv = ctx.saved_tensors
-        T = x2.shape[0] // 60
-        dO2 = dO.reshape(T * 60, 64).contiguous()
+        T, E = x2.shape[0] // 60, x2.shape[1]
+        dO2 = dO.reshape(T * 60, E).contiguous()
         wqkv = torch.cat([wq, wk, wv], 0).contiguous()
         qkv = ops.linear(x2, wqkv)
-        dqkv = torch.empty_like(qkv)
-        _check(_lib.lib().etch_mhsa_attention_backward(ctypes.c_long(T), _ptr(qkv), ctypes.c_long(192), 0, 64, 128, _ptr(dO2), ctypes.c_long(64),
-                                                       _ptr(dqkv), _stream()), "etch_mhsa_attention_backward")
+        dqkv = _mhsa_attention_backward(T, E, qkv, dO2)
         dx = ops.linear(dqkv, wqkv.t().contiguous())
         dwqkv = gemm_tn(dqkv, x2)
-        return dx.view(ctx.xshape), dwqkv[:64], dwqkv[64:128], dwqkv[128:]
+        return dx.view(ctx.xshape), dwqkv[:E], dwqkv[E:2 * E], dwqkv[2 * E:]
 
 
 def mhsa_heads(x, wq, wk, wv):

@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(long MN, int splits
 // One workgroup per SOURCE point q (gather side): the chunk's index list is scanned 256 slots at a time in index order; a matching
 // slot (p, n) contributes  sum_k w[p,a,k,n] dX1[(p,a), c*24+k]  to dF[q,a,c] with w regenerated from g = xyz_q - new_xyz_p.
 // thread <-> (anchor a, channel group): 240 threads = 60 anchors x 4 groups of cin/4 channels.
-__global__ void __launch_bounds__(256) inter_dfeat_kernel(int cin, int p1, int p2, int p_begin, int pc, int nn, float inv_sigma,
+__global__ void __launch_bounds__(256) inter_dfeat_kernel(int cin, int cbase, int cw, int p1, int p2, int p_begin, int pc, int nn, float inv_sigma,
                                                           const float* __restrict__ xyz, const float* __restrict__ new_xyz,
                                                           const int* __restrict__ ball_idx, const float* __restrict__ rk,
                                                           const float* __restrict__ dx1, float* __restrict__ dfeats, int accumulate) {
@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(256) inter_dfeat_kernel(int cin, int p1, int p
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, q = blockIdx.x;
     const float* X = xyz + (size_t)b * 3 * p1;
     const float qx = X[q], qy = X[p1 + q], qz = X[2 * p1 + q];
-    const int a = tid >> 2, cg = tid & 3, cper = cin >> 2, kk = cin * KS;
+    const int a = tid >> 2, cg = tid & 3, cper = cw >> 2, kk = cin * KS;      // this launch: channels cbase .. cbase + cw - 1 (cw <= 64)
     const bool worker = tid < NA * 4;
     float acc[16];                                        // cin / 4 <= 16 channels per thread
 #pragma unroll
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(256) inter_dfeat_kernel(int cin, int p1, int p
                 const float gx = qx - new_xyz[((size_t)b * 3 + 0) * p2 + p], gy = qy - new_xyz[((size_t)b * 3 + 1) * p2 + p],
                             gz = qz - new_xyz[((size_t)b * 3 + 2) * p2 + p];
                 const float ga = 1.0f - (gx * gx + gy * gy + gz * gz) * inv_sigma;
-                const float* drow = dx1 + (((size_t)b * pc + pl) * NA + a) * kk + (size_t)cg * cper * KS;
+                const float* drow = dx1 + (((size_t)b * pc + pl) * NA + a) * kk + (size_t)(cbase + cg * cper) * KS;
                 for (int k = 0; k < KS; ++k) {
                     const float rx = rk[(a * KS + k) * 3], ry = rk[(a * KS + k) * 3 + 1], rz = rk[(a * KS + k) * 3 + 2];
                     const float w = fmaxf(0.f, fmaf(2.0f * inv_sigma * gz, rz, fmaf(2.0f * inv_sigma * gy, ry, fmaf(2.0f * inv_sigma * gx, rx,
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(256) inter_dfeat_kernel(int cin, int p1, int p
         __syncthreads();
     }
     if (worker) {
-        float* dst = dfeats + (((size_t)b * p1 + q) * NA + a) * cin + cg * cper;
+        float* dst = dfeats + (((size_t)b * p1 + q) * NA + a) * cin + cbase + cg * cper;
 #pragma unroll
         for (int c = 0; c < 16; ++c)
             if (c < cper) dst[c] = (accumulate ? dst[c] : 0.f) + acc[c];
@@ -315,10 +315,13 @@ int etch_gemm_tn(long R, int M, int N, const float* A, long lda, const float* B,
 int etch_inter_dfeat(int b, int cin, int p1, int p2, int p_begin, int pc, int nn, float sigma, const float* xyz, const float* new_xyz,
                      const int* ball_idx, const float* rk, const float* dx1, float* dfeats, int accumulate, void* stream) {
     if (b <= 0 || p1 <= 0) return ETCH_OK;
-    if (cin <= 0 || (cin & 3) || cin > 64 || nn <= 0 || p_begin < 0 || p_begin + pc > p2 || b > 65535) return ETCH_EUNSUPPORTED;
-    hipLaunchKernelGGL(inter_dfeat_kernel, dim3(p1, b), dim3(256), 0, (hipStream_t)stream, cin, p1, p2, p_begin, pc, nn, 1.0f / sigma, xyz, new_xyz,
-                       ball_idx, rk, dx1, dfeats, accumulate);
-    ETCH_RETURN_IF_LAUNCH_FAILED();
+    if (cin <= 0 || (cin & 3) || (cin > 64 && (cin & 63)) || nn <= 0 || p_begin < 0 || p_begin + pc > p2 || b > 65535) return ETCH_EUNSUPPORTED;
+    for (int cbase = 0; cbase < cin; cbase += 64) {         // wider inputs (encoder depths 3 / 4: 128 / 256 channels) in windows of 64 channels
+        const int cw = cin - cbase < 64 ? cin - cbase : 64;
+        hipLaunchKernelGGL(inter_dfeat_kernel, dim3(p1, b), dim3(256), 0, (hipStream_t)stream, cin, cbase, cw, p1, p2, p_begin, pc, nn, 1.0f / sigma, xyz,
+                           new_xyz, ball_idx, rk, dx1, dfeats, accumulate);
+        ETCH_RETURN_IF_LAUNCH_FAILED();
+    }
     return ETCH_OK;
 }
 
@@ -370,18 +373,22 @@ int etch_instnorm_act_backward_workspace_bytes(int b, int C) { return (int)((siz
 // no cross-lane reductions, every sum runs over the 60 tokens in index order: reproducible bit for bit.
 // ------------------------------------------------------------------------------------------------
 #define MB_L 60
-#define MB_HD 8
+// MB_HD = head width (embedding_dim / 8): 8 for the released encoder depth, 4 / 16 / 32 for EPN_layer_num 1 / 3 / 4 (models_pointcloud.py:34-48)
+template <int MB_HD>
 __global__ void __launch_bounds__(256) mhsa_attention_backward_kernel(const float* __restrict__ qkv, long ld, int qoff, int koff, int voff,
                                                                       const float* __restrict__ dO, long ldo, float* __restrict__ dqkv) {
-    __shared__ float qs[4][MB_L][MB_HD], ks[4][MB_L][MB_HD], vs[4][MB_L][MB_HD], gs[4][MB_L][MB_HD];
-    __shared__ float st_m[4][64], st_l[4][64], st_d[4][64];
+    extern __shared__ __attribute__((aligned(16))) float mb_smem[];
+    typedef float (*mb_tile)[MB_L][MB_HD];
+    mb_tile qs = reinterpret_cast<mb_tile>(mb_smem), ks = qs + 4, vs = ks + 4, gs = vs + 4;      // [4 waves][60 tokens][head width] each
+    typedef float (*mb_stat)[64];
+    mb_stat st_m = reinterpret_cast<mb_stat>(mb_smem + 16 * MB_L * MB_HD), st_l = st_m + 4, st_d = st_l + 4;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const size_t row0 = (size_t)blockIdx.x * MB_L;
-    const float scale = 0.35355339059327373f;                  // 1/sqrt(8)
+    const float scale = MB_HD == 8 ? 0.35355339059327373f : MB_HD == 4 ? 0.5f : MB_HD == 16 ? 0.25f : 0.17677669529663687f;      // 1 / sqrt(head width)
     for (int round = 0; round < 2; ++round) {
         const int h = round * 4 + w;
-        for (int e = lane; e < MB_L * 2; e += 64) {
-            const int r = e >> 1, half = (e & 1) * 4;
+        for (int e = lane; e < MB_L * (MB_HD / 4); e += 64) {
+            const int r = e / (MB_HD / 4), half = (e % (MB_HD / 4)) * 4;
             const float* base = qkv + (row0 + r) * ld + h * MB_HD + half;
             *reinterpret_cast<float4*>(&qs[w][r][half]) = *reinterpret_cast<const float4*>(base + qoff);
             *reinterpret_cast<float4*>(&ks[w][r][half]) = *reinterpret_cast<const float4*>(base + koff);
@@ -427,8 +434,8 @@ __global__ void __launch_bounds__(256) mhsa_attention_backward_kernel(const floa
             st_m[w][lane] = m; st_l[w][lane] = il; st_d[w][lane] = D;
             if (lane < MB_L) {
                 float* o = dqkv + (row0 + lane) * ld + qoff + h * MB_HD;
-                *reinterpret_cast<float4*>(o) = make_float4(dq[0], dq[1], dq[2], dq[3]);
-                *reinterpret_cast<float4*>(o + 4) = make_float4(dq[4], dq[5], dq[6], dq[7]);
+#pragma unroll
+                for (int d = 0; d < MB_HD; d += 4) *reinterpret_cast<float4*>(o + d) = make_float4(dq[d], dq[d + 1], dq[d + 2], dq[d + 3]);
             }
         }
         __syncthreads();
@@ -449,24 +456,48 @@ __global__ void __launch_bounds__(256) mhsa_attention_backward_kernel(const floa
             if (lane < MB_L) {
                 float* ok = dqkv + (row0 + lane) * ld + koff + h * MB_HD;
                 float* ov = dqkv + (row0 + lane) * ld + voff + h * MB_HD;
-                *reinterpret_cast<float4*>(ok) = make_float4(dk[0], dk[1], dk[2], dk[3]);
-                *reinterpret_cast<float4*>(ok + 4) = make_float4(dk[4], dk[5], dk[6], dk[7]);
-                *reinterpret_cast<float4*>(ov) = make_float4(dv[0], dv[1], dv[2], dv[3]);
-                *reinterpret_cast<float4*>(ov + 4) = make_float4(dv[4], dv[5], dv[6], dv[7]);
+#pragma unroll
+                for (int d = 0; d < MB_HD; d += 4) {
+                    *reinterpret_cast<float4*>(ok + d) = make_float4(dk[d], dk[d + 1], dk[d + 2], dk[d + 3]);
+                    *reinterpret_cast<float4*>(ov + d) = make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]);
+                }
             }
         }
         __syncthreads();
     }
 }
 
-extern "C" int etch_mhsa_attention_backward(long T, const float* qkv, long ld, int qoff, int koff, int voff, const float* dO, long ldo,
-                                            float* dqkv, void* stream) {
+template <int HD>
+static int launch_mhsa_attention_backward(long T, const float* qkv, long ld, int qoff, int koff, int voff, const float* dO, long ldo, float* dqkv, hipStream_t st) {
+    const size_t lds = (size_t)(16 * MB_L * HD + 12 * 64) * sizeof(float);
+    auto kern = mhsa_attention_backward_kernel<HD>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)T), dim3(256), lds, st, qkv, ld, qoff, koff, voff, dO, ldo, dqkv);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+extern "C" int etch_mhsa_attention_backward_dim(long T, int embedding_dim, const float* qkv, long ld, int qoff, int koff, int voff, const float* dO, long ldo,
+                                                float* dqkv, void* stream) {
     if (T <= 0) return ETCH_OK;
     if (!qkv || !dO || !dqkv) return ETCH_EINVAL;
     if ((ld & 3) || (ldo & 3) || (qoff & 3) || (koff & 3) || (voff & 3) || (((uintptr_t)qkv | (uintptr_t)dO | (uintptr_t)dqkv) & 15)) return ETCH_EINVAL;
-    hipLaunchKernelGGL(mhsa_attention_backward_kernel, dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, qkv, ld, qoff, koff, voff, dO, ldo, dqkv);
-    ETCH_RETURN_IF_LAUNCH_FAILED();
-    return ETCH_OK;
+    hipStream_t st = (hipStream_t)stream;
+    switch (embedding_dim) {
+        case 32: return launch_mhsa_attention_backward<4>(T, qkv, ld, qoff, koff, voff, dO, ldo, dqkv, st);
+        case 64: return launch_mhsa_attention_backward<8>(T, qkv, ld, qoff, koff, voff, dO, ldo, dqkv, st);
+        case 128: return launch_mhsa_attention_backward<16>(T, qkv, ld, qoff, koff, voff, dO, ldo, dqkv, st);
+        case 256: return launch_mhsa_attention_backward<32>(T, qkv, ld, qoff, koff, voff, dO, ldo, dqkv, st);
+    }
+    return ETCH_EUNSUPPORTED;
+}
+
+extern "C" int etch_mhsa_attention_backward(long T, const float* qkv, long ld, int qoff, int koff, int voff, const float* dO, long ldo,
+                                            float* dqkv, void* stream) {
+    return etch_mhsa_attention_backward_dim(T, 64, qkv, ld, qoff, koff, voff, dO, ldo, dqkv, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

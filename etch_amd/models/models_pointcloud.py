@@ -165,8 +165,9 @@ class GT_network_equiv(nn.Module):
         return self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 
     def differentiable_supported(self):
-        """The differentiable direction head is built for the released width (EPN_layer_num = 2: 64-dim tokens)."""
-        return all(l.embedding_dim == 64 for l in self.direction_encoder.self_attention_layers)
+        """The differentiable direction head covers every encoder depth of the reference (EPN_layer_num 1 / 2 / 3 / 4: 32 / 64 / 128 / 256-dim
+        tokens, models_pointcloud.py:34-48): the fused attention layer at 64, the un-fused chain + etch_mhsa_attention_backward_dim otherwise."""
+        return all(l.embedding_dim in (32, 64, 128, 256) for l in self.direction_encoder.self_attention_layers)
 
     def encode_differentiable(self, hitpts):
         """The EPN encoder through etch_amd.autograd (hand-written backward kernels): what train.py:77-101 back-propagates through
@@ -193,7 +194,7 @@ class GT_network_equiv(nn.Module):
 
     def direction_differentiable(self, tokens, anchors, B, N):
         """direction_encoder -> direction_predictor -> so3_reg -> so3_mean -> R @ [0,0,1] (models_pointcloud.py:111-126) on the propagated
-        tokens (B*N, 60, 64), with autograd history; un-fused (no folded linear chains: every parameter receives its own gradient)."""
+        tokens (B*N, 60, E), with autograd history; un-fused (no folded linear chains: every parameter receives its own gradient)."""
         from .. import autograd as A
         x = tokens
         layers = list(self.direction_encoder.self_attention_layers)
@@ -248,7 +249,7 @@ class GT_network_equiv(nn.Module):
                 with pointops.knn_scope():
                     return self.forward_differentiable(hitpts, pred_items, direction_mode)
             if self.differentiable:
-                raise NotImplementedError("the differentiable direction head is built for the released width (EPN_layer_num = 2: 64-dim tokens)")
+                raise NotImplementedError("the differentiable direction head is built for 32 / 64 / 128 / 256-dim tokens (EPN_layer_num 1 .. 4)")
             import warnings
             warnings.warn("GT_network_equiv: no differentiable path for this token width; running the inference path (results carry no "
                           "autograd history)", stacklevel=2)

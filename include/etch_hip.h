@@ -478,6 +478,9 @@ int etch_pt_softmax_agg_backward(long n, int ns, int c, int cs, const float* sm,
  * [T*60][ldo] = gradient of the concatenated head outputs -> dqkv rows [T*60][ld] at the same offsets.  Fixed summation order. */
 int etch_mhsa_attention_backward(long T, const float* qkv, long ld, int qoff, int koff, int voff, const float* dO, long ldo, float* dqkv,
                                  void* stream);
+/* The same for the other encoder depths: embedding_dim in {32, 64, 128, 256} = 8 heads of width 4 / 8 / 16 / 32 (models_pointcloud.py:34-48). */
+int etch_mhsa_attention_backward_dim(long T, int embedding_dim, const float* qkv, long ld, int qoff, int koff, int voff, const float* dO, long ldo,
+                                     float* dqkv, void* stream);
 
 /* Column sums s[c] = sum_r x[r,c] (bias gradients): fp64, two levels, fixed order.  workspace: 64*C doubles. */
 int etch_colsum(long R, int C, const float* x, double* workspace, float* out, void* stream);

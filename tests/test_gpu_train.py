@@ -135,11 +135,14 @@ def test_maxpool_softmax_agg_gather_interp_segment_ops_vs_fp64_autograd():
     assert rel_err(xs.grad.cpu().numpy(), dx64.numpy()) < 1e-6 and rel_err(g.grad.cpu().numpy(), dg64.numpy()) < 1e-6
 
 
-def _setup(tmp_path, B, N):
+MLPS = ((32, 32), (64, 64), (128, 128), (256, 256))
+
+
+def _setup(tmp_path, B, N, depth=2):
     from etch_amd import constants as K
     from etch_amd.models.models_pointcloud import GT_network_equiv
     from etch_amd.utils.weights import load_seeded
-    args = types.SimpleNamespace(output_folder=str(tmp_path), EPN_input_radius=0.4, EPN_layer_num=2, device=torch.device("cuda"),
+    args = types.SimpleNamespace(output_folder=str(tmp_path), EPN_input_radius=0.4, EPN_layer_num=depth, device=torch.device("cuda"),
                                  markerset=K.default_markerset())
     model = load_seeded(GT_network_equiv(option=args), 1).cuda()
     pts = np.stack([scan(80 + b, N) for b in range(B)])
@@ -179,7 +182,8 @@ def _oracle(model, pts, vec, conf, labels, dtype, which, mask, lr=None, bn_train
         for k in names:
             sd[k] = sd[k].clone().requires_grad_()
         x = torch.from_numpy(pts).to(dtype)
-        xyz, feats = S1.encoder_forward(sd, x, S1.build_layer_table())
+        depth = len(model.encoder.backbone)
+        xyz, feats = S1.encoder_forward(sd, x, S1.build_layer_table(mlps=MLPS[:depth], strides=(2,) * depth))
         S_ = xyz.shape[-1]
         pef = S1.feat_propagation(x.permute(0, 2, 1), xyz.to(dtype), feats.permute(0, 1, 3, 2).reshape(B, -1, S_)).reshape(B, N, -1, 60)
         res = {}
@@ -192,7 +196,7 @@ def _oracle(model, pts, vec, conf, labels, dtype, which, mask, lr=None, bn_train
             res["magnitude"] = S1.pt_magnitude(sd, "magnitude_encoder.", p, inv, o)
         if "direction" in which:
             aw = S1.direction_anchor_weights(sd, pef)
-            R, Ce, sv = S1.so3_mean(sd["encoder.backbone.1.blocks.1.intra_conv.conv.anchors"], aw)
+            R, Ce, sv = S1.so3_mean(sd[f"encoder.backbone.{depth - 1}.blocks.1.intra_conv.conv.anchors"], aw)
             res["direction"] = R[:, :, 2].reshape(B, N, 3)
             if mask is None:
                 sig = torch.stack([sv[:, 0], sv[:, 1], torch.det(Ce.detach()).sign() * sv[:, 2]], 1).detach()
@@ -362,6 +366,29 @@ def test_eval_mode_gradients_of_all_four_losses_strict(tmp_path):
     gg, lg = _gpu(model, pts, vec, conf, labels, which, mask, ["confidence", "direction", "magnitude"])
     print("losses (fp64 oracle / fp32 oracle / gpu):", {k: (round(l64[k], 6), round(l32[k], 6), round(lg[k], 6)) for k in l64})
     n, m_gpu, m_32 = _compare(names, gg, g64, g32, "all four losses, eval-mode BatchNorm", tol=1e-3, slack=8.0)
+    assert n == len(names) and m_gpu <= max(1e-4, 2.0 * m_32)
+
+
+@pytest.mark.parametrize("depth,N", [(1, 512), (3, 512), (4, 512)])
+def test_eval_mode_gradients_at_encoder_depths_1_3_4(tmp_path, depth, N):
+    """train.py:61-101 trains whatever EPN_layer_num builds (models_pointcloud.py:34-48: 32 / 128 / 256-dim tokens, conv channel
+    pairs up to (256, 256)).  The same strict end-to-end statement as test_eval_mode_gradients_of_all_four_losses_strict at the other three depths:
+    eval() mode, model.differentiable = True, all four losses, d(loss)/d(every parameter) against the fp64 oracle (1e-3 or slack x the fp32 oracle's
+    own deviation per tensor); the direction head runs the un-fused attention chain + etch_mhsa_attention_backward_dim (head widths 4 / 16 / 32)."""
+    B = 1
+    model, pts, vec, conf, labels = _setup(tmp_path, B, N, depth)
+    model.eval()
+    model.differentiable = True
+    assert model.differentiable_supported()
+    names = [k for k, _ in model.named_parameters()]
+    which = ("direction", "magnitude", "confidence")
+    g64, mask, l64, _ = _oracle(model, pts, vec, conf, labels, torch.float64, which, None, bn_training=False)
+    g32, _, l32, _ = _oracle(model, pts, vec, conf, labels, torch.float32, which, mask, bn_training=False)
+    gg, lg = _gpu(model, pts, vec, conf, labels, which, mask, ["confidence", "direction", "magnitude"])
+    print(f"depth {depth} losses (fp64 oracle / fp32 oracle / gpu):", {k: (round(l64[k], 6), round(l32[k], 6), round(lg[k], 6)) for k in l64})
+    for k in l64:
+        assert abs(lg[k] - l64[k]) <= max(1e-4 * max(1.0, abs(l64[k])), 4.0 * abs(l32[k] - l64[k])), (k, lg[k], l64[k], l32[k])
+    n, m_gpu, m_32 = _compare(names, gg, g64, g32, f"all four losses, eval-mode BatchNorm, depth {depth}", tol=1e-3, slack=8.0)
     assert n == len(names) and m_gpu <= max(1e-4, 2.0 * m_32)
 
 
