@@ -270,7 +270,8 @@ class GT_network_equiv(nn.Module):
         main = torch.cuda.current_stream()
         if not hasattr(self, "_side_stream"):
             # (normal priority: as a high-priority queue it starves the stage-2 fit, see pipeline.py)
-            self._side_stream = torch.cuda.Stream(priority=int(os.environ.get("ETCH_INDEX_STREAM_PRIORITY", "0")))
+            from ..utils.cu_streams import make_stream
+            self._side_stream = make_stream("side", priority=int(os.environ.get("ETCH_INDEX_STREAM_PRIORITY", "0")))
         side = self._side_stream
         side.wait_stream(self.input_producer if self.input_producer is not None else main)
         made = []
@@ -319,7 +320,8 @@ class GT_network_equiv(nn.Module):
             # the nets are long chains of small kernels (the critical path of this phase), the direction head on the current
             # stream is a few chip-wide kernels: high-priority queues let the chains go first whenever they have work
             prio = int(os.environ.get("ETCH_HEAD_STREAM_PRIORITY", "-1"))
-            self._head_streams = (torch.cuda.Stream(priority=prio), torch.cuda.Stream(priority=prio))
+            from ..utils.cu_streams import make_stream
+            self._head_streams = (make_stream("side", priority=prio), make_stream("side", priority=prio))
         return self._head_streams
 
     def _forward(self, hitpts, pred_items, direction_mode, B, N):

@@ -20,12 +20,13 @@ class HotPathPipeline:
         self.args, self.model, self.gender, self.fit_kwargs = args, model, gender, fit_kwargs
         # stage 1 of consecutive batches alternates over `stage1_streams` streams: with 2, the low-occupancy kernels of one
         # batch (deep Point-Transformer levels: a few dozen workgroups) fill behind the chip-wide kernels of the other
-        self.s1s = [torch.cuda.Stream() for _ in range(stage1_streams)]
+        from .utils.cu_streams import make_stream
+        self.s1s = [make_stream("main") for _ in range(stage1_streams)]      # plain torch streams unless ETCH_CU_PARTITION asks for a CU partition (A/B switch)
         # (priorities: the two Point-Transformer nets' streams are high-priority queues; raising the index stream as well gained 0.5 % on the frozen-fit
         # workload but starved this stream's fit -- 32 - 96 long-running workgroups that each need a whole compute unit -- whenever the fit runs its full
         # schedule: 548 against 700 scans/s with well-posed markers; raising both: 660.  Both stay at normal priority; ETCH_*_STREAM_PRIORITY override.)
         import os
-        self.s2 = torch.cuda.Stream(priority=int(os.environ.get("ETCH_STAGE2_STREAM_PRIORITY", "0")))
+        self.s2 = make_stream("side", priority=int(os.environ.get("ETCH_STAGE2_STREAM_PRIORITY", "0")))
         self.max_in_flight = max_in_flight
         self.in_flight = []
         self._pinned = [None] * (max_in_flight + 1)     # ring of pinned host buffers, one set per batch in flight (+1 being read)

@@ -392,6 +392,67 @@ def test_eval_mode_gradients_at_encoder_depths_1_3_4(tmp_path, depth, N):
     assert n == len(names) and m_gpu <= max(1e-4, 2.0 * m_32)
 
 
+def test_magnitude_net_train_mode_at_4096_points_entitled_error(tmp_path):
+    """at the path's real size the train-mode nets are NOT chaotic (a BatchNorm over thousands of rows does not re-amplify rounding
+    noise), so the tight statement is available: the magnitude net alone, 1 x 4 096 points, train-mode BatchNorm, train.py's magnitude loss.  Output
+    and parameter gradients must be as close to the fp64 oracle as the oracle's OWN fp32 run is, x 2 (entitled-error rule): the output and the
+    concatenated gradient in relative L2, and the per-tensor deviations in their median and 90 % quantile."""
+    from etch_amd import autograd_pt as P
+    from etch_amd.utils.weights import seeded_state_dict
+    from oracle import stage1 as S1
+    B, N = 1, 4096
+    model, pts, vec, conf, labels = _setup(tmp_path, B, N)
+    model.train()
+    net, pre = model.magnitude_encoder, "magnitude_encoder."
+    names = [pre + k for k, _ in net.named_parameters()]
+    rng = np.random.default_rng(2)
+    x_np = rng.standard_normal((B * N, 64))
+    tgt_np = np.linalg.norm(vec, axis=-1, keepdims=True) * 10
+
+    def oracle(dtype):
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        S1.BN_TRAINING = True
+        try:
+            sd = {k: (v.cpu().to(dtype) if v.is_floating_point() else v.cpu()) for k, v in seeded_state_dict(model, 1).items()}
+            for k in names:
+                sd[k] = sd[k].clone().requires_grad_()
+            p = torch.from_numpy(pts).to(dtype).reshape(-1, 3).contiguous()
+            o = torch.tensor([N * (i + 1) for i in range(B)], dtype=torch.int32)
+            y = S1.pt_magnitude(sd, pre, p, torch.from_numpy(x_np).to(dtype), o)
+            F.mse_loss(torch.from_numpy(tgt_np).to(dtype), y).backward()
+            return y.detach().double().numpy(), {k: sd[k].grad.detach().double().numpy() for k in names if sd[k].grad is not None}
+        finally:
+            torch.set_default_dtype(old)
+            S1.BN_TRAINING = False
+
+    y64, g64 = oracle(torch.float64)
+    y32, g32 = oracle(torch.float32)
+    net.zero_grad(set_to_none=True)
+    c = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32)).cuda()
+    o_gpu = torch.tensor([N * (i + 1) for i in range(B)], dtype=torch.int32, device="cuda")
+    yg = P.magnitude_forward(net, (c(pts).reshape(-1, 3).contiguous(), c(x_np), o_gpu))
+    F.mse_loss(c(tgt_np), yg).backward()
+    gg = {pre + k: p.grad.detach().cpu().double().numpy() for k, p in net.named_parameters() if p.grad is not None}
+    rl2 = lambda a, b: float(np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel()))
+    ey_gpu, ey_32 = rl2(yg.detach().cpu().double().numpy().reshape(y64.shape), y64), rl2(y32, y64)
+    top = max(np.abs(v).max() for v in g64.values())
+    keys = [k for k in g64 if np.abs(g64[k]).max() > 1e-6 * top]            # (analytically zero gradients: biases in front of a train-mode BatchNorm)
+    assert set(gg) == set(g64)
+    cat = lambda d: np.concatenate([d[k].ravel() for k in keys])
+    eg_gpu, eg_32 = rl2(cat({k: gg[k].reshape(g64[k].shape) for k in keys}), cat(g64)), rl2(cat(g32), cat(g64))
+    per_gpu = np.array([rl2(gg[k].reshape(g64[k].shape), g64[k]) for k in keys])
+    per_32 = np.array([rl2(g32[k], g64[k]) for k in keys])
+    print(f"magnitude net, train mode, 1 x {N}: output rel L2 vs fp64: gpu {ey_gpu:.2e} / fp32 oracle {ey_32:.2e}; all gradients: {eg_gpu:.2e} / {eg_32:.2e}; "
+          f"per tensor median {np.median(per_gpu):.2e} / {np.median(per_32):.2e}, 90 % {np.quantile(per_gpu, .9):.2e} / {np.quantile(per_32, .9):.2e} ({len(keys)} tensors)")
+    assert ey_gpu <= 2.0 * ey_32 + 1e-6, (ey_gpu, ey_32)
+    assert eg_gpu <= 2.0 * eg_32 + 1e-6, (eg_gpu, eg_32)
+    assert np.median(per_gpu) <= 2.0 * np.median(per_32) + 1e-6 and np.quantile(per_gpu, .9) <= 2.0 * np.quantile(per_32, .9) + 1e-6
+    for k in g64:
+        if k not in keys:
+            assert np.abs(gg[k]).max() <= max(1e-4 * top, 4.0 * np.abs(g32[k]).max()), k
+
+
 def test_point_transformer_modules_train_mode_vs_fp64_autograd(tmp_path):
     """Every module of the Point-Transformer nets in train() mode on ITS OWN, fed the oracle's fp64 activations of a real forward (B = 2 scans of
     1024 points, magnitude net): TransitionDown (both strides), PointTransformerBlock (= PointTransformerLayer + three BatchNorms),
