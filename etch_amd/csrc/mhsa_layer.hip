@@ -15,6 +15,7 @@
 //   C  head_combine (+ bias + residual) from the attention tile in LDS, float4 stores.
 // Keys 60..63 (tile padding) are masked to -inf; rows 60..63 are never stored.
 #include "common.h"
+#include "split_bf16.h"
 #include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -73,7 +74,6 @@ __device__ __forceinline__ void ml_softmax(f32x4 (&s)[4], int fg) {
 // instead of on its datapath.  Their C/D layout is that of v_mfma_f32_16x16x4_f32, so the attention phase -- whose operands ARE the
 // projections' accumulators -- is untouched (it stays on the fp32 MFMA: its operands are produced per use).  The weights are split once per
 // workgroup (registers), the token tile when it is staged in LDS, the attention output when it is stored for head_combine.
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
 #define ML_PL (64 * 64)      // bf16 elements of one plane of a 64 x 64 tile: rows of 128 bytes, 16-byte units XOR-swizzled with the row (no padding:
                              // three planes of a tile take 24.6 KB against 26.6 KB of the padded fp32 tile, so three workgroups still share a CU)
 __device__ __forceinline__ int ml_sw(int row, int k) { return row * 64 + ((((k) >> 3) ^ (row & 7)) << 3) + (k & 7); }
@@ -243,7 +243,12 @@ __device__ __forceinline__ void ml_combine(const unsigned short* Ap, WC wc, f32x
     }
 }
 
-// MODE 0: out = X + att Wc^T + bc (residual layer);  1: out = att Wc^T + bc;  2: out = att (head_combine folded downstream)
+// MODE 0: out = X + att Wc^T + bc (residual layer);  1: out = att Wc^T + bc;  2: out = att (head_combine folded downstream);
+// MODE 3 (round 5): the direction tail folded in -- out[token] = v . relu(Wf att[token] + bf) + c (models_pointcloud.py:115-117 with the linear
+//   chains folded on the host: Wf = net[0] o head_combine, v = so3_reg o net[2]): the 60 x 64 attention tile is in LDS when the layer ends, the
+//   hidden layer (64 -> 128 -> 1, 1 MFLOP per point) runs on v_mfma_f32_32x32x16_f16 from two fp16 planes per operand (split_bf16.h; Wf arrives as
+//   the planes of 2^6 Wf in fragment order, `Wc`; `bc` = [bf (128) | v (128) | c]); 240 bytes per point leave the kernel instead of 15 KB, and
+//   linear_relu_dot_ws_kernel<64, 1> (1.74 ms, 2.46 GB read) leaves the path.
 // waves per SIMD the layer is compiled for: the split weight fragments (72 - 96 registers) no longer fit three (168 registers, 116 - 268 bytes
 // of scratch: mode 0 / mode 2 = 5.02 / 3.93 ms); two (no scratch): 4.13 / 3.68 ms
 #ifndef ML_LAYER_WPE
@@ -256,16 +261,30 @@ __global__ void __launch_bounds__(256, ML_LAYER_WPE) mhsa_layer_kernel(long T, c
                                                             float* __restrict__ out, unsigned* __restrict__ ctr) {
     __shared__ unsigned s_grab;
     __shared__ __attribute__((aligned(16))) unsigned short Xp[3 * ML_PL];                     // token tile, three planes
-    __shared__ __attribute__((aligned(16))) float Asm[MODE == 2 ? 64 * ML_S : 3 * ML_PL / 2];   // attention tile: fp32 (MODE 2) or three planes
+    __shared__ __attribute__((aligned(16))) float Asm[MODE >= 2 ? 64 * ML_S : 3 * ML_PL / 2];   // attention tile: fp32 (MODE 2, 3) or three planes
+    __shared__ __attribute__((aligned(16))) float tail_tab[MODE == 3 ? 256 : 4];              // MODE 3: bf | v
+    __shared__ float tail_part[MODE == 3 ? 4 * 64 : 4];                                         // MODE 3: the four waves' shares of the 64 token sums
     float* As = Asm;
     unsigned short* Ap = reinterpret_cast<unsigned short*>(Asm);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
 
     MlWeights W;
-    ml_load_weights<MODE != 2>(W, Wq, Wk, Wv, Wc, w, fr, fg);
+    ml_load_weights<(MODE < 2)>(W, Wq, Wk, Wv, Wc, w, fr, fg);
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (MODE != 2 && bc) bias = *reinterpret_cast<const float4*>(bc + 16 * w + 4 * fg);
+    if (MODE < 2 && bc) bias = *reinterpret_cast<const float4*>(bc + 16 * w + 4 * fg);
+    // MODE 3: this wave's 32 hidden units of Wf as A fragments (K step ks = channels 16 ks + 8 (lane / 32) .., two planes), resident in registers
+    f16x8 Wt[4][2];
+    float tail_c = 0.f;
+    if (MODE == 3) {
+        const f16x8* wf = reinterpret_cast<const f16x8*>(Wc) + (size_t)w * 4 * 2 * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) Wt[ks][pl] = wf[(ks * 2 + pl) * 64];
+        tail_tab[tid] = bc[tid];
+        tail_c = bc[256];
+    }
     // token rows 60..63 stay zero for the whole kernel (all planes): 3 x 4 rows x 64 bf16 = 384 dwords
     for (int e = tid; e < 384; e += 256) reinterpret_cast<unsigned*>(Xp + (e / 128) * ML_PL + ML_TOK * 64)[e % 128] = 0u;
 
@@ -294,11 +313,51 @@ __global__ void __launch_bounds__(256, ML_LAYER_WPE) mhsa_layer_kernel(long T, c
 
         f32x4 Q[4], Kt[4], V[4];
         ml_project(Xp, W, Q, Kt, V, fr, fg);
-        ml_attention<MODE != 2>(Q, Kt, V, As, Ap, w, fr, fg);
+        ml_attention<(MODE < 2)>(Q, Kt, V, As, Ap, w, fr, fg);
         __syncthreads();
 
         float* dst = out + pt * (ML_TOK * ML_C);
-        if (MODE == 2) {
+        if (MODE == 3) {
+            // hidden[h][token] = sum_c Wf[h][c] att[token][c]: A = Wf (rows = this wave's hidden units), B = the attention tile (column = token, 8 channels
+            // per lane and K step, split into two fp16 planes by the wave that reads them); three cross terms, smallest first
+            const int tl = lane & 31, kg = lane >> 5;
+            typedef float f32x16_ __attribute__((ext_vector_type(16)));
+            f32x16_ d[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) d[tt][v] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const float* xr = &As[(32 * tt + tl) * ML_S + 16 * ks + 8 * kg];
+                    f16x8 bh, bl;
+                    split2h_pack8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4), bh, bl);
+                    d[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wt[ks][1], bh, d[tt], 0, 0, 0);
+                    d[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wt[ks][0], bl, d[tt], 0, 0, 0);
+                    d[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wt[ks][0], bh, d[tt], 0, 0, 0);
+                }
+            // d[tt][v] = 2^6 hidden[32 w + 8 (v / 4) + 4 kg + v % 4][token 32 tt + tl]: bias, ReLU, . v, summed over this lane's 16 hidden units,
+            // then over the two lane halves and (through LDS, fixed order) over the four waves
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(&tail_tab[32 * w + 8 * q4 + 4 * kg]);
+                    const float4 v4 = *reinterpret_cast<const float4*>(&tail_tab[128 + 32 * w + 8 * q4 + 4 * kg]);
+                    sacc = fmaf(fmaxf(fmaf(d[tt][4 * q4 + 0], 0.015625f, b4.x), 0.f), v4.x, sacc);
+                    sacc = fmaf(fmaxf(fmaf(d[tt][4 * q4 + 1], 0.015625f, b4.y), 0.f), v4.y, sacc);
+                    sacc = fmaf(fmaxf(fmaf(d[tt][4 * q4 + 2], 0.015625f, b4.z), 0.f), v4.z, sacc);
+                    sacc = fmaf(fmaxf(fmaf(d[tt][4 * q4 + 3], 0.015625f, b4.w), 0.f), v4.w, sacc);
+                }
+                const ml_u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(sacc), __float_as_uint(sacc), false, false);
+                if (kg == 0) tail_part[w * 64 + 32 * tt + tl] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            }
+            __syncthreads();
+            if (tid < ML_TOK) out[pt * ML_TOK + tid] = ((tail_part[tid] + tail_part[64 + tid]) + (tail_part[128 + tid] + tail_part[192 + tid])) + tail_c;
+        } else if (MODE == 2) {
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
                 const int e = tid + 256 * h;
@@ -521,6 +580,16 @@ static int launch_layer(long T, const float* X, const float* Wq, const float* Wk
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, T, X, Wq, Wk, Wv, Wc, bc, out, etch_work_counter_slot(st));
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
+}
+
+// MODE 3: attention heads of the last layer + the folded direction tail.  Wfq = ops.dirtail_weight_split(Wf): [4 waves][4 K steps][2 planes][64 lanes][8] fp16 of
+// 2^6 Wf (Wf 128 x 64 = direction_predictor.net[0] o head_combine); tab = [bf (128) | v (128) | c] fp32; out (T, 60) = the anchor weights of so3_mean
+extern "C" int etch_mhsa_layer_dirtail(long T, const float* X, const float* Wq, const float* Wk, const float* Wv, const void* Wfq, const float* tab,
+                                       float* out, void* stream) {
+    if (T <= 0) return ETCH_OK;
+    if (!X || !Wq || !Wk || !Wv || !Wfq || !tab || !out) return ETCH_EINVAL;
+    if (((uintptr_t)X | (uintptr_t)Wq | (uintptr_t)Wk | (uintptr_t)Wv | (uintptr_t)Wfq | (uintptr_t)tab) & 15) return ETCH_EINVAL;
+    return launch_layer<3>(T, X, Wq, Wk, Wv, reinterpret_cast<const float*>(Wfq), tab, out, (hipStream_t)stream);
 }
 
 extern "C" int etch_mhsa_layer(long T, const float* X, const float* Wq, const float* Wk, const float* Wv, const float* Wc,

@@ -89,7 +89,8 @@ class GT_network_equiv(nn.Module):
             bf = (W1 @ bc + b1).float().contiguous().to(dev)
             v = (W2.t() @ wr).float().contiguous().to(dev)
             c = (b2 @ wr + br[0]).float().view(1).to(dev)
-            return Wf, bf, v, c, ops.permute_weight_frag_grouped(Wf)
+            tab = torch.cat([bf, v, c]).contiguous()                      # [bf | v | c]: the fused tail's constants (etch_mhsa_layer_dirtail)
+            return Wf, bf, v, c, ops.permute_weight_frag_grouped(Wf), ops.dirtail_weight_split(Wf), tab
 
         if not hasattr(self, "_fold_cache"):
             from ..vgtk_so3conv import _Derived
@@ -97,6 +98,7 @@ class GT_network_equiv(nn.Module):
         return self._fold_cache.get(ps, build)
 
     fuse_direction_interp = True   # the first MHSA layer forms the 3-NN interpolated tokens itself (they are never written out)
+    fuse_direction_tail = os.environ.get("ETCH_DIR_TAIL", "1") != "0"   # the last MHSA layer carries the folded tail (round 5; 0: mhsa_layer mode 2 + linear_relu_dot)
 
     def _can_fuse_interp(self):
         layers = self.direction_encoder.self_attention_layers
@@ -126,7 +128,11 @@ class GT_network_equiv(nn.Module):
         for layer in layers[first:-1]:
             x = layer(x, x, x, residual=True)
         last = layers[-1]
-        Wf, bf, v, c, Wfp = self._folded()
+        Wf, bf, v, c, Wfp, Wfq, tab = self._folded()
+        if self.fuse_direction_tail and last.embedding_dim == 64:
+            # the last layer's heads AND relu(att Wf^T + bf) . v + c in one kernel: neither the attention output nor the hidden layer leaves the chip
+            return ops.mhsa_layer_dirtail(x.reshape(T * 60, 64).contiguous(), last.query_transform.weight.detach(), last.key_transform.weight.detach(),
+                                          last.value_transform.weight.detach(), Wfq, tab)
         att = last.heads(x.reshape(T * 60, last.embedding_dim))                       # concatenated heads; head_combine is folded into Wf
         # relu(att Wf^T + bf) . v + c in one kernel: the (T*60, 128) hidden layer stays on chip
         return ops.linear_relu_dot(att, Wf, bf, v, c, 1, wp=Wfp).view(T, 60)

@@ -552,6 +552,30 @@ def mhsa_layer(x, wq, wk, wv, wc=None, bc=None, mode=0):
     return out
 
 
+def dirtail_weight_split(Wf):
+    """Wf (128, 64) fp32 (direction_predictor.net[0] o head_combine) -> the two fp16 planes of 2^6 Wf as A fragments of v_mfma_f32_32x32x16_f16:
+    [wave w = hidden tile of 32][K step ks][plane][lane = 32 * (k / 8 % 2) + h % 32][8] with k = 16 ks + 8 (lane / 32) + e (etch_mhsa_layer_dirtail)."""
+    assert tuple(Wf.shape) == (128, 64)
+    w64 = Wf.float() * 64.0
+    hi = w64.to(torch.float16)
+    planes = torch.stack([hi, (w64 - hi.float()).to(torch.float16)])       # [2][128][64]
+    q = planes.reshape(2, 4, 32, 4, 2, 8)                                  # [pl][w][h][ks][kg][e]
+    return q.permute(1, 3, 0, 4, 2, 5).contiguous().reshape(-1)            # [w][ks][pl][kg][h][e]
+
+
+def mhsa_layer_dirtail(x, wq, wk, wv, Wfq, tab):
+    """x [T*60, 64] tokens -> anc_w [T, 60]: the last MultiHeadAttention layer's heads + the folded direction tail in one kernel."""
+    for t, n in ((x, "x"), (wq, "wq"), (wk, "wk"), (wv, "wv"), (tab, "tab")):
+        _need(t, torch.float32, n)
+    _need(Wfq, torch.float16, "Wfq")
+    assert x.shape[-1] == 64 and x.numel() % (60 * 64) == 0 and wq.shape == (64, 64) and Wfq.numel() == 2 * 128 * 64 and tab.numel() == 257
+    T = x.numel() // (60 * 64)
+    out = torch.empty((T, 60), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().etch_mhsa_layer_dirtail(_c_long(T), _ptr(x), _ptr(wq), _ptr(wk), _ptr(wv), _ptr(Wfq), _ptr(tab), _ptr(out), _stream()),
+               "etch_mhsa_layer_dirtail")
+    return out
+
+
 def mhsa_interp_layer(feats_cl, idx, w, wq, wk, wv, wc, bc, order=None):
     """First (residual) MHSA layer on the 3-NN interpolated tokens, which are formed inside the kernel: feats_cl (B,S,60,64) coarse
     tokens, idx / w (B,N,3) from prop3nn -> (B*N*60, 64).  order (B,N) int32: processing order of the fine points (scheduling only)."""

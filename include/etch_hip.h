@@ -277,6 +277,12 @@ int etch_mhsa_attention_dim(long T, int embedding_dim, const float* qkv, long ld
  * mode 1: out = att Wc^T + bc       mode 2: out = att (concatenated heads; Wc/bc unused -- head_combine folded downstream) */
 int etch_mhsa_layer(long T, const float* X, const float* Wq, const float* Wk, const float* Wv, const float* Wc, const float* bc,
                     int mode, float* out, void* stream);
+/* Round 5: the LAST attention layer of the direction head with the folded tail inside (models_pointcloud.py:115-117): out (T, 60) =
+ * v . relu(Wf att + bf) + c per token, the anchor weights that so3_mean consumes -- the (T*60, 64) attention output and the (T*60, 128) hidden layer
+ * never reach HBM.  Wfq = the two fp16 planes of 2^6 Wf (Wf 128 x 64 = direction_predictor.net[0] o head_combine, folded on the host) as matrix-core A
+ * fragments [4 waves][4 K steps][2 planes][64 lanes][8] (etch_amd/ops.py dirtail_weight_split); tab = [bf (128) | v (128) | c] fp32 (257 floats). */
+int etch_mhsa_layer_dirtail(long T, const float* X, const float* Wq, const float* Wk, const float* Wv, const void* Wfq, const float* tab,
+                            float* out, void* stream);
 
 /* The first MultiHeadAttention layer of the direction head applied to 3-NN INTERPOLATED tokens (PointFeatPropagation,
  * pointnet2_utils.py:45-74, feeding StackedMHSA, direction_backbones.py:216-221) without writing them out: F (B,S,60,64) coarse

@@ -184,3 +184,35 @@ def test_work_counters_graph_replay_next_to_eager_launches():
             bad_e += int(not torch.equal(out_e, ref))
     torch.cuda.synchronize()
     assert bad_e == 0 and bad_g == 0 and torch.equal(out_g, ref), (bad_e, bad_g)
+
+
+@pytest.mark.parametrize("T", [1, 37, 700])
+def test_direction_tail_inside_the_last_attention_layer_matches_the_two_kernel_form(tmp_path, T):
+    """etch_mhsa_layer_dirtail (the last MultiHeadAttention layer's heads + relu(att Wf^T + bf) . v + c in one kernel, the hidden
+    layer on the fp16 matrix cores from two planes per operand) against mhsa_layer(mode 2) + linear_relu_dot and against the fp64 formula
+    (models_pointcloud.py:115-117 with the folded linear chains): entitled-error rule, bitwise reproducible, independent of the batch around a point."""
+    import types
+
+    from etch_amd import constants as K
+    from etch_amd import ops
+    from etch_amd.models.models_pointcloud import GT_network_equiv
+    args = types.SimpleNamespace(output_folder=str(tmp_path), EPN_input_radius=0.4, EPN_layer_num=2, device=torch.device("cuda"), markerset=K.default_markerset())
+    model = load_seeded(GT_network_equiv(option=args), 1).cuda().eval()
+    g = torch.Generator().manual_seed(T)
+    x = (torch.randn(T, 60, 64, generator=g) * 1.5).cuda()
+    last = model.direction_encoder.self_attention_layers[-1]
+    Wf, bf, v, c, Wfp, Wfq, tab = model._folded()
+    wq, wk, wv = (t.weight.detach() for t in (last.query_transform, last.key_transform, last.value_transform))
+    x2 = x.reshape(T * 60, 64).contiguous()
+    fused = ops.mhsa_layer_dirtail(x2, wq, wk, wv, Wfq, tab)
+    att = ops.mhsa_layer(x2, wq, wk, wv, mode=2)
+    two = ops.linear_relu_dot(att, Wf, bf, v, c, 1, wp=Wfp).view(T, 60)
+    ref = (torch.relu(att.double() @ Wf.double().t() + bf.double()) @ v.double() + c.double()).view(T, 60)
+    scale = float(ref.abs().max())
+    e_f, e_t = float((fused.double() - ref).abs().max()), float((two.double() - ref).abs().max())
+    assert float((fused - two).abs().max()) < 3e-6 * scale, float((fused - two).abs().max()) / scale
+    assert e_f <= 2.0 * e_t + 2e-7 * scale, (e_f, e_t, scale)
+    assert torch.equal(fused, ops.mhsa_layer_dirtail(x2, wq, wk, wv, Wfq, tab))
+    if T > 1:
+        solo = ops.mhsa_layer_dirtail(x2[:60].contiguous(), wq, wk, wv, Wfq, tab)
+        assert torch.equal(solo[0], fused[0])
