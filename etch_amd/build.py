@@ -66,8 +66,15 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
+    # both variants (default / ETCH_BUILD_EXPERIMENTS=1) link to the same libetch_hip.so from their own object directories: the variant last linked is
+    # recorded next to the library, and a request for the other one relinks even when no source changed
+    stamp = LIB + ".variant"
+    variant = "experiments" if EXPERIMENTS else "default"
+    linked = open(stamp).read().strip() if os.path.exists(stamp) else None
+    if force or jobs or _stale(LIB, objs) or linked != variant:
         run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+        with open(stamp, "w") as f:
+            f.write(variant + "\n")
     return LIB
 
 

@@ -164,6 +164,7 @@ class GT_network_equiv(nn.Module):
     #   differentiable = False            never
     differentiable = None
     _warned_switch = False
+    _warned_eval_grad = False
 
     def wants_grad(self):
         if self.differentiable is not None:
@@ -259,6 +260,14 @@ class GT_network_equiv(nn.Module):
             import warnings
             warnings.warn("GT_network_equiv: no differentiable path for this token width; running the inference path (results carry no "
                           "autograd history)", stacklevel=2)
+        elif (self.differentiable is None and not self.training and torch.is_grad_enabled() and not GT_network_equiv._warned_eval_grad
+              and (hitpts.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            # the reference back-propagates in eval() mode too (frozen-BatchNorm fine-tuning, input / test-time gradients); here eval() takes the fused
+            # inference path, whose results carry no autograd history -- say so once instead of returning history-free tensors silently
+            GT_network_equiv._warned_eval_grad = True
+            import warnings
+            warnings.warn("GT_network_equiv: eval() mode with gradients enabled -> the fused inference path (results carry NO autograd history); "
+                          "set model.differentiable = True for gradients in eval() mode, or wrap the call in torch.no_grad()", stacklevel=2)
         with pointops.knn_scope():
             return self._forward(hitpts, pred_items, direction_mode, B, N)
 

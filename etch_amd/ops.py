@@ -80,6 +80,15 @@ def fps_split_failed(idx):
     return bool(out.value)
 
 
+def _fps_split_checked(idx, split):
+    """A split launch that the DISPATCH chose (split=None: ETCH_FPS_SPLIT / FPS_SPLIT_FORCE -- the model path, whose callers gather with the result at
+    once) is verified here: a scan that gave up carries INT_MIN indices, which must not reach a gather.  Costs a stream synchronisation
+    on this opt-in path only; an explicit split=G leaves the check to the caller (fps_split_failed), as the failure-path test does."""
+    if split is None and fps_split_failed(idx):
+        raise _lib.EtchHipError("split FPS gave up (a workgroup of a scan never arrived): rerun with ETCH_FPS_SPLIT unset (one workgroup per scan)")
+    return idx
+
+
 def furthest_point_sampling(xyz, m, split=None):
     """epn_grouping.furthest_point_sampling (grouping_cuda.cpp:158-173): (b,3,n) -> (b,m) int32.  split = workgroups per scan (None: auto)."""
     _need(xyz, torch.float32, "xyz")
@@ -91,7 +100,7 @@ def furthest_point_sampling(xyz, m, split=None):
         _lib.check(_lib.lib().etch_furthest_point_sampling_split(b, n, int(m), _ptr(xyz), _ptr(idx), G, _ptr(ws), _stream()),
                    "etch_furthest_point_sampling_split")
         idx._etch_split_ws = ws
-        return idx
+        return _fps_split_checked(idx, split)
     _lib.check(_lib.lib().etch_furthest_point_sampling(b, n, int(m), _ptr(xyz), _ptr(idx), _stream()), "etch_furthest_point_sampling")
     return idx
 
@@ -160,7 +169,7 @@ def furthestsampling(xyz, offset, new_offset, offset_host=None, new_offset_host=
         _lib.check(_lib.lib().etch_furthestsampling_split(nseg, n_max, _ptr(xyz), _ptr(offset), _ptr(new_offset), _ptr(idx), G, _ptr(ws), _stream()),
                    "etch_furthestsampling_split")
         idx._etch_split_ws = ws
-        return idx
+        return _fps_split_checked(idx, split)
     _lib.check(_lib.lib().etch_furthestsampling(nseg, n_max, _ptr(xyz), _ptr(offset), _ptr(new_offset), _ptr(idx), _stream()), "etch_furthestsampling")
     return idx
 
@@ -656,8 +665,8 @@ def _need_experiments(what):
 
 
 def pt_block_k1(x, w1, s1, t1, wqkv, bqkv):
-    _need_experiments("etch_pt_block_k1")
     """First half of a PointTransformerBlock: qkv (n, 3c) = relu(bn1(x W1^T)) Wqkv^T + bqkv (pointtransformer_seg.py:112-113, 27)."""
+    _need_experiments("etch_pt_block_k1")
     n, c = x.shape
     assert x.stride(1) == 1 and w1.shape == (c, c) and wqkv.shape == (3 * c, c)
     qkv = torch.empty((n, 3 * c), dtype=torch.float32, device=x.device)
