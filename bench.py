@@ -83,7 +83,7 @@ def algorithmic_flops(name, a):
     if name == "etch_inter_so3conv32":
         b, cin, cout, p1, p2, nn = v[0:6]
         return 2.0 * b * p2 * 60 * 24 * (cin * nn + cout * cin), f"inter_so3conv32_kernel<{cin},{cout},{(nn + 7) // 8}>"
-    if name in ("etch_intra_so3conv", "etch_intra_so3conv_stats", "etch_intra_so3conv32", "etch_intra_so3conv_split"):
+    if name in ("etch_intra_so3conv", "etch_intra_so3conv_stats", "etch_intra_so3conv32", "etch_intra_so3conv_split", "etch_intra_so3conv_f16"):
         b, c, cout, p = v[0:4]
         kern = "intra_so3conv_ws_kernel" if name.endswith("split") else "intra_so3conv32_kernel" if name.endswith("32") else "intra_so3conv_kernel"
         return 2.0 * b * p * 60 * 12 * c * cout, kern + f"<{c},{cout}>"

@@ -12,11 +12,15 @@
 // A workgroup is persistent: it walks point pairs (grid = CUs), the next pair's rows are in flight (registers) while the matrix cores work.
 // Per pair and (point, anchor half): wave (mt, kq) forms the partial tile Y[32 mt .. + 31][32 anchors] over its three taps; the four K-parts meet
 // in LDS (double-buffered: one barrier per phase), bias, output, fp64 InstanceNorm partial sums per pair as etch_intra_so3conv32.
+// Round 5, template flag F16 (C ABI etch_intra_so3conv_f16): the same kernel on v_mfma_f32_32x32x16_f16 with TWO fp16 planes per operand (split_bf16.h:
+// h = fp16(x) by truncation, l = fp16(x - h); three cross terms) -- the operands here are at unit scale (InstanceNorm + LeakyReLU outputs; W arrives
+// as the planes of 2^6 W, the epilogue multiplies by 2^-6), where that split carries the fp32 MFMA's error (profiles/r05_f16_two_plane_split.txt):
+// half the matrix instructions, two thirds of the LDS plane traffic, 48 / 96 instead of 72 / 144 registers of weight fragments.
 #include "common.h"
+#include "split_bf16.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
 #define NA 60
 
 // 4 consecutive fp32 values -> 3 planes x 4 bf16 (2 dwords each); exact: v = hi + mid + lo
@@ -36,8 +40,9 @@ __device__ __forceinline__ void ws_split3_pack4(const float4 v4, uint2& hi, uint
     lo = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
 }
 
-template <int C>
+template <int C, bool F16 = false>
 struct WsShape {
+    static constexpr int NPL = F16 ? 2 : 3;       // operand planes
     static constexpr int NT = C * 8;              // threads: 4 (C = 32) or 8 (C = 64) waves
     static constexpr int MT = C / 32;             // output-channel tiles
     static constexpr int KQ = 4;                  // K parts (3 taps each)
@@ -47,7 +52,7 @@ struct WsShape {
     static constexpr int PLANE = NA * LDB;        // bf16 elements of one plane of one point
     static constexpr int NPRE = (NA * (C / 4) + NT - 1) / NT;          // float4 loads per thread and point
     // [2 points][3 planes] + [2 buffers][KQ][32 cols][PS] partial tiles + anchor table + statistics staging
-    static constexpr size_t lds_bytes = (size_t)2 * 3 * PLANE * 2 + (size_t)2 * KQ * 32 * PS * 4 + NA * 12 * 4 + (size_t)2 * NT * 8;
+    static constexpr size_t lds_bytes = (size_t)2 * NPL * PLANE * 2 + (size_t)2 * KQ * 32 * PS * 4 + NA * 12 * 4 + (size_t)2 * NT * 8;
 };
 
 // The kernel is a pipeline of PHASES (point, anchor half).  In phase (pt, half) a wave
@@ -60,20 +65,20 @@ struct WsShape {
 // Nothing in a phase is conditional (rows and stores of points past the end go through zero-sized buffer resources: loads return 0, stores
 // are dropped; anchors 60..63 of a tile fall outside the point's 60 x C records), so a phase is ONE basic block.
 #define SROW_REGS_C(C) ((C) <= 32)
-template <int C, bool NORM, bool STATS>     // NORM: mean / rstd given (InstanceNorm + LeakyReLU on load); STATS: stat_part given
+template <int C, bool NORM, bool STATS, bool F16 = false>     // NORM: mean / rstd given (InstanceNorm + LeakyReLU on load); STATS: stat_part given
 __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total, int pts_per_batch, const float* __restrict__ X,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const int* __restrict__ intra_idx, const bf16x8* __restrict__ Wq,
                                                                  const float* __restrict__ bias, float* __restrict__ Y,
                                                                  double* __restrict__ stat_part, unsigned* __restrict__ ctr) {
     __shared__ unsigned s_grab;
-    using S = WsShape<C>;
-    constexpr int NT = S::NT, MT = S::MT, KQ = S::KQ, NKS = S::NKS, LDB = S::LDB, PS = S::PS, PLANE = S::PLANE, NPRE = S::NPRE;
+    using S = WsShape<C, F16>;
+    constexpr int NT = S::NT, MT = S::MT, KQ = S::KQ, NKS = S::NKS, LDB = S::LDB, PS = S::PS, PLANE = S::PLANE, NPRE = S::NPRE, NPL = S::NPL;
     constexpr int SPT = C / 16;                   // K steps per tap
     constexpr int PBYTES = NA * C * 4;            // bytes of one point's rows
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned short* planes = reinterpret_cast<unsigned short*>(smem_raw);                    // [2 points][3][60][LDB]
-    float* part = reinterpret_cast<float*>(planes + 2 * 3 * PLANE);                          // [2 buffers][KQ][32 cols][PS]
+    unsigned short* planes = reinterpret_cast<unsigned short*>(smem_raw);                    // [2 points][NPL][60][LDB]
+    float* part = reinterpret_cast<float*>(planes + 2 * NPL * PLANE);                          // [2 buffers][KQ][32 cols][PS]
     int* iidx = reinterpret_cast<int*>(part + 2 * KQ * 32 * PS);                              // [60][12]
     double* dred = reinterpret_cast<double*>(iidx + NA * 12);                                 // [2][NT]
     int tid = threadIdx.x;
@@ -83,14 +88,15 @@ __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total,
     const int npairs = (npts_total + 1) >> 1;
 
     // ---- the wave's weight fragments, for the whole launch
-    bf16x8 aq[NKS][3];
+    bf16x8 aq[NKS][NPL];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) aq[ks][pl] = Wq[((((size_t)mt * KQ + kq) * NKS + ks) * 3 + pl) * 64 + lane];
+        for (int pl = 0; pl < NPL; ++pl) aq[ks][pl] = Wq[((((size_t)mt * KQ + kq) * NKS + ks) * NPL + pl) * 64 + lane];
     for (int e = tid; e < NA * 12; e += NT) iidx[e] = intra_idx[e];
     int o_out = tid % C;                          // the output channel this thread writes in every phase (NT % C == 0)
     const float bo = bias[o_out];
+    constexpr float oscale = F16 ? 0.015625f : 1.0f;      // F16: the weight planes carry 2^6 W (exact)
     __syncthreads();
     // source rows of this lane's anchors (both halves) for the wave's three taps
     // (C = 64: 144 registers of weight fragments leave no room for the six offsets -- 8 spilled registers -- so they are re-read from the LDS
@@ -132,11 +138,17 @@ __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total,
                 v.x = v.x > 0.f ? v.x : 0.01f * v.x; v.y = v.y > 0.f ? v.y : 0.01f * v.y;
                 v.z = v.z > 0.f ? v.z : 0.01f * v.z; v.w = v.w > 0.f ? v.w : 0.01f * v.w;
             }
-            uint2 ph, pm, pl;
-            ws_split3_pack4(v, ph, pm, pl);
             // (threads past the 60 rows write into the 8-element row padding region of row 59 .. never read: clamp instead of a branch)
             unsigned short* dst = P + (e < NA * (C / 4) ? row * LDB + c4 * 4 : (NA - 1) * LDB + C);
-            *reinterpret_cast<uint2*>(dst) = ph; *reinterpret_cast<uint2*>(dst + PLANE) = pm; *reinterpret_cast<uint2*>(dst + 2 * PLANE) = pl;
+            if constexpr (F16) {
+                uint2 ph, pl;
+                split2h_pack4(v, ph, pl);
+                *reinterpret_cast<uint2*>(dst) = ph; *reinterpret_cast<uint2*>(dst + PLANE) = pl;
+            } else {
+                uint2 ph, pm, pl;
+                ws_split3_pack4(v, ph, pm, pl);
+                *reinterpret_cast<uint2*>(dst) = ph; *reinterpret_cast<uint2*>(dst + PLANE) = pm; *reinterpret_cast<uint2*>(dst + 2 * PLANE) = pl;
+            }
         }
     };
     // ---- one phase's matrix work: planes P of the point, anchor half -> partial tile into pb
@@ -150,12 +162,18 @@ __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total,
 #pragma unroll
             for (int s_ = 0; s_ < SPT; ++s_) {
                 const int ks = tl * SPT + s_;
-                bf16x8 bq[3];
+                bf16x8 bq[NPL];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bq[pl] = *reinterpret_cast<const bf16x8*>(xrow + pl * PLANE + 16 * s_);
+                for (int pl = 0; pl < NPL; ++pl) bq[pl] = *reinterpret_cast<const bf16x8*>(xrow + pl * PLANE + 16 * s_);
                 // smallest cross products first
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks][2], bq[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks][0], bq[2], acc, 0, 0, 0);
+                if constexpr (F16) {
+#define WS_H(a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aq[ks][a]), __builtin_bit_cast(f16x8, bq[b]), acc, 0, 0, 0)
+                    WS_H(1, 0); WS_H(0, 1); WS_H(0, 0);
+#undef WS_H
+                    continue;
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks][2 % NPL], bq[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks][0], bq[2 % NPL], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks][1], bq[1], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks][1], bq[0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks][0], bq[1], acc, 0, 0, 0);
@@ -179,7 +197,7 @@ __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total,
             float v = pb[col * PS + o_out];
 #pragma unroll
             for (int q = 1; q < KQ; ++q) v += pb[(q * 32 + col) * PS + o_out];
-            v += bo;
+            v = v * oscale + bo;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (a * C + o_out) * 4, 0, 0);      // anchors 60..63 / points past the end: dropped
             const double dv = (ok && a < NA) ? (double)v : 0.0;
             st_s += dv; st_q += dv * dv;
@@ -208,7 +226,7 @@ __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total,
         }
     };
     unsigned short* P0 = planes;
-    unsigned short* P1 = planes + 3 * PLANE;
+    unsigned short* P1 = planes + NPL * PLANE;
     float* part0 = part;
     float* part1 = part + KQ * 32 * PS;
     int pp = blockIdx.x;
@@ -267,11 +285,11 @@ __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total,
     finish_stats(prev_pp);
 }
 
-template <int C, bool NORM, bool STATS>
+template <int C, bool NORM, bool STATS, bool F16>
 static int launch_intra_ws_t(int npts, int ppb, const float* X, const float* mean, const float* rstd, const int* intra_idx, const void* Wq,
                              const float* bias, float* Y, double* stat_part, hipStream_t st) {
-    using S = WsShape<C>;
-    auto kern = intra_so3conv_ws_kernel<C, NORM, STATS>;
+    using S = WsShape<C, F16>;
+    auto kern = intra_so3conv_ws_kernel<C, NORM, STATS, F16>;
     static bool ready = false;
     if (!ready) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::lds_bytes);
@@ -287,12 +305,12 @@ static int launch_intra_ws_t(int npts, int ppb, const float* X, const float* mea
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }
-template <int C>
+template <int C, bool F16>
 static int launch_intra_ws(int npts, int ppb, const float* X, const float* mean, const float* rstd, const int* intra_idx, const void* Wq,
                            const float* bias, float* Y, double* stat_part, hipStream_t st) {
     if (stat_part && (ppb % 2) != 0) return ETCH_EUNSUPPORTED;          // a pair's points must belong to one sample
     if ((mean == nullptr) != (rstd == nullptr)) return ETCH_EINVAL;
-#define WS_GO(N, S_) return launch_intra_ws_t<C, N, S_>(npts, ppb, X, mean, rstd, intra_idx, Wq, bias, Y, stat_part, st)
+#define WS_GO(N, S_) return launch_intra_ws_t<C, N, S_, F16>(npts, ppb, X, mean, rstd, intra_idx, Wq, bias, Y, stat_part, st)
     if (mean) { if (stat_part) WS_GO(true, true); WS_GO(true, false); }
     if (stat_part) WS_GO(false, true);
     WS_GO(false, false);
@@ -307,7 +325,18 @@ extern "C" int etch_intra_so3conv_split(int b, int c, int cout, int p, const flo
     if (b <= 0 || p <= 0) return ETCH_OK;
     if (c != cout || !Wq) return ETCH_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if (c == 32) return launch_intra_ws<32>(b * p, p, X, mean, rstd, intra_idx, Wq, bias, Y, stat_part, st);
-    if (c == 64) return launch_intra_ws<64>(b * p, p, X, mean, rstd, intra_idx, Wq, bias, Y, stat_part, st);
+    if (c == 32) return launch_intra_ws<32, false>(b * p, p, X, mean, rstd, intra_idx, Wq, bias, Y, stat_part, st);
+    if (c == 64) return launch_intra_ws<64, false>(b * p, p, X, mean, rstd, intra_idx, Wq, bias, Y, stat_part, st);
+    return ETCH_EUNSUPPORTED;
+}
+
+// The same on the fp16 matrix cores with two planes per operand.  Wqh = ops.intra_weight_split_f16: the layout above with two fp16 planes of 2^6 W2.
+extern "C" int etch_intra_so3conv_f16(int b, int c, int cout, int p, const float* X, const float* mean, const float* rstd, const int* intra_idx,
+                                      const void* Wqh, const float* bias, float* Y, double* stat_part, void* stream) {
+    if (b <= 0 || p <= 0) return ETCH_OK;
+    if (c != cout || !Wqh) return ETCH_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (c == 32) return launch_intra_ws<32, true>(b * p, p, X, mean, rstd, intra_idx, Wqh, bias, Y, stat_part, st);
+    if (c == 64) return launch_intra_ws<64, true>(b * p, p, X, mean, rstd, intra_idx, Wqh, bias, Y, stat_part, st);
     return ETCH_EUNSUPPORTED;
 }

@@ -290,6 +290,19 @@ def intra_weight_split(w2):
     return q.permute(1, 3, 4, 0, 5, 2, 6).contiguous().reshape(-1)       # [mt][kq][ks][pl][kg][i][e]
 
 
+def intra_weight_split_f16(w2):
+    """W2 [C, 12 C] -> the fragments of etch_intra_so3conv_f16: intra_weight_split's order with TWO fp16 planes of 2^6 W2 (h = fp16(64 W), l = fp16(64 W - h);
+    the scale is exact and keeps the residual plane of Xavier-sized weights normal, the kernel's epilogue multiplies by 2^-6)."""
+    C, K = w2.shape
+    assert K == 12 * C and C in (32, 64)
+    nks = 3 * C // 16
+    w64 = w2 * 64.0
+    hi = w64.to(torch.float16)
+    planes = torch.stack([hi, (w64 - hi.float()).to(torch.float16)])    # [2][C][K]
+    q = planes.reshape(2, C // 32, 32, 4, nks, 2, 8)                     # [pl][mt][i][kq][ks][kg][e]
+    return q.permute(1, 3, 4, 0, 5, 2, 6).contiguous().reshape(-1).view(torch.int16)       # [mt][kq][ks][pl][kg][i][e]
+
+
 def inter_weight_frag32(W, cin, ks=24):
     """Fragment order of the 32x32x2 inter conv (csrc/so3conv32.hip): [slice = 3 h + g][mt][kp][u][lane][4] with
     [lane][s] = W[32 mt + lane % 32][(32 h + c) * 24 + 8 g + 4 (lane / 32) + s], c = kp * NU + u -- h = 32-channel tile of the input,
@@ -455,9 +468,10 @@ def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, orde
 
 INTRA_MFMA32 = os.environ.get("ETCH_INTRA_MFMA32", "1") != "0"     # widths 32 / 64: the 32x32x2 MFMA form (ETCH_INTRA_MFMA32=0: the 16x16x4 kernel)
 INTRA_SPLIT = os.environ.get("ETCH_INTRA_SPLIT", "1") != "0"       # widths 32 / 64: weight-stationary on the bf16 matrix cores, split fp32 operands
+INTRA_F16 = os.environ.get("ETCH_INTRA_SPLIT", "1") != "bf16"     # ... as two fp16 planes and three cross terms (round 5); "bf16": the three-plane bf16 form
 
 
-def intra_so3conv(x_cl, intra_idx32, Wp, bias, cout, mean=None, rstd=None, want_stats=False, Wp32=None, Wq=None):
+def intra_so3conv(x_cl, intra_idx32, Wp, bias, cout, mean=None, rstd=None, want_stats=False, Wp32=None, Wq=None, Wqh=None):
     """want_stats: also return the InstanceNorm (mean, rstd) of the output, accumulated in the conv's epilogue (even point counts;
     otherwise by the separate statistics pass)."""
     b, p, na, c = x_cl.shape
@@ -465,7 +479,11 @@ def intra_so3conv(x_cl, intra_idx32, Wp, bias, cout, mean=None, rstd=None, want_
     out = torch.empty((b, p, 60, cout), dtype=torch.float32, device=x_cl.device)
     fused = want_stats and p % 2 == 0 and c <= 64        # wider tiles (encoder depths 3 / 4) take the separate statistics pass
     part = torch.empty((b * (p // 2), 2, cout), dtype=torch.float64, device=x_cl.device) if fused else None
-    if Wq is not None and INTRA_SPLIT and c == cout and c in (32, 64) and (part is None or p % 2 == 0):
+    if Wqh is not None and INTRA_SPLIT and INTRA_F16 and c == cout and c in (32, 64) and (part is None or p % 2 == 0):
+        _need(Wqh, torch.int16, "Wqh")
+        _lib.check(_lib.lib().etch_intra_so3conv_f16(b, c, cout, p, _ptr(x_cl), _optptr(mean), _optptr(rstd), _ptr(intra_idx32), _ptr(Wqh),
+                                                    _ptr(bias), _ptr(out), _optptr(part), _stream()), "etch_intra_so3conv_f16")
+    elif Wq is not None and INTRA_SPLIT and c == cout and c in (32, 64) and (part is None or p % 2 == 0):
         _need(Wq, torch.int16, "Wq")
         _lib.check(_lib.lib().etch_intra_so3conv_split(b, c, cout, p, _ptr(x_cl), _optptr(mean), _optptr(rstd), _ptr(intra_idx32), _ptr(Wq),
                                                       _ptr(bias), _ptr(out), _optptr(part), _stream()), "etch_intra_so3conv_split")

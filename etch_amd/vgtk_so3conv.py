@@ -245,6 +245,7 @@ class IntraSO3Conv(nn.Module):
         self.register_buffer("intra_idx", torch.from_numpy(intra_idx).long())
         self._d = _Derived()
         self._wq = None
+        self._wqh = None
 
     def _derived(self):
         W, bias = self.basic_conv.W, self.basic_conv.bias
@@ -255,6 +256,7 @@ class IntraSO3Conv(nn.Module):
             W2 = W.detach().view(self.dim_out, c, ks).permute(0, 2, 1).reshape(self.dim_out, ks * c).contiguous()
             Wp32 = ops.permute_weight_frag32(W2) if (c == self.dim_out and c in (32, 64)) else None       # the 32x32x2 kernel's fragment order
             self._wq = ops.intra_weight_split(W2) if (c == self.dim_out and c in (32, 64)) else None       # the weight-stationary split kernel's
+            self._wqh = ops.intra_weight_split_f16(W2) if (c == self.dim_out and c in (32, 64)) else None  # ... and its two-plane fp16 form's
             return ops.permute_weight_frag(W2), bias.detach().reshape(-1).contiguous(), self.intra_idx.to(torch.int32).contiguous(), Wp32
 
         return self._d.get((W, bias, self.intra_idx), build)
@@ -262,11 +264,11 @@ class IntraSO3Conv(nn.Module):
     def forward(self, x, mean=None, rstd=None, want_stats=False):
         Wp, bias, idx32, Wp32 = self._derived()
         if want_stats:
-            y, stats = ops.intra_so3conv(x.feats_cl, idx32, Wp, bias, self.dim_out, mean, rstd, want_stats=True, Wp32=Wp32, Wq=self._wq)
+            y, stats = ops.intra_so3conv(x.feats_cl, idx32, Wp, bias, self.dim_out, mean, rstd, want_stats=True, Wp32=Wp32, Wq=self._wq, Wqh=self._wqh)
             cloud = SphericalPointCloud(x.xyz, None, self.anchors, feats_cl=y)
             cloud.in_stats = stats      # InstanceNorm (mean, rstd) of the output, a by-product of the conv's epilogue
             return cloud
-        y = ops.intra_so3conv(x.feats_cl, idx32, Wp, bias, self.dim_out, mean, rstd, Wp32=Wp32, Wq=self._wq)
+        y = ops.intra_so3conv(x.feats_cl, idx32, Wp, bias, self.dim_out, mean, rstd, Wp32=Wp32, Wq=self._wq, Wqh=self._wqh)
         return SphericalPointCloud(x.xyz, None, self.anchors, feats_cl=y)
 
 

@@ -230,6 +230,12 @@ int etch_intra_so3conv32(int b, int c, int cout, int p, const float* X, const fl
 int etch_intra_so3conv_split(int b, int c, int cout, int p, const float* X, const float* mean, const float* rstd, const int* intra_idx,
                              const void* Wq, const float* bias, float* Y, double* stat_part, void* stream);
 
+/* Round 5: the same kernel on v_mfma_f32_32x32x16_f16 with TWO fp16 planes per operand (h = fp16(x) by truncation, l = fp16(x - h); three cross
+ * products; for this path's unit-scale operands the fp32 MFMA's error against fp64, profiles/r05_f16_two_plane_split.txt).  Wqh = etch_amd/ops.py
+ * intra_weight_split_f16: [mt][kq][K step][plane h / l][lane][8 fp16] of 2^6 W2 (the kernel's epilogue multiplies by 2^-6: exact). */
+int etch_intra_so3conv_f16(int b, int c, int cout, int p, const float* X, const float* mean, const float* rstd, const int* intra_idx,
+                           const void* Wqh, const float* bias, float* Y, double* stat_part, void* stream);
+
 /* InstanceNorm2d(affine=False, eps=1e-5) statistics over (p,a) per (b,c) (src/models/so3conv.py:24,85,168).
  * x (b,rows,C) -> mean (b,C), rstd (b,C).  workspace: etch_instnorm_stats_workspace_bytes(b, C) bytes. */
 int etch_instnorm_stats(int b, int rows, int C, const float* x, double* workspace, float* mean, float* rstd, void* stream);

@@ -63,7 +63,7 @@ for f in sorted(glob.glob(os.path.join(root, "etch_amd", "csrc", "*"))):
 for o in outs:
     json.dump(h, open(o, "w"), indent=1, sort_keys=True)
 PY
-cp $O/${tag}_pmc_traffic.json.sources.json $R/profiles/
+cp $O/${tag}_pmc_traffic.json.sources.json $O/${tag}_pmc_mfma.txt $O/${tag}_pmc_mfma.txt.sources.json $R/profiles/
 # the bench lines themselves (default run with the CPU baseline; forward only; the dense SMPL-X-sized config; two ranks on this one GPU)
 python3 $R/bench.py > $O/${tag}_bench_line_default_run.json 2> $O/bench_default.err
 python3 $R/bench.py --config 1 --steps 10 > $O/${tag}_bench_line_config1_forward_only.json 2> $O/bench_c1.err

@@ -216,3 +216,37 @@ def test_direction_tail_inside_the_last_attention_layer_matches_the_two_kernel_f
     if T > 1:
         solo = ops.mhsa_layer_dirtail(x2[:60].contiguous(), wq, wk, wv, Wfq, tab)
         assert torch.equal(solo[0], fused[0])
+
+
+@pytest.mark.parametrize("c,p,b,normed", [(64, 256, 2, True), (32, 512, 2, False), (64, 57, 3, True), (32, 1, 1, True), (64, 2, 1, False), (32, 2500, 1, True)])
+def test_intra_conv_two_plane_f16_matches_the_fp32_kernel_and_fp64(c, p, b, normed):
+    """etch_intra_so3conv_f16 (the weight-stationary intra conv on v_mfma_f32_32x32x16_f16, two fp16 planes per operand, three cross terms)
+    against the fp32 kernel, the three-plane bf16 form and the fp64 formula (functional.py:331-378 + modules.py:150-153; InstanceNorm +
+    LeakyReLU on load as so3conv.py:96-99): the same bars as the bf16 split's test (tests/test_gpu_encoder.py)."""
+    from etch_amd import ops
+    from etch_amd import vgtk_so3conv as V
+    g = torch.Generator().manual_seed(c + p)
+    conv = load_seeded(V.IntraSO3Conv(c, c), 5).cuda()
+    Wp, bias, idx32, Wp32 = conv._derived()
+    assert conv._wqh is not None and conv._wqh.dtype == torch.int16 and conv._wqh.numel() * 3 == conv._wq.numel() * 2
+    x = (torch.randn(b, p, 60, c, generator=g) * 2 + 0.5).cuda()
+    mm, rr = ops.instnorm_stats(x) if normed else (None, None)
+    ws = p % 2 == 0
+    new = ops.intra_so3conv(x, idx32, Wp, bias, c, mm, rr, Wq=conv._wq, Wqh=conv._wqh, want_stats=ws)
+    f32 = ops.intra_so3conv(x, idx32, Wp, bias, c, mm, rr, want_stats=ws)
+    b16 = ops.intra_so3conv(x, idx32, Wp, bias, c, mm, rr, Wq=conv._wq)
+    if ws:
+        (new, (m1, r1)), (f32, (m0, r0)) = new, f32
+        assert rel_err(m1.cpu().numpy(), m0.cpu().numpy()) < 2e-6 and rel_err(r1.cpu().numpy(), r0.cpu().numpy()) < 2e-6
+    assert torch.equal(new, ops.intra_so3conv(x, idx32, Wp, bias, c, mm, rr, Wqh=conv._wqh))
+    scale = float(f32.abs().max())
+    assert float((new - f32).abs().max()) < 3e-6 * scale
+    assert float((new - b16).abs().max()) < 2e-6 * scale
+    xd = x.double()
+    if normed:
+        xd = (xd - mm.double()[:, None, None]) * rr.double()[:, None, None]
+        xd = torch.where(xd > 0, xd, 0.01 * xd)
+    W3 = conv.basic_conv.W.detach().double().view(c, c, 12)                              # [o][ch][tap]
+    ref = torch.einsum("bpatc,oct->bpao", xd[:, :, conv.intra_idx.cuda()], W3) + bias.double()
+    e_new, e_f32 = float((new.double() - ref).abs().max()), float((f32.double() - ref).abs().max())
+    assert e_f32 < 3e-6 * scale and e_new <= 2.0 * e_f32 + 1e-7 * scale, (e_new, e_f32)
