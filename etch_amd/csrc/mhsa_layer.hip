@@ -44,13 +44,122 @@ __device__ __forceinline__ float ml_xsum(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// softmax over the 64 (60 valid) keys of one query, scores spread over the 4 lane groups x 16 registers; returns P / sum
-__device__ __forceinline__ void ml_softmax(f32x4 (&s)[4], int fg) {
-    const float c = 0.35355339059327373f * 1.4426950408889634f;     // 1/sqrt(8) * log2(e)
-    // keys 60..63 do not exist: their scores arrive as -1e30 (the accumulators of the last key tile start there in lane group 3)
-    float m = -INFINITY;
+// ---- Round 5: every product of the layer on the fp16 matrix cores (v_mfma_f32_16x16x32_f16) from TWO fp16 planes per operand (split_bf16.h:
+// h = fp16(x), l = fp16(x - h): 22 mantissa bits; cross terms l h + h l + h h, the score product also l l), fp32 accumulation.  Per wave and point:
+// 72 + 32 + 48 MFMAs instead of 144 bf16 (six cross terms of the three-plane split) + 192 fp32 16x16x4 ones -- the attention phase's fp32 MFMAs were
+// 73 % of the layer's matrix time (profiles/r05_mhsa_f16.txt).
+//   Range: fp16 planes carry 22 bits only for |h| >= 2^-3, so nothing here relies on the operands' natural scale -- every operand is brought to a
+//   known power-of-two range first and the powers are taken out again where a scalar is applied anyway:
+//     token tile   x 2^kx, max |x| 2^kx in [8, 16) (the tile's maximum is found while the previous point computes);
+//     weights      x 2^kw likewise (once per workgroup, in the kernel);  |q|, |k|, |v| accumulators <= 64 * 16 * 16 = 2^14 -- inside fp16's range, so
+//                  they are split as they stand; the scores' power 2^-(2 kx + kq + kk) rides on the softmax's 1/sqrt(8) log2(e) factor;
+//     softmax      P x 2^13 (the factor of the normalisation), attention output x 2^-13 x 2^-(kx + kv) on its way out (or later: head_combine and the
+//                  fused tail take it at <= 2^14 and apply the power with their own epilogue factor).
+//   All powers of two: exact.  Elements below 2^-3 after scaling (2^-7 of the tile's maximum) keep an absolute error of 2^-25 -- 2^-29 of the maximum,
+//   under the fp32 MFMA's own rounding of the sums they enter.
+// The C/D layout of v_mfma_f32_16x16x32_f16 is that of v_mfma_f32_16x16x4_f32: the projections' accumulators are still the attention phase's operands
+// (lane (fr, fg) of the Q^T / K^T tiles holds dims 2 fg, 2 fg + 1 of both heads for token fr = its own slots 8 fg .. 8 fg + 7 of a K = 32 step).
+#define ML_PL (64 * 64)      // fp16 elements of one plane of a 64 x 64 tile: rows of 128 bytes, 16-byte units XOR-swizzled with the row
+__device__ __forceinline__ int ml_sw(int row, int k) { return row * 64 + ((((k) >> 3) ^ (row & 7)) << 3) + (k & 7); }
+#define ML_MFMAH(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+typedef unsigned ml_u32x4 __attribute__((ext_vector_type(4)));
+
+// maximum over the wave of a non-negative value: quad / half-row / row mirrors inside the rows of 16 (DPP), swaps across the lane groups
+__device__ __forceinline__ float ml_wave_max(float v) {
+#define ML_DPP(C) v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), (C), 0xf, 0xf, true)));
+    ML_DPP(0xB1) ML_DPP(0x4E) ML_DPP(0x141) ML_DPP(0x140)
+#undef ML_DPP
+    return ml_xmax(v);
+}
+// v_max3_f32 as written (fmaxf chains carry a canonicalising v_max_f32 x, x per operand that comes from memory or an MFMA: 240 instead of 64 operations per point)
+__device__ __forceinline__ float ml_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float ml_max3abs(float a, float b, float c) { float r; asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float ml_max4(const float4 v, float m) { return ml_max3abs(v.z, v.w, ml_max3abs(v.x, v.y, m)); }
+// k with m 2^k in [8, 16) (m = 0 or subnormal: 0; capped so that 2^k is a float)
+__device__ __forceinline__ int ml_scale_exp(float m) {
+    const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
+    return e == 0 ? 0 : (130 - e < 120 ? 130 - e : 120);
+}
+
+// float4 number e (row e >> 4, channels 4 (e & 15) ..) of a token tile, times the tile's power of two -> the two planes
+__device__ __forceinline__ void ml_stage4(unsigned short* P, int e, const float4 v, float s) {
+    uint2 ph, pl;
+    split2h_pack4(make_float4(v.x * s, v.y * s, v.z * s, v.w * s), ph, pl);
+    unsigned short* d = P + ml_sw(e >> 4, (e & 15) * 4);
+    *reinterpret_cast<uint2*>(d) = ph;
+    *reinterpret_cast<uint2*>(d + ML_PL) = pl;
+}
+// three cross products of one K = 32 step, smallest first
+#define ML_HX3(ACC, A, B) ACC = ML_MFMAH(A[1], B[0], ACC); ACC = ML_MFMAH(A[0], B[1], ACC); ACC = ML_MFMAH(A[0], B[0], ACC);
+
+struct MlWeights {          // fragments of this wave's tiles (x 2^kw), K step ks = channels 32 ks + 8 fg .. + 7 of row / column fr; planes h, l
+    f16x8 q[2][2], k[2][2], v[2][2], c[2][2];
+    int kq, kk, kv, kc;     // the powers
+};
+// red: 16 floats of LDS; ends with a barrier
+template <bool COMBINE>
+__device__ __forceinline__ void ml_load_weights(MlWeights& W, const float* __restrict__ Wq, const float* __restrict__ Wk, const float* __restrict__ Wv,
+                                                const float* __restrict__ Wc, float* red, int tid, int w, int fr, int fg) {
+    const float* Ws[4] = {Wq, Wk, Wv, Wc};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) m = fmaxf(fmaxf(fmaxf(s[j][0], s[j][1]), fmaxf(s[j][2], s[j][3])), m);
+    for (int j = 0; j < (COMBINE ? 4 : 3); ++j) {
+        float m = 0.f;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) m = ml_max4(reinterpret_cast<const float4*>(Ws[j])[tid + 256 * h], m);
+        m = ml_wave_max(m);
+        if ((tid & 63) == 0) red[4 * j + w] = m;
+    }
+    __syncthreads();
+    int kw[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < (COMBINE ? 4 : 3); ++j) kw[j] = ml_scale_exp(fmaxf(fmaxf(red[4 * j], red[4 * j + 1]), fmaxf(red[4 * j + 2], red[4 * j + 3])));
+    W.kq = kw[0]; W.kk = kw[1]; W.kv = kw[2]; W.kc = kw[3];
+    const int chq = 8 * (2 * w + ((fr & 3) >> 1)) + 2 * (fr >> 2) + (fr & 1);    // Q/K tile row fr -> original channel
+    const int chv = 16 * w + fr;
+#define ML_W8(P, K, OUT)                                                                                           \
+    {                                                                                                              \
+        const float s_ = ldexpf(1.0f, (K));                                                                        \
+        const float4 a_ = *reinterpret_cast<const float4*>(P), b_ = *reinterpret_cast<const float4*>((P) + 4);      \
+        split2h_pack8(make_float4(a_.x * s_, a_.y * s_, a_.z * s_, a_.w * s_), make_float4(b_.x * s_, b_.y * s_, b_.z * s_, b_.w * s_), OUT[0], OUT[1]); \
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int o = ks * 32 + fg * 8;
+        ML_W8(Wq + chq * ML_C + o, W.kq, W.q[ks])
+        ML_W8(Wk + chq * ML_C + o, W.kk, W.k[ks])
+        ML_W8(Wv + chv * ML_C + o, W.kv, W.v[ks])
+        if (COMBINE) ML_W8(Wc + chv * ML_C + o, W.kc, W.c[ks])
+    }
+}
+// A: projections of this wave's two heads from the token planes
+__device__ __forceinline__ void ml_project(const unsigned short* Xp, const MlWeights& W, f32x4 (&Q)[4], f32x4 (&Kt)[4], f32x4 (&V)[4], int fr, int fg) {
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        f32x4 q = {0.f, 0.f, 0.f, 0.f}, k = q, v = q;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 x[2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) x[pl] = *reinterpret_cast<const f16x8*>(Xp + pl * ML_PL + ml_sw(tt * 16 + fr, ks * 32 + fg * 8));
+            // term-major over q / k / v: consecutive MFMAs are independent
+#define ML_T(PA, PB) q = ML_MFMAH(W.q[ks][PA], x[PB], q); k = ML_MFMAH(W.k[ks][PA], x[PB], k); v = ML_MFMAH(x[PB], W.v[ks][PA], v);
+            ML_T(1, 0) ML_T(0, 1) ML_T(0, 0)
+#undef ML_T
+        }
+        Q[tt] = q; Kt[tt] = k; V[tt] = v;
+    }
+}
+// softmax over the 64 (60 valid) keys of one query, scores spread over the 4 lane groups x 16 registers, c = the scores' factor (1/sqrt(8) log2(e) and
+// their power of two); returns 2^13 P
+__device__ __forceinline__ void ml_softmax(f32x4 (&s)[4], float c) {
+    // keys 60..63 do not exist: their scores arrive as -inf (the accumulators of the last key tile start there in lane group 3)
+    float m = ml_max3(s[0][0], s[0][1], s[0][2]);
+    m = ml_max3(m, s[0][3], s[1][0]);
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        m = ml_max3(m, s[j][1], s[j][2]);
+        m = ml_max3(m, s[j][3], s[j < 3 ? j + 1 : 0][0]);
+    }
     m = ml_xmax(m);
     const float mc = m * c;
     float sum = 0.f;
@@ -63,182 +172,103 @@ __device__ __forceinline__ void ml_softmax(f32x4 (&s)[4], int fg) {
             sum += p;
         }
     sum = ml_xsum(sum);
-    const float inv = 1.0f / sum;
+    float inv = __builtin_amdgcn_rcpf(sum);          // + one Newton step: the quotient to an ulp in 4 operations instead of the division's 10
+    inv = fmaf(fmaf(-sum, inv, 1.0f), inv, inv) * 8192.0f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) s[j] *= inv;
 }
-
-// ---- the four dense products of the layer (q / k / v transforms, head_combine: 57 % of its MFMAs) on the bf16 matrix cores with exactly split
-// fp32 operands: x = hi + mid + lo (8 + 8 + 8 mantissa bits, by truncation), the six largest cross products accumulated in fp32 by
-// v_mfma_f32_16x16x32_bf16 -- the error against fp64 of the fp32 MFMA (profiles/r03_bf16x3_split.txt) at 2.3 x its rate, and beside the VALU
-// instead of on its datapath.  Their C/D layout is that of v_mfma_f32_16x16x4_f32, so the attention phase -- whose operands ARE the
-// projections' accumulators -- is untouched (it stays on the fp32 MFMA: its operands are produced per use).  The weights are split once per
-// workgroup (registers), the token tile when it is staged in LDS, the attention output when it is stored for head_combine.
-#define ML_PL (64 * 64)      // bf16 elements of one plane of a 64 x 64 tile: rows of 128 bytes, 16-byte units XOR-swizzled with the row (no padding:
-                             // three planes of a tile take 24.6 KB against 26.6 KB of the padded fp32 tile, so three workgroups still share a CU)
-__device__ __forceinline__ int ml_sw(int row, int k) { return row * 64 + ((((k) >> 3) ^ (row & 7)) << 3) + (k & 7); }
-#define ML_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
-
-__device__ __forceinline__ void ml_split(const float v, unsigned& h, unsigned& m, unsigned& l) {
-    h = __float_as_uint(v);
-    const float r = v - __uint_as_float(h & 0xffff0000u);
-    m = __float_as_uint(r);
-    l = __float_as_uint(r - __uint_as_float(m & 0xffff0000u));
-}
-// 8 consecutive fp32 values -> 3 planes x 8 bf16
-__device__ __forceinline__ void ml_split8(const float4 v0, const float4 v1, bf16x8 (&o)[3]) {
-    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    unsigned h[8], m[8], l[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ml_split(v[i], h[i], m[i], l[i]);
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    // v_perm_b32: bytes 2, 3 of the even element below bytes 2, 3 of the odd one
-#define ML_PK(a) (u32x4){__builtin_amdgcn_perm(a[1], a[0], 0x07060302u), __builtin_amdgcn_perm(a[3], a[2], 0x07060302u), \
-                         __builtin_amdgcn_perm(a[5], a[4], 0x07060302u), __builtin_amdgcn_perm(a[7], a[6], 0x07060302u)}
-    const u32x4 ph = ML_PK(h), pm = ML_PK(m), pl = ML_PK(l);
-#undef ML_PK
-    o[0] = __builtin_bit_cast(bf16x8, ph); o[1] = __builtin_bit_cast(bf16x8, pm); o[2] = __builtin_bit_cast(bf16x8, pl);
-}
-// float4 number e (row e >> 4, channels 4 (e & 15) ..) of a token tile -> the three planes
-__device__ __forceinline__ void ml_stage4(unsigned short* P, int e, const float4 v4) {
-    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
-    unsigned h[4], m[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ml_split(v[i], h[i], m[i], l[i]);
-    unsigned short* d = P + ml_sw(e >> 4, (e & 15) * 4);
-    *reinterpret_cast<uint2*>(d) = make_uint2(__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u));
-    *reinterpret_cast<uint2*>(d + ML_PL) = make_uint2(__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u));
-    *reinterpret_cast<uint2*>(d + 2 * ML_PL) = make_uint2(__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u));
-}
-// six cross products of one K = 32 step, smallest first
-#define ML_BX6(ACC, A, B)                                                                                   \
-    ACC = ML_MFMA16(A[2], B[0], ACC); ACC = ML_MFMA16(A[0], B[2], ACC); ACC = ML_MFMA16(A[1], B[1], ACC);  \
-    ACC = ML_MFMA16(A[1], B[0], ACC); ACC = ML_MFMA16(A[0], B[1], ACC); ACC = ML_MFMA16(A[0], B[0], ACC);
-
-struct MlWeights {          // fragments of this wave's tiles, K step ks = channels 32 ks + 8 fg .. + 7 of row / column fr
-    bf16x8 q[2][3], k[2][3], v[2][3], c[2][3];
-};
-template <bool COMBINE>
-__device__ __forceinline__ void ml_load_weights(MlWeights& W, const float* __restrict__ Wq, const float* __restrict__ Wk, const float* __restrict__ Wv,
-                                                const float* __restrict__ Wc, int w, int fr, int fg) {
-    const int chq = 8 * (2 * w + ((fr & 3) >> 1)) + 2 * (fr >> 2) + (fr & 1);    // Q/K tile row fr -> original channel
-    const int chv = 16 * w + fr;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const int o = ks * 32 + fg * 8;
-        ml_split8(*reinterpret_cast<const float4*>(Wq + chq * ML_C + o), *reinterpret_cast<const float4*>(Wq + chq * ML_C + o + 4), W.q[ks]);
-        ml_split8(*reinterpret_cast<const float4*>(Wk + chq * ML_C + o), *reinterpret_cast<const float4*>(Wk + chq * ML_C + o + 4), W.k[ks]);
-        ml_split8(*reinterpret_cast<const float4*>(Wv + chv * ML_C + o), *reinterpret_cast<const float4*>(Wv + chv * ML_C + o + 4), W.v[ks]);
-        if (COMBINE) ml_split8(*reinterpret_cast<const float4*>(Wc + chv * ML_C + o), *reinterpret_cast<const float4*>(Wc + chv * ML_C + o + 4), W.c[ks]);
-    }
-}
-// A: projections of this wave's two heads from the token planes
-__device__ __forceinline__ void ml_project(const unsigned short* Xp, const MlWeights& W, f32x4 (&Q)[4], f32x4 (&Kt)[4], f32x4 (&V)[4], int fr, int fg) {
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-        f32x4 q = {0.f, 0.f, 0.f, 0.f}, k = q, v = q;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 x[3];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) x[pl] = *reinterpret_cast<const bf16x8*>(Xp + pl * ML_PL + ml_sw(tt * 16 + fr, ks * 32 + fg * 8));
-            // term-major over q / k / v: consecutive MFMAs are independent
-#define ML_T(PA, PB) q = ML_MFMA16(W.q[ks][PA], x[PB], q); k = ML_MFMA16(W.k[ks][PA], x[PB], k); v = ML_MFMA16(x[PB], W.v[ks][PA], v);
-            ML_T(2, 0) ML_T(0, 2) ML_T(1, 1) ML_T(1, 0) ML_T(0, 1) ML_T(0, 0)
-#undef ML_T
-        }
-        Q[tt] = q; Kt[tt] = k; V[tt] = v;
-    }
-}
-// B: attention of heads 2w (registers 0,1 / output columns 0-7) and 2w+1 (registers 2,3 / columns 8-15): scores on the fp32 MFMA (their operands are the
-// projections' accumulators as they stand; 8-dim heads fill only a quarter of a bf16 K step) and so does P V (see ML_PV_BF16); the output tile goes to
-// LDS as fp32 (As: the layer's output in MODE 2) or as the three planes of head_combine's operand (Ap)
+// B: attention of heads 2w (registers 0,1 / output columns 0-7) and 2w+1 (registers 2,3 / columns 8-15).  Score product: ONE MFMA per (key tile, query
+// tile, head) -- the lane's two dims of a head, as planes, fill its eight slots of the K = 32 step with all four cross terms:
+// K side [h h' | l l' | h h' | l l'], Q side [l l' | h h' | h h' | l l'].  P V: a lane's 16 probabilities and its 16 V accumulators belong to the SAME
+// keys (16 jt + 4 fg + r), so they are the lane's slices of the operands as they stand: K step ks = key tiles 2 ks, 2 ks + 1, element 4 (jt - 2 ks) + r.
+// cs: the scores' factor; the output tile, times os, goes to LDS as fp32 (As) or as the two planes of head_combine's operand (Ap)
 template <bool PLANES>
-__device__ __forceinline__ void ml_attention(const f32x4 (&Q)[4], const f32x4 (&Kt)[4], const f32x4 (&V)[4], float* As, unsigned short* Ap, int w, int fr, int fg) {
-#ifdef ML_PV_BF16
-    bf16x8 Vq[2][3];                                                   // the V accumulators as split operands, once per point
+__device__ __forceinline__ void ml_attention(const f32x4 (&Q)[4], const f32x4 (&Kt)[4], const f32x4 (&V)[4], float* As, unsigned short* Ap, float cs, float os,
+                                             int w, int fr, int fg) {
+    f16x8 KB[4][2], Vq[2][2];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int hd = 0; hd < 2; ++hd) {
+            unsigned h, l;
+            split2h_pair(Kt[tt][2 * hd], Kt[tt][2 * hd + 1], h, l);
+            KB[tt][hd] = __builtin_bit_cast(f16x8, (ml_u32x4){h, l, h, l});
+        }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
-        ml_split8(make_float4(V[2 * ks][0], V[2 * ks][1], V[2 * ks][2], V[2 * ks][3]),
-                  make_float4(V[2 * ks + 1][0], V[2 * ks + 1][1], V[2 * ks + 1][2], V[2 * ks + 1][3]), Vq[ks]);
-#endif
+        split2h_pack8(make_float4(V[2 * ks][0], V[2 * ks][1], V[2 * ks][2], V[2 * ks][3]),
+                      make_float4(V[2 * ks + 1][0], V[2 * ks + 1][1], V[2 * ks + 1][2], V[2 * ks + 1][3]), Vq[ks][0], Vq[ks][1]);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         f32x4 sa[4], sb[4];
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const float pad = fg == 3 ? -1e30f : 0.f;                     // padded keys 60..63 (tile 3, lane group 3): exp2 -> 0
+        const float pad = fg == 3 ? -INFINITY : 0.f;                     // padded keys 60..63 (tile 3, lane group 3): exp2 -> 0
         const f32x4 zpad = {pad, pad, pad, pad};
+        f16x8 QA[2];                                                   // this query tile's operands (the fp32 accumulators stay: 16 instead of 32 registers)
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-            sa[jt] = ML_MFMA(Kt[jt][0], Q[it][0], jt == 3 ? zpad : z);
-            sb[jt] = ML_MFMA(Kt[jt][2], Q[it][2], jt == 3 ? zpad : z);
+        for (int hd = 0; hd < 2; ++hd) {
+            unsigned h, l;
+            split2h_pair(Q[it][2 * hd], Q[it][2 * hd + 1], h, l);
+            QA[hd] = __builtin_bit_cast(f16x8, (ml_u32x4){l, h, h, l});
         }
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
-            sa[jt] = ML_MFMA(Kt[jt][1], Q[it][1], sa[jt]);
-            sb[jt] = ML_MFMA(Kt[jt][3], Q[it][3], sb[jt]);
+            sa[jt] = ML_MFMAH(KB[jt][0], QA[0], jt == 3 ? zpad : z);
+            sb[jt] = ML_MFMAH(KB[jt][1], QA[1], jt == 3 ? zpad : z);
         }
-        ml_softmax(sa, fg);
-        ml_softmax(sb, fg);
-#ifdef ML_PV_BF16      // measured SLOWER (interp layer 4.54 -> 4.77 ms, mode 2 3.68 -> 3.76): splitting 32 probabilities per lane and query tile costs more
-                       // VALU time than the 32 -> 24 cheaper MFMAs give back; kept as the record of the experiment (tests pass with it)
-        // P V on the bf16 matrix cores.  A lane's 16 probabilities and its 16 V accumulators belong to the SAME keys (16 jt + 4 fg + r), so they
-        // are the lane's slices of the 16x16x32 operands as they stand: K step ks = key tiles 2 ks, 2 ks + 1, element e = 4 (jt - 2 ks) + r.
+        // ml_softmax's first reads of the scores are inline asm (v_max3_f32), which the compiler's hazard recogniser does not see: a VALU read of an MFMA
+        // result needs up to 19 wait states (CDNA3 ISA 4.5) and the hardware does not interlock.  This block depends on all eight accumulators and
+        // everything after depends on it; MFMAs retire in order, so 20 wait states behind the last one cover them all (once per query tile: 80 cycles per point).
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(sa[3]), "+v"(sb[0]), "+v"(sb[1]), "+v"(sb[2]), "+v"(sb[3]));
+        ml_softmax(sa, cs);
+        ml_softmax(sb, cs);
         f32x4 o4[2][2] = {{z, z}, {z, z}};                             // [head][ks]: four independent chains
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 pa[3], pb[3];
-            ml_split8(make_float4(sa[2 * ks][0], sa[2 * ks][1], sa[2 * ks][2], sa[2 * ks][3]),
-                      make_float4(sa[2 * ks + 1][0], sa[2 * ks + 1][1], sa[2 * ks + 1][2], sa[2 * ks + 1][3]), pa);
-            ml_split8(make_float4(sb[2 * ks][0], sb[2 * ks][1], sb[2 * ks][2], sb[2 * ks][3]),
-                      make_float4(sb[2 * ks + 1][0], sb[2 * ks + 1][1], sb[2 * ks + 1][2], sb[2 * ks + 1][3]), pb);
-#define ML_T(PA, PB) o4[0][ks] = ML_MFMA16(pa[PA], Vq[ks][PB], o4[0][ks]); o4[1][ks] = ML_MFMA16(pb[PA], Vq[ks][PB], o4[1][ks]);
-            ML_T(2, 0) ML_T(0, 2) ML_T(1, 1) ML_T(1, 0) ML_T(0, 1) ML_T(0, 0)
+            f16x8 pa[2], pb[2];
+            split2h_pack8(make_float4(sa[2 * ks][0], sa[2 * ks][1], sa[2 * ks][2], sa[2 * ks][3]),
+                          make_float4(sa[2 * ks + 1][0], sa[2 * ks + 1][1], sa[2 * ks + 1][2], sa[2 * ks + 1][3]), pa[0], pa[1]);
+            split2h_pack8(make_float4(sb[2 * ks][0], sb[2 * ks][1], sb[2 * ks][2], sb[2 * ks][3]),
+                          make_float4(sb[2 * ks + 1][0], sb[2 * ks + 1][1], sb[2 * ks + 1][2], sb[2 * ks + 1][3]), pb[0], pb[1]);
+#define ML_T(PA, PB) o4[0][ks] = ML_MFMAH(pa[PA], Vq[ks][PB], o4[0][ks]); o4[1][ks] = ML_MFMAH(pb[PA], Vq[ks][PB], o4[1][ks]);
+            ML_T(1, 0) ML_T(0, 1) ML_T(0, 0)
 #undef ML_T
         }
         const f32x4 oa = o4[0][0] + o4[0][1], ob = o4[1][0] + o4[1][1];
-#else
-        f32x4 oa = z, ob = z;
+        const int col = 16 * w + fr;
+        if (PLANES) {
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                oa = ML_MFMA(sa[jt][r], V[jt][r], oa);
-                ob = ML_MFMA(sb[jt][r], V[jt][r], ob);
+            for (int r = 0; r < 4; r += 2) {
+                unsigned h, l;
+                split2h_pair((fr < 8 ? oa[r] : ob[r]) * os, (fr < 8 ? oa[r + 1] : ob[r + 1]) * os, h, l);
+                unsigned short* d = Ap + ml_sw(it * 16 + fg * 4 + r, col);           // rows r, r + 1: the same 16-byte unit only if their low bits agree -> two addresses
+                unsigned short* d1 = Ap + ml_sw(it * 16 + fg * 4 + r + 1, col);
+                d[0] = (unsigned short)(h & 0xffffu); d[ML_PL] = (unsigned short)(l & 0xffffu);
+                d1[0] = (unsigned short)(h >> 16); d1[ML_PL] = (unsigned short)(l >> 16);
             }
-#endif
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float o = fr < 8 ? oa[r] : ob[r];
-            const int row = it * 16 + fg * 4 + r, col = 16 * w + fr;
-            if (PLANES) {
-                unsigned h, m, l;
-                ml_split(o, h, m, l);
-                unsigned short* d = Ap + ml_sw(row, col);
-                d[0] = (unsigned short)(h >> 16); d[ML_PL] = (unsigned short)(m >> 16); d[2 * ML_PL] = (unsigned short)(l >> 16);
-            } else {
-                As[row * ML_S + col] = o;
-            }
+            for (int r = 0; r < 4; ++r) As[(it * 16 + fg * 4 + r) * ML_S + col] = (fr < 8 ? oa[r] : ob[r]) * os;
         }
     }
 }
 // C: head_combine, transposed (rows = this wave's 16 output channels, columns = tokens)
-// wc: the wave's head_combine fragments [ks][plane] -- registers (W.c) or, where registers are short, its 6 x 1 KB slice of an LDS copy
+// wc: the wave's head_combine fragments [ks][plane] -- registers (W.c) or, where registers are short, its slice of an LDS copy
 template <class WC>
 __device__ __forceinline__ void ml_combine(const unsigned short* Ap, WC wc, f32x4 (&y)[4], int fr, int fg) {
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) y[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 a[4][3], c[3];
+        f16x8 a[4][2], c[2];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) c[pl] = wc(ks, pl);
+        for (int pl = 0; pl < 2; ++pl) c[pl] = wc(ks, pl);
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) a[tt][pl] = *reinterpret_cast<const bf16x8*>(Ap + pl * ML_PL + ml_sw(tt * 16 + fr, ks * 32 + fg * 8));
-#define ML_T(PA, PB) _Pragma("unroll") for (int tt = 0; tt < 4; ++tt) y[tt] = ML_MFMA16(c[PA], a[tt][PB], y[tt]);
-        ML_T(2, 0) ML_T(0, 2) ML_T(1, 1) ML_T(1, 0) ML_T(0, 1) ML_T(0, 0)
+            for (int pl = 0; pl < 2; ++pl) a[tt][pl] = *reinterpret_cast<const f16x8*>(Ap + pl * ML_PL + ml_sw(tt * 16 + fr, ks * 32 + fg * 8));
+#define ML_T(PA, PB) _Pragma("unroll") for (int tt = 0; tt < 4; ++tt) y[tt] = ML_MFMAH(c[PA], a[tt][PB], y[tt]);
+        ML_T(1, 0) ML_T(0, 1) ML_T(0, 0)
 #undef ML_T
     }
 }
@@ -249,8 +279,7 @@ __device__ __forceinline__ void ml_combine(const unsigned short* Ap, WC wc, f32x
 //   hidden layer (64 -> 128 -> 1, 1 MFLOP per point) runs on v_mfma_f32_32x32x16_f16 from two fp16 planes per operand (split_bf16.h; Wf arrives as
 //   the planes of 2^6 Wf in fragment order, `Wc`; `bc` = [bf (128) | v (128) | c]); 240 bytes per point leave the kernel instead of 15 KB, and
 //   linear_relu_dot_ws_kernel<64, 1> (1.74 ms, 2.46 GB read) leaves the path.
-// waves per SIMD the layer is compiled for: the split weight fragments (72 - 96 registers) no longer fit three (168 registers, 116 - 268 bytes
-// of scratch: mode 0 / mode 2 = 5.02 / 3.93 ms); two (no scratch): 4.13 / 3.68 ms
+// waves per SIMD the layer is compiled for: two (the weight fragments, the score operands of all four token tiles and the V planes are resident)
 #ifndef ML_LAYER_WPE
 #define ML_LAYER_WPE 2
 #endif
@@ -260,8 +289,10 @@ __global__ void __launch_bounds__(256, ML_LAYER_WPE) mhsa_layer_kernel(long T, c
                                                             const float* __restrict__ Wc, const float* __restrict__ bc,
                                                             float* __restrict__ out, unsigned* __restrict__ ctr) {
     __shared__ unsigned s_grab;
-    __shared__ __attribute__((aligned(16))) unsigned short Xp[3 * ML_PL];                     // token tile, three planes
-    __shared__ __attribute__((aligned(16))) float Asm[MODE >= 2 ? 64 * ML_S : 3 * ML_PL / 2];   // attention tile: fp32 (MODE 2, 3) or three planes
+    __shared__ __attribute__((aligned(16))) unsigned short Xp[2 * ML_PL];                     // token tile, two planes
+    __shared__ __attribute__((aligned(16))) float Asm[MODE >= 2 ? 64 * ML_S : ML_PL];         // attention tile: fp32 (MODE 2, 3) or two planes
+    __shared__ float s_red[16];                                                                 // the weights' maxima
+    __shared__ float s_tmax[4];                                                                 // the four waves' shares of the next tile's maximum
     __shared__ __attribute__((aligned(16))) float tail_tab[MODE == 3 ? 256 : 4];              // MODE 3: bf | v
     __shared__ float tail_part[MODE == 3 ? 4 * 64 : 4];                                         // MODE 3: the four waves' shares of the 64 token sums
     float* As = Asm;
@@ -270,7 +301,7 @@ __global__ void __launch_bounds__(256, ML_LAYER_WPE) mhsa_layer_kernel(long T, c
     const int fr = lane & 15, fg = lane >> 4;
 
     MlWeights W;
-    ml_load_weights<(MODE < 2)>(W, Wq, Wk, Wv, Wc, w, fr, fg);
+    ml_load_weights<(MODE < 2)>(W, Wq, Wk, Wv, Wc, s_red, tid, w, fr, fg);
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
     if (MODE < 2 && bc) bias = *reinterpret_cast<const float4*>(bc + 16 * w + 4 * fg);
     // MODE 3: this wave's 32 hidden units of Wf as A fragments (K step ks = channels 16 ks + 8 (lane / 32) .., two planes), resident in registers
@@ -285,8 +316,8 @@ __global__ void __launch_bounds__(256, ML_LAYER_WPE) mhsa_layer_kernel(long T, c
         tail_tab[tid] = bc[tid];
         tail_c = bc[256];
     }
-    // token rows 60..63 stay zero for the whole kernel (all planes): 3 x 4 rows x 64 bf16 = 384 dwords
-    for (int e = tid; e < 384; e += 256) reinterpret_cast<unsigned*>(Xp + (e / 128) * ML_PL + ML_TOK * 64)[e % 128] = 0u;
+    // token rows 60..63 stay zero for the whole kernel (both planes): 2 x 4 rows x 64 fp16 = 256 dwords
+    reinterpret_cast<unsigned*>(Xp + (tid / 128) * ML_PL + ML_TOK * 64)[tid % 128] = 0u;
 
     // next point's tokens: 960 float4 over 256 threads, four named registers (an indexed array captured by a lambda ended up
     // in scratch memory: +5 GB of HBM traffic per launch)
@@ -301,11 +332,21 @@ __global__ void __launch_bounds__(256, ML_LAYER_WPE) mhsa_layer_kernel(long T, c
     // static round-robin makes the whole launch wait for the workgroups that were slowed down.  With `ctr` (zeroed by the launcher) the first two
     // points of a workgroup are static and every further one is taken from a device-wide counter: thread 0 asks for the point after next while the
     // current one computes (the atomic's latency disappears behind the layer), the answer crosses LDS behind the loop's last barrier.
+    // the maximum of the tile in x0..x3: this wave's share to s_tmax (read behind the next barrier)
+#define ML_TILE_MAX()                                                                        \
+    {                                                                                        \
+        const float m_ = ml_wave_max(ml_max4(x0, ml_max4(x1, ml_max4(x2, ml_max4(x3, 0.f))))); \
+        if (lane == 0) s_tmax[w] = m_;                                                       \
+    }
     long pt = blockIdx.x, nxt = (long)blockIdx.x + gridDim.x;
     if (pt < T) ML_GLOAD(pt)
+    ML_TILE_MAX()
+    __syncthreads();
     for (; pt < T;) {
-        ml_stage4(Xp, tid, x0); ml_stage4(Xp, tid + 256, x1); ml_stage4(Xp, tid + 512, x2);
-        if (tid < ML_TOK * ML_C / 4 - 768) ml_stage4(Xp, tid + 768, x3);
+        const int kx = ml_scale_exp(fmaxf(fmaxf(s_tmax[0], s_tmax[1]), fmaxf(s_tmax[2], s_tmax[3])));
+        const float sx = ldexpf(1.0f, kx);
+        ml_stage4(Xp, tid, x0, sx); ml_stage4(Xp, tid + 256, x1, sx); ml_stage4(Xp, tid + 512, x2, sx);
+        if (tid < ML_TOK * ML_C / 4 - 768) ml_stage4(Xp, tid + 768, x3, sx);
         __syncthreads();
         if (nxt < T) ML_GLOAD(nxt)                            // next point's tokens: in flight during the whole layer
         unsigned grabbed = 0u;
@@ -313,7 +354,9 @@ __global__ void __launch_bounds__(256, ML_LAYER_WPE) mhsa_layer_kernel(long T, c
 
         f32x4 Q[4], Kt[4], V[4];
         ml_project(Xp, W, Q, Kt, V, fr, fg);
-        ml_attention<(MODE < 2)>(Q, Kt, V, As, Ap, w, fr, fg);
+        // MODE 2: the attention output itself leaves the kernel; otherwise it stays at <= 2^14 and its power is applied by the consumer's epilogue
+        ml_attention<(MODE < 2)>(Q, Kt, V, As, Ap, ldexpf(0.35355339059327373f * 1.4426950408889634f, -(2 * kx + W.kq + W.kk)),
+                                 ldexpf(1.0f, MODE == 2 ? -13 - kx - W.kv : -13), w, fr, fg);
         __syncthreads();
 
         float* dst = out + pt * (ML_TOK * ML_C);
@@ -338,7 +381,8 @@ __global__ void __launch_bounds__(256, ML_LAYER_WPE) mhsa_layer_kernel(long T, c
                     d[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wt[ks][0], bl, d[tt], 0, 0, 0);
                     d[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wt[ks][0], bh, d[tt], 0, 0, 0);
                 }
-            // d[tt][v] = 2^6 hidden[32 w + 8 (v / 4) + 4 kg + v % 4][token 32 tt + tl]: bias, ReLU, . v, summed over this lane's 16 hidden units,
+            const float tf = ldexpf(0.015625f, -(kx + W.kv));
+            // d[tt][v] = 2^(6 + kx + kv) hidden[32 w + 8 (v / 4) + 4 kg + v % 4][token 32 tt + tl]: bias, ReLU, . v, summed over this lane's 16 hidden units,
             // then over the two lane halves and (through LDS, fixed order) over the four waves
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
@@ -347,10 +391,10 @@ __global__ void __launch_bounds__(256, ML_LAYER_WPE) mhsa_layer_kernel(long T, c
                 for (int q4 = 0; q4 < 4; ++q4) {
                     const float4 b4 = *reinterpret_cast<const float4*>(&tail_tab[32 * w + 8 * q4 + 4 * kg]);
                     const float4 v4 = *reinterpret_cast<const float4*>(&tail_tab[128 + 32 * w + 8 * q4 + 4 * kg]);
-                    sacc = fmaf(fmaxf(fmaf(d[tt][4 * q4 + 0], 0.015625f, b4.x), 0.f), v4.x, sacc);
-                    sacc = fmaf(fmaxf(fmaf(d[tt][4 * q4 + 1], 0.015625f, b4.y), 0.f), v4.y, sacc);
-                    sacc = fmaf(fmaxf(fmaf(d[tt][4 * q4 + 2], 0.015625f, b4.z), 0.f), v4.z, sacc);
-                    sacc = fmaf(fmaxf(fmaf(d[tt][4 * q4 + 3], 0.015625f, b4.w), 0.f), v4.w, sacc);
+                    sacc = fmaf(fmaxf(fmaf(d[tt][4 * q4 + 0], tf, b4.x), 0.f), v4.x, sacc);
+                    sacc = fmaf(fmaxf(fmaf(d[tt][4 * q4 + 1], tf, b4.y), 0.f), v4.y, sacc);
+                    sacc = fmaf(fmaxf(fmaf(d[tt][4 * q4 + 2], tf, b4.z), 0.f), v4.z, sacc);
+                    sacc = fmaf(fmaxf(fmaf(d[tt][4 * q4 + 3], tf, b4.w), 0.f), v4.w, sacc);
                 }
                 const ml_u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(sacc), __float_as_uint(sacc), false, false);
                 if (kg == 0) tail_part[w * 64 + 32 * tt + tl] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -367,11 +411,12 @@ __global__ void __launch_bounds__(256, ML_LAYER_WPE) mhsa_layer_kernel(long T, c
         } else {
             f32x4 y[4];
             ml_combine(Ap, [&](int ks, int pl) { return W.c[ks][pl]; }, y, fr, fg);
+            const float ys = ldexpf(1.0f, -(kx + W.kv + W.kc));
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 const int tok = tt * 16 + fr;
                 if (tok < ML_TOK) {
-                    float4 o = make_float4(y[tt][0] + bias.x, y[tt][1] + bias.y, y[tt][2] + bias.z, y[tt][3] + bias.w);
+                    float4 o = make_float4(fmaf(y[tt][0], ys, bias.x), fmaf(y[tt][1], ys, bias.y), fmaf(y[tt][2], ys, bias.z), fmaf(y[tt][3], ys, bias.w));
                     if (MODE == 0) {                       // the residual: the point's own rows again (L2: they were read a layer ago)
                         const float4 rx = *reinterpret_cast<const float4*>(X + pt * (ML_TOK * ML_C) + tok * ML_C + 16 * w + 4 * fg);
                         o.x += rx.x; o.y += rx.y; o.z += rx.z; o.w += rx.w;
@@ -381,6 +426,7 @@ __global__ void __launch_bounds__(256, ML_LAYER_WPE) mhsa_layer_kernel(long T, c
             }
         }
         if (ctr && tid == 0) s_grab = grabbed;
+        ML_TILE_MAX()         // the next point's tokens have had the whole layer to arrive
         __syncthreads();      // Xp / As are rewritten by the next point
         pt = nxt;
         nxt = ctr ? 2L * gridDim.x + s_grab : nxt + gridDim.x;
@@ -425,9 +471,11 @@ __global__ void __launch_bounds__(256) interp_schedule_kernel(int B, int N, int 
 
 // out[b,n] = X + att Wc^T + bc with X = blend of three rows of F (B,S,60,64), sched from interp_schedule_kernel.  Grid = multiple of 8
 // workgroups.  Per scan point: its three coarse token rows were requested during the previous point (12 float4 in registers) and are
-// blended into LDS (fp32 for the residual, three bf16 planes for the projections); the rows of the NEXT point are requested before the
-// layer's three phases start.  LDS: 24.6 + 24.6 + 24.6 KB (dynamic).
-#define ML_INTERP_LDS (2 * 3 * ML_PL * 2 + 4 * 2 * 3 * 64 * 16)
+// blended when the previous point's layer ends (16 registers across the barrier instead of 48; the tile's maximum is taken there), then staged
+// in LDS as two fp16 planes for the projections and as fp32 for the residual; the rows of the NEXT point are requested before the layer's three
+// phases start.  LDS: 16.4 (token planes) + 16.4 (attention planes) + 16.4 (head_combine fragments) + 16.4 KB (fp32 tokens), dynamic.
+#define ML_INTERP_LDS (2 * 2 * ML_PL * 2 + 4 * 2 * 2 * 64 * 16 + 64 * 64 * 4)
+__device__ __forceinline__ int ml_swf(int row, int c4) { return row * 64 + ((c4 ^ (row & 15)) << 2); }      // fp32 tile: 16-byte units XOR-swizzled with the row
 __global__ void __launch_bounds__(256, MHSA_INTERP_WGS) mhsa_interp_layer_kernel(int B, int N, int S, const float* __restrict__ F,
                                                                    const int* __restrict__ sched, const float* __restrict__ Wq,
                                                                    const float* __restrict__ Wk, const float* __restrict__ Wv,
@@ -435,25 +483,27 @@ __global__ void __launch_bounds__(256, MHSA_INTERP_WGS) mhsa_interp_layer_kernel
                                                                    float* __restrict__ out, unsigned* __restrict__ ctr) {
     __shared__ unsigned s_grab;
     extern __shared__ __attribute__((aligned(16))) float ml_dyn[];
-    unsigned short* Xp = reinterpret_cast<unsigned short*>(ml_dyn);                // token tile, three planes (the residual is rebuilt from them: exact)
-    unsigned short* Ap = Xp + 3 * ML_PL;                                           // attention tile, three planes
-    bf16x8* Wcl = reinterpret_cast<bf16x8*>(Ap + 3 * ML_PL);                       // head_combine fragments [wave][ks][plane][lane]: 24 registers the
+    __shared__ float s_red[16];
+    __shared__ float s_tmax[4];
+    unsigned short* Xp = reinterpret_cast<unsigned short*>(ml_dyn);                // token tile, two planes
+    unsigned short* Ap = Xp + 2 * ML_PL;                                           // attention tile, two planes
+    f16x8* Wcl = reinterpret_cast<f16x8*>(Ap + 2 * ML_PL);                         // head_combine fragments [wave][ks][plane][lane]: 16 registers the
                                                                                    // prefetched coarse rows (48) leave no room for
+    float* Xf = reinterpret_cast<float*>(Wcl + 4 * 2 * 2 * 64);                    // the tokens in fp32 (the residual)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     MlWeights W;
-    ml_load_weights<false>(W, Wq, Wk, Wv, Wc, w, fr, fg);
+    ml_load_weights<true>(W, Wq, Wk, Wv, Wc, s_red, tid, w, fr, fg);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 c[3];
-        const float* p = Wc + (16 * w + fr) * ML_C + ks * 32 + fg * 8;
-        ml_split8(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4), c);
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) Wcl[((w * 2 + ks) * 3 + pl) * 64 + lane] = c[pl];
-    }
+        for (int pl = 0; pl < 2; ++pl) {
+            Wcl[((w * 2 + ks) * 2 + pl) * 64 + lane] = W.c[ks][pl];
+            W.c[ks][pl] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};           // dead from here on
+        }
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bc) bias = *reinterpret_cast<const float4*>(bc + 16 * w + 4 * fg);
-    for (int e = tid; e < 384; e += 256) reinterpret_cast<unsigned*>(Xp + (e / 128) * ML_PL + ML_TOK * 64)[e % 128] = 0u;      // token rows 60..63: zero
+    reinterpret_cast<unsigned*>(Xp + (tid / 128) * ML_PL + ML_TOK * 64)[tid % 128] = 0u;      // token rows 60..63: zero (both planes)
 
     const long T = (long)B * N;
     const long share = (T + 7) >> 3;                    // contiguous slots of the spatial order per XCD
@@ -484,16 +534,32 @@ __global__ void __launch_bounds__(256, MHSA_INTERP_WGS) mhsa_interp_layer_kernel
 #pragma unroll
     for (int h = 0; h < 4; ++h) xa[h] = xb[h] = xc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (q < lim) ML_XLOAD(c_i)
+    // the blended tile of the point whose rows are in xa / xb / xc (element e = tid + 256 h), and this wave's share of its maximum
+    f32x4 xv[4];
+#define ML_BLEND(WR)                                                                                       \
+    {                                                                                                      \
+        const float a0_ = __int_as_float((WR).x), a1_ = __int_as_float((WR).y), a2_ = __int_as_float((WR).z);  \
+        float m_ = 0.f;                                                                                    \
+        _Pragma("unroll") for (int h = 0; h < 4; ++h) {                                                    \
+            xv[h] = ml_blend(xa[h], xb[h], xc[h], a0_, a1_, a2_);                                          \
+            m_ = ml_max4(make_float4(xv[h][0], xv[h][1], xv[h][2], xv[h][3]), m_);                         \
+        }                                                                                                  \
+        m_ = ml_wave_max(m_);                                                                              \
+        if (lane == 0) s_tmax[w] = m_;                                                                     \
+    }
+    ML_BLEND(c_w)
+    __syncthreads();
     for (; q < lim;) {
         const long cpt = c_i.x;
-        const float a0 = __int_as_float(c_w.x), a1 = __int_as_float(c_w.y), a2 = __int_as_float(c_w.z);
+        const int kx = ml_scale_exp(fmaxf(fmaxf(s_tmax[0], s_tmax[1]), fmaxf(s_tmax[2], s_tmax[3])));
+        const float sx = ldexpf(1.0f, kx);
         // the token tile itself (projections, residual)
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const int e = tid + 256 * h;
             if (h < 3 || e < ML_TOK * ML_C / 4) {
-                const f32x4 v = ml_blend(xa[h], xb[h], xc[h], a0, a1, a2);
-                ml_stage4(Xp, e, make_float4(v[0], v[1], v[2], v[3]));
+                ml_stage4(Xp, e, make_float4(xv[h][0], xv[h][1], xv[h][2], xv[h][3]), sx);
+                *reinterpret_cast<f32x4*>(&Xf[ml_swf(e >> 4, e & 15)]) = xv[h];
             }
         }
         // the next point's token rows: in flight during the whole layer
@@ -506,32 +572,26 @@ __global__ void __launch_bounds__(256, MHSA_INTERP_WGS) mhsa_interp_layer_kernel
 
         f32x4 Q[4], Kt[4], V[4];
         ml_project(Xp, W, Q, Kt, V, fr, fg);
-        ml_attention<true>(Q, Kt, V, nullptr, Ap, w, fr, fg);
+        ml_attention<true>(Q, Kt, V, nullptr, Ap, ldexpf(0.35355339059327373f * 1.4426950408889634f, -(2 * kx + W.kq + W.kk)), ldexpf(1.0f, -13), w, fr, fg);
         __syncthreads();
 
         // ---- C: head_combine + bias + residual
         f32x4 y[4];
-        ml_combine(Ap, [&](int ks, int pl) { return Wcl[((w * 2 + ks) * 3 + pl) * 64 + lane]; }, y, fr, fg);
+        ml_combine(Ap, [&](int ks, int pl) { return Wcl[((w * 2 + ks) * 2 + pl) * 64 + lane]; }, y, fr, fg);
+        const float ys = ldexpf(1.0f, -(kx + W.kv + W.kc));
         float* dst = out + cpt * (ML_TOK * ML_C);
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
             const int tok = tt * 16 + fr;
             if (tok < ML_TOK) {
-                // the residual X[tok][16 w + 4 fg ..] = hi + mid + lo of the planes: (hi + mid) + lo is exact in fp32
-                const unsigned short* xp = Xp + ml_sw(tok, 16 * w + 4 * fg);
-                const uint2 ph = *reinterpret_cast<const uint2*>(xp), pm = *reinterpret_cast<const uint2*>(xp + ML_PL), pl = *reinterpret_cast<const uint2*>(xp + 2 * ML_PL);
-#define ML_LO(u) __uint_as_float((u) << 16)
-#define ML_HI(u) __uint_as_float((u) & 0xffff0000u)
-                const float4 rx = make_float4((ML_LO(ph.x) + ML_LO(pm.x)) + ML_LO(pl.x), (ML_HI(ph.x) + ML_HI(pm.x)) + ML_HI(pl.x),
-                                              (ML_LO(ph.y) + ML_LO(pm.y)) + ML_LO(pl.y), (ML_HI(ph.y) + ML_HI(pm.y)) + ML_HI(pl.y));
-#undef ML_LO
-#undef ML_HI
+                const f32x4 rx = *reinterpret_cast<const f32x4*>(&Xf[ml_swf(tok, 4 * w + fg)]);      // the residual X[tok][16 w + 4 fg ..]
                 *reinterpret_cast<float4*>(dst + tok * ML_C + 16 * w + 4 * fg) =
-                    make_float4(y[tt][0] + bias.x + rx.x, y[tt][1] + bias.y + rx.y, y[tt][2] + bias.z + rx.z, y[tt][3] + bias.w + rx.w);
+                    make_float4(fmaf(y[tt][0], ys, bias.x) + rx[0], fmaf(y[tt][1], ys, bias.y) + rx[1], fmaf(y[tt][2], ys, bias.z) + rx[2], fmaf(y[tt][3], ys, bias.w) + rx[3]);
             }
         }
         if (ctr && tid == 0) s_grab = grabbed;
-        __syncthreads();      // Xp / Ap are rewritten by the next point
+        ML_BLEND(c_w)         // the next point's rows have had the whole layer to arrive (c_w: its weights since the top of this iteration)
+        __syncthreads();      // Xp / Ap / Xf are rewritten by the next point
         q = q1; q1 = q2;
         q2 = ctr ? 3L * per + s_grab : q2 + per;
     }

@@ -90,9 +90,13 @@ __device__ __forceinline__ void split3_pack8p(const float4 v0, const float4 v1, 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2h_pair(float a, float b, unsigned& h, unsigned& l) {
-    const f16x2 hp = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
-    h = __builtin_bit_cast(unsigned, hp);
-    l = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - (float)hp[0], b - (float)hp[1]));
+    h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+    // l = fp16 half * (-1) + x in one instruction each (v_fma_mix_f32 reads the half directly; exact: x - h has at most 13 significant bits) instead of
+    // a conversion and a subtraction: 4 instead of 6 VALU operations per pair
+    float la, lb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(la) : "v"(h), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(h), "v"(b));
+    l = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(la, lb));
 }
 // 4 consecutive fp32 values -> 2 planes x 4 fp16 (8 bytes each)
 __device__ __forceinline__ void split2h_pack4(const float4 v, uint2& h, uint2& l) {
