@@ -814,8 +814,8 @@ def main():
                        "algorithmic_gflop_per_launch": round(d["flops"] / d["calls"] / 1e9, 3),
                        "share_of_step": round(d["ms"] / tot_ms, 3),
                        "arithmetic": "fp32 results throughout, priced against the fp32 matrix peak (157.3: `frac` can exceed what the fp32 MFMA could ever reach).  "
-                                     + ("The inter conv (round 5, csrc/so3conv_y.hip) runs both contractions on v_mfma_f32_32x32x16_f16 with TWO fp16 planes per operand (h = fp16(x) by "
-                                        "truncation, l = fp16(x - h); three cross products; the fp32 MFMA's error against fp64 for this path's O(1) operands, profiles/r05_f16_two_plane_split.txt) "
+                                     + ("The inter conv (round 5, csrc/so3conv_y.hip) runs both contractions on v_mfma_f32_32x32x16_f16 with TWO fp16 planes per operand (h = fp16(x), l = "
+                                        "fp16(x - h), both to nearest; three cross products; the fp32 MFMA's error against fp64 for this path's O(1) operands, profiles/r05_f16_two_plane_split.txt) "
                                         "and forms the kernel weights' pre-activation on v_mfma_f32_32x32x16_bf16 from exactly split factors; " if y_kernel else "")
                                      + "the intra conv, q/k/v + head_combine, linear_relu_dot and the small-weight Linear layers run as exact 3 x bf16 operand splits with six "
                                      "fp32-accumulated cross products on the bf16 matrix cores (profiles/r03_bf16x3_split.txt); the pipe the dominant kernel actually runs on is priced in "

@@ -70,19 +70,24 @@ __global__ void __launch_bounds__(256) inter_x1_rows_kernel(int cin, int p1, int
 // grid (N/64, M/64, splits): a workgroup owns a 64x64 tile of C and a contiguous range of the R rows; 32 rows at a time go through
 // LDS row-major (coalesced loads), the MFMA fragments are read transposed (row stride = 16 mod 64 floats: conflict-free).
 // Partial tiles [split][M][N] are summed in split order by gemm_tn_reduce_kernel (deterministic).
+// Round 5: on v_mfma_f64_16x16x4_f64 -- fp32 operands widened exactly, products exact (48 < 53 bits), fp64 accumulation and fp64 partial tiles.  These
+// are the weight gradients: sums over every row (token) of the batch, and for the direction head's layers they cancel to ~1e-7 of the sum of the
+// terms' magnitudes (profiles/r05_weight_gradient_accumulation.txt): fp32 accumulation, though exact to 2e-8 of that sum, left 12 % error in
+// d(net[2].weight).  The fp64 matrix pipe runs at half the fp32 one's rate and these GEMMs are ~2 % of a training step.
 #define TN_LD 80
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) gemm_tn_kernel(long R, int M, int N, const float* __restrict__ A, long lda, const float* __restrict__ B,
-                                                      long ldb, float* __restrict__ part) {
+                                                      long ldb, double* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) float As[32 * TN_LD], Bs[32 * TN_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64, sp = blockIdx.z, nsp = gridDim.z;
     const long r_begin = R * sp / nsp, r_end = R * (sp + 1) / nsp;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;          // the wave's 32x32 quadrant
-    f32x4 acc[2][2];
+    f64x4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0, 0, 0, 0};
     for (long r0 = r_begin; r0 < r_end; r0 += 32) {
         __syncthreads();
         for (int e = tid; e < 32 * 16; e += 256) {                  // 32 rows x 16 float4 per operand
@@ -100,32 +105,32 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(long R, int M, int N, cons
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            float a[2], bq[2];
+            double a[2], bq[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { a[i] = As[(4 * t + fg) * TN_LD + wm + 16 * i + fr]; bq[i] = Bs[(4 * t + fg) * TN_LD + wn + 16 * i + fr]; }
+            for (int i = 0; i < 2; ++i) { a[i] = (double)As[(4 * t + fg) * TN_LD + wm + 16 * i + fr]; bq[i] = (double)Bs[(4 * t + fg) * TN_LD + wn + 16 * i + fr]; }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bq[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bq[j], acc[i][j], 0, 0, 0);
         }
     }
-    float* P = part + (size_t)sp * M * N;
+    double* P = part + (size_t)sp * M * N;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int m = m0 + wm + 16 * i + 4 * fg + q, n = n0 + wn + 16 * j + fr;
+                const int m = m0 + wm + 16 * i + 4 * q + fg, n = n0 + wn + 16 * j + fr;       // D layout of the fp64 MFMA: row 4 q + lane / 16 (the fp32 one's: 4 (lane / 16) + q)
                 if (m < M && n < N) P[(size_t)m * N + n] = acc[i][j][q];
             }
 }
 
-__global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(long MN, int splits, const float* __restrict__ part, float* __restrict__ C, int accumulate) {
+__global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(long MN, int splits, const double* __restrict__ part, float* __restrict__ C, int accumulate) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < MN; i += (long)gridDim.x * 256) {
-        float s = accumulate ? C[i] : 0.f;
+        double s = accumulate ? (double)C[i] : 0.0;
         for (int k = 0; k < splits; ++k) s += part[(size_t)k * MN + i];
-        C[i] = s;
+        C[i] = (float)s;
     }
 }
 
@@ -294,7 +299,7 @@ int etch_gemm_tn_workspace_floats(long R, int M, int N) {
     int splits = (int)((R + 2047) / 2048);
     if (splits > 64) splits = 64;
     if (splits < 1) splits = 1;
-    return splits * M * N;
+    return 2 * splits * M * N + 2;      // fp64 partial tiles (+ 2: room to align the base to 8 bytes)
 }
 
 int etch_gemm_tn(long R, int M, int N, const float* A, long lda, const float* B, long ldb, float* C, int accumulate, float* workspace,
@@ -305,9 +310,10 @@ int etch_gemm_tn(long R, int M, int N, const float* A, long lda, const float* B,
     if (splits > 64) splits = 64;
     if (splits < 1) splits = 1;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3((N + 63) / 64, (M + 63) / 64, splits), dim3(256), 0, st, R, M, N, A, lda, B, ldb, workspace);
+    double* part = reinterpret_cast<double*>(((uintptr_t)workspace + 7) & ~(uintptr_t)7);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((N + 63) / 64, (M + 63) / 64, splits), dim3(256), 0, st, R, M, N, A, lda, B, ldb, part);
     ETCH_RETURN_IF_LAUNCH_FAILED();
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, st, (long)M * N, splits, workspace, C, accumulate);
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, st, (long)M * N, splits, part, C, accumulate);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }

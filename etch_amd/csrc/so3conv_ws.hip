@@ -13,7 +13,7 @@
 // Per pair and (point, anchor half): wave (mt, kq) forms the partial tile Y[32 mt .. + 31][32 anchors] over its three taps; the four K-parts meet
 // in LDS (double-buffered: one barrier per phase), bias, output, fp64 InstanceNorm partial sums per pair as etch_intra_so3conv32.
 // Round 5, template flag F16 (C ABI etch_intra_so3conv_f16): the same kernel on v_mfma_f32_32x32x16_f16 with TWO fp16 planes per operand (split_bf16.h:
-// h = fp16(x) by truncation, l = fp16(x - h); three cross terms) -- the operands here are at unit scale (InstanceNorm + LeakyReLU outputs; W arrives
+// h = fp16(x), l = fp16(x - h), both to nearest; three cross terms) -- the operands here are at unit scale (InstanceNorm + LeakyReLU outputs; W arrives
 // as the planes of 2^6 W, the epilogue multiplies by 2^-6), where that split carries the fp32 MFMA's error (profiles/r05_f16_two_plane_split.txt):
 // half the matrix instructions, two thirds of the LDS plane traffic, 48 / 96 instead of 72 / 144 registers of weight fragments.
 #include "common.h"

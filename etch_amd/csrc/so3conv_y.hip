@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
 #endif
     };
     // clamp to [0, 1] (the weight's mathematical range) + two-plane fp16 split of the pair k = (P[2 k], P[2 k + 1]) as a software pipeline over the
-    // pairs: tick tau runs stage 1 of pair tau (clamp), stage 2 of pair tau - 1 (h = fp16 pair, truncation), stage 3 of pair tau - 2 (l = w - h:
+    // pairs: tick tau runs stage 1 of pair tau (clamp), stage 2 of pair tau - 1 (h = fp16 pair), stage 3 of pair tau - 2 (l = w - h:
     // v_fma_mix_f32 reads the fp16 half directly), stage 4 of pair tau - 3 (l as fp16 pair) -- inside a tick nothing depends on anything (a VALU
     // instruction that reads its predecessor's result issues ~4 cycles late, profiles/r05_valu_rates_f16.txt).  K step h2 = k / 4 of step 1,
     // dword d = k % 4 of its fragment.
@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
         }
         if (k >= 1 && k < 9) {
             const int pr = k - 1;
-            S_.h[pr] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(S_.w[2 * pr], S_.w[2 * pr + 1]));
+            S_.h[pr] = __builtin_bit_cast(unsigned, (f16x2){(_Float16)S_.w[2 * pr], (_Float16)S_.w[2 * pr + 1]});      // both planes rounded to nearest (split_bf16.h)
             aw[pr / 4][0][pr % 4] = S_.h[pr];
         }
         if (k >= 2 && k < 10) {
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
         }
         if (k >= 3) {
             const int pr = k - 3;
-            aw[pr / 4][1][pr % 4] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(S_.l[2 * pr], S_.l[2 * pr + 1]));
+            aw[pr / 4][1][pr % 4] = __builtin_bit_cast(unsigned, (f16x2){(_Float16)S_.l[2 * pr], (_Float16)S_.l[2 * pr + 1]});
         }
     };
     // X1 store addresses of this lane (LDS byte addresses): column 0 of the wave, kernel point kp, channel blocks (2 q + kg) ^ sw(kp), q < NKR / 4;

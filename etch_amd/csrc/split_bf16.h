@@ -83,20 +83,23 @@ __device__ __forceinline__ void split3_pack8p(const float4 v0, const float4 v1, 
 #undef ETCH_PK
 }
 
-// ---- two-plane fp16 split (round 5): x = h + l with h = fp16(x) by truncation and l = fp16(x - h), 22 significant bits above 2^-14 and an absolute
-// floor of 2^-24 below (fp16 subnormals, which the gfx950 matrix cores keep: profiles/r05_f16_two_plane_split.txt) -- for O(1) operands a product
-// (l*h + h*l + h*h, three v_mfma_f32_32x32x16_f16) carries the error of the fp32 MFMA, with half the matrix instructions, 4 instead of 6 bytes per
-// element and 4 instead of 6.5 VALU operations per split value of the exact three-plane bf16 split above.
+// ---- two-plane fp16 split (round 5): x = h + l with h = fp16(x) and l = fp16(x - h), BOTH rounded to nearest (v_cvt_pk_f16_f32): 23 significant bits
+// above 2^-13 and an absolute floor of 2^-25 below (fp16 subnormals, which the gfx950 matrix cores keep: profiles/r05_f16_two_plane_split.txt) -- for
+// O(1) operands a product (l*h + h*l + h*h, three v_mfma_f32_32x32x16_f16) carries the error of the fp32 MFMA, with half the matrix instructions, 4
+// instead of 6 bytes per element and 4 instead of 5.5 VALU operations per split value of the exact three-plane bf16 split above.
+// Rounding to nearest, not truncation: a truncated residual makes every represented value SMALLER in magnitude (2^-23 on average), a bias that is
+// coherent over a whole batch -- invisible in any single product, but the direction loss's weight gradients cancel to 1e-7 of their terms and a
+// coherent 2e-7 came out of them as a 10 - 50 % error (profiles/r05_weight_gradient_accumulation.txt).  Rounded planes have zero-mean residuals.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2h_pair(float a, float b, unsigned& h, unsigned& l) {
-    h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
-    // l = fp16 half * (-1) + x in one instruction each (v_fma_mix_f32 reads the half directly; exact: x - h has at most 13 significant bits) instead of
+    h = __builtin_bit_cast(unsigned, (f16x2){(_Float16)a, (_Float16)b});
+    // l = fp16 half * (-1) + x in one instruction each (v_fma_mix_f32 reads the half directly; exact: x - h has at most 14 significant bits) instead of
     // a conversion and a subtraction: 4 instead of 6 VALU operations per pair
     float la, lb;
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(la) : "v"(h), "v"(a));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(h), "v"(b));
-    l = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(la, lb));
+    l = __builtin_bit_cast(unsigned, (f16x2){(_Float16)la, (_Float16)lb});
 }
 // 4 consecutive fp32 values -> 2 planes x 4 fp16 (8 bytes each)
 __device__ __forceinline__ void split2h_pack4(const float4 v, uint2& h, uint2& l) {

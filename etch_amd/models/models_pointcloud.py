@@ -90,7 +90,7 @@ class GT_network_equiv(nn.Module):
             v = (W2.t() @ wr).float().contiguous().to(dev)
             c = (b2 @ wr + br[0]).float().view(1).to(dev)
             tab = torch.cat([bf, v, c]).contiguous()                      # [bf | v | c]: the fused tail's constants (etch_mhsa_layer_dirtail)
-            return Wf, bf, v, c, ops.permute_weight_frag_grouped(Wf), ops.dirtail_weight_split(Wf), tab
+            return Wf, bf, v, c, ops.permute_weight_frag_grouped(Wf), (ops.dirtail_weight_split(Wf) if tuple(Wf.shape) == (128, 64) else None), tab      # the fused tail: 64-wide tokens
 
         if not hasattr(self, "_fold_cache"):
             from ..vgtk_so3conv import _Derived

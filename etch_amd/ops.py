@@ -332,7 +332,7 @@ def inter_planes_form(cin):
 
 
 def split2_planes_f16(x_cl):
-    """x (..., C) fp32 -> (..., 2, C) float16: h = fp16(x) by truncation, l = fp16(x - h), the layout etch_inter_so3conv_planes_kq gathers (the
+    """x (..., C) fp32 -> (..., 2, C) float16: h = fp16(x), l = fp16(x - h), both to nearest, the layout etch_inter_so3conv_planes_kq gathers (the
     encoder's own producer, instnorm_act_add(want_planes="f16"), writes it directly)."""
     _need(x_cl, torch.float32, "x")
     C = x_cl.shape[-1]

@@ -178,7 +178,7 @@ int etch_inter_so3conv_planes32(int b, int cin, int cout, int p1, int p2, int nn
  * this round (profiles/r05_inter_conv_latency_bound.txt, r05_f16_two_plane_split.txt):
  *   (1) kernel weights off the MATRIX cores: the pre-activation 1 - |g_n - R_a kappa_k|^2 / sigma = [a_n, 1, G_n] . [1, b_k, r_ak] is a rank-5
  *       bilinear form whose six largest exactly-split bf16 cross terms fill one pair of v_mfma_f32_32x32x16_bf16 per (anchor, 32 neighbours);
- *   (2) both contractions on v_mfma_f32_32x32x16_f16 with TWO fp16 planes per operand (x = h + l, h = fp16(x) by truncation, l = fp16(x - h):
+ *   (2) both contractions on v_mfma_f32_32x32x16_f16 with TWO fp16 planes per operand (x = h + l, h = fp16(x), l = fp16(x - h), both to nearest:
  *       22 significant bits, absolute floor 2^-24; three cross products): for the O(1) operands of this path the error of the fp32 MFMA, with half
  *       the matrix instructions, 4 instead of 6 bytes per gathered element and 40 % of the split work of the three-plane bf16 split;
  *   (3) gathered rows through a register ring (plain loads, several chunks in flight per wave) instead of LDS-direct loads.
@@ -193,7 +193,7 @@ int etch_inter_so3conv_planes_kq(int b, int cin, int cout, int p1, int p2, int n
                                  const int* ball_idx, const void* feats_planes, const void* kq, const void* Wq32, const float* bias, float* out,
                                  const int* order, double* stat_part, void* stream);
 
-/* x (rows, C) fp32 -> planes (rows, 2, C) fp16: h = fp16(x) by truncation, l = fp16(x - h) (the gather format of etch_inter_so3conv_planes_kq). */
+/* x (rows, C) fp32 -> planes (rows, 2, C) fp16: h = fp16(x), l = fp16(x - h), both to nearest (the gather format of etch_inter_so3conv_planes_kq). */
 int etch_split2_planes_f16(long rows, int C, const float* x, void* planes, void* stream);
 
 /* x (rows, C) fp32 -> planes (rows, 3, C) bf16: the exact split x = hi + mid + lo (8 + 8 + 8 mantissa bits, by truncation). */
@@ -230,7 +230,7 @@ int etch_intra_so3conv32(int b, int c, int cout, int p, const float* X, const fl
 int etch_intra_so3conv_split(int b, int c, int cout, int p, const float* X, const float* mean, const float* rstd, const int* intra_idx,
                              const void* Wq, const float* bias, float* Y, double* stat_part, void* stream);
 
-/* Round 5: the same kernel on v_mfma_f32_32x32x16_f16 with TWO fp16 planes per operand (h = fp16(x) by truncation, l = fp16(x - h); three cross
+/* Round 5: the same kernel on v_mfma_f32_32x32x16_f16 with TWO fp16 planes per operand (h = fp16(x), l = fp16(x - h), both to nearest; three cross
  * products; for this path's unit-scale operands the fp32 MFMA's error against fp64, profiles/r05_f16_two_plane_split.txt).  Wqh = etch_amd/ops.py
  * intra_weight_split_f16: [mt][kq][K step][plane h / l][lane][8 fp16] of 2^6 W2 (the kernel's epilogue multiplies by 2^-6: exact). */
 int etch_intra_so3conv_f16(int b, int c, int cout, int p, const float* X, const float* mean, const float* rstd, const int* intra_idx,
@@ -440,8 +440,10 @@ int etch_index_points(int B, int N, long S, int C, const float* points, const lo
 int etch_inter_x1_rows(int b, int cin, int p1, int p2, int p_begin, int pc, int nn, float sigma, const float* xyz, const float* new_xyz,
                        const int* ball_idx, const float* feats, const float* rk, float* x1, void* stream);
 
-/* C (M,N) (+)= A (R,M)^T B (R,N) on the fp32 matrix cores (dW = dY^T X1): split over R, partial tiles in `workspace`
- * (etch_gemm_tn_workspace_floats(R, M, N) floats), summed in split order. */
+/* C (M,N) (+)= A (R,M)^T B (R,N) (dW = dY^T X1: the weight gradients, sums over every row of the batch) on the fp64 matrix cores
+ * (v_mfma_f64_16x16x4_f64: fp32 operands widened exactly, exact products, fp64 accumulation -- these sums cancel to ~1e-7 of their terms for the
+ * direction head, profiles/r05_weight_gradient_accumulation.txt): split over R, fp64 partial tiles in `workspace`
+ * (etch_gemm_tn_workspace_floats(R, M, N) floats), summed in split order, rounded to fp32 once. */
 int etch_gemm_tn_workspace_floats(long R, int M, int N);
 int etch_gemm_tn(long R, int M, int N, const float* A, long lda, const float* B, long ldb, float* C, int accumulate, float* workspace,
                  void* stream);

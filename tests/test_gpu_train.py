@@ -168,8 +168,13 @@ def _losses(res, vec, conf, labels, mask, which):
     return sum(out.values()), out
 
 
-def _oracle(model, pts, vec, conf, labels, dtype, which, mask, lr=None, bn_training=True):
-    """The oracle's forward in train() mode + torch.autograd (+ one Adam step) on the CPU in `dtype`."""
+_LAST = {}       # the last oracle run's anchor weights (B*N, 60)
+
+
+def _oracle(model, pts, vec, conf, labels, dtype, which, mask, lr=None, bn_training=True, aw_at=None):
+    """The oracle's forward in train() mode + torch.autograd (+ one Adam step) on the CPU in `dtype`.
+    aw_at (B*N, 60): evaluate so3_mean and its derivative AT these anchor weights (the oracle's own anc_w + a constant offset: the graph is unchanged) --
+    the gradient of the loss at the linearisation point of the run under test, see test_eval_mode_gradients_of_all_four_losses_strict."""
     from etch_amd.utils.weights import seeded_state_dict
     from oracle import stage1 as S1
     B, N, _ = pts.shape
@@ -196,8 +201,11 @@ def _oracle(model, pts, vec, conf, labels, dtype, which, mask, lr=None, bn_train
             res["magnitude"] = S1.pt_magnitude(sd, "magnitude_encoder.", p, inv, o)
         if "direction" in which:
             aw = S1.direction_anchor_weights(sd, pef)
+            if aw_at is not None:
+                aw = aw + (torch.from_numpy(np.asarray(aw_at)).to(dtype) - aw).detach()
             R, Ce, sv = S1.so3_mean(sd[f"encoder.backbone.{depth - 1}.blocks.1.intra_conv.conv.anchors"], aw)
             res["direction"] = R[:, :, 2].reshape(B, N, 3)
+            _LAST["anc_w"] = aw.detach().double().numpy().copy()
             if mask is None:
                 sig = torch.stack([sv[:, 0], sv[:, 1], torch.det(Ce.detach()).sign() * sv[:, 2]], 1).detach()
                 gap = torch.stack([sig[:, 0] + sig[:, 1], sig[:, 0] + sig[:, 2], sig[:, 1] + sig[:, 2]], 1).min(1).values
@@ -344,8 +352,8 @@ def test_eval_mode_gradients_of_all_four_losses_strict(tmp_path, depth):
     """The whole differentiable chain end to end where it IS well conditioned: eval() mode (BatchNorm on its running statistics is an affine map),
     model.differentiable = True, all four losses of train.py:81-101, B = 2 scans of 512 points.  d(loss)/d(every parameter) -- 1 174 tensors,
     every autograd Function and every module of autograd.py / autograd_pt.py on the way -- against the fp64 oracle: relative L2 per tensor
-    within 1e-3 or twice the deviation of the oracle's own fp32 autograd (the direction loss over the well-gapped points, slack 8 as in
-    test_gpu_backward.py); median over all tensors within 1e-4.
+    within 1e-3 or twice the deviation of the oracle's own fp32 autograd (with the direction loss: over the well-gapped points, at the anchor weights
+    the path itself computed, slack 4 -- see the comment at that part); median over all tensors within 1e-4.
     Round 5: at EVERY encoder depth the reference trains (train.py:61-101 trains whatever EPN_layer_num builds,
     models_pointcloud.py:34-48: 32 / 64 / 128 / 256-dim tokens, conv channel pairs up to (256, 256)); depths 1 / 3 / 4 run the un-fused attention chain +
     etch_mhsa_attention_backward_dim (head widths 4 / 16 / 32) and the inter conv's data gradient in 64-channel windows."""
@@ -367,12 +375,31 @@ def test_eval_mode_gradients_of_all_four_losses_strict(tmp_path, depth):
     n, m_gpu, m_32 = _compare(names, gg, g64, g32, "PT losses, eval-mode BatchNorm", tol=3e-3 if depth == 4 else 1e-3, slack=2.0)
     assert n >= 1100 and m_gpu <= 1e-4
     assert int(model.confidence_encoder.enc1[0].bn.num_batches_tracked) == 0     # eval(): running statistics untouched
+    # The direction loss.  so3_mean projects sum_a w_a R_a onto SO(3); with seeded random weights the anchor weights are nearly uniform, the sum nearly
+    # cancels and the projection's SECOND derivative is huge: d(loss)/d(anc_w) moves by 84 % (relative L2, encoder depth 4; the reference formula's own
+    # fp32 run against its fp64 run) for the 2e-5 relative difference between the two runs' anc_w (profiles/r05_weight_gradient_accumulation.txt).  fp32
+    # does not determine this gradient at the fp64 run's linearisation point, for any implementation.  What it does determine, and what is asserted:
+    #   (1) forward: the path's anc_w is as close to the fp64 oracle's as the oracle's own fp32 run (entitled error, x 2);
+    #   (2) backward: the gradient of the loss AT the anc_w the path itself computed -- the fp64 oracle with so3_mean evaluated at the path's anchor
+    #       weights (a constant offset on its own anc_w: same graph) -- per tensor within 1e-3 or `slack` x the deviation of the oracle's fp32 run
+    #       evaluated at that same point.
     which = ("direction", "magnitude", "confidence")
-    g64, mask, l64, _ = _oracle(model, pts, vec, conf, labels, torch.float64, which, None, bn_training=False)
-    g32, _, l32, _ = _oracle(model, pts, vec, conf, labels, torch.float32, which, mask, bn_training=False)
+    _, mask0, _, _ = _oracle(model, pts, vec, conf, labels, torch.float64, ("direction",), None, bn_training=False)
+    aw64 = _LAST["anc_w"]
+    _oracle(model, pts, vec, conf, labels, torch.float32, ("direction",), mask0, bn_training=False)
+    aw32 = _LAST["anc_w"]
+    with torch.enable_grad():
+        model(torch.from_numpy(pts).cuda(), ["direction"], "standard_vector")
+    aw_gpu = model.last_anc_w.detach().double().cpu().numpy().reshape(B * N, 60)
+    l2 = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    print(f"anc_w against the fp64 oracle, relative L2: gpu {l2(aw_gpu, aw64):.2e}, oracle's own fp32 {l2(aw32, aw64):.2e}")
+    assert l2(aw_gpu, aw64) <= 2.0 * l2(aw32, aw64) + 1e-7
+    g64, mask, l64, _ = _oracle(model, pts, vec, conf, labels, torch.float64, which, None, bn_training=False, aw_at=aw_gpu)
+    g32, _, l32, _ = _oracle(model, pts, vec, conf, labels, torch.float32, which, mask, bn_training=False, aw_at=aw_gpu)
     gg, lg = _gpu(model, pts, vec, conf, labels, which, mask, ["confidence", "direction", "magnitude"])
+    assert np.array_equal(model.last_anc_w.detach().double().cpu().numpy().reshape(B * N, 60), aw_gpu)      # the forward is reproducible: same linearisation point
     print("losses (fp64 oracle / fp32 oracle / gpu):", {k: (round(l64[k], 6), round(l32[k], 6), round(lg[k], 6)) for k in l64})
-    n, m_gpu, m_32 = _compare(names, gg, g64, g32, "all four losses, eval-mode BatchNorm", tol=1e-3, slack=8.0)
+    n, m_gpu, m_32 = _compare(names, gg, g64, g32, "all four losses, eval-mode BatchNorm, at the path's own anchor weights", tol=3e-3 if depth == 4 else 1e-3, slack=4.0)
     assert n == len(names) and m_gpu <= max(1e-4, 2.0 * m_32)
 
 
