@@ -14,6 +14,7 @@
 // applies bias / ReLU / w2 in registers, sums the strip's 16 columns with DPP row reductions, and the 8 strips through a
 // double-buffered LDS table (one barrier per group, fixed summation order: results are run-to-run reproducible).
 #include "common.h"
+#include "split_bf16.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -293,20 +294,26 @@ static int launch_lrd_bx(long R, int G, const float* X, long ldx, const void* Wq
 // adds plus two lane-group swaps per row tile instead of four DPP reductions per accumulator register.
 // SPW = strips per wave: 2 (a column block = two groups, 16 strips over the 8 waves) or 1 (a column block = one group: G = 1, the direction
 // head's tail, whose 49 KB of weights stream from L2 for nothing otherwise and whose 9.6 M rows make the epilogue the larger half of the work).
-template <int K, int SPW>
+// F16 (round 5, etch_linear_relu_dot_f16): the same kernel on v_mfma_f32_16x16x32_f16 with TWO fp16 planes per operand and three cross terms -- half
+// the matrix instructions of the bf16 split (the confidence head's launch is matrix-bound: pipe busy 0.61).  X has no known scale (Point-Transformer
+// features), so every ROW is multiplied by the power of two that puts its maximum into [8, 16) (its 128 channels sit in 32 consecutive lanes when the
+// tile is staged: a DPP maximum, no barrier) and the power leaves again in the epilogue's fmaf with the bias; Wq arrives as the planes of 2^wexp W.
+template <int K, int SPW, bool F16 = false>
 __global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, const float* __restrict__ X, long ldx,
                                                                  const bf16x8* __restrict__ Wq, const float* __restrict__ b1,
                                                                  const float* __restrict__ w2, const float* __restrict__ b2,
-                                                                 float* __restrict__ out, long ldo, unsigned* __restrict__ ctr) {
+                                                                 float* __restrict__ out, long ldo, unsigned* __restrict__ ctr, int wexp) {
     __shared__ unsigned s_grab[2];
     // 64-row tiles, planes and reduction table double-buffered: ONE barrier per tile, and the next tile's split + LDS stores sit between the two
     // halves of this tile's MFMA stream (VALU work beside the bf16 matrix cores is free; beside a barrier it is not)
     constexpr int FD_ROWS = 64, SB = K + 8, KT = K / 32, PLANE = FD_ROWS * SB, RT = FD_ROWS / 16;
+    constexpr int NPL = F16 ? 2 : 3;              // operand planes
     constexpr int GPB = SPW;                      // groups per column block
     constexpr int WPG = 8 / GPB;                  // waves per group
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    unsigned short* Xp = reinterpret_cast<unsigned short*>(lds);            // [2 buffers][3][FD_ROWS][SB]
-    float* red = lds + 2 * 3 * PLANE / 2;                                    // [2 buffers][8 waves][FD_ROWS]
+    unsigned short* Xp = reinterpret_cast<unsigned short*>(lds);            // [2 buffers][NPL][FD_ROWS][SB]
+    float* red = lds + 2 * NPL * PLANE / 2;                                  // [2 buffers][8 waves][FD_ROWS]
+    float* rsc = red + 2 * 8 * FD_ROWS;                                      // F16: [2 buffers][FD_ROWS] the rows' epilogue factors 2^-(kx + wexp)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
     const int cb = blockIdx.x, rb = blockIdx.y;
@@ -315,13 +322,13 @@ __global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, 
     const int gq = GPB * cb + wave / WPG;
     const int g = gq < G ? gq : G - 1;
     const int s0 = (SPW * wave) & 7;
-    bf16x8 wf[KT][SPW][3];
+    bf16x8 wf[KT][SPW][NPL];
 #pragma unroll
     for (int t = 0; t < KT; ++t)
 #pragma unroll
         for (int s2 = 0; s2 < SPW; ++s2)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) wf[t][s2][pl] = Wq[((((long)g * KT + t) * 8 + s0 + s2) * 3 + pl) * 64 + lane];
+            for (int pl = 0; pl < NPL; ++pl) wf[t][s2][pl] = Wq[((((long)g * KT + t) * 8 + s0 + s2) * NPL + pl) * 64 + lane];
     // hidden units of this lane: strip s0 + s2, rows 4 fg .. 4 fg + 3
     float4 bs[SPW], ww[SPW];
 #pragma unroll
@@ -349,12 +356,24 @@ __global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, 
             if (e < FD_ROWS * C4 && r0 + row < row_hi) xn[h] = *reinterpret_cast<const float4*>(X + (r0 + row) * ldx + c);   // rows past the block are zero
         }
     };
-    auto stage = [&](unsigned short* P) {
+    auto stage = [&](unsigned short* P, float* rs) {
 #pragma unroll
         for (int h = 0; h < XL; ++h) {
             const int e = tid + 512 * h;
             if (e >= FD_ROWS * C4) continue;
             const int row = e / C4, c = (e - row * C4) * 4;
+            if constexpr (F16) {
+                static_assert(C4 == 8 || C4 == 16 || C4 == 32, "a row's float4s sit in one aligned lane group");
+                const int kx = etch_scale_exp(etch_group_max<C4>(etch_max4abs(xn[h], 0.f)));      // the row's power of two
+                const float sx = ldexpf(1.0f, kx);
+                uint2 ph, pl;
+                split2h_pack4(make_float4(xn[h].x * sx, xn[h].y * sx, xn[h].z * sx, xn[h].w * sx), ph, pl);
+                unsigned short* d = P + row * SB + c;
+                *reinterpret_cast<uint2*>(d) = ph;
+                *reinterpret_cast<uint2*>(d + PLANE) = pl;
+                if (c == 0) rs[row] = ldexpf(1.0f, -(kx + wexp));
+                continue;
+            }
             const float v[4] = {xn[h].x, xn[h].y, xn[h].z, xn[h].w};
             unsigned hh[4], mm[4], ll[4];
 #pragma unroll
@@ -366,7 +385,7 @@ __global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, 
         }
     };
     // two row tiles: D[hidden 4 fg + q of strip s2][row 16 i + fr] -> sums over the wave's hidden units into rt[]
-    auto half_tile = [&](const unsigned short* P, int i0, float* rt) {
+    auto half_tile = [&](const unsigned short* P, int i0, float* rt, const float* rs) {
         f32x4 acc[2][SPW];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -374,21 +393,34 @@ __global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, 
             for (int s2 = 0; s2 < SPW; ++s2) acc[i][s2] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
-            bf16x8 x[2][3];
+            bf16x8 x[2][NPL];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) x[i][pl] = *reinterpret_cast<const bf16x8*>(P + pl * PLANE + ((i0 + i) * 16 + fr) * SB + t * 32 + fg * 8);
+                for (int pl = 0; pl < NPL; ++pl) x[i][pl] = *reinterpret_cast<const bf16x8*>(P + pl * PLANE + ((i0 + i) * 16 + fr) * SB + t * 32 + fg * 8);
+            if constexpr (F16) {
 #define FD_T(PA, PB) _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int s2 = 0; s2 < SPW; ++s2) \
-        acc[i][s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][s2][PA], x[i][PB], acc[i][s2], 0, 0, 0);
+        acc[i][s2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[t][s2][PA]), __builtin_bit_cast(f16x8, x[i][PB]), acc[i][s2], 0, 0, 0);
+                FD_T(1, 0) FD_T(0, 1) FD_T(0, 0)
+#undef FD_T
+                continue;
+            }
+#define FD_T(PA, PB) _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int s2 = 0; s2 < SPW; ++s2) \
+        acc[i][s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][s2][PA % NPL], x[i][PB % NPL], acc[i][s2], 0, 0, 0);
             FD_T(2, 0) FD_T(0, 2) FD_T(1, 1) FD_T(1, 0) FD_T(0, 1) FD_T(0, 0)
 #undef FD_T
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             float tsum = 0.f;
+            const float sc = F16 ? rs[(i0 + i) * 16 + fr] : 1.0f;       // this lane's row: the power of two of its staging and of W (exact)
 #pragma unroll
             for (int s2 = 0; s2 < SPW; ++s2) {
+                if constexpr (F16) {
+                    tsum += fmaxf(fmaf(acc[i][s2][0], sc, bs[s2].x), 0.f) * ww[s2].x; tsum += fmaxf(fmaf(acc[i][s2][1], sc, bs[s2].y), 0.f) * ww[s2].y;
+                    tsum += fmaxf(fmaf(acc[i][s2][2], sc, bs[s2].z), 0.f) * ww[s2].z; tsum += fmaxf(fmaf(acc[i][s2][3], sc, bs[s2].w), 0.f) * ww[s2].w;
+                    continue;
+                }
                 tsum += fmaxf(acc[i][s2][0] + bs[s2].x, 0.f) * ww[s2].x; tsum += fmaxf(acc[i][s2][1] + bs[s2].y, 0.f) * ww[s2].y;
                 tsum += fmaxf(acc[i][s2][2] + bs[s2].z, 0.f) * ww[s2].z; tsum += fmaxf(acc[i][s2][3] + bs[s2].w, 0.f) * ww[s2].w;
             }
@@ -403,20 +435,20 @@ __global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, 
     };
     if (t0 >= ntiles) return;
     fetch(t0 * FD_ROWS);
-    stage(Xp);
+    stage(Xp, rsc);
     fetch(t1 * FD_ROWS);                          // (tiles past the end: rows >= R are fetched as zeros)
     __syncthreads();
     int buf = 0;
     for (; t0 < ntiles; buf ^= 1) {
         const long r0 = t0 * FD_ROWS;
-        const unsigned short* P = Xp + buf * 3 * PLANE;
+        const unsigned short* P = Xp + buf * NPL * PLANE;
         float* rtab = red + buf * 8 * FD_ROWS;
         unsigned grabbed = 0u;
         if (ctr && tid == 0) grabbed = __hip_atomic_fetch_add(ctr + (cb & 63), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        half_tile(P, 0, rtab + wave * FD_ROWS);
-        stage(Xp + (buf ^ 1) * 3 * PLANE);       // the next tile (its buffer's last readers finished before the previous barrier)
+        half_tile(P, 0, rtab + wave * FD_ROWS, rsc + buf * FD_ROWS);
+        stage(Xp + (buf ^ 1) * NPL * PLANE, rsc + (buf ^ 1) * FD_ROWS);       // the next tile (its buffer's last readers finished before the previous barrier)
         fetch(t2 * FD_ROWS);
-        half_tile(P, 2, rtab + wave * FD_ROWS);
+        half_tile(P, 2, rtab + wave * FD_ROWS, rsc + buf * FD_ROWS);
         if (ctr && tid == 0) s_grab[buf] = grabbed;
         __syncthreads();
         t0 = t1; t1 = t2;
@@ -435,12 +467,12 @@ __global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, 
     }
 }
 
-template <int K, int SPW>
+template <int K, int SPW, bool F16 = false>
 static int launch_lrd_ws(long R, int G, const float* X, long ldx, const void* Wq, const float* b1, const float* w2, const float* b2, float* out,
-                         long ldo, hipStream_t st) {
+                         long ldo, hipStream_t st, int wexp = 0) {
     constexpr int FD_ROWS = 64;
-    const size_t lds = (size_t)2 * 3 * FD_ROWS * (K + 8) * 2 + (size_t)2 * 8 * FD_ROWS * sizeof(float);
-    auto kern = linear_relu_dot_ws_kernel<K, SPW>;
+    const size_t lds = (size_t)2 * (F16 ? 2 : 3) * FD_ROWS * (K + 8) * 2 + (size_t)2 * 8 * FD_ROWS * sizeof(float) + (size_t)2 * FD_ROWS * sizeof(float);
+    auto kern = linear_relu_dot_ws_kernel<K, SPW, F16>;
     static int per_cu = 0;
     if (per_cu == 0) {
         if (lds > 64 * 1024) {
@@ -460,9 +492,31 @@ static int launch_lrd_ws(long R, int G, const float* X, long ldx, const void* Wq
                        // one column block only (the direction tail).  With many column blocks (the confidence head: 43) the workgroups of a row position
                        // walk the same X tiles in lock-step and share them through L2; per-block counters let them drift apart (measured: 706 against
                        // 744 scans/s, and unstable) -- those launches keep the static round-robin
-                       ncb == 1 ? etch_work_counter_slot(st) : nullptr);
+                       ncb == 1 ? etch_work_counter_slot(st) : nullptr, wexp);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
+}
+
+// The weight-stationary kernel on the fp16 matrix cores (two planes per operand).  Wqh = ops.lrd_weight_split_f16: lrd_weight_split's order with two fp16
+// planes of 2^wexp W.  Shapes the weight-stationary kernel covers: K in {32, 64, 128}, G = 1 or G >= 8, b1 / w2 16-byte aligned; else ETCH_EUNSUPPORTED.
+extern "C" int etch_linear_relu_dot_f16(long R, int K, int G, int J, const float* X, long ldx, const void* Wqh, int wexp, const float* b1, const float* w2,
+                                        const float* b2, float* out, long ldo, void* stream) {
+    if (R <= 0 || G <= 0) return ETCH_OK;
+    if (!X || !Wqh || !b1 || !w2 || !b2 || !out) return ETCH_EINVAL;
+    if ((ldx & 3) || ((uintptr_t)X & 15) || ((uintptr_t)Wqh & 15)) return ETCH_EINVAL;
+    if (J != FD_J || ((((uintptr_t)b1 | (uintptr_t)w2) & 15) != 0)) return ETCH_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (G >= 8) {
+        if (K == 32) return launch_lrd_ws<32, 2, true>(R, G, X, ldx, Wqh, b1, w2, b2, out, ldo, st, wexp);
+        if (K == 64) return launch_lrd_ws<64, 2, true>(R, G, X, ldx, Wqh, b1, w2, b2, out, ldo, st, wexp);
+        if (K == 128) return launch_lrd_ws<128, 2, true>(R, G, X, ldx, Wqh, b1, w2, b2, out, ldo, st, wexp);
+    }
+    if (G == 1) {
+        if (K == 32) return launch_lrd_ws<32, 1, true>(R, G, X, ldx, Wqh, b1, w2, b2, out, ldo, st, wexp);
+        if (K == 64) return launch_lrd_ws<64, 1, true>(R, G, X, ldx, Wqh, b1, w2, b2, out, ldo, st, wexp);
+        if (K == 128) return launch_lrd_ws<128, 1, true>(R, G, X, ldx, Wqh, b1, w2, b2, out, ldo, st, wexp);
+    }
+    return ETCH_EUNSUPPORTED;
 }
 
 // Wq = ops.lrd_weight_split: [g][K step of 32][strip of 16 hidden columns][plane hi / mid / lo][lane = 16 * (k / 8) + column][8 bf16]

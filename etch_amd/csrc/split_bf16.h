@@ -114,3 +114,28 @@ __device__ __forceinline__ void split2h_pack8(const float4 v0, const float4 v1, 
     split2h_pair(v1.x, v1.y, hh[2], ll[2]); split2h_pair(v1.z, v1.w, hh[3], ll[3]);
     h = __builtin_bit_cast(f16x8, (u32x4_){hh[0], hh[1], hh[2], hh[3]}); l = __builtin_bit_cast(f16x8, (u32x4_){ll[0], ll[1], ll[2], ll[3]});
 }
+
+// ---- bringing an operand into the fp16 planes' range (round 5).  The planes carry 23 bits only where |h| >= 2^-2, so a kernel whose operands have no
+// known scale multiplies a tile / a row by the power of two that puts its maximum into [8, 16) and takes the power out again where a scalar is applied
+// anyway (exact).  v_max3_f32 as written: fmaxf chains carry a canonicalising v_max_f32 x, x per operand that comes from memory.
+__device__ __forceinline__ float etch_max3abs(float a, float b, float c) { float r; asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float etch_max4abs(const float4 v, float m) { return etch_max3abs(v.z, v.w, etch_max3abs(v.x, v.y, m)); }
+// k with m 2^k in [8, 16) (m = 0 or subnormal: 0; capped so that 2^k is a float)
+__device__ __forceinline__ int etch_scale_exp(float m) {
+    const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
+    return e == 0 ? 0 : (130 - e < 120 ? 130 - e : 120);
+}
+// maximum of a non-negative value over aligned groups of W = 8 / 16 / 32 consecutive lanes (DPP mirrors inside rows of 16, a row swap for 32)
+template <int W>
+__device__ __forceinline__ float etch_group_max(float v) {
+#define ETCH_DPP(C) v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), (C), 0xf, 0xf, true)));
+    ETCH_DPP(0xB1) ETCH_DPP(0x4E) ETCH_DPP(0x141)
+    if (W >= 16) { ETCH_DPP(0x140) }
+#undef ETCH_DPP
+    if (W >= 32) {
+        typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+        const u32x2_ r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    return v;
+}

@@ -5,6 +5,7 @@ hands raw device pointers to libetch_hip.so; there is no eager/CPU fallback -- a
 missing library raises.
 """
 import ctypes
+import math
 import os
 
 import torch
@@ -797,6 +798,7 @@ def grouped_dot(h, w, bias, G, J, out=None):
 
 
 LRD_SPLIT = os.environ.get("ETCH_LRD_SPLIT", "1") != "0"       # linear_relu_dot on the bf16 matrix cores (split fp32 operands); 0: fp32 MFMA
+LRD_F16 = os.environ.get("ETCH_LRD_SPLIT", "1") != "bf16"      # ... as two fp16 planes per operand where the weight-stationary kernel applies; "bf16": three bf16 planes
 
 
 def lrd_weight_split(w, J=128):
@@ -809,10 +811,29 @@ def lrd_weight_split(w, J=128):
     return q.permute(1, 4, 2, 0, 5, 3, 6).contiguous().reshape(-1)           # [g][t][strip][pl][kg][col][e]
 
 
-def permute_weight_frag_grouped(w, J=128):
-    """[G*J, K] -> the weight operand of linear_relu_dot: split bf16 planes (lrd_weight_split; int16) by default, else the fp32 fragment order
-    [G][K/16][J/16][64][4] of etch_linear_relu_dot."""
+def lrd_weight_split_f16(w, J=128):
+    """[G*J, K] -> float16 [G][K/32][J/16 strips][plane h / l][lane = 16 * (k / 8) + column][8]: two fp16 planes of 2^wexp W (wexp: the power of two that
+    puts max |W| into [8, 16); exact, the kernel's epilogue takes it out again) in v_mfma_f32_16x16x32_f16 fragment order; the exponent rides on the
+    tensor as `.wexp` (etch_linear_relu_dot_f16)."""
     GJ, K = w.shape
+    assert GJ % J == 0 and J % 16 == 0 and K % 32 == 0
+    m = float(w.detach().abs().max())
+    wexp = 0 if m == 0.0 or not math.isfinite(m) else 3 - math.frexp(m)[1] + 1          # frexp: m = f 2^e, f in [0.5, 1)  ->  m 2^(4 - e) in [8, 16)
+    ws = w.detach() * (2.0 ** wexp)
+    hi = ws.to(torch.float16)
+    planes = torch.stack([hi, (ws - hi.float()).to(torch.float16)])          # [2][GJ][K]
+    q = planes.reshape(2, GJ // J, J // 16, 16, K // 32, 4, 8)               # [pl][g][strip][col][t][kg][e]
+    out = q.permute(1, 4, 2, 0, 5, 3, 6).contiguous().reshape(-1)            # [g][t][strip][pl][kg][col][e]
+    out.wexp = int(wexp)
+    return out
+
+
+def permute_weight_frag_grouped(w, J=128):
+    """[G*J, K] -> the weight operand of linear_relu_dot: two fp16 planes (lrd_weight_split_f16; round 5) where the weight-stationary kernel covers the
+    shape, else the three bf16 planes (lrd_weight_split; int16), else the fp32 fragment order [G][K/16][J/16][64][4] of etch_linear_relu_dot."""
+    GJ, K = w.shape
+    if LRD_SPLIT and LRD_F16 and J == 128 and K in (32, 64, 128) and (GJ // J == 1 or GJ // J >= 8):
+        return lrd_weight_split_f16(w.contiguous(), J)
     if LRD_SPLIT and J == 128 and K in (32, 64, 128, 256):
         return lrd_weight_split(w.contiguous(), J)
     return torch.cat([permute_weight_frag(w[g * J:(g + 1) * J].contiguous()) for g in range(GJ // J)])
@@ -829,6 +850,13 @@ def linear_relu_dot(x, w, b1, w2, b2, G, wp=None, out=None):
     assert x.stride(1) == 1 and w.shape == (G * J, K) and b1.numel() == G * J and w2.numel() == G * J and b2.numel() == G
     if out is None:
         out = torch.empty((R, G), dtype=torch.float32, device=x.device)
+    if wp is not None and wp.dtype == torch.float16 and (b1.data_ptr() | w2.data_ptr()) % 16 == 0:
+        _lib.check(_lib.lib().etch_linear_relu_dot_f16(_c_long(R), int(K), int(G), int(J), _ptr(x), _c_long(x.stride(0) if R > 1 else K), _ptr(wp), int(wp.wexp),
+                                                       _ptr(b1), _ptr(w2), _ptr(b2), _ptr(out), _c_long(out.stride(0) if R > 1 else G), _stream()),
+                   "etch_linear_relu_dot_f16")
+        return out
+    if wp is not None and wp.dtype == torch.float16:
+        wp = None                                  # (a bias / w2 view off the 16-byte grid: the fp32 kernel below)
     if wp is not None and wp.dtype == torch.int16:
         _lib.check(_lib.lib().etch_linear_relu_dot_split(_c_long(R), int(K), int(G), int(J), _ptr(x), _c_long(x.stride(0) if R > 1 else K), _ptr(wp),
                                                          _ptr(b1), _ptr(w2), _ptr(b2), _ptr(out), _c_long(out.stride(0) if R > 1 else G), _stream()),

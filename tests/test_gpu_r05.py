@@ -253,3 +253,29 @@ def test_intra_conv_two_plane_f16_matches_the_fp32_kernel_and_fp64(c, p, b, norm
     ref = torch.einsum("bpatc,oct->bpao", xd[:, :, conv.intra_idx.cuda()], W3) + bias.double()
     e_new, e_f32 = float((new.double() - ref).abs().max()), float((f32.double() - ref).abs().max())
     assert e_f32 < 3e-6 * scale and e_new <= 2.0 * e_f32 + 1e-7 * scale, (e_new, e_f32)
+
+
+@pytest.mark.parametrize("R,K,G", [(5000, 128, 86), (777, 64, 9), (4100, 32, 8), (3000, 128, 1)])
+def test_linear_relu_dot_f16_rows_of_any_scale(R, K, G):
+    """etch_linear_relu_dot_f16 (weight-stationary, v_mfma_f32_16x16x32_f16, two fp16 planes per operand): X carries no known scale, every row is staged
+    times its own power of two.  Rows spanning nine decades (b1 = 0: the output scales with the row) must each come out as close to the fp64 formula
+    (pointtransformer_seg.py:145) as the fp32-MFMA kernel's rows do (entitled error per row, x 2), and weights far from unit scale (x 2^-9, x 2^11) too."""
+    from etch_amd import ops
+    g = torch.Generator().manual_seed(R + K + G)
+    x = torch.randn(R, K, generator=g) * 10.0 ** (torch.rand(R, 1, generator=g) * 9 - 5)
+    b1, b2 = torch.zeros(G * 128), torch.zeros(G)
+    w2 = torch.randn(G, 128, generator=g) / 128 ** 0.5
+    for wscale in (1.0, 2.0 ** -9, 2.0 ** 11):
+        w = torch.randn(G * 128, K, generator=g) / K ** 0.5 * wscale
+        hid = torch.relu(x.double() @ w.double().T).view(R, G, 128) * w2.double()
+        ref = hid.sum(-1)
+        xc, wc, b1c, w2c, b2c = (t.cuda() for t in (x, w, b1, w2, b2))
+        wp = ops.permute_weight_frag_grouped(wc)
+        assert wp.dtype == torch.float16 and 8.0 <= float(wc.abs().max()) * 2.0 ** wp.wexp < 16.0
+        out = ops.linear_relu_dot(xc, wc, b1c, w2c.view(-1), b2c, G, wp=wp).double().cpu()
+        f32 = ops.linear_relu_dot(xc, wc, b1c, w2c.view(-1), b2c, G).double().cpu()
+        assert torch.equal(out, ops.linear_relu_dot(xc, wc, b1c, w2c.view(-1), b2c, G, wp=wp).double().cpu())
+        rows = hid.abs().sum(-1).amax(1).clamp_min(1e-300)              # the row's scale: the sum of its terms' magnitudes (one group: the sum itself may cancel)
+        e_new, e_f32 = (out - ref).abs().amax(1) / rows, (f32 - ref).abs().amax(1) / rows
+        assert float(e_f32.max()) < 3e-6 and float(e_new.max()) < 3e-6, (float(e_new.max()), float(e_f32.max()))
+        assert float(e_new.mean()) <= 2.0 * float(e_f32.mean()) + 1e-8, (float(e_new.mean()), float(e_f32.mean()))
