@@ -715,6 +715,9 @@ def main():
            "config": {"workload": cfg_name, "schedule": sched, "global_batch": B * world, "points": N, "parallelism": f"scan-sharded x{world}",
                       "distinct_batches": nbatch, "launcher": "torchrun/env" if "TORCHELASTIC_RUN_ID" in os.environ else ("self" if world > 1 else "single"),
                       "cpu_pinning": None if pinned is None else f"rank 0 on {len(pinned)} NUMA-local cores",
+                      # the box's 1-minute load average and hardware threads when the line was written: the host enqueues ~300 launches per step (8.5 ms of
+                      # Python undisturbed); on a box whose cores are busy with other tenants that becomes the bound
+                      "host_load": {"loadavg_1m": round(os.getloadavg()[0], 1), "hardware_threads": os.cpu_count()},
                       "collective_backend": (torch.distributed.get_backend() + (" (forced world-size-1 group: ETCH_FORCE_DIST)" if world == 1 else ""))
                       if torch.distributed.is_initialized() else None},
            "gathered_rows": {"columns": row_names, "scans_reported": int(allrows.shape[0]), "finite_scans": int(finite.sum()),

@@ -72,9 +72,9 @@ __device__ __forceinline__ float ml_wave_max(float v) {
     return ml_xmax(v);
 }
 // v_max3_f32 as written (fmaxf chains carry a canonicalising v_max_f32 x, x per operand that comes from memory or an MFMA: 240 instead of 64 operations per point)
-__device__ __forceinline__ float ml_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ __forceinline__ float ml_max3abs(float a, float b, float c) { float r; asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ __forceinline__ float ml_max4(const float4 v, float m) { return ml_max3abs(v.z, v.w, ml_max3abs(v.x, v.y, m)); }
+// (in place -- the result overwrites the first operand's register: see split_bf16.h on inline-asm results and in-flight MFMAs)
+__device__ __forceinline__ float ml_max3(float a, float b, float c) { asm("v_max3_f32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c)); return a; }
+__device__ __forceinline__ float ml_max4(const float4 v, float m) { return etch_max4abs(v, m); }
 // k with m 2^k in [8, 16) (m = 0 or subnormal: 0; capped so that 2^k is a float)
 __device__ __forceinline__ int ml_scale_exp(float m) {
     const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);

@@ -96,9 +96,13 @@ __device__ __forceinline__ void split2h_pair(float a, float b, unsigned& h, unsi
     h = __builtin_bit_cast(unsigned, (f16x2){(_Float16)a, (_Float16)b});
     // l = fp16 half * (-1) + x in one instruction each (v_fma_mix_f32 reads the half directly; exact: x - h has at most 14 significant bits) instead of
     // a conversion and a subtraction: 4 instead of 6 VALU operations per pair
-    float la, lb;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(la) : "v"(h), "v"(a));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(h), "v"(b));
+    // IN PLACE (the result overwrites the register that holds x): the compiler's hazard recogniser does not see inline asm, and a fresh output register
+    // could be one that an MFMA issued a moment ago is still reading as its accumulator input (write-after-read, up to 7 wait states for an 8-pass
+    // MFMA, no hardware interlock; etch_amd/isa_lint.py reported exactly that in csrc/mhsa_layer.hip).  A register that holds a live value cannot be
+    // one, and where x is needed afterwards the copy is a compiler-emitted move, which gets its wait states.  Reads: x was read by the conversion above.
+    float la = a, lb = b;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(la) : "v"(h));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lb) : "v"(h));
     l = __builtin_bit_cast(unsigned, (f16x2){(_Float16)la, (_Float16)lb});
 }
 // 4 consecutive fp32 values -> 2 planes x 4 fp16 (8 bytes each)
@@ -118,7 +122,8 @@ __device__ __forceinline__ void split2h_pack8(const float4 v0, const float4 v1, 
 // ---- bringing an operand into the fp16 planes' range (round 5).  The planes carry 23 bits only where |h| >= 2^-2, so a kernel whose operands have no
 // known scale multiplies a tile / a row by the power of two that puts its maximum into [8, 16) and takes the power out again where a scalar is applied
 // anyway (exact).  v_max3_f32 as written: fmaxf chains carry a canonicalising v_max_f32 x, x per operand that comes from memory.
-__device__ __forceinline__ float etch_max3abs(float a, float b, float c) { float r; asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// (in place, like the splits above: an inline-asm result never lands in a register the compiler considers free)
+__device__ __forceinline__ float etch_max3abs(float a, float b, float c) { asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(c) : "v"(a), "v"(b)); return c; }
 __device__ __forceinline__ float etch_max4abs(const float4 v, float m) { return etch_max3abs(v.z, v.w, etch_max3abs(v.x, v.y, m)); }
 // k with m 2^k in [8, 16) (m = 0 or subnormal: 0; capped so that 2^k is a float)
 __device__ __forceinline__ int etch_scale_exp(float m) {

@@ -180,6 +180,81 @@ def _lint_kernel(kernel, body, only_asm_loads):
     return findings
 
 
+MFMA_WINDOW = 24      # instructions: more than the 19 wait states the longest MFMA needs before a VALU may read its result (CDNA3 ISA 4.5)
+
+
+def lint_mfma_asm_reads(text):
+    """Second hazard class (round 5, found the hard way in csrc/mhsa_layer.hip): a VALU instruction written as INLINE ASM that reads a register a
+    v_mfma wrote a few instructions earlier.  The compiler's hazard recogniser inserts the required wait states (s_nop) only in front of instructions
+    it emitted itself, and the hardware does not interlock: the asm instruction reads the accumulator's OLD contents.  Safe patterns: a compiler-emitted
+    instruction reads the result first (it gets the wait states; MFMAs retire in order, so everything older is complete too), or an asm block with
+    >= 16 wait states of s_nop sits between (the guard in ml_attention).  -> findings: dict(kernel, line_no, instr, reg, mfma_line, distance)"""
+    findings = []
+    kernel, in_asm, idx = None, False, 0
+    fresh = {}            # register -> (instruction index of the v_mfma that wrote it, line number)
+    srcc = {}             # register -> (instruction index, line) of the youngest v_mfma that reads it as its accumulator INPUT (SrcC != vDst):
+                          # an inline-asm VALU WRITE to it while that MFMA is still reading is the write-after-read form of the same blind spot
+    label_re = re.compile(r"^([A-Za-z_.$][\w.$]*):")
+    for no, raw in enumerate(text.split("\n"), 1):
+        m = label_re.match(raw)
+        if m and m.group(1).startswith("_Z"):
+            kernel, fresh, srcc, idx = m.group(1), {}, {}, 0
+            continue
+        if ";;#ASMSTART" in raw:
+            in_asm, nops = True, 0
+            continue
+        if ";;#ASMEND" in raw:
+            in_asm = False
+            if nops >= 16:
+                fresh, srcc = {}, {}
+            continue
+        s = raw.split(";")[0].strip()
+        if kernel is None or not s or s.startswith((".", "//")) or label_re.match(s):
+            continue
+        idx += 1
+        op = s.split()[0]
+        operands = s[len(op):]
+        if op == "s_nop":
+            if in_asm:
+                nops += int(operands.strip() or 0) + 1
+            continue
+        parts = operands.split(",")
+        if op.startswith("v_mfma") or op.startswith("v_smfmac"):
+            dst = _regs(parts[0])
+            for r in dst:
+                fresh[r] = (idx, no)
+                srcc.pop(r, None)
+            if len(parts) >= 4:
+                for r in _regs(parts[3]) - dst:
+                    srcc[r] = (idx, no)
+            continue
+        if not fresh and not srcc:
+            continue
+        has_dst = op.startswith("v_") or _kind(op)[2]
+        srcs = _regs(",".join(parts[1:])) if has_dst else _regs(operands)
+        hit = [r for r in srcs if r in fresh]
+        if hit and in_asm and op.startswith("v_"):
+            for r in hit:
+                if idx - fresh[r][0] < MFMA_WINDOW:
+                    findings.append(dict(kernel=kernel, line_no=no, instr=s, reg="%s%d" % r, mfma_line=fresh[r][1], distance=idx - fresh[r][0]))
+        elif hit:       # a compiler-emitted read: it carries the wait states; everything at least as old is complete
+            newest = max(fresh[r][0] for r in hit)
+            fresh = {r: v for r, v in fresh.items() if v[0] > newest}
+        if has_dst:     # overwritten by something else: no longer an MFMA result (write-after-MFMA hazards of compiler-emitted writes are the compiler's)
+            wr = _regs(parts[0])
+            for r in wr:
+                fresh.pop(r, None)
+            over = [r for r in wr if r in srcc]
+            if over and in_asm and op.startswith("v_"):
+                for r in over:
+                    if idx - srcc[r][0] < MFMA_WINDOW // 2:
+                        findings.append(dict(kernel=kernel, line_no=no, instr=s, reg="%s%d" % r, mfma_line=srcc[r][1], distance=idx - srcc[r][0], kind="write-after-read"))
+            elif over:  # a compiler-emitted write got the wait states: that MFMA and every older one are past their reads
+                newest = max(srcc[r][0] for r in over)
+                srcc = {r: v for r, v in srcc.items() if v[0] > newest}
+    return findings
+
+
 def compile_to_asm(src, defines=(), extra=()):
     here = os.path.dirname(os.path.abspath(__file__))
     from . import build as B
@@ -208,7 +283,11 @@ def main(argv):
         for x in v[:40]:
             print(f"   line {x['line_no']}: `{x['instr']}` touches {x['reg']} while `{x['load_instr']}` (line {x['load_line']}, {'inline asm' if x['load_in_asm'] else 'compiler'}) may be in flight")
     print(f"{len(f)} finding(s) in {len(by_kernel)} kernel(s)")
-    return 1 if f else 0
+    g = lint_mfma_asm_reads(text)
+    for x in g[:40]:
+        print(f"   {x['kernel']} line {x['line_no']}: inline-asm `{x['instr']}` reads {x['reg']} {x['distance']} instructions after the v_mfma of line {x['mfma_line']} wrote it (no wait states)")
+    print(f"{len(g)} inline-asm VALU read(s) of a fresh MFMA result")
+    return 1 if f or g else 0
 
 
 if __name__ == "__main__":

@@ -42,3 +42,38 @@ def test_shipped_kernels_never_touch_an_asm_load_before_its_wait(src):
     assert n_asm_loads > 0
     f = L.lint_asm(text, only_asm_loads=True)
     assert f == [], f[:5]
+
+
+def test_lint_flags_an_asm_valu_read_of_a_fresh_mfma_result():
+    """The hazard behind the first build of the fp16 attention layer: `v_max3_f32` in inline asm straight after the MFMA that writes its operand."""
+    mfma = "\tv_mfma_f32_16x16x32_f16 v[4:7], v[8:11], v[12:15], 0\n"
+    bad = _kernel(mfma + "\t;;#ASMSTART\n\tv_max3_f32 v0, v4, v5, v6\n\t;;#ASMEND")
+    f = L.lint_mfma_asm_reads(bad)
+    assert len(f) == 3 and {x["reg"] for x in f} == {"v4", "v5", "v6"} and f[0]["distance"] == 1
+    # the destination of the asm instruction is not a read
+    assert L.lint_mfma_asm_reads(_kernel(mfma + "\t;;#ASMSTART\n\tv_max3_f32 v4, v1, v2, v3\n\t;;#ASMEND")) == []
+    # a compiler-emitted read first (it gets the wait states; older MFMAs are complete too) ...
+    ok1 = _kernel("\tv_mfma_f32_16x16x32_f16 v[20:23], v[8:11], v[12:15], 0\n" + mfma + "\tv_mul_f32_e32 v1, v2, v7\n\t;;#ASMSTART\n\tv_max3_f32 v0, v4, v20, v6\n\t;;#ASMEND")
+    assert L.lint_mfma_asm_reads(ok1) == []
+    # ... but not when it read an OLDER result only
+    bad2 = _kernel("\tv_mfma_f32_16x16x32_f16 v[20:23], v[8:11], v[12:15], 0\n" + mfma + "\tv_mul_f32_e32 v1, v2, v21\n\t;;#ASMSTART\n\tv_max3_f32 v0, v4, v20, v6\n\t;;#ASMEND")
+    assert {x["reg"] for x in L.lint_mfma_asm_reads(bad2)} == {"v4", "v6"}
+    # the guard block of ml_attention: >= 16 wait states of s_nop in inline asm
+    ok2 = _kernel(mfma + "\t;;#ASMSTART\n\ts_nop 7\n\ts_nop 7\n\ts_nop 3\n\t;;#ASMEND\n\t;;#ASMSTART\n\tv_max3_f32 v0, v4, v5, v6\n\t;;#ASMEND")
+    assert L.lint_mfma_asm_reads(ok2) == []
+    # write-after-read: an asm result landing in a register that an MFMA issued a moment ago still reads as its accumulator input
+    war = _kernel("\tv_mfma_f32_16x16x32_f16 v[16:19], v[8:11], v[12:15], v[4:7]\n\t;;#ASMSTART\n\tv_fma_mix_f32 v5, v1, -1.0, v2 op_sel_hi:[1,0,0]\n\t;;#ASMEND")
+    f = L.lint_mfma_asm_reads(war)
+    assert len(f) == 1 and f[0]["reg"] == "v5" and f[0].get("kind") == "write-after-read"
+    # in place on the accumulator of an in-place MFMA chain is a read of a fresh result instead (caught above); a compiler-emitted write first is fine
+    ok3 = _kernel("\tv_mfma_f32_16x16x32_f16 v[16:19], v[8:11], v[12:15], v[4:7]\n\tv_mov_b32_e32 v4, v1\n\t;;#ASMSTART\n\tv_fma_mix_f32 v5, v1, -1.0, v2 op_sel_hi:[1,0,0]\n\t;;#ASMEND")
+    assert L.lint_mfma_asm_reads(ok3) == []
+
+
+@pytest.mark.parametrize("src", ["mhsa_layer.hip", "so3conv_y.hip", "so3conv_ws.hip", "fused_dense.hip", "so3conv.hip"])
+def test_shipped_kernels_never_read_a_fresh_mfma_result_from_inline_asm(src):
+    """Every kernel source that mixes MFMAs with inline-asm VALU instructions (v_fma_mix_f32, v_max3_f32)."""
+    text = L.compile_to_asm(os.path.join(CSRC, src))
+    assert "v_mfma" in text
+    f = L.lint_mfma_asm_reads(text)
+    assert f == [], f[:5]
