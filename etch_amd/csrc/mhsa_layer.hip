@@ -162,16 +162,21 @@ __device__ __forceinline__ void ml_softmax(f32x4 (&s)[4], float c) {
     }
     m = ml_xmax(m);
     const float mc = m * c;
-    float sum = 0.f;
+    // the layer is VALU-bound since round 5: the exponent's fma and the running sum as PACKED fp32 instructions (v_pk_fma_f32 / v_pk_add_f32: two values
+    // per issue slot; beside an idle matrix pipe that is half the instructions) -- two partial sums, added at the end
+    typedef float ml_f32x2 __attribute__((ext_vector_type(2)));
+    const ml_f32x2 c2 = {c, c}, nmc2 = {-mc, -mc};
+    ml_f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float p = __builtin_amdgcn_exp2f(fmaf(s[j][r], c, -mc));
-            s[j][r] = p;
-            sum += p;
+        for (int r = 0; r < 4; r += 2) {
+            const ml_f32x2 t = __builtin_elementwise_fma((ml_f32x2){s[j][r], s[j][r + 1]}, c2, nmc2);
+            const ml_f32x2 p = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+            s[j][r] = p[0]; s[j][r + 1] = p[1];
+            sum2 += p;
         }
-    sum = ml_xsum(sum);
+    float sum = ml_xsum(sum2[0] + sum2[1]);
     float inv = __builtin_amdgcn_rcpf(sum);          // + one Newton step: the quotient to an ulp in 4 operations instead of the division's 10
     inv = fmaf(fmaf(-sum, inv, 1.0f), inv, inv) * 8192.0f;
 #pragma unroll
