@@ -33,11 +33,32 @@ class HotPathPipeline:
         self._n = 0
         self.host_times = [] if os.environ.get("ETCH_PIPE_TIMING") == "1" else None
 
+    def _reserve_allocator(self):
+        """Once, when the second batch is submitted (every stream of the path exists by then): give each stream's pool of the caching allocator a large
+        free block.  The pools are per stream and grow on demand; with three batches in flight the interleaving of allocations and cross-stream frees
+        keeps changing for dozens of steps, and every new segment is a hipMalloc on the enqueueing thread (measured: 13 new segments inside 16 timed
+        steps, one of them a 78 ms stall -- two steps' worth of the host's lead).  ETCH_PIPE_RESERVE_GIB (default 2 per stream, 0 = off); the path's
+        own peak is ~5 GiB of the GPU's 288."""
+        import os
+        gib = float(os.environ.get("ETCH_PIPE_RESERVE_GIB", "2"))
+        if gib <= 0 or not torch.cuda.is_available():
+            return
+        streams = list(self.s1s) + [self.s2]
+        side = getattr(self.model, "_side_stream", None)
+        streams += [side] if side is not None else []
+        streams += list(getattr(self.model, "_head_streams", None) or [])
+        for st in streams:
+            with torch.cuda.stream(st):
+                blk = torch.empty(int(gib * 2 ** 30), dtype=torch.uint8, device=self.args.device)
+                del blk
+
     def submit(self, points):
         """Enqueue one batch (B,N,3) resident on the device; returns a Ticket.  Does not block on the GPU unless
         `max_in_flight` batches are already outstanding: the pinned host buffers are a ring of max_in_flight + 1 slots, so the
         oldest ticket is then retired first (host waits for it; its result is kept on the ticket for result())."""
         import time
+        if self._n == 1:
+            self._reserve_allocator()
         t0 = time.perf_counter()
         t1 = t0
         while len(self.in_flight) >= self.max_in_flight:
