@@ -369,6 +369,7 @@ class GT_network_equiv(nn.Module):
         return results, selected_indexs
 
     concurrent_heads = True    # run the confidence and magnitude nets on their own HIP streams next to the direction head
+    direction_first = os.environ.get("ETCH_DIRECTION_FIRST", "1") != "0"      # host enqueue order of the three heads (A/B switch)
     defer_join = False         # True (set by a pipelined caller around forward): leave `pending_join` events instead of joining
     pending_join = None
 
@@ -395,17 +396,28 @@ class GT_network_equiv(nn.Module):
                 t.record_stream(main)
             return out
 
+        # The direction head is ENQUEUED first: a handful of chip-wide launches on the current stream, against ~200 small launches for the two nets.
+        # When the host is ahead of the GPU (the pipeline's normal state) the order is immaterial; when it is not (a busy host, a profiler) the current
+        # stream would otherwise idle for the whole time the host spends enqueueing the nets (seen as 15 - 70 ms gaps in front of
+        # interp_schedule_kernel in profiles/r05_stream_timeline.txt).  The side streams forked above: they do not wait for these kernels.
+        direction = None
+        if "direction" in pred_items and self.direction_first:
+            if direction_mode != "standard_vector":
+                raise AssertionError("Not implemented")   # same as the reference (:199,210)
+            standard_vector = self.standard_vector.repeat(B, N, 1)
+            direction = self.decode_direction(None, so3_anchors, standard_vector, tokens_cl=point_equiv_cl, interp=interp)
         if "confidence" in pred_items:
             part_labels, confidences = branch(0, lambda: self.decode_confidence(point_inv_feat, hitpts))
             results["confidences"] = confidences
             results["part_labels"] = part_labels
         if "magnitude" in pred_items:
             results["magnitude"] = branch(1, lambda: self.decode_magnitude(point_inv_feat, hitpts))
-        if "direction" in pred_items:
+        if "direction" in pred_items and not self.direction_first:
             if direction_mode != "standard_vector":
-                raise AssertionError("Not implemented")   # same as the reference (:199,210)
-            standard_vector = self.standard_vector.repeat(B, N, 1)
-            results["direction"] = self.decode_direction(None, so3_anchors, standard_vector, tokens_cl=point_equiv_cl, interp=interp)
+                raise AssertionError("Not implemented")
+            direction = self.decode_direction(None, so3_anchors, self.standard_vector.repeat(B, N, 1), tokens_cl=point_equiv_cl, interp=interp)
+        if direction is not None:
+            results["direction"] = direction
         self.pending_join = None
         if fork:
             if self.defer_join:
