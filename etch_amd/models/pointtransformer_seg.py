@@ -51,8 +51,18 @@ class PointTransformerLayer(nn.Module):
         self.softmax = nn.Softmax(dim=1)
         self._d = _Derived()
 
+    def _apply(self, fn, *a, **k):
+        self._ps = None                 # .to() / .cuda() / .float(): the tensors behind the cached list may be replaced
+        return super()._apply(fn, *a, **k)
+
     def _derived(self):
-        ps = [p for p in self.parameters()] + [b for b in self.buffers()]
+        # the tensors the derived constants depend on, enumerated ONCE: Module.parameters() / buffers() walk the module tree (named_modules), and 72
+        # such walks per forward were 45 % of the host's time per step (cProfile on the GPU box).  In-place updates (optimizer steps, load_state_dict)
+        # keep the objects and are seen by _Derived's (data_ptr, version) key; re-assigning a Parameter object of a sub-module needs `layer._ps = None`
+        ps = getattr(self, "_ps", None)
+        if ps is None:
+            ps = [p for p in self.parameters()] + [b for b in self.buffers()]
+            self.__dict__["_ps"] = ps
 
         def build():
             d = lambda t: t.detach().contiguous()

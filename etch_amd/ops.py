@@ -15,7 +15,14 @@ from . import _lib
 _c_int, _c_float, _vp = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """The current HIP stream's handle.  Asked ~300 times per step: torch.cuda.current_stream() builds a Stream object (10 us each, 3 ms of the host's
+    8.5 ms per step); the raw accessor returns the integer."""
+    if _raw_stream is not None:
+        return _vp(_raw_stream(torch.cuda.current_device()))
     return _vp(torch.cuda.current_stream().cuda_stream)
 
 

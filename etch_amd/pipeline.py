@@ -105,6 +105,13 @@ class HotPathPipeline:
         self.in_flight.append(t)
         if self.host_times is not None:      # (wait for the oldest ticket, finalize it, enqueue this batch) in ms: diagnostics
             self.host_times.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (time.perf_counter() - t2) * 1e3))
+            ms = torch.cuda.memory_stats()
+            cur = {k: ms.get(k, 0) for k in ("segment.large_pool.allocated", "segment.small_pool.allocated", "reserved_bytes.all.current", "num_alloc_retries")}
+            prev = getattr(self, "_ms_prev", cur)
+            if self.host_times[-1][2] > 25.0:
+                import sys
+                print("slow enqueue %.0f ms (batch %d): allocator deltas %s" % (self.host_times[-1][2], self._n, {k: cur[k] - prev[k] for k in cur}), file=sys.stderr)
+            self._ms_prev = cur
         return t
 
     def result(self, ticket):
