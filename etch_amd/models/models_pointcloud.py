@@ -274,6 +274,20 @@ class GT_network_equiv(nn.Module):
     overlap_index_ops = True   # run every coordinate-only index op (EPN FPS / ball queries, PT FPS / kNN) on a side stream
     input_producer = None      # stream that produced `hitpts` if it is not the current one (set by a pipelined caller)
 
+    keepalive = None     # a list set by a pipelined caller around forward(): cross-stream tensors are appended to it instead of being record_stream()-ed
+
+    def _cross_stream(self, tensors, streams):
+        """Tensors allocated on one stream and read on others.  Default: Tensor.record_stream (the caching allocator then defers the reuse of the block
+        until the other streams have passed the point of the free -- at the price of an event per (block, stream) that EVERY later allocation polls:
+        torch.empty cost ~45 us instead of ~5 on the pipeline's enqueue thread, the largest single item of its time per step).  A caller that retires
+        whole batches (pipeline.py) hands in a list instead and drops it when the batch's last kernel has completed: no events, same safety."""
+        if self.keepalive is not None:
+            self.keepalive.extend(tensors)
+            return
+        for t in tensors:
+            for st in streams:
+                t.record_stream(st)
+
     def _prefetch_indices(self, hitpts, B, N, want_pt):
         """FPS / ball queries of the EPN encoder and all FPS / kNN queries of both Point-Transformer nets depend on the
         coordinates only: issue them on a side HIP stream; the layers find them memoised (pointops.knn_scope).  The side
@@ -290,7 +304,7 @@ class GT_network_equiv(nn.Module):
         side = self._side_stream
         side.wait_stream(self.input_producer if self.input_producer is not None else main)
         made = []
-        hitpts.record_stream(side)
+        self._cross_stream([hitpts], [side])
         with torch.cuda.stream(side):
             cur = input_xyz(hitpts)
             made.append(cur)
@@ -316,9 +330,7 @@ class GT_network_equiv(nn.Module):
             done = torch.cuda.Event()
             done.record(side)
         users = [main] + (list(self._heads_streams()) if self.concurrent_heads else [])
-        for t in made:
-            for st in users:
-                t.record_stream(st)
+        self._cross_stream(made, users)
         return epn_ready, done
 
     def _input_order(self, hitpts):
@@ -384,16 +396,14 @@ class GT_network_equiv(nn.Module):
         if fork:
             for st in self._heads_streams():
                 st.wait_stream(main)
-                for t in (point_inv_feat, hitpts):      # read by the branch after this function returned (deferred join)
-                    t.record_stream(st)
+            self._cross_stream([point_inv_feat, hitpts], self._heads_streams())      # read by the branches after this function returned (deferred join)
 
         def branch(k, fn):
             if not fork:
                 return fn()
             with torch.cuda.stream(self._head_streams[k]):
                 out = fn()
-            for t in (out if isinstance(out, tuple) else (out,)):
-                t.record_stream(main)
+            self._cross_stream(list(out) if isinstance(out, tuple) else [out], [main])
             return out
 
         # The direction head is ENQUEUED first: a handful of chip-wide launches on the current stream, against ~200 small launches for the two nets.

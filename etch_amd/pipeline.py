@@ -10,6 +10,8 @@ from .models.fit_SMPL import fit_smpl_device, fit_smpl_finalize, fit_smpl_stage_
 
 
 class Ticket:
+    keepalive = None
+
     def __init__(self, done, stage1, fit):
         self.done, self.stage1, self.fit = done, stage1, fit
         self.finalized = None           # host-side result, set when the ticket was retired early to free its pinned buffers
@@ -32,6 +34,13 @@ class HotPathPipeline:
         self._pinned = [None] * (max_in_flight + 1)     # ring of pinned host buffers, one set per batch in flight (+1 being read)
         self._n = 0
         self.host_times = [] if os.environ.get("ETCH_PIPE_TIMING") == "1" else None
+
+    def __del__(self):
+        try:        # batches still in flight keep their cross-stream tensors alive through their tickets: do not let them go before the GPU is done
+            for t in self.in_flight:
+                t.done.synchronize()
+        except Exception:
+            pass
 
     def _reserve_allocator(self):
         """Once, when the second batch is submitted (every stream of the path exists by then): give each stream's pool of the caching allocator a large
@@ -64,29 +73,34 @@ class HotPathPipeline:
         while len(self.in_flight) >= self.max_in_flight:
             oldest = self.in_flight.pop(0)
             oldest.done.synchronize()
+            oldest.keepalive = None
             t1 = time.perf_counter()
             oldest.finalized = fit_smpl_finalize(oldest.fit)
         t2 = time.perf_counter()
         caller = torch.cuda.current_stream()
         s1 = self.s1s[self._n % len(self.s1s)]
         s1.wait_stream(caller)
-        points.record_stream(s1)        # the caller may drop `points` right after submit(): keep its memory until s1 is done with it
+        # Every tensor that crosses streams inside this batch (the input, the index tensors of the model's index stream, what the side streams' heads
+        # read and return, what stage 2 reads) is kept alive on the ticket until the batch's LAST kernel has completed, instead of being
+        # record_stream()-ed: no allocator events (which every later torch.empty of the enqueue thread would poll, models_pointcloud._cross_stream),
+        # and the caller may still drop `points` right after submit().  The pipeline owns the ticket (self.in_flight) until it is retired.
+        keep = [points]
         with torch.no_grad():
             with torch.cuda.stream(s1):
                 # the model's index stream waits for the producer of `points` (the caller's stream), not for s1's queue
                 self.model.input_producer = caller
                 self.model.defer_join = True          # the heads on side streams are joined on s2 below, not on s1
+                self.model.keepalive = keep
                 try:
                     results, _ = self.model(points, pred_items=["confidence", "direction", "magnitude"], direction_mode="standard_vector")
                 finally:
-                    self.model.input_producer, self.model.defer_join = None, False
+                    self.model.input_producer, self.model.defer_join, self.model.keepalive = None, False, None
                 joins = self.model.pending_join or []
                 self.model.pending_join = None
                 ready = torch.cuda.Event()
                 ready.record(s1)
             conf = results["confidences"]
-            for t in (points, conf, results["part_labels"], results["direction"], results["magnitude"]):
-                t.record_stream(self.s2)
+            keep += [conf, results["part_labels"], results["direction"], results["magnitude"]]
             with torch.cuda.stream(self.s2):
                 self.s2.wait_event(ready)
                 for ev in joins:
@@ -102,6 +116,7 @@ class HotPathPipeline:
                 done = torch.cuda.Event()
                 done.record(self.s2)
         t = Ticket(done, results, fit)
+        t.keepalive = keep
         self.in_flight.append(t)
         if self.host_times is not None:      # (wait for the oldest ticket, finalize it, enqueue this batch) in ms: diagnostics
             self.host_times.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (time.perf_counter() - t2) * 1e3))
@@ -119,6 +134,7 @@ class HotPathPipeline:
         if ticket.finalized is not None:
             return ticket.finalized
         ticket.done.synchronize()
+        ticket.keepalive = None
         if ticket in self.in_flight:
             self.in_flight.remove(ticket)
         return fit_smpl_finalize(ticket.fit)
