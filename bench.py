@@ -55,7 +55,7 @@ def build(device, seed=1, body="smpl"):
 
 # ------------------------------------------------------------------------------------------------ roofline
 SOURCE_OF_KERNEL = {"inter_so3conv_y_kernel": "so3conv_y.hip", "inter_so3conv_x_kernel": "so3conv_x.hip", "inter_so3conv_kernel": "so3conv.hip", "gemm_nt_kernel": "gemm.hip",
-                    "mhsa_layer_kernel": "mhsa_layer.hip", "mhsa_interp_layer_kernel": "mhsa_layer.hip", "linear_relu_dot_ws_kernel": "fused_dense.hip"}
+                    "mhsa_layer_kernel": "mhsa_layer.hip", "mhsa_layer_kernel<3>": "mhsa_layer.hip", "mhsa_interp_layer_kernel": "mhsa_layer.hip", "linear_relu_dot_ws_kernel": "fused_dense.hip"}
 SPLIT_RATE_TFLOPS = 403.0     # fp32 products per second on the bf16 matrix cores as six-term splits: 2418 TFLOP/s measured for v_mfma_f32_32x32x16_bf16 / 6 (profiles/r04_mfma_bf16_issue_rates.txt)
 
 
@@ -65,10 +65,10 @@ def algorithmic_flops(name, a):
     if name == "etch_linear":
         R, K, O = v[0], v[1], v[2]
         return 2.0 * R * K * O, f"gemm_nt_kernel"
-    if name in ("etch_linear_relu_dot", "etch_linear_relu_dot_split"):
+    if name in ("etch_linear_relu_dot", "etch_linear_relu_dot_split", "etch_linear_relu_dot_f16"):
         R, K, G, J = v[0], v[1], v[2], v[3]
-        ws = name.endswith("split") and K <= 128 and (G >= 8 or G == 1)          # the dispatch of etch_linear_relu_dot_split
-        return 2.0 * R * G * J * (K + 1), ("linear_relu_dot_ws_kernel" if ws else "linear_relu_dot_bx_kernel") if name.endswith("split") else "linear_relu_dot_kernel"
+        ws = name.endswith("f16") or (name.endswith("split") and K <= 128 and (G >= 8 or G == 1))          # the dispatch of etch_linear_relu_dot_split
+        return 2.0 * R * G * J * (K + 1), ("linear_relu_dot_ws_kernel" if ws else "linear_relu_dot_bx_kernel") if not name.endswith("dot") else "linear_relu_dot_kernel"
     if name in ("etch_inter_so3conv", "etch_inter_so3conv_ordered", "etch_inter_so3conv_split"):
         b, cin, cout, p1, p2, nn = v[0:6]
         kern = "inter_so3conv_c1_kernel" if cin == 1 else f"inter_so3conv_kernel<{cin},{cout},{(nn + 15) // 16 if nn <= 32 else 4}{',split' if name.endswith('split') else ''}>"
@@ -85,11 +85,13 @@ def algorithmic_flops(name, a):
         return 2.0 * b * p2 * 60 * 24 * (cin * nn + cout * cin), f"inter_so3conv32_kernel<{cin},{cout},{(nn + 7) // 8}>"
     if name in ("etch_intra_so3conv", "etch_intra_so3conv_stats", "etch_intra_so3conv32", "etch_intra_so3conv_split", "etch_intra_so3conv_f16"):
         b, c, cout, p = v[0:4]
-        kern = "intra_so3conv_ws_kernel" if name.endswith("split") else "intra_so3conv32_kernel" if name.endswith("32") else "intra_so3conv_kernel"
+        kern = "intra_so3conv_ws_kernel" if name.endswith(("split", "f16")) else "intra_so3conv32_kernel" if name.endswith("32") else "intra_so3conv_kernel"
         return 2.0 * b * p * 60 * 12 * c * cout, kern + f"<{c},{cout}>"
     if name == "etch_mhsa_layer":
         T, mode = v[0], v[7]
         return T * (2.0 * 60 * 64 * 192 + 8 * (2.0 * 60 * 60 * 8 * 2) + (2.0 * 60 * 64 * 64 if mode != 2 else 0.0)), "mhsa_layer_kernel"
+    if name == "etch_mhsa_layer_dirtail":    # heads of the last layer + the folded tail (64 -> 128 hidden -> 1 per token) in mhsa_layer_kernel<3>
+        return v[0] * (2.0 * 60 * 64 * 192 + 8 * (2.0 * 60 * 60 * 8 * 2) + 2.0 * 60 * 64 * 128 + 2.0 * 60 * 128), "mhsa_layer_kernel<3>"
     if name == "etch_mhsa_interp_layer":   # mode-0 layer on tokens interpolated in the kernel
         return float(v[0]) * v[1] * (2.0 * 60 * 64 * 192 + 8 * (2.0 * 60 * 60 * 8 * 2) + 2.0 * 60 * 64 * 64), "mhsa_interp_layer_kernel"
     if name == "etch_pt_attention_mfma":     # the c -> c/8 -> c/8 MLP of linear_w over the n * ns (point, neighbour) rows
