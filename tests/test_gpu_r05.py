@@ -279,3 +279,64 @@ def test_linear_relu_dot_f16_rows_of_any_scale(R, K, G):
         e_new, e_f32 = (out - ref).abs().amax(1) / rows, (f32 - ref).abs().amax(1) / rows
         assert float(e_f32.max()) < 3e-6 and float(e_new.max()) < 3e-6, (float(e_new.max()), float(e_f32.max()))
         assert float(e_new.mean()) <= 2.0 * float(e_f32.mean()) + 1e-8, (float(e_new.mean()), float(e_f32.mean()))
+
+
+def test_fp16_attention_intra_and_confidence_kernels_soak_under_contention(tmp_path):
+    """The other kernels that went to two fp16 planes in round 5 (attention layers incl. the fused tail and the interpolating first layer, intra
+    conv, confidence head) mix MFMAs with inline-asm VALU instructions, the class of code whose hazards the compiler does not see (DESIGN 3d;
+    tests/test_isa_lint.py checks the ISA).  Run time check: each kernel launched REPS times at the bench's shapes while a second stream keeps the
+    compute units busy with a gather-heavy inter conv -- every result bitwise equal to the first.  REPS from ETCH_SOAK_REPS / 4 (default 500)."""
+    import os
+
+    from etch_amd import ops
+    from etch_amd import vgtk_so3conv as V
+    reps = max(1, int(os.environ.get("ETCH_SOAK_REPS", "2000")) // 4)
+    g = torch.Generator().manual_seed(11)
+    T, B, S, N = 20000, 4, 1250, 5000
+    tok = (torch.randn(T, 60, 64, generator=g) * 10.0 ** (torch.rand(T, 1, 1, generator=g) * 4 - 2)).cuda()      # tiles of very different scales
+    wq, wk, wv, wc = (torch.randn(64, 64, generator=g).cuda() * 0.1 for _ in range(4))
+    bc = (torch.randn(64, generator=g) * 0.1).cuda()
+    Wf = (torch.randn(128, 64, generator=g) * 0.1).cuda()
+    tab = torch.randn(257, generator=g).cuda()
+    Wfq = ops.dirtail_weight_split(Wf)
+    pts = (torch.randn(B, N, 3, generator=g) * torch.tensor([0.14, 0.31, 0.085])).cuda()
+    sel = torch.stack([torch.randperm(N, generator=g)[:S] for _ in range(B)]).cuda()
+    xyz2 = torch.gather(pts, 1, sel[..., None].expand(-1, -1, 3)).permute(0, 2, 1).contiguous()
+    F = torch.randn(B, S, 60, 64, generator=g).cuda()
+    idx3, w3 = ops.prop3nn(pts, xyz2)
+    order = ops.spatial_order(pts.permute(0, 2, 1).contiguous())
+    conv = load_seeded(V.IntraSO3Conv(64, 64), 5).cuda()
+    Wp, bias, idx32, Wp32 = conv._derived()
+    xi = torch.randn(8, 1250, 60, 64, generator=g).cuda()
+    mm, rr = ops.instnorm_stats(xi)
+    xr = torch.randn(40000, 128, generator=g).cuda()
+    wl = (torch.randn(86 * 128, 128, generator=g) / 128 ** 0.5).cuda()
+    b1, w2, b2 = (torch.randn(86 * 128, generator=g) * 0.1).cuda(), (torch.randn(86 * 128, generator=g) / 11).cuda(), torch.randn(86, generator=g).cuda()
+    wlq = ops.permute_weight_frag_grouped(wl)
+    assert wlq.dtype == torch.float16
+    runs = {
+        "mhsa_layer_dirtail": lambda: ops.mhsa_layer_dirtail(tok.view(-1, 64), wq, wk, wv, Wfq, tab),
+        "mhsa_layer mode 0": lambda: ops.mhsa_layer(tok.view(-1, 64), wq, wk, wv, wc, bc, mode=0),
+        "mhsa_interp_layer": lambda: ops.mhsa_interp_layer(F, idx3, w3, wq, wk, wv, wc, bc, order=order),
+        "intra_so3conv_f16": lambda: ops.intra_so3conv(xi, idx32, Wp, bias, 64, mm, rr, Wqh=conv._wqh),
+        "linear_relu_dot_f16": lambda: ops.linear_relu_dot(xr, wl, b1, w2, b2, 86, wp=wlq),
+    }
+    # the contender: the round-5 inter conv (register-ring gathers, LDS staging, both matrix-core shapes) on a second stream
+    ci = load_seeded(V.InterSO3Conv(32, 32, 1, 1, 0.113137, 0.0064, 32), 3).cuda()
+    x0 = pts.permute(0, 2, 1).contiguous()[:, :, :2500].contiguous()
+    ball = ops.ball_query(x0, x0, 0.113137, 32)
+    rk, W, Wpi, bi = ci._derived()
+    fi = torch.randn(B, 2500, 60, 32, generator=g).cuda()
+    pl = ops.split2_planes_f16(fi)
+    s2 = torch.cuda.Stream()
+    first = {k: f() for k, f in runs.items()}
+    assert all(bool(torch.isfinite(v).all()) for v in first.values())
+    bad = {k: 0 for k in runs}
+    for i in range(reps):
+        if i % 2 == 0:
+            with torch.cuda.stream(s2):
+                ops.inter_so3conv(x0, x0, ball, fi, rk, W, Wpi, bi, 0.0064, Wqh=ci._wqh(), kq=ci._kq(), feats_planes=pl)
+        for k, f in runs.items():
+            bad[k] += int(not torch.equal(f(), first[k]))
+    torch.cuda.synchronize()
+    assert not any(bad.values()), bad
