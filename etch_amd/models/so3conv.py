@@ -1,4 +1,6 @@
 """MI355X counterpart of /root/reference/src/models/so3conv.py (same classes, same state-dict keys)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -97,16 +99,15 @@ class SeparableSO3ConvBlock(nn.Module):
         self.norm = nn.InstanceNorm2d(dim_out, affine=False)
         self.emit_planes = False
 
-    def forward(self, x, inter_idx, inter_w):
-        conv = self.inter_conv.conv
-        inter_idx, _, sample_idx, y = conv(x, inter_idx, inter_w)
-        m1, r1 = getattr(y, "in_stats", None) or ops.instnorm_stats(y.feats_cl)     # from the conv's epilogue
-        z = self.intra_conv.conv(y, m1, r1, want_stats=True)     # IN + lrelu of the inter output applied on load; statistics of z in the epilogue
-        m2, r2 = z.in_stats
-        # skip branch: 1x1 conv on (optionally sub-sampled) input rows
-        fin = x.feats_cl
+    # ETCH_SKIP_STREAM=1 (A/B switch): the skip branch (a bandwidth-bound 1x1 conv + its statistics pass, independent of the inter / intra convs until
+    # the final add) on a side stream next to the latency-bound inter conv.  The side stream waits for an event recorded on the current stream before
+    # the inter conv is enqueued and the current stream waits for the branch before the final pass, so every buffer either stream frees is reused in
+    # stream order behind those waits (no record_stream needed).
+    skip_on_side_stream = os.environ.get("ETCH_SKIP_STREAM", "0") == "1"
+    _side = None
+
+    def _skip_branch(self, fin, sample_idx, p2):
         b, p1, na, cin = fin.shape
-        p2 = y.feats_cl.shape[1]
         w = self.skip_conv.weight.detach().view(self.skip_conv.out_channels, cin)
         bias = self.skip_conv.bias.detach()
         if self.stride > 1:
@@ -115,6 +116,37 @@ class SeparableSO3ConvBlock(nn.Module):
             s = ops.linear(fin.view(-1, cin), w, bias=bias)
         s = s.view(b, p2, na, -1)
         m3, r3 = ops.instnorm_stats(s)
+        return s, m3, r3
+
+    def forward(self, x, inter_idx, inter_w):
+        conv = self.inter_conv.conv
+        fin = x.feats_cl
+        branch = None
+        if self.skip_on_side_stream and fin.is_cuda and not torch.is_grad_enabled():
+            if SeparableSO3ConvBlock._side is None:
+                from ..utils.cu_streams import make_stream
+                SeparableSO3ConvBlock._side = make_stream("side")
+            side, main = SeparableSO3ConvBlock._side, torch.cuda.current_stream()
+            _, sidx0, nx = conv.group(x.xyz)                # memoised: the conv below finds the same tensors
+            ev0 = torch.cuda.Event()
+            ev0.record(main)
+            side.wait_event(ev0)
+            with torch.cuda.stream(side):
+                branch = self._skip_branch(fin, sidx0, nx.shape[-1])
+                ev1 = torch.cuda.Event()
+                ev1.record(side)
+        inter_idx, _, sample_idx, y = conv(x, inter_idx, inter_w)
+        m1, r1 = getattr(y, "in_stats", None) or ops.instnorm_stats(y.feats_cl)     # from the conv's epilogue
+        z = self.intra_conv.conv(y, m1, r1, want_stats=True)     # IN + lrelu of the inter output applied on load; statistics of z in the epilogue
+        m2, r2 = z.in_stats
+        # skip branch: 1x1 conv on (optionally sub-sampled) input rows
+        b, p1, na, cin = fin.shape
+        p2 = y.feats_cl.shape[1]
+        if branch is None:
+            s, m3, r3 = self._skip_branch(fin, sample_idx, p2)
+        else:
+            s, m3, r3 = branch
+            torch.cuda.current_stream().wait_event(ev1)
         # emit_planes (set by EquivBackbone when the NEXT conv gathers planes; True / "bf16" / "f16" = their format): the output is also written split, once, by this pass
         planes = None
         if self.emit_planes:
