@@ -348,7 +348,11 @@ class GT_network_equiv(nn.Module):
             # stream is a few chip-wide kernels: high-priority queues let the chains go first whenever they have work
             prio = int(os.environ.get("ETCH_HEAD_STREAM_PRIORITY", "-1"))
             from ..utils.cu_streams import make_stream
-            self._head_streams = (make_stream("side", priority=prio), make_stream("side", priority=prio))
+            if os.environ.get("ETCH_HEAD_STREAMS", "2") == "1":     # A/B switch: both nets on ONE side stream (four streams in all = HIP's four hardware queues)
+                one = make_stream("side", priority=prio)
+                self._head_streams = (one, one)
+            else:
+                self._head_streams = (make_stream("side", priority=prio), make_stream("side", priority=prio))
         return self._head_streams
 
     def _forward(self, hitpts, pred_items, direction_mode, B, N):
