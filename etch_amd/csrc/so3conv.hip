@@ -486,13 +486,50 @@ __global__ void __launch_bounds__(256) inter_so3conv_c1_kernel(
     }
     __syncthreads();
     float* outp = out + ((size_t)b * p2 + p) * NA * cout;
+    // Step 2 (32 output channels, the path's first conv): thread = (anchor, block of 8 channels) keeps its X1 row in registers and reads the weights as
+    // 16-byte broadcasts -- 54 LDS instructions per thread instead of 360 scalar ones (two per FMA: the launch was as much LDS- as VALU-bound); the
+    // 60 x 32 outputs go through the (now free) gathered-feature tile so that the store / statistics loop below keeps its thread mapping, i.e. the
+    // same FMA order per output and the same fp64 summation order: results bit for bit those of the scalar form.
+#ifdef C1_SCALAR_STEP2
+    const bool tile2 = false;                               // (A/B build: the scalar form)
+#else
+    const bool tile2 = cout == 32 && nn >= 32;
+#endif
+    float* Yt = Fn;                                         // [NA][32]
+    if (tile2) {
+        if (tid < NA * 4) {
+            const int a = tid % NA, ob = tid / NA;
+            float x[KS];
+#pragma unroll
+            for (int i = 0; i < KS / 4; ++i) {
+                const float4 v = *reinterpret_cast<const float4*>(&X1[a * KS + 4 * i]);
+                x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int o = 8 * ob + j;
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < KS / 4; ++i) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(&Ws[o * KS + 4 * i]);
+                    acc = fmaf(w4.x, x[4 * i], acc); acc = fmaf(w4.y, x[4 * i + 1], acc); acc = fmaf(w4.z, x[4 * i + 2], acc); acc = fmaf(w4.w, x[4 * i + 3], acc);
+                }
+                Yt[a * 32 + o] = acc + bias[o];
+            }
+        }
+        __syncthreads();
+    }
     double st_s = 0.0, st_q = 0.0;                          // fused InstanceNorm statistics in fp64 (needs 256 % cout == 0: fixed channel per thread)
     for (int e = tid; e < NA * cout; e += 256) {
         const int a = e / cout, o = e - a * cout;
         float acc = 0.f;
+        if (tile2) {
+            acc = Yt[e];
+        } else {
 #pragma unroll
-        for (int i = 0; i < KS; ++i) acc = fmaf(Ws[o * KS + i], X1[a * KS + i], acc);
-        acc += bias[o];
+            for (int i = 0; i < KS; ++i) acc = fmaf(Ws[o * KS + i], X1[a * KS + i], acc);
+            acc += bias[o];
+        }
         outp[e] = acc;
         st_s += (double)acc; st_q += (double)acc * (double)acc;
     }
