@@ -297,12 +297,13 @@ static int launch_lrd_bx(long R, int G, const float* X, long ldx, const void* Wq
 // F16 (round 5, etch_linear_relu_dot_f16): the same kernel on v_mfma_f32_16x16x32_f16 with TWO fp16 planes per operand and three cross terms -- half
 // the matrix instructions of the bf16 split (the confidence head's launch is matrix-bound: pipe busy 0.61).  X has no known scale (Point-Transformer
 // features), so every ROW is multiplied by the power of two that puts its maximum into [8, 16) (its 128 channels sit in 32 consecutive lanes when the
-// tile is staged: a DPP maximum, no barrier) and the power leaves again in the epilogue's fmaf with the bias; Wq arrives as the planes of 2^wexp W.
+// tile is staged: a DPP maximum, no barrier) and the power leaves again in the epilogue's fmaf with the bias; Wq arrives as planes of W with every row (hidden unit) times its own power
+// of two, `wsc` holds the inverse powers (an operand scaled per matrix only would leave rows far below the matrix maximum with the planes' absolute floor).
 template <int K, int SPW, bool F16 = false>
 __global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, const float* __restrict__ X, long ldx,
                                                                  const bf16x8* __restrict__ Wq, const float* __restrict__ b1,
                                                                  const float* __restrict__ w2, const float* __restrict__ b2,
-                                                                 float* __restrict__ out, long ldo, unsigned* __restrict__ ctr, int wexp) {
+                                                                 float* __restrict__ out, long ldo, unsigned* __restrict__ ctr, const float* __restrict__ wsc) {
     __shared__ unsigned s_grab[2];
     // 64-row tiles, planes and reduction table double-buffered: ONE barrier per tile, and the next tile's split + LDS stores sit between the two
     // halves of this tile's MFMA stream (VALU work beside the bf16 matrix cores is free; beside a barrier it is not)
@@ -313,7 +314,7 @@ __global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned short* Xp = reinterpret_cast<unsigned short*>(lds);            // [2 buffers][NPL][FD_ROWS][SB]
     float* red = lds + 2 * NPL * PLANE / 2;                                  // [2 buffers][8 waves][FD_ROWS]
-    float* rsc = red + 2 * 8 * FD_ROWS;                                      // F16: [2 buffers][FD_ROWS] the rows' epilogue factors 2^-(kx + wexp)
+    float* rsc = red + 2 * 8 * FD_ROWS;                                      // F16: [2 buffers][FD_ROWS] the rows' epilogue factors 2^-kx
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
     const int cb = blockIdx.x, rb = blockIdx.y;
@@ -335,6 +336,13 @@ __global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, 
     for (int s2 = 0; s2 < SPW; ++s2) {
         bs[s2] = *reinterpret_cast<const float4*>(b1 + g * FD_J + (s0 + s2) * 16 + 4 * fg);
         ww[s2] = *reinterpret_cast<const float4*>(w2 + g * FD_J + (s0 + s2) * 16 + 4 * fg);
+        if constexpr (F16) {
+            // every hidden unit's weight row carries its own power of two 2^kw; wsc = 2^-kw.  relu(2^-kw a + b) w2 = relu(a + 2^kw b) (2^-kw w2): the powers
+            // move into the bias and w2 once per workgroup (exact), the epilogue stays as it is
+            const float4 k4 = *reinterpret_cast<const float4*>(wsc + g * FD_J + (s0 + s2) * 16 + 4 * fg);
+            bs[s2] = make_float4(bs[s2].x / k4.x, bs[s2].y / k4.y, bs[s2].z / k4.z, bs[s2].w / k4.w);
+            ww[s2] = make_float4(ww[s2].x * k4.x, ww[s2].y * k4.y, ww[s2].z * k4.z, ww[s2].w * k4.w);
+        }
     }
     const float b2a = b2[GPB * cb < G ? GPB * cb : G - 1], b2b = b2[GPB * cb + 1 < G ? GPB * cb + 1 : G - 1];
 
@@ -371,7 +379,7 @@ __global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, 
                 unsigned short* d = P + row * SB + c;
                 *reinterpret_cast<uint2*>(d) = ph;
                 *reinterpret_cast<uint2*>(d + PLANE) = pl;
-                if (c == 0) rs[row] = ldexpf(1.0f, -(kx + wexp));
+                if (c == 0) rs[row] = ldexpf(1.0f, -kx);
                 continue;
             }
             const float v[4] = {xn[h].x, xn[h].y, xn[h].z, xn[h].w};
@@ -469,7 +477,7 @@ __global__ void __launch_bounds__(512) linear_relu_dot_ws_kernel(long R, int G, 
 
 template <int K, int SPW, bool F16 = false>
 static int launch_lrd_ws(long R, int G, const float* X, long ldx, const void* Wq, const float* b1, const float* w2, const float* b2, float* out,
-                         long ldo, hipStream_t st, int wexp = 0) {
+                         long ldo, hipStream_t st, const float* wsc = nullptr) {
     constexpr int FD_ROWS = 64;
     const size_t lds = (size_t)2 * (F16 ? 2 : 3) * FD_ROWS * (K + 8) * 2 + (size_t)2 * 8 * FD_ROWS * sizeof(float) + (size_t)2 * FD_ROWS * sizeof(float);
     auto kern = linear_relu_dot_ws_kernel<K, SPW, F16>;
@@ -492,29 +500,30 @@ static int launch_lrd_ws(long R, int G, const float* X, long ldx, const void* Wq
                        // one column block only (the direction tail).  With many column blocks (the confidence head: 43) the workgroups of a row position
                        // walk the same X tiles in lock-step and share them through L2; per-block counters let them drift apart (measured: 706 against
                        // 744 scans/s, and unstable) -- those launches keep the static round-robin
-                       ncb == 1 ? etch_work_counter_slot(st) : nullptr, wexp);
+                       ncb == 1 ? etch_work_counter_slot(st) : nullptr, wsc);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }
 
 // The weight-stationary kernel on the fp16 matrix cores (two planes per operand).  Wqh = ops.lrd_weight_split_f16: lrd_weight_split's order with two fp16
-// planes of 2^wexp W.  Shapes the weight-stationary kernel covers: K in {32, 64, 128}, G = 1 or G >= 8, b1 / w2 16-byte aligned; else ETCH_EUNSUPPORTED.
-extern "C" int etch_linear_relu_dot_f16(long R, int K, int G, int J, const float* X, long ldx, const void* Wqh, int wexp, const float* b1, const float* w2,
+// planes of W, every ROW (hidden unit) times its own power of two; wsc (G * J floats) = the inverse powers.  Shapes the weight-stationary kernel covers:
+// K in {32, 64, 128}, G = 1 or G >= 8, b1 / w2 / wsc 16-byte aligned; else ETCH_EUNSUPPORTED.
+extern "C" int etch_linear_relu_dot_f16(long R, int K, int G, int J, const float* X, long ldx, const void* Wqh, const float* wsc, const float* b1, const float* w2,
                                         const float* b2, float* out, long ldo, void* stream) {
     if (R <= 0 || G <= 0) return ETCH_OK;
-    if (!X || !Wqh || !b1 || !w2 || !b2 || !out) return ETCH_EINVAL;
-    if ((ldx & 3) || ((uintptr_t)X & 15) || ((uintptr_t)Wqh & 15)) return ETCH_EINVAL;
+    if (!X || !Wqh || !wsc || !b1 || !w2 || !b2 || !out) return ETCH_EINVAL;
+    if ((ldx & 3) || ((uintptr_t)X & 15) || ((uintptr_t)Wqh & 15) || ((uintptr_t)wsc & 15)) return ETCH_EINVAL;
     if (J != FD_J || ((((uintptr_t)b1 | (uintptr_t)w2) & 15) != 0)) return ETCH_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (G >= 8) {
-        if (K == 32) return launch_lrd_ws<32, 2, true>(R, G, X, ldx, Wqh, b1, w2, b2, out, ldo, st, wexp);
-        if (K == 64) return launch_lrd_ws<64, 2, true>(R, G, X, ldx, Wqh, b1, w2, b2, out, ldo, st, wexp);
-        if (K == 128) return launch_lrd_ws<128, 2, true>(R, G, X, ldx, Wqh, b1, w2, b2, out, ldo, st, wexp);
+        if (K == 32) return launch_lrd_ws<32, 2, true>(R, G, X, ldx, Wqh, b1, w2, b2, out, ldo, st, wsc);
+        if (K == 64) return launch_lrd_ws<64, 2, true>(R, G, X, ldx, Wqh, b1, w2, b2, out, ldo, st, wsc);
+        if (K == 128) return launch_lrd_ws<128, 2, true>(R, G, X, ldx, Wqh, b1, w2, b2, out, ldo, st, wsc);
     }
     if (G == 1) {
-        if (K == 32) return launch_lrd_ws<32, 1, true>(R, G, X, ldx, Wqh, b1, w2, b2, out, ldo, st, wexp);
-        if (K == 64) return launch_lrd_ws<64, 1, true>(R, G, X, ldx, Wqh, b1, w2, b2, out, ldo, st, wexp);
-        if (K == 128) return launch_lrd_ws<128, 1, true>(R, G, X, ldx, Wqh, b1, w2, b2, out, ldo, st, wexp);
+        if (K == 32) return launch_lrd_ws<32, 1, true>(R, G, X, ldx, Wqh, b1, w2, b2, out, ldo, st, wsc);
+        if (K == 64) return launch_lrd_ws<64, 1, true>(R, G, X, ldx, Wqh, b1, w2, b2, out, ldo, st, wsc);
+        if (K == 128) return launch_lrd_ws<128, 1, true>(R, G, X, ldx, Wqh, b1, w2, b2, out, ldo, st, wsc);
     }
     return ETCH_EUNSUPPORTED;
 }

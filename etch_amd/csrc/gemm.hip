@@ -9,6 +9,7 @@
 // interleaved order (lane group g = lane>>4 takes k = 16t + 4g + s in MFMA step s) so that one
 // ds_read_b128 per operand feeds four MFMAs; A and B use the same order, so the sum is unchanged.
 #include "common.h"
+#include "split_bf16.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -334,18 +335,26 @@ __device__ __forceinline__ void g_split8(const float4 v0, const float4 v1, g_bf1
 }
 
 // O = 16 * SPW * (8 / RP) output channels; RP row parts (the 4 row tiles of a 64-row tile divided among them)
-template <int K, int SPW, int RP>
+// F16 (round 5): two fp16 planes per operand on v_mfma_f32_16x16x32_f16, three cross terms.  Neither operand has a known scale here (Point-Transformer
+// features, trained weights): every row of X is staged times the power of two that puts its maximum into [8, 16) (its K / 4 float4s sit in one aligned
+// lane group: DPP maximum, no barrier), every ROW of W (output channel) likewise, once per workgroup; both powers leave in the epilogue's
+// first fmaf (exact).  Opt-in (ETCH_LINEAR_SPLIT=f16): see the dispatch in etch_linear.
+template <int K, int SPW, int RP, bool F16 = false>
 __global__ void __launch_bounds__(512) gemm_ws_split_kernel(GemmArgs a, long rows_per_block) {
     constexpr int FD_ROWS = 64, SB = K + 8, KT = K / 32, PLANE = FD_ROWS * SB;
+    constexpr int NPL = F16 ? 2 : 3;
     constexpr int SG = 8 / RP;                    // strip groups (waves along the output channels)
     constexpr int RTW = (FD_ROWS / 16) / RP;      // row tiles per wave
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    unsigned short* Xp = reinterpret_cast<unsigned short*>(lds);            // [2 buffers][3][FD_ROWS][SB]
+    unsigned short* Xp = reinterpret_cast<unsigned short*>(lds);            // [2 buffers][NPL][FD_ROWS][SB]
+    float* rsc = lds + 2 * NPL * PLANE / 2;                                 // F16: [2 buffers][FD_ROWS] the rows' factors 2^-kx
+    float* wtab = rsc + 2 * FD_ROWS;                                        // F16: [8 waves][SPW][16] the weight rows' factors 2^-kw
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
     const int sg = wave % SG, rp = wave / SG;
     // this wave's weight fragments: strips SPW sg .. + SPW - 1, rows (output channels) 16 strip + fr, k = 32 t + 8 fg + e
-    g_bf16x8 wf[KT][SPW][3];
+    g_bf16x8 wf[KT][SPW][NPL];
+    float4 wk4[SPW];                              // F16: 2^-kw of this lane's four output channels (rows 4 fg .. of the strip)
     // epilogue constants: resident next to the weight fragments where both fit the 256-register budget of 2 waves/SIMD, re-read per row tile
     // (36 of them, L1 hits) where the fragments alone take 144 (K = 128, 3 strips: 22 spilled registers otherwise)
     constexpr bool EPI_REGS = KT * SPW * 12 <= 96;
@@ -358,10 +367,42 @@ __global__ void __launch_bounds__(512) gemm_ws_split_kernel(GemmArgs a, long row
 #pragma unroll
     for (int s2 = 0; s2 < SPW; ++s2) {
         const int o = 16 * (SPW * sg + s2);
+        wk4[s2] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if constexpr (F16) {
+            float4 w0[KT], w1[KT];
+            float m = 0.f;
 #pragma unroll
-        for (int t = 0; t < KT; ++t) {
-            const float* p = a.W + (long)(o + fr) * a.ldw + 32 * t + 8 * fg;
-            g_split8(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4), wf[t][s2]);
+            for (int t = 0; t < KT; ++t) {
+                const float* p = a.W + (long)(o + fr) * a.ldw + 32 * t + 8 * fg;
+                w0[t] = *reinterpret_cast<const float4*>(p); w1[t] = *reinterpret_cast<const float4*>(p + 4);
+                m = etch_max4abs(w1[t], etch_max4abs(w0[t], m));
+            }
+            // the maximum of THIS lane's weight row (output channel o + fr): its K / 8 slices sit in the four lanes fr, fr + 16, fr + 32, fr + 48
+            {
+                typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+                u32x2_ r_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+                m = fmaxf(__uint_as_float(r_[0]), __uint_as_float(r_[1]));
+                r_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+                m = fmaxf(__uint_as_float(r_[0]), __uint_as_float(r_[1]));
+            }
+            const int kw = etch_scale_exp(m);
+            const float sw = ldexpf(1.0f, kw);
+            if (fg == 0) wtab[(wave * SPW + s2) * 16 + fr] = ldexpf(1.0f, -kw);
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                f16x8 h, l;
+                split2h_pack8(make_float4(w0[t].x * sw, w0[t].y * sw, w0[t].z * sw, w0[t].w * sw), make_float4(w1[t].x * sw, w1[t].y * sw, w1[t].z * sw, w1[t].w * sw), h, l);
+                wf[t][s2][0] = __builtin_bit_cast(g_bf16x8, h); wf[t][s2][1] = __builtin_bit_cast(g_bf16x8, l);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                const float* p = a.W + (long)(o + fr) * a.ldw + 32 * t + 8 * fg;
+                g_bf16x8 q3[3];
+                g_split8(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4), q3);
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) wf[t][s2][pl] = q3[pl % 3];
+            }
         }
         // epilogue constants of the lane's 4 channels o + 4 fg .. + 3
         if constexpr (EPI_REGS) epi_load(o, bs[s2], sc[s2], sh[s2]);
@@ -383,10 +424,21 @@ __global__ void __launch_bounds__(512) gemm_ws_split_kernel(GemmArgs a, long row
             if (r0 + row0 + h * RSTEP < row_hi) xn[h] = *reinterpret_cast<const float4*>(src + (long)(h * RSTEP) * a.ldx);
         }
     };
-    auto stage = [&](unsigned short* P) {
+    auto stage = [&](unsigned short* P, float* rs) {
         unsigned short* d0 = P + row0 * SB + c0;
 #pragma unroll
         for (int h = 0; h < XL; ++h) {
+            if constexpr (F16) {
+                const int kx = etch_scale_exp(etch_group_max<C4>(etch_max4abs(xn[h], 0.f)));      // the row's power of two (its C4 float4s: one lane group)
+                const float sx = ldexpf(1.0f, kx);
+                uint2 ph, pl;
+                split2h_pack4(make_float4(xn[h].x * sx, xn[h].y * sx, xn[h].z * sx, xn[h].w * sx), ph, pl);
+                unsigned short* d = d0 + h * RSTEP * SB;
+                *reinterpret_cast<uint2*>(d) = ph;
+                *reinterpret_cast<uint2*>(d + PLANE) = pl;
+                if (c0 == 0) rs[row0 + h * RSTEP] = ldexpf(1.0f, -kx);
+                continue;
+            }
             const float v[4] = {xn[h].x, xn[h].y, xn[h].z, xn[h].w};
             unsigned hh[4], mm[4], ll[4];
 #pragma unroll
@@ -398,20 +450,28 @@ __global__ void __launch_bounds__(512) gemm_ws_split_kernel(GemmArgs a, long row
         }
     };
     // row tile i of the 64-row tile at r0: D[channel 4 fg + q of strip s2][row 16 i + fr] -> epilogue -> Y
-    auto row_tile = [&](const unsigned short* P, int i, long r0) {
+    auto row_tile = [&](const unsigned short* P, int i, long r0, const float* rs) {
         f32x4 acc[SPW];
 #pragma unroll
         for (int s2 = 0; s2 < SPW; ++s2) acc[s2] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
-            g_bf16x8 x[3];
+            g_bf16x8 x[NPL];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) x[pl] = *reinterpret_cast<const g_bf16x8*>(P + pl * PLANE + (i * 16 + fr) * SB + t * 32 + fg * 8);
-#define G_T(PA, PB) _Pragma("unroll") for (int s2 = 0; s2 < SPW; ++s2) acc[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][s2][PA], x[PB], acc[s2], 0, 0, 0);
+            for (int pl = 0; pl < NPL; ++pl) x[pl] = *reinterpret_cast<const g_bf16x8*>(P + pl * PLANE + (i * 16 + fr) * SB + t * 32 + fg * 8);
+            if constexpr (F16) {
+#define G_T(PA, PB) _Pragma("unroll") for (int s2 = 0; s2 < SPW; ++s2) \
+        acc[s2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[t][s2][PA]), __builtin_bit_cast(f16x8, x[PB]), acc[s2], 0, 0, 0);
+                G_T(1, 0) G_T(0, 1) G_T(0, 0)
+#undef G_T
+                continue;
+            }
+#define G_T(PA, PB) _Pragma("unroll") for (int s2 = 0; s2 < SPW; ++s2) acc[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][s2][PA % NPL], x[PB % NPL], acc[s2], 0, 0, 0);
             G_T(2, 0) G_T(0, 2) G_T(1, 1) G_T(1, 0) G_T(0, 1) G_T(0, 0)
 #undef G_T
         }
         const long r = r0 + i * 16 + fr;
+        const float rsv = F16 ? rs[i * 16 + fr] : 1.0f;      // this lane's row: the power of two of its staging
         if (r < row_hi) {
 #pragma unroll
             for (int s2 = 0; s2 < SPW; ++s2) {
@@ -419,7 +479,14 @@ __global__ void __launch_bounds__(512) gemm_ws_split_kernel(GemmArgs a, long row
                 float4 b_, s_, h_;
                 if constexpr (EPI_REGS) { b_ = bs[s2]; s_ = sc[s2]; h_ = sh[s2]; }
                 else epi_load(o - 4 * fg, b_, s_, h_);
-                float4 v = make_float4(acc[s2][0] + b_.x, acc[s2][1] + b_.y, acc[s2][2] + b_.z, acc[s2][3] + b_.w);
+                float4 v;
+                if constexpr (F16) {
+                    // 2^-(kx + kw) of this row and these channels: exact
+                    v = make_float4(fmaf(acc[s2][0], rsv * wk4[s2].x, b_.x), fmaf(acc[s2][1], rsv * wk4[s2].y, b_.y), fmaf(acc[s2][2], rsv * wk4[s2].z, b_.z),
+                                    fmaf(acc[s2][3], rsv * wk4[s2].w, b_.w));
+                } else {
+                    v = make_float4(acc[s2][0] + b_.x, acc[s2][1] + b_.y, acc[s2][2] + b_.z, acc[s2][3] + b_.w);
+                }
                 if (a.scale) { v.x = v.x * s_.x + h_.x; v.y = v.y * s_.y + h_.y; v.z = v.z * s_.z + h_.z; v.w = v.w * s_.w + h_.w; }
                 float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (a.res_mode != 0) rs = *reinterpret_cast<const float4*>(a.res + r * a.ldr + o);
@@ -433,27 +500,31 @@ __global__ void __launch_bounds__(512) gemm_ws_split_kernel(GemmArgs a, long row
     };
     if (row_lo >= row_hi) return;
     fetch(row_lo);
-    stage(Xp);
+    stage(Xp, rsc);
     fetch(row_lo + FD_ROWS);
     __syncthreads();
+    if constexpr (F16) {
+#pragma unroll
+        for (int s2 = 0; s2 < SPW; ++s2) wk4[s2] = *reinterpret_cast<const float4*>(&wtab[(wave * SPW + s2) * 16 + 4 * fg]);
+    }
     int buf = 0;
     for (long r0 = row_lo; r0 < row_hi; r0 += FD_ROWS, buf ^= 1) {
-        const unsigned short* P = Xp + buf * 3 * PLANE;
-        row_tile(P, rp * RTW, r0);
-        stage(Xp + (buf ^ 1) * 3 * PLANE);       // the next tile (its buffer's last readers finished before the previous barrier)
+        const unsigned short* P = Xp + buf * NPL * PLANE;
+        row_tile(P, rp * RTW, r0, rsc + buf * FD_ROWS);
+        stage(Xp + (buf ^ 1) * NPL * PLANE, rsc + (buf ^ 1) * FD_ROWS);       // the next tile (its buffer's last readers finished before the previous barrier)
         if constexpr (EPI_REGS) fetch(r0 + 2 * FD_ROWS);
 #pragma unroll
-        for (int i = 1; i < RTW; ++i) row_tile(P, rp * RTW + i, r0);
+        for (int i = 1; i < RTW; ++i) row_tile(P, rp * RTW + i, r0, rsc + buf * FD_ROWS);
         if constexpr (!EPI_REGS) fetch(r0 + 2 * FD_ROWS);      // register-bound shape: the prefetch registers are not live across the row tiles
         __syncthreads();
     }
 }
 
-template <int K, int SPW, int RP>
+template <int K, int SPW, int RP, bool F16 = false>
 static int launch_ws_split(const GemmArgs& a, hipStream_t st) {
     constexpr int FD_ROWS = 64;
-    const size_t lds = (size_t)2 * 3 * FD_ROWS * (K + 8) * 2;
-    auto kern = gemm_ws_split_kernel<K, SPW, RP>;
+    const size_t lds = (size_t)2 * (F16 ? 2 : 3) * FD_ROWS * (K + 8) * 2 + (size_t)2 * FD_ROWS * sizeof(float) + (size_t)8 * SPW * 16 * sizeof(float);
+    auto kern = gemm_ws_split_kernel<K, SPW, RP, F16>;
     static int per_cu = 0;
     if (per_cu == 0) {
         if (lds > 64 * 1024) {
@@ -499,8 +570,12 @@ extern "C" int etch_linear(int R, int K, int O, const float* X, long ldx, const 
     // weight-stationary split kernel: chosen by the layer's shape only (never by R: a scan's result may not depend on its batch neighbours)
     static const bool no_split = getenv("ETCH_LINEAR_SPLIT") != nullptr && !strcmp(getenv("ETCH_LINEAR_SPLIT"), "0");
     const bool al = vx && vw && !row_idx && !(ldy & 3) && !((uintptr_t)Y & 15) && (!res || (!(ldr & 3) && !((uintptr_t)res & 15)));
+    // ETCH_LINEAR_SPLIT=f16: the two-plane fp16 form (built and parity-tested in round 5; serially 5 % faster over the step's ~40 launches, but these layers
+    // run on the side streams NEXT TO the VALU-bound kernels of the main stream, whose matrix pipe is two thirds idle: trading MFMAs for VALU work is the
+    // wrong direction there -- the bench did not gain, the three-plane form stays the default)
+    static const bool split_f16 = getenv("ETCH_LINEAR_SPLIT") != nullptr && !strcmp(getenv("ETCH_LINEAR_SPLIT"), "f16");
     if (!no_split && al) {
-#define WS_CASE(KK, OO, SPW, RP) if (K == KK && O == OO) return launch_ws_split<KK, SPW, RP>(a, st);
+#define WS_CASE(KK, OO, SPW, RP) if (K == KK && O == OO) return split_f16 ? launch_ws_split<KK, SPW, RP, true>(a, st) : launch_ws_split<KK, SPW, RP, false>(a, st);
         WS_CASE(32, 32, 1, 4) WS_CASE(32, 64, 1, 2) WS_CASE(32, 128, 1, 1)
         WS_CASE(64, 64, 1, 2) WS_CASE(64, 128, 1, 1) WS_CASE(64, 192, 3, 2) WS_CASE(64, 256, 2, 1)
         WS_CASE(128, 128, 1, 1) WS_CASE(128, 256, 2, 1) WS_CASE(128, 384, 3, 1)

@@ -144,3 +144,10 @@ __device__ __forceinline__ float etch_group_max(float v) {
     }
     return v;
 }
+// maximum of a non-negative value over the whole wave
+__device__ __forceinline__ float etch_wave_max(float v) {
+    v = etch_group_max<32>(v);
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    const u32x2_ r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}

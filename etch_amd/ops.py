@@ -819,19 +819,20 @@ def lrd_weight_split(w, J=128):
 
 
 def lrd_weight_split_f16(w, J=128):
-    """[G*J, K] -> float16 [G][K/32][J/16 strips][plane h / l][lane = 16 * (k / 8) + column][8]: two fp16 planes of 2^wexp W (wexp: the power of two that
-    puts max |W| into [8, 16); exact, the kernel's epilogue takes it out again) in v_mfma_f32_16x16x32_f16 fragment order; the exponent rides on the
-    tensor as `.wexp` (etch_linear_relu_dot_f16)."""
+    """[G*J, K] -> float16 [G][K/32][J/16 strips][plane h / l][lane = 16 * (k / 8) + column][8]: two fp16 planes of W with every ROW (hidden unit) times
+    the power of two that puts its maximum into [8, 16) (exact; the kernel's epilogue takes it out again), in v_mfma_f32_16x16x32_f16 fragment order; the
+    rows' inverse powers ride on the tensor as `.wsc` (float32 [G*J], etch_linear_relu_dot_f16)."""
     GJ, K = w.shape
     assert GJ % J == 0 and J % 16 == 0 and K % 32 == 0
-    m = float(w.detach().abs().max())
-    wexp = 0 if m == 0.0 or not math.isfinite(m) else 3 - math.frexp(m)[1] + 1          # frexp: m = f 2^e, f in [0.5, 1)  ->  m 2^(4 - e) in [8, 16)
-    ws = w.detach() * (2.0 ** wexp)
+    wd = w.detach()
+    m = wd.abs().amax(1)
+    e = torch.where((m > 0) & torch.isfinite(m), 4 - torch.frexp(m.clamp_min(1e-38))[1], torch.zeros_like(m, dtype=torch.int32)).to(torch.float32)
+    ws = wd * torch.exp2(e)[:, None]                                          # frexp: m = f 2^x, f in [0.5, 1)  ->  m 2^(4 - x) in [8, 16)
     hi = ws.to(torch.float16)
     planes = torch.stack([hi, (ws - hi.float()).to(torch.float16)])          # [2][GJ][K]
     q = planes.reshape(2, GJ // J, J // 16, 16, K // 32, 4, 8)               # [pl][g][strip][col][t][kg][e]
     out = q.permute(1, 4, 2, 0, 5, 3, 6).contiguous().reshape(-1)            # [g][t][strip][pl][kg][col][e]
-    out.wexp = int(wexp)
+    out.wsc = torch.exp2(-e).contiguous()
     return out
 
 
@@ -858,7 +859,7 @@ def linear_relu_dot(x, w, b1, w2, b2, G, wp=None, out=None):
     if out is None:
         out = torch.empty((R, G), dtype=torch.float32, device=x.device)
     if wp is not None and wp.dtype == torch.float16 and (b1.data_ptr() | w2.data_ptr()) % 16 == 0:
-        _lib.check(_lib.lib().etch_linear_relu_dot_f16(_c_long(R), int(K), int(G), int(J), _ptr(x), _c_long(x.stride(0) if R > 1 else K), _ptr(wp), int(wp.wexp),
+        _lib.check(_lib.lib().etch_linear_relu_dot_f16(_c_long(R), int(K), int(G), int(J), _ptr(x), _c_long(x.stride(0) if R > 1 else K), _ptr(wp), _ptr(wp.wsc),
                                                        _ptr(b1), _ptr(w2), _ptr(b2), _ptr(out), _c_long(out.stride(0) if R > 1 else G), _stream()),
                    "etch_linear_relu_dot_f16")
         return out

@@ -403,10 +403,11 @@ int etch_linear_relu_dot_split(long R, int K, int G, int J, const float* X, long
                                const float* b2, float* out, long ldo, void* stream);
 
 /* Round 5: the weight-stationary form of the same chain on v_mfma_f32_16x16x32_f16 with TWO fp16 planes per operand (three cross terms; half the matrix
- * instructions).  X carries no known scale, so each row is staged times the power of two that puts its maximum into [8, 16) and the power leaves in
- * the epilogue's fmaf with the bias (exact); Wqh = etch_amd/ops.py lrd_weight_split_f16: the planes of 2^wexp W.  K in {32, 64, 128}, G = 1 or
- * G >= 8, b1 / w2 16-byte aligned; other shapes: ETCH_EUNSUPPORTED (the caller keeps etch_linear_relu_dot_split / etch_linear_relu_dot). */
-int etch_linear_relu_dot_f16(long R, int K, int G, int J, const float* X, long ldx, const void* Wqh, int wexp, const float* b1, const float* w2,
+ * instructions).  Neither operand carries a known scale: each row of X is staged times the power of two that puts its maximum into [8, 16), each row of
+ * W (hidden unit) likewise on the host; both powers leave in the epilogue's fmaf with the bias (exact).  Wqh = etch_amd/ops.py lrd_weight_split_f16;
+ * wsc (G * J floats) = the weight rows' inverse powers.  K in {32, 64, 128}, G = 1 or G >= 8, b1 / w2 / wsc 16-byte aligned; other shapes:
+ * ETCH_EUNSUPPORTED (the caller keeps etch_linear_relu_dot_split / etch_linear_relu_dot). */
+int etch_linear_relu_dot_f16(long R, int K, int G, int J, const float* X, long ldx, const void* Wqh, const float* wsc, const float* b1, const float* w2,
                              const float* b2, float* out, long ldo, void* stream);
 
 /* confidence = sum_g softmax(logits)_g * v_g (pointtransformer_seg.py:183-189): (R,G),(R,G) -> (R). */

@@ -266,12 +266,12 @@ def test_linear_relu_dot_f16_rows_of_any_scale(R, K, G):
     b1, b2 = torch.zeros(G * 128), torch.zeros(G)
     w2 = torch.randn(G, 128, generator=g) / 128 ** 0.5
     for wscale in (1.0, 2.0 ** -9, 2.0 ** 11):
-        w = torch.randn(G * 128, K, generator=g) / K ** 0.5 * wscale
+        w = torch.randn(G * 128, K, generator=g) / K ** 0.5 * wscale * 10.0 ** (torch.rand(G * 128, 1, generator=g) * 4 - 2)      # hidden units spanning four decades
         hid = torch.relu(x.double() @ w.double().T).view(R, G, 128) * w2.double()
         ref = hid.sum(-1)
         xc, wc, b1c, w2c, b2c = (t.cuda() for t in (x, w, b1, w2, b2))
         wp = ops.permute_weight_frag_grouped(wc)
-        assert wp.dtype == torch.float16 and 8.0 <= float(wc.abs().max()) * 2.0 ** wp.wexp < 16.0
+        assert wp.dtype == torch.float16 and bool(((wc.abs().amax(1) / wp.wsc >= 8.0) & (wc.abs().amax(1) / wp.wsc < 16.0)).all())
         out = ops.linear_relu_dot(xc, wc, b1c, w2c.view(-1), b2c, G, wp=wp).double().cpu()
         f32 = ops.linear_relu_dot(xc, wc, b1c, w2c.view(-1), b2c, G).double().cpu()
         assert torch.equal(out, ops.linear_relu_dot(xc, wc, b1c, w2c.view(-1), b2c, G, wp=wp).double().cpu())
@@ -340,3 +340,34 @@ def test_fp16_attention_intra_and_confidence_kernels_soak_under_contention(tmp_p
             bad[k] += int(not torch.equal(f(), first[k]))
     torch.cuda.synchronize()
     assert not any(bad.values()), bad
+
+
+@pytest.mark.parametrize("R,K,O", [(5000, 128, 128), (4100, 64, 192), (777, 32, 64), (9000, 128, 384)])
+def test_linear_ws_split_f16_form_rows_and_weights_of_any_scale(R, K, O):
+    """The opt-in two-plane fp16 form of the weight-stationary Linear kernel (ETCH_LINEAR_SPLIT=f16; csrc/gemm.hip): rows spanning nine decades, weight
+    strips spanning four, bias + folded BatchNorm + ReLU epilogue -- every row as close to fp64 as the default three-plane bf16 form's (entitled error
+    per row).  Runs in a child process (the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    code = f'''
+import torch
+from etch_amd import ops
+g = torch.Generator().manual_seed({R + K + O})
+x = torch.randn({R}, {K}, generator=g) * 10.0 ** (torch.rand({R}, 1, generator=g) * 9 - 5)
+w = torch.randn({O}, {K}, generator=g) / {K} ** 0.5 * 10.0 ** (torch.rand({O}, 1, generator=g) * 4 - 2)
+b = torch.zeros({O}); s = torch.rand({O}, generator=g) + 0.5; t = torch.zeros({O})
+terms = x.double().abs() @ w.double().abs().T
+ref = (x.double() @ w.double().T) * s.double()
+y = ops.linear(x.cuda(), w.cuda(), bias=b.cuda(), scale=s.cuda(), shift=t.cuda()).double().cpu()
+print("ERR", float(((y - ref).abs() / (terms * s.double()).clamp_min(1e-300)).max()))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    errs = {}
+    for mode in ("f16", "bf16"):
+        env = dict(os.environ, ETCH_LINEAR_SPLIT=mode, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        errs[mode] = float([l for l in r.stdout.splitlines() if l.startswith("ERR")][0].split()[1])
+    # error relative to the sum of the terms' magnitudes of each output (the natural scale of a dot product's rounding error)
+    assert errs["bf16"] < 5e-7 and errs["f16"] < 5e-7 and errs["f16"] <= 2.0 * errs["bf16"] + 2e-8, errs
