@@ -371,3 +371,30 @@ print("ERR", float(((y - ref).abs() / (terms * s.double()).clamp_min(1e-300)).ma
         errs[mode] = float([l for l in r.stdout.splitlines() if l.startswith("ERR")][0].split()[1])
     # error relative to the sum of the terms' magnitudes of each output (the natural scale of a dot product's rounding error)
     assert errs["bf16"] < 5e-7 and errs["f16"] < 5e-7 and errs["f16"] <= 2.0 * errs["bf16"] + 2e-8, errs
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_fp16_attention_layer_with_weight_rows_and_tokens_of_mixed_scale(mode):
+    """The attention layer's weights are range-scaled per MATRIX and its tokens per point tile.  Weight rows spanning two decades and point
+    tiles spanning four: every point's output as close to the fp64 formula (direction_backbones.py:160-194) as the un-fused fp32 chain's, measured per
+    point relative to that point's largest output (entitled error, x 2, plus the bound of the per-matrix scaling: 2^(s - 29) for a row 2^-s below the
+    matrix maximum, s <= 7 here)."""
+    from etch_amd import ops
+    from tests.test_gpu_heads import _mhsa_reference
+    g = torch.Generator().manual_seed(5 + mode)
+    T = 300
+    x = torch.randn(T, 60, 64, generator=g) * 10.0 ** (torch.rand(T, 1, 1, generator=g) * 4 - 4)      # (larger tokens saturate the softmax: a conditioning matter, tests/test_gpu_heads.py)
+    ws = [torch.randn(64, 64, generator=g) * 0.2 * 10.0 ** (torch.rand(64, 1, generator=g) * 2 - 1) for _ in range(4)]
+    bc = torch.randn(64, generator=g) * 0.1
+    # small token tiles would drown in the bias: compare without it
+    ref = _mhsa_reference(x, ws[0], ws[1], ws[2], ws[3], bc * 0, mode).reshape(T, 60 * 64)
+    xc = x.cuda().contiguous()
+    wc = [w.cuda().contiguous() for w in ws]
+    out = ops.mhsa_layer(xc.view(T * 60, 64), wc[0], wc[1], wc[2], wc[3], (bc * 0).cuda(), mode=mode).double().cpu().reshape(T, 60 * 64)
+    qkv = ops.linear(xc.view(T * 60, 64), torch.cat(wc[:3], 0).contiguous())
+    att = ops.mhsa_attention(qkv, T, 0, 64, 128)
+    chain = (att if mode == 2 else ops.linear(att, wc[3], res=xc.view(T * 60, 64), res_mode=2)).double().cpu().reshape(T, 60 * 64)
+    scale = ref.abs().amax(1).clamp_min(1e-300)
+    e_new, e_chain = (out - ref).abs().amax(1) / scale, (chain - ref).abs().amax(1) / scale
+    assert float(e_chain.max()) < 1e-5 and float(e_new.max()) < 1e-5, (float(e_new.max()), float(e_chain.max()))
+    assert float(e_new.mean()) <= 2.0 * float(e_chain.mean()) + 2.5e-7, (float(e_new.mean()), float(e_chain.mean()))
