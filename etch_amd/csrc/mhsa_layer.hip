@@ -282,7 +282,7 @@ __device__ __forceinline__ void ml_combine(const unsigned short* Ap, WC wc, f32x
 // MODE 3 (round 5): the direction tail folded in -- out[token] = v . relu(Wf att[token] + bf) + c (models_pointcloud.py:115-117 with the linear
 //   chains folded on the host: Wf = net[0] o head_combine, v = so3_reg o net[2]): the 60 x 64 attention tile is in LDS when the layer ends, the
 //   hidden layer (64 -> 128 -> 1, 1 MFLOP per point) runs on v_mfma_f32_32x32x16_f16 from two fp16 planes per operand (split_bf16.h; Wf arrives as
-//   the planes of 2^6 Wf in fragment order, `Wc`; `bc` = [bf (128) | v (128) | c]); 240 bytes per point leave the kernel instead of 15 KB, and
+//   the planes of Wf (rows times their own powers of two, folded into bf / v on the host) in fragment order, `Wc`; `bc` = [bf (128) | v (128) | c]); 240 bytes per point leave the kernel instead of 15 KB, and
 //   linear_relu_dot_ws_kernel<64, 1> (1.74 ms, 2.46 GB read) leaves the path.
 // waves per SIMD the layer is compiled for: two (the weight fragments, the score operands of all four token tiles and the V planes are resident)
 #ifndef ML_LAYER_WPE
@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(256, ML_LAYER_WPE) mhsa_layer_kernel(long T, c
                     d[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wt[ks][0], bl, d[tt], 0, 0, 0);
                     d[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wt[ks][0], bh, d[tt], 0, 0, 0);
                 }
-            const float tf = ldexpf(0.015625f, -(kx + W.kv));
+            const float tf = ldexpf(1.0f, -(kx + W.kv));        // (the hidden units' own powers of two are folded into bf and v on the host: dirtail_weight_split)
             // d[tt][v] = 2^(6 + kx + kv) hidden[32 w + 8 (v / 4) + 4 kg + v % 4][token 32 tt + tl]: bias, ReLU, . v, summed over this lane's 16 hidden units,
             // then over the two lane halves and (through LDS, fixed order) over the four waves
 #pragma unroll
@@ -648,7 +648,7 @@ static int launch_layer(long T, const float* X, const float* Wq, const float* Wk
 }
 
 // MODE 3: attention heads of the last layer + the folded direction tail.  Wfq = ops.dirtail_weight_split(Wf): [4 waves][4 K steps][2 planes][64 lanes][8] fp16 of
-// 2^6 Wf (Wf 128 x 64 = direction_predictor.net[0] o head_combine); tab = [bf (128) | v (128) | c] fp32; out (T, 60) = the anchor weights of so3_mean
+// row-scaled Wf (Wf 128 x 64 = direction_predictor.net[0] o head_combine); tab = [bf (128) | v (128) | c] fp32; out (T, 60) = the anchor weights of so3_mean
 extern "C" int etch_mhsa_layer_dirtail(long T, const float* X, const float* Wq, const float* Wk, const float* Wv, const void* Wfq, const float* tab,
                                        float* out, void* stream) {
     if (T <= 0) return ETCH_OK;

@@ -14,7 +14,7 @@
 // in LDS (double-buffered: one barrier per phase), bias, output, fp64 InstanceNorm partial sums per pair as etch_intra_so3conv32.
 // Round 5, template flag F16 (C ABI etch_intra_so3conv_f16): the same kernel on v_mfma_f32_32x32x16_f16 with TWO fp16 planes per operand (split_bf16.h:
 // h = fp16(x), l = fp16(x - h), both to nearest; three cross terms) -- the operands here are at unit scale (InstanceNorm + LeakyReLU outputs; W arrives
-// as the planes of 2^6 W, the epilogue multiplies by 2^-6), where that split carries the fp32 MFMA's error (profiles/r05_f16_two_plane_split.txt):
+// as planes of its rows times their own powers of two, the epilogue multiplies by the inverse power), where that split carries the fp32 MFMA's error (profiles/r05_f16_two_plane_split.txt):
 // half the matrix instructions, two thirds of the LDS plane traffic, 48 / 96 instead of 72 / 144 registers of weight fragments.
 #include "common.h"
 #include "split_bf16.h"
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const int* __restrict__ intra_idx, const bf16x8* __restrict__ Wq,
                                                                  const float* __restrict__ bias, float* __restrict__ Y,
-                                                                 double* __restrict__ stat_part, unsigned* __restrict__ ctr) {
+                                                                 double* __restrict__ stat_part, unsigned* __restrict__ ctr, const float* __restrict__ wsc) {
     __shared__ unsigned s_grab;
     using S = WsShape<C, F16>;
     constexpr int NT = S::NT, MT = S::MT, KQ = S::KQ, NKS = S::NKS, LDB = S::LDB, PS = S::PS, PLANE = S::PLANE, NPRE = S::NPRE, NPL = S::NPL;
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total,
     for (int e = tid; e < NA * 12; e += NT) iidx[e] = intra_idx[e];
     int o_out = tid % C;                          // the output channel this thread writes in every phase (NT % C == 0)
     const float bo = bias[o_out];
-    constexpr float oscale = F16 ? 0.015625f : 1.0f;      // F16: the weight planes carry 2^6 W (exact)
+    const float oscale = F16 ? wsc[o_out] : 1.0f;         // F16: the weight planes carry this output channel's row times its own power of two (exact)
     __syncthreads();
     // source rows of this lane's anchors (both halves) for the wave's three taps
     // (C = 64: 144 registers of weight fragments leave no room for the six offsets -- 8 spilled registers -- so they are re-read from the LDS
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(C * 8) intra_so3conv_ws_kernel(int npts_total,
 
 template <int C, bool NORM, bool STATS, bool F16>
 static int launch_intra_ws_t(int npts, int ppb, const float* X, const float* mean, const float* rstd, const int* intra_idx, const void* Wq,
-                             const float* bias, float* Y, double* stat_part, hipStream_t st) {
+                             const float* bias, float* Y, double* stat_part, hipStream_t st, const float* wsc) {
     using S = WsShape<C, F16>;
     auto kern = intra_so3conv_ws_kernel<C, NORM, STATS, F16>;
     static bool ready = false;
@@ -301,16 +301,16 @@ static int launch_intra_ws_t(int npts, int ppb, const float* X, const float* mea
     int grid = etch_cu_count() * wgs_per_cu;
     if (grid > npairs) grid = npairs;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(S::NT), S::lds_bytes, st, npts, ppb, X, mean, rstd, intra_idx, reinterpret_cast<const bf16x8*>(Wq), bias, Y,
-                       stat_part, etch_work_counter_slot(st));
+                       stat_part, etch_work_counter_slot(st), wsc);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }
 template <int C, bool F16>
 static int launch_intra_ws(int npts, int ppb, const float* X, const float* mean, const float* rstd, const int* intra_idx, const void* Wq,
-                           const float* bias, float* Y, double* stat_part, hipStream_t st) {
+                           const float* bias, float* Y, double* stat_part, hipStream_t st, const float* wsc = nullptr) {
     if (stat_part && (ppb % 2) != 0) return ETCH_EUNSUPPORTED;          // a pair's points must belong to one sample
     if ((mean == nullptr) != (rstd == nullptr)) return ETCH_EINVAL;
-#define WS_GO(N, S_) return launch_intra_ws_t<C, N, S_, F16>(npts, ppb, X, mean, rstd, intra_idx, Wq, bias, Y, stat_part, st)
+#define WS_GO(N, S_) return launch_intra_ws_t<C, N, S_, F16>(npts, ppb, X, mean, rstd, intra_idx, Wq, bias, Y, stat_part, st, wsc)
     if (mean) { if (stat_part) WS_GO(true, true); WS_GO(true, false); }
     if (stat_part) WS_GO(false, true);
     WS_GO(false, false);
@@ -330,13 +330,14 @@ extern "C" int etch_intra_so3conv_split(int b, int c, int cout, int p, const flo
     return ETCH_EUNSUPPORTED;
 }
 
-// The same on the fp16 matrix cores with two planes per operand.  Wqh = ops.intra_weight_split_f16: the layout above with two fp16 planes of 2^6 W2.
+// The same on the fp16 matrix cores with two planes per operand.  Wqh = ops.intra_weight_split_f16: the layout above with two fp16 planes of W2, every
+// row (output channel) times its own power of two; wsc (cout floats) = the inverse powers.
 extern "C" int etch_intra_so3conv_f16(int b, int c, int cout, int p, const float* X, const float* mean, const float* rstd, const int* intra_idx,
-                                      const void* Wqh, const float* bias, float* Y, double* stat_part, void* stream) {
+                                      const void* Wqh, const float* wsc, const float* bias, float* Y, double* stat_part, void* stream) {
     if (b <= 0 || p <= 0) return ETCH_OK;
-    if (c != cout || !Wqh) return ETCH_EUNSUPPORTED;
+    if (c != cout || !Wqh || !wsc) return ETCH_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if (c == 32) return launch_intra_ws<32, true>(b * p, p, X, mean, rstd, intra_idx, Wqh, bias, Y, stat_part, st);
-    if (c == 64) return launch_intra_ws<64, true>(b * p, p, X, mean, rstd, intra_idx, Wqh, bias, Y, stat_part, st);
+    if (c == 32) return launch_intra_ws<32, true>(b * p, p, X, mean, rstd, intra_idx, Wqh, bias, Y, stat_part, st, wsc);
+    if (c == 64) return launch_intra_ws<64, true>(b * p, p, X, mean, rstd, intra_idx, Wqh, bias, Y, stat_part, st, wsc);
     return ETCH_EUNSUPPORTED;
 }

@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(128) inter_kpoint_operand_kernel(float inv_sig
 }
 
 // step 2 of the 32x32x16 kernels on the fp16 matrix cores: Y[o][a] += sum_kappa W[o][kappa] X1[a][kappa] with both operands as two fp16 planes (W pre-split
-// and scaled by 2^6 on the host, ops.inter_weight_split32_f16; the X1 row split by the wave that reads it) and the three largest cross products.
+// with every output channel's row times its own power of two, ops.inter_weight_split32_f16 -- undone per channel in the epilogue; the X1 row split by the wave that reads it) and the three largest cross products.
 // W fragments: [K step of 16][o tile of 32][plane][lane][8], streamed from L2 one batch ahead (inline-asm loads + counted waits, see X32Step2).
 template <int CIN, int COUT, int PAD>
 struct H32Step2 {
@@ -108,8 +108,8 @@ struct H32Step2 {
 template <int CIN, int COUT, int NCH, int D>
 __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
     int p1, int p2, float inv_sigma, const float* __restrict__ xyz, const float* __restrict__ new_xyz, const int* __restrict__ ball_idx,
-    const unsigned short* __restrict__ Fq, const bf16x8* __restrict__ kq, const bf16x8* __restrict__ Wq, const float* __restrict__ bias,
-    float* __restrict__ out, const int* __restrict__ order, double* __restrict__ stat_part) {
+    const unsigned short* __restrict__ Fq, const bf16x8* __restrict__ kq, const bf16x8* __restrict__ Wq, const float* __restrict__ wsc,
+    const float* __restrict__ bias, float* __restrict__ out, const int* __restrict__ order, double* __restrict__ stat_part) {
     constexpr int NN = 32 * NCH;
     constexpr int AG = 32, NJ = 8, NG = 2;         // anchors per pass, per wave and pass; passes per point
     constexpr int NT32 = CIN / 32;                 // 32-channel tiles of step 1
@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
         s2.template half<1>(y, X1s, Wq_g, wave, lane);
 #endif
         __syncthreads();                                // every wave finished reading X1s: the partial table may overwrite it
-        // y[mt][v] = 2^6 Y[o = 32 mt + 8 (v / 4) + 4 kg + v % 4][anchor column = lane % 32]
+        // y[mt][v] = 2^kw(o) Y[o = 32 mt + 8 (v / 4) + 4 kg + v % 4][anchor column = lane % 32]
 #pragma unroll
         for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
             if (a < NA) {
                 float v = part[(0 * AG + col) * PS + o] + part[(1 * AG + col) * PS + o];
                 v += part[(2 * AG + col) * PS + o] + part[(3 * AG + col) * PS + o];
-                v = v * 0.015625f + bias[o];            // the weight planes carry W * 2^6 (exact)
+                v = v * wsc[o] + bias[o];               // the weight planes carry every output channel's row times its own power of two (exact)
                 outp[(size_t)a * COUT + o] = v;
                 st_s += (double)v; st_q += (double)v * (double)v;
             }
@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
 
 template <int CIN, int COUT, int NCH>
 static int launch_y(int b, int p1, int p2, float sigma, const float* xyz, const float* new_xyz, const int* idx, const void* Fq, const void* kq,
-                    const void* Wq, const float* bias, float* out, const int* order, double* stat_part, hipStream_t st) {
+                    const void* Wq, const float* wsc, const float* bias, float* out, const int* order, double* stat_part, hipStream_t st) {
     constexpr int NN = 32 * NCH;
     const size_t lds = (size_t)(32 * ((CIN / 2) * KS + Y_PAD(CIN)) + 17 * NN + 256) * sizeof(float);
     auto kern = inter_so3conv_y_kernel<CIN, COUT, NCH, INTER_Y_DEPTH(CIN)>;
@@ -469,7 +469,7 @@ static int launch_y(int b, int p1, int p2, float sigma, const float* xyz, const 
     }
     const unsigned gx = order ? 8u * (unsigned)((p2 + 7) / 8) : (unsigned)p2;
     hipLaunchKernelGGL(kern, dim3(gx, b), dim3(256), lds, st, p1, p2, 1.0f / sigma, xyz, new_xyz, idx, reinterpret_cast<const unsigned short*>(Fq),
-                       reinterpret_cast<const bf16x8*>(kq), reinterpret_cast<const bf16x8*>(Wq), bias, out, order, stat_part);
+                       reinterpret_cast<const bf16x8*>(kq), reinterpret_cast<const bf16x8*>(Wq), wsc, bias, out, order, stat_part);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }
@@ -510,15 +510,15 @@ int etch_inter_kpoint_operand(float sigma, const float* rk, void* kq, void* stre
 
 // etch_inter_so3conv_planes32 with the kernel weights formed on the matrix cores.  kq = etch_inter_kpoint_operand(sigma, rk); Wq32 and feats_planes as there.
 int etch_inter_so3conv_planes_kq(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
-                                 const int* ball_idx, const void* feats_planes, const void* kq, const void* Wq32, const float* bias, float* out,
-                                 const int* order, double* stat_part, void* stream) {
+                                 const int* ball_idx, const void* feats_planes, const void* kq, const void* Wq32, const float* wsc, const float* bias,
+                                 float* out, const int* order, double* stat_part, void* stream) {
     if (b <= 0 || p2 <= 0) return ETCH_OK;
-    if (sigma <= 0.f || !Wq32 || !feats_planes || !kq) return ETCH_EINVAL;
+    if (sigma <= 0.f || !Wq32 || !wsc || !feats_planes || !kq) return ETCH_EINVAL;
     if (((uintptr_t)feats_planes & 15) || ((uintptr_t)Wq32 & 15) || ((uintptr_t)kq & 15)) return ETCH_EINVAL;
     if ((size_t)p1 * NA * 2 * cin * 2 >= ((size_t)1 << 32)) return ETCH_EUNSUPPORTED;      // 32-bit byte offsets inside a scan
     hipStream_t st = (hipStream_t)stream;
 #define Y_CASE(CI, CO, NC) \
-    if (cin == CI && cout == CO && nn == 32 * NC) return launch_y<CI, CO, NC>(b, p1, p2, sigma, xyz, new_xyz, ball_idx, feats_planes, kq, Wq32, bias, out, order, stat_part, st);
+    if (cin == CI && cout == CO && nn == 32 * NC) return launch_y<CI, CO, NC>(b, p1, p2, sigma, xyz, new_xyz, ball_idx, feats_planes, kq, Wq32, wsc, bias, out, order, stat_part, st);
     Y_CASE(32, 32, 1) Y_CASE(32, 32, 2) Y_CASE(32, 64, 1) Y_CASE(32, 64, 2) Y_CASE(64, 64, 1) Y_CASE(64, 64, 2)
 #undef Y_CASE
     return ETCH_EUNSUPPORTED;

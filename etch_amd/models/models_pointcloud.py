@@ -89,8 +89,10 @@ class GT_network_equiv(nn.Module):
             bf = (W1 @ bc + b1).float().contiguous().to(dev)
             v = (W2.t() @ wr).float().contiguous().to(dev)
             c = (b2 @ wr + br[0]).float().view(1).to(dev)
-            tab = torch.cat([bf, v, c]).contiguous()                      # [bf | v | c]: the fused tail's constants (etch_mhsa_layer_dirtail)
-            return Wf, bf, v, c, ops.permute_weight_frag_grouped(Wf), (ops.dirtail_weight_split(Wf) if tuple(Wf.shape) == (128, 64) else None), tab      # the fused tail: 64-wide tokens
+            Wfq = ops.dirtail_weight_split(Wf) if tuple(Wf.shape) == (128, 64) else None      # the fused tail: 64-wide tokens
+            # [bf | v | c]: the fused tail's constants (etch_mhsa_layer_dirtail), with the hidden units' powers of two folded in
+            tab = ops.dirtail_constants(bf, v, c, Wfq.wsc) if Wfq is not None else torch.cat([bf, v, c]).contiguous()
+            return Wf, bf, v, c, ops.permute_weight_frag_grouped(Wf), Wfq, tab
 
         if not hasattr(self, "_fold_cache"):
             from ..vgtk_so3conv import _Derived

@@ -298,17 +298,29 @@ def intra_weight_split(w2):
     return q.permute(1, 3, 4, 0, 5, 2, 6).contiguous().reshape(-1)       # [mt][kq][ks][pl][kg][i][e]
 
 
+def _row_pow2(w):
+    """w [rows, K] -> (w with every row times the power of two that puts its maximum into [8, 16), the inverse powers float32 [rows]); exact.  The fp16
+    planes of an operand carry 23 bits only near that range: scaling per ROW keeps rows far below the matrix maximum at full precision (a trained
+    weight matrix's rows may differ by orders of magnitude)."""
+    wd = w.detach()
+    m = wd.abs().amax(1)
+    e = torch.where((m > 0) & torch.isfinite(m), 4 - torch.frexp(m.clamp_min(1e-38))[1], torch.zeros_like(m, dtype=torch.int32)).to(torch.float32)
+    return wd * torch.exp2(e)[:, None], torch.exp2(-e).contiguous()        # frexp: m = f 2^x, f in [0.5, 1)  ->  m 2^(4 - x) in [8, 16)
+
+
 def intra_weight_split_f16(w2):
-    """W2 [C, 12 C] -> the fragments of etch_intra_so3conv_f16: intra_weight_split's order with TWO fp16 planes of 2^6 W2 (h = fp16(64 W), l = fp16(64 W - h);
-    the scale is exact and keeps the residual plane of Xavier-sized weights normal, the kernel's epilogue multiplies by 2^-6)."""
+    """W2 [C, 12 C] -> the fragments of etch_intra_so3conv_f16: intra_weight_split's order with TWO fp16 planes (h = fp16(w), l = fp16(w - h)) of W2 with every
+    row (output channel) times its own power of two (_row_pow2; exact); the inverse powers ride on the tensor as `.wsc` (the kernel's epilogue applies them)."""
     C, K = w2.shape
     assert K == 12 * C and C in (32, 64)
     nks = 3 * C // 16
-    w64 = w2 * 64.0
-    hi = w64.to(torch.float16)
-    planes = torch.stack([hi, (w64 - hi.float()).to(torch.float16)])    # [2][C][K]
+    ws, wsc = _row_pow2(w2)
+    hi = ws.to(torch.float16)
+    planes = torch.stack([hi, (ws - hi.float()).to(torch.float16)])      # [2][C][K]
     q = planes.reshape(2, C // 32, 32, 4, nks, 2, 8)                     # [pl][mt][i][kq][ks][kg][e]
-    return q.permute(1, 3, 4, 0, 5, 2, 6).contiguous().reshape(-1).view(torch.int16)       # [mt][kq][ks][pl][kg][i][e]
+    out = q.permute(1, 3, 4, 0, 5, 2, 6).contiguous().reshape(-1).view(torch.int16)       # [mt][kq][ks][pl][kg][i][e]
+    out.wsc = wsc
+    return out
 
 
 def inter_weight_frag32(W, cin, ks=24):
@@ -350,21 +362,23 @@ def split2_planes_f16(x_cl):
 
 
 def inter_weight_split32_f16(W, cin, ks=24):
-    """Weight of etch_inter_so3conv_planes_kq: the columns of W [cout, cin*24] in the physical contraction order of inter_weight_split32, scaled by
-    2^6 (exact; Xavier-sized weights then keep a normal fp16 residual plane, the kernel's epilogue multiplies by 2^-6), as two fp16 planes
-    h = fp16(64 W), l = fp16(64 W - h), in A-fragment order [K step of 16][o tile of 32][plane][lane = 32 * (kappa / 8 % 2) + o % 32][8]."""
+    """Weight of etch_inter_so3conv_planes_kq: the columns of W [cout, cin*24] in the physical contraction order of inter_weight_split32, every row (output
+    channel) times its own power of two (_row_pow2: exact; `.wsc` = the inverse powers, applied by the kernel's epilogue), as two fp16 planes
+    h = fp16(w), l = fp16(w - h), in A-fragment order [K step of 16][o tile of 32][plane][lane = 32 * (kappa / 8 % 2) + o % 32][8]."""
     cout = W.shape[0]
     assert ks == 24 and cin in (32, 64) and cout % 32 == 0 and W.shape[1] == cin * ks
     ch = cin // 2
     cols = [(h * ch + 4 * (pb ^ (((k >> 1) & 3) if ch == 16 else (k & 7))) + i) * ks + k
             for h in range(2) for k in range(ks) for pb in range(ch // 4) for i in range(4)]
     assert sorted(cols) == list(range(cin * ks))
-    w64 = W[:, torch.tensor(cols, dtype=torch.long, device=W.device)] * 64.0
-    hi = w64.to(torch.float16)
-    planes = torch.stack([hi, (w64 - hi.float()).to(torch.float16)])                      # [2][cout][K]
+    ws, wsc = _row_pow2(W[:, torch.tensor(cols, dtype=torch.long, device=W.device)])
+    hi = ws.to(torch.float16)
+    planes = torch.stack([hi, (ws - hi.float()).to(torch.float16)])                       # [2][cout][K]
     K = cin * ks
     q = planes.reshape(2, cout // 32, 32, K // 16, 2, 8)                 # [pl][mt][o][s][kg][e]
-    return q.permute(3, 1, 0, 4, 2, 5).contiguous().reshape(-1)          # [s][mt][pl][kg][o][e]
+    out = q.permute(3, 1, 0, 4, 2, 5).contiguous().reshape(-1)           # [s][mt][pl][kg][o][e]
+    out.wsc = wsc
+    return out
 
 
 def inter_kpoint_operand(rk, sigma):
@@ -430,7 +444,7 @@ def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, orde
         _need(feats_planes, torch.float16, "feats_planes")
         assert tuple(feats_planes.shape) == (b, p1, na, 2, cin) and kq.numel() == 60 * 2 * 64 * 8 and Wqh.numel() == 2 * cout * cin * 24
         _lib.check(_lib.lib().etch_inter_so3conv_planes_kq(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
-                                                          _ptr(feats_planes), _ptr(kq), _ptr(Wqh), _ptr(bias), _ptr(out), _optptr(order),
+                                                          _ptr(feats_planes), _ptr(kq), _ptr(Wqh), _ptr(Wqh.wsc), _ptr(bias), _ptr(out), _optptr(order),
                                                           _optptr(part), _stream()), "etch_inter_so3conv_planes_kq")
     elif Wq32 is not None and cin == 64 and inter_planes_form(cin) == 32 and inter_planes_supported(cin, cout, nn):
         _need(Wq32, torch.int16, "Wq32")
@@ -490,7 +504,7 @@ def intra_so3conv(x_cl, intra_idx32, Wp, bias, cout, mean=None, rstd=None, want_
     if Wqh is not None and INTRA_SPLIT and INTRA_F16 and c == cout and c in (32, 64) and (part is None or p % 2 == 0):
         _need(Wqh, torch.int16, "Wqh")
         _lib.check(_lib.lib().etch_intra_so3conv_f16(b, c, cout, p, _ptr(x_cl), _optptr(mean), _optptr(rstd), _ptr(intra_idx32), _ptr(Wqh),
-                                                    _ptr(bias), _ptr(out), _optptr(part), _stream()), "etch_intra_so3conv_f16")
+                                                    _ptr(Wqh.wsc), _ptr(bias), _ptr(out), _optptr(part), _stream()), "etch_intra_so3conv_f16")
     elif Wq is not None and INTRA_SPLIT and c == cout and c in (32, 64) and (part is None or p % 2 == 0):
         _need(Wq, torch.int16, "Wq")
         _lib.check(_lib.lib().etch_intra_so3conv_split(b, c, cout, p, _ptr(x_cl), _optptr(mean), _optptr(rstd), _ptr(intra_idx32), _ptr(Wq),
@@ -588,14 +602,23 @@ def mhsa_layer(x, wq, wk, wv, wc=None, bc=None, mode=0):
 
 
 def dirtail_weight_split(Wf):
-    """Wf (128, 64) fp32 (direction_predictor.net[0] o head_combine) -> the two fp16 planes of 2^6 Wf as A fragments of v_mfma_f32_32x32x16_f16:
-    [wave w = hidden tile of 32][K step ks][plane][lane = 32 * (k / 8 % 2) + h % 32][8] with k = 16 ks + 8 (lane / 32) + e (etch_mhsa_layer_dirtail)."""
+    """Wf (128, 64) fp32 (direction_predictor.net[0] o head_combine) -> the two fp16 planes of Wf, every row (hidden unit) times its own power of two 2^kw
+    (_row_pow2), as A fragments of v_mfma_f32_32x32x16_f16: [wave w = hidden tile of 32][K step ks][plane][lane = 32 * (k / 8 % 2) + h % 32][8] with
+    k = 16 ks + 8 (lane / 32) + e (etch_mhsa_layer_dirtail).  `.wsc` = 2^-kw: the caller folds it into the tail's constants -- relu(2^-kw a + b) v =
+    relu(a + 2^kw b) (2^-kw v) -- so the kernel needs no per-unit factor (dirtail_constants)."""
     assert tuple(Wf.shape) == (128, 64)
-    w64 = Wf.float() * 64.0
-    hi = w64.to(torch.float16)
-    planes = torch.stack([hi, (w64 - hi.float()).to(torch.float16)])       # [2][128][64]
+    ws, wsc = _row_pow2(Wf.float())
+    hi = ws.to(torch.float16)
+    planes = torch.stack([hi, (ws - hi.float()).to(torch.float16)])        # [2][128][64]
     q = planes.reshape(2, 4, 32, 4, 2, 8)                                  # [pl][w][h][ks][kg][e]
-    return q.permute(1, 3, 0, 4, 2, 5).contiguous().reshape(-1)            # [w][ks][pl][kg][h][e]
+    out = q.permute(1, 3, 0, 4, 2, 5).contiguous().reshape(-1)             # [w][ks][pl][kg][h][e]
+    out.wsc = wsc
+    return out
+
+
+def dirtail_constants(bf, v, c, wsc):
+    """[bf (128) | v (128) | c] of etch_mhsa_layer_dirtail with the hidden units' powers of two folded in (exact): bf / wsc, v * wsc."""
+    return torch.cat([bf / wsc, v * wsc, c.view(1)]).contiguous()
 
 
 def mhsa_layer_dirtail(x, wq, wk, wv, Wfq, tab):

@@ -184,14 +184,15 @@ int etch_inter_so3conv_planes32(int b, int cin, int cout, int p1, int p2, int nn
  *   (3) gathered rows through a register ring (plain loads, several chunks in flight per wave) instead of LDS-direct loads.
  * feats_planes (b, p1, 60, 2, cin) fp16 = etch_split2_planes_f16 / etch_instnorm_act_add_planes_f16 of the fp32 features; kq =
  * etch_inter_kpoint_operand(sigma, rk): [60 anchors][2 K steps][64 lanes][8] bf16 (122 880 bytes), the kernel-point factor in B-fragment order, built
- * once per layer from rk [60][24][3] = anchors @ kernel points (functional.py:296); Wq: 2 * cout * cin * 24 fp16 = the two planes of 2^6 W in the
- * physical contraction order of etch_inter_so3conv_planes32, [K step of 16][o tile of 32][plane][lane][8] (etch_amd/ops.py inter_weight_split32_f16).
+ * once per layer from rk [60][24][3] = anchors @ kernel points (functional.py:296); Wq: 2 * cout * cin * 24 fp16 = the two planes of W, every row (output
+ * channel) times the power of two that puts its maximum into [8, 16), in the physical contraction order of etch_inter_so3conv_planes32,
+ * [K step of 16][o tile of 32][plane][lane][8]; wsc (cout floats) = the rows' inverse powers (etch_amd/ops.py inter_weight_split32_f16 and its `.wsc`).
  * Covers every shape of etch_inter_so3conv_planes_supported; order / stat_part as for etch_inter_so3conv.  Same result as the fp32 kernels to
  * ~1e-6 of the output scale (tests/test_gpu_r05.py holds it to the fp32 kernel AND to fp64 under the entitled-error rule). */
 int etch_inter_kpoint_operand(float sigma, const float* rk, void* kq, void* stream);
 int etch_inter_so3conv_planes_kq(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
-                                 const int* ball_idx, const void* feats_planes, const void* kq, const void* Wq32, const float* bias, float* out,
-                                 const int* order, double* stat_part, void* stream);
+                                 const int* ball_idx, const void* feats_planes, const void* kq, const void* Wq32, const float* wsc, const float* bias,
+                                 float* out, const int* order, double* stat_part, void* stream);
 
 /* x (rows, C) fp32 -> planes (rows, 2, C) fp16: h = fp16(x), l = fp16(x - h), both to nearest (the gather format of etch_inter_so3conv_planes_kq). */
 int etch_split2_planes_f16(long rows, int C, const float* x, void* planes, void* stream);
@@ -232,9 +233,10 @@ int etch_intra_so3conv_split(int b, int c, int cout, int p, const float* X, cons
 
 /* Round 5: the same kernel on v_mfma_f32_32x32x16_f16 with TWO fp16 planes per operand (h = fp16(x), l = fp16(x - h), both to nearest; three cross
  * products; for this path's unit-scale operands the fp32 MFMA's error against fp64, profiles/r05_f16_two_plane_split.txt).  Wqh = etch_amd/ops.py
- * intra_weight_split_f16: [mt][kq][K step][plane h / l][lane][8 fp16] of 2^6 W2 (the kernel's epilogue multiplies by 2^-6: exact). */
+ * intra_weight_split_f16: [mt][kq][K step][plane h / l][lane][8 fp16] of W2 with every row (output channel) times its own power of two; wsc (cout
+ * floats) = the inverse powers, applied by the kernel's epilogue (exact). */
 int etch_intra_so3conv_f16(int b, int c, int cout, int p, const float* X, const float* mean, const float* rstd, const int* intra_idx,
-                           const void* Wqh, const float* bias, float* Y, double* stat_part, void* stream);
+                           const void* Wqh, const float* wsc, const float* bias, float* Y, double* stat_part, void* stream);
 
 /* InstanceNorm2d(affine=False, eps=1e-5) statistics over (p,a) per (b,c) (src/models/so3conv.py:24,85,168).
  * x (b,rows,C) -> mean (b,C), rstd (b,C).  workspace: etch_instnorm_stats_workspace_bytes(b, C) bytes. */
@@ -285,7 +287,8 @@ int etch_mhsa_layer(long T, const float* X, const float* Wq, const float* Wk, co
                     int mode, float* out, void* stream);
 /* Round 5: the LAST attention layer of the direction head with the folded tail inside (models_pointcloud.py:115-117): out (T, 60) =
  * v . relu(Wf att + bf) + c per token, the anchor weights that so3_mean consumes -- the (T*60, 64) attention output and the (T*60, 128) hidden layer
- * never reach HBM.  Wfq = the two fp16 planes of 2^6 Wf (Wf 128 x 64 = direction_predictor.net[0] o head_combine, folded on the host) as matrix-core A
+ * never reach HBM.  Wfq = the two fp16 planes of Wf with every hidden unit's row times its own power of two, the powers folded into tab (ops.dirtail_weight_split /
+ * dirtail_constants) (Wf 128 x 64 = direction_predictor.net[0] o head_combine, folded on the host) as matrix-core A
  * fragments [4 waves][4 K steps][2 planes][64 lanes][8] (etch_amd/ops.py dirtail_weight_split); tab = [bf (128) | v (128) | c] fp32 (257 floats). */
 int etch_mhsa_layer_dirtail(long T, const float* X, const float* Wq, const float* Wk, const float* Wv, const void* Wfq, const float* tab,
                             float* out, void* stream);

@@ -398,3 +398,46 @@ def test_fp16_attention_layer_with_weight_rows_and_tokens_of_mixed_scale(mode):
     e_new, e_chain = (out - ref).abs().amax(1) / scale, (chain - ref).abs().amax(1) / scale
     assert float(e_chain.max()) < 1e-5 and float(e_new.max()) < 1e-5, (float(e_new.max()), float(e_chain.max()))
     assert float(e_new.mean()) <= 2.0 * float(e_chain.mean()) + 2.5e-7, (float(e_new.mean()), float(e_chain.mean()))
+
+
+def test_conv_weights_with_rows_of_any_scale_keep_the_fp32_error():
+    """The fp16 planes of the conv weights are formed per ROW (output channel): `_row_pow2` puts every row's maximum into [8, 16) and the kernels' epilogues
+    apply the inverse power per channel.  Output channels spanning six decades (and a whole weight tensor at 2^-12) must come out as close to fp64 as
+    the fp32-MFMA kernels' -- per channel, relative to that channel's largest output (entitled error, x 2) -- for the intra conv and the inter conv."""
+    from etch_amd import ops
+    from etch_amd import vgtk_so3conv as V
+    g = torch.Generator().manual_seed(21)
+    rows = 10.0 ** (torch.rand(64, 1, generator=g) * 6 - 3)
+    # ---- intra conv, 64 channels
+    conv = load_seeded(V.IntraSO3Conv(64, 64), 5).cuda()
+    with torch.no_grad():
+        conv.basic_conv.W.mul_((rows * 2.0 ** -4).cuda())
+    Wp, bias, idx32, Wp32 = conv._derived()
+    bias = bias * 0
+    x = torch.randn(2, 300, 60, 64, generator=g).cuda()
+    mm, rr = ops.instnorm_stats(x)
+    new = ops.intra_so3conv(x, idx32, Wp, bias, 64, mm, rr, Wqh=conv._wqh).double()
+    f32 = ops.intra_so3conv(x, idx32, Wp, bias, 64, mm, rr).double()
+    xd = (x.double() - mm.double()[:, None, None]) * rr.double()[:, None, None]
+    xd = torch.where(xd > 0, xd, 0.01 * xd)
+    ref = torch.einsum("bpatc,oct->bpao", xd[:, :, conv.intra_idx.cuda()], conv.basic_conv.W.detach().double().view(64, 64, 12))
+    ch = ref.abs().amax((0, 1, 2)).clamp_min(1e-300)
+    e_new, e_f32 = (new - ref).abs().amax((0, 1, 2)) / ch, (f32 - ref).abs().amax((0, 1, 2)) / ch
+    assert float(e_f32.max()) < 3e-6 and float(e_new.max()) <= 2.0 * float(e_f32.max()) + 1e-7, (float(e_new.max()), float(e_f32.max()))
+    # ---- inter conv 32 -> 64, nn 64
+    b, p1, p2, nn = 2, 211, 101, 64
+    xyz = (torch.randn(b, 3, p1, generator=g) * 0.2).cuda()
+    new_xyz = xyz[:, :, :p2].contiguous()
+    ball = ops.ball_query(new_xyz, xyz, 0.25, nn)
+    ci = load_seeded(V.InterSO3Conv(32, 64, 1, 2, 0.25, 0.03, nn), 3).cuda()
+    with torch.no_grad():
+        ci.basic_conv.W.mul_((rows * 2.0 ** -12).cuda())
+    rk, W, Wpi, bi = ci._derived()
+    bi = bi * 0
+    feats = torch.randn(b, p1, 60, 32, generator=g).cuda()
+    new = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wpi, bi, ci.sigma, Wqh=ci._wqh(), kq=ci._kq(), feats_planes=ops.split2_planes_f16(feats)).double()
+    f32 = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wpi, bi, ci.sigma).double()
+    ref = _inter_conv_fp64(xyz, new_xyz, ball, feats, rk, W, bi, ci.sigma)
+    ch = ref.abs().amax((0, 1, 2)).clamp_min(1e-300)
+    e_new, e_f32 = (new - ref).abs().amax((0, 1, 2)) / ch, (f32 - ref).abs().amax((0, 1, 2)) / ch
+    assert float(e_f32.max()) < 3e-6 and float(e_new.max()) <= 2.0 * float(e_f32.max()) + 1e-7, (float(e_new.max()), float(e_f32.max()))
