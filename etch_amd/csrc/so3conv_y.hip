@@ -176,6 +176,8 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
             toff[ct] = (unsigned)(r0 * CIN * 2 + (NT32 == 1 ? 0 : 64 * ((ct + (r0 >> 1)) & 1)) + 32 * (g & 1) + 8 * (i & 3));
     }
     float* outp = out + ((size_t)b * p2 + p) * NA * COUT;
+    static_assert(256 % COUT == 0, "a thread's epilogue elements e = tid + 256 j all belong to output channel tid % COUT");
+    const float ws_t = wsc[tid % COUT], b_t = bias[tid % COUT];
 
     // ---- the software pipeline of one wave.  Global step G = 0 .. 2 NSTEP - 1 of a point: anchor sequence index G / NCH, chunk G % NCH.
     //   gathered rows   global -> registers (ring of D chunks, plain loads: in order, tracked by the compiler) -> staging tile (ds_write) -> fragments
@@ -431,7 +433,7 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
             if (a < NA) {
                 float v = part[(0 * AG + col) * PS + o] + part[(1 * AG + col) * PS + o];
                 v += part[(2 * AG + col) * PS + o] + part[(3 * AG + col) * PS + o];
-                v = v * wsc[o] + bias[o];               // the weight planes carry every output channel's row times its own power of two (exact)
+                v = v * ws_t + b_t;                     // the weight planes carry every output channel's row times its own power of two (exact); o == tid % COUT
                 outp[(size_t)a * COUT + o] = v;
                 st_s += (double)v; st_q += (double)v * (double)v;
             }
