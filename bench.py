@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_*_f32)
+F16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 / fp16 matrix peak (v_mfma_f32_32x32x16_{f16,bf16}); measured there 2495
 HBM_PEAK_GBS = 8000.0
 
 
@@ -56,7 +57,6 @@ def build(device, seed=1, body="smpl"):
 # ------------------------------------------------------------------------------------------------ roofline
 SOURCE_OF_KERNEL = {"inter_so3conv_y_kernel": "so3conv_y.hip", "inter_so3conv_x_kernel": "so3conv_x.hip", "inter_so3conv_kernel": "so3conv.hip", "gemm_nt_kernel": "gemm.hip",
                     "mhsa_layer_kernel": "mhsa_layer.hip", "mhsa_layer_kernel<3>": "mhsa_layer.hip", "mhsa_interp_layer_kernel": "mhsa_layer.hip", "linear_relu_dot_ws_kernel": "fused_dense.hip"}
-SPLIT_RATE_TFLOPS = 403.0     # fp32 products per second on the bf16 matrix cores as six-term splits: 2418 TFLOP/s measured for v_mfma_f32_32x32x16_bf16 / 6 (profiles/r04_mfma_bf16_issue_rates.txt)
 
 
 def algorithmic_flops(name, a):
@@ -713,7 +713,7 @@ def main():
     out = {"metric": metric,
            "value": round(value, 3), "unit": "scans/s", "n_gpus": world,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32 (matrix operands: 2 x fp16 planes per fp32 value, fp32 accumulate)", "data": "synthetic",
            "config": {"workload": cfg_name, "schedule": sched, "global_batch": B * world, "points": N, "parallelism": f"scan-sharded x{world}",
                       "distinct_batches": nbatch, "launcher": "torchrun/env" if "TORCHELASTIC_RUN_ID" in os.environ else ("self" if world > 1 else "single"),
                       "cpu_pinning": None if pinned is None else f"rank 0 on {len(pinned)} NUMA-local cores",
@@ -730,6 +730,7 @@ def main():
         print(json.dumps(out), flush=True)
         return
     out["peak_hbm_gib"] = round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2)
+    out["allocator_reserved_gib"] = round(getattr(pipe, "reserved_gib", 0.0), 2)       # free blocks handed to the streams' allocator pools up front (pipeline._reserve_allocator)
 
     # roofline of the dominant kernel: one instrumented pass of the same step (HIP events on the launch stream).
     # the instrumented pass runs the step on ONE stream (no heads / index ops on side streams): with kernels of several
@@ -809,28 +810,39 @@ def main():
             pipe_busy = {"source": os.path.basename(f_), "per_instantiation": got}
             counter_files["matrix_pipe_busy"] = stamp(f_)
             break
+    # the roofline is priced on the pipe the kernel RUNS on.  inter_so3conv_y_kernel forms every fp32-equivalent product as three
+    # fp16 x fp16 cross terms on v_mfma_f32_32x32x16_f16, so its ceiling in algorithmic (fp32-equivalent) FLOP/s is the guide's dense fp16 matrix
+    # peak / 3 = 833 TFLOP/s; the bf16 six-term kernels (rounds 3 - 4) have 2 500 / 6; an fp32-MFMA kernel has 157.3.  `frac` = achieved / that peak,
+    # reproducible from profiles/r06_serial_kernel_stats.txt as  sum_k 2 B p 60 24 (cin nn + cout cin) / sum_k avg duration / peak  (DESIGN 3, 5).
+    # The fraction of the fp32 matrix peak SURVEY 8d wrote its ceiling in is kept beside it as `frac_vs_fp32_matrix_peak` (it can exceed 1).
     y_kernel = kern == "inter_so3conv_y_kernel"
-    split_rate = SPLIT_RATE_TFLOPS * (2.0 if y_kernel else 1.0)        # three cross terms instead of six on the same 32x32x16 issue rate
-    out["roofline"] = {"bound": "mfma", "kernel": kern, "instantiations": d["members"], "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                       "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+    cross_terms = 3 if y_kernel else 6 if kern.startswith("inter_so3conv_x") else None
+    peak = F16_MFMA_PEAK_TFLOPS / cross_terms if cross_terms else FP32_MFMA_PEAK_TFLOPS
+    out["roofline"] = {"bound": "mfma", "kernel": kern, "instantiations": d["members"], "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                       "frac": round(achieved / peak, 4), "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                        "traffic_over_algorithmic": round(traffic / alg_bytes, 2) if traffic and alg_bytes else None,
                        "matrix_pipe_busy": pipe_busy, "counter_files": counter_files,
                        "launches_per_step": d["calls"], "avg_launch_ms": round(d["ms"] / d["calls"], 4),
                        "algorithmic_gflop_per_launch": round(d["flops"] / d["calls"] / 1e9, 3),
                        "share_of_step": round(d["ms"] / tot_ms, 3),
-                       "arithmetic": "fp32 results throughout, priced against the fp32 matrix peak (157.3: `frac` can exceed what the fp32 MFMA could ever reach).  "
-                                     + ("The inter conv (round 5, csrc/so3conv_y.hip) runs both contractions on v_mfma_f32_32x32x16_f16 with TWO fp16 planes per operand (h = fp16(x), l = "
-                                        "fp16(x - h), both to nearest; three cross products; the fp32 MFMA's error against fp64 for this path's O(1) operands, profiles/r05_f16_two_plane_split.txt) "
-                                        "and forms the kernel weights' pre-activation on v_mfma_f32_32x32x16_bf16 from exactly split factors; " if y_kernel else "")
-                                     + "the intra conv, q/k/v + head_combine, linear_relu_dot and the small-weight Linear layers run as exact 3 x bf16 operand splits with six "
-                                     "fp32-accumulated cross products on the bf16 matrix cores (profiles/r03_bf16x3_split.txt); the pipe the dominant kernel actually runs on is priced in "
-                                     "`frac_of_split_rate` (measured 32x32x16 issue rate, profiles/r04_mfma_bf16_issue_rates.txt, / cross terms per product: 3 for the two-plane fp16 split, 6 for the bf16 split)",
-                       "split_rate_tflops": split_rate, "frac_of_split_rate": round(achieved / split_rate, 4)}
+                       "peak_is": (f"dense fp16 matrix peak {F16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s (MI355X_MICROARCH.md) / {cross_terms} cross terms per fp32-equivalent product"
+                                   if cross_terms else "dense fp32 matrix peak (MI355X_MICROARCH.md)"),
+                       "executed_mfma_tflops": round(achieved * (cross_terms or 1), 1),
+                       "frac_vs_fp32_matrix_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                       "arithmetic": "fp32 results and accumulators throughout.  "
+                                     + ("The inter conv (csrc/so3conv_y.hip) runs both contractions on v_mfma_f32_32x32x16_f16 with TWO fp16 planes per operand (h = fp16(x), l = "
+                                        "fp16(x - h), both to nearest; three cross products; operands brought to a known power-of-two range first; the fp32 MFMA's error against fp64, "
+                                        "profiles/r05_f16_two_plane_split.txt) and forms the kernel weights' pre-activation on v_mfma_f32_32x32x16_bf16 from exactly split factors; "
+                                        if y_kernel else "")
+                                     + "the intra conv, the attention layers, the confidence head and the fused direction tail use the same two-plane fp16 form; the small-weight "
+                                     "Linear layers run as exact 3 x bf16 operand splits with six cross products (profiles/r03_bf16x3_split.txt)"}
     if longest != kern:
         out["roofline"]["longest_kernel"] = {"kernel": longest, "ms": round(fam[longest]["ms"], 3), "note": "one workgroup per scan: latency-bound"}
     out["kernel_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]}
     total_flops = sum(v["flops"] for v in agg.values())
-    out["whole_step_mfma_frac"] = round(total_flops / (dt / a.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+    # the whole step's algorithmic FLOPs against the same two ceilings: the two-plane fp16 pipe (lead) and the fp32 matrix peak (SURVEY 8d's unit)
+    out["whole_step_mfma_frac"] = round(total_flops / (dt / a.steps) / 1e12 / (F16_MFMA_PEAK_TFLOPS / 3.0), 4)
+    out["whole_step_frac_vs_fp32_matrix_peak"] = round(total_flops / (dt / a.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
     if not a.forward_only and not a.no_extras:
         out["stage2_latency"] = stage2_latency(args, device, cfg["iters"], B)
     if wp is not None:
@@ -855,13 +867,15 @@ def main():
     if N == 5000 and not a.forward_only:
         # 152.4 GFLOP matmul / conv + 5.2 GFLOP kernel-weight generation per 5 000-point scan -> 1.0 ms at the fp32-MFMA
         # peak, HBM-side 0.05 ms: ceiling ~ 1 030 scans/s per GPU for the whole path
-        # ceiling_mixed: the products that run split (everything but the attention scores / P V, the first conv's VALU work and the kernel-weight generation:
-        # 140.7 of the 152.4 GFLOP) at the measured split rate, the rest (11.7 + 5.2 GFLOP) at the fp32 peak
-        t_mixed = 140.7e9 / (SPLIT_RATE_TFLOPS * 1e12) + (11.7e9 + 5.2e9) / (FP32_MFMA_PEAK_TFLOPS * 1e12)
-        out["path_roofline"] = {"ceiling_scans_per_s_per_gpu": 1030, "frac": round(value / world / 1030.0, 4),
-                                "ceiling_mixed": round(1.0 / t_mixed), "frac_mixed": round(value / world * t_mixed, 4),
-                                "note": "ceiling = 152.4 GFLOP + 5.2 GFLOP weight generation per scan at the fp32 matrix peak (SURVEY 8d); ceiling_mixed prices the split-operand "
-                                        "products at the measured bf16-MFMA rate / 6"}
+        # ceiling_mixed (the lead): the products that run as two fp16 planes (everything but the first conv's VALU work and the kernel-weight generation:
+        # 140.7 + 11.7 of the 152.4 GFLOP since round 5 moved the attention scores / P V too) at the dense fp16 peak / 3 cross terms, the weight generation
+        # (5.2 GFLOP) at the fp32 peak
+        t_mixed = 152.4e9 / (F16_MFMA_PEAK_TFLOPS / 3.0 * 1e12) + 5.2e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12)
+        out["path_roofline"] = {"ceiling_mixed": round(1.0 / t_mixed), "frac_mixed": round(value / world * t_mixed, 4),
+                                "ceiling_scans_per_s_per_gpu_fp32_matrix_peak": 1030, "frac_vs_fp32_matrix_peak": round(value / world / 1030.0, 4),
+                                "note": "frac_mixed (lead) = value / ceiling_mixed: 152.4 GFLOP of products per scan at the dense fp16 matrix peak / 3 cross terms (833 TFLOP/s) "
+                                        "+ 5.2 GFLOP weight generation at the fp32 peak; the second pair prices everything at the fp32 matrix peak, the unit SURVEY 8d's "
+                                        "1 030 scans/s ceiling is written in (the path no longer runs on that pipe)"}
 
     if world == 1 and not a.no_cpu_baseline:
         def refit(run):          # the GPU fit of batch 0 with a shortened schedule (parity partner of the bounded oracle run)

@@ -187,6 +187,11 @@ __device__ __forceinline__ void ml_softmax(f32x4 (&s)[4], float c) {
 // K side [h h' | l l' | h h' | l l'], Q side [l l' | h h' | h h' | l l'].  P V: a lane's 16 probabilities and its 16 V accumulators belong to the SAME
 // keys (16 jt + 4 fg + r), so they are the lane's slices of the operands as they stand: K step ks = key tiles 2 ks, 2 ks + 1, element 4 (jt - 2 ks) + r.
 // cs: the scores' factor; the output tile, times os, goes to LDS as fp32 (As) or as the two planes of head_combine's operand (Ap)
+// the scores' factor 1/sqrt(8) log2(e) 2^-k (k = the powers of two the projections' operands carry).  The exponent is held at >= -125 so that the
+// factor stays a NORMAL float: a factor that underflowed to 0 met the padded keys' -inf start value as (-inf) * 0 = NaN (k > 149 needs a token
+// tile below ~1e-20).  With the clamp the padded keys stay at -inf (probability 0) and the real scores, all ~0, give the uniform softmax over the 60
+// keys that the reference returns for such a tile.
+__device__ __forceinline__ float ml_score_factor(int k) { return ldexpf(0.35355339059327373f * 1.4426950408889634f, k < 125 ? -k : -125); }
 template <bool PLANES>
 __device__ __forceinline__ void ml_attention(const f32x4 (&Q)[4], const f32x4 (&Kt)[4], const f32x4 (&V)[4], float* As, unsigned short* Ap, float cs, float os,
                                              int w, int fr, int fg) {
@@ -360,7 +365,7 @@ __global__ void __launch_bounds__(256, ML_LAYER_WPE) mhsa_layer_kernel(long T, c
         f32x4 Q[4], Kt[4], V[4];
         ml_project(Xp, W, Q, Kt, V, fr, fg);
         // MODE 2: the attention output itself leaves the kernel; otherwise it stays at <= 2^14 and its power is applied by the consumer's epilogue
-        ml_attention<(MODE < 2)>(Q, Kt, V, As, Ap, ldexpf(0.35355339059327373f * 1.4426950408889634f, -(2 * kx + W.kq + W.kk)),
+        ml_attention<(MODE < 2)>(Q, Kt, V, As, Ap, ml_score_factor(2 * kx + W.kq + W.kk),
                                  ldexpf(1.0f, MODE == 2 ? -13 - kx - W.kv : -13), w, fr, fg);
         __syncthreads();
 
@@ -577,7 +582,7 @@ __global__ void __launch_bounds__(256, MHSA_INTERP_WGS) mhsa_interp_layer_kernel
 
         f32x4 Q[4], Kt[4], V[4];
         ml_project(Xp, W, Q, Kt, V, fr, fg);
-        ml_attention<true>(Q, Kt, V, nullptr, Ap, ldexpf(0.35355339059327373f * 1.4426950408889634f, -(2 * kx + W.kq + W.kk)), ldexpf(1.0f, -13), w, fr, fg);
+        ml_attention<true>(Q, Kt, V, nullptr, Ap, ml_score_factor(2 * kx + W.kq + W.kk), ldexpf(1.0f, -13), w, fr, fg);
         __syncthreads();
 
         // ---- C: head_combine + bias + residual

@@ -52,17 +52,30 @@ class PointTransformerLayer(nn.Module):
         self._d = _Derived()
 
     def _apply(self, fn, *a, **k):
-        self._ps = None                 # .to() / .cuda() / .float(): the tensors behind the cached list may be replaced
+        self.__dict__["_slots"] = None        # .to() / .cuda() / .float(): the tensors behind the cached slots may be replaced
         return super()._apply(fn, *a, **k)
 
+    def __setattr__(self, name, value):
+        if isinstance(value, (nn.Module, nn.Parameter)):
+            self.__dict__["_slots"] = None    # a sub-module or Parameter object was re-assigned
+        super().__setattr__(name, value)
+
+    def _load_from_state_dict(self, *a, **k):
+        self.__dict__["_slots"] = None        # load_state_dict(assign=True) replaces the Parameter objects
+        return super()._load_from_state_dict(*a, **k)
+
     def _derived(self):
-        # the tensors the derived constants depend on, enumerated ONCE: Module.parameters() / buffers() walk the module tree (named_modules), and 72
-        # such walks per forward were 45 % of the host's time per step (cProfile on the GPU box).  In-place updates (optimizer steps, load_state_dict)
-        # keep the objects and are seen by _Derived's (data_ptr, version) key; re-assigning a Parameter object of a sub-module needs `layer._ps = None`
-        ps = getattr(self, "_ps", None)
-        if ps is None:
-            ps = [p for p in self.parameters()] + [b for b in self.buffers()]
-            self.__dict__["_ps"] = ps
+        # the tensors the derived constants depend on.  Module.parameters() / buffers() walk the module tree (named_modules), and 72 such walks per forward
+        # were 45 % of the host's time per step (cProfile on the GPU box): the tree is walked ONCE into a list of (owner's dict, name) slots and every call
+        # reads the CURRENT tensor of each slot (a list comprehension over ~30 dict lookups).  In-place updates (optimizer steps, load_state_dict) keep the
+        # objects and are seen by _Derived's (data_ptr, version) key; a re-assigned Parameter (module.weight = nn.Parameter(...), load_state_dict(
+        # assign=True)) is seen because the slot is looked up again; a REPLACED sub-module invalidates the slots (__setattr__ here; replacing a
+        # module two levels down, e.g. layer.linear_p[0] = ..., needs `layer._slots = None`)
+        slots = self.__dict__.get("_slots")
+        if slots is None:
+            slots = [(m._parameters, n) for m in self.modules() for n in m._parameters] + [(m._buffers, n) for m in self.modules() for n in m._buffers]
+            self.__dict__["_slots"] = slots
+        ps = [t for t in (d[n] for d, n in slots) if t is not None]
 
         def build():
             d = lambda t: t.detach().contiguous()

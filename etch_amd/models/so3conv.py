@@ -123,10 +123,15 @@ class SeparableSO3ConvBlock(nn.Module):
         fin = x.feats_cl
         branch = None
         if self.skip_on_side_stream and fin.is_cuda and not torch.is_grad_enabled():
+            # one side stream PER main stream (with stage1_streams = 2 a single shared side stream would order the two main streams' skip
+            # branches against each other's buffers, and "no record_stream needed" would no longer hold across them)
+            main = torch.cuda.current_stream()
             if SeparableSO3ConvBlock._side is None:
+                SeparableSO3ConvBlock._side = {}
+            side = SeparableSO3ConvBlock._side.get(main.cuda_stream)
+            if side is None:
                 from ..utils.cu_streams import make_stream
-                SeparableSO3ConvBlock._side = make_stream("side")
-            side, main = SeparableSO3ConvBlock._side, torch.cuda.current_stream()
+                side = SeparableSO3ConvBlock._side[main.cuda_stream] = make_stream("side")
             _, sidx0, nx = conv.group(x.xyz)                # memoised: the conv below finds the same tensors
             ev0 = torch.cuda.Event()
             ev0.record(main)

@@ -298,14 +298,22 @@ def intra_weight_split(w2):
     return q.permute(1, 3, 4, 0, 5, 2, 6).contiguous().reshape(-1)       # [mt][kq][ks][pl][kg][i][e]
 
 
-def _row_pow2(w):
+def _pow2_exp(m, cap=120):
+    """m >= 0 (any shape) -> k (float32, integer valued) with m 2^k in [8, 16) -- the host mirror of the device's etch_scale_exp (csrc/split_bf16.h): zero,
+    subnormal (below FLT_MIN) and non-finite maxima give k = 0, and k is capped at 120 so that 2^k AND 2^-k stay normal floats (an
+    uncapped 4 - frexp(m) reaches 128 .. 130 for m <= 2^-124, exp2 of which is inf)."""
+    ok = (m >= 1.1754943508222875e-38) & torch.isfinite(m)
+    x = torch.frexp(torch.where(ok, m, torch.ones_like(m)))[1]           # m = f 2^x, f in [0.5, 1)  ->  m 2^(4 - x) in [8, 16)
+    return torch.where(ok, (4 - x).clamp(max=cap), torch.zeros_like(x)).to(torch.float32)
+
+
+def _row_pow2(w, cap=120):
     """w [rows, K] -> (w with every row times the power of two that puts its maximum into [8, 16), the inverse powers float32 [rows]); exact.  The fp16
     planes of an operand carry 23 bits only near that range: scaling per ROW keeps rows far below the matrix maximum at full precision (a trained
-    weight matrix's rows may differ by orders of magnitude)."""
+    weight matrix's rows may differ by orders of magnitude).  Rows whose maximum is zero / subnormal / non-finite keep the factor 1 (_pow2_exp)."""
     wd = w.detach()
-    m = wd.abs().amax(1)
-    e = torch.where((m > 0) & torch.isfinite(m), 4 - torch.frexp(m.clamp_min(1e-38))[1], torch.zeros_like(m, dtype=torch.int32)).to(torch.float32)
-    return wd * torch.exp2(e)[:, None], torch.exp2(-e).contiguous()        # frexp: m = f 2^x, f in [0.5, 1)  ->  m 2^(4 - x) in [8, 16)
+    e = _pow2_exp(wd.abs().amax(1), cap)
+    return wd * torch.exp2(e)[:, None], torch.exp2(-e).contiguous()
 
 
 def intra_weight_split_f16(w2):
@@ -359,6 +367,19 @@ def split2_planes_f16(x_cl):
     planes = torch.empty(tuple(x_cl.shape[:-1]) + (2, C), dtype=torch.float16, device=x_cl.device)
     _lib.check(_lib.lib().etch_split2_planes_f16(_c_long(x_cl.numel() // C), int(C), _ptr(x_cl), _ptr(planes), _stream()), "etch_split2_planes_f16")
     return planes
+
+
+def split2_planes_f16_scaled(x_cl):
+    """x (b, ..., C) fp32 of ANY scale -> ((b, ..., 2, C) float16 planes of x[s] * 2^k(s), fsc (b,) float32 = 2^-k(s)): every scan is brought to a maximum
+    magnitude in [8, 16) before the split (exact), fsc is the factor etch_inter_so3conv_planes_kq's epilogue multiplies that scan's outputs with."""
+    _need(x_cl, torch.float32, "x")
+    b, C = x_cl.shape[0], x_cl.shape[-1]
+    planes = torch.empty(tuple(x_cl.shape[:-1]) + (2, C), dtype=torch.float16, device=x_cl.device)
+    mx = torch.zeros((b,), dtype=torch.int32, device=x_cl.device)
+    fsc = torch.empty((b,), dtype=torch.float32, device=x_cl.device)
+    _lib.check(_lib.lib().etch_split2_planes_f16_scaled(int(b), _c_long(x_cl.numel() // (b * C)), int(C), _ptr(x_cl), _ptr(mx), _ptr(planes), _ptr(fsc), _stream()),
+               "etch_split2_planes_f16_scaled")
+    return planes, fsc
 
 
 def inter_weight_split32_f16(W, cin, ks=24):
@@ -439,12 +460,15 @@ def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, orde
     part = torch.empty((b, p2, 2, cout), dtype=torch.float64, device=xyz.device) if fused else None
     if kq is not None and Wqh is not None and INTER_KQ and inter_planes_supported(cin, cout, nn):
         _need(Wqh, torch.float16, "Wqh"), _need(kq, torch.int16, "kq")
+        fsc = None
         if feats_planes is None or feats_planes.dtype != torch.float16:
-            feats_planes = split2_planes_f16(feats_cl)
+            # the caller's own features, of unknown scale (the operator API has no domain restriction): planes of every scan times its own power of two,
+            # undone by the kernel's epilogue (fsc).  Planes that arrive with the features are the producer's (instnorm_act_add: unit scale by construction)
+            feats_planes, fsc = split2_planes_f16_scaled(feats_cl)
         _need(feats_planes, torch.float16, "feats_planes")
         assert tuple(feats_planes.shape) == (b, p1, na, 2, cin) and kq.numel() == 60 * 2 * 64 * 8 and Wqh.numel() == 2 * cout * cin * 24
         _lib.check(_lib.lib().etch_inter_so3conv_planes_kq(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
-                                                          _ptr(feats_planes), _ptr(kq), _ptr(Wqh), _ptr(Wqh.wsc), _ptr(bias), _ptr(out), _optptr(order),
+                                                          _ptr(feats_planes), _ptr(kq), _ptr(Wqh), _ptr(Wqh.wsc), _optptr(fsc), _ptr(bias), _ptr(out), _optptr(order),
                                                           _optptr(part), _stream()), "etch_inter_so3conv_planes_kq")
     elif Wq32 is not None and cin == 64 and inter_planes_form(cin) == 32 and inter_planes_supported(cin, cout, nn):
         _need(Wq32, torch.int16, "Wq32")
@@ -501,7 +525,9 @@ def intra_so3conv(x_cl, intra_idx32, Wp, bias, cout, mean=None, rstd=None, want_
     out = torch.empty((b, p, 60, cout), dtype=torch.float32, device=x_cl.device)
     fused = want_stats and p % 2 == 0 and c <= 64        # wider tiles (encoder depths 3 / 4) take the separate statistics pass
     part = torch.empty((b * (p // 2), 2, cout), dtype=torch.float64, device=x_cl.device) if fused else None
-    if Wqh is not None and INTRA_SPLIT and INTRA_F16 and c == cout and c in (32, 64) and (part is None or p % 2 == 0):
+    # the two-plane fp16 form splits the NORMALISED tile (unit scale by construction); without statistics the rows are the caller's own, of unknown scale
+    # (> 65 504 -> inf, far below 1 -> the planes' absolute floor): those calls take the exact forms below
+    if Wqh is not None and mean is not None and rstd is not None and INTRA_SPLIT and INTRA_F16 and c == cout and c in (32, 64) and (part is None or p % 2 == 0):
         _need(Wqh, torch.int16, "Wqh")
         _lib.check(_lib.lib().etch_intra_so3conv_f16(b, c, cout, p, _ptr(x_cl), _optptr(mean), _optptr(rstd), _ptr(intra_idx32), _ptr(Wqh),
                                                     _ptr(Wqh.wsc), _ptr(bias), _ptr(out), _optptr(part), _stream()), "etch_intra_so3conv_f16")
@@ -607,7 +633,7 @@ def dirtail_weight_split(Wf):
     k = 16 ks + 8 (lane / 32) + e (etch_mhsa_layer_dirtail).  `.wsc` = 2^-kw: the caller folds it into the tail's constants -- relu(2^-kw a + b) v =
     relu(a + 2^kw b) (2^-kw v) -- so the kernel needs no per-unit factor (dirtail_constants)."""
     assert tuple(Wf.shape) == (128, 64)
-    ws, wsc = _row_pow2(Wf.float())
+    ws, wsc = _row_pow2(Wf.float(), cap=60)         # the power is folded into the bias (bf 2^kw, dirtail_constants): capped so that fold cannot overflow
     hi = ws.to(torch.float16)
     planes = torch.stack([hi, (ws - hi.float()).to(torch.float16)])        # [2][128][64]
     q = planes.reshape(2, 4, 32, 4, 2, 8)                                  # [pl][w][h][ks][kg][e]
@@ -847,15 +873,12 @@ def lrd_weight_split_f16(w, J=128):
     rows' inverse powers ride on the tensor as `.wsc` (float32 [G*J], etch_linear_relu_dot_f16)."""
     GJ, K = w.shape
     assert GJ % J == 0 and J % 16 == 0 and K % 32 == 0
-    wd = w.detach()
-    m = wd.abs().amax(1)
-    e = torch.where((m > 0) & torch.isfinite(m), 4 - torch.frexp(m.clamp_min(1e-38))[1], torch.zeros_like(m, dtype=torch.int32)).to(torch.float32)
-    ws = wd * torch.exp2(e)[:, None]                                          # frexp: m = f 2^x, f in [0.5, 1)  ->  m 2^(4 - x) in [8, 16)
+    ws, wsc = _row_pow2(w)
     hi = ws.to(torch.float16)
     planes = torch.stack([hi, (ws - hi.float()).to(torch.float16)])          # [2][GJ][K]
     q = planes.reshape(2, GJ // J, J // 16, 16, K // 32, 4, 8)               # [pl][g][strip][col][t][kg][e]
     out = q.permute(1, 4, 2, 0, 5, 3, 6).contiguous().reshape(-1)            # [g][t][strip][pl][kg][col][e]
-    out.wsc = torch.exp2(-e).contiguous()
+    out.wsc = wsc
     return out
 
 

@@ -34,6 +34,7 @@ class HotPathPipeline:
         self._pinned = [None] * (max_in_flight + 1)     # ring of pinned host buffers, one set per batch in flight (+1 being read)
         self._n = 0
         self.host_times = [] if os.environ.get("ETCH_PIPE_TIMING") == "1" else None
+        self.reserved_gib = 0.0          # what _reserve_allocator put into the streams' allocator pools (reported next to peak_hbm_gib)
 
     def __del__(self):
         try:        # batches still in flight keep their cross-stream tensors alive through their tickets: do not let them go before the GPU is done
@@ -56,10 +57,24 @@ class HotPathPipeline:
         side = getattr(self.model, "_side_stream", None)
         streams += [side] if side is not None else []
         streams += list(getattr(self.model, "_head_streams", None) or [])
+        # an optimisation must never take the run down: the reservation is scaled to what the GPU has free -- at most a quarter of it over all
+        # streams (a smaller GPU, or one shared by several ranks) -- and an allocation that fails anyway is skipped
+        try:
+            free_b, _ = torch.cuda.mem_get_info(self.args.device)
+        except Exception:
+            free_b = 0
+        per = min(int(gib * 2 ** 30), int(free_b // (4 * max(1, len(streams)))))
+        self.reserved_gib = 0.0
+        if per < 2 ** 26:
+            return
         for st in streams:
-            with torch.cuda.stream(st):
-                blk = torch.empty(int(gib * 2 ** 30), dtype=torch.uint8, device=self.args.device)
-                del blk
+            try:
+                with torch.cuda.stream(st):
+                    blk = torch.empty(per, dtype=torch.uint8, device=self.args.device)
+                    del blk
+                self.reserved_gib += per / 2 ** 30
+            except torch.cuda.OutOfMemoryError:
+                break
 
     def submit(self, points):
         """Enqueue one batch (B,N,3) resident on the device; returns a Ticket.  Does not block on the GPU unless

@@ -187,15 +187,22 @@ int etch_inter_so3conv_planes32(int b, int cin, int cout, int p1, int p2, int nn
  * once per layer from rk [60][24][3] = anchors @ kernel points (functional.py:296); Wq: 2 * cout * cin * 24 fp16 = the two planes of W, every row (output
  * channel) times the power of two that puts its maximum into [8, 16), in the physical contraction order of etch_inter_so3conv_planes32,
  * [K step of 16][o tile of 32][plane][lane][8]; wsc (cout floats) = the rows' inverse powers (etch_amd/ops.py inter_weight_split32_f16 and its `.wsc`).
+ * fsc: NULL (the planes are those of the features as they stand: InstanceNorm outputs, unit scale by construction) or b floats, scan s's outputs
+ * (before the bias) are multiplied by fsc[s] (etch_split2_planes_f16_scaled).  Round 6: persistent workgroups (one grid of 2 x CUs workgroups walks the
+ * b * p2 output points, XCD-aware, dynamic beyond the first two points of a workgroup) -- results are bit for bit those of one workgroup per point.
  * Covers every shape of etch_inter_so3conv_planes_supported; order / stat_part as for etch_inter_so3conv.  Same result as the fp32 kernels to
  * ~1e-6 of the output scale (tests/test_gpu_r05.py holds it to the fp32 kernel AND to fp64 under the entitled-error rule). */
 int etch_inter_kpoint_operand(float sigma, const float* rk, void* kq, void* stream);
 int etch_inter_so3conv_planes_kq(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
-                                 const int* ball_idx, const void* feats_planes, const void* kq, const void* Wq32, const float* wsc, const float* bias,
-                                 float* out, const int* order, double* stat_part, void* stream);
+                                 const int* ball_idx, const void* feats_planes, const void* kq, const void* Wq32, const float* wsc, const float* fsc,
+                                 const float* bias, float* out, const int* order, double* stat_part, void* stream);
 
 /* x (rows, C) fp32 -> planes (rows, 2, C) fp16: h = fp16(x), l = fp16(x - h), both to nearest (the gather format of etch_inter_so3conv_planes_kq). */
 int etch_split2_planes_f16(long rows, int C, const float* x, void* planes, void* stream);
+/* Features of unknown scale (callers of the operator API, vgtk so3conv/modules.py:92-128 has no domain restriction): x (b, rows, C) fp32 -> planes
+ * (b, rows, 2, C) fp16 of x[s] * 2^k(s), k(s) = the power of two that brings scan s's largest magnitude into [8, 16) (exact), and fsc[s] = 2^-k(s): pass
+ * `fsc` to etch_inter_so3conv_planes_kq, whose epilogue multiplies scan s's outputs by it.  mx: b unsigned words of workspace, zeroed by the caller. */
+int etch_split2_planes_f16_scaled(int b, long rows, int C, const float* x, void* mx, void* planes, float* fsc, void* stream);
 
 /* x (rows, C) fp32 -> planes (rows, 3, C) bf16: the exact split x = hi + mid + lo (8 + 8 + 8 mantissa bits, by truncation). */
 int etch_split3_planes(long rows, int C, const float* x, void* planes, void* stream);

@@ -47,7 +47,9 @@ for name, cin, cout, nn, radius, sigma, xyz, p2 in shapes:
         res[label] = (e0.elapsed_time(e1) / reps, y[0])
     tot += res["kq"][0]
     if only_kq:
-        line.append(f"{name} {res['kq'][0]:.3f}")
+        # checksum of the output bits and of the statistics (A/B of two builds of the kernel: equal checksums = bitwise equal results)
+        cs = int(res["kq"][1].view(torch.int32).to(torch.int64).sum()) & 0xffffffffffff
+        line.append(f"{name} {res['kq'][0]:.3f} [{cs:012x}]")
     else:
         d = float((res["kq"][1] - res["r03"][1]).abs().max()) / float(res["r03"][1].abs().max())
         print(f"{name} {cin}->{cout} nn={nn} p2={p2}: r03 {res['r03'][0]:.3f} ms, r04 {res['r04'][0]:.3f} ms, kq {res['kq'][0]:.3f} ms, kq vs r03 max diff / scale {d:.2e}", flush=True)

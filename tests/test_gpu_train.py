@@ -171,8 +171,11 @@ def _losses(res, vec, conf, labels, mask, which):
 _LAST = {}       # the last oracle run's anchor weights (B*N, 60)
 
 
-def _oracle(model, pts, vec, conf, labels, dtype, which, mask, lr=None, bn_training=True, aw_at=None):
-    """The oracle's forward in train() mode + torch.autograd (+ one Adam step) on the CPU in `dtype`.
+def _oracle_jobs(model, pts, vec, conf, labels, dtype, jobs, bn_training=True):
+    """The oracle's forward in train() / eval() mode ONCE, then torch.autograd of several losses through the same graph (+ one Adam step for the last
+    job that asks for it), on the CPU in `dtype`.  jobs: dicts {which, mask=None, lr=None, aw_at=None}; returns one (grads, mask, losses, new) per job
+    and leaves the forward's own anchor weights in _LAST["anc_w"].  (Round 6: each test used to re-run the whole un-fused forward -- the expensive part on
+    the CPU -- once per loss set and once more just to read the anchor weights; the gradients are those of the same graphs, bit for bit.)
     aw_at (B*N, 60): evaluate so3_mean and its derivative AT these anchor weights (the oracle's own anc_w + a constant offset: the graph is unchanged) --
     the gradient of the loss at the linearisation point of the run under test, see test_eval_mode_gradients_of_all_four_losses_strict."""
     from etch_amd.utils.weights import seeded_state_dict
@@ -191,38 +194,58 @@ def _oracle(model, pts, vec, conf, labels, dtype, which, mask, lr=None, bn_train
         xyz, feats = S1.encoder_forward(sd, x, S1.build_layer_table(mlps=MLPS[:depth], strides=(2,) * depth))
         S_ = xyz.shape[-1]
         pef = S1.feat_propagation(x.permute(0, 2, 1), xyz.to(dtype), feats.permute(0, 1, 3, 2).reshape(B, -1, S_)).reshape(B, N, -1, 60)
-        res = {}
+        base = {}
         p = x.reshape(-1, 3).contiguous()
         inv = pef.mean(-1).reshape(B * N, -1).contiguous()
         o = torch.tensor([N * (i + 1) for i in range(B)], dtype=torch.int32)
-        if "confidence" in which:
-            res["part_labels"], res["confidences"] = S1.pt_confidence(sd, "confidence_encoder.", p, inv, o, 86)
-        if "magnitude" in which:
-            res["magnitude"] = S1.pt_magnitude(sd, "magnitude_encoder.", p, inv, o)
-        if "direction" in which:
-            aw = S1.direction_anchor_weights(sd, pef)
-            if aw_at is not None:
-                aw = aw + (torch.from_numpy(np.asarray(aw_at)).to(dtype) - aw).detach()
-            R, Ce, sv = S1.so3_mean(sd[f"encoder.backbone.{depth - 1}.blocks.1.intra_conv.conv.anchors"], aw)
-            res["direction"] = R[:, :, 2].reshape(B, N, 3)
-            _LAST["anc_w"] = aw.detach().double().numpy().copy()
-            if mask is None:
-                sig = torch.stack([sv[:, 0], sv[:, 1], torch.det(Ce.detach()).sign() * sv[:, 2]], 1).detach()
-                gap = torch.stack([sig[:, 0] + sig[:, 1], sig[:, 0] + sig[:, 2], sig[:, 1] + sig[:, 2]], 1).min(1).values
-                mask = (gap > 0.25 * sv[:, 0].detach()).reshape(B, N)
+        need = set(w for j in jobs for w in j["which"])
+        if "confidence" in need:
+            base["part_labels"], base["confidences"] = S1.pt_confidence(sd, "confidence_encoder.", p, inv, o, 86)
+        if "magnitude" in need:
+            base["magnitude"] = S1.pt_magnitude(sd, "magnitude_encoder.", p, inv, o)
+        aw0 = None
+        if "direction" in need:
+            aw0 = S1.direction_anchor_weights(sd, pef)
+            _LAST["anc_w"] = aw0.detach().double().numpy().copy()
         t = lambda a: torch.from_numpy(a).to(dtype)
-        loss, parts = _losses(res, t(vec), t(conf), torch.from_numpy(labels), None if mask is None else mask.to(dtype), which)
-        loss.backward()
-        grads = {k: (None if sd[k].grad is None else sd[k].grad.detach().double().numpy()) for k in names}
-        new = None
-        if lr is not None:
-            ps = [sd[k] for k in names if sd[k].grad is not None]
-            torch.optim.Adam(ps, lr=lr).step()
-            new = {k: sd[k].detach().double().numpy() for k in names}
-        return grads, mask, {k: float(v.detach()) for k, v in parts.items()}, new
+        out = []
+        for ji, job in enumerate(jobs):
+            which, mask, lr, aw_at = job["which"], job.get("mask"), job.get("lr"), job.get("aw_at")
+            res = dict(base)
+            if "direction" in which:
+                aw = aw0
+                if aw_at is not None:
+                    aw = aw + (torch.from_numpy(np.asarray(aw_at)).to(dtype) - aw).detach()
+                R, Ce, sv = S1.so3_mean(sd[f"encoder.backbone.{depth - 1}.blocks.1.intra_conv.conv.anchors"], aw)
+                res["direction"] = R[:, :, 2].reshape(B, N, 3)
+                if mask is None:
+                    sig = torch.stack([sv[:, 0], sv[:, 1], torch.det(Ce.detach()).sign() * sv[:, 2]], 1).detach()
+                    gap = torch.stack([sig[:, 0] + sig[:, 1], sig[:, 0] + sig[:, 2], sig[:, 1] + sig[:, 2]], 1).min(1).values
+                    mask = (gap > 0.25 * sv[:, 0].detach()).reshape(B, N)
+            loss, parts = _losses(res, t(vec), t(conf), torch.from_numpy(labels), None if mask is None else mask.to(dtype), which)
+            last = ji == len(jobs) - 1
+            assert lr is None or last, "the Adam step changes the parameters: only the last job may ask for it"
+            gs = torch.autograd.grad(loss, [sd[k] for k in names], retain_graph=not last, allow_unused=True)
+            grads = {k: (None if g is None else g.detach().double().numpy()) for k, g in zip(names, gs)}
+            new = None
+            if lr is not None:
+                ps = []
+                for k, g in zip(names, gs):
+                    if g is not None:
+                        sd[k].grad = g
+                        ps.append(sd[k])
+                torch.optim.Adam(ps, lr=lr).step()
+                new = {k: sd[k].detach().double().numpy() for k in names}
+            out.append((grads, mask, {k: float(v.detach()) for k, v in parts.items()}, new))
+        return out
     finally:
         torch.set_default_dtype(old)
         S1.BN_TRAINING = False
+
+
+def _oracle(model, pts, vec, conf, labels, dtype, which, mask, lr=None, bn_training=True, aw_at=None):
+    """One loss set (see _oracle_jobs)."""
+    return _oracle_jobs(model, pts, vec, conf, labels, dtype, [dict(which=which, mask=mask, lr=lr, aw_at=aw_at)], bn_training)[0]
 
 
 def _gpu(model, pts, vec, conf, labels, which, mask, pred_items):
@@ -302,10 +325,13 @@ def test_train_mode_gradients_of_all_four_losses_and_one_adam_step(tmp_path):
     model.train()
     names = [k for k, _ in model.named_parameters()]
     all_items = ["confidence", "direction", "magnitude"]
+    # ONE oracle forward per precision, both loss sets differentiated through it; the fp64 run's Adam step comes last (it changes the parameters)
+    pt_losses, all_losses = ("magnitude", "confidence"), ("direction", "magnitude", "confidence")
+    (g64, _, l64, _), (g64b, mask_b, l64b, new64) = _oracle_jobs(model, pts, vec, conf, labels, torch.float64,
+                                                                  [dict(which=pt_losses), dict(which=all_losses, lr=1e-4)])
+    (g32, _, l32, _), (g32b, _, l32b, _) = _oracle_jobs(model, pts, vec, conf, labels, torch.float32, [dict(which=pt_losses), dict(which=all_losses, mask=mask_b)])
     # (a)
-    which = ("magnitude", "confidence")
-    g64, _, l64, _ = _oracle(model, pts, vec, conf, labels, torch.float64, which, None)
-    g32, _, l32, _ = _oracle(model, pts, vec, conf, labels, torch.float32, which, None)
+    which = pt_losses
     with pytest.warns(UserWarning, match="differentiable"):
         gg, lg = _gpu(model, pts, vec, conf, labels, which, None, ["confidence", "magnitude"])
     print("losses (fp64 oracle / fp32 oracle / gpu):", {k: (round(l64[k], 6), round(l32[k], 6), round(lg[k], 6)) for k in l64})
@@ -320,10 +346,9 @@ def test_train_mode_gradients_of_all_four_losses_and_one_adam_step(tmp_path):
     for k in names:
         assert (gg[k] is None and g2[k] is None) or torch.equal(g2[k], gg[k]), k          # bitwise reproducible
     # (b)
-    which = ("direction", "magnitude", "confidence")
-    g64, mask, l64, new64 = _oracle(model, pts, vec, conf, labels, torch.float64, which, None, lr=1e-4)
+    which = all_losses
+    g64, mask, l64, g32, l32 = g64b, mask_b, l64b, g32b, l32b
     assert 0.15 < float(mask.float().mean()) < 1.0
-    g32, _, l32, _ = _oracle(model, pts, vec, conf, labels, torch.float32, which, mask)
     gg, lg = _gpu(model, pts, vec, conf, labels, which, mask, all_items)
     print("losses (fp64 oracle / fp32 oracle / gpu):", {k: (round(l64[k], 6), round(l32[k], 6), round(lg[k], 6)) for k in l64})
     assert all(gg[k] is not None for k in names)
@@ -357,15 +382,28 @@ def test_eval_mode_gradients_of_all_four_losses_strict(tmp_path, depth):
     Round 5: at EVERY encoder depth the reference trains (train.py:61-101 trains whatever EPN_layer_num builds,
     models_pointcloud.py:34-48: 32 / 64 / 128 / 256-dim tokens, conv channel pairs up to (256, 256)); depths 1 / 3 / 4 run the un-fused attention chain +
     etch_mhsa_attention_backward_dim (head widths 4 / 16 / 32) and the inter conv's data gradient in 64-channel windows."""
-    B, N = 2, 512
+    # two scans at the depths the path is built around (the released depth 2, and 1); one scan at depths 3 / 4, whose oracle runs (fp64 autograd through
+    # the materialised 128- / 256-channel kernel-weight tensors on the CPU) were 285 s of the GPU suite -- the per-scan segmentation of the training kernels
+    # is depth-independent and stays covered by the two-scan runs (VERDICT r05 item 3: the suite has a 1 200 s limit)
+    B, N = (2 if depth <= 2 else 1), 512
     model, pts, vec, conf, labels = _setup(tmp_path, B, N, depth)
     model.eval()
     model.differentiable = True
     assert model.differentiable_supported()
     names = [k for k, _ in model.named_parameters()]
-    which = ("magnitude", "confidence")
-    g64, _, l64, _ = _oracle(model, pts, vec, conf, labels, torch.float64, which, None, bn_training=False)
-    g32, _, l32, _ = _oracle(model, pts, vec, conf, labels, torch.float32, which, None, bn_training=False)
+    # the path's own forward first: its anchor weights are the linearisation point of the direction loss below
+    with torch.enable_grad():
+        model(torch.from_numpy(pts).cuda(), ["direction"], "standard_vector")
+    aw_gpu = model.last_anc_w.detach().double().cpu().numpy().reshape(B * N, 60)
+    pt_losses, all_losses = ("magnitude", "confidence"), ("direction", "magnitude", "confidence")
+    # ONE oracle forward per precision; both loss sets are differentiated through it (the fp32 run takes the fp64 run's direction mask)
+    (g64, _, l64, _), (g64d, mask, l64d, _) = _oracle_jobs(model, pts, vec, conf, labels, torch.float64,
+                                                            [dict(which=pt_losses), dict(which=all_losses, aw_at=aw_gpu)], bn_training=False)
+    aw64 = _LAST["anc_w"]
+    (g32, _, l32, _), (g32d, _, l32d, _) = _oracle_jobs(model, pts, vec, conf, labels, torch.float32,
+                                                         [dict(which=pt_losses), dict(which=all_losses, mask=mask, aw_at=aw_gpu)], bn_training=False)
+    aw32 = _LAST["anc_w"]
+    which = pt_losses
     gg, lg = _gpu(model, pts, vec, conf, labels, which, None, ["confidence", "magnitude"])
     print("losses (fp64 oracle / fp32 oracle / gpu):", {k: (round(l64[k], 6), round(l32[k], 6), round(lg[k], 6)) for k in l64})
     for k in l64:
@@ -383,19 +421,11 @@ def test_eval_mode_gradients_of_all_four_losses_strict(tmp_path, depth):
     #   (2) backward: the gradient of the loss AT the anc_w the path itself computed -- the fp64 oracle with so3_mean evaluated at the path's anchor
     #       weights (a constant offset on its own anc_w: same graph) -- per tensor within 1e-3 or `slack` x the deviation of the oracle's fp32 run
     #       evaluated at that same point.
-    which = ("direction", "magnitude", "confidence")
-    _, mask0, _, _ = _oracle(model, pts, vec, conf, labels, torch.float64, ("direction",), None, bn_training=False)
-    aw64 = _LAST["anc_w"]
-    _oracle(model, pts, vec, conf, labels, torch.float32, ("direction",), mask0, bn_training=False)
-    aw32 = _LAST["anc_w"]
-    with torch.enable_grad():
-        model(torch.from_numpy(pts).cuda(), ["direction"], "standard_vector")
-    aw_gpu = model.last_anc_w.detach().double().cpu().numpy().reshape(B * N, 60)
+    which = all_losses
     l2 = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
     print(f"anc_w against the fp64 oracle, relative L2: gpu {l2(aw_gpu, aw64):.2e}, oracle's own fp32 {l2(aw32, aw64):.2e}")
     assert l2(aw_gpu, aw64) <= 2.0 * l2(aw32, aw64) + 1e-7
-    g64, mask, l64, _ = _oracle(model, pts, vec, conf, labels, torch.float64, which, None, bn_training=False, aw_at=aw_gpu)
-    g32, _, l32, _ = _oracle(model, pts, vec, conf, labels, torch.float32, which, mask, bn_training=False, aw_at=aw_gpu)
+    g64, g32, l64, l32 = g64d, g32d, l64d, l32d
     gg, lg = _gpu(model, pts, vec, conf, labels, which, mask, ["confidence", "direction", "magnitude"])
     assert np.array_equal(model.last_anc_w.detach().double().cpu().numpy().reshape(B * N, 60), aw_gpu)      # the forward is reproducible: same linearisation point
     print("losses (fp64 oracle / fp32 oracle / gpu):", {k: (round(l64[k], 6), round(l32[k], 6), round(lg[k], 6)) for k in l64})
