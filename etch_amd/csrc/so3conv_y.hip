@@ -68,35 +68,70 @@ __global__ void __launch_bounds__(128) inter_kpoint_operand_kernel(float inv_sig
 // step 2 of the 32x32x16 kernels on the fp16 matrix cores: Y[o][a] += sum_kappa W[o][kappa] X1[a][kappa] with both operands as two fp16 planes (W pre-split
 // with every output channel's row times its own power of two, ops.inter_weight_split32_f16 -- undone per channel in the epilogue; the X1 row split by the wave that reads it) and the three largest cross products.
 // W fragments: [K step of 16][o tile of 32][plane][lane][8], streamed from L2 one batch ahead (inline-asm loads + counted waits, see X32Step2).
-template <int CIN, int COUT, int PAD>
+// Round 6: the look-ahead ring holds RD batches.  With ONE batch ahead (round 5) a batch's loads were requested 3 MFMAs (~100 cycles) before their wait --
+// an L2 round trip is several times that, and the 64-channel kernel (one wave per SIMD: nothing else to run meanwhile) spent step 2 waiting for W.
+template <int CIN, int COUT, int PAD, int RD>
 struct H32Step2 {
     static constexpr int MT2 = COUT / 32, CH = CIN / 2, KH = CH * KS, S = KH + PAD;
     static constexpr int NSW = KH / 16 / 4;         // K steps per wave and half
     static constexpr int NB = NSW * MT2;            // batches (one K step x one o tile: two planes) per half
-    f32x4 ra[2][2];
+    static_assert(RD >= 2 && RD - 1 <= 2 * NB, "ring depth");
+    f32x4 ra[RD][2];
     __device__ __forceinline__ void issue(int i, const bf16x8* __restrict__ Wq, int wave, int lane) {
         const int h = i / NB, c = (i % NB) / MT2, mt = i % MT2;
         const char* b0 = reinterpret_cast<const char*>(Wq) + ((size_t)(h * (KH / 16) + wave + 4 * c) * MT2 + mt) * 2 * 1024;
         const unsigned vo = (unsigned)lane * 16u;
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) x_wload_s(ra[i & 1][pl], vo, b0, pl);
+        for (int pl = 0; pl < 2; ++pl) x_wload_s(ra[i % RD][pl], vo, b0, pl);
+    }
+    // the first RD - 1 batches (before the barrier in front of the first half)
+    __device__ __forceinline__ void prime(const bf16x8* __restrict__ Wq, int wave, int lane) {
+#pragma unroll
+        for (int i = 0; i < RD - 1; ++i) issue(i, Wq, wave, lane);
     }
     template <int N> __device__ __forceinline__ void wait(f32x4 (&v)[2]) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(v[0]), "+v"(v[1]) : "n"(N)); }
+    // PF (the 64-channel kernel: one wave per SIMD, registers to spare): the X1 row of K step c + 1 is read while step c computes -- read where it is
+    // split, every K step waited out an LDS round trip with nothing else to issue
+    static constexpr bool PF = CIN >= 64;
     template <int H>
     __device__ __forceinline__ void half(f32x16 (&y)[MT2], const float* X1s, const bf16x8* __restrict__ Wq, int wave, int lane) {
         const int an = lane & 31, kg = lane >> 5;
         f16x8 bq[2];
+        float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), xb = xa;
+        if (PF) {
+            const float* xr = &X1s[an * S + wave * 16 + kg * 8];
+            xa = *reinterpret_cast<const float4*>(xr); xb = *reinterpret_cast<const float4*>(xr + 4);
+        }
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
             const int i = H * NB + r, c = r / MT2, mt = r % MT2;
             if (mt == 0) {
                 asm volatile("" ::: "memory");             // keeps the X1 reads (and their splits) of later steps from being hoisted
-                const float* xr = &X1s[an * S + (wave + 4 * c) * 16 + kg * 8];
-                split2h_pack8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4), bq[0], bq[1]);
+                if (PF) {
+                    split2h_pack8(xa, xb, bq[0], bq[1]);
+                    if (c + 1 < NSW) {
+                        const float* xr = &X1s[an * S + (wave + 4 * (c + 1)) * 16 + kg * 8];
+                        xa = *reinterpret_cast<const float4*>(xr); xb = *reinterpret_cast<const float4*>(xr + 4);
+                    }
+                } else {
+                    const float* xr = &X1s[an * S + (wave + 4 * c) * 16 + kg * 8];
+                    split2h_pack8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4), bq[0], bq[1]);
+                }
             }
-            if (i + 1 < 2 * NB) { issue(i + 1, Wq, wave, lane); wait<2>(ra[i & 1]); }
-            else wait<0>(ra[i & 1]);
-            f32x4 (&ac)[2] = ra[i & 1];
+            // batch i + RD - 1 goes into the entry batch i - 1 left; then all but the younger batches' loads must have landed (two loads per batch, in order)
+            if (i + RD - 1 < 2 * NB) issue(i + RD - 1, Wq, wave, lane);
+            constexpr int TOT = 2 * NB;
+            const int younger = (i + RD - 1 < TOT ? RD - 1 : TOT - 1 - i);
+            static_assert(RD <= 8, "wait table");
+            if (younger >= 7) wait<14>(ra[i % RD]);
+            else if (younger == 6) wait<12>(ra[i % RD]);
+            else if (younger == 5) wait<10>(ra[i % RD]);
+            else if (younger == 4) wait<8>(ra[i % RD]);
+            else if (younger == 3) wait<6>(ra[i % RD]);
+            else if (younger == 2) wait<4>(ra[i % RD]);
+            else if (younger == 1) wait<2>(ra[i % RD]);
+            else wait<0>(ra[i % RD]);
+            f32x4 (&ac)[2] = ra[i % RD];
             // smallest cross products first: l * h, h * l, h * h
             y[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ac[1]), bq[0], y[mt], 0, 0, 0);
             y[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ac[0]), bq[1], y[mt], 0, 0, 0);
@@ -104,6 +139,10 @@ struct H32Step2 {
         }
     }
 };
+
+#ifndef Y_S2_DEPTH
+#define Y_S2_DEPTH(CIN) ((CIN) <= 32 ? 2 : 6)
+#endif
 
 // Round 6: PERSISTENT workgroups.  profiles/r05_inter_conv_latency_bound.txt priced 8.3 of the 22 us a workgroup spends on a point as
 // per-point fixed cost: workgroup launch, ball_idx -> row offsets -> barrier -> first gathers / coordinates -> neighbour factor -> barrier, pipeline fill.
@@ -527,10 +566,10 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
 #pragma unroll
             for (int v = 0; v < 16; ++v) y[mt][v] = 0.f;
 #ifndef Y_ABL_NOSTEP2
-        H32Step2<CIN, COUT, Y_PAD(CIN)> s2;
+        H32Step2<CIN, COUT, Y_PAD(CIN), Y_S2_DEPTH(CIN)> s2;
         const bf16x8* Wq_g = Wq;
         asm volatile("" : "+s"(Wq_g));
-        s2.issue(0, Wq_g, wave, lane);
+        s2.prime(Wq_g, wave, lane);
         __syncthreads();
         s2.template half<0>(y, X1s, Wq_g, wave, lane);
 #endif
@@ -560,12 +599,20 @@ __global__ void __launch_bounds__(256, INTER_Y_WPE(CIN)) inter_so3conv_y_kernel(
             const float* fsc = Y_RARE(fsc);
             const float wsf = fsc ? ws_t * fsc[b] : ws_t;      // the weight planes carry every output channel's row times its own power of two, the feature planes (when the
                                                                // caller scaled them: fsc) their scan's -- both exact, both taken out here; o == tid % COUT
-            for (int e = tid; e < AG * COUT; e += 256) {
-                const int col = e / COUT, o = e - col * COUT;
-                const int a = ag * AG + col;
+            // (all of the thread's partial sums are read before the first is used: read element by element, each element waited out its own LDS round trip)
+            constexpr int NE = AG * COUT / 256;
+            const int o = tid % COUT, col0 = tid / COUT;
+            float pv[NE][4];
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) pv[e][w4] = part[(w4 * AG + col0 + e * (256 / COUT)) * PS + o];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int a = ag * AG + col0 + e * (256 / COUT);
                 if (a < NA) {
-                    float v = part[(0 * AG + col) * PS + o] + part[(1 * AG + col) * PS + o];
-                    v += part[(2 * AG + col) * PS + o] + part[(3 * AG + col) * PS + o];
+                    float v = pv[e][0] + pv[e][1];
+                    v += pv[e][2] + pv[e][3];
                     v = v * wsf + b_t;
                     outp[(size_t)a * COUT + o] = v;
                     st_s += (double)v; st_q += (double)v * (double)v;
