@@ -500,6 +500,9 @@ def main():
     ap.add_argument("--sync", action="store_true", help="synchronous steps (stage 2 of a batch finishes before stage 1 of the next starts). Default: the "
                     "stream pipeline of etch_amd.pipeline (3 batches in flight) -- stage 2 of step i (32 persistent workgroups, 1/8 of the chip) runs on a second "
                     "HIP stream next to stage 1 of step i+1; every one of the K steps still completes inside the timed region")
+    ap.add_argument("--schedule", default="eager", choices=["eager", "graph"], help="how a pipelined step reaches the GPU: eager (default: five streams, the launches "
+                    "come from Python) or graph (A/B: one HIP-graph replay per batch slot -- immune to a busy host, but 25 %% slower on a quiet one: "
+                    "profiles/r06_schedule_ab.txt)")
     ap.add_argument("--serial", action="store_true", help="profiling schedule: synchronous steps and every kernel on one stream")
     ap.add_argument("--unfused-interp", action="store_true", help="A/B: separate 3-NN interpolation kernel in front of the direction head")
     ap.add_argument("--stage1-streams", type=int, default=1, help="stage-1 streams the pipeline alternates over (batches in flight = this + 2; ETCH_MAX_IN_FLIGHT overrides)")
@@ -580,6 +583,7 @@ def main():
     pts = batches[0]
     timed = [batches[(k + 1) % nbatch] for k in range(a.steps)]
     last = {}
+    sched_report = {"schedule": "none"}
     if dry:
         def step(p=pts):
             time.sleep(0.002)
@@ -611,7 +615,13 @@ def main():
                         frozen=(tr[:, 1:] == tr[:, :-1]).sum(1))
 
         step = stage1_only if a.forward_only else full_step
-        pipe = HotPathPipeline(args, model, "neutral", max_in_flight=in_flight, stage1_streams=a.stage1_streams, want_trace=True, **fit_kw)
+        from etch_amd.pipeline import choose_pipeline
+        pipe = None
+        if a.pipeline:
+            for _ in range(max(1, a.warmup)):      # the model's caches (folded weights, fragments, device body tables) fill before anything is captured / timed
+                (stage1_only if a.forward_only else full_step)()
+            pipe, sched_report = choose_pipeline(args, model, pts, "neutral", max_in_flight=in_flight, schedule="eager" if a.forward_only else a.schedule,
+                                                 stage1_streams=a.stage1_streams, want_trace=True, log=lambda m: print(m, file=sys.stderr), **fit_kw)
 
         def run_steps(bs):
             """One step per batch of `bs`; with the pipeline, stage 2 of step i overlaps stage 1 of step i+1 (all finish inside the call)."""
@@ -660,8 +670,8 @@ def main():
     wp = None
     if not dry and not a.forward_only and not a.no_extras:
         mk_wp = well_posed_markers(args, device, B)
-        pipe_wp = HotPathPipeline(args, model, "neutral", max_in_flight=in_flight, stage1_streams=a.stage1_streams, want_trace=True,
-                                  markers_override=mk_wp[:3], **fit_kw)
+        pipe_wp, _ = choose_pipeline(args, model, pts, "neutral", max_in_flight=in_flight, schedule=sched_report["schedule"] if a.pipeline else "eager",
+                                     stage1_streams=a.stage1_streams, want_trace=True, markers_override=mk_wp[:3], **fit_kw)
         for r_ in pipe_wp.run(iter([pts] * 2)):
             pass
         P.barrier()
@@ -706,7 +716,11 @@ def main():
                 f"configs[2]: batch={B}/GPU synthetic {N}-pt Gaussian-blob scans, full pipeline (eq-net + 30+50-iter LM SMPL fit), "
                 "seeded random weights, seeded SMPL-shaped body model, 86-marker superset")
     sched = ("serial: synchronous steps, one stream" if a.serial else "synchronous steps") if not a.pipeline else \
-        f"stream pipeline, {in_flight} batches in flight: stage 2 of step i overlaps stage 1 of step i+1, the host enqueues two steps ahead"
+        (f"stream pipeline, {in_flight} batches in flight: stage 2 of step i overlaps stage 1 of step i+1, the host enqueues two steps ahead"
+         if sched_report.get("schedule") != "graph" else
+         f"graph-replay pipeline, {in_flight} batches in flight: every batch's device work (stage 1 with its side streams, glue, marker fit, LBS) is one HIP graph per "
+         "slot, replayed with one host call; stage 2 of step i overlaps stage 1 of step i+1") + \
+        (f"; --schedule {a.schedule}" if a.schedule != "eager" else "")
     metric = "scans/s (5k pts, eq-net forward only)" if a.forward_only else "scans/s (5k pts, eq-net + 50-iter SMPL fit)"
     if a.config == 4:
         metric = "scans/s (20k pts, eq-net + 200-iter SMPL-X-sized fit)"

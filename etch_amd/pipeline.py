@@ -163,3 +163,84 @@ class HotPathPipeline:
                 yield self.result(pending.pop(0))
         while pending:
             yield self.result(pending.pop(0))
+
+
+class GraphPipeline:
+    """The same schedule -- `max_in_flight` batches on the device at once, stage 2 of a batch next to stage 1 of the next -- with the device work of a batch
+    recorded ONCE per slot as a HIP graph (etch_amd.graph.GraphedHotPath: stage 1 with its side streams as branches, labels / inner points, marker fit,
+    final LBS) and replayed with one host call.  Why: the eager pipeline needs ~430 launches = ~7 ms of Python per 33 ms step, and on a host whose cores
+    are busy with other tenants those 7 ms become 20 - 60 ms -- the enqueueing thread, not the GPU, then sets the rate (640 - 860 instead of
+    900+ scans/s).  A replay costs the host the runtime's own submission of the recorded nodes (C++, ~1 ms) and nothing else.  OPT-IN: on a quiet host
+    the eager pipeline is much the faster of the two (946 - 986 against 707 - 716 scans/s, profiles/r06_schedule_ab.txt: replays on different streams do
+    not overlap each other on this runtime), so this only pays on a host that cannot keep the eager pipeline fed.  Results are bit-identical (the same
+    kernels on the same data: tests/test_gpu_pipeline.py).  One instance serves ONE batch shape (B, N): the graphs own static input / output buffers and private memory pools."""
+
+    def __init__(self, args, model, B, N, gender="neutral", max_in_flight=3, want_trace=False, **fit_kwargs):
+        from .graph import GraphedHotPath
+        self.args, self.B, self.N = args, B, N
+        fit_kwargs = dict(fit_kwargs, want_trace=want_trace)
+        self.slots = [GraphedHotPath(args, model, B, N, gender, **fit_kwargs) for _ in range(max_in_flight)]
+        self.streams = [torch.cuda.Stream() for _ in range(max_in_flight)]
+        self.max_in_flight = max_in_flight
+        self.busy = [None] * max_in_flight          # the ticket that currently owns slot k's static buffers
+        self._pinned = [None] * max_in_flight
+        self._n = 0
+        self.reserved_gib = 0.0
+        self.host_times = None
+
+    def _retire(self, t):
+        if t.finalized is None:
+            t.done.synchronize()
+            t.finalized = fit_smpl_finalize(t.fit)
+            t.keepalive = None
+
+    def submit(self, points):
+        """Enqueue one batch (B,N,3) resident on the device; returns a Ticket.  The slot's previous batch is retired first (its results leave the static
+        buffers as host copies / clones before the replay overwrites them)."""
+        assert tuple(points.shape) == (self.B, self.N, 3), (tuple(points.shape), (self.B, self.N, 3))
+        k = self._n % self.max_in_flight
+        if self.busy[k] is not None:
+            self._retire(self.busy[k])
+        st = self.streams[k]
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.no_grad(), torch.cuda.stream(st):
+            dev = dict(self.slots[k].replay(points))
+            # markers / valid are part of the result tuple and live in the slot's static buffers: cloned (stream-ordered behind the replay)
+            dev["markers"], dev["valid"] = dev["markers"].clone(), dev["valid"].clone()
+            fit_smpl_stage_host(dev, self._pinned[k])
+            self._pinned[k] = dev["host"]
+            done = torch.cuda.Event()
+            done.record(st)
+        t = Ticket(done, dev["results"], dev)
+        t.keepalive = [points]
+        self.busy[k] = t
+        self._n += 1
+        return t
+
+    def result(self, ticket):
+        self._retire(ticket)
+        return ticket.finalized
+
+    def run(self, batches):
+        pending = []
+        for pts in batches:
+            pending.append(self.submit(pts))
+            if len(pending) >= self.max_in_flight:
+                yield self.result(pending.pop(0))
+        while pending:
+            yield self.result(pending.pop(0))
+
+
+def choose_pipeline(args, model, sample_batch, gender="neutral", max_in_flight=3, schedule="eager", log=None, **kw):
+    """-> (pipeline, report) for schedule "eager" (HotPathPipeline, the default) or "graph" (GraphPipeline; `sample_batch` gives its fixed shape).
+    Measured (round 6, one MI355X, host load 11 - 20, bench.py --schedule ...): eager 946 / 986 scans/s, graph replay 707 / 716 -- three graphs replayed on
+    three streams run at the SYNCHRONOUS schedule's rate (44 ms/step): on this runtime the replays of a 430-node graph do not overlap each other the way
+    the eager streams do.  The graph pipeline only wins on a host so busy that the eager enqueue drops below ~700 scans/s (seen: 628 - 657 at load 50)
+    and is therefore opt-in; an automatic choice by a warm-up calibration was tried and dropped (profiles/r06_schedule_ab.txt)."""
+    B, N = int(sample_batch.shape[0]), int(sample_batch.shape[1])
+    report = {"schedule_requested": schedule, "schedule": schedule}
+    if schedule == "graph":
+        gkw = {k: v for k, v in kw.items() if k != "stage1_streams"}
+        return GraphPipeline(args, model, B, N, gender, max_in_flight=max_in_flight, **gkw), report
+    assert schedule == "eager", schedule
+    return HotPathPipeline(args, model, gender, max_in_flight=max_in_flight, **kw), report
