@@ -246,7 +246,11 @@ def test_intra_conv_two_plane_f16_matches_the_fp32_kernel_and_fp64(c, p, b, norm
     if ws:
         (new, (m1, r1)), (f32, (m0, r0)) = new, f32
         assert rel_err(m1.cpu().numpy(), m0.cpu().numpy()) < 2e-6 and rel_err(r1.cpu().numpy(), r0.cpu().numpy()) < 2e-6
-    assert torch.equal(new, ops.intra_so3conv(x, idx32, Wp, bias, c, mm, rr, Wqh=conv._wqh))
+    if normed:
+        assert torch.equal(new, ops.intra_so3conv(x, idx32, Wp, bias, c, mm, rr, Wqh=conv._wqh))
+    else:
+        # round 6: without statistics the rows are the caller's own, of unknown scale -- such calls take the exact three-plane form
+        assert torch.equal(new, b16)
     scale = float(f32.abs().max())
     assert float((new - f32).abs().max()) < 3e-6 * scale
     assert float((new - b16).abs().max()) < 2e-6 * scale

@@ -1,0 +1,184 @@
+"""Round-6 GPU tests: the persistent inter conv (csrc/so3conv_y.hip), operands of any scale through the operator API, the ADVICE r05
+corner cases of the two-plane fp16 kernels, and the graph-replay pipeline."""
+import numpy as np
+import pytest
+import torch
+
+from etch_amd.utils.weights import load_seeded
+from tests.test_gpu_encoder import _inter_conv_fp64
+
+pytestmark = pytest.mark.gpu
+
+
+def _inter_setup(cin, cout, nn, b, p1, p2, seed=3, radius=0.25, sigma=0.03):
+    from etch_amd import ops
+    from etch_amd import vgtk_so3conv as V
+    g = torch.Generator().manual_seed(seed)
+    xyz = (torch.randn(b, 3, p1, generator=g) * 0.2).cuda()
+    new_xyz = xyz[:, :, :p2].contiguous()
+    ball = ops.ball_query(new_xyz, xyz, radius, nn)
+    conv = load_seeded(V.InterSO3Conv(cin, cout, 1, 1, radius, sigma, nn), 3).cuda()
+    feats = torch.randn(b, p1, 60, cin, generator=g).cuda()
+    return g, xyz, new_xyz, ball, conv, feats
+
+
+@pytest.mark.parametrize("cin,cout,nn,p1,p2", [(32, 32, 32, 301, 149), (32, 64, 64, 211, 60), (64, 64, 32, 211, 101)])
+@pytest.mark.parametrize("scale", [2.0 ** -10, 2.0 ** -5, 2.0 ** 5, 2.0 ** 12, 1e5, "channels"])
+def test_inter_conv_features_of_any_scale(cin, cout, nn, p1, p2, scale):
+    """VERDICT r05 item 4.  The operator API (vgtk so3conv/modules.py:92-128) has no domain restriction: features at 2^-10 .. 1e5 of unit scale, and with
+    per-channel scales spanning four decades, through ops.inter_so3conv WITHOUT producer planes (they are then made per call, every scan times its own
+    power of two, undone in the epilogue: etch_split2_planes_f16_scaled / `fsc`).  No inf / nan; as close to the fp64 formula as the fp32-MFMA kernel
+    (exact for any scale) -- entitled-error rule: error <= 2 x the fp32 kernel's + 1e-7 of the output scale."""
+    from etch_amd import ops
+    g, xyz, new_xyz, ball, conv, feats = _inter_setup(cin, cout, nn, 2, p1, p2)
+    if scale == "channels":
+        feats = feats * (10.0 ** (torch.rand(cin, generator=g) * 4 - 2)).cuda()
+    else:
+        feats = feats * scale
+    feats = feats.contiguous()
+    rk, W, Wp, bias = conv._derived()
+    bias = bias * 0                           # (a bias of unit size would hide the small-scale cases)
+    new = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, order=ops.spatial_order(new_xyz), Wqh=conv._wqh(), kq=conv._kq())
+    f32 = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma)
+    assert bool(torch.isfinite(new).all())
+    ref = _inter_conv_fp64(xyz, new_xyz, ball, feats, rk, W, bias, conv.sigma)
+    s = float(ref.abs().max())
+    e_new, e_f32 = float((new.double() - ref).abs().max()), float((f32.double() - ref).abs().max())
+    assert e_f32 < 3e-6 * s and e_new <= 2.0 * e_f32 + 1e-7 * s, (e_new / s, e_f32 / s)
+
+
+def test_inter_conv_scan_scaling_is_per_scan_and_the_model_planes_are_untouched():
+    """The power of two of a scan comes from that scan alone: scan 0's result is bit for bit the same next to a neighbour 1e5 times larger and alone;
+    planes that arrive WITH the features (the producer's, unit scale by construction) are gathered as they are."""
+    from etch_amd import ops
+    g, xyz, new_xyz, ball, conv, feats = _inter_setup(32, 64, 64, 3, 211, 60)
+    feats[1] *= 1e5
+    feats[2] *= 2.0 ** -9
+    rk, W, Wp, bias = conv._derived()
+    kw = dict(Wqh=conv._wqh(), kq=conv._kq())
+    full = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, **kw)
+    for i in range(3):
+        solo = ops.inter_so3conv(xyz[i:i + 1].contiguous(), new_xyz[i:i + 1].contiguous(), ball[i:i + 1].contiguous(), feats[i:i + 1].contiguous(), rk, W, Wp, bias,
+                                 conv.sigma, **kw)
+        assert torch.equal(solo[0], full[i]), i
+    planes, fsc = ops.split2_planes_f16_scaled(feats)
+    k = torch.log2(fsc).cpu()
+    assert torch.equal(k, k.round()) and float(k[1] - k[0]) >= 16 and float(k[2] - k[0]) == -9      # fsc = 2^-k: powers of two, per scan
+    m = (feats * (1.0 / fsc).view(3, 1, 1, 1)).abs().amax((1, 2, 3)).cpu()
+    assert bool(((m >= 8) & (m < 16)).all()), m
+    assert torch.equal(planes[0, :, :, 0], (feats[0] / fsc[0]).half())
+
+
+@pytest.mark.parametrize("cin,cout,nn,b,p2", [(32, 32, 32, 3, 5), (32, 64, 64, 1, 1), (64, 64, 32, 5, 700), (32, 32, 32, 16, 1250)])
+def test_persistent_inter_conv_item_lists(cin, cout, nn, b, p2):
+    """Round 6: persistent workgroups walk per-XCD item lists (two static items, then a work counter).  Fewer items than workgroups, one item, odd scan
+    counts, many items per workgroup: every output row is written (the whole tensor equals the fp32-MFMA kernel's to 2e-6), ordered == plain order bit for
+    bit, repeated launches bit for bit (whatever the dynamic distribution),."""
+    from etch_amd import ops
+    p1 = max(p2, 130)
+    g, xyz, new_xyz, ball, conv, feats = _inter_setup(cin, cout, nn, b, p1, p2, radius=0.25 if p1 < 1000 else 0.113137, sigma=0.03 if p1 < 1000 else 0.0064)
+    rk, W, Wp, bias = conv._derived()
+    planes = ops.split2_planes_f16(feats)
+    kw = dict(Wqh=conv._wqh(), kq=conv._kq(), feats_planes=planes)
+    order = ops.spatial_order(new_xyz)
+    f32 = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma)
+    first = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, order=order, **kw)
+    assert bool(torch.isfinite(first).all())
+    assert float((first - f32).abs().max()) < 2e-6 * float(f32.abs().max())
+    for rep in range(6):
+        again, (m1, r1) = ops.inter_so3conv(xyz, new_xyz, ball, feats, rk, W, Wp, bias, conv.sigma, order=order if rep % 2 else None, want_stats=True, **kw)
+        assert torch.equal(again, first), rep
+    m0, r0 = ops.instnorm_stats(first)
+    assert float((m1 - m0).abs().max()) < 1e-5 * float(m0.abs().max() + 1) and float((r1 / r0 - 1).abs().max()) < 1e-5
+
+
+def test_attention_layer_per_matrix_weight_scaling_bound_at_s12():
+    """the attention layers' weights are range-scaled per MATRIX; an output channel whose weight row lies 2^-s below the matrix maximum keeps a
+    relative error of 2^(s - 29) (the planes' absolute floor 2^-25 against a row at 2^(4 - s)).  Pinned at s = 12: rows of the value
+    projection at 2^-12 of the others -- their output channels must stay within 4 x 2^-17 of their own scale (+ the fp32 level), all other channels at the
+    usual bar."""
+    from etch_amd import ops
+    from tests.test_gpu_heads import _mhsa_reference
+    g = torch.Generator().manual_seed(12)
+    T, s = 200, 12
+    x = torch.randn(T, 60, 64, generator=g)
+    wq, wk, wv, wc = (torch.randn(64, 64, generator=g) * 0.25 for _ in range(4))
+    small = torch.tensor([3, 17, 40, 63])
+    wv[small] *= 2.0 ** -s
+    ref = _mhsa_reference(x, wq, wk, wv, wc, torch.zeros(64), 2).reshape(T * 60, 64)
+    out = ops.mhsa_layer(x.cuda().view(T * 60, 64), wq.cuda(), wk.cuda(), wv.cuda(), mode=2).double().cpu()
+    ch = ref.abs().amax(0)
+    err = (out - ref).abs().amax(0) / ch
+    big = torch.ones(64, dtype=torch.bool)
+    big[small] = False
+    assert float(err[big].max()) < 3e-6, float(err[big].max())
+    assert float(err[small].max()) < 4 * 2.0 ** (s - 29) + 3e-6, (float(err[small].max()), 2.0 ** (s - 29))
+
+
+def test_rows_and_tiles_at_the_bottom_of_the_float_range():
+    """ADVICE r05.  (1) weight rows whose maximum is 1e-38 / subnormal / zero: the host's row powers are capped like the device's (ops._pow2_exp), the
+    planes stay finite, and the conv's output for such a row is what the fp32 kernel gives (~0).  (2) a token tile at 1e-25: the scores' factor would
+    underflow; it is held normal, the padded keys stay at probability 0 and the layer returns the uniform softmax the reference formula gives."""
+    from etch_amd import ops
+    from etch_amd import vgtk_so3conv as V
+    from tests.test_gpu_heads import _mhsa_reference
+    g = torch.Generator().manual_seed(4)
+    conv = load_seeded(V.IntraSO3Conv(64, 64), 5).cuda()
+    with torch.no_grad():
+        conv.basic_conv.W[5] *= 1e-38 / float(conv.basic_conv.W[5].abs().max())
+        conv.basic_conv.W[9] *= 1e-44 / float(conv.basic_conv.W[9].abs().max())
+        conv.basic_conv.W[11] = 0.0
+    Wp, bias, idx32, Wp32 = conv._derived()
+    assert bool(torch.isfinite(conv._wqh.wsc).all()) and bool(torch.isfinite(conv._wqh.view(torch.float16).float()).all())
+    x = torch.randn(2, 64, 60, 64, generator=g).cuda()
+    mm, rr = ops.instnorm_stats(x)
+    new = ops.intra_so3conv(x, idx32, Wp, bias * 0, 64, mm, rr, Wqh=conv._wqh)
+    f32 = ops.intra_so3conv(x, idx32, Wp, bias * 0, 64, mm, rr)
+    assert bool(torch.isfinite(new).all())
+    assert float((new - f32).abs().max()) < 2e-6 * float(f32.abs().max())
+    assert float(new[..., [5, 9, 11]].abs().max()) < 1e-30
+    # (2)
+    T = 40
+    x = torch.randn(T, 60, 64, generator=g)
+    x[::2] *= 1e-25
+    ws = [torch.randn(64, 64, generator=g) * 0.2 for _ in range(4)]
+    ref = _mhsa_reference(x, ws[0], ws[1], ws[2], ws[3], torch.zeros(64), 2).reshape(T, 60 * 64)
+    out = ops.mhsa_layer(x.cuda().view(T * 60, 64), ws[0].cuda(), ws[1].cuda(), ws[2].cuda(), mode=2).double().cpu().reshape(T, 60 * 64)
+    assert bool(torch.isfinite(out).all())
+    e = (out - ref).abs().amax(1) / ref.abs().amax(1)
+    assert float(e.max()) < 3e-6, float(e.max())
+
+
+def test_intra_conv_without_statistics_takes_an_exact_form():
+    """without (mean, rstd) the intra conv's rows are the caller's own, of unknown scale -- those calls do not take the two-plane fp16 form
+    (values above 65 504 would become inf): rows at 1e6 and at 1e-6 come out finite and within the fp32 bar of the fp64 formula."""
+    from etch_amd import ops
+    from etch_amd import vgtk_so3conv as V
+    g = torch.Generator().manual_seed(8)
+    conv = load_seeded(V.IntraSO3Conv(32, 32), 5).cuda()
+    Wp, bias, idx32, Wp32 = conv._derived()
+    for scale in (1e6, 1e-6):
+        x = (torch.randn(2, 50, 60, 32, generator=g) * scale).cuda()
+        out = ops.intra_so3conv(x, idx32, Wp, bias * 0, 32, Wp32=Wp32, Wq=conv._wq, Wqh=conv._wqh)
+        ref = torch.einsum("bpatc,oct->bpao", x.double()[:, :, conv.intra_idx.cuda()], conv.basic_conv.W.detach().double().view(32, 32, 12))
+        assert bool(torch.isfinite(out).all())
+        assert float((out.double() - ref).abs().max()) < 3e-6 * float(ref.abs().max()), scale
+
+
+def test_graph_replay_pipeline_matches_the_synchronous_path(tmp_path):
+    """etch_amd.pipeline.GraphPipeline (opt-in schedule: one HIP-graph replay per batch slot, two slots here): the same bits as one batch at a time."""
+    from etch_amd.inference_demo import predict_smpl_batch
+    from etch_amd.pipeline import GraphPipeline
+    from tests.test_gpu_pipeline import make, scan
+    args, model = make(tmp_path)
+    B, N, nb = 2, 640, 4
+    mk = lambda k: torch.from_numpy(np.stack([scan(300 + 10 * k + b, N) for b in range(B)])).cuda()
+    ref = [predict_smpl_batch(args, model, mk(k), "neutral") for k in range(nb)]
+    pipe = GraphPipeline(args, model, B, N, "neutral", max_in_flight=2)
+    got = list(pipe.run(mk(k) for k in range(nb)))
+    same = lambda a, b: np.array_equal(np.asarray(a.cpu() if torch.is_tensor(a) else a), np.asarray(b.cpu() if torch.is_tensor(b) else b), equal_nan=True)
+    for (m0, mk0, v0, i0), (m1, mk1, v1, i1) in zip(ref, got):
+        assert same(mk0, mk1) and same(v0, v1)
+        for a, b in zip(i0, i1):
+            assert same(a, b)
+        assert same(m0[0].vertices, m1[0].vertices)

@@ -316,3 +316,35 @@ def test_split_weight_layouts_address_the_right_elements():
         for _ in range(50):
             gi, t, strip, pl, lane, e = (int(rng.integers(n)) for n in q.shape)
             assert q[gi, t, strip, pl, lane, e] == P[pl, gi * 128 + 16 * strip + lane % 16, 32 * t + 8 * (lane // 16) + e]
+
+
+def test_row_powers_of_two_are_capped_like_the_device_side():
+    """ops._row_pow2 / _pow2_exp mirror the device's etch_scale_exp (csrc/split_bf16.h) -- rows whose maximum is zero, subnormal or
+    non-finite keep the factor 1, the exponent is capped at 120 (dirtail: 60, its power is folded into a bias), every scaled row and every
+    inverse power is finite and the scaling is exact."""
+    import torch
+
+    from etch_amd import ops
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(8, 64, generator=g)
+    w[0] *= 1e-38
+    w[1] = 1e-45
+    w[2] *= 1e30
+    w[3] = 0
+    w[4] *= 3e-37
+    w[5, 0] = float("inf")
+    ws, wsc = ops._row_pow2(w)
+    assert bool(torch.isfinite(wsc).all()) and bool(torch.isfinite(ws[[0, 1, 2, 3, 4, 6, 7]]).all())
+    assert torch.equal(wsc[[1, 3, 5]], torch.ones(3))                                   # subnormal / zero / non-finite rows: factor 1
+    assert bool((torch.log2(wsc) >= -120).all()) and bool((torch.log2(wsc) == torch.log2(wsc).round()).all())
+    m = ws[[2, 6, 7]].abs().amax(1)
+    assert bool(((m >= 8) & (m < 16)).all())
+    keep = [0, 1, 2, 3, 4, 6, 7]
+    assert torch.equal((ws * wsc[:, None])[keep], w[keep])                               # exact
+    _, wsc60 = ops._row_pow2(w, cap=60)
+    assert bool((torch.log2(wsc60) >= -60).all())
+    Wf = torch.randn(128, 64, generator=g)
+    Wf[7] *= 1e-37
+    q = ops.dirtail_weight_split(Wf)
+    tab = ops.dirtail_constants(torch.randn(128, generator=g) * 100, torch.randn(128, generator=g), torch.tensor(0.5), q.wsc)
+    assert bool(torch.isfinite(tab).all())
