@@ -11,6 +11,16 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
+    # The CPU oracle (the checker of the parity tests) runs through torch's CPU kernels.  On the GPU box's 128-core host torch defaults to 128 intra-op
+    # threads, and the oracle's many small / gather-scatter kernels then run SLOWER than on 8 cores: autograd through the oracle took 38 s per backward
+    # pass there against 3 s here (cProfile of test_eval_mode_gradients_of_all_four_losses_strict[3], round 6; profiles/r02_cpu_baseline_threads.txt shows
+    # the same for the forward: 128 threads 0.035 scans/s, 32 threads 0.116).  32 threads is what bench.py's cpu_baseline uses for the same reason.
+    try:
+        import torch
+
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

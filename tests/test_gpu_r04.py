@@ -66,7 +66,7 @@ def test_inter_conv_planes_matches_the_fp32_kernel_and_fp64(cin, cout, nn, p1, p
 
 
 def test_encoder_with_plane_producers_equals_encoder_without(monkeypatch):
-    """The encoder with its blocks emitting planes for the next conv == the encoder that splits inside ops.inter_so3conv (bitwise), and both
+    """The encoder with its blocks emitting planes for the next conv == the encoder that splits inside ops.inter_so3conv (to the planes' last bit), and both
     within the split kernels' bound of the round-3 path (ETCH_INTER_X=0: step 1 on the fp32 MFMA)."""
     import types
 
@@ -85,7 +85,9 @@ def test_encoder_with_plane_producers_equals_encoder_without(monkeypatch):
             for c in blk.blocks:
                 c.emit_planes = False
         bb = model.encoder(pts)[0].feats_cl
-        assert torch.equal(a, bb)
+        # (bitwise until round 5; since round 6 planes made inside ops.inter_so3conv carry every scan's own power of two -- the same sums from operands
+        # shifted by a power of two: equal up to the planes' last bit, through four convs)
+        assert float((a - bb).abs().max()) < 2e-6 * float(a.abs().max())
         monkeypatch.setattr(ops, "INTER_X", False)
         c3 = model.encoder(pts)[0].feats_cl
     assert float((a - c3).abs().max()) < 2e-5 * float(c3.abs().max())

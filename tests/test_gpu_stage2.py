@@ -83,7 +83,7 @@ def test_lbs_vs_oracle(model):
 def test_lm_fit_vs_oracle():
     from etch_amd.models.fit_SMPL import fit_smpl
     from oracle import stage2 as S2
-    B = 2          # (the live oracle differentiates the full mesh on the CPU: ~19 s per scan; four more scans are held to the COMMITTED oracle run below)
+    B = 3
     bm, ms, mv, tgt, valid, vgt = _problem(B)
     trace = []
     ref = S2.fit_smpl(bm, mv, tgt, valid, trace=trace)

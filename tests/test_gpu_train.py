@@ -382,10 +382,7 @@ def test_eval_mode_gradients_of_all_four_losses_strict(tmp_path, depth):
     Round 5: at EVERY encoder depth the reference trains (train.py:61-101 trains whatever EPN_layer_num builds,
     models_pointcloud.py:34-48: 32 / 64 / 128 / 256-dim tokens, conv channel pairs up to (256, 256)); depths 1 / 3 / 4 run the un-fused attention chain +
     etch_mhsa_attention_backward_dim (head widths 4 / 16 / 32) and the inter conv's data gradient in 64-channel windows."""
-    # two scans at the depths the path is built around (the released depth 2, and 1); one scan at depths 3 / 4, whose oracle runs (fp64 autograd through
-    # the materialised 128- / 256-channel kernel-weight tensors on the CPU) were 285 s of the GPU suite -- the per-scan segmentation of the training kernels
-    # is depth-independent and stays covered by the two-scan runs (VERDICT r05 item 3: the suite has a 1 200 s limit)
-    B, N = (2 if depth <= 2 else 1), 512
+    B, N = 2, 512
     model, pts, vec, conf, labels = _setup(tmp_path, B, N, depth)
     model.eval()
     model.differentiable = True
