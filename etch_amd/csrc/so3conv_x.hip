@@ -25,6 +25,13 @@
 
 #include "so3conv_x.h"
 
+// Round 6: the round-4 kernels below -- LDS-direct gathers, inline-asm LDS reads and loads with hand-counted waits -- are compiled only
+// with ETCH_BUILD_EXPERIMENTS.  One of their instantiations (the 32x32x16 form at 32 input channels) mis-executed in a build-dependent way and the cause
+// was never named (profiles/r04_x32_cin32_miscompile.txt, profiles/r05_x32_cin32_root_cause.txt: the asm-load hypothesis was tested and refuted), so the
+// default library carries none of their siblings: the default inter conv is inter_so3conv_y_kernel (so3conv_y.hip), its parity partner and the
+// ETCH_INTER_KQ=0 path the fp32-MFMA / three-plane kernels of so3conv.hip.  What stays in every build: etch_split3_planes (the exact bf16 split, used by
+// the three-plane kernels' callers and tests) and the shape predicate.
+#ifdef ETCH_BUILD_EXPERIMENTS
 // step 2, Y[o, col] += sum_kappa W[o, kappa] X1[col][kappa], for the two channel halves of the X1 tile: chunk of 32 kappas -> wave (chunk & 3); six bf16
 // MFMAs per (chunk, o tile), smallest cross products first, term-major so that consecutive MFMAs are independent (so3conv.hip, BX step 2).  The W
 // fragments (L2) travel one batch (two o tiles x three planes) ahead of the matrix cores through inline-asm loads + counted waits, across chunks AND
@@ -726,19 +733,6 @@ static int launch_x32(int b, int p1, int p2, float sigma, const float* xyz, cons
     return ETCH_OK;
 }
 
-// x [rows][C] fp32 -> planes [rows][3][C] bf16 (exact split); thread = 4 consecutive channels
-__global__ void __launch_bounds__(256) split3_planes_kernel(long n4, int C, const float* __restrict__ x, unsigned short* __restrict__ planes) {
-    const int c4 = C >> 2;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        const long row = i / c4;
-        const int c = (int)(i - row * c4) * 4;
-        uint2 hi, mid, lo;
-        split3_pack4(reinterpret_cast<const float4*>(x)[i], hi, mid, lo);
-        unsigned short* pr = planes + (size_t)row * 3 * C + c;
-        *reinterpret_cast<uint2*>(pr) = hi; *reinterpret_cast<uint2*>(pr + C) = mid; *reinterpret_cast<uint2*>(pr + 2 * C) = lo;
-    }
-}
-
 template <int CIN, int COUT, int NCH>
 static int launch_x(int b, int p1, int p2, float sigma, const float* xyz, const float* new_xyz, const int* idx, const void* Fq, const float* rk,
                     const void* Wq, const float* bias, float* out, const int* order, double* stat_part, hipStream_t st) {
@@ -756,6 +750,21 @@ static int launch_x(int b, int p1, int p2, float sigma, const float* xyz, const 
                        reinterpret_cast<const bf16x8*>(Wq), bias, out, order, stat_part);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
+}
+
+#endif  // ETCH_BUILD_EXPERIMENTS
+
+// x [rows][C] fp32 -> planes [rows][3][C] bf16 (exact split); thread = 4 consecutive channels
+__global__ void __launch_bounds__(256) split3_planes_kernel(long n4, int C, const float* __restrict__ x, unsigned short* __restrict__ planes) {
+    const int c4 = C >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / c4;
+        const int c = (int)(i - row * c4) * 4;
+        uint2 hi, mid, lo;
+        split3_pack4(reinterpret_cast<const float4*>(x)[i], hi, mid, lo);
+        unsigned short* pr = planes + (size_t)row * 3 * C + c;
+        *reinterpret_cast<uint2*>(pr) = hi; *reinterpret_cast<uint2*>(pr + C) = mid; *reinterpret_cast<uint2*>(pr + 2 * C) = lo;
+    }
 }
 
 extern "C" {
@@ -776,6 +785,7 @@ int etch_inter_so3conv_planes_supported(int cin, int cout, int nn) {
     return ((cin == 32 && (cout == 32 || cout == 64)) || (cin == 64 && cout == 64)) && (nn == 32 || nn == 64);
 }
 
+#ifdef ETCH_BUILD_EXPERIMENTS
 int etch_inter_so3conv_planes(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
                               const int* ball_idx, const void* feats_planes, const float* rk, const void* Wq, const float* bias, float* out,
                               const int* order, double* stat_part, void* stream) {
@@ -811,5 +821,7 @@ int etch_inter_so3conv_planes32(int b, int cin, int cout, int p1, int p2, int nn
 #undef X_CASE
     return ETCH_EUNSUPPORTED;
 }
+
+#endif  // ETCH_BUILD_EXPERIMENTS
 
 }  // extern "C"

@@ -351,7 +351,8 @@ INTER_X = os.environ.get("ETCH_INTER_X", "1") != "0"             # both contract
 INTER_X32 = os.environ.get("ETCH_INTER_X", "1") != "16"          # 64 input channels: the 32x32x16 MFMA form (ETCH_INTER_X=16: the 16x16x32 form everywhere)
 
 
-INTER_KQ = os.environ.get("ETCH_INTER_KQ", "1") != "0"          # kernel weights formed on the matrix cores (csrc/so3conv_y.hip); 0: the round-4 kernels
+INTER_KQ = os.environ.get("ETCH_INTER_KQ", "1") != "0"          # kernel weights formed on the matrix cores (csrc/so3conv_y.hip); 0: the round-3 kernels (fp32 MFMA step 1,
+                                                                 # exact three-plane step 2) -- or, in an ETCH_BUILD_EXPERIMENTS library, the retired round-4 planes kernels
 
 
 def inter_planes_form(cin):
@@ -470,7 +471,7 @@ def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, orde
         _lib.check(_lib.lib().etch_inter_so3conv_planes_kq(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
                                                           _ptr(feats_planes), _ptr(kq), _ptr(Wqh), _ptr(Wqh.wsc), _optptr(fsc), _ptr(bias), _ptr(out), _optptr(order),
                                                           _optptr(part), _stream()), "etch_inter_so3conv_planes_kq")
-    elif Wq32 is not None and cin == 64 and inter_planes_form(cin) == 32 and inter_planes_supported(cin, cout, nn):
+    elif Wq32 is not None and cin == 64 and inter_planes_form(cin) == 32 and inter_planes_supported(cin, cout, nn) and _lib.has_experiments():
         _need(Wq32, torch.int16, "Wq32")
         if feats_planes is None or feats_planes.dtype != torch.int16:
             feats_planes = split3_planes(feats_cl)
@@ -479,7 +480,7 @@ def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, orde
         _lib.check(_lib.lib().etch_inter_so3conv_planes32(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
                                                          _ptr(feats_planes), _ptr(rk), _ptr(Wq32), _ptr(bias), _ptr(out), _optptr(order),
                                                          _optptr(part), _stream()), "etch_inter_so3conv_planes32")
-    elif Wqn is not None and inter_planes_supported(cin, cout, nn):
+    elif Wqn is not None and inter_planes_supported(cin, cout, nn) and _lib.has_experiments():
         _need(Wqn, torch.int16, "Wqn")
         if feats_planes is None or feats_planes.dtype != torch.int16:
             feats_planes = split3_planes(feats_cl)

@@ -193,7 +193,10 @@ class InterSO3Conv(nn.Module):
         "f16" (two fp16 planes, etch_inter_so3conv_planes_kq) / "bf16" (three bf16 planes, the round-4 kernels)."""
         if not (ops.inter_planes_supported(self.dim_in, self.dim_out, self.n_neighbor) and self.kernel_size == 24):
             return False
-        return "f16" if ops.INTER_KQ else "bf16"
+        if ops.INTER_KQ:
+            return "f16"
+        from . import _lib
+        return "bf16" if _lib.has_experiments() else False        # the round-4 planes kernels exist only in an ETCH_BUILD_EXPERIMENTS library (round 6)
 
     def group(self, xyz):
         """functional.py:176-185 inter_spconv_grouping_ball (index part): -> ball_idx, sample_idx, new_xyz.

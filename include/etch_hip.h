@@ -155,6 +155,10 @@ int etch_inter_so3conv_split(int b, int cin, int cout, int p1, int p2, int nn, f
                              const int* ball_idx, const float* feats, const float* rk, const void* Wq, const float* bias, float* out,
                              const int* order, double* stat_part, void* stream);
 
+/* 1 if (cin, cout, nn) is a shape the planes kernels (etch_inter_so3conv_planes_kq; with ETCH_BUILD_EXPERIMENTS also the round-4 forms) are built for. */
+int etch_inter_so3conv_planes_supported(int cin, int cout, int nn);
+
+#ifdef ETCH_BUILD_EXPERIMENTS      /* round-4 kernels, retired from the default build in round 6 (a sibling instantiation mis-executed for a cause that was never named: profiles/r05_x32_cin32_root_cause.txt) */
 /* The same convolution with BOTH contractions on the bf16 matrix cores (round 4, etch_amd/csrc/so3conv_x.hip): the neighbour contraction
  * X1[k, c] = sum_n w[a, k, n] F[idx_n, a, c] (functional.py:61-67 with the weights of :286-324 generated in registers) runs as split-operand
  * products too.  The gathered rows come as three bf16 planes written once by their producer: feats_planes (b, p1, 60, 3, cin) bf16 =
@@ -166,13 +170,13 @@ int etch_inter_so3conv_split(int b, int cin, int cout, int p1, int p2, int nn, f
 int etch_inter_so3conv_planes(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
                               const int* ball_idx, const void* feats_planes, const float* rk, const void* Wq, const float* bias, float* out,
                               const int* order, double* stat_part, void* stream);
-int etch_inter_so3conv_planes_supported(int cin, int cout, int nn);
 /* The same on v_mfma_f32_32x32x16_bf16, the bf16 shape that issues at the matrix peak on this chip (profiles/r04_mfma_bf16_issue_rates.txt; the 16x16x32
  * shape of the entry above reaches 0.55 - 0.6 of it).  Wq32: 3 * cout * cin * 24 bf16 = [K step of 16][o tile of 32][plane][lane][8] in the kernel's
  * physical contraction order (etch_amd/ops.py inter_weight_split32).  Same shapes, same result up to the order of the fp32 sums. */
 int etch_inter_so3conv_planes32(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
                                 const int* ball_idx, const void* feats_planes, const float* rk, const void* Wq32, const float* bias, float* out,
                                 const int* order, double* stat_part, void* stream);
+#endif
 
 /* Round 5 (etch_amd/csrc/so3conv_y.hip): the inter conv of functional.py:286-324, :61-67 + modules.py:33-39 rebuilt around three measurements of
  * this round (profiles/r05_inter_conv_latency_bound.txt, r05_f16_two_plane_split.txt):
