@@ -515,6 +515,11 @@ def main():
                     "global batch, the CPU set it would pin itself to, the rendezvous and the RCCL-relevant environment -- so that a failed scaling run "
                     "can be diagnosed from its log")
     a = ap.parse_args()
+    # The GPU phases need ONE host thread; torch's CPU pool (128 threads on the pool's hosts) spinning beside it exhausts the container's CPU quota and freezes
+    # the enqueueing thread for up to 100 ms at a time (etch_amd/pipeline.py limit_host_threads; profiles/r06_host_throttling.txt).  The cpu_baseline leg sets
+    # its own thread count when it runs, after the timed region.
+    from etch_amd.pipeline import limit_host_threads
+    limit_host_threads()
     # batches in flight: with 2 the host submits batch i+1 only after batch i-1 has finished stage 2 -- whose start waits for that batch's Point-Transformer
     # nets, which trail into the next batch's encoder -- so that every other step's index ops were enqueued late and its first conv idled 3.5 ms on them
     # (profiles/r04_stream_timeline.txt); with 3 the step boundary is a steady 0.3 ms
@@ -651,6 +656,14 @@ def main():
         print("timed region: allocator segments allocated %d, gc collections per generation %s" % (
             torch.cuda.memory_stats().get("segment.all.allocated", 0) - seg0, [g["collections"] - c for g, c in zip(gc.get_stats(), gc0)]), file=sys.stderr)
     gc.enable()
+    if a.pipeline and not dry and getattr(pipe, "host_times", None) and hasattr(pipe, "gap_report"):
+        gr = pipe.gap_report(last=a.steps)
+        if gr:
+            f = lambda v: " ".join("%.2f" % x for x in v)
+            print("stage-1 stream timeline of the timed steps (HIP events, no tracer; ms):\n  stage-1 span per batch  %s\n  idle gap to the next batch's stage 1  %s\n"
+                  "  batch done behind its stage 1  %s\n  period (stage-1 end to stage-1 end)  %s\n  medians: span %.2f  gap %.2f  period %.2f" %
+                  (f(gr["stage1_span_ms"]), f(gr["stage1_gap_ms"]), f(gr["stage2_lag_ms"]), f(gr["period_ms"]), float(np.median(gr["stage1_span_ms"])),
+                   float(np.median(gr["stage1_gap_ms"])), float(np.median(gr["period_ms"]))), file=sys.stderr)
     if a.pipeline and not dry and getattr(pipe, "host_times", None):
         ht = np.array(pipe.host_times[-a.steps:])
         print("host ms per submit (wait for the oldest ticket / finalize it / enqueue the batch): median %s, max %s; enqueue ms per step: %s"

@@ -9,6 +9,22 @@ from . import ops
 from .models.fit_SMPL import fit_smpl_device, fit_smpl_finalize, fit_smpl_stage_host
 
 
+def limit_host_threads(n=None):
+    """Cap torch's CPU intra-op thread pool for a process whose job is to feed the GPU.  Measured in round 6 (scratch/cgroup_probe.sh, thread_probe.sh on the
+    pool's GPU boxes): the pipeline's host side is ONE enqueueing thread, but any small CPU tensor op wakes torch's OpenMP pool -- 128 threads on these
+    hosts -- and the workers then spin; together they burned 12 - 16 CPUs, the container's CFS quota ran out in most 100 ms periods (cpu.stat: 58 of 81
+    periods throttled) and the enqueueing thread was frozen with them for the rest of the period: the 80 - 100 ms "slow enqueue" stalls that rounds 4 - 5
+    attributed to other tenants' load (640 - 860 instead of 900+ scans/s).  n: threads to keep (default: ETCH_HOST_THREADS or 4; 0 = leave the
+    pool alone).  Returns the previous setting."""
+    import os
+    prev = torch.get_num_threads()
+    if n is None:
+        n = int(os.environ.get("ETCH_HOST_THREADS", "4"))
+    if n > 0 and prev > n:
+        torch.set_num_threads(n)
+    return prev
+
+
 class Ticket:
     keepalive = None
 
@@ -20,6 +36,7 @@ class Ticket:
 class HotPathPipeline:
     def __init__(self, args, model, gender="neutral", max_in_flight=3, stage1_streams=1, **fit_kwargs):
         self.args, self.model, self.gender, self.fit_kwargs = args, model, gender, fit_kwargs
+        limit_host_threads()              # (see there: a spinning 128-thread CPU pool starves the one thread that feeds the GPU)
         # stage 1 of consecutive batches alternates over `stage1_streams` streams: with 2, the low-occupancy kernels of one
         # batch (deep Point-Transformer levels: a few dozen workgroups) fill behind the chip-wide kernels of the other
         from .utils.cu_streams import make_stream
@@ -34,6 +51,7 @@ class HotPathPipeline:
         self._pinned = [None] * (max_in_flight + 1)     # ring of pinned host buffers, one set per batch in flight (+1 being read)
         self._n = 0
         self.host_times = [] if os.environ.get("ETCH_PIPE_TIMING") == "1" else None
+        self._timeline = []              # ETCH_PIPE_TIMING=1: (stage-1 begin, stage-1 end, batch done) events per batch + the host time of the submit's end
         self.reserved_gib = 0.0          # what _reserve_allocator put into the streams' allocator pools (reported next to peak_hbm_gib)
 
     def __del__(self):
@@ -100,8 +118,13 @@ class HotPathPipeline:
         # record_stream()-ed: no allocator events (which every later torch.empty of the enqueue thread would poll, models_pointcloud._cross_stream),
         # and the caller may still drop `points` right after submit().  The pipeline owns the ticket (self.in_flight) until it is retired.
         keep = [points]
+        timing = self.host_times is not None
+        ev_begin = None
         with torch.no_grad():
             with torch.cuda.stream(s1):
+                if timing:       # ETCH_PIPE_TIMING=1: the stage-1 stream's own timeline (gap_report): where the batch's first / last stage-1 kernel sit
+                    ev_begin = torch.cuda.Event(enable_timing=True)
+                    ev_begin.record(s1)
                 # the model's index stream waits for the producer of `points` (the caller's stream), not for s1's queue
                 self.model.input_producer = caller
                 self.model.defer_join = True          # the heads on side streams are joined on s2 below, not on s1
@@ -112,7 +135,7 @@ class HotPathPipeline:
                     self.model.input_producer, self.model.defer_join, self.model.keepalive = None, False, None
                 joins = self.model.pending_join or []
                 self.model.pending_join = None
-                ready = torch.cuda.Event()
+                ready = torch.cuda.Event(enable_timing=timing)
                 ready.record(s1)
             conf = results["confidences"]
             keep += [conf, results["part_labels"], results["direction"], results["magnitude"]]
@@ -128,10 +151,12 @@ class HotPathPipeline:
                 fit_smpl_stage_host(fit, self._pinned[self._n % len(self._pinned)])
                 self._pinned[self._n % len(self._pinned)] = fit["host"]
                 self._n += 1
-                done = torch.cuda.Event()
+                done = torch.cuda.Event(enable_timing=timing)
                 done.record(self.s2)
         t = Ticket(done, results, fit)
         t.keepalive = keep
+        if timing:
+            self._timeline.append((ev_begin, ready, done, time.perf_counter()))
         self.in_flight.append(t)
         if self.host_times is not None:      # (wait for the oldest ticket, finalize it, enqueue this batch) in ms: diagnostics
             self.host_times.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (time.perf_counter() - t2) * 1e3))
@@ -143,6 +168,19 @@ class HotPathPipeline:
                 print("slow enqueue %.0f ms (batch %d): allocator deltas %s" % (self.host_times[-1][2], self._n, {k: cur[k] - prev[k] for k in cur}), file=sys.stderr)
             self._ms_prev = cur
         return t
+
+    def gap_report(self, last=None):
+        """ETCH_PIPE_TIMING=1, after a synchronize: the stage-1 stream's timeline from HIP events (no tracer attached) -- per batch the span of its stage 1
+        (first to last kernel on the stage-1 stream), the idle gap between the end of batch i's stage 1 and the start of batch i+1's on that stream, and
+        the lag of batch i's completion (stage 2 on its own stream) behind its stage 1.  -> dict of lists (ms)."""
+        tl = self._timeline[-last:] if last else self._timeline
+        if len(tl) < 2 or len(self.s1s) != 1:
+            return None
+        span = [a.elapsed_time(b) for a, b, _, _ in tl]
+        gap = [tl[i][1].elapsed_time(tl[i + 1][0]) for i in range(len(tl) - 1)]
+        lag = [b.elapsed_time(c) for _, b, c, _ in tl]
+        period = [tl[i][1].elapsed_time(tl[i + 1][1]) for i in range(len(tl) - 1)]
+        return dict(stage1_span_ms=span, stage1_gap_ms=gap, stage2_lag_ms=lag, period_ms=period)
 
     def result(self, ticket):
         """Wait for one batch and return the reference's fit_smpl tuple (meshes, markers, valid, smpl_info)."""
@@ -177,6 +215,7 @@ class GraphPipeline:
 
     def __init__(self, args, model, B, N, gender="neutral", max_in_flight=3, want_trace=False, **fit_kwargs):
         from .graph import GraphedHotPath
+        limit_host_threads()
         self.args, self.B, self.N = args, B, N
         fit_kwargs = dict(fit_kwargs, want_trace=want_trace)
         self.slots = [GraphedHotPath(args, model, B, N, gender, **fit_kwargs) for _ in range(max_in_flight)]
