@@ -70,18 +70,30 @@ __global__ void __launch_bounds__(WAVES * 64) ball_query_kernel(int n, int m, fl
 // -- the same order as the 64-bit keys -- and the key is composed once per round; invalid slots carry distance -2 (< the initial -1) instead of an
 // exec-mask branch per slot.  10 instead of 13 VALU instructions + a branch per slot: 2.29 -> 2.18 us per round at 20 000 points; slower where
 // few of a thread's slots are occupied (5 000 points: 1.11 -> 1.24), so only the large-scan (CARRY) variants use it (profiles/r04_fps_split.txt).
+// One sampling problem (either flavour).  A launch may carry TWO of them over the same point count (round 6, etch_fps_pair): the workgroups
+// [0, nseg0) work on the first, the rest on the second -- the encoder's FPS and the first FPS level of the Point-Transformer nets depend on the same
+// coordinates only, run one workgroup per scan each, and used to queue behind each other on the index stream (34 of the 58 ms of a step of the dense
+// 8-scan shard of configs[4]); a second stream for one of them loses more to hardware-queue sharing than it gains (profiles/r06_config4_fps_pair.txt).
+struct FpsProb {
+    const float* xyz; long cs, ps, batch_stride; int n_fixed, m_fixed; const int* offset; const int* new_offset; int skip_origin; int* idx;
+};
 template <int THREADS, int PPT, bool REGS, bool CARRY, bool FAST = false>   // lds_xyz = capacity (points) of the dynamic-LDS coordinate copy, 0 = none
-__global__ void __launch_bounds__(THREADS) fps_kernel(int lds_xyz, const float* __restrict__ xyz, long cs, long ps,
-                                                      long batch_stride, int n_fixed, int m_fixed,
-                                                      const int* __restrict__ offset, const int* __restrict__ new_offset,
-                                                      int bs, int bs_bits, int skip_origin, int* __restrict__ idx) {
+__global__ void __launch_bounds__(THREADS) fps_kernel(int lds_xyz, FpsProb A0, FpsProb A1, int nseg0, int bs, int bs_bits) {
     // per-wave partial maxima, double-buffered
     struct Cand { unsigned long long key; float x, y, z, pad; };
     __shared__ Cand red[2 * (THREADS / 64)];
     extern __shared__ __attribute__((aligned(16))) float fps_xyz[];     // [3][lds_xyz]: non-REGS variants read the winner from here
     const int CAP = lds_xyz;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int seg = blockIdx.x;
+    const bool second = (int)blockIdx.x >= nseg0;                       // (wave-uniform: the selects below are scalar)
+    const float* __restrict__ xyz = second ? A1.xyz : A0.xyz;
+    const long cs = second ? A1.cs : A0.cs, ps = second ? A1.ps : A0.ps, batch_stride = second ? A1.batch_stride : A0.batch_stride;
+    const int n_fixed = second ? A1.n_fixed : A0.n_fixed, m_fixed = second ? A1.m_fixed : A0.m_fixed;
+    const int* __restrict__ offset = second ? A1.offset : A0.offset;
+    const int* __restrict__ new_offset = second ? A1.new_offset : A0.new_offset;
+    const int skip_origin = second ? A1.skip_origin : A0.skip_origin;
+    int* __restrict__ idx = second ? A1.idx : A0.idx;
+    const int seg = (int)blockIdx.x - (second ? nseg0 : 0);
     int start_n, n, start_m, m;
     const float* src;
     if (offset == nullptr) {                 // vgtk flavour: dense (b,3,n) batches, local indices
@@ -644,20 +656,21 @@ static int opt_n_threads_host(int work_size) {
 
 static int g_fps_fast = 1;     // etch_fps_split_debug's third knob: 0 = the 64-bit-key form everywhere (A/B timing, tests)
 
-static int launch_fps(int nseg, int n_max, const float* xyz, long cs, long ps, long bstride, int n_fixed, int m_fixed,
-                      const int* offset, const int* new_offset, int skip_origin, int* idx, hipStream_t st) {
+// nseg1 > 0: a second problem over the same n_max in the same launch (the workgroups behind the first problem's)
+static int launch_fps2(int nseg0, int nseg1, int n_max, const FpsProb& p0, const FpsProb& p1, hipStream_t st) {
     const int bs = opt_n_threads_host(n_max);
     const int bits = ilog2_floor_host(bs);
     const bool fits_lds = (size_t)3 * n_max * sizeof(float) <= 62 * 1024;
+    const int nseg = nseg0 + nseg1;
 #define FPS_CASE(T, P, R, C, COND)                                                                                     \
     if (n_max <= T * P && (COND)) {                                                                                    \
         const int use_lds = !C && fits_lds ? n_max : 0;                                                                \
         if (R && C && T == 1024 && bs == T && g_fps_fast)     /* large scans only: at <= 8 slots the branchy loop skips the empty ones */ \
             hipLaunchKernelGGL((fps_kernel<T, P, R, C, (R && C && T == 1024)>), dim3(nseg), dim3(T), (size_t)3 * use_lds * sizeof(float), st,   \
-                               use_lds, xyz, cs, ps, bstride, n_fixed, m_fixed, offset, new_offset, bs, bits, skip_origin, idx);   \
+                               use_lds, p0, p1, nseg0, bs, bits);                                                      \
         else                                                                                                           \
             hipLaunchKernelGGL((fps_kernel<T, P, R, C>), dim3(nseg), dim3(T), (size_t)3 * use_lds * sizeof(float), st, \
-                               use_lds, xyz, cs, ps, bstride, n_fixed, m_fixed, offset, new_offset, bs, bits, skip_origin, idx);   \
+                               use_lds, p0, p1, nseg0, bs, bits);                                                      \
         ETCH_RETURN_IF_LAUNCH_FAILED();                                                                                \
         return ETCH_OK;                                                                                                \
     }
@@ -666,6 +679,12 @@ static int launch_fps(int nseg, int n_max, const float* xyz, long cs, long ps, l
     FPS_CASE(1024, 12, true, true, true) FPS_CASE(1024, 20, true, true, true) FPS_CASE(1024, 32, false, false, true)
 #undef FPS_CASE
     return ETCH_EUNSUPPORTED;  // more than 32768 points per segment
+}
+
+static int launch_fps(int nseg, int n_max, const float* xyz, long cs, long ps, long bstride, int n_fixed, int m_fixed,
+                      const int* offset, const int* new_offset, int skip_origin, int* idx, hipStream_t st) {
+    const FpsProb p = {xyz, cs, ps, bstride, n_fixed, m_fixed, offset, new_offset, skip_origin, idx};
+    return launch_fps2(nseg, 0, n_max, p, p, st);
 }
 
 static unsigned g_fps_spin_limit = 1u << 22;
@@ -755,6 +774,18 @@ int etch_furthestsampling(int b, int n_max, const float* xyz, const int* offset,
     if (b <= 0) return ETCH_OK;
     if (n_max <= 0) return ETCH_EINVAL;
     return launch_fps(b, n_max, xyz, 1, 3, 0, 0, 0, offset, new_offset, 0, idx, (hipStream_t)stream);
+}
+
+// Both samplings of one batch of b equally sized scans in ONE launch of 2 b workgroups: etch_furthest_point_sampling(b, n, m, xyz_b3n, idx_a) and
+// etch_furthestsampling(b, n, xyz_packed, offset, new_offset, idx_b) -- same picks as the two separate launches, bit for bit (the kernel is the same; a
+// workgroup reads one problem or the other).
+int etch_fps_pair(int b, int n, int m, const float* xyz_b3n, int* idx_a, const float* xyz_packed, const int* offset, const int* new_offset, int* idx_b,
+                  void* stream) {
+    if (b <= 0) return ETCH_OK;
+    if (n <= 0 || m <= 0 || !xyz_b3n || !xyz_packed || !offset || !new_offset || !idx_a || !idx_b) return ETCH_EINVAL;
+    const FpsProb p0 = {xyz_b3n, (long)n, 1, (long)3 * n, n, m, nullptr, nullptr, 1, idx_a};
+    const FpsProb p1 = {xyz_packed, 1, 3, 0, 0, 0, offset, new_offset, 0, idx_b};
+    return launch_fps2(b, b, n, p0, p1, (hipStream_t)stream);
 }
 
 int etch_gather_points(int b, int c, int n, int m, const float* points, const int* idx, float* out, void* stream) {

@@ -273,6 +273,7 @@ class GT_network_equiv(nn.Module):
         with pointops.knn_scope():
             return self._forward(hitpts, pred_items, direction_mode, B, N)
 
+    pt_index_stream = os.environ.get("ETCH_PT_INDEX_STREAM", "0") == "1"      # the Point-Transformer nets' index chain on its own stream (A/B)
     overlap_index_ops = True   # run every coordinate-only index op (EPN FPS / ball queries, PT FPS / kNN) on a side stream
     input_producer = None      # stream that produced `hitpts` if it is not the current one (set by a pipelined caller)
 
@@ -313,6 +314,8 @@ class GT_network_equiv(nn.Module):
             od = self._input_order(hitpts)
             if od is not None:
                 made.append(od)
+            if want_pt and self.fps_pair and not self.pt_index_stream:
+                made += self._fps_pair_ahead(hitpts, cur, B, N)
             for block in self.encoder.backbone:
                 for conv in block.blocks:
                     ic = conv.inter_conv.conv
@@ -325,15 +328,52 @@ class GT_network_equiv(nn.Module):
             epn_ready.record(side)
             # (the Point-Transformer nets' FPS / kNN chain stays on this stream behind the EPN part: a stream of its own -- so that the next batch's first
             # FPS does not queue behind this batch's kNN queries -- measured no better, 6 streams on 4 hardware queues)
-            if want_pt:
+            if want_pt and not self.pt_index_stream:
                 oh = [N * (i + 1) for i in range(B)]
                 o = pointops.offsets_tensor(oh, hitpts.device)
                 made += prefetch_indices(hitpts.view(-1, 3), o)
             done = torch.cuda.Event()
             done.record(side)
+        if want_pt and self.pt_index_stream:
+            # A/B switch (ETCH_PT_INDEX_STREAM=1): the nets' FPS / kNN chain on a stream of its own, so that it runs NEXT TO the encoder's FPS
+            # (one workgroup per scan each: 8 + 8 of 256 compute units on the dense 8-scan shard of configs[4]) instead of behind it
+            if not hasattr(self, "_side_stream2"):
+                from ..utils.cu_streams import make_stream
+                self._side_stream2 = make_stream("side", priority=int(os.environ.get("ETCH_INDEX_STREAM_PRIORITY", "0")))
+            side2 = self._side_stream2
+            side2.wait_stream(self.input_producer if self.input_producer is not None else main)
+            self._cross_stream([hitpts], [side2])
+            with torch.cuda.stream(side2):
+                oh = [N * (i + 1) for i in range(B)]
+                o = pointops.offsets_tensor(oh, hitpts.device)
+                made += prefetch_indices(hitpts.view(-1, 3), o)
+                done = torch.cuda.Event()
+                done.record(side2)
         users = [main] + (list(self._heads_streams()) if self.concurrent_heads else [])
         self._cross_stream(made, users)
         return epn_ready, done
+
+    fps_pair = os.environ.get("ETCH_FPS_PAIR", "1") != "0"
+
+    def _fps_pair_ahead(self, hitpts, xyz_b3n, B, N):
+        """The encoder's FPS and the nets' first FPS level in one launch (ops.fps_pair), handed to their callers through ops._FPS_READY: on the dense 8-scan
+        shard of configs[4] the two chains (27 + 11 ms, eight workgroups each) no longer queue behind each other on the index stream.  Only where both
+        will really be asked for with exactly these arguments (first conv strided and not lazily sampled, split FPS not selected)."""
+        from .pointtransformer_seg import downsampled_offsets
+        ops._FPS_READY.clear()            # (a forward that raised half-way must not leave a result behind for a later tensor at the same address)
+        ic = self.encoder.backbone[0].blocks[0].inter_conv.conv
+        m = -(-N // ic.stride)
+        if ic.stride <= 1 or ic.lazy_sample or m == N or ops.fps_split_default(B, N, hitpts.device) >= 2:
+            return []
+        oh = [N * (i + 1) for i in range(B)]
+        o = pointops.offsets_tensor(oh, hitpts.device)
+        n_o = downsampled_offsets(oh, 4)
+        n_o_t = pointops.make_offsets(n_o, hitpts.device, like=(o, 4))
+        packed = hitpts.view(-1, 3)
+        idx_a, idx_b = ops.fps_pair(xyz_b3n, m, packed, o, n_o_t, n_o)
+        ops._FPS_READY[("vgtk", xyz_b3n.data_ptr(), int(m))] = idx_a
+        ops._FPS_READY[("pointops", packed.data_ptr(), n_o_t.data_ptr())] = idx_b
+        return [idx_a, idx_b, n_o_t]
 
     def _input_order(self, hitpts):
         """Morton order of the input points of each scan (scheduling hint for the gather-heavy kernels), memoised per forward and

@@ -97,10 +97,33 @@ def _fps_split_checked(idx, split):
     return idx
 
 
+# One-shot hand-over of sampling results that fps_pair computed ahead of their callers (models_pointcloud._prefetch_indices): key -> idx.  A result is taken
+# (popped) by the first call whose arguments match; the keys hold data pointers of tensors the prefetcher keeps alive until then.
+_FPS_READY = {}
+
+
+def fps_pair(xyz_b3n, m, xyz_packed, offset, new_offset, new_offset_host):
+    """The encoder's FPS (furthest_point_sampling(xyz_b3n, m)) and the Point-Transformer nets' first FPS level (furthestsampling(xyz_packed, offset,
+    new_offset)) over the same b scans of n points each in ONE launch of 2 b workgroups (etch_fps_pair): both are one workgroup per scan and depend on the
+    coordinates only.  -> (idx_a (b,m) int32, idx_b (sum m') int32), bit-identical to the separate calls."""
+    _need(xyz_b3n, torch.float32, "xyz_b3n"), _need(xyz_packed, torch.float32, "xyz_packed")
+    _need(offset, torch.int32, "offset"), _need(new_offset, torch.int32, "new_offset")
+    b, _, n = xyz_b3n.shape
+    assert xyz_packed.shape == (b * n, 3)
+    idx_a = torch.zeros((b, m), dtype=torch.int32, device=xyz_b3n.device)
+    idx_b = torch.zeros((int(new_offset_host[-1]),), dtype=torch.int32, device=xyz_b3n.device)
+    _lib.check(_lib.lib().etch_fps_pair(b, n, int(m), _ptr(xyz_b3n), _ptr(idx_a), _ptr(xyz_packed), _ptr(offset), _ptr(new_offset), _ptr(idx_b), _stream()),
+               "etch_fps_pair")
+    return idx_a, idx_b
+
+
 def furthest_point_sampling(xyz, m, split=None):
     """epn_grouping.furthest_point_sampling (grouping_cuda.cpp:158-173): (b,3,n) -> (b,m) int32.  split = workgroups per scan (None: auto)."""
     _need(xyz, torch.float32, "xyz")
     b, _, n = xyz.shape
+    ready = _FPS_READY.pop(("vgtk", xyz.data_ptr(), int(m)), None) if _FPS_READY else None
+    if ready is not None:
+        return ready
     idx = torch.zeros((b, m), dtype=torch.int32, device=xyz.device)
     G = fps_split_default(b, n, xyz.device) if split is None else int(split)
     if G >= 2:
@@ -169,6 +192,9 @@ def furthestsampling(xyz, offset, new_offset, offset_host=None, new_offset_host=
         offset_host = offset.tolist()
     if new_offset_host is None:
         new_offset_host = new_offset.tolist()
+    ready = _FPS_READY.pop(("pointops", xyz.data_ptr(), new_offset.data_ptr()), None) if _FPS_READY else None
+    if ready is not None:
+        return ready
     idx = torch.zeros((int(new_offset_host[-1]),), dtype=torch.int32, device=xyz.device)
     nseg, n_max = len(offset_host), _seg_max(offset_host)
     G = fps_split_default(nseg, n_max, xyz.device) if split is None else int(split)

@@ -71,6 +71,11 @@ int etch_knnquery(int b, int m_max, int m_total, int nsample, const float* xyz, 
  * The reference's caller-provided `tmp` scratch is not needed (distances live in registers). */
 int etch_furthestsampling(int b, int n_max, const float* xyz, const int* offset, const int* new_offset, int* idx,
                           void* stream);
+/* Round 6: the vgtk FPS of a batch (grouping_cuda_kernel.cu:352-466, as etch_furthest_point_sampling) and the pointops FPS of the SAME scans
+ * (sampling_cuda_kernel.cu:15-129, as etch_furthestsampling; every segment n points) in one launch of 2 b workgroups -- both chains are one workgroup per
+ * scan and depend on the coordinates only; bit-identical picks. */
+int etch_fps_pair(int b, int n, int m, const float* xyz_b3n, int* idx_a, const float* xyz_packed, const int* offset, const int* new_offset, int* idx_b,
+                  void* stream);
 
 /* etch_knnquery without any host knowledge of the offsets: every query finds its segment on the device by scanning new_offset the way
  * the reference kernel does (knnquery_cuda_kernel.cu:52-62 get_bt_idx, :74-80), the grid is sized from m alone.  Same results as

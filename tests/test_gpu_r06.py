@@ -182,3 +182,50 @@ def test_graph_replay_pipeline_matches_the_synchronous_path(tmp_path):
         for a, b in zip(i0, i1):
             assert same(a, b)
         assert same(m0[0].vertices, m1[0].vertices)
+
+
+@pytest.mark.parametrize("b,n,stride", [(3, 5000, 2), (2, 20000, 2), (4, 1024, 2), (1, 777, 3)])
+def test_fps_pair_equals_the_two_separate_samplings(b, n, stride):
+    """etch_fps_pair: the encoder's FPS (grouping_cuda_kernel.cu:352-466) and the nets' first FPS level (sampling_cuda_kernel.cu:15-129) of the same
+    scans in one launch of 2 b workgroups -- bit for bit the picks of the separate launches, on random scans, on a lattice full of ties and with points at
+    the origin (which only the vgtk flavour skips)."""
+    from etch_amd import ops
+    from etch_amd.models import pointops
+    from etch_amd.models.pointtransformer_seg import downsampled_offsets
+    g = torch.Generator().manual_seed(n + b)
+    for kind in ("random", "lattice"):
+        if kind == "random":
+            pts = torch.randn(b, n, 3, generator=g) * torch.tensor([0.14, 0.31, 0.085])
+        else:
+            pts = torch.randint(0, 7, (b, n, 3), generator=g).float() * 0.05
+        pts[:, 5] = 0.0                                   # a point at the origin
+        pts = pts.cuda().contiguous()
+        xyz = pts.permute(0, 2, 1).contiguous()
+        m = -(-n // stride)
+        oh = [n * (i + 1) for i in range(b)]
+        o = pointops.offsets_tensor(oh, pts.device)
+        n_o = downsampled_offsets(oh, 4)
+        n_o_t = pointops.offsets_tensor(n_o, pts.device)
+        ia, ib = ops.fps_pair(xyz, m, pts.view(-1, 3), o, n_o_t, n_o)
+        ra = ops.furthest_point_sampling(xyz, m, split=1)
+        rb = ops.furthestsampling(pts.view(-1, 3), o, n_o_t, oh, n_o, split=1)
+        assert torch.equal(ia, ra) and torch.equal(ib, rb), kind
+
+
+def test_model_with_and_without_the_paired_fps_is_bitwise_identical(tmp_path):
+    from tests.test_gpu_pipeline import make, scan
+    args, model = make(tmp_path)
+    pts = torch.from_numpy(np.stack([scan(500 + b, 2048) for b in range(2)])).cuda()
+    items = ["confidence", "direction", "magnitude"]
+    out = {}
+    for on in (True, False, True):
+        model.fps_pair = on
+        with torch.no_grad():
+            res, _ = model(pts, items, "standard_vector")
+        torch.cuda.synchronize()
+        if not out:
+            out = {k: v.clone() for k, v in res.items()}
+        for k in out:
+            assert torch.equal(res[k], out[k]), (k, on)
+    from etch_amd import ops
+    assert not ops._FPS_READY
