@@ -68,4 +68,14 @@ cp $O/${tag}_pmc_traffic.json.sources.json $O/${tag}_pmc_mfma.txt $O/${tag}_pmc_
 python3 $R/bench.py > $O/${tag}_bench_line_default_run.json 2> $O/bench_default.err
 python3 $R/bench.py --config 1 --steps 10 > $O/${tag}_bench_line_config1_forward_only.json 2> $O/bench_c1.err
 python3 $R/bench.py --config 4 --steps 5 --warmup 2 > $O/${tag}_bench_line_config4_dense20k_smplx.json 2> $O/bench_c4.err
+# (round 6) the training step: its bench line and its kernel table; the stage-1 stream's own timeline of the default run from HIP events (no tracer)
+python3 $R/bench.py --train > $O/${tag}_bench_line_train.json 2> $O/bench_train.err
+run trace_train --kernel-trace --stats -d $O/prof_train -o train -- python3 $R/bench.py --train --steps 6 --warmup 2 --no-cpu-baseline
+python3 profiles/summarize_rocpd.py $(find $O/prof_train -name '*_results.db' | head -1) > $O/${tag}_train_kernel_stats.txt
+rm -rf $O/prof_train
+ETCH_PIPE_TIMING=1 python3 $R/bench.py --steps 60 --no-cpu-baseline --no-extras > /dev/null 2> $O/gaps.err
+{ echo "# ETCH_PIPE_TIMING=1 python3 bench.py --steps 60 --no-cpu-baseline --no-extras: the stage-1 stream's timeline from HIP events (etch_amd/pipeline.py gap_report), no tracer attached";
+  grep -v amdgpu.ids $O/gaps.err; } > $O/${tag}_boundary_gaps.txt
+# SQ counters of the inter conv alone (profiles/scripts/pmc_inter_y.sh: four separate passes over profiles/scripts/time_inter_kq.py)
+bash profiles/scripts/pmc_inter_y.sh $O/pmc_y > $O/${tag}_inter_conv_counters.txt 2>&1
 ls -la $O
