@@ -67,7 +67,7 @@ cp $O/${tag}_pmc_traffic.json.sources.json $O/${tag}_pmc_mfma.txt $O/${tag}_pmc_
 # the bench lines themselves (default run with the CPU baseline; forward only; the dense SMPL-X-sized config; two ranks on this one GPU)
 python3 $R/bench.py > $O/${tag}_bench_line_default_run.json 2> $O/bench_default.err
 python3 $R/bench.py --config 1 --steps 10 > $O/${tag}_bench_line_config1_forward_only.json 2> $O/bench_c1.err
-python3 $R/bench.py --config 4 --steps 5 --warmup 2 > $O/${tag}_bench_line_config4_dense20k_smplx.json 2> $O/bench_c4.err
+python3 $R/bench.py --config 4 --steps 20 --warmup 3 > $O/${tag}_bench_line_config4_dense20k_smplx.json 2> $O/bench_c4.err
 # (round 6) the training step: its bench line and its kernel table; the stage-1 stream's own timeline of the default run from HIP events (no tracer)
 python3 $R/bench.py --train > $O/${tag}_bench_line_train.json 2> $O/bench_train.err
 run trace_train --kernel-trace --stats -d $O/prof_train -o train -- python3 $R/bench.py --train --steps 6 --warmup 2 --no-cpu-baseline
