@@ -92,7 +92,10 @@ struct H32Step2 {
     template <int N> __device__ __forceinline__ void wait(f32x4 (&v)[2]) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(v[0]), "+v"(v[1]) : "n"(N)); }
     // PF (the 64-channel kernel: one wave per SIMD, registers to spare): the X1 row of K step c + 1 is read while step c computes -- read where it is
     // split, every K step waited out an LDS round trip with nothing else to issue
-    static constexpr bool PF = CIN >= 64;
+#ifndef Y_S2_PF
+#define Y_S2_PF(CIN, COUT) ((CIN) >= 64)
+#endif
+    static constexpr bool PF = Y_S2_PF(CIN, COUT);
     template <int H>
     __device__ __forceinline__ void half(f32x16 (&y)[MT2], const float* X1s, const bf16x8* __restrict__ Wq, int wave, int lane) {
         const int an = lane & 31, kg = lane >> 5;
