@@ -77,7 +77,7 @@ class InterSO3ConvFunction(torch.autograd.Function):
         return dfeats, dW, dbias, None, None, None, None, None, None
 
 
-def inter_so3conv(feats_cl, W, bias, xyz, new_xyz, ball_idx, rk, sigma, chunk=256):
+def inter_so3conv(feats_cl, W, bias, xyz, new_xyz, ball_idx, rk, sigma, chunk=1024):
     return InterSO3ConvFunction.apply(feats_cl, W, bias, xyz, new_xyz, ball_idx, rk, sigma, chunk)
 
 

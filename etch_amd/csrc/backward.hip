@@ -173,17 +173,30 @@ __global__ void __launch_bounds__(256) inter_dfeat_kernel(int cin, int cbase, in
                 const float gx = qx - new_xyz[((size_t)b * 3 + 0) * p2 + p], gy = qy - new_xyz[((size_t)b * 3 + 1) * p2 + p],
                             gz = qz - new_xyz[((size_t)b * 3 + 2) * p2 + p];
                 const float ga = 1.0f - (gx * gx + gy * gy + gz * gz) * inv_sigma;
-                const float* drow = dx1 + (((size_t)b * pc + pl) * NA + a) * kk + (size_t)(cbase + cg * cper) * KS;
+                // Round 6: the 24 weights of this (match, anchor) once into registers, then every channel's 24 gradients as SIX 16-byte loads (a channel's
+                // row of dX1 is 24 consecutive floats, 96 bytes, 16-byte aligned: kk and KS are multiples of 4) -- the first form read them one float at a
+                // time with a stride of 24 between a thread's channels: 26 % of a training step (profiles/r06_train_kernel_stats.txt).  Same products,
+                // same order of the sum over k for every channel (k ascending; zero weights contribute +0 instead of being skipped: bitwise the same sum
+                // unless an accumulator is -0).
+                float wv[KS];
+#pragma unroll
                 for (int k = 0; k < KS; ++k) {
                     const float rx = rk[(a * KS + k) * 3], ry = rk[(a * KS + k) * 3 + 1], rz = rk[(a * KS + k) * 3 + 2];
-                    const float w = fmaxf(0.f, fmaf(2.0f * inv_sigma * gz, rz, fmaf(2.0f * inv_sigma * gy, ry, fmaf(2.0f * inv_sigma * gx, rx,
-                                                    ga - (rx * rx + ry * ry + rz * rz) * inv_sigma))));
-                    if (w > 0.f) {
-#pragma unroll
-                        for (int c = 0; c < 16; ++c)
-                            if (c < cper) acc[c] = fmaf(w, drow[c * KS + k], acc[c]);
-                    }
+                    wv[k] = fmaxf(0.f, fmaf(2.0f * inv_sigma * gz, rz, fmaf(2.0f * inv_sigma * gy, ry, fmaf(2.0f * inv_sigma * gx, rx,
+                                                ga - (rx * rx + ry * ry + rz * rz) * inv_sigma))));
                 }
+                const float4* drow = reinterpret_cast<const float4*>(dx1 + (((size_t)b * pc + pl) * NA + a) * kk + (size_t)(cbase + cg * cper) * KS);
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (c < cper) {
+                        float s_ = acc[c];
+#pragma unroll
+                        for (int k4 = 0; k4 < KS / 4; ++k4) {
+                            const float4 d = drow[c * (KS / 4) + k4];
+                            s_ = fmaf(wv[4 * k4], d.x, s_); s_ = fmaf(wv[4 * k4 + 1], d.y, s_); s_ = fmaf(wv[4 * k4 + 2], d.z, s_); s_ = fmaf(wv[4 * k4 + 3], d.w, s_);
+                        }
+                        acc[c] = s_;
+                    }
             }
         }
         __syncthreads();

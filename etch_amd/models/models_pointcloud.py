@@ -241,8 +241,20 @@ class GT_network_equiv(nn.Module):
                 results["magnitude"] = P.magnitude_forward(self.magnitude_encoder, pxo)
         if "direction" in pred_items:
             results["direction"] = self.direction_differentiable(tokens.view(B * N, 60, feats_cl.shape[-1]), anchors, B, N)
-        selected_indexs = torch.arange(0, N, device=hitpts.device).repeat(B, 1).unsqueeze(-1).expand(-1, -1, 3)
+        selected_indexs = self._const(('sel', B, N, str(hitpts.device)), lambda: torch.arange(0, N, device=hitpts.device).repeat(B, 1)).unsqueeze(-1).expand(-1, -1, 3)
         return results, selected_indexs
+
+    def _const(self, key, make):
+        """Per-shape constants of a forward (the identity `selected_indexs`, the broadcast standard vector): built once per (shape, device) instead of with
+        2 - 3 launches per forward.  Read-only by contract: the reference returns fresh tensors, callers that write into them must clone."""
+        c = self.__dict__.setdefault("_const_cache", {})
+        v = c.get(key)
+        if v is None:
+            if len(c) > 64:
+                c.clear()
+            with torch.no_grad():
+                v = c[key] = make()
+        return v
 
     def forward(self, hitpts, pred_items=["direction", "magnitude"], direction_mode="standard_vector"):
         """models_pointcloud.py:146-221.  See `differentiable` above for when the path with autograd history is taken."""
@@ -404,7 +416,7 @@ class GT_network_equiv(nn.Module):
             torch.cuda.current_stream().wait_event(epn_ready)
         r, sample_idx_lists = self.encode(hitpts)
         so3_anchors = r.anchors
-        selected_indexs = torch.arange(0, N, device=hitpts.device).repeat(B, 1).unsqueeze(-1).expand(-1, -1, 3)
+        selected_indexs = self._const(('sel', B, N, str(hitpts.device)), lambda: torch.arange(0, N, device=hitpts.device).repeat(B, 1)).unsqueeze(-1).expand(-1, -1, 3)
         # 3-NN propagation of the [C*60] equivariant features to all N points + anchor mean (:181-184), channels-last
         order = self._input_order(hitpts)
         interp = None
@@ -460,7 +472,7 @@ class GT_network_equiv(nn.Module):
         if "direction" in pred_items and self.direction_first:
             if direction_mode != "standard_vector":
                 raise AssertionError("Not implemented")   # same as the reference (:199,210)
-            standard_vector = self.standard_vector.repeat(B, N, 1)
+            standard_vector = self._const(('sv', B, N, self.standard_vector.data_ptr(), self.standard_vector._version), lambda: self.standard_vector.repeat(B, N, 1))
             direction = self.decode_direction(None, so3_anchors, standard_vector, tokens_cl=point_equiv_cl, interp=interp)
         if "confidence" in pred_items:
             part_labels, confidences = branch(0, lambda: self.decode_confidence(point_inv_feat, hitpts))
@@ -471,7 +483,7 @@ class GT_network_equiv(nn.Module):
         if "direction" in pred_items and not self.direction_first:
             if direction_mode != "standard_vector":
                 raise AssertionError("Not implemented")
-            direction = self.decode_direction(None, so3_anchors, self.standard_vector.repeat(B, N, 1), tokens_cl=point_equiv_cl, interp=interp)
+            direction = self.decode_direction(None, so3_anchors, self._const(('sv', B, N, self.standard_vector.data_ptr(), self.standard_vector._version), lambda: self.standard_vector.repeat(B, N, 1)), tokens_cl=point_equiv_cl, interp=interp)
         if direction is not None:
             results["direction"] = direction
         self.pending_join = None

@@ -58,11 +58,20 @@ def ball_query_index(query_points, support_points, radius, n_sample):
     return ops.ball_query(query_points, support_points, radius, n_sample)
 
 
+_IDENTITY_SAMPLES = {}
+
+
 def furthest_sample_index(pc, n_sample, lazy_sample):
     """pc/sample.py:75-85."""
     if pc.shape[2] == n_sample or lazy_sample:
         nb = pc.shape[0]
-        return torch.arange(n_sample, device=pc.device, dtype=torch.int32).view(1, -1).expand(nb, -1).contiguous()
+        key = (nb, int(n_sample), str(pc.device))
+        v = _IDENTITY_SAMPLES.get(key)
+        if v is None:            # (a per-shape constant: two launches per conv and forward otherwise; read-only by contract)
+            if len(_IDENTITY_SAMPLES) > 64:
+                _IDENTITY_SAMPLES.clear()
+            v = _IDENTITY_SAMPLES[key] = torch.arange(n_sample, device=pc.device, dtype=torch.int32).view(1, -1).expand(nb, -1).contiguous()
+        return v
     return ops.furthest_point_sampling(pc, n_sample)
 
 
