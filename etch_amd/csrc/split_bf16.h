@@ -100,10 +100,22 @@ __device__ __forceinline__ void split2h_pair(float a, float b, unsigned& h, unsi
     // could be one that an MFMA issued a moment ago is still reading as its accumulator input (write-after-read, up to 7 wait states for an 8-pass
     // MFMA, no hardware interlock; etch_amd/isa_lint.py reported exactly that in csrc/mhsa_layer.hip).  A register that holds a live value cannot be
     // one, and where x is needed afterwards the copy is a compiler-emitted move, which gets its wait states.  Reads: x was read by the conversion above.
+#ifndef ETCH_SPLIT2H_MIXF16
     float la = a, lb = b;
     asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(la) : "v"(h));
     asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lb) : "v"(h));
     l = __builtin_bit_cast(unsigned, (f16x2){(_Float16)la, (_Float16)lb});
+#else
+    // Round 6, measured and NOT adopted: v_fma_mixlo_f16 / v_fma_mixhi_f16 round the product-sum once to fp16 straight into the low / high half of the
+    // packed pair -- three instructions per pair instead of four, bit for bit the same planes (2^20 random pairs incl. subnormal residuals, +-0, 65 504:
+    // scratch/mix/mixtest.hip) -- and SLOWER: the attention layers 3.03 / 2.75 against 2.96 / 2.63 ms, the inter conv 9.13 against 8.99 ms on the same
+    // box.  The second instruction merges into the half-written register of the first: a dependent pair per value pair where the form above has two
+    // independent instructions (profiles/r06_inter_conv_persistent.txt, section 3).
+    float la = a;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(la) : "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(la) : "v"(h), "v"(b));
+    l = __builtin_bit_cast(unsigned, la);
+#endif
 }
 // 4 consecutive fp32 values -> 2 planes x 4 fp16 (8 bytes each)
 __device__ __forceinline__ void split2h_pack4(const float4 v, uint2& h, uint2& l) {
