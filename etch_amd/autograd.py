@@ -18,14 +18,28 @@ def _check(status, what):
     _lib.check(status, what)
 
 
+_COUNTERS = {}
+
+
+def reduce_counters(device):
+    """The 64 zero-initialised counters of the one-launch reductions (include/etch_hip.h: etch_gemm_tn_fused, etch_colsum_fused, etch_bn_*): every call
+    leaves them zero; one set per (device, stream) -- calls that share a set must be ordered on one stream, which launches on one stream are."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    c = _COUNTERS.get(key)
+    if c is None:
+        c = _COUNTERS[key] = torch.zeros((64,), dtype=torch.int32, device=device)
+    return c
+
+
 def gemm_tn(A, B, out=None, accumulate=False):
     """A (R,M), B (R,N) -> A^T B (M,N)."""
     R, M = A.shape
     N = B.shape[1]
     C = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=A.device)
     ws = torch.empty((_lib.lib().etch_gemm_tn_workspace_floats(ctypes.c_long(R), M, N),), dtype=torch.float32, device=A.device)
-    _check(_lib.lib().etch_gemm_tn(ctypes.c_long(R), M, N, _ptr(A), ctypes.c_long(A.stride(0)), _ptr(B), ctypes.c_long(B.stride(0)), _ptr(C),
-                                   1 if accumulate else 0, _ptr(ws), _stream()), "etch_gemm_tn")
+    counters = reduce_counters(A.device)
+    _check(_lib.lib().etch_gemm_tn_fused(ctypes.c_long(R), M, N, _ptr(A), ctypes.c_long(A.stride(0)), _ptr(B), ctypes.c_long(B.stride(0)), _ptr(C),
+                                         1 if accumulate else 0, _ptr(ws), _ptr(counters), _stream()), "etch_gemm_tn_fused")
     return C
 
 
@@ -33,7 +47,9 @@ def colsum(x2d):
     R, C = x2d.shape
     ws = torch.empty((64 * C,), dtype=torch.float64, device=x2d.device)
     out = torch.empty((C,), dtype=torch.float32, device=x2d.device)
-    _check(_lib.lib().etch_colsum(ctypes.c_long(R), C, _ptr(x2d), _ptr(ws), _ptr(out), _stream()), "etch_colsum")
+    counters = reduce_counters(x2d.device)
+    _check(_lib.lib().etch_colsum_fused(ctypes.c_long(R), C, _ptr(x2d), ctypes.c_long(x2d.stride(0)), _ptr(ws), _ptr(counters), _ptr(out),
+                                        _stream()), "etch_colsum_fused")
     return out
 
 

@@ -31,26 +31,39 @@ def bn_stats(x2):
     R, C = x2.shape
     mean = torch.empty((C,), dtype=torch.float32, device=x2.device)
     var = torch.empty_like(mean)
-    _lib.check(_lib.lib().etch_bn_stats(_c_long(R), C, _ptr(x2), _c_long(x2.stride(0)), _ptr(_ws(C, x2.device)), _ptr(mean), _ptr(var), _stream()),
+    ws = _ws(C, x2.device)               # held in a name: a temporary would be back in the allocator (and could be handed out again) before the launch
+    _lib.check(_lib.lib().etch_bn_stats(_c_long(R), C, _ptr(x2), _c_long(x2.stride(0)), _ptr(ws), _ptr(mean), _ptr(var), _stream()),
                "etch_bn_stats")
     return mean, var
 
 
 class BatchNormFunction(torch.autograd.Function):
     """y = act(gamma * (x - mean) / sqrt(var + eps) + beta) on rows x (R,C).  train: (mean, var) are the batch statistics of x (the backward
-    carries their dependence on x); eval: constants."""
+    carries their dependence on x), computed here together with the module's running statistics (etch_bn_train_forward: 2 launches; round 5 spent
+    12 per call -- 246 calls per training step); eval: (mean, var) given, constants."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, mean, var, eps, relu, train):
+    def forward(ctx, x, gamma, beta, mean, var, eps, relu, train, running):
         x = x.contiguous()
         R, C = x.shape
-        rstd = torch.rsqrt(var + eps)
-        g = gamma.detach()
-        scale = (g * rstd).contiguous()
+        g = gamma.detach().contiguous()
         y = torch.empty((R, C), dtype=torch.float32, device=x.device)
-        _lib.check(_lib.lib().etch_bn_apply(_c_long(R), C, _ptr(x), _c_long(x.stride(0)), _ptr(mean.contiguous()), _ptr(scale),
-                                            _ptr(beta.detach().contiguous()), 1 if relu else 0, _ptr(y), _stream()), "etch_bn_apply")
-        ctx.save_for_backward(x, y if relu else None, mean, rstd, g.contiguous())
+        if train:
+            rm, rv, nbt, momentum = running
+            stats = torch.empty((3, C), dtype=torch.float32, device=x.device)
+            ws, counters = _ws(C, x.device), A.reduce_counters(x.device)
+            mean, rstd, scale = stats[0], stats[1], stats[2]
+            _lib.check(_lib.lib().etch_bn_train_forward(_c_long(R), C, _ptr(x), _c_long(x.stride(0)), _ptr(g), _ptr(beta.detach().contiguous()),
+                                                        ctypes.c_float(eps), ctypes.c_float(-1.0 if momentum is None else momentum), ops._optptr(rm),
+                                                        ops._optptr(rv), ops._optptr(nbt), 1 if relu else 0, _ptr(ws),
+                                                        _ptr(counters), _ptr(mean), _ptr(rstd), _ptr(scale), _ptr(y), _stream()),
+                       "etch_bn_train_forward")
+        else:
+            rstd = torch.rsqrt(var + eps)
+            scale = (g * rstd).contiguous()
+            _lib.check(_lib.lib().etch_bn_apply(_c_long(R), C, _ptr(x), _c_long(x.stride(0)), _ptr(mean.contiguous()), _ptr(scale),
+                                                _ptr(beta.detach().contiguous()), 1 if relu else 0, _ptr(y), _stream()), "etch_bn_apply")
+        ctx.save_for_backward(x, y if relu else None, mean, rstd, g)
         ctx.relu, ctx.train = bool(relu), bool(train)
         return y
 
@@ -60,28 +73,22 @@ class BatchNormFunction(torch.autograd.Function):
         dy = dy.contiguous()
         R, C = x.shape
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dgamma = torch.empty((C,), dtype=torch.float32, device=x.device)
-        dbeta = torch.empty_like(dgamma)
-        _lib.check(_lib.lib().etch_bn_backward(_c_long(R), C, _ptr(x), _c_long(x.stride(0)), ops._optptr(y), _ptr(dy), _ptr(mean), _ptr(rstd), _ptr(g),
-                                               1 if ctx.relu else 0, 1 if ctx.train else 0, _ptr(_ws(C, x.device)), ops._optptr(dx), _ptr(dgamma),
-                                               _ptr(dbeta), _stream()), "etch_bn_backward")
-        return dx, dgamma, dbeta, None, None, None, None, None
+        dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        ws, counters = _ws(C, x.device), A.reduce_counters(x.device)
+        _lib.check(_lib.lib().etch_bn_backward_fused(_c_long(R), C, _ptr(x), _c_long(x.stride(0)), ops._optptr(y), _ptr(dy), _ptr(mean), _ptr(rstd), _ptr(g),
+                                                     1 if ctx.relu else 0, 1 if ctx.train else 0, _ptr(ws), _ptr(counters),
+                                                     ops._optptr(dx), _ptr(dgb[0]), _ptr(dgb[1]), _stream()), "etch_bn_backward_fused")
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None
 
 
 def batch_norm(x2, m, relu=False):
     """torch.nn.BatchNorm1d `m` on rows x2 (R,C) (+ ReLU): batch statistics and running-statistic update in train() mode
     (momentum / unbiased variance / num_batches_tracked as torch.nn.functional.batch_norm), running statistics in eval() mode."""
-    R = x2.shape[0]
     if m.training:
-        mean, var = bn_stats(x2.detach().contiguous())
-        with torch.no_grad():
-            if m.track_running_stats and m.running_mean is not None:
-                m.num_batches_tracked += 1
-                mom = m.momentum if m.momentum is not None else 1.0 / float(m.num_batches_tracked)
-                m.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-                m.running_var.mul_(1 - mom).add_(var * (R / max(R - 1, 1)), alpha=mom)
-        return BatchNormFunction.apply(x2, m.weight, m.bias, mean, var, m.eps, relu, True)
-    return BatchNormFunction.apply(x2, m.weight, m.bias, m.running_mean.detach(), m.running_var.detach(), m.eps, relu, False)
+        track = m.track_running_stats and m.running_mean is not None
+        running = (m.running_mean, m.running_var, m.num_batches_tracked, m.momentum) if track else (None, None, None, 0.0)
+        return BatchNormFunction.apply(x2, m.weight, m.bias, None, None, m.eps, relu, True, running)
+    return BatchNormFunction.apply(x2, m.weight, m.bias, m.running_mean.detach(), m.running_var.detach(), m.eps, relu, False, None)
 
 
 def _segments(index, nseg):

@@ -74,56 +74,100 @@ __global__ void __launch_bounds__(256) inter_x1_rows_kernel(int cin, int p1, int
 // are the weight gradients: sums over every row (token) of the batch, and for the direction head's layers they cancel to ~1e-7 of the sum of the
 // terms' magnitudes (profiles/r05_weight_gradient_accumulation.txt): fp32 accumulation, though exact to 2e-8 of that sum, left 12 % error in
 // d(net[2].weight).  The fp64 matrix pipe runs at half the fp32 one's rate and these GEMMs are ~2 % of a training step.
-#define TN_LD 80
+// Round 6: (a) tiles of 32 or 64 rows / columns of C (the Point-Transformer nets' layers are 3 .. 64 wide mostly: a 64 x 64 tile spent 3/4 .. 15/16 of
+// its fp64 MFMAs on padding), (b) row ranges of ~256 rows per workgroup instead of 2048 (a 32-wide layer over 80 000 rows ran on 40 of 256 CUs, each
+// bound by its own fp64 matrix pipe: 354 launches of ~90 us were 32 of a training step's 125 ms of kernel time), (c) the next 32 rows' loads in flight
+// while the current ones are multiplied.  The partial tiles are still summed in split order: a result depends on (R, M, N) only.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+// FUSED (round 6): the workgroup of a tile that finishes last (common.h: etch_last_block, one counter per tile) sums the tile's partials in split order
+// -- gemm_tn_reduce_kernel's sums, bit for bit -- so a weight gradient is one launch instead of two (177 per training step).
+template <int TM, int TN, bool FUSED>
 __global__ void __launch_bounds__(256) gemm_tn_kernel(long R, int M, int N, const float* __restrict__ A, long lda, const float* __restrict__ B,
-                                                      long ldb, double* __restrict__ part) {
-    __shared__ __attribute__((aligned(16))) float As[32 * TN_LD], Bs[32 * TN_LD];
+                                                      long ldb, double* part, unsigned* counters, float* C, int accumulate) {
+    constexpr int LDA = TM + 16, LDB = TN + 16;                    // row stride = 16 mod 32 / 64 floats: the transposed fragment reads are conflict-free
+    constexpr int NI = TM / 32, NJ = TN / 32;                      // 16 x 16 blocks per wave (waves 2 x 2 over the tile)
+    constexpr int QA = TM / 4, QB = TN / 4, NLA = 32 * QA / 256 > 0 ? 32 * QA / 256 : 1, NLB = 32 * QB / 256 > 0 ? 32 * QB / 256 : 1;
+    __shared__ __attribute__((aligned(16))) float As[32 * LDA], Bs[32 * LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
-    const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64, sp = blockIdx.z, nsp = gridDim.z;
+    const int n0 = blockIdx.x * TN, m0 = blockIdx.y * TM, sp = blockIdx.z, nsp = gridDim.z;
     const long r_begin = R * sp / nsp, r_end = R * (sp + 1) / nsp;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;          // the wave's 32x32 quadrant
-    f64x4 acc[2][2];
+    const int wm = (wave >> 1) * (TM / 2), wn = (wave & 1) * (TN / 2);
+    f64x4 acc[NI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0, 0, 0, 0};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f64x4){0, 0, 0, 0};
+    float4 va[NLA], vb[NLB];
+    auto fetch = [&](long r0) {
+#pragma unroll
+        for (int l = 0; l < NLA; ++l) {
+            const int e = tid + 256 * l, r = e / QA, c4 = (e % QA) * 4;
+            va[l] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < 32 * QA && r0 + r < r_end) {
+                const float* ar = A + (r0 + r) * lda + m0 + c4;
+                va[l] = make_float4(m0 + c4 < M ? ar[0] : 0.f, m0 + c4 + 1 < M ? ar[1] : 0.f, m0 + c4 + 2 < M ? ar[2] : 0.f, m0 + c4 + 3 < M ? ar[3] : 0.f);
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < NLB; ++l) {
+            const int e = tid + 256 * l, r = e / QB, c4 = (e % QB) * 4;
+            vb[l] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < 32 * QB && r0 + r < r_end) {
+                const float* br = B + (r0 + r) * ldb + n0 + c4;
+                vb[l] = make_float4(n0 + c4 < N ? br[0] : 0.f, n0 + c4 + 1 < N ? br[1] : 0.f, n0 + c4 + 2 < N ? br[2] : 0.f, n0 + c4 + 3 < N ? br[3] : 0.f);
+            }
+        }
+    };
+    if (r_begin < r_end) fetch(r_begin);
     for (long r0 = r_begin; r0 < r_end; r0 += 32) {
         __syncthreads();
-        for (int e = tid; e < 32 * 16; e += 256) {                  // 32 rows x 16 float4 per operand
-            const int r = e >> 4, c4 = (e & 15) * 4;
-            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-            if (r0 + r < r_end) {
-                const float* ar = A + (r0 + r) * lda + m0 + c4;
-                const float* br = B + (r0 + r) * ldb + n0 + c4;
-                va = make_float4(m0 + c4 < M ? ar[0] : 0.f, m0 + c4 + 1 < M ? ar[1] : 0.f, m0 + c4 + 2 < M ? ar[2] : 0.f, m0 + c4 + 3 < M ? ar[3] : 0.f);
-                vb = make_float4(n0 + c4 < N ? br[0] : 0.f, n0 + c4 + 1 < N ? br[1] : 0.f, n0 + c4 + 2 < N ? br[2] : 0.f, n0 + c4 + 3 < N ? br[3] : 0.f);
-            }
-            *reinterpret_cast<float4*>(&As[r * TN_LD + c4]) = va;
-            *reinterpret_cast<float4*>(&Bs[r * TN_LD + c4]) = vb;
+#pragma unroll
+        for (int l = 0; l < NLA; ++l) {
+            const int e = tid + 256 * l;
+            if (e < 32 * QA) *reinterpret_cast<float4*>(&As[(e / QA) * LDA + (e % QA) * 4]) = va[l];
+        }
+#pragma unroll
+        for (int l = 0; l < NLB; ++l) {
+            const int e = tid + 256 * l;
+            if (e < 32 * QB) *reinterpret_cast<float4*>(&Bs[(e / QB) * LDB + (e % QB) * 4]) = vb[l];
         }
         __syncthreads();
+        if (r0 + 32 < r_end) fetch(r0 + 32);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            double a[2], bq[2];
+            double a[NI], bq[NJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { a[i] = (double)As[(4 * t + fg) * TN_LD + wm + 16 * i + fr]; bq[i] = (double)Bs[(4 * t + fg) * TN_LD + wn + 16 * i + fr]; }
+            for (int i = 0; i < NI; ++i) a[i] = (double)As[(4 * t + fg) * LDA + wm + 16 * i + fr];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < NJ; ++j) bq[j] = (double)Bs[(4 * t + fg) * LDB + wn + 16 * j + fr];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bq[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bq[j], acc[i][j], 0, 0, 0);
         }
     }
     double* P = part + (size_t)sp * M * N;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int m = m0 + wm + 16 * i + 4 * q + fg, n = n0 + wn + 16 * j + fr;       // D layout of the fp64 MFMA: row 4 q + lane / 16 (the fp32 one's: 4 (lane / 16) + q)
                 if (m < M && n < N) P[(size_t)m * N + n] = acc[i][j][q];
             }
+    if (FUSED) {
+        if (!etch_last_block(counters + blockIdx.y * gridDim.x + blockIdx.x, (unsigned)nsp)) return;
+        const size_t MN = (size_t)M * N;
+        for (int e = tid; e < TM * TN; e += 256) {
+            const int m = m0 + e / TN, n = n0 + e % TN;
+            if (m >= M || n >= N) continue;
+            const size_t i = (size_t)m * N + n;
+            double s = accumulate ? (double)C[i] : 0.0;
+            for (int k = 0; k < nsp; ++k) s += part[(size_t)k * MN + i];
+            C[i] = (float)s;
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(long MN, int splits, const double* __restrict__ part, float* __restrict__ C, int accumulate) {
@@ -243,6 +287,27 @@ __global__ void colsum_final_kernel(int C, int nparts, const double* __restrict_
     out[c] = (float)s;
 }
 
+// Round 6: one launch, coalesced.  block = 64 columns x 4 row lanes, grid (64 row chunks, C / 64 column groups); the last workgroup of a column group
+// (common.h: etch_last_block) sums the group's 64 chunk partials in chunk order.  (The two kernels above give one column to a workgroup: a stride-C walk.)
+__global__ void __launch_bounds__(256) colsum_fused_kernel(long R, int C, const float* __restrict__ x, long ldx, double* part, unsigned* counters,
+                                                           float* __restrict__ out) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x, cl = tid & 63, rl = tid >> 6, c = blockIdx.y * 64 + cl, nb = gridDim.x;
+    const long r_begin = R * blockIdx.x / nb, r_end = R * (blockIdx.x + 1) / nb;
+    double s = 0.0;
+    if (c < C)
+        for (long r = r_begin + rl; r < r_end; r += 4) s += (double)x[r * ldx + c];
+    red[tid] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) part[(size_t)blockIdx.x * C + c] = ((red[cl] + red[64 + cl]) + red[128 + cl]) + red[192 + cl];
+    if (!etch_last_block(counters + blockIdx.y, (unsigned)nb)) return;
+    if (rl == 0 && c < C) {
+        double t = 0.0;
+        for (int k = 0; k < nb; ++k) t += part[(size_t)k * C + c];
+        out[c] = (float)t;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- InstanceNorm + LeakyReLU backward
 // y = lrelu(xh), xh = (x - mean) * rstd over the rows of one (scan, channel):  g = dy * lrelu'(xh),
 // dx = rstd * (g - mean_rows(g) - xh * mean_rows(g * xh)).  Pass 1: per-chunk fp64 partial sums of g and g*xh; pass 2: apply.
@@ -296,6 +361,33 @@ static inline unsigned grid_for(long total) {
     return (unsigned)blocks;
 }
 
+// Row ranges: ~256 rows per workgroup, at most 64 per tile (the last workgroup of a tile sums them), and no more workgroups than ~8 per CU in all.
+static inline void gemm_tn_shape(long R, int M, int N, int& tm, int& tn, int& gx, int& gy, int& splits) {
+    tm = M <= 32 ? 32 : 64; tn = N <= 32 ? 32 : 64;
+    gx = (N + tn - 1) / tn; gy = (M + tm - 1) / tm;
+    long s = (R + 255) / 256;
+    const long cap = 2048 / ((long)gx * gy) > 0 ? 2048 / ((long)gx * gy) : 1;
+    if (s > cap) s = cap;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    splits = (int)s;
+}
+template <bool FUSED>
+static int gemm_tn_launch(long R, int M, int N, const float* A, long lda, const float* B, long ldb, double* part, unsigned* counters, float* C,
+                          int accumulate, hipStream_t st) {
+    int tm, tn, gx, gy, splits;
+    gemm_tn_shape(R, M, N, tm, tn, gx, gy, splits);
+    const dim3 grid(gx, gy, splits);
+#define TN_GO(TM_, TN_) hipLaunchKernelGGL((gemm_tn_kernel<TM_, TN_, FUSED>), grid, dim3(256), 0, st, R, M, N, A, lda, B, ldb, part, counters, C, accumulate)
+    if (tm == 32 && tn == 32) TN_GO(32, 32);
+    else if (tm == 32) TN_GO(32, 64);
+    else if (tn == 32) TN_GO(64, 32);
+    else TN_GO(64, 64);
+#undef TN_GO
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return splits;
+}
+
 extern "C" {
 
 int etch_inter_x1_rows(int b, int cin, int p1, int p2, int p_begin, int pc, int nn, float sigma, const float* xyz, const float* new_xyz,
@@ -309,9 +401,8 @@ int etch_inter_x1_rows(int b, int cin, int p1, int p2, int p_begin, int pc, int 
 }
 
 int etch_gemm_tn_workspace_floats(long R, int M, int N) {
-    int splits = (int)((R + 2047) / 2048);
-    if (splits > 64) splits = 64;
-    if (splits < 1) splits = 1;
+    int tm, tn, gx, gy, splits;
+    gemm_tn_shape(R, M, N, tm, tn, gx, gy, splits);
     return 2 * splits * M * N + 2;      // fp64 partial tiles (+ 2: room to align the base to 8 bytes)
 }
 
@@ -319,16 +410,25 @@ int etch_gemm_tn(long R, int M, int N, const float* A, long lda, const float* B,
                  void* stream) {
     if (M <= 0 || N <= 0) return ETCH_OK;
     if (R < 0 || lda < M || ldb < N) return ETCH_EINVAL;
-    int splits = (int)((R + 2047) / 2048);
-    if (splits > 64) splits = 64;
-    if (splits < 1) splits = 1;
     hipStream_t st = (hipStream_t)stream;
     double* part = reinterpret_cast<double*>(((uintptr_t)workspace + 7) & ~(uintptr_t)7);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3((N + 63) / 64, (M + 63) / 64, splits), dim3(256), 0, st, R, M, N, A, lda, B, ldb, part);
-    ETCH_RETURN_IF_LAUNCH_FAILED();
+    const int splits = gemm_tn_launch<false>(R, M, N, A, lda, B, ldb, part, nullptr, nullptr, 0, st);
+    if (splits < 0) return splits;
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, st, (long)M * N, splits, part, C, accumulate);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
+}
+
+int etch_gemm_tn_fused(long R, int M, int N, const float* A, long lda, const float* B, long ldb, float* C, int accumulate, float* workspace,
+                       unsigned* counters, void* stream) {
+    if (M <= 0 || N <= 0) return ETCH_OK;
+    if (R < 0 || lda < M || ldb < N || !counters) return ETCH_EINVAL;
+    int tm, tn, gx, gy, splits;
+    gemm_tn_shape(R, M, N, tm, tn, gx, gy, splits);
+    if (gx * gy > ETCH_REDUCE_COUNTERS) return etch_gemm_tn(R, M, N, A, lda, B, ldb, C, accumulate, workspace, stream);
+    double* part = reinterpret_cast<double*>(((uintptr_t)workspace + 7) & ~(uintptr_t)7);
+    const int rc = gemm_tn_launch<true>(R, M, N, A, lda, B, ldb, part, counters, C, accumulate, (hipStream_t)stream);
+    return rc < 0 ? rc : ETCH_OK;
 }
 
 int etch_inter_dfeat(int b, int cin, int p1, int p2, int p_begin, int pc, int nn, float sigma, const float* xyz, const float* new_xyz,
@@ -348,6 +448,16 @@ int etch_intra_rows(long points, int C, int nt, const int* intra_idx, const floa
     const long total = points * NA * nt * C;
     if (total <= 0) return ETCH_OK;
     hipLaunchKernelGGL(intra_rows_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, total, C, nt, intra_idx, x, xg);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_colsum(long R, int C, const float* x, double* workspace, float* out, void* stream);
+int etch_colsum_fused(long R, int C, const float* x, long ldx, double* workspace, unsigned* counters, float* out, void* stream) {
+    if (C <= 0) return ETCH_OK;
+    if (R < 0 || !x || !workspace || !counters || !out || ldx < C) return ETCH_EINVAL;
+    if ((C + 63) / 64 > ETCH_REDUCE_COUNTERS) return ldx == C ? etch_colsum(R, C, x, workspace, out, stream) : ETCH_EUNSUPPORTED;
+    hipLaunchKernelGGL(colsum_fused_kernel, dim3(64, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream, R, C, x, ldx, workspace, counters, out);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }

@@ -67,6 +67,27 @@ __device__ __forceinline__ unsigned long long etch_wave_max_u64_dpp(unsigned lon
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// "Last workgroup done" (round 6: the two-level fixed-order reductions of the training kernels in ONE launch).  Every workgroup of a group writes its
+// partial result, then arrives at the group's counter; the workgroup that arrives last sums the partials IN INDEX ORDER (so the result does not depend
+// on which workgroup that was) and leaves the counter at zero for the next launch.  The fences are the release / acquire pair of the hand-over (on
+// gfx950 they write back / invalidate the XCD's L2: the partials of workgroups on other XCDs are read from memory).  `counter` must be zero when the
+// launch starts; launches that share counters must be ordered on one stream.
+__device__ __forceinline__ bool etch_last_block(unsigned* counter, unsigned total) {
+    __shared__ unsigned s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const unsigned t = atomicAdd(counter, 1u);
+        s_last = t == total - 1u ? 1u : 0u;
+        if (t == total - 1u) atomicExch(counter, 0u);
+    }
+    __syncthreads();
+    const bool last = s_last != 0u;
+    if (last) __threadfence();
+    return last;
+}
+#define ETCH_REDUCE_COUNTERS 64          /* counters a fused reduction may touch (one per column group / output tile) */
+
 __device__ __forceinline__ float etch_wave_sum_f32(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);

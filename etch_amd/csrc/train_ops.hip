@@ -53,9 +53,44 @@ __global__ void bn_stats_final_kernel(long R, int C, const double* __restrict__ 
     mean[c] = (float)m; var[c] = (float)v;
 }
 
+// Round 6: one launch for the statistics AND everything torch.nn.functional.batch_norm derives from them in train() mode -- the last workgroup of a
+// column group (common.h: etch_last_block) sums the group's partials in chunk order (= bn_stats_final_kernel's sums, bit for bit) and writes mean,
+// rstd = 1 / sqrt(var + eps), scale = gamma rstd, the running statistics (momentum < 0: the cumulative average 1 / num_batches_tracked) and
+// num_batches_tracked.  Before: 2 launches here + 9 element-wise torch launches per BatchNorm call, 246 calls per training step.
+__global__ void __launch_bounds__(256) bn_train_stats_kernel(long R, int C, const float* __restrict__ x, long ldx, double* part, unsigned* counters,
+                                                             const float* __restrict__ gamma, float eps, float momentum, float* running_mean,
+                                                             float* running_var, long long* num_batches, float* __restrict__ mean,
+                                                             float* __restrict__ rstd, float* __restrict__ scale) {
+    colstat_partial<2>(R, C, part, [&](long r, int c, double (&v)[2]) {
+        const double t = (double)x[r * ldx + c];
+        v[0] = t; v[1] = t * t;
+    });
+    if (!etch_last_block(counters + blockIdx.y, gridDim.x)) return;
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+    long long nb = 0;
+    if (num_batches) nb = *num_batches + 1;              // read only: the apply kernel behind this one counts the call (no column group races another's read)
+    if ((threadIdx.x >> 6) == 0 && c < C) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < TO_CHUNKS; ++k) { s1 += part[((size_t)k * 2 + 0) * C + c]; s2 += part[((size_t)k * 2 + 1) * C + c]; }
+        const double m = s1 / (double)R;
+        double v = s2 / (double)R - m * m;
+        if (v < 0.0) v = 0.0;
+        const float mf = (float)m, vf = (float)v, rs = rsqrtf(vf + eps);
+        mean[c] = mf; rstd[c] = rs; scale[c] = gamma[c] * rs;
+        if (running_mean && running_var) {
+            const float mom = momentum >= 0.f ? momentum : (float)(1.0 / (double)(nb > 0 ? nb : 1));
+            const float unbiased = vf * (float)((double)R / (double)(R > 1 ? R - 1 : 1));
+            running_mean[c] = fmaf(mom, mf, running_mean[c] * (1.f - mom));
+            running_var[c] = fmaf(mom, unbiased, running_var[c] * (1.f - mom));
+        }
+    }
+}
+
 // centred before scaling: x * scale + (beta - mean * scale) cancels when |x - mean| << |x|
 __global__ void __launch_bounds__(256) bn_apply_kernel(long n, int C, const float* __restrict__ x, long ldx, const float* __restrict__ mean,
-                                                       const float* __restrict__ scale, const float* __restrict__ beta, int relu, float* __restrict__ y) {
+                                                       const float* __restrict__ scale, const float* __restrict__ beta, int relu, float* __restrict__ y,
+                                                       long long* count_call) {
+    if (count_call && blockIdx.x == 0 && threadIdx.x == 0) *count_call += 1;          // num_batches_tracked (etch_bn_train_forward)
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const long r = i / C;
         const int c = (int)(i - r * C);
@@ -81,6 +116,25 @@ __global__ void bn_bwd_final_kernel(int C, const double* __restrict__ part, floa
     double s1 = 0.0, s2 = 0.0;
     for (int k = 0; k < TO_CHUNKS; ++k) { s1 += part[((size_t)k * 2 + 0) * C + c]; s2 += part[((size_t)k * 2 + 1) * C + c]; }
     dbeta[c] = (float)s1; dgamma[c] = (float)s2;
+}
+// the two kernels above in one launch (the last workgroup of a column group sums its partials in chunk order)
+__global__ void __launch_bounds__(256) bn_bwd_stats_kernel(long R, int C, const float* __restrict__ x, long ldx, const float* __restrict__ y,
+                                                           const float* __restrict__ dy, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, int relu, double* part, unsigned* counters,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    colstat_partial<2>(R, C, part, [&](long r, int c, double (&v)[2]) {
+        float g = dy[r * C + c];
+        if (relu && !(y[r * C + c] > 0.f)) g = 0.f;
+        const float xh = (x[r * ldx + c] - mean[c]) * rstd[c];
+        v[0] = (double)g; v[1] = (double)g * (double)xh;
+    });
+    if (!etch_last_block(counters + blockIdx.y, gridDim.x)) return;
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+    if ((threadIdx.x >> 6) == 0 && c < C) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < TO_CHUNKS; ++k) { s1 += part[((size_t)k * 2 + 0) * C + c]; s2 += part[((size_t)k * 2 + 1) * C + c]; }
+        dbeta[c] = (float)s1; dgamma[c] = (float)s2;
+    }
 }
 // train: dx = gamma rstd (g - s1/R - xhat s2/R);  eval (statistics are constants): dx = gamma rstd g
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(long R, int C, const float* __restrict__ x, long ldx, const float* __restrict__ y,
@@ -193,7 +247,7 @@ int etch_bn_stats(long R, int C, const float* x, long ldx, double* workspace, fl
 int etch_bn_apply(long R, int C, const float* x, long ldx, const float* mean, const float* scale, const float* beta, int relu, float* y, void* stream) {
     if (R <= 0 || C <= 0) return ETCH_OK;
     if (!x || !mean || !scale || !beta || !y || ldx < C) return ETCH_EINVAL;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(to_grid(R * C)), dim3(256), 0, (hipStream_t)stream, R * C, C, x, ldx, mean, scale, beta, relu, y);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(to_grid(R * C)), dim3(256), 0, (hipStream_t)stream, R * C, C, x, ldx, mean, scale, beta, relu, y, (long long*)nullptr);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }
@@ -205,6 +259,36 @@ int etch_bn_backward(long R, int C, const float* x, long ldx, const float* y, co
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(TO_CHUNKS, (C + 63) / 64), dim3(256), 0, st, R, C, x, ldx, y, dy, mean, rstd, relu, workspace);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, C, workspace, dgamma, dbeta);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    if (dx) {
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(to_grid(R * C)), dim3(256), 0, st, R, C, x, ldx, y, dy, mean, rstd, gamma, dgamma, dbeta, relu, train, dx);
+        ETCH_RETURN_IF_LAUNCH_FAILED();
+    }
+    return ETCH_OK;
+}
+
+int etch_bn_train_forward(long R, int C, const float* x, long ldx, const float* gamma, const float* beta, float eps, float momentum,
+                          float* running_mean, float* running_var, long long* num_batches, int relu, double* workspace, unsigned* counters,
+                          float* mean, float* rstd, float* scale, float* y, void* stream) {
+    if (R <= 0 || C <= 0 || !x || !gamma || !beta || !workspace || !counters || !mean || !rstd || !scale || !y || ldx < C) return ETCH_EINVAL;
+    if ((C + 63) / 64 > ETCH_REDUCE_COUNTERS) return ETCH_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_train_stats_kernel, dim3(TO_CHUNKS, (C + 63) / 64), dim3(256), 0, st, R, C, x, ldx, workspace, counters, gamma, eps, momentum,
+                       running_mean, running_var, num_batches, mean, rstd, scale);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(to_grid(R * C)), dim3(256), 0, st, R * C, C, x, ldx, mean, scale, beta, relu, y, num_batches);
+    ETCH_RETURN_IF_LAUNCH_FAILED();
+    return ETCH_OK;
+}
+
+int etch_bn_backward_fused(long R, int C, const float* x, long ldx, const float* y, const float* dy, const float* mean, const float* rstd,
+                           const float* gamma, int relu, int train, double* workspace, unsigned* counters, float* dx, float* dgamma, float* dbeta,
+                           void* stream) {
+    if (R <= 0 || C <= 0 || !x || !dy || !mean || !rstd || !gamma || !workspace || !counters || !dgamma || !dbeta || ldx < C || (relu && !y)) return ETCH_EINVAL;
+    if ((C + 63) / 64 > ETCH_REDUCE_COUNTERS) return ETCH_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(TO_CHUNKS, (C + 63) / 64), dim3(256), 0, st, R, C, x, ldx, y, dy, mean, rstd, relu, workspace, counters,
+                       dgamma, dbeta);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     if (dx) {
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(to_grid(R * C)), dim3(256), 0, st, R, C, x, ldx, y, dy, mean, rstd, gamma, dgamma, dbeta, relu, train, dx);

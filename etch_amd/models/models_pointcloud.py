@@ -191,7 +191,7 @@ class GT_network_equiv(nn.Module):
             for conv in block.blocks:
                 ic, itc = conv.inter_conv.conv, conv.intra_conv.conv
                 ball, sidx, new_xyz = ic.group(xyz)
-                rk = ic._derived()[0]
+                rk = ic.rotated_kernels()
                 y = A.inter_so3conv(feats, ic.basic_conv.W, ic.basic_conv.bias, xyz, new_xyz, ball, rk, ic.sigma)
                 y = A.instnorm_leaky_relu(y)
                 z = A.instnorm_leaky_relu(A.intra_so3conv(y, itc.basic_conv.W, itc.basic_conv.bias, itc.intra_idx))

@@ -261,8 +261,18 @@ def inter_weight_frag(W, cin, ks=24):
     return permute_weight_frag(W[:, _inter_contraction_cols(cin, ks, W.device)].contiguous())
 
 
+_CONTRACTION_COLS = {}
+
+
 def _inter_contraction_cols(cin, ks, device):
-    """Column permutation of W [cout, cin*ks] into the contraction order of inter_so3conv_kernel (see inter_weight_frag)."""
+    """Column permutation of W [cout, cin*ks] into the contraction order of inter_so3conv_kernel (see inter_weight_frag); one upload per (shape, device)."""
+    key = (cin, ks, str(device))
+    if key not in _CONTRACTION_COLS:
+        _CONTRACTION_COLS[key] = _inter_contraction_cols_build(cin, ks, device)
+    return _CONTRACTION_COLS[key]
+
+
+def _inter_contraction_cols_build(cin, ks, device):
     cch = min(cin, 64)
     vec = cch // 16
     halves = 2 if cch >= 32 else 1

@@ -135,6 +135,7 @@ class InterSO3Conv(nn.Module):
         self.register_buffer("anchors", torch.from_numpy(K.get_anchors(kanchor)))
         self.register_buffer("kernels", torch.from_numpy(kernels))
         self._d = _Derived()
+        self._drk = _Derived()
         self._d32 = _Derived()
         self._dq = _Derived()
         self._dqn = _Derived()
@@ -142,17 +143,24 @@ class InterSO3Conv(nn.Module):
         self._dkq = _Derived()
         self._dqh = _Derived()
 
+    def rotated_kernels(self):
+        """Rotated kernel points exactly as functional.py:296 (CPU matmul, then uploaded) [60, 24, 3]; constants of the module: not rebuilt when W changes
+        (a training step would pay a device -> host round trip per conv, and could not be captured into a graph)."""
+        def build_rk():
+            rk = torch.matmul(self.anchors.cpu(), self.kernels.cpu().transpose(0, 1)).permute(0, 2, 1).contiguous()
+            return rk.to(self.anchors.device)
+
+        return self._drk.get((self.anchors, self.kernels), build_rk)
+
     def _derived(self):
         W, bias = self.basic_conv.W, self.basic_conv.bias
 
         def build():
-            # rotated kernel points exactly as functional.py:296 (CPU matmul, then uploaded)
-            rk = torch.matmul(self.anchors.cpu(), self.kernels.cpu().transpose(0, 1)).permute(0, 2, 1).contiguous()  # [60, 24, 3]
             Wd = W.detach().contiguous()
             Wp = ops.inter_weight_frag(Wd, self.dim_in, self.kernel_size) if self.dim_in % 16 == 0 else None
-            return rk.to(W.device), Wd, Wp, bias.detach().reshape(-1).contiguous()
+            return Wd, Wp, bias.detach().reshape(-1).contiguous()
 
-        return self._d.get((W, bias, self.anchors, self.kernels), build)
+        return (self.rotated_kernels(),) + self._d.get((W, bias), build)
 
     def _wp32(self):
         """Weight in the fragment order of the 32x32x2 kernel (csrc/so3conv32.hip), for the widths it covers; else None."""
@@ -194,7 +202,7 @@ class InterSO3Conv(nn.Module):
         """Kernel-point factor of the weights' pre-activation (etch_inter_so3conv_planes_kq); None where that kernel is not used."""
         if not (ops.INTER_KQ and self.wants_planes()):
             return None
-        rk = self._derived()[0]
+        rk = self.rotated_kernels()
         return self._dkq.get((self.anchors, self.kernels), lambda: ops.inter_kpoint_operand(rk, self.sigma))
 
     def wants_planes(self):

@@ -474,6 +474,11 @@ int etch_inter_x1_rows(int b, int cin, int p1, int p2, int p_begin, int pc, int 
 int etch_gemm_tn_workspace_floats(long R, int M, int N);
 int etch_gemm_tn(long R, int M, int N, const float* A, long lda, const float* B, long ldb, float* C, int accumulate, float* workspace,
                  void* stream);
+/* etch_gemm_tn in ONE launch: the workgroup of a 64 x 64 tile of C that finishes last sums the tile's partials in split order (bit for bit
+ * etch_gemm_tn's result).  counters: 64 unsigned, zero before the first call, left zero (see etch_bn_train_forward); more than 64 tiles: the
+ * two-launch form. */
+int etch_gemm_tn_fused(long R, int M, int N, const float* A, long lda, const float* B, long ldb, float* C, int accumulate, float* workspace,
+                       unsigned* counters, void* stream);
 
 /* d feats of the inter conv from d x1 of the output points [p_begin, p_begin + pc): dfeats (b,p1,60,cin) (+)= the gather-side sum over
  * the neighbour slots (p,n) with idx[b,p,n] == q, taken in slot order.  cin in {4..64}, multiple of 4. */
@@ -507,6 +512,20 @@ int etch_bn_apply(long R, int C, const float* x, long ldx, const float* mean, co
  * workspace: 64 * 2 * C doubles. */
 int etch_bn_backward(long R, int C, const float* x, long ldx, const float* y, const float* dy, const float* mean, const float* rstd, const float* gamma,
                      int relu, int train, double* workspace, float* dx, float* dgamma, float* dbeta, void* stream);
+/* Round 6 -- the same reductions in ONE launch each (the workgroup that finishes last sums the partials in their fixed order: results bit for bit those
+ * of the two-launch forms above).  counters: ETCH_REDUCE_COUNTERS (64) unsigned, ZERO before the first call and left zero by every call; calls that
+ * share `counters` / `workspace` must be ordered on one stream.
+ * etch_bn_train_forward = torch.nn.functional.batch_norm(training=True) (+ ReLU) on rows (pointtransformer_seg.py's nn.BatchNorm1d in train() mode,
+ * train.py:77-101): batch statistics -> mean, rstd = 1/sqrt(var + eps), scale = gamma rstd (kept for the backward), y = act((x - mean) scale + beta),
+ * and -- when running_mean / running_var are given -- running = (1 - momentum) running + momentum {mean, unbiased var} (momentum < 0: the cumulative
+ * average over *num_batches + 1 calls); *num_batches += 1 when given.  2 launches.  workspace: 64 * 2 * C doubles; C <= 4096. */
+int etch_bn_train_forward(long R, int C, const float* x, long ldx, const float* gamma, const float* beta, float eps, float momentum,
+                          float* running_mean, float* running_var, long long* num_batches, int relu, double* workspace, unsigned* counters,
+                          float* mean, float* rstd, float* scale, float* y, void* stream);
+/* etch_bn_backward with the column sums and their final reduction in one launch (2 launches with dx). */
+int etch_bn_backward_fused(long R, int C, const float* x, long ldx, const float* y, const float* dy, const float* mean, const float* rstd,
+                           const float* gamma, int relu, int train, double* workspace, unsigned* counters, float* dx, float* dgamma, float* dbeta,
+                           void* stream);
 /* Backward of etch_rows_maxpool (nn.MaxPool1d(nsample), pointtransformer_seg.py:66): dy (m*ns,c) = dout at the first maximum of each group. */
 int etch_rows_maxpool_backward(long m, int ns, int c, const float* y, const float* dout, float* dy, void* stream);
 /* The tail of PointTransformerLayer.forward (pointtransformer_seg.py:34-36): softmax over the ns neighbours of logit (n*ns, cs), then
@@ -525,6 +544,10 @@ int etch_mhsa_attention_backward_dim(long T, int embedding_dim, const float* qkv
 
 /* Column sums s[c] = sum_r x[r,c] (bias gradients): fp64, two levels, fixed order.  workspace: 64*C doubles. */
 int etch_colsum(long R, int C, const float* x, double* workspace, float* out, void* stream);
+
+/* The same in one coalesced launch (x with leading dimension ldx; counters / ordering as etch_bn_train_forward); C > 4096: the two-launch form
+ * (which needs ldx == C). */
+int etch_colsum_fused(long R, int C, const float* x, long ldx, double* workspace, unsigned* counters, float* out, void* stream);
 
 /* d/dx of leaky_relu(InstanceNorm2d(x), slope) (so3conv.py:36-44): x, dy (b,rows,C) channels-last, mean / rstd (b,C) of the forward. */
 int etch_instnorm_act_backward_workspace_bytes(int b, int C);

@@ -229,3 +229,82 @@ def test_model_with_and_without_the_paired_fps_is_bitwise_identical(tmp_path):
             assert torch.equal(res[k], out[k]), (k, on)
     from etch_amd import ops
     assert not ops._FPS_READY
+
+
+# ---------------------------------------------------------------------------------------------- one-launch reductions of the training kernels
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,M,N", [(80000, 32, 32), (5000, 64, 1536), (300000, 64, 128), (2000, 4, 3), (50, 512, 512), (777, 32, 48), (1, 16, 16),
+                                   (4097, 33, 31), (1250, 512, 64)])
+def test_gemm_tn_one_launch_is_bitwise_the_two_launch_form_and_exact_to_fp64(R, M, N):
+    """etch_gemm_tn_fused (the workgroup of a tile that finishes last sums the tile's partials in split order) against etch_gemm_tn (partials + a
+    reduction launch): the same bits, with and without accumulation; both within fp32 rounding of the fp64 product (fp64 matrix cores); the counters
+    are left at zero; strided operands (column windows of wider matrices)."""
+    import ctypes
+    from etch_amd import _lib, autograd as A
+    from etch_amd.ops import _ptr, _stream
+    rng = np.random.default_rng(R + M + N)
+    a_full = torch.from_numpy(rng.standard_normal((R, M + 5)).astype(np.float32)).cuda()
+    b_full = torch.from_numpy(rng.standard_normal((R, N + 3)).astype(np.float32)).cuda()
+    a, bm = a_full[:, 2:2 + M], b_full[:, 1:1 + N]
+    ref = (a.double().t() @ bm.double())
+    c0 = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).cuda()
+    lib = _lib.lib()
+    nws = lib.etch_gemm_tn_workspace_floats(ctypes.c_long(R), M, N)
+    for accumulate in (0, 1):
+        two, one = c0.clone(), c0.clone()
+        ws = torch.empty((nws,), dtype=torch.float32, device="cuda")
+        _lib.check(lib.etch_gemm_tn(ctypes.c_long(R), M, N, _ptr(a), ctypes.c_long(a.stride(0)), _ptr(bm), ctypes.c_long(bm.stride(0)), _ptr(two), accumulate,
+                                    _ptr(ws), _stream()), "etch_gemm_tn")
+        ws2 = torch.empty((nws,), dtype=torch.float32, device="cuda")
+        counters = A.reduce_counters(a.device)
+        _lib.check(lib.etch_gemm_tn_fused(ctypes.c_long(R), M, N, _ptr(a), ctypes.c_long(a.stride(0)), _ptr(bm), ctypes.c_long(bm.stride(0)), _ptr(one),
+                                          accumulate, _ptr(ws2), _ptr(counters), _stream()), "etch_gemm_tn_fused")
+        assert torch.equal(one, two)
+        want = (ref + c0.double()) if accumulate else ref
+        assert float((one.double() - want).abs().max()) <= 1.2e-7 * float(want.abs().max()) + 1e-30
+        assert int(counters.abs().sum()) == 0
+    again = A.gemm_tn(a, bm)
+    assert torch.equal(again, A.gemm_tn(a, bm))                     # run to run
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,C", [(80000, 32), (5000, 131), (3, 512), (1, 1), (300000, 64), (1000, 4100)])
+def test_colsum_one_launch(R, C):
+    """etch_colsum_fused: fp64 column sums in a fixed order, one launch (C > 4096: the two-launch form behind the same entry point)."""
+    from etch_amd import autograd as A
+    rng = np.random.default_rng(R + C)
+    x = torch.from_numpy((rng.standard_normal((R, C)) * 3 + 0.7).astype(np.float32)).cuda()
+    s = A.colsum(x)
+    ref = x.double().sum(0)
+    assert float((s.double() - ref).abs().max()) <= 1.2e-7 * float(ref.abs().max()) + 1e-30
+    assert torch.equal(s, A.colsum(x))
+    assert int(A.reduce_counters(x.device).abs().sum()) == 0
+
+
+@pytest.mark.gpu
+def test_batch_norm_train_forward_in_two_launches_matches_torch_over_many_calls():
+    """etch_bn_train_forward / etch_bn_backward_fused behind autograd_pt.batch_norm: ten consecutive train() calls on one module against
+    torch.nn.BatchNorm1d (+ ReLU) -- outputs, running statistics after every call (momentum 0.1 and the cumulative average momentum=None),
+    num_batches_tracked, gradients -- and the counters are zero afterwards."""
+    from etch_amd import autograd_pt as P, autograd as A
+    rng = np.random.default_rng(5)
+    for C, momentum in ((96, 0.1), (7, None), (512, 0.3)):
+        m, m2 = torch.nn.BatchNorm1d(C, momentum=momentum).cuda().train(), torch.nn.BatchNorm1d(C, momentum=momentum).cuda().train()
+        with torch.no_grad():
+            w = torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32)).cuda()
+            m.weight.copy_(w), m2.weight.copy_(w)
+        for it in range(10):
+            R = int(rng.integers(2, 3000))
+            x = torch.from_numpy((rng.standard_normal((R, C)) * (1 + it) + it).astype(np.float32)).cuda().requires_grad_()
+            x2 = x.detach().clone().requires_grad_()
+            y, y2 = P.batch_norm(x, m, relu=True), torch.relu(m2(x2))
+            assert float((y - y2).abs().max()) <= 2e-6 * float(y2.abs().max())
+            for got, want in ((m.running_mean, m2.running_mean), (m.running_var, m2.running_var)):
+                assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
+            assert int(m.num_batches_tracked) == int(m2.num_batches_tracked) == it + 1
+            g = torch.randn_like(y)
+            y.backward(g), y2.backward(g)
+            assert float((x.grad - x2.grad).abs().max()) <= 2e-4 * float(x2.grad.abs().max()) + 1e-6
+        assert float((m.weight.grad - m2.weight.grad).abs().max()) <= 1e-4 * float(m2.weight.grad.abs().max())
+        assert float((m.bias.grad - m2.bias.grad).abs().max()) <= 1e-4 * float(m2.bias.grad.abs().max())
+    assert int(A.reduce_counters(torch.device("cuda", 0)).abs().sum()) == 0

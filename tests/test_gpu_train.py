@@ -606,6 +606,9 @@ def test_eval_mode_takes_the_inference_path_and_train_mode_matches_it_on_running
     items = ["confidence", "direction", "magnitude"]
     with warnings.catch_warnings():
         warnings.simplefilter("error")
+        # the once-per-process notice that eval() with gradients enabled returns history-free results is expected here (whether it fires depends on
+        # which test ran first); anything else is an error
+        warnings.filterwarnings("ignore", message=r".*eval\(\) mode with gradients enabled.*")
         res0, _ = model(x, items, "standard_vector")
     assert not any(v.requires_grad for v in res0.values())
     model.differentiable = True
