@@ -13,6 +13,7 @@
 //   etch_instnorm_act_backward  d/dx of leaky_relu(InstanceNorm(x)) given dy, mean, rstd
 // Activations are channels-last ([b, p, 60, c]) as in the forward kernels.
 #include "common.h"
+#include "colstat.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define NA 60
@@ -146,6 +147,18 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(long R, int M, int N, cons
                 for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bq[j], acc[i][j], 0, 0, 0);
         }
     }
+    if (FUSED && nsp == 1) {                                       // one row range: the tile is complete -- no partials, no hand-over (the same bits: 0 + acc)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = m0 + wm + 16 * i + 4 * q + fg, n = n0 + wn + 16 * j + fr;
+                    if (m < M && n < N) C[(size_t)m * N + n] = (float)((accumulate ? (double)C[(size_t)m * N + n] : 0.0) + acc[i][j][q]);
+                }
+        return;
+    }
     double* P = part + (size_t)sp * M * N;
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -164,7 +177,13 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(long R, int M, int N, cons
             if (m >= M || n >= N) continue;
             const size_t i = (size_t)m * N + n;
             double s = accumulate ? (double)C[i] : 0.0;
-            for (int k = 0; k < nsp; ++k) s += part[(size_t)k * MN + i];
+            for (int k = 0; k < nsp; k += 8) {                      // eight loads in flight (after the acquire they come from memory), added in split order
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = k + q < nsp ? part[(size_t)(k + q) * MN + i] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (k + q < nsp) s += v[q];
+            }
             C[i] = (float)s;
         }
     }
@@ -287,25 +306,19 @@ __global__ void colsum_final_kernel(int C, int nparts, const double* __restrict_
     out[c] = (float)s;
 }
 
-// Round 6: one launch, coalesced.  block = 64 columns x 4 row lanes, grid (64 row chunks, C / 64 column groups); the last workgroup of a column group
-// (common.h: etch_last_block) sums the group's 64 chunk partials in chunk order.  (The two kernels above give one column to a workgroup: a stride-C walk.)
+// Round 6: one launch (colstat.h: 16-byte loads, as many row lanes as the width leaves room for, the last workgroup folds the chunks).  The two
+// kernels above give one column to a workgroup -- a stride-C walk.
+struct ColsumLoad {
+    const float* x; long ldx;
+    template <int W> __device__ __forceinline__ void load(long r, int c, double (&v)[1][W]) const {
+        if (W == 4) { const float4 q = *reinterpret_cast<const float4*>(x + r * ldx + c); v[0][0] = q.x; v[0][1] = q.y; v[0][2] = q.z; v[0][W - 1] = q.w; }
+        else v[0][0] = (double)x[r * ldx + c];
+    }
+};
+template <int W>
 __global__ void __launch_bounds__(256) colsum_fused_kernel(long R, int C, const float* __restrict__ x, long ldx, double* part, unsigned* counters,
                                                            float* __restrict__ out) {
-    __shared__ double red[256];
-    const int tid = threadIdx.x, cl = tid & 63, rl = tid >> 6, c = blockIdx.y * 64 + cl, nb = gridDim.x;
-    const long r_begin = R * blockIdx.x / nb, r_end = R * (blockIdx.x + 1) / nb;
-    double s = 0.0;
-    if (c < C)
-        for (long r = r_begin + rl; r < r_end; r += 4) s += (double)x[r * ldx + c];
-    red[tid] = s;
-    __syncthreads();
-    if (rl == 0 && c < C) part[(size_t)blockIdx.x * C + c] = ((red[cl] + red[64 + cl]) + red[128 + cl]) + red[192 + cl];
-    if (!etch_last_block(counters + blockIdx.y, (unsigned)nb)) return;
-    if (rl == 0 && c < C) {
-        double t = 0.0;
-        for (int k = 0; k < nb; ++k) t += part[(size_t)k * C + c];
-        out[c] = (float)t;
-    }
+    colstat_run<1, W>(R, C, part, counters, ColsumLoad{x, ldx}, [&](int c, const double (&s)[1]) { out[c] = (float)s[0]; });
 }
 
 // ---------------------------------------------------------------------------------------------- InstanceNorm + LeakyReLU backward
@@ -457,7 +470,10 @@ int etch_colsum_fused(long R, int C, const float* x, long ldx, double* workspace
     if (C <= 0) return ETCH_OK;
     if (R < 0 || !x || !workspace || !counters || !out || ldx < C) return ETCH_EINVAL;
     if ((C + 63) / 64 > ETCH_REDUCE_COUNTERS) return ldx == C ? etch_colsum(R, C, x, workspace, out, stream) : ETCH_EUNSUPPORTED;
-    hipLaunchKernelGGL(colsum_fused_kernel, dim3(64, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream, R, C, x, ldx, workspace, counters, out);
+    if (colstat_vec_ok(C, ldx, x))
+        hipLaunchKernelGGL(colsum_fused_kernel<4>, dim3(colstat_chunks(R), colstat_groups<4>(C)), dim3(256), 0, (hipStream_t)stream, R, C, x, ldx, workspace, counters, out);
+    else
+        hipLaunchKernelGGL(colsum_fused_kernel<1>, dim3(colstat_chunks(R), colstat_groups<1>(C)), dim3(256), 0, (hipStream_t)stream, R, C, x, ldx, workspace, counters, out);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     return ETCH_OK;
 }

@@ -7,6 +7,7 @@
 //   etch_pt_softmax_agg        out[i, s*cs + j] = sum_k softmax_k(logit[i, k, j]) v[i, k, s*cs + j]   (pointtransformer_seg.py:34-36) and its backward
 // Reductions are fixed-order (no atomics): gradients are reproducible run to run.
 #include "common.h"
+#include "colstat.h"
 
 #define TO_CHUNKS 64
 
@@ -57,33 +58,36 @@ __global__ void bn_stats_final_kernel(long R, int C, const double* __restrict__ 
 // column group (common.h: etch_last_block) sums the group's partials in chunk order (= bn_stats_final_kernel's sums, bit for bit) and writes mean,
 // rstd = 1 / sqrt(var + eps), scale = gamma rstd, the running statistics (momentum < 0: the cumulative average 1 / num_batches_tracked) and
 // num_batches_tracked.  Before: 2 launches here + 9 element-wise torch launches per BatchNorm call, 246 calls per training step.
+struct BnStatsLoad {
+    const float* x; long ldx;
+    template <int W> __device__ __forceinline__ void load(long r, int c, double (&v)[2][W]) const {
+        float t[W];
+        if (W == 4) { const float4 q = *reinterpret_cast<const float4*>(x + r * ldx + c); t[0] = q.x; t[1] = q.y; t[2] = q.z; t[W - 1] = q.w; }
+        else t[0] = x[r * ldx + c];
+#pragma unroll
+        for (int j = 0; j < W; ++j) { v[0][j] = (double)t[j]; v[1][j] = (double)t[j] * (double)t[j]; }
+    }
+};
+template <int W>
 __global__ void __launch_bounds__(256) bn_train_stats_kernel(long R, int C, const float* __restrict__ x, long ldx, double* part, unsigned* counters,
                                                              const float* __restrict__ gamma, float eps, float momentum, float* running_mean,
-                                                             float* running_var, long long* num_batches, float* __restrict__ mean,
+                                                             float* running_var, const long long* num_batches, float* __restrict__ mean,
                                                              float* __restrict__ rstd, float* __restrict__ scale) {
-    colstat_partial<2>(R, C, part, [&](long r, int c, double (&v)[2]) {
-        const double t = (double)x[r * ldx + c];
-        v[0] = t; v[1] = t * t;
-    });
-    if (!etch_last_block(counters + blockIdx.y, gridDim.x)) return;
-    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
-    long long nb = 0;
-    if (num_batches) nb = *num_batches + 1;              // read only: the apply kernel behind this one counts the call (no column group races another's read)
-    if ((threadIdx.x >> 6) == 0 && c < C) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < TO_CHUNKS; ++k) { s1 += part[((size_t)k * 2 + 0) * C + c]; s2 += part[((size_t)k * 2 + 1) * C + c]; }
-        const double m = s1 / (double)R;
-        double v = s2 / (double)R - m * m;
+    colstat_run<2, W>(R, C, part, counters, BnStatsLoad{x, ldx}, [&](int c, const double (&s)[2]) {
+        const double m = s[0] / (double)R;
+        double v = s[1] / (double)R - m * m;
         if (v < 0.0) v = 0.0;
         const float mf = (float)m, vf = (float)v, rs = rsqrtf(vf + eps);
         mean[c] = mf; rstd[c] = rs; scale[c] = gamma[c] * rs;
         if (running_mean && running_var) {
+            // num_batches is read only here (every column sees the value of before this call); the apply kernel behind this one counts the call
+            const long long nb = num_batches ? *num_batches + 1 : 1;
             const float mom = momentum >= 0.f ? momentum : (float)(1.0 / (double)(nb > 0 ? nb : 1));
             const float unbiased = vf * (float)((double)R / (double)(R > 1 ? R - 1 : 1));
             running_mean[c] = fmaf(mom, mf, running_mean[c] * (1.f - mom));
             running_var[c] = fmaf(mom, unbiased, running_var[c] * (1.f - mom));
         }
-    }
+    });
 }
 
 // centred before scaling: x * scale + (beta - mean * scale) cancels when |x - mean| << |x|
@@ -118,23 +122,34 @@ __global__ void bn_bwd_final_kernel(int C, const double* __restrict__ part, floa
     dbeta[c] = (float)s1; dgamma[c] = (float)s2;
 }
 // the two kernels above in one launch (the last workgroup of a column group sums its partials in chunk order)
+struct BnBwdLoad {
+    const float *x, *y, *dy, *mean, *rstd; long ldx; int C, relu;
+    template <int W> __device__ __forceinline__ void load(long r, int c, double (&v)[2][W]) const {
+        float g[W], xv[W], yv[W];
+        if (W == 4) {
+            const float4 q = *reinterpret_cast<const float4*>(dy + r * C + c), p = *reinterpret_cast<const float4*>(x + r * ldx + c);
+            g[0] = q.x; g[1] = q.y; g[2] = q.z; g[W - 1] = q.w; xv[0] = p.x; xv[1] = p.y; xv[2] = p.z; xv[W - 1] = p.w;
+            if (relu) { const float4 o = *reinterpret_cast<const float4*>(y + r * C + c); yv[0] = o.x; yv[1] = o.y; yv[2] = o.z; yv[W - 1] = o.w; }
+        } else {
+            g[0] = dy[r * C + c]; xv[0] = x[r * ldx + c];
+            if (relu) yv[0] = y[r * C + c];
+        }
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const float gg = relu && !(yv[j] > 0.f) ? 0.f : g[j];
+            const float xh = (xv[j] - mean[c + j]) * rstd[c + j];
+            v[0][j] = (double)gg; v[1][j] = (double)gg * (double)xh;
+        }
+    }
+};
+template <int W>
 __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(long R, int C, const float* __restrict__ x, long ldx, const float* __restrict__ y,
                                                            const float* __restrict__ dy, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, int relu, double* part, unsigned* counters,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    colstat_partial<2>(R, C, part, [&](long r, int c, double (&v)[2]) {
-        float g = dy[r * C + c];
-        if (relu && !(y[r * C + c] > 0.f)) g = 0.f;
-        const float xh = (x[r * ldx + c] - mean[c]) * rstd[c];
-        v[0] = (double)g; v[1] = (double)g * (double)xh;
+    colstat_run<2, W>(R, C, part, counters, BnBwdLoad{x, y, dy, mean, rstd, ldx, C, relu}, [&](int c, const double (&s)[2]) {
+        dbeta[c] = (float)s[0]; dgamma[c] = (float)s[1];
     });
-    if (!etch_last_block(counters + blockIdx.y, gridDim.x)) return;
-    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
-    if ((threadIdx.x >> 6) == 0 && c < C) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < TO_CHUNKS; ++k) { s1 += part[((size_t)k * 2 + 0) * C + c]; s2 += part[((size_t)k * 2 + 1) * C + c]; }
-        dbeta[c] = (float)s1; dgamma[c] = (float)s2;
-    }
 }
 // train: dx = gamma rstd (g - s1/R - xhat s2/R);  eval (statistics are constants): dx = gamma rstd g
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(long R, int C, const float* __restrict__ x, long ldx, const float* __restrict__ y,
@@ -273,8 +288,12 @@ int etch_bn_train_forward(long R, int C, const float* x, long ldx, const float* 
     if (R <= 0 || C <= 0 || !x || !gamma || !beta || !workspace || !counters || !mean || !rstd || !scale || !y || ldx < C) return ETCH_EINVAL;
     if ((C + 63) / 64 > ETCH_REDUCE_COUNTERS) return ETCH_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_train_stats_kernel, dim3(TO_CHUNKS, (C + 63) / 64), dim3(256), 0, st, R, C, x, ldx, workspace, counters, gamma, eps, momentum,
-                       running_mean, running_var, num_batches, mean, rstd, scale);
+    if (colstat_vec_ok(C, ldx, x))
+        hipLaunchKernelGGL(bn_train_stats_kernel<4>, dim3(colstat_chunks(R), colstat_groups<4>(C)), dim3(256), 0, st, R, C, x, ldx, workspace, counters, gamma, eps,
+                           momentum, running_mean, running_var, num_batches, mean, rstd, scale);
+    else
+        hipLaunchKernelGGL(bn_train_stats_kernel<1>, dim3(colstat_chunks(R), colstat_groups<1>(C)), dim3(256), 0, st, R, C, x, ldx, workspace, counters, gamma, eps,
+                           momentum, running_mean, running_var, num_batches, mean, rstd, scale);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     hipLaunchKernelGGL(bn_apply_kernel, dim3(to_grid(R * C)), dim3(256), 0, st, R * C, C, x, ldx, mean, scale, beta, relu, y, num_batches);
     ETCH_RETURN_IF_LAUNCH_FAILED();
@@ -287,8 +306,12 @@ int etch_bn_backward_fused(long R, int C, const float* x, long ldx, const float*
     if (R <= 0 || C <= 0 || !x || !dy || !mean || !rstd || !gamma || !workspace || !counters || !dgamma || !dbeta || ldx < C || (relu && !y)) return ETCH_EINVAL;
     if ((C + 63) / 64 > ETCH_REDUCE_COUNTERS) return ETCH_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(TO_CHUNKS, (C + 63) / 64), dim3(256), 0, st, R, C, x, ldx, y, dy, mean, rstd, relu, workspace, counters,
-                       dgamma, dbeta);
+    if (colstat_vec_ok(C, ldx, x, dy, relu ? y : nullptr))
+        hipLaunchKernelGGL(bn_bwd_stats_kernel<4>, dim3(colstat_chunks(R), colstat_groups<4>(C)), dim3(256), 0, st, R, C, x, ldx, y, dy, mean, rstd, relu, workspace,
+                           counters, dgamma, dbeta);
+    else
+        hipLaunchKernelGGL(bn_bwd_stats_kernel<1>, dim3(colstat_chunks(R), colstat_groups<1>(C)), dim3(256), 0, st, R, C, x, ldx, y, dy, mean, rstd, relu, workspace,
+                           counters, dgamma, dbeta);
     ETCH_RETURN_IF_LAUNCH_FAILED();
     if (dx) {
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(to_grid(R * C)), dim3(256), 0, st, R, C, x, ldx, y, dy, mean, rstd, gamma, dgamma, dbeta, relu, train, dx);
