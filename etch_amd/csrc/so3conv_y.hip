@@ -91,7 +91,7 @@ struct H32Step2 {
     // the first RD - 1 batches (before the barrier in front of the first half)
     __device__ __forceinline__ void prime(const bf16x8* __restrict__ Wq, int wave, int lane) {
 #pragma unroll
-        for (int i = 0; i < NPRIME; ++i) issue(i, Wq, wave, lane);
+        for (int i = 0; i < RD - 1; ++i) issue(i, Wq, wave, lane);
     }
     template <int N> __device__ __forceinline__ void wait(f32x4 (&v)[2]) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(v[0]), "+v"(v[1]) : "n"(N)); }
     // PF (the 64-channel kernel: one wave per SIMD, registers to spare): the X1 row of K step c + 1 is read while step c computes -- read where it is
@@ -100,66 +100,8 @@ struct H32Step2 {
 #define Y_S2_PF(CIN, COUT) ((CIN) >= 64)
 #endif
     static constexpr bool PF = Y_S2_PF(CIN, COUT);
-    // PAIR (the 64 -> 64 kernel: two output tiles, one wave per SIMD): the two batches of a K step are consumed TOGETHER, their MFMAs alternating between the
-    // two accumulators -- consecutive MFMAs are then independent (a chain of three dependent MFMAs per batch issues every ~46 instead of 32 cycles, and
-    // nothing else runs on the SIMD meanwhile).  Each accumulator still receives its products in the same order: bitwise the batch-by-batch results.
-    // (Also tried: the split of the NEXT K step's X1 row between the MFMAs, pinned with sched_barriers -- 75 - 164 spilled registers: the arch-VGPR
-    // budget of 256 holds at one wave per SIMD too, the other 256 are accumulator registers.)
-#ifndef Y_S2_PAIR
-#define Y_S2_PAIR(CIN, COUT) ((CIN) >= 64 && (COUT) == 64)
-#endif
-    static constexpr bool PAIR = MT2 == 2 && Y_S2_PAIR(CIN, COUT);
-    static constexpr int NPRIME = PAIR ? RD - 2 : RD - 1;
-    static_assert(!PAIR || (RD >= 4 && RD % 2 == 0), "pairs: an even ring of at least two pairs");
-    template <int N> __device__ __forceinline__ void wait2(f32x4 (&u)[2], f32x4 (&v)[2]) {
-        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(u[0]), "+v"(u[1]), "+v"(v[0]), "+v"(v[1]) : "n"(N));
-    }
-    template <int H>
-    __device__ __forceinline__ void half_pairs(f32x16 (&y)[MT2], const float* X1s, const bf16x8* __restrict__ Wq, int wave, int lane) {
-        const int an = lane & 31, kg = lane >> 5;
-        constexpr int TOT = 2 * NB;
-        f16x8 bq[2];
-        float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), xb = xa;
-        auto xrow = [&](int c) { return &X1s[an * S + (wave + 4 * c) * 16 + kg * 8]; };
-        if (PF) { xa = *reinterpret_cast<const float4*>(xrow(0)); xb = *reinterpret_cast<const float4*>(xrow(0) + 4); }
-#pragma unroll
-        for (int c = 0; c < NSW; ++c) {
-            const int i0 = H * NB + 2 * c;
-            asm volatile("" ::: "memory");             // keeps the X1 reads (and their splits) of later steps from being hoisted
-            if (PF) {
-                split2h_pack8(xa, xb, bq[0], bq[1]);
-                if (c + 1 < NSW) { xa = *reinterpret_cast<const float4*>(xrow(c + 1)); xb = *reinterpret_cast<const float4*>(xrow(c + 1) + 4); }
-            } else {
-                split2h_pack8(*reinterpret_cast<const float4*>(xrow(c)), *reinterpret_cast<const float4*>(xrow(c) + 4), bq[0], bq[1]);
-            }
-            if (i0 + RD - 2 < TOT) issue(i0 + RD - 2, Wq, wave, lane);
-            if (i0 + RD - 1 < TOT) issue(i0 + RD - 1, Wq, wave, lane);
-            const int younger = (i0 + RD - 1 < TOT ? RD - 2 : (TOT - 2 - i0 > 0 ? TOT - 2 - i0 : 0));      // batches behind the pair (two loads each, in order)
-            f32x4 (&a0)[2] = ra[i0 % RD];
-            f32x4 (&a1)[2] = ra[(i0 + 1) % RD];
-            static_assert(RD <= 8, "wait table");
-            if (younger >= 6) wait2<12>(a0, a1);
-            else if (younger == 5) wait2<10>(a0, a1);
-            else if (younger == 4) wait2<8>(a0, a1);
-            else if (younger == 3) wait2<6>(a0, a1);
-            else if (younger == 2) wait2<4>(a0, a1);
-            else if (younger == 1) wait2<2>(a0, a1);
-            else wait2<0>(a0, a1);
-            // smallest cross products first per accumulator (l * h, h * l, h * h), the two accumulators alternating
-            y[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[1]), bq[0], y[0], 0, 0, 0);
-            y[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[1]), bq[0], y[1], 0, 0, 0);
-            y[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[0]), bq[1], y[0], 0, 0, 0);
-            y[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[0]), bq[1], y[1], 0, 0, 0);
-            y[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[0]), bq[0], y[0], 0, 0, 0);
-            y[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[0]), bq[0], y[1], 0, 0, 0);
-            // both accumulators pinned in program order: left alone, the compiler sinks one accumulator's whole chain behind the other's (its operands then
-            // stay live over the half: 75 - 164 spilled registers)
-            asm volatile("" : "+a"(y[0]), "+a"(y[1]));
-        }
-    }
     template <int H>
     __device__ __forceinline__ void half(f32x16 (&y)[MT2], const float* X1s, const bf16x8* __restrict__ Wq, int wave, int lane) {
-        if constexpr (PAIR) { half_pairs<H>(y, X1s, Wq, wave, lane); return; }
         const int an = lane & 31, kg = lane >> 5;
         f16x8 bq[2];
         float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), xb = xa;
