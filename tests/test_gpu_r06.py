@@ -298,7 +298,7 @@ def test_batch_norm_train_forward_in_two_launches_matches_torch_over_many_calls(
             x = torch.from_numpy((rng.standard_normal((R, C)) * (1 + it) + it).astype(np.float32)).cuda().requires_grad_()
             x2 = x.detach().clone().requires_grad_()
             y, y2 = P.batch_norm(x, m, relu=True), torch.relu(m2(x2))
-            assert float((y - y2).abs().max()) <= 2e-6 * float(y2.abs().max())
+            assert float((y - y2).detach().abs().max()) <= 2e-6 * float(y2.detach().abs().max())
             for got, want in ((m.running_mean, m2.running_mean), (m.running_var, m2.running_var)):
                 assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
             assert int(m.num_batches_tracked) == int(m2.num_batches_tracked) == it + 1
