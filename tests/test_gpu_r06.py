@@ -308,3 +308,46 @@ def test_batch_norm_train_forward_in_two_launches_matches_torch_over_many_calls(
         assert float((m.weight.grad - m2.weight.grad).abs().max()) <= 1e-4 * float(m2.weight.grad.abs().max())
         assert float((m.bias.grad - m2.bias.grad).abs().max()) <= 1e-4 * float(m2.bias.grad.abs().max())
     assert int(A.reduce_counters(torch.device("cuda", 0)).abs().sum()) == 0
+
+
+@pytest.mark.gpu
+def test_last_workgroup_reductions_soak_under_contention():
+    """The hand-over of the one-launch reductions (common.h: etch_last_block -- partials, release fence, one atomic per workgroup, the last arrival
+    acquires and sums) across the eight XCDs' L2s: 400 rounds of randomly shaped weight gradients (bitwise against the two-launch form), column sums
+    and BatchNorm statistics (bitwise run to run) while a second stream keeps the memory system busy.  A lost or stale partial shows as a mismatch."""
+    import ctypes
+    from etch_amd import _lib, autograd as A, autograd_pt as P
+    from etch_amd.ops import _ptr, _stream
+    lib = _lib.lib()
+    rng = np.random.default_rng(12)
+    big = torch.randn(64 * 1024 * 1024 // 4, device="cuda")
+    side = torch.cuda.Stream()
+    shapes = [(80000, 32, 32), (20000, 128, 16), (5000, 64, 64), (1250, 128, 128), (300000, 64, 8), (4992, 256, 4), (312, 256, 256), (40000, 8, 64)]
+    data = {}
+    for (R, M, N) in shapes:
+        data[(R, M, N)] = (torch.randn(R, M, device="cuda"), torch.randn(R, N, device="cuda"))
+    ref = {}
+    for it in range(400):
+        if it % 8 == 0:
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    big.mul_(1.0000001)
+        R, M, N = shapes[int(rng.integers(len(shapes)))]
+        a, bm = data[(R, M, N)]
+        one = A.gemm_tn(a, bm)
+        cs = A.colsum(a)
+        m = torch.nn.BatchNorm1d(M).cuda().train()
+        y = P.batch_norm(a, m, relu=True)
+        key = (R, M, N)
+        if key not in ref:
+            two = torch.empty_like(one)
+            ws = torch.empty((lib.etch_gemm_tn_workspace_floats(ctypes.c_long(R), M, N),), dtype=torch.float32, device="cuda")
+            _lib.check(lib.etch_gemm_tn(ctypes.c_long(R), M, N, _ptr(a), ctypes.c_long(a.stride(0)), _ptr(bm), ctypes.c_long(bm.stride(0)), _ptr(two), 0, _ptr(ws),
+                                        _stream()), "etch_gemm_tn")
+            ref[key] = (two, cs.clone(), y.detach().clone(), m.running_var.clone())
+        two, cs0, y0, rv0 = ref[key]
+        assert torch.equal(one, two), (it, key)
+        assert torch.equal(cs, cs0), (it, key)
+        assert torch.equal(y.detach(), y0) and torch.equal(m.running_var, rv0), (it, key)
+    torch.cuda.synchronize()
+    assert int(A.reduce_counters(torch.device("cuda", 0)).abs().sum()) == 0
