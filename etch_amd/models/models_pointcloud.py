@@ -228,10 +228,18 @@ class GT_network_equiv(nn.Module):
         if direction_mode != "standard_vector":
             raise AssertionError("Not implemented")
         B, N, _ = hitpts.shape
+        # the index ops (FPS / ball queries of the encoder, FPS / kNN chain of the nets: functions of the coordinates only, no gradient) on the index
+        # stream like the inference path's: the nets' chain runs beside the encoder, and the two serial FPS launches of a small batch share one
+        idx_ready = None
+        if self.overlap_index_ops and hitpts.is_cuda:
+            epn_ready, idx_ready = self._prefetch_indices(hitpts.detach(), B, N, "confidence" in pred_items or "magnitude" in pred_items)
+            torch.cuda.current_stream().wait_event(epn_ready)
         xyz, feats_cl, anchors = self.encode_differentiable(hitpts)
         idx3, w3 = ops.prop3nn(hitpts, xyz)
         tokens = A.prop_interp(feats_cl, idx3, w3)                                 # (B,N,60,C): models_pointcloud.py:181-183
         results = {}
+        if idx_ready is not None:
+            torch.cuda.current_stream().wait_event(idx_ready)
         if "confidence" in pred_items or "magnitude" in pred_items:
             inv = tokens.mean(2)                                                    # the anchor mean (:184)
             pxo = self.preprocess_data(hitpts, inv)
