@@ -18,6 +18,10 @@ def _check(status, what):
     _lib.check(status, what)
 
 
+import os
+
+SLOT_DFEAT = os.environ.get("ETCH_SLOT_DFEAT", "1") != "0"      # the inter conv's feature gradient from the target side (round 6; 0: inter_dfeat_kernel)
+CHUNK_BYTES = 1.2e9                                             # bound on each of a chunk's temporaries in the inter conv's backward
 _COUNTERS = {}
 
 
@@ -76,16 +80,35 @@ class InterSO3ConvFunction(torch.autograd.Function):
         lib = _lib.lib()
         need_df = ctx.needs_input_grad[0]
         dW = torch.zeros_like(W)
-        dfeats = torch.zeros_like(feats) if need_df else None
+        dfeats = None
         Wt = W.t().contiguous()                                              # (kk, cout): dX1 = dY W  as an NT product
-        for s in range(0, p2, ctx.chunk):
-            pc = min(ctx.chunk, p2 - s)
+        # chunks of output points: the X1 / dX1 rows (b pc 60 x cin 24) and the per-slot contributions (b pc nn x 60 cin) of a chunk stay under ~1.2 GB each;
+        # one chunk where that allows (a training batch of one scan: one sort of the slots per conv and step)
+        slots = SLOT_DFEAT and nn <= 64
+        per_point = 4 * b * max(na * kk, nn * na * cin if slots else 0)
+        chunk = max(ctx.chunk, min(p2, int(CHUNK_BYTES // per_point)))
+        for s in range(0, p2, chunk):
+            pc = min(chunk, p2 - s)
             x1 = torch.empty((b, pc, na, kk), dtype=torch.float32, device=feats.device)
             _check(lib.etch_inter_x1_rows(b, cin, p1, p2, s, pc, nn, _c_float(ctx.sigma), _ptr(xyz), _ptr(new_xyz), _ptr(idx), _ptr(feats), _ptr(rk),
                                           _ptr(x1), _stream()), "etch_inter_x1_rows")
             dyc = dy[:, s:s + pc].contiguous().view(b * pc * na, cout)
             gemm_tn(dyc, x1.view(b * pc * na, kk), out=dW, accumulate=True)   # dW += dY^T X1
-            if need_df:
+            if need_df and slots:
+                dx1 = ops.linear(dyc, Wt)                                    # (rows, kk) = dY W
+                contrib = torch.empty((b * pc * nn, na * cin), dtype=torch.float32, device=feats.device)
+                _check(lib.etch_inter_dfeat_slots(b, cin, p1, p2, s, pc, nn, _c_float(ctx.sigma), _ptr(xyz), _ptr(new_xyz), _ptr(idx), _ptr(rk), _ptr(dx1),
+                                                  _ptr(contrib), _stream()), "etch_inter_dfeat_slots")
+                del dx1
+                # rows of one source point, in slot order (stable sort): the reproducible scatter-add; padded slots (index < 0) go to a segment of their own
+                src = idx[:, s:s + pc].long() + (torch.arange(b, device=idx.device, dtype=torch.int64) * p1).view(b, 1, 1)
+                src = torch.where(idx[:, s:s + pc] < 0, torch.full_like(src, b * p1), src).reshape(-1)
+                part = segment_sum_rows(contrib, src, b * p1 + 1)[:b * p1].view(b, p1, na, cin)
+                dfeats = part if dfeats is None else dfeats.add_(part)
+                del contrib
+            elif need_df:
+                if dfeats is None:
+                    dfeats = torch.zeros_like(feats)
                 dx1 = ops.linear(dyc, Wt)                                    # (rows, kk) = dY W
                 _check(lib.etch_inter_dfeat(b, cin, p1, p2, s, pc, nn, _c_float(ctx.sigma), _ptr(xyz), _ptr(new_xyz), _ptr(idx), _ptr(rk), _ptr(dx1),
                                             _ptr(dfeats), 1, _stream()), "etch_inter_dfeat")

@@ -272,6 +272,51 @@ __global__ void __launch_bounds__(256) inter_dfeat_kernel(int cin, int cbase, in
     }
 }
 
+// Round 6: the same gradient from the TARGET side.  inter_dfeat_kernel above reads the whole dX1 tile of a target point (60 anchors x cin x 24 floats: 184 /
+// 368 KB) once per neighbour SLOT that points at its source -- nn times per target point, 12 GB per 1 024-point chunk, 9.5 ms of a training step.  Here a
+// workgroup owns a target point, reads its tile once (one anchor row at a time, transposed into LDS as [k][channel]) and writes the contribution of every
+// one of its nn slots:  contrib[b, p, n][a][c] = sum_k w[p, a, k, n] dX1[(p, a), c * 24 + k];  the caller then sums the rows of each SOURCE point in the
+// order of a stable sort of the slots by source (etch_segment_sum_rows: the reproducible scatter-add the Point-Transformer gathers already use).
+// thread <-> (4 channels, neighbour n0 + j * (256 / (cw / 4))): a slot's 4-channel pieces are contiguous in a row of contrib (cw bytes x 4 per 16 lanes).
+__global__ void __launch_bounds__(256) inter_dfeat_slots_kernel(int cin, int cbase, int cw, int p1, int p2, int p_begin, int pc, int nn, float inv_sigma,
+                                                                const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                                const int* __restrict__ ball_idx, const float* __restrict__ rk,
+                                                                const float* __restrict__ dx1, float* __restrict__ contrib) {
+    __shared__ float4 gs[64];                                 // per neighbour: 2 g / sigma, 1 - |g|^2 / sigma   (nn <= 64)
+    __shared__ __attribute__((aligned(16))) float dXs[KS * 64];          // this anchor's gradients, [k][channel of the window]
+    const int tid = threadIdx.x, b = blockIdx.y, pl = blockIdx.x, p = p_begin + pl, kk = cin * KS;
+    const float* X = xyz + (size_t)b * 3 * p1;
+    if (tid < nn) {
+        const int q = ball_idx[((size_t)b * p2 + p) * nn + tid], qq = q < 0 ? 0 : q;
+        const float gx = X[qq] - new_xyz[((size_t)b * 3 + 0) * p2 + p], gy = X[p1 + qq] - new_xyz[((size_t)b * 3 + 1) * p2 + p],
+                    gz = X[2 * p1 + qq] - new_xyz[((size_t)b * 3 + 2) * p2 + p];
+        gs[tid] = make_float4(2.0f * inv_sigma * gx, 2.0f * inv_sigma * gy, 2.0f * inv_sigma * gz, q < 0 ? -1e30f : 1.0f - (gx * gx + gy * gy + gz * gz) * inv_sigma);
+    }
+    const int cq = cw >> 2, c4 = tid % cq, n0 = tid / cq, nstep = 256 / cq;           // cw in {4 .. 64}, a power of two times 4 is not required: tid / cq >= nn idles
+    for (int a = 0; a < NA; ++a) {
+        __syncthreads();                                      // the previous anchor's readers of dXs are done (first pass: gs is written)
+        const float4* drow = reinterpret_cast<const float4*>(dx1 + (((size_t)b * pc + pl) * NA + a) * kk + (size_t)cbase * KS);
+        for (int e = tid; e < cw * (KS / 4); e += 256) {
+            const int c = e / (KS / 4), k4 = e - c * (KS / 4);
+            const float4 v = drow[e];
+            dXs[(4 * k4) * cw + c] = v.x; dXs[(4 * k4 + 1) * cw + c] = v.y; dXs[(4 * k4 + 2) * cw + c] = v.z; dXs[(4 * k4 + 3) * cw + c] = v.w;
+        }
+        __syncthreads();
+        for (int n = n0; n < nn; n += nstep) {
+            const float4 g = gs[n];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                const float rx = rk[(a * KS + k) * 3], ry = rk[(a * KS + k) * 3 + 1], rz = rk[(a * KS + k) * 3 + 2];
+                const float w = fmaxf(0.f, fmaf(g.z, rz, fmaf(g.y, ry, fmaf(g.x, rx, g.w - (rx * rx + ry * ry + rz * rz) * inv_sigma))));
+                const float4 d = *reinterpret_cast<const float4*>(&dXs[k * cw + 4 * c4]);
+                acc.x = fmaf(w, d.x, acc.x); acc.y = fmaf(w, d.y, acc.y); acc.z = fmaf(w, d.z, acc.z); acc.w = fmaf(w, d.w, acc.w);
+            }
+            *reinterpret_cast<float4*>(contrib + ((((size_t)b * pc + pl) * nn + n) * NA + a) * cin + cbase + 4 * c4) = acc;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- intra conv: gathered rows
 __global__ void __launch_bounds__(256) intra_rows_kernel(long total, int C, int nt, const int* __restrict__ intra_idx, const float* __restrict__ x,
                                                          float* __restrict__ xg) {
@@ -452,6 +497,20 @@ int etch_inter_dfeat(int b, int cin, int p1, int p2, int p_begin, int pc, int nn
         const int cw = cin - cbase < 64 ? cin - cbase : 64;
         hipLaunchKernelGGL(inter_dfeat_kernel, dim3(p1, b), dim3(256), 0, (hipStream_t)stream, cin, cbase, cw, p1, p2, p_begin, pc, nn, 1.0f / sigma, xyz,
                            new_xyz, ball_idx, rk, dx1, dfeats, accumulate);
+        ETCH_RETURN_IF_LAUNCH_FAILED();
+    }
+    return ETCH_OK;
+}
+
+int etch_inter_dfeat_slots(int b, int cin, int p1, int p2, int p_begin, int pc, int nn, float sigma, const float* xyz, const float* new_xyz,
+                           const int* ball_idx, const float* rk, const float* dx1, float* contrib, void* stream) {
+    if (b <= 0 || pc <= 0) return ETCH_OK;
+    if (cin <= 0 || (cin & 3) || (cin > 64 && (cin & 63)) || nn <= 0 || nn > 64 || p_begin < 0 || p_begin + pc > p2 || b > 65535) return ETCH_EUNSUPPORTED;
+    if (!xyz || !new_xyz || !ball_idx || !rk || !dx1 || !contrib || sigma <= 0.f) return ETCH_EINVAL;
+    for (int cbase = 0; cbase < cin; cbase += 64) {
+        const int cw = cin - cbase < 64 ? cin - cbase : 64;
+        hipLaunchKernelGGL(inter_dfeat_slots_kernel, dim3(pc, b), dim3(256), 0, (hipStream_t)stream, cin, cbase, cw, p1, p2, p_begin, pc, nn, 1.0f / sigma, xyz,
+                           new_xyz, ball_idx, rk, dx1, contrib);
         ETCH_RETURN_IF_LAUNCH_FAILED();
     }
     return ETCH_OK;

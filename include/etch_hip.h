@@ -484,6 +484,12 @@ int etch_gemm_tn_fused(long R, int M, int N, const float* A, long lda, const flo
  * the neighbour slots (p,n) with idx[b,p,n] == q, taken in slot order.  cin in {4..64}, multiple of 4. */
 int etch_inter_dfeat(int b, int cin, int p1, int p2, int p_begin, int pc, int nn, float sigma, const float* xyz, const float* new_xyz,
                      const int* ball_idx, const float* rk, const float* dx1, float* dfeats, int accumulate, void* stream);
+/* The same gradient from the target side (round 6): contrib [b][pc][nn][60][cin] receives, per neighbour slot (p, n) of the chunk, the row
+ * sum_k w[p,a,k,n] dX1[(p,a), c*24+k]; d feats[b, q] = the sum of the rows of the slots with ball_idx == q, which the caller takes with
+ * etch_segment_sum_rows over a stable sort of the slots by source point (fixed order: reproducible).  Reads every dX1 tile once instead of nn times.
+ * nn <= 64; cin as for etch_inter_dfeat.  A slot with ball_idx < 0 gets a zero row. */
+int etch_inter_dfeat_slots(int b, int cin, int p1, int p2, int p_begin, int pc, int nn, float sigma, const float* xyz, const float* new_xyz,
+                           const int* ball_idx, const float* rk, const float* dx1, float* contrib, void* stream);
 
 /* Gathered operand of the intra conv's weight gradient: x (points,60,C) -> xg (points,60,nt,C) with xg[p,a,t,:] = x[p,intra_idx[a,t],:]
  * (functional.py:331-378 in channels-last rows). */

@@ -351,3 +351,36 @@ def test_last_workgroup_reductions_soak_under_contention():
         assert torch.equal(y.detach(), y0) and torch.equal(m.running_var, rv0), (it, key)
     torch.cuda.synchronize()
     assert int(A.reduce_counters(torch.device("cuda", 0)).abs().sum()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,nn,b,p1,p2", [(32, 32, 32, 2, 301, 149), (32, 64, 64, 1, 400, 200), (64, 64, 32, 2, 211, 101), (16, 32, 9, 1, 100, 37)])
+def test_inter_conv_feature_gradient_from_the_target_side(cin, cout, nn, b, p1, p2):
+    """etch_inter_dfeat_slots + the ordered segment sum (every dX1 tile read once) against inter_dfeat_kernel (every slot re-reads its target's tile):
+    the same gradient to fp32 rounding (the slots' contributions are rounded before they are summed instead of inside one running sum), in one chunk
+    and in several, bitwise run to run; the weight / bias gradients do not depend on the path."""
+    from etch_amd import autograd as A
+    g, xyz, new_xyz, ball, conv, feats = _inter_setup(cin, cout, nn, b, p1, p2, seed=cin + nn)
+    rk = conv.rotated_kernels()
+    G = torch.randn(b, p2, 60, cout, generator=g).cuda()
+
+    def grads(slot, chunk_bytes):
+        old = A.SLOT_DFEAT, A.CHUNK_BYTES
+        A.SLOT_DFEAT, A.CHUNK_BYTES = slot, chunk_bytes
+        try:
+            f = feats.detach().clone().requires_grad_()
+            W = conv.basic_conv.W.detach().clone().requires_grad_()
+            bs = conv.basic_conv.bias.detach().clone().requires_grad_()
+            y = A.inter_so3conv(f, W, bs, xyz, new_xyz, ball, rk, conv.sigma, chunk=40)
+            (y * G).sum().backward()
+            return f.grad, W.grad, bs.grad
+        finally:
+            A.SLOT_DFEAT, A.CHUNK_BYTES = old
+    f0, W0, b0 = grads(False, 1.2e9)
+    f1, W1, b1 = grads(True, 1.2e9)            # one chunk
+    f2, W2, b2 = grads(True, 1.0)              # chunks of 40 points
+    f3, _, _ = grads(True, 1.0)
+    s = float(f0.abs().max())
+    assert float((f1 - f0).abs().max()) <= 3e-6 * s and float((f2 - f0).abs().max()) <= 3e-6 * s
+    assert torch.equal(f2, f3) and torch.equal(W0, W1) and torch.equal(b0, b1)
+    assert float((W2 - W0).abs().max()) <= 1e-6 * float(W0.abs().max())
