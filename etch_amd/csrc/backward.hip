@@ -82,7 +82,8 @@ __global__ void __launch_bounds__(256) inter_x1_rows_kernel(int cin, int p1, int
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 // FUSED (round 6): the workgroup of a tile that finishes last (common.h: etch_last_block, one counter per tile) sums the tile's partials in split order
 // -- gemm_tn_reduce_kernel's sums, bit for bit -- so a weight gradient is one launch instead of two (177 per training step).
-template <int TM, int TN, bool FUSED>
+// VEC: M, N, lda, ldb multiples of 4 and 16-byte aligned bases -- one 16-byte load per operand piece instead of four predicated 4-byte ones.
+template <int TM, int TN, bool FUSED, bool VEC>
 __global__ void __launch_bounds__(256) gemm_tn_kernel(long R, int M, int N, const float* __restrict__ A, long lda, const float* __restrict__ B,
                                                       long ldb, double* part, unsigned* counters, float* C, int accumulate) {
     constexpr int LDA = TM + 16, LDB = TN + 16;                    // row stride = 16 mod 32 / 64 floats: the transposed fragment reads are conflict-free
@@ -106,7 +107,8 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(long R, int M, int N, cons
             va[l] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < 32 * QA && r0 + r < r_end) {
                 const float* ar = A + (r0 + r) * lda + m0 + c4;
-                va[l] = make_float4(m0 + c4 < M ? ar[0] : 0.f, m0 + c4 + 1 < M ? ar[1] : 0.f, m0 + c4 + 2 < M ? ar[2] : 0.f, m0 + c4 + 3 < M ? ar[3] : 0.f);
+                if (VEC) { if (m0 + c4 < M) va[l] = *reinterpret_cast<const float4*>(ar); }
+                else va[l] = make_float4(m0 + c4 < M ? ar[0] : 0.f, m0 + c4 + 1 < M ? ar[1] : 0.f, m0 + c4 + 2 < M ? ar[2] : 0.f, m0 + c4 + 3 < M ? ar[3] : 0.f);
             }
         }
 #pragma unroll
@@ -115,7 +117,8 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(long R, int M, int N, cons
             vb[l] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < 32 * QB && r0 + r < r_end) {
                 const float* br = B + (r0 + r) * ldb + n0 + c4;
-                vb[l] = make_float4(n0 + c4 < N ? br[0] : 0.f, n0 + c4 + 1 < N ? br[1] : 0.f, n0 + c4 + 2 < N ? br[2] : 0.f, n0 + c4 + 3 < N ? br[3] : 0.f);
+                if (VEC) { if (n0 + c4 < N) vb[l] = *reinterpret_cast<const float4*>(br); }
+                else vb[l] = make_float4(n0 + c4 < N ? br[0] : 0.f, n0 + c4 + 1 < N ? br[1] : 0.f, n0 + c4 + 2 < N ? br[2] : 0.f, n0 + c4 + 3 < N ? br[3] : 0.f);
             }
         }
     };
@@ -419,24 +422,29 @@ static inline unsigned grid_for(long total) {
     return (unsigned)blocks;
 }
 
-// Row ranges: ~256 rows per workgroup, at most 64 per tile (the last workgroup of a tile sums them), and no more workgroups than ~8 per CU in all.
+// Row ranges: ~256 rows per workgroup and no more workgroups than ~8 per CU in all; at most 256 per tile.  Up to 64 ranges the last workgroup of a tile sums
+// them (one launch); beyond -- the long-and-narrow products of the direction head and the encoder, 300 000 rows into 2 x 2 tiles, which ran one workgroup
+// per CU with every 32-row step's load latency exposed -- the reduction is a launch of its own over all of C.
 static inline void gemm_tn_shape(long R, int M, int N, int& tm, int& tn, int& gx, int& gy, int& splits) {
     tm = M <= 32 ? 32 : 64; tn = N <= 32 ? 32 : 64;
     gx = (N + tn - 1) / tn; gy = (M + tm - 1) / tm;
     long s = (R + 255) / 256;
     const long cap = 2048 / ((long)gx * gy) > 0 ? 2048 / ((long)gx * gy) : 1;
     if (s > cap) s = cap;
-    if (s > 64) s = 64;
+    if (s > 256) s = 256;
     if (s < 1) s = 1;
     splits = (int)s;
 }
+#define GEMM_TN_FUSED_MAX_SPLITS 64
 template <bool FUSED>
 static int gemm_tn_launch(long R, int M, int N, const float* A, long lda, const float* B, long ldb, double* part, unsigned* counters, float* C,
                           int accumulate, hipStream_t st) {
     int tm, tn, gx, gy, splits;
     gemm_tn_shape(R, M, N, tm, tn, gx, gy, splits);
     const dim3 grid(gx, gy, splits);
-#define TN_GO(TM_, TN_) hipLaunchKernelGGL((gemm_tn_kernel<TM_, TN_, FUSED>), grid, dim3(256), 0, st, R, M, N, A, lda, B, ldb, part, counters, C, accumulate)
+    const bool vec = (M & 3) == 0 && (N & 3) == 0 && (lda & 3) == 0 && (ldb & 3) == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0;
+#define TN_GO(TM_, TN_) do { if (vec) hipLaunchKernelGGL((gemm_tn_kernel<TM_, TN_, FUSED, true>), grid, dim3(256), 0, st, R, M, N, A, lda, B, ldb, part, counters, C, accumulate); \
+                             else hipLaunchKernelGGL((gemm_tn_kernel<TM_, TN_, FUSED, false>), grid, dim3(256), 0, st, R, M, N, A, lda, B, ldb, part, counters, C, accumulate); } while (0)
     if (tm == 32 && tn == 32) TN_GO(32, 32);
     else if (tm == 32) TN_GO(32, 64);
     else if (tn == 32) TN_GO(64, 32);
@@ -483,7 +491,7 @@ int etch_gemm_tn_fused(long R, int M, int N, const float* A, long lda, const flo
     if (R < 0 || lda < M || ldb < N || !counters) return ETCH_EINVAL;
     int tm, tn, gx, gy, splits;
     gemm_tn_shape(R, M, N, tm, tn, gx, gy, splits);
-    if (gx * gy > ETCH_REDUCE_COUNTERS) return etch_gemm_tn(R, M, N, A, lda, B, ldb, C, accumulate, workspace, stream);
+    if (gx * gy > ETCH_REDUCE_COUNTERS || splits > GEMM_TN_FUSED_MAX_SPLITS) return etch_gemm_tn(R, M, N, A, lda, B, ldb, C, accumulate, workspace, stream);
     double* part = reinterpret_cast<double*>(((uintptr_t)workspace + 7) & ~(uintptr_t)7);
     const int rc = gemm_tn_launch<true>(R, M, N, A, lda, B, ldb, part, counters, C, accumulate, (hipStream_t)stream);
     return rc < 0 ? rc : ETCH_OK;

@@ -475,8 +475,8 @@ int etch_gemm_tn_workspace_floats(long R, int M, int N);
 int etch_gemm_tn(long R, int M, int N, const float* A, long lda, const float* B, long ldb, float* C, int accumulate, float* workspace,
                  void* stream);
 /* etch_gemm_tn in ONE launch: the workgroup of a 64 x 64 tile of C that finishes last sums the tile's partials in split order (bit for bit
- * etch_gemm_tn's result).  counters: 64 unsigned, zero before the first call, left zero (see etch_bn_train_forward); more than 64 tiles: the
- * two-launch form. */
+ * etch_gemm_tn's result).  counters: 64 unsigned, zero before the first call, left zero (see etch_bn_train_forward); more than 64 tiles or more
+ * than 64 row ranges per tile (long-and-narrow products): the two-launch form. */
 int etch_gemm_tn_fused(long R, int M, int N, const float* A, long lda, const float* B, long ldb, float* C, int accumulate, float* workspace,
                        unsigned* counters, void* stream);
 
