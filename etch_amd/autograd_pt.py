@@ -248,10 +248,13 @@ class ConcatBcastFunction(torch.autograd.Function):
 
 
 def _rel(p, new_p, idx):
-    """p[idx] - new_p (E,3): coordinates only, no gradient."""
-    with torch.no_grad():
-        m, ns = idx.shape
-        return (p[idx.view(-1).long()].view(m, ns, 3) - new_p.view(m, 1, 3)).reshape(m * ns, 3)
+    """p[idx] - new_p (E,3): coordinates only, no gradient; one tensor per kNN table inside a pointops.knn_scope (every block of a level, in both nets,
+    asks for the same one: 44 x 3 launches per training step were 12 x 3)."""
+    def make():
+        with torch.no_grad():
+            m, ns = idx.shape
+            return (p[idx.view(-1).long()].view(m, ns, 3) - new_p.view(m, 1, 3)).reshape(m * ns, 3).contiguous()
+    return pointops._memo(("pt_rel", p.data_ptr(), new_p.data_ptr(), idx.data_ptr()), (p, new_p, idx), make)
 
 
 def _lin(x, layer, act=None):
@@ -268,7 +271,7 @@ def pt_layer(m, p, x, o):
     lp = m.linear_p
     pr = (rel.unsqueeze(1) * lp[0].weight.unsqueeze(0)).sum(-1) + lp[0].bias        # Linear(3,3): 9 products per row, element-wise
     pr = batch_norm(pr, lp[1], relu=True)
-    pr = A.linear(F.pad(pr, (0, 1)), F.pad(lp[3].weight, (0, 1)), lp[3].bias)       # Linear(3,c) with K padded to 4
+    pr = A.linear(pr, lp[3].weight, lp[3].bias)                                     # Linear(3,c) (K = 3: the dense kernels take any K; the pads were launches)
     gk, gv = gather_rows(xk, idx), gather_rows(xv, idx)
     w = (gk.view(n, ns, c) - xq.view(n, 1, c) + pr.view(n, ns, c)).view(n * ns, c)
     lw = m.linear_w
@@ -298,7 +301,7 @@ def transition_down(m, p, x, o):
         n_p = pointops.gather_rows(p, idx)
         kidx = pointops.knnquery(m.nsample, p, n_p, o, n_o)[0]
         ux = A.linear(x, w[:, 3:])
-        z = gather_rows(ux, kidx) + A.linear(F.pad(_rel(p, n_p, kidx), (0, 1)), F.pad(w[:, :3], (0, 1)))
+        z = gather_rows(ux, kidx) + A.linear(_rel(p, n_p, kidx), w[:, :3])
         y = batch_norm(z, m.bn, relu=True)
         return n_p, RowsMaxPoolFunction.apply(y, m.nsample), n_o
     if x.shape[1] != w.shape[1]:                                                    # zero-padded input columns (see unet)
