@@ -120,6 +120,26 @@ def inter_so3conv(feats_cl, W, bias, xyz, new_xyz, ball_idx, rk, sigma, chunk=10
     return InterSO3ConvFunction.apply(feats_cl, W, bias, xyz, new_xyz, ball_idx, rk, sigma, chunk)
 
 
+_INV_TABLES = {}
+
+
+def _inverse_tables(idx32):
+    """Column-wise inverse of the intra conv's anchor tables (60, nt) -- every column is a permutation of the anchors.  A constant of the module's buffer:
+    built once per (tensor, version) instead of with 2 nt launches in every backward (96 per training step)."""
+    key = (idx32.data_ptr(), idx32._version, tuple(idx32.shape), str(idx32.device))
+    hit = _INV_TABLES.get(key)
+    if hit is None:
+        if len(_INV_TABLES) > 16:
+            _INV_TABLES.clear()
+        with torch.no_grad():
+            inv = torch.empty_like(idx32)
+            ar = torch.arange(idx32.shape[0], dtype=torch.int32, device=idx32.device)
+            for t in range(idx32.shape[1]):
+                inv[idx32[:, t].long(), t] = ar
+        hit = _INV_TABLES[key] = (inv.contiguous(), idx32)          # (the key tensor is held: its address stays unique)
+    return hit[0]
+
+
 class IntraSO3ConvFunction(torch.autograd.Function):
     """y (b,p,60,C) = fused intra conv of x (b,p,60,C) with W (C, C*12) [column c*12+t], bias (C); intra_idx (60,12) whose columns are
     permutations of the anchors (so the data gradient is the same kernel run with the inverse tables and the transposed weight)."""
@@ -150,13 +170,10 @@ class IntraSO3ConvFunction(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             # dx[p,a',c] = sum_t sum_o W[o, c*nt+t] dy[p, inv_t(a'), o]: the forward kernel with inverse tables and W'[c, o*nt+t] = W[o, c*nt+t]
-            inv = torch.empty_like(idx32)
-            ar = torch.arange(na, dtype=torch.int32, device=x.device)
-            for t in range(nt):
-                inv[idx32[:, t].long(), t] = ar
+            inv = _inverse_tables(idx32)
             Wb = W.view(cout, C, nt).permute(1, 0, 2).reshape(C, cout * nt).contiguous()
             zero = torch.zeros((C,), dtype=torch.float32, device=x.device)
-            dx = ops.intra_so3conv(dy, inv.contiguous(), IntraSO3ConvFunction._frag(Wb, cout, nt), zero, C)
+            dx = ops.intra_so3conv(dy, inv, IntraSO3ConvFunction._frag(Wb, cout, nt), zero, C)
         xg = torch.empty((b * p * na, nt * C), dtype=torch.float32, device=x.device)
         _check(lib.etch_intra_rows(ctypes.c_long(b * p), C, nt, _ptr(idx32), _ptr(x), _ptr(xg), _stream()), "etch_intra_rows")
         dW2 = gemm_tn(dy.view(b * p * na, cout), xg)                          # (cout, nt*C), tap-major columns

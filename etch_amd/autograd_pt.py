@@ -257,6 +257,24 @@ def _rel(p, new_p, idx):
     return pointops._memo(("pt_rel", p.data_ptr(), new_p.data_ptr(), idx.data_ptr()), (p, new_p, idx), make)
 
 
+class NeighbourDiffFunction(torch.autograd.Function):
+    """w[i*ns + j] = gk[i*ns + j] - xq[i] + pr[i*ns + j] (pointtransformer_seg.py:32) as one autograd node: 2 launches forward and 2 backward (the
+    broadcast's gradient is one row-group sum) where the element-wise form spent ~8 engine launches per layer."""
+
+    @staticmethod
+    def forward(ctx, gk, xq, pr, ns):
+        n, c = xq.shape
+        ctx.ns = ns
+        return ((gk.view(n, ns, c) - xq.view(n, 1, c)) + pr.view(n, ns, c)).view(n * ns, c)
+
+    @staticmethod
+    def backward(ctx, dw):
+        ns = ctx.ns
+        c = dw.shape[1]
+        dxq = dw.view(-1, ns, c).sum(1).neg_() if ctx.needs_input_grad[1] else None
+        return dw, dxq, dw, None
+
+
 def _lin(x, layer, act=None):
     return A.linear(x, layer.weight, layer.bias, act=act)
 
@@ -269,11 +287,11 @@ def pt_layer(m, p, x, o):
     idx = pointops.knnquery(ns, p, p, o, o)[0]
     rel = _rel(p, p, idx)                                                          # (E,3)
     lp = m.linear_p
-    pr = (rel.unsqueeze(1) * lp[0].weight.unsqueeze(0)).sum(-1) + lp[0].bias        # Linear(3,3): 9 products per row, element-wise
+    pr = A.linear(rel, lp[0].weight, lp[0].bias)                                    # Linear(3,3)
     pr = batch_norm(pr, lp[1], relu=True)
     pr = A.linear(pr, lp[3].weight, lp[3].bias)                                     # Linear(3,c) (K = 3: the dense kernels take any K; the pads were launches)
     gk, gv = gather_rows(xk, idx), gather_rows(xv, idx)
-    w = (gk.view(n, ns, c) - xq.view(n, 1, c) + pr.view(n, ns, c)).view(n * ns, c)
+    w = NeighbourDiffFunction.apply(gk, xq, pr, ns)                                 # x_k - x_q + p_r (pointtransformer_seg.py:32)
     lw = m.linear_w
     w = batch_norm(w, lw[0], relu=True)
     w = batch_norm(_lin(w, lw[2]), lw[3], relu=True)
