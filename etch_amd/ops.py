@@ -600,6 +600,21 @@ def instnorm_stats(x_cl):
     return mean, rstd
 
 
+def instnorm_act_add_k1(x1, m1, r1, f, slope, offset, want_planes=False):
+    """out = lrelu((x1 - m1) r1) + lrelu(f slope + offset): the second branch a one-channel 1x1 conv + InstanceNorm folded into per-(scan, channel)
+    slope / offset (etch_instnorm_act_add_k1_planes_f16).  x1 (b, ..., C), f (b, rows) one value per row of x1, slope / offset (b, C).
+    want_planes: False or "f16"."""
+    _need(x1, torch.float32, "x1"), _need(f, torch.float32, "f"), _need(slope, torch.float32, "slope"), _need(offset, torch.float32, "offset")
+    b, C = x1.shape[0], x1.shape[-1]
+    rows = x1.numel() // (b * C)
+    assert f.numel() == b * rows and tuple(slope.shape) == (b, C) and tuple(offset.shape) == (b, C) and want_planes in (False, None, "f16")
+    out = torch.empty_like(x1)
+    planes = torch.empty(tuple(x1.shape[:-1]) + (2, C), dtype=torch.float16, device=x1.device) if want_planes else None
+    _lib.check(_lib.lib().etch_instnorm_act_add_k1_planes_f16(b, rows, C, _ptr(x1), _ptr(m1), _ptr(r1), _ptr(f.contiguous()), _ptr(slope.contiguous()),
+                                                               _ptr(offset.contiguous()), _ptr(out), _optptr(planes), _stream()), "etch_instnorm_act_add_k1")
+    return (out, planes) if want_planes else out
+
+
 def instnorm_act_add(x1, m1, r1, x2=None, m2=None, r2=None, want_planes=False):
     """want_planes: also return the result split for the next conv's gathers -- True / "bf16": three bf16 planes (..., 3, C) int16
     (etch_inter_so3conv_planes); "f16": two fp16 planes (..., 2, C) float16 (etch_inter_so3conv_planes_kq)."""

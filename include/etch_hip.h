@@ -269,6 +269,12 @@ int etch_instnorm_act_add_planes(int b, int rows, int C, const float* x1, const 
 /* The same with two fp16 planes (b, rows, 2, C) for etch_inter_so3conv_planes_kq. */
 int etch_instnorm_act_add_planes_f16(int b, int rows, int C, const float* x1, const float* m1, const float* r1, const float* x2,
                                      const float* m2, const float* r2, float* out, void* planes, void* stream);
+/* Round 6 -- the same with the second branch a ONE-channel 1x1 conv + InstanceNorm folded in (the skip branch of the encoder's first block,
+ * so3conv.py:171-183 with dim_in = 1): f [b][rows] holds the branch's input value per row; slope / offset [b][C] = w_c rstd_c and (bias_c - mean_c) rstd_c
+ * of its conv output s = w_c f + bias_c (mean_c = w_c mean(f) + bias_c, var_c = w_c^2 var(f): the conv output and its statistics pass are never made):
+ *   out = lrelu((x1 - m1) r1) + lrelu(f slope_c + offset_c);  planes (may be NULL): the two fp16 planes of out. */
+int etch_instnorm_act_add_k1_planes_f16(int b, int rows, int C, const float* x1, const float* m1, const float* r1, const float* f, const float* slope,
+                                        const float* offset, float* out, void* planes, void* stream);
 
 /* ---- feature propagation + direction head --------------------------------------------------------------- */
 

@@ -384,3 +384,65 @@ def test_inter_conv_feature_gradient_from_the_target_side(cin, cout, nn, b, p1, 
     assert float((f1 - f0).abs().max()) <= 3e-6 * s and float((f2 - f0).abs().max()) <= 3e-6 * s
     assert torch.equal(f2, f3) and torch.equal(W0, W1) and torch.equal(b0, b1)
     assert float((W2 - W0).abs().max()) <= 1e-6 * float(W0.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,rows,C,planes", [(2, 1000, 32, "f16"), (3, 777, 64, False), (1, 60, 32, "f16")])
+def test_one_channel_skip_branch_folded_into_the_final_pass(b, rows, C, planes):
+    """etch_instnorm_act_add_k1_planes_f16: lrelu(IN(x1)) + lrelu(IN(w f + bias)) with the one-channel conv and its InstanceNorm as a slope / offset per
+    (scan, channel), against the un-folded chain (etch_linear -> etch_instnorm_stats -> etch_instnorm_act_add) and the fp64 formula of so3conv.py:171-183;
+    random features (the model feeds ones: see the model-level test below), constant features (variance 0: the branch is exactly 0)."""
+    from etch_amd import ops
+    g = torch.Generator().manual_seed(rows + C)
+    x1 = torch.randn(b, rows, C, generator=g).cuda()
+    m1, r1 = ops.instnorm_stats(x1)
+    w = (torch.randn(C, 1, generator=g) * 0.7).cuda()
+    bias = (torch.randn(C, generator=g) * 0.3).cuda()
+    for kind in ("random", "ones"):
+        f = (torch.randn(b, rows, generator=g) * 1.3 + 0.4).cuda() if kind == "random" else torch.ones(b, rows).cuda()
+        var, mean = torch.var_mean(f.double(), dim=1, unbiased=False, keepdim=True)
+        w64, b64 = w.double().view(1, -1), bias.double().view(1, -1)
+        rstd = torch.rsqrt(w64 * w64 * var + 1e-5)
+        res = ops.instnorm_act_add_k1(x1, m1, r1, f, (w64 * rstd).float(), (-(w64 * mean) * rstd).float(), want_planes=planes)
+        out, pl = res if planes else (res, None)
+        s = ops.linear(f.view(-1, 1), w, bias=bias).view(b, rows, C)
+        m3, r3 = ops.instnorm_stats(s)
+        res0 = ops.instnorm_act_add(x1, m1, r1, s, m3, r3, want_planes=planes)
+        out0, pl0 = res0 if planes else (res0, None)
+        lr = torch.nn.functional.leaky_relu
+        s64 = f.double().unsqueeze(-1) * w.double().view(1, 1, -1) + bias.double()
+        ref = lr((x1.double() - x1.double().mean(1, keepdim=True)) / torch.sqrt(x1.double().var(1, unbiased=False, keepdim=True) + 1e-5), 0.01) + \
+            lr((s64 - s64.mean(1, keepdim=True)) / torch.sqrt(s64.var(1, unbiased=False, keepdim=True) + 1e-5), 0.01)
+        sc = float(ref.abs().max())
+        e_new, e_old = float((out.double() - ref).abs().max()), float((out0.double() - ref).abs().max())
+        assert e_new <= 2.0 * e_old + 2e-6 * sc, (kind, e_new / sc, e_old / sc)
+        if pl is not None:
+            back = pl.float().sum(-2)                       # h + l
+            assert float((back - out).abs().max()) <= 2e-6 * sc
+
+
+@pytest.mark.gpu
+def test_model_with_and_without_the_folded_skip_branch(tmp_path):
+    """GT_network_equiv with ETCH_SKIP_K1_FOLD on / off: the same outputs to fp32 rounding of the first block's skip branch."""
+    import types
+    from etch_amd import constants as K
+    from etch_amd.models.models_pointcloud import GT_network_equiv
+    from etch_amd.models.so3conv import SeparableSO3ConvBlock
+    dev = torch.device("cuda", 0)
+    args = types.SimpleNamespace(output_folder=str(tmp_path), EPN_input_radius=0.4, EPN_layer_num=2, device=dev, markerset=K.default_markerset(), scale_magnitude=10)
+    model = load_seeded(GT_network_equiv(option=args), 1).to(dev).eval()
+    g = torch.Generator().manual_seed(5)
+    pts = (torch.randn(2, 1500, 3, generator=g) * torch.tensor([0.14, 0.31, 0.085])).cuda()
+    items = ["confidence", "direction", "magnitude"]
+    old = SeparableSO3ConvBlock.fold_k1_skip
+    try:
+        res = {}
+        for flag in (True, False):
+            SeparableSO3ConvBlock.fold_k1_skip = flag
+            with torch.no_grad():
+                res[flag] = model(pts, items, "standard_vector")[0]
+    finally:
+        SeparableSO3ConvBlock.fold_k1_skip = old
+    for k in ("magnitude", "confidences", "part_labels"):
+        a, b_ = res[True][k], res[False][k]
+        assert float((a - b_).abs().max()) <= 2e-5 * float(b_.abs().max()) + 1e-6, k
