@@ -116,7 +116,7 @@ class SeparableSO3ConvBlock(nn.Module):
             # s = w_c f + bias_c is affine in the ONE input value of a row: its InstanceNorm statistics follow from mean / variance of f over the scan's
             # (sampled) rows -- mean_c = w_c mean(f) + bias_c, var_c = w_c^2 var(f) -- and the normalised branch is f slope_c + offset_c.  The (rows, C)
             # conv output, its statistics pass and its read by the final pass (0.31 + 0.18 ms, 0.6 GB at 32 x 5 000 points) are never made.
-            f = fin.view(b, p1, na)
+            f = fin.reshape(b, p1, na)
             if self.stride > 1:
                 f = torch.gather(f, 1, sample_idx.long().unsqueeze(-1).expand(-1, -1, na))
             f = f.reshape(b, p2 * na)
