@@ -28,6 +28,7 @@ def _occupancy_ones(b, n, na, device):
             _ones_cache.clear()
         t = torch.ones((b, n, na, 1), dtype=torch.float32, device=device)
         torch.cuda.current_stream(device).synchronize() if device.type == "cuda" else None
+        t._etch_constant = 1.0          # read-only by contract: consumers may use the value instead of the tensor (SeparableSO3ConvBlock's one-channel skip branch)
         _ones_cache[key] = t
     return t
 
@@ -116,6 +117,9 @@ class SeparableSO3ConvBlock(nn.Module):
             # s = w_c f + bias_c is affine in the ONE input value of a row: its InstanceNorm statistics follow from mean / variance of f over the scan's
             # (sampled) rows -- mean_c = w_c mean(f) + bias_c, var_c = w_c^2 var(f) -- and the normalised branch is f slope_c + offset_c.  The (rows, C)
             # conv output, its statistics pass and its read by the final pass (0.31 + 0.18 ms, 0.6 GB at 32 x 5 000 points) are never made.
+            if getattr(fin, "_etch_constant", None) is not None:
+                # constant features (the occupancy ones of so3conv.py:7-16): s is constant per channel, its InstanceNorm is 0 -- the branch adds nothing
+                return ("zero",)
             f = fin.reshape(b, p1, na)
             if self.stride > 1:
                 f = torch.gather(f, 1, sample_idx.long().unsqueeze(-1).expand(-1, -1, na))
@@ -167,9 +171,12 @@ class SeparableSO3ConvBlock(nn.Module):
             branch = self._skip_branch(fin, sample_idx, p2)
         else:
             torch.cuda.current_stream().wait_event(ev1)
-        if isinstance(branch[0], str):                      # ("k1", f, slope, offset): the folded one-channel branch
-            _, f, slope, offset = branch
-            res = ops.instnorm_act_add_k1(z.feats_cl, m2, r2, f, slope, offset, want_planes=self.emit_planes)
+        if isinstance(branch[0], str):                      # ("k1", f, slope, offset): the folded one-channel branch; ("zero",): constant features
+            if branch[0] == "zero":
+                res = ops.instnorm_act_add(z.feats_cl, m2, r2, want_planes=self.emit_planes)
+            else:
+                _, f, slope, offset = branch
+                res = ops.instnorm_act_add_k1(z.feats_cl, m2, r2, f, slope, offset, want_planes=self.emit_planes)
             out, planes = res if self.emit_planes else (res, None)
             cloud = sptk.SphericalPointCloud(y.xyz, None, z.anchors, feats_cl=out)
             if planes is not None:
