@@ -433,7 +433,10 @@ __global__ void __launch_bounds__(256) inter_so3conv_small_kernel(
 // One workgroup per output point; thread = (anchor, group of 6 kernel points): 240 of 256 threads busy in one pass, the
 // per-neighbour terms (G_n, ga_n) and the gathered features F[idx_n, :] are staged once in LDS (one broadcast
 // ds_read_b128 + one ds_read_b32 per neighbour feed 36 VALU ops); two kernel points per instruction (v_pk_fma_f32).
+// UNIT (round 6): feats == NULL stands for the all-ones occupancy features the encoder feeds this conv (so3conv.py:7-16, functional.py:70-89): no gather of
+// the neighbours' feature rows (nn x 60 floats per point through LDS), no product with them.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool UNIT>
 __global__ void __launch_bounds__(256) inter_so3conv_c1_kernel(
     int cout, int p1, int p2, int nn, float inv_sigma, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
     const int* __restrict__ ball_idx, const float* __restrict__ feats, const float* __restrict__ rk, const float* __restrict__ W,
@@ -455,12 +458,14 @@ __global__ void __launch_bounds__(256) inter_so3conv_c1_kernel(
     }
     for (int e = tid; e < cout * KS; e += 256) Ws[e] = W[e];
     __syncthreads();
-    const float* Fb = feats + (size_t)b * p1 * NA;
-    for (int e = tid; e < nn * NA; e += 256) {
-        const int n = e / NA, a = e - n * NA;
-        Fn[e] = Fb[(size_t)qi[n] * NA + a];
+    if (!UNIT) {
+        const float* Fb = feats + (size_t)b * p1 * NA;
+        for (int e = tid; e < nn * NA; e += 256) {
+            const int n = e / NA, a = e - n * NA;
+            Fn[e] = Fb[(size_t)qi[n] * NA + a];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (tid < NA * 4) {
         const int a = tid >> 2, k0 = (tid & 3) * 6;
         f32x2 rx[3], ry[3], rz[3], rb[3], acc[3];
@@ -473,7 +478,7 @@ __global__ void __launch_bounds__(256) inter_so3conv_c1_kernel(
         }
         for (int n = 0; n < nn; ++n) {
             const float4 g = GA[n];
-            const float f = Fn[n * NA + a];
+            const float f = UNIT ? 1.0f : Fn[n * NA + a];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 f32x2 w = rz[j] * g.z + (ry[j] * g.y + (rx[j] * g.x + (rb[j] + g.w)));
@@ -1077,6 +1082,7 @@ int etch_inter_so3conv_ordered(int b, int cin, int cout, int p1, int p2, int nn,
                                const float* bias, float* out, const int* order, double* stat_part, void* stream) {
     if (b <= 0 || p2 <= 0) return ETCH_OK;
     if (nn <= 0 || nn > 64 || sigma <= 0.f) return ETCH_EINVAL;
+    if (!feats && cin != 1) return ETCH_EINVAL;            // feats == NULL: all-ones features, the one-channel conv only
     hipStream_t st = (hipStream_t)stream;
 #define INTER_CASE(CI, CO) \
     if (cin == CI && cout == CO) return launch_inter<CI, CO, false>(b, p1, p2, nn, sigma, xyz, new_xyz, ball_idx, feats, rk, Wp, bias, out, order, stat_part, st);
@@ -1086,13 +1092,15 @@ int etch_inter_so3conv_ordered(int b, int cin, int cout, int p1, int p2, int nn,
     if (cin == 1 && cout <= 64 && (!stat_part || (256 % cout == 0 && nn * NA >= 1026))) {
         const size_t lds = ((size_t)4 * nn + (size_t)nn * NA + NA * KS + (size_t)cout * KS + nn) * sizeof(float);
         if (lds <= 64 * 1024) {
-            hipLaunchKernelGGL(inter_so3conv_c1_kernel, dim3(p2, b), dim3(256), lds, st, cout, p1, p2, nn, 1.0f / sigma, xyz, new_xyz, ball_idx,
-                               feats, rk, W, bias, out, stat_part);
+            if (feats) hipLaunchKernelGGL(inter_so3conv_c1_kernel<false>, dim3(p2, b), dim3(256), lds, st, cout, p1, p2, nn, 1.0f / sigma, xyz, new_xyz, ball_idx,
+                                          feats, rk, W, bias, out, stat_part);
+            else hipLaunchKernelGGL(inter_so3conv_c1_kernel<true>, dim3(p2, b), dim3(256), lds, st, cout, p1, p2, nn, 1.0f / sigma, xyz, new_xyz, ball_idx,
+                                    feats, rk, W, bias, out, stat_part);
             ETCH_RETURN_IF_LAUNCH_FAILED();
             return ETCH_OK;
         }
     }
-    if (stat_part) return ETCH_EUNSUPPORTED;               // the generic small-CIN kernel has no fused statistics
+    if (stat_part || !feats) return ETCH_EUNSUPPORTED;     // the generic small-CIN kernel has no fused statistics (and reads its features)
     if (cin <= 8) {
         const size_t lds = (size_t)(4 * nn + NA * cin * KS) * sizeof(float);
         hipLaunchKernelGGL(inter_so3conv_small_kernel, dim3(p2, b), dim3(256), lds, st, cin, cout, p1, p2, nn, 1.0f / sigma, xyz,

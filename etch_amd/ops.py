@@ -536,8 +536,10 @@ def inter_so3conv(xyz, new_xyz, ball_idx, feats_cl, rk, W, Wp, bias, sigma, orde
                                                       _ptr(feats_cl), _ptr(rk), _ptr(Wq), _ptr(bias), _ptr(out), _optptr(order),
                                                       _optptr(part), _stream()), "etch_inter_so3conv_split")
     else:
+        # all-ones features (the encoder's occupancy tensor, tagged by models/so3conv.py): the one-channel kernel takes NULL and skips the feature gather
+        unit = cin == 1 and getattr(feats_cl, "_etch_constant", None) == 1.0 and cout <= 64 and nn * 60 >= 1026
         _lib.check(_lib.lib().etch_inter_so3conv_ordered(b, cin, cout, p1, p2, nn, _c_float(sigma), _ptr(xyz), _ptr(new_xyz), _ptr(ball_idx),
-                                                         _ptr(feats_cl), _ptr(rk), _ptr(W), _optptr(Wp), _ptr(bias), _ptr(out), _optptr(order),
+                                                         _vp(0) if unit else _ptr(feats_cl), _ptr(rk), _ptr(W), _optptr(Wp), _ptr(bias), _ptr(out), _optptr(order),
                                                          _optptr(part), _stream()), "etch_inter_so3conv")
     if not want_stats:
         return out

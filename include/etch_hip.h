@@ -137,7 +137,9 @@ int etch_inter_so3conv(int b, int cin, int cout, int p1, int p2, int nn, float s
  * `order`, one contiguous eighth per XCD, so that the workgroups sharing an L2 gather from the same source rows.
  * stat_part (b,p2,2,cout) fp64 or NULL: per output point the sum and the sum of squares of its 60 x cout outputs, i.e. the
  * InstanceNorm2d statistics of so3conv.py:96-99 without a second pass over the output (etch_instnorm_from_partials finishes them);
- * accumulated in fp64 so that a channel whose mean dominates its spread keeps its variance. */
+ * accumulated in fp64 so that a channel whose mean dominates its spread keeps its variance.
+ * Round 6: cin == 1 accepts feats == NULL for ALL-ONES features (the encoder's occupancy input, so3conv.py:7-16): the neighbours' feature rows are then
+ * neither gathered nor multiplied in. */
 int etch_inter_so3conv_ordered(int b, int cin, int cout, int p1, int p2, int nn, float sigma, const float* xyz, const float* new_xyz,
                                const int* ball_idx, const float* feats, const float* rk, const float* W, const float* Wp,
                                const float* bias, float* out, const int* order, double* stat_part, void* stream);

@@ -446,3 +446,18 @@ def test_model_with_and_without_the_folded_skip_branch(tmp_path):
     for k in ("magnitude", "confidences", "part_labels"):
         a, b_ = res[True][k], res[False][k]
         assert float((a - b_).abs().max()) <= 2e-5 * float(b_.abs().max()) + 1e-6, k
+
+
+@pytest.mark.gpu
+def test_first_conv_with_all_ones_features_passed_as_null():
+    """cin = 1 with feats == NULL (all-ones occupancy features: no gather, no product) is bitwise the kernel fed a tensor of ones, statistics included."""
+    from etch_amd import ops
+    from etch_amd.models.so3conv import _occupancy_ones
+    g, xyz, new_xyz, ball, conv, _ = _inter_setup(1, 32, 64, 2, 400, 200, seed=9)
+    rk, W, Wp, bias = conv._derived()
+    ones = torch.ones(2, 400, 60, 1, device="cuda")
+    tagged = _occupancy_ones(2, 400, 60, ones.device)
+    assert getattr(tagged, "_etch_constant", None) == 1.0 and bool((tagged == 1).all())
+    a, (ma, ra) = ops.inter_so3conv(xyz, new_xyz, ball, ones, rk, W, Wp, bias, conv.sigma, want_stats=True)
+    c, (mc, rc) = ops.inter_so3conv(xyz, new_xyz, ball, tagged, rk, W, Wp, bias, conv.sigma, want_stats=True)
+    assert torch.equal(a, c) and torch.equal(ma, mc) and torch.equal(ra, rc)
